@@ -1,0 +1,267 @@
+/*
+ * rtpose_mi355x.h — C ABI of librtpose_mi355x.so (gfx950 / MI355X only).
+ *
+ * This is the drop-in boundary for ONE hot path of
+ * tensorboy/pytorch_Realtime_Multi-Person_Pose_Estimation:
+ *
+ *   rtpose_vgg forward  ->  heat-map peak NMS + sub-pixel refine  ->  PAF
+ *   line-integral scoring  ->  greedy limb assignment  ->  person grouping
+ *
+ * Plain pointers and sizes only: no torch / numpy types cross this line.
+ * Device pointers are HIP device pointers; `stream` is a hipStream_t passed
+ * as void* (NULL = the default stream).  The library never allocates device
+ * memory on the forward path: the host language (Python + torch here) owns
+ * every buffer and hands in pointers + byte counts that the *_bytes() queries
+ * report.
+ *
+ * Each entry point cites the reference interface (file:line under
+ * /root/reference) it stands in for.
+ *
+ * Return codes: 0 = ok, negative = RTPOSE_E_* below.  The library never
+ * falls back to a CPU path: without a HIP device every compute entry point
+ * returns RTPOSE_E_NODEVICE (or the HIP error, negated and offset).
+ */
+#ifndef RTPOSE_MI355X_H
+#define RTPOSE_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTPOSE_OK 0
+#define RTPOSE_E_INVAL (-1)     /* bad argument / unsupported shape          */
+#define RTPOSE_E_NODEVICE (-2)  /* no HIP device / HIP runtime error         */
+#define RTPOSE_E_CAPACITY (-3)  /* a fixed-capacity device table overflowed  */
+#define RTPOSE_E_STATE (-4)     /* call order violated (e.g. not bound)      */
+#define RTPOSE_E_HIP(code) (-1000 - (int)(code))
+
+/* ------------------------------------------------------------------------
+ * 0. Library
+ * ---------------------------------------------------------------------- */
+const char* rtpose_version(void);
+/* Last error text of the calling thread ("" if none). */
+const char* rtpose_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * 1. Activation layout ("shared-gap padded NHWC")
+ *
+ * Every activation tensor lives in HBM as rows of pixels, `cstride` floats
+ * per pixel.  Pixel (n, y, x) sits at pixel index
+ *        q = lead + (n * hs + y) * ws + x
+ * with ws >= W + pad and hs >= H + pad, lead >= pad * ws + pad.  The pixels
+ * that are not (n, y<H, x<W) are never written and stay zero, so a k x k
+ * stencil tap (dy, dx) is the constant pixel offset dy * ws + dx and needs no
+ * bounds test: the right gap of one row is the left gap of the next, and the
+ * bottom gap of one image is the top gap of the next.
+ * A plain dense NHWC tensor is the case lead = 0, ws = W, hs = H.
+ * ---------------------------------------------------------------------- */
+typedef struct rtpose_layout {
+  int32_t cstride; /* floats per pixel                                     */
+  int32_t choff;   /* first channel of the slice this view addresses       */
+  int32_t ws;      /* row stride, pixels                                   */
+  int32_t hs;      /* image stride, rows                                   */
+  int32_t lead;    /* pixel index of (0,0,0)                               */
+} rtpose_layout;
+
+/* Pixels (not bytes) a buffer with this layout needs for N images of H x W,
+ * including the tail slack the 2-D tile mode may read. */
+size_t rtpose_layout_pixels(const rtpose_layout* l, int N, int H, int W);
+
+/* ------------------------------------------------------------------------
+ * 2. Convolution (stride 1, "same" padding, k in {1,3,7}) + bias (+ReLU)
+ *    stands in for torch.nn.Conv2d + nn.ReLU as instantiated by
+ *    lib/network/rtpose_vgg.py:23-35, :49-55 (ATen conv2d on the reference).
+ *
+ * Weights are consumed in the packed order produced by
+ * rtpose_pack_conv_weights (shape independent).  fp32 in, fp32 accumulate
+ * (v_mfma_f32_32x32x2_f32), fp32 out.
+ * ---------------------------------------------------------------------- */
+/* floats needed for the packed form of a [cout][cin][k][k] filter */
+size_t rtpose_packed_weight_floats(int cout, int cin, int k);
+/* floats needed for the padded bias */
+size_t rtpose_packed_bias_floats(int cout);
+
+/* Pack device OIHW fp32 weights (+bias) for the conv kernel.
+ * `cin_map` (device or NULL): packed input channel c reads source channel
+ * cin_map[c] (-1 = zero); NULL = identity over cin_src channels.
+ * cin_packed is the channel count of the activation slice the conv will read
+ * (>= cin_src, multiple of 8). */
+int rtpose_pack_conv_weights(const float* w_oihw, const float* bias, int cout,
+                             int cin_src, int k, const int32_t* cin_map,
+                             int cin_packed, float* w_packed,
+                             float* bias_packed, void* stream);
+
+typedef struct rtpose_conv_desc {
+  const float* in;       /* activation buffer base (layout `lin`)           */
+  const float* w_packed; /* from rtpose_pack_conv_weights                   */
+  const float* bias_packed;
+  float* out;            /* activation buffer base (layout `lout`)          */
+  rtpose_layout lin;
+  rtpose_layout lout;
+  int32_t cin;  /* packed input channels (multiple of 8)                    */
+  int32_t cout; /* real output channels                                     */
+  int32_t k;    /* 1, 3 or 7                                                */
+  int32_t relu; /* 0/1                                                      */
+  int32_t pool; /* 0, or 1 = fuse MaxPool2d(2,2,0): `lout` is then the
+                   half-resolution layout (rtpose_vgg.py:49-50)             */
+} rtpose_conv_desc;
+
+/* Launch one conv, or `ngroups` (<= 2) convs of identical geometry in one
+ * grid (the L1/L2 branches of a CPM stage, rtpose_vgg.py:163-164). */
+int rtpose_conv2d(const rtpose_conv_desc* d, int ngroups, int N, int H, int W,
+                  void* stream);
+
+/* MaxPool2d(kernel 2, stride 2, pad 0) between two layouts
+ * (rtpose_vgg.py:49-50; floor semantics of nn.MaxPool2d). */
+int rtpose_maxpool2x2(const float* in, const rtpose_layout* lin, float* out,
+                      const rtpose_layout* lout, int C, int N, int H, int W,
+                      void* stream);
+
+/* NCHW dense fp32 -> layout (channels [0,C) of the slice; extra channels of
+ * the slice up to cpad are written as zero). */
+int rtpose_nchw_to_layout(const float* src_nchw, float* dst,
+                          const rtpose_layout* ldst, int C, int cpad, int N,
+                          int H, int W, void* stream);
+/* layout slice -> dense NCHW fp32 */
+int rtpose_layout_to_nchw(const float* src, const rtpose_layout* lsrc,
+                          float* dst_nchw, int C, int N, int H, int W,
+                          void* stream);
+/* layout slice -> layout slice (C channels) */
+int rtpose_layout_copy(const float* src, const rtpose_layout* lsrc, float* dst,
+                       const rtpose_layout* ldst, int C, int N, int H, int W,
+                       void* stream);
+
+/* ------------------------------------------------------------------------
+ * 3. The rtpose_vgg network (lib/network/rtpose_vgg.py:60-225)
+ *
+ *   get_model('vgg19')       -> rtpose_net_create + rtpose_net_load_conv x92
+ *   rtpose_model.forward     -> rtpose_net_forward   (rtpose_vgg.py:158-198)
+ *
+ * Conv index order == state_dict order of the reference module:
+ *   model0.{0,2,5,7,10,12,14,16,19,21,23,25}, model1_1.{0,2,4,6,8},
+ *   model2_1.{0,2,4,6,8,10,12} ... model6_1, model1_2 ..., model6_2
+ *   (rtpose_vgg.py:141-155 registration order).
+ * ---------------------------------------------------------------------- */
+typedef struct rtpose_net rtpose_net;
+
+int rtpose_net_create(int N, int H, int W, rtpose_net** out);
+void rtpose_net_destroy(rtpose_net* net);
+size_t rtpose_net_workspace_bytes(const rtpose_net* net);
+size_t rtpose_net_weight_bytes(const rtpose_net* net);
+/* Hand in the two device arenas.  The workspace is zero-filled on `stream`
+ * (the gaps of every activation layout must be zero); the weight arena may be
+ * shared by nets of different N/H/W (its packing is shape independent). */
+int rtpose_net_bind(rtpose_net* net, void* workspace, size_t workspace_bytes,
+                    void* weights, size_t weight_bytes, int zero_workspace,
+                    void* stream);
+int rtpose_net_num_convs(const rtpose_net* net);
+/* name: e.g. "model0.0" (state_dict prefix); returns 0 or RTPOSE_E_INVAL */
+int rtpose_net_conv_info(const rtpose_net* net, int idx, char* name,
+                         int name_cap, int* cout, int* cin, int* k);
+/* Pack one conv's OIHW weight + bias (device pointers) into the weight arena */
+int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw,
+                         const float* bias, void* stream);
+/* Enqueue the whole forward on `stream`: x is dense NCHW fp32 [N,3,H,W]. */
+int rtpose_net_forward(rtpose_net* net, const float* x_nchw, void* stream);
+/* Copy stage output `which` (0..11 = saved_for_loss order: out1_1, out1_2,
+ * ... out6_1, out6_2; rtpose_vgg.py:166-196) as dense NCHW.  Only the last
+ * two survive a forward unless keep_intermediates was set. */
+int rtpose_net_set_keep_intermediates(rtpose_net* net, int keep);
+int rtpose_net_read_output(rtpose_net* net, int which, float* dst_nchw,
+                           void* stream);
+/* In-place view of the final PAF (which=0, 38 ch) / heat-map (which=1, 19 ch)
+ * so the post-processing reads them where the last conv wrote them. */
+int rtpose_net_output_view(const rtpose_net* net, int which, const float** base,
+                           rtpose_layout* layout, int* C, int* H, int* W);
+/* Per-layer HIP-event timing of the next forwards (bench.py roofline leg). */
+int rtpose_net_set_profiling(rtpose_net* net, int enable);
+int rtpose_net_num_launches(const rtpose_net* net);
+/* After the stream has been synchronised: milliseconds of launch i of the
+ * LAST forward, its conv kernel size (0 = not a conv), and algorithmic flops. */
+int rtpose_net_launch_info(rtpose_net* net, int i, float* ms, int* k,
+                           double* flops, char* name, int name_cap);
+
+/* ------------------------------------------------------------------------
+ * 4. Batched pose decoding on the device
+ *    stands in for lib/utils/paf_to_pose.py:372-406 (paf_to_pose_cpp):
+ *      NMS            paf_to_pose.py:67-145   (find_peaks :25-38)
+ *      process_paf    lib/pafprocess/pafprocess.cpp:22-194
+ * ---------------------------------------------------------------------- */
+#define RTPOSE_NUM_PART 18
+#define RTPOSE_NUM_LIMB 19
+
+typedef struct rtpose_decode_cfg {
+  int32_t num_keypoints;  /* cfg.MODEL.NUM_KEYPOINTS (18)   default.py:40  */
+  int32_t upsample;       /* cfg.MODEL.DOWNSAMPLE   (8)     default.py:41  */
+  float thresh_heatmap;   /* cfg.TEST.THRESH_HEATMAP (0.1)  default.py:126 */
+  int32_t max_peaks_per_part; /* device table capacity per (image, part)   */
+  int32_t max_humans;         /* device table capacity per image           */
+} rtpose_decode_cfg;
+
+/* One decoded peak: paf_to_pose.py:141-142 row (x, y, score, id). */
+typedef struct rtpose_peak {
+  int32_t x, y; /* refined, at upsampled (input) resolution                */
+  float score;
+  int32_t id;   /* running counter over parts then peaks (pafprocess cid)  */
+} rtpose_peak;
+
+/* Bytes of the caller-provided device scratch + result block for N images. */
+size_t rtpose_decode_workspace_bytes(const rtpose_decode_cfg* cfg, int N);
+/* Bytes of the compact result record block (device or host copy of it). */
+size_t rtpose_decode_result_bytes(const rtpose_decode_cfg* cfg, int N);
+
+/* Enqueue NMS + refine + PAF scoring + assignment + grouping for N images.
+ * heat: 19-channel (>= num_keypoints used) map, paf: 38-channel map, any
+ * layout (dense HWC = lead 0, ws = w, hs = h, cstride = C).
+ * `result` (device, rtpose_decode_result_bytes) receives, per image:
+ *   int32 header[8]: n_peaks, n_humans, overflow_flags, 0...
+ *   int32 part_count[18]
+ *   rtpose_peak peaks[18 * max_peaks_per_part]   (grouped by part, cid order)
+ *   int32 human_parts[max_humans][18]            (cid, -1 = absent)
+ *   float human_score[max_humans]                (get_score, cpp:204-206)
+ */
+int rtpose_decode_batch(const float* heat, const rtpose_layout* lheat,
+                        const float* paf, const rtpose_layout* lpaf, int N,
+                        int h, int w, const rtpose_decode_cfg* cfg,
+                        void* workspace, size_t workspace_bytes, void* result,
+                        void* stream);
+
+/* Stage-wise entry points (same kernels, for tests and the legacy API).      */
+/* NMS only (paf_to_pose.py:67-145): fills part_count + peaks of `result`.    */
+int rtpose_nms_batch(const float* heat, const rtpose_layout* lheat, int N,
+                     int h, int w, const rtpose_decode_cfg* cfg, void* result,
+                     void* stream);
+
+/* ------------------------------------------------------------------------
+ * 5. Flip test-time-augmentation merge
+ *    stands in for evaluate/coco_eval.py:197-242 (handle_paf_and_heat).
+ *    All four inputs dense HWC fp32 on the device, outputs likewise.
+ * ---------------------------------------------------------------------- */
+int rtpose_flip_merge(const float* heat, const float* heat_flipped,
+                      const float* paf, const float* paf_flipped, int N, int h,
+                      int w, float* heat_avg, float* paf_avg, void* stream);
+
+/* ------------------------------------------------------------------------
+ * 6. Legacy single-image API — same seven names and argument meaning as the
+ *    SWIG module (lib/pafprocess/pafprocess.h:53-59, pafprocess.i:14-15).
+ *    Host pointers in, results kept in process-global state until the next
+ *    process_paf (pafprocess.cpp:12-13), guarded by a mutex.  The scoring /
+ *    assignment / grouping run on the GPU; getters are bounds-checked and
+ *    return -1 / NaN instead of the reference's undefined behaviour.
+ * ---------------------------------------------------------------------- */
+int process_paf(int p1, int p2, int p3, float* peaks, int h1, int h2, int h3,
+                float* heatmap, int f1, int f2, int f3, float* pafmap);
+int get_num_humans(void);
+int get_part_cid(int human_id, int part_id);
+float get_score(int human_id);
+int get_part_x(int cid);
+int get_part_y(int cid);
+float get_part_score(int cid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTPOSE_MI355X_H */

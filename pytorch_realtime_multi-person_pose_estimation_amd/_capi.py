@@ -1,0 +1,133 @@
+"""ctypes binding of librtpose_mi355x.so (the C ABI in include/rtpose_mi355x.h).
+
+This is the only place the package touches native code.  The library is built
+in-tree (``csrc/Makefile`` -> ``lib/librtpose_mi355x.so``) and loaded from
+there; if it is missing the import fails loudly — there is no Python/CPU
+fallback for the hot path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librtpose_mi355x.so")
+
+NUM_PART = 18
+NUM_LIMB = 19
+
+
+class RtposeError(RuntimeError):
+    pass
+
+
+class Layout(C.Structure):
+    """rtpose_layout: shared-gap padded NHWC addressing (header §1)."""
+    _fields_ = [("cstride", C.c_int32), ("choff", C.c_int32), ("ws", C.c_int32),
+                ("hs", C.c_int32), ("lead", C.c_int32)]
+
+    @classmethod
+    def dense(cls, c, h, w, choff=0):
+        return cls(c, choff, w, h, 0)
+
+    @classmethod
+    def padded(cls, c, h, w, pad, choff=0):
+        ws = w + pad
+        return cls(c, choff, ws, h + pad, pad * ws + pad)
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("w_packed", C.c_void_p), ("bias_packed", C.c_void_p),
+                ("out", C.c_void_p), ("lin", Layout), ("lout", Layout), ("cin", C.c_int32),
+                ("cout", C.c_int32), ("k", C.c_int32), ("relu", C.c_int32), ("pool", C.c_int32)]
+
+
+class DecodeCfg(C.Structure):
+    _fields_ = [("num_keypoints", C.c_int32), ("upsample", C.c_int32),
+                ("thresh_heatmap", C.c_float), ("max_peaks_per_part", C.c_int32),
+                ("max_humans", C.c_int32)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "librtpose_mi355x.so not found at %s — build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C %s`; "
+            "this package has no CPU fallback" % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+_LP = C.POINTER(Layout)
+
+_SIGS = {
+    "rtpose_version": (C.c_char_p, []),
+    "rtpose_last_error": (C.c_char_p, []),
+    "rtpose_layout_pixels": (_sz, [_LP, _i, _i, _i]),
+    "rtpose_packed_weight_floats": (_sz, [_i, _i, _i]),
+    "rtpose_packed_bias_floats": (_sz, [_i]),
+    "rtpose_pack_conv_weights": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "rtpose_conv2d": (_i, [C.POINTER(ConvDesc), _i, _i, _i, _i, _vp]),
+    "rtpose_maxpool2x2": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, _i, _vp]),
+    "rtpose_nchw_to_layout": (_i, [_vp, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
+    "rtpose_layout_to_nchw": (_i, [_vp, _LP, _vp, _i, _i, _i, _i, _vp]),
+    "rtpose_layout_copy": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, _i, _vp]),
+    "rtpose_net_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
+    "rtpose_net_destroy": (None, [_vp]),
+    "rtpose_net_workspace_bytes": (_sz, [_vp]),
+    "rtpose_net_weight_bytes": (_sz, [_vp]),
+    "rtpose_net_bind": (_i, [_vp, _vp, _sz, _vp, _sz, _i, _vp]),
+    "rtpose_net_num_convs": (_i, [_vp]),
+    "rtpose_net_conv_info": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "rtpose_net_load_conv": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "rtpose_net_forward": (_i, [_vp, _vp, _vp]),
+    "rtpose_net_set_keep_intermediates": (_i, [_vp, _i]),
+    "rtpose_net_read_output": (_i, [_vp, _i, _vp, _vp]),
+    "rtpose_net_output_view": (_i, [_vp, _i, C.POINTER(_vp), _LP, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "rtpose_net_set_profiling": (_i, [_vp, _i]),
+    "rtpose_net_num_launches": (_i, [_vp]),
+    "rtpose_net_launch_info": (_i, [_vp, _i, C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(C.c_double), C.c_char_p, _i]),
+    "rtpose_decode_workspace_bytes": (_sz, [C.POINTER(DecodeCfg), _i]),
+    "rtpose_decode_result_bytes": (_sz, [C.POINTER(DecodeCfg), _i]),
+    "rtpose_decode_batch": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, C.POINTER(DecodeCfg), _vp, _sz, _vp, _vp]),
+    "rtpose_nms_batch": (_i, [_vp, _LP, _i, _i, _i, C.POINTER(DecodeCfg), _vp, _vp]),
+    "rtpose_flip_merge": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    # legacy SWIG-module names (lib/pafprocess/pafprocess.h:53-59)
+    "process_paf": (_i, [_i, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "get_num_humans": (_i, []),
+    "get_part_cid": (_i, [_i, _i]),
+    "get_score": (C.c_float, [_i]),
+    "get_part_x": (_i, [_i]),
+    "get_part_y": (_i, [_i]),
+    "get_part_score": (C.c_float, [_i]),
+}
+
+EXPORTED = tuple(_SIGS)
+
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here == header/library mismatch
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error():
+    return lib.rtpose_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RtposeError("%s failed (rc=%d): %s" % (what or "librtpose_mi355x call", rc, last_error()))
+
+
+def ptr(t):
+    """Device/host address of a torch tensor or numpy array as c_void_p."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.ctypes.data)
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

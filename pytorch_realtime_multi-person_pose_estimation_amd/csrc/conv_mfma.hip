@@ -1,0 +1,567 @@
+// fp32 implicit-GEMM convolution for gfx950 (MI355X), stride 1, "same" padding,
+// k in {1,3,7}, fused bias (+ReLU) (+2x2 max-pool).
+//
+// Stands in for the nn.Conv2d / nn.ReLU / nn.MaxPool2d modules instantiated by
+// lib/network/rtpose_vgg.py:23-35 and :49-55 (ATen kernels on the reference).
+//
+// Design (MI355X-first, not a translation of any CUDA kernel):
+//  * GEMM view: M = output pixels, N = output channels, K = taps x channels.
+//    Block tile 128(M) x 64(N), 4 wave64s as 2(M) x 2(N), each wave a 64 x 32
+//    tile = two 32x32 accumulators of v_mfma_f32_32x32x2_f32 (exact fp32, the
+//    only fp32-input matrix op on CDNA4; 64 cycles/instruction/SIMD).
+//  * Activations use the shared-gap padded NHWC layout (include/rtpose_mi355x.h
+//    §1): a stencil tap is a constant pixel offset, so the A operand is NOT an
+//    im2col gather: per 16-channel chunk the block stages ONE halo of input
+//    pixels in LDS and re-uses it for all k*k taps (49x re-use for 7x7).
+//    LDS image is [channel/4][pixel][4 floats]; every A fragment read is one
+//    conflict-free ds_read_b128 per lane (4 consecutive k for its k-half).
+//  * The B operand (weights, pre-packed [chunk][tap][c/4][cout][4]) goes
+//    straight from L2 to registers with a one-tap-deep register prefetch: a
+//    wave reads 1 KiB contiguous per instruction, no LDS, no per-tap barrier.
+//    One barrier per channel chunk (k*k*16 MFMAs per wave apart).
+//  * The next chunk's halo is fetched one 16-byte piece per thread per tap
+//    underneath the MFMAs and written to the other LDS buffer.
+//  * Two tilings: MODE 0 "strip" = 128 consecutive pixels of the flattened
+//    (n,y,x) space (no tile waste on the 46x46 maps: 32*46*46 = 529 * 128);
+//    MODE 1 = TH x TW 2-D tiles inside one image for wide maps (bounded halo).
+//  * 2 blocks per CU (launch bounds) so one block's chunk barrier / epilogue
+//    hides under the other's MFMAs.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace rtpose {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct ConvGroup {
+  const float* in;
+  const float* w;
+  const float* bias;
+  float* out;
+  int in_cstride, in_choff, in_ws, in_hs, in_lead;
+  int out_cstride, out_choff, out_ws, out_hs, out_lead;
+  int cout, cout_pad;
+};
+
+struct ConvArgs {
+  ConvGroup g[2];
+  int N, H, W, M;     // output == input spatial size (before pooling)
+  int cin;            // packed input channels
+  int relu, pool;
+  int qs;             // LDS pixels per channel-group plane
+  int hw_lds;         // MODE 1: LDS row stride of the halo (pixels)
+  int tw_log2;        // MODE 1: log2(tile width); tile height = 128 >> tw_log2
+  int tiles_x, tiles_y;
+};
+
+constexpr int kBM = 128;
+
+template <int KS>
+struct PiecesPerTap {
+  static constexpr int value = (KS == 1) ? 6 : 1;
+};
+
+// m_local (0..127) -> (ty, tx) inside a 2-D tile.  2x2 quads are 4 consecutive
+// m so that a fused max-pool is a max over 4 accumulator registers of one lane.
+__device__ __forceinline__ void tile_local_yx(int ml, int tw_log2, int& ty, int& tx) {
+  const int qi = ml >> 2;
+  const int hw_log2 = tw_log2 - 1;  // quads per tile row
+  ty = ((qi >> hw_log2) << 1) + ((ml >> 1) & 1);
+  tx = ((qi & ((1 << hw_log2) - 1)) << 1) + (ml & 1);
+}
+
+template <int KS, int CK, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
+  constexpr int P = KS / 2;
+  constexpr int T = KS * KS;
+  constexpr int CG = CK / 4;  // 16-byte channel groups per chunk
+  constexpr int G = CK / 8;   // 8-deep k groups per chunk (4 MFMAs each)
+  constexpr int PPT = PiecesPerTap<KS>::value;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  const ConvGroup& g = A.g[blockIdx.z];
+  const int QS = A.qs;
+  const int buf_floats = CG * QS * 4;
+
+  // ---- block -> tile -------------------------------------------------------
+  int m0 = 0, n_img = 0, y0 = 0, x0 = 0;  // MODE 0 uses m0; MODE 1 uses the rest
+  int q_origin, np_pix, row_lds;
+  int qc0 = 0;
+  if (MODE == 0) {
+    m0 = blockIdx.x * kBM;
+    const int HW = A.H * A.W;
+    const int n = m0 / HW, r = m0 - n * HW;
+    const int y = r / A.W, x = r - y * A.W;
+    qc0 = g.in_lead + (n * g.in_hs + y) * g.in_ws + x;
+    int ml = min(m0 + kBM, A.M) - 1;
+    const int n2 = ml / HW, r2 = ml - n2 * HW;
+    const int y2 = r2 / A.W, x2 = r2 - y2 * A.W;
+    const int qcl = g.in_lead + (n2 * g.in_hs + y2) * g.in_ws + x2;
+    q_origin = qc0 - P * g.in_ws - P;
+    np_pix = qcl + P * g.in_ws + P - q_origin + 1;
+    row_lds = g.in_ws;
+  } else {
+    int b = blockIdx.x;
+    const int txi = b % A.tiles_x;
+    b /= A.tiles_x;
+    const int tyi = b % A.tiles_y;
+    n_img = b / A.tiles_y;
+    const int TW = 1 << A.tw_log2, TH = kBM >> A.tw_log2;
+    y0 = tyi * TH;
+    x0 = txi * TW;
+    q_origin = g.in_lead + (n_img * g.in_hs + y0 - P) * g.in_ws + x0 - P;
+    np_pix = (TH + 2 * P) * A.hw_lds;
+    row_lds = A.hw_lds;
+  }
+  const int np_total = np_pix * CG;  // 16-byte pieces per chunk
+
+  // ---- per-lane A fragment bases (LDS pixel index of this lane's row) ------
+  int abase[2];
+#pragma unroll
+  for (int fm = 0; fm < 2; ++fm) {
+    const int ml = wm * 64 + fm * 32 + l31;
+    if (MODE == 0) {
+      const int m = min(m0 + ml, A.M - 1);
+      const int HW = A.H * A.W;
+      const int n = m / HW, r = m - n * HW;
+      const int y = r / A.W, x = r - y * A.W;
+      abase[fm] = g.in_lead + (n * g.in_hs + y) * g.in_ws + x - qc0;
+    } else {
+      int ty, tx;
+      tile_local_yx(ml, A.tw_log2, ty, tx);
+      abase[fm] = ty * A.hw_lds + tx;
+    }
+  }
+
+  // ---- halo staging helpers -------------------------------------------------
+  const float* in_base = g.in + g.in_choff;
+  auto piece_src = [&](int idx, int chunk) -> const float4* {
+    const int pix = idx / CG, j = idx - pix * CG;
+    int q;
+    if (MODE == 0) {
+      q = q_origin + pix;
+    } else {
+      const int hy = pix / A.hw_lds, hx = pix - hy * A.hw_lds;
+      q = q_origin + hy * g.in_ws + hx;
+    }
+    return reinterpret_cast<const float4*>(in_base + (size_t)q * g.in_cstride +
+                                           chunk * CK + j * 4);
+  };
+  auto piece_dst = [&](float* buf, int idx) -> float4* {
+    const int pix = idx / CG, j = idx - pix * CG;
+    return reinterpret_cast<float4*>(buf + (size_t)(j * QS + pix) * 4);
+  };
+
+  // ---- B operand pointers ---------------------------------------------------
+  const int nchunks = A.cin / CK;
+  const int total = nchunks * T;
+  const int ncol = blockIdx.y * kConvBN + wn * 32 + l31;
+  const float4* bp = reinterpret_cast<const float4*>(g.w) +
+                     (size_t)kh * g.cout_pad + ncol;
+  const size_t b_it_stride = (size_t)CG * g.cout_pad;  // float4 per (chunk,tap)
+  const size_t b_g_stride = (size_t)2 * g.cout_pad;    // float4 per k-group
+
+  float4 bcur[G];
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi) bcur[gi] = bp[gi * b_g_stride];
+
+  // ---- prologue: halo of chunk 0 ---------------------------------------------
+  for (int idx = tid; idx < np_total; idx += 256)
+    *piece_dst(smem, idx) = *piece_src(idx, 0);
+  __syncthreads();
+
+  floatx16 acc[2];
+#pragma unroll
+  for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[fm][r] = 0.f;
+
+  int it = 0;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const float* hb = smem + (chunk & 1) * buf_floats;
+    float* hn = smem + ((chunk + 1) & 1) * buf_floats;
+    const bool has_next = (chunk + 1) < nchunks;
+    float4 hreg[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) hreg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // A fragments of tap 0 (the barrier that published `hb` is behind us)
+    float4 acur[G][2];
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+      for (int fm = 0; fm < 2; ++fm)
+        acur[gi][fm] = *reinterpret_cast<const float4*>(
+            hb + (size_t)((2 * gi + kh) * QS + abase[fm]) * 4);
+
+    for (int tap = 0; tap < T; ++tap, ++it) {
+      // B prefetch for the next (chunk, tap)
+      float4 bnxt[G];
+      {
+        const int itn = (it + 1 < total) ? it + 1 : it;
+        const float4* bq = bp + (size_t)itn * b_it_stride;
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) bnxt[gi] = bq[gi * b_g_stride];
+      }
+      // halo of the next chunk: write what was fetched during the previous
+      // tap, fetch the next piece set
+      if (has_next) {
+        if (tap > 0) {
+#pragma unroll
+          for (int p = 0; p < PPT; ++p) {
+            const int idx = ((tap - 1) * PPT + p) * 256 + tid;
+            if (idx < np_total) *piece_dst(hn, idx) = hreg[p];
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+          const int idx = (tap * PPT + p) * 256 + tid;
+          if (idx < np_total) hreg[p] = *piece_src(idx, chunk + 1);
+        }
+      }
+      // A prefetch for the next tap of this chunk (same LDS buffer, no barrier)
+      float4 anxt[G][2];
+      {
+        const int tn = (tap + 1 < T) ? tap + 1 : tap;
+        const int ky = tn / KS, kx = tn - ky * KS;
+        const int tapoff = ky * row_lds + kx;
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+          for (int fm = 0; fm < 2; ++fm)
+            anxt[gi][fm] = *reinterpret_cast<const float4*>(
+                hb + (size_t)((2 * gi + kh) * QS + abase[fm] + tapoff) * 4);
+      }
+      // MFMAs of this tap
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi) {
+        const float bv[4] = {bcur[gi].x, bcur[gi].y, bcur[gi].z, bcur[gi].w};
+        const float a0[4] = {acur[gi][0].x, acur[gi][0].y, acur[gi][0].z, acur[gi][0].w};
+        const float a1[4] = {acur[gi][1].x, acur[gi][1].y, acur[gi][1].z, acur[gi][1].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bv[j], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bv[j], acc[1], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi) {
+        bcur[gi] = bnxt[gi];
+        acur[gi][0] = anxt[gi][0];
+        acur[gi][1] = anxt[gi][1];
+      }
+    }
+    if (has_next) {
+#pragma unroll
+      for (int p = 0; p < PPT; ++p) {
+        const int idx = ((T - 1) * PPT + p) * 256 + tid;
+        if (idx < np_total) *piece_dst(hn, idx) = hreg[p];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias (+ReLU) (+2x2 max-pool), masked stores -----------------
+  const bool col_ok = ncol < g.cout;
+  const float bias = g.bias[ncol];  // bias is padded to cout_pad
+  float* out_base = g.out + g.out_choff + ncol;
+  if (!A.pool) {
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        // rows rg*8 + 4*kh + {0,1,2,3}
+        const int ml0 = wm * 64 + fm * 32 + rg * 8 + 4 * kh;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int ml = ml0 + rr;
+          int n, y, x;
+          bool ok;
+          if (MODE == 0) {
+            const int m = m0 + ml;
+            ok = m < A.M;
+            const int HW = A.H * A.W;
+            n = m / HW;
+            const int r = m - n * HW;
+            y = r / A.W;
+            x = r - y * A.W;
+          } else {
+            int ty, tx;
+            tile_local_yx(ml, A.tw_log2, ty, tx);
+            n = n_img;
+            y = y0 + ty;
+            x = x0 + tx;
+            ok = (y < A.H) && (x < A.W);
+          }
+          float v = acc[fm][rg * 4 + rr] + bias;
+          if (A.relu) v = fmaxf(v, 0.f);
+          if (ok && col_ok) {
+            const size_t q = (size_t)g.out_lead + (size_t)(n * g.out_hs + y) * g.out_ws + x;
+            out_base[q * g.out_cstride] = v;
+          }
+        }
+      }
+    }
+  } else {
+    // MODE 1 only: quad = 4 consecutive m = 4 consecutive accumulator registers
+    const int Ho = A.H >> 1, Wo = A.W >> 1;
+    const int hw_log2 = A.tw_log2 - 1;
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int ml0 = wm * 64 + fm * 32 + rg * 8 + 4 * kh;
+        const int qi = ml0 >> 2;
+        const int py = (y0 >> 1) + (qi >> hw_log2);
+        const int px = (x0 >> 1) + (qi & ((1 << hw_log2) - 1));
+        float v = fmaxf(fmaxf(acc[fm][rg * 4 + 0], acc[fm][rg * 4 + 1]),
+                        fmaxf(acc[fm][rg * 4 + 2], acc[fm][rg * 4 + 3])) + bias;
+        if (A.relu) v = fmaxf(v, 0.f);
+        if (py < Ho && px < Wo && col_ok) {
+          const size_t q = (size_t)g.out_lead + (size_t)(n_img * g.out_hs + py) * g.out_ws + px;
+          out_base[q * g.out_cstride] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---- weight packing -------------------------------------------------------------
+// packed[chunk][tap][cg][cout_pad][4]  <-  w[cout][cin_src][k][k]
+__global__ void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                    int cout, int cin_src, int k, const int32_t* __restrict__ cin_map,
+                                    int cin_packed, int ck, int coutp, float* __restrict__ wp,
+                                    float* __restrict__ bp) {
+  const int T = k * k;
+  const size_t total = (size_t)T * cin_packed * coutp;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)coutp) bp[i] = (i < (size_t)cout && bias) ? bias[i] : 0.f;
+  if (i >= total) return;
+  const int e = i & 3;
+  size_t r = i >> 2;
+  const int n = r % coutp;
+  r /= coutp;
+  const int cg = r % (ck / 4);
+  r /= (ck / 4);
+  const int tap = r % T;
+  const int chunk = r / T;
+  const int c = chunk * ck + cg * 4 + e;
+  int src = cin_map ? cin_map[c] : (c < cin_src ? c : -1);
+  float v = 0.f;
+  if (n < cout && src >= 0 && src < cin_src) {
+    const int ky = tap / k, kx = tap - ky * k;
+    v = w[(((size_t)n * cin_src + src) * k + ky) * k + kx];
+  }
+  wp[i] = v;
+}
+
+// ---- host side --------------------------------------------------------------------
+static int conv_ck(int cin) { return (cin % 16 == 0) ? 16 : 8; }
+
+struct ConvPlan {
+  int mode, ck, qs, hw_lds, tw_log2, tiles_x, tiles_y, grid_x;
+  size_t lds_bytes;
+};
+
+// LDS plane size: pixel count rounded so that the 4 channel-group planes of one
+// pixel land in different 16-byte bank slots on the staging writes.
+static int round_qs(int npix) {
+  int qs = npix;
+  while ((qs & 3) != 2) ++qs;
+  return qs;
+}
+
+static int halo_row_lds(int tw, int p) {
+  int w = tw + 2 * p;
+  while ((w & 15) != 8) ++w;  // consecutive tile rows half a bank-row apart
+  return w;
+}
+
+static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* pl) {
+  const int P = d.k / 2;
+  pl->ck = conv_ck(d.cin);
+  const int M = N * H * W;
+  const int max_pieces = (d.k == 1) ? PiecesPerTap<1>::value : d.k * d.k;  // per thread
+  const int cg = pl->ck / 4;
+  bool strip = (W <= 64) && !d.pool;
+  if (strip) {
+    const rtpose_layout& l = d.lin;
+    const int lb = (kBM - 1) + ((kBM - 1) / W + 1) * (l.ws - W) +
+                   ((kBM - 1) / (H * W) + 1) * (l.hs - H) * l.ws + 2 * P * l.ws + 2 * P + 1;
+    const int qs = round_qs(lb);
+    const size_t lds = (size_t)2 * cg * qs * 16;
+    if (ceil_div(qs * cg, 256) > max_pieces || lds > 80 * 1024) strip = false;
+    if (strip) {
+      pl->mode = 0;
+      pl->qs = qs;
+      pl->hw_lds = 0;
+      pl->tw_log2 = 0;
+      pl->tiles_x = pl->tiles_y = 0;
+      pl->grid_x = ceil_div(M, kBM);
+      pl->lds_bytes = lds;
+      return 0;
+    }
+  }
+  // 2-D tiles: pick the tile width with the least padded work
+  int best_tw = 0;
+  long best_cost = -1;
+  for (int twl = 2; twl <= 6; ++twl) {
+    const int tw = 1 << twl, th = kBM >> twl;
+    if (th < 2) continue;
+    const long cost = (long)ceil_div(W, tw) * ceil_div(H, th);
+    const long halo = (long)(th + 2 * P) * halo_row_lds(tw, P);
+    // tie-break on the smaller halo
+    const long key = cost * 100000 + halo;
+    if (best_cost < 0 || key < best_cost) {
+      best_cost = key;
+      best_tw = twl;
+    }
+  }
+  const int tw = 1 << best_tw, th = kBM >> best_tw;
+  pl->mode = 1;
+  pl->tw_log2 = best_tw;
+  pl->hw_lds = halo_row_lds(tw, P);
+  const int npix = (th + 2 * P) * pl->hw_lds;
+  pl->qs = round_qs(npix);
+  pl->tiles_x = ceil_div(W, tw);
+  pl->tiles_y = ceil_div(H, th);
+  pl->grid_x = N * pl->tiles_x * pl->tiles_y;
+  pl->lds_bytes = (size_t)2 * cg * pl->qs * 16;
+  if (ceil_div(pl->qs * cg, 256) > max_pieces)
+    return fail(RTPOSE_E_INVAL, "conv halo too large for the staging schedule");
+  return 0;
+}
+
+template <int KS, int CK, int MODE>
+static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = conv_mfma_f32<KS, CK, MODE>;
+  if (!attr_set) {
+    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s) {
+  if (!d || ngroups < 1 || ngroups > 2) return fail(RTPOSE_E_INVAL, "conv2d: ngroups must be 1 or 2");
+  const rtpose_conv_desc& d0 = d[0];
+  if (d0.k != 1 && d0.k != 3 && d0.k != 7) return fail(RTPOSE_E_INVAL, "conv2d: k must be 1, 3 or 7");
+  if (d0.cin % 8 != 0 || d0.cin <= 0) return fail(RTPOSE_E_INVAL, "conv2d: cin must be a multiple of 8");
+  if (N <= 0 || H <= 0 || W <= 0) return fail(RTPOSE_E_INVAL, "conv2d: empty tensor");
+  const int P = d0.k / 2;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < ngroups; ++i) {
+    const rtpose_conv_desc& di = d[i];
+    if (di.k != d0.k || di.cin != d0.cin || di.relu != d0.relu || di.pool != d0.pool ||
+        cout_pad(di.cout) != cout_pad(d0.cout) || di.lin.ws != d0.lin.ws || di.lin.hs != d0.lin.hs)
+      return fail(RTPOSE_E_INVAL, "conv2d: grouped convs must share geometry");
+    if (di.lin.ws < W + P || di.lin.hs < H + P || di.lin.lead < P * di.lin.ws + P)
+      return fail(RTPOSE_E_INVAL, "conv2d: input layout gap smaller than the conv padding");
+    if ((di.lin.cstride % 4) || (di.lin.choff % 4))
+      return fail(RTPOSE_E_INVAL, "conv2d: input slice must be 16-byte aligned");
+    if (di.lin.choff + di.cin > di.lin.cstride)
+      return fail(RTPOSE_E_INVAL, "conv2d: input slice exceeds cstride");
+    ConvGroup& g = a.g[i];
+    g.in = di.in;
+    g.w = di.w_packed;
+    g.bias = di.bias_packed;
+    g.out = di.out;
+    g.in_cstride = di.lin.cstride;
+    g.in_choff = di.lin.choff;
+    g.in_ws = di.lin.ws;
+    g.in_hs = di.lin.hs;
+    g.in_lead = di.lin.lead;
+    g.out_cstride = di.lout.cstride;
+    g.out_choff = di.lout.choff;
+    g.out_ws = di.lout.ws;
+    g.out_hs = di.lout.hs;
+    g.out_lead = di.lout.lead;
+    g.cout = di.cout;
+    g.cout_pad = cout_pad(di.cout);
+  }
+  if (d0.pool && ((H | W) & 1)) return fail(RTPOSE_E_INVAL, "conv2d: fused pool needs even H and W");
+  ConvPlan pl;
+  int rc = plan_conv(d0, N, H, W, &pl);
+  if (rc) return rc;
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.M = N * H * W;
+  a.cin = d0.cin;
+  a.relu = d0.relu;
+  a.pool = d0.pool;
+  a.qs = pl.qs;
+  a.hw_lds = pl.hw_lds;
+  a.tw_log2 = pl.tw_log2;
+  a.tiles_x = pl.tiles_x;
+  a.tiles_y = pl.tiles_y;
+  dim3 grid(pl.grid_x, cout_pad(d0.cout) / kConvBN, ngroups);
+#define RTPOSE_CONV_CASE(KS_, CK_, MODE_)                     \
+  if (d0.k == KS_ && pl.ck == CK_ && pl.mode == MODE_)        \
+    return launch_inst<KS_, CK_, MODE_>(a, grid, pl.lds_bytes, s);
+  RTPOSE_CONV_CASE(3, 8, 0)
+  RTPOSE_CONV_CASE(3, 8, 1)
+  RTPOSE_CONV_CASE(3, 16, 0)
+  RTPOSE_CONV_CASE(3, 16, 1)
+  RTPOSE_CONV_CASE(7, 16, 0)
+  RTPOSE_CONV_CASE(7, 16, 1)
+  RTPOSE_CONV_CASE(1, 16, 0)
+  RTPOSE_CONV_CASE(1, 16, 1)
+  RTPOSE_CONV_CASE(1, 8, 0)
+  RTPOSE_CONV_CASE(1, 8, 1)
+  RTPOSE_CONV_CASE(7, 8, 0)
+  RTPOSE_CONV_CASE(7, 8, 1)
+#undef RTPOSE_CONV_CASE
+  return fail(RTPOSE_E_INVAL, "conv2d: no kernel instance for k=%d ck=%d mode=%d", d0.k, pl.ck, pl.mode);
+}
+
+int pack_weights_launch(const float* w, const float* bias, int cout, int cin_src, int k,
+                        const int32_t* cin_map, int cin_packed, float* wp, float* bp, hipStream_t s) {
+  if (cin_packed % 8 || cin_packed < cin_src && !cin_map)
+    return fail(RTPOSE_E_INVAL, "pack: cin_packed must be a multiple of 8 and >= cin_src");
+  if (k != 1 && k != 3 && k != 7) return fail(RTPOSE_E_INVAL, "pack: k must be 1, 3 or 7");
+  const int coutp = cout_pad(cout);
+  const size_t total = (size_t)k * k * cin_packed * coutp;
+  const int threads = 256;
+  const unsigned blocks = (unsigned)((total + threads - 1) / threads);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(threads), 0, s, w, bias, cout, cin_src, k,
+                     cin_map, cin_packed, conv_ck(cin_packed), coutp, wp, bp);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace rtpose
+
+extern "C" {
+
+size_t rtpose_packed_weight_floats(int cout, int cin, int k) {
+  const int cinp = rtpose::ceil_div(cin, 8) * 8;
+  return (size_t)k * k * cinp * rtpose::cout_pad(cout);
+}
+size_t rtpose_packed_bias_floats(int cout) { return (size_t)rtpose::cout_pad(cout); }
+
+int rtpose_pack_conv_weights(const float* w_oihw, const float* bias, int cout, int cin_src, int k,
+                             const int32_t* cin_map, int cin_packed, float* w_packed,
+                             float* bias_packed, void* stream) {
+  return rtpose::pack_weights_launch(w_oihw, bias, cout, cin_src, k, cin_map, cin_packed, w_packed,
+                                     bias_packed, rtpose::as_stream(stream));
+}
+
+int rtpose_conv2d(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, void* stream) {
+  return rtpose::conv2d_launch(d, ngroups, N, H, W, rtpose::as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// Layout of the decode result block and scratch (shared by host and device code).
+#pragma once
+#include "common.h"
+
+namespace rtpose {
+
+constexpr int kDecodeMaxPeaks = 128;  // per (image, part) table capacity limit
+
+// word (4-byte) offsets inside one image's result record
+constexpr int kResHeader = 0;      // [0] n_peaks [1] n_humans [2] overflow flags
+constexpr int kResPartCount = 8;   // int32[18]
+constexpr int kResPeaks = 32;      // rtpose_peak[18 * pcap], then human tables
+
+constexpr int kOverflowPeaks = 1;   // a part had more than max_peaks_per_part peaks
+constexpr int kOverflowHumans = 2;  // more subset rows / humans than capacity
+
+__host__ __device__ inline int decode_result_words(const rtpose_decode_cfg* c) {
+  const int w = kResPeaks + 4 * RTPOSE_NUM_PART * c->max_peaks_per_part +
+                (RTPOSE_NUM_PART + 1) * c->max_humans;
+  return (w + 3) & ~3;
+}
+// per image: 19 x { count, (a, b, score) x pcap }
+inline int decode_conn_words(const rtpose_decode_cfg* c) {
+  return RTPOSE_NUM_LIMB * (1 + 3 * c->max_peaks_per_part);
+}
+// subset rows alive at any time before pruning (LDS resident, 21 floats each)
+inline int decode_row_cap(const rtpose_decode_cfg* c) {
+  int r = 2 * c->max_humans;
+  if (r < 64) r = 64;
+  if (r > 720) r = 720;
+  return r;
+}
+inline size_t decode_workspace_bytes(const rtpose_decode_cfg* c, int N) {
+  return round_up((size_t)N * decode_conn_words(c) * sizeof(int32_t), 256);
+}
+
+int nms_launch(const float* heat, const rtpose_layout* lheat, int N, int h, int w,
+               const rtpose_decode_cfg* cfg, void* result, hipStream_t s);
+int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int h, int w, double inv_up,
+                        int h1, const rtpose_decode_cfg* cfg, void* workspace, size_t workspace_bytes,
+                        void* result, hipStream_t s);
+
+}  // namespace rtpose

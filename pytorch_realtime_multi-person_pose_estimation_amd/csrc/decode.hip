@@ -1,0 +1,571 @@
+// Batched pose decoding on the GPU — replaces the numpy/scipy/cv2 control flow
+// of lib/utils/paf_to_pose.py (NMS :67-145, find_peaks :25-38) and the serial
+// C++ of lib/pafprocess/pafprocess.cpp (process_paf :22-194) with three
+// wavefront-level kernels, one launch each for a whole batch of images:
+//
+//   nms_refine_kernel      grid (18 parts, N)   peak test + ordered compaction +
+//                                               8x bicubic patch refine/arg-max
+//   limb_assign_kernel     grid (19 limbs, N)   10-sample PAF line integral for
+//                                               every (a,b) pair + greedy 1:1
+//   group_kernel           grid (N)             subset merge + prune (one wave)
+//
+// Integer outputs (peak coordinates, ids, part->peak assignments) are bit-exact
+// to the reference; float scores reproduce its operation order (this file is
+// compiled with -ffp-contract=off; hipcc's default correctly rounded fp32
+// divide/sqrt is relied upon).  All HBM reads are of the low-resolution maps:
+// the x8 nearest-neighbour up-sampling of paf_to_pose.py:382-385 is an index
+// computation (floor(x * 1/8)), never materialised.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "decode.h"
+
+namespace rtpose {
+
+// pafprocess.h:16-24
+__constant__ int kPairNet[19][2] = {{12, 13}, {20, 21}, {14, 15}, {16, 17}, {22, 23}, {24, 25}, {0, 1},
+                                    {2, 3},   {4, 5},   {6, 7},   {8, 9},   {10, 11}, {28, 29}, {30, 31},
+                                    {34, 35}, {32, 33}, {36, 37}, {18, 19}, {26, 27}};
+__constant__ int kPairs[19][2] = {{1, 2}, {1, 5},   {2, 3},   {3, 4},   {5, 6},   {6, 7},   {1, 8},
+                                  {8, 9}, {9, 10},  {1, 11},  {11, 12}, {12, 13}, {1, 0},   {0, 14},
+                                  {14, 16}, {0, 15}, {15, 17}, {2, 16},  {5, 17}};
+
+struct MapView {
+  const float* base;
+  int cstride, choff, ws, hs, lead;
+};
+
+__device__ __forceinline__ float map_at(const MapView& m, int n, int y, int x, int c) {
+  return m.base[((size_t)m.lead + (size_t)(n * m.hs + y) * m.ws + x) * m.cstride + m.choff + c];
+}
+
+// ------------------------------------------------------------------------------
+// 1. NMS + refine
+// ------------------------------------------------------------------------------
+constexpr int kMaxUp = 16;               // largest supported up-sampling factor
+constexpr int kMaxDst = 5 * kMaxUp;      // widest up-sampled patch
+
+// OpenCV interpolateCubic (A = -0.75f), float arithmetic, no contraction.
+__device__ __forceinline__ void cubic_coeffs(float x, float* c) {
+  const float A = -0.75f;
+  c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+  c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+  c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+__global__ __launch_bounds__(256) void nms_refine_kernel(MapView heat, int h, int w, int up,
+                                                         double inv_up, float thr, int pcap,
+                                                         int32_t* __restrict__ result,
+                                                         int result_words) {
+  const int part = blockIdx.x, n = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int32_t* res = result + (size_t)n * result_words;
+
+  __shared__ int s_sx[kMaxDst];
+  __shared__ float s_alpha[kMaxDst][4];
+  __shared__ int s_wcount[4];
+  __shared__ int s_px[kDecodeMaxPeaks], s_py[kDecodeMaxPeaks];
+  __shared__ float s_patch[4][25];
+  __shared__ float s_hbuf[4][5 * kMaxDst];
+
+  // per-destination-index source offset and cubic weights (cv2.resize INTER_CUBIC:
+  // fx = (float)((dx+0.5)*scale - 0.5); sx = floor(fx); fx -= sx)
+  if (tid < 5 * up) {
+    float fx = (float)(((double)tid + 0.5) * inv_up - 0.5);
+    const int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    float c[4];
+    cubic_coeffs(fx, c);
+    s_sx[tid] = sx;
+    s_alpha[tid][0] = c[0];
+    s_alpha[tid][1] = c[1];
+    s_alpha[tid][2] = c[2];
+    s_alpha[tid][3] = c[3];
+  }
+
+  // ---- find_peaks (paf_to_pose.py:25-38): 4-neighbour maximum, > thr, row-major order
+  int base = 0;
+  const int npix = h * w;
+  for (int start = 0; start < npix; start += 256) {
+    const int idx = start + tid;
+    bool pk = false;
+    int x = 0, y = 0;
+    if (idx < npix) {
+      y = idx / w;
+      x = idx - y * w;
+      const float v = map_at(heat, n, y, x, part);
+      pk = v > thr;
+      if (pk && y > 0) pk = v >= map_at(heat, n, y - 1, x, part);
+      if (pk && y + 1 < h) pk = v >= map_at(heat, n, y + 1, x, part);
+      if (pk && x > 0) pk = v >= map_at(heat, n, y, x - 1, part);
+      if (pk && x + 1 < w) pk = v >= map_at(heat, n, y, x + 1, part);
+    }
+    const unsigned long long mask = __ballot(pk);
+    if (lane == 0) s_wcount[wave] = __popcll(mask);
+    __syncthreads();
+    int off = base;
+    for (int k = 0; k < wave; ++k) off += s_wcount[k];
+    if (pk) {
+      const int pos = off + __popcll(mask & ((1ull << lane) - 1ull));
+      if (pos < pcap) {
+        s_px[pos] = x;
+        s_py[pos] = y;
+      }
+    }
+    base += s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+    __syncthreads();
+  }
+  const int count = min(base, pcap);
+  if (tid == 0) {
+    res[kResPartCount + part] = count;
+    if (base > pcap) atomicOr(&res[kResHeader + 2], kOverflowPeaks);
+  }
+
+  // ---- refine (paf_to_pose.py:106-142): one wave per peak
+  rtpose_peak* peaks = reinterpret_cast<rtpose_peak*>(res + kResPeaks) + (size_t)part * pcap;
+  for (int i = wave; i < count; i += 4) {
+    const int px = s_px[i], py = s_py[i];
+    const int x_min = max(0, px - 2), y_min = max(0, py - 2);
+    const int x_max = min(w - 1, px + 2), y_max = min(h - 1, py + 2);
+    const int pw = x_max - x_min + 1, ph = y_max - y_min + 1;
+    const int dw = pw * up, dh = ph * up;
+    if (lane < pw * ph) {
+      const int r = lane / pw, c = lane - r * pw;
+      s_patch[wave][lane] = map_at(heat, n, y_min + r, x_min + c, part);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // horizontal pass: hbuf[r][dx] = sum_j patch[r][clamp(sx-1+j)] * alpha[dx][j]
+    for (int e = lane; e < ph * dw; e += 64) {
+      const int r = e / dw, dx = e - r * dw;
+      const int sx = s_sx[dx];
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int sxj = min(max(sx - 1 + j, 0), pw - 1);
+        v = v + s_patch[wave][r * pw + sxj] * s_alpha[dx][j];
+      }
+      s_hbuf[wave][r * dw + dx] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // vertical pass + running arg-max (first maximum in row-major order)
+    float best = -INFINITY;
+    int best_idx = 0x7fffffff;
+    for (int e = lane; e < dh * dw; e += 64) {
+      const int dy = e / dw, dx = e - dy * dw;
+      const int sy = s_sx[dy];
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int syj = min(max(sy - 1 + j, 0), ph - 1);
+        const float t = s_hbuf[wave][syj * dw + dx] * s_alpha[dy][j];
+        v = (j == 0) ? t : v + t;
+      }
+      if (v > best) {
+        best = v;
+        best_idx = e;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float ob = __shfl_xor(best, o);
+      const int oi = __shfl_xor(best_idx, o);
+      if (ob > best || (ob == best && oi < best_idx)) {
+        best = ob;
+        best_idx = oi;
+      }
+    }
+    if (lane == 0) {
+      const int dy = best_idx / dw, dx = best_idx - dy * dw;
+      rtpose_peak p;
+      p.x = x_min * up + dx;  // paf_to_pose.py:129-141 collapses to this
+      p.y = y_min * up + dy;
+      p.score = best;
+      p.id = i;  // rebased to the running counter by the prefix kernel
+      peaks[i] = p;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ids = running counter over parts then peaks (paf_to_pose.py:141-142); also
+// totals in the header.  One wave per image.
+__global__ void peak_prefix_kernel(int pcap, int32_t* __restrict__ result, int result_words,
+                                   int nparts) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  int32_t* res = result + (size_t)n * result_words;
+  __shared__ int s_start[RTPOSE_NUM_PART + 1];
+  if (lane == 0) {
+    int acc = 0;
+    for (int p = 0; p < RTPOSE_NUM_PART; ++p) {
+      s_start[p] = acc;
+      acc += (p < nparts) ? res[kResPartCount + p] : 0;
+    }
+    s_start[RTPOSE_NUM_PART] = acc;
+    res[kResHeader + 0] = acc;
+  }
+  __syncthreads();
+  rtpose_peak* peaks = reinterpret_cast<rtpose_peak*>(res + kResPeaks);
+  for (int p = 0; p < nparts; ++p) {
+    const int cnt = res[kResPartCount + p];
+    for (int i = lane; i < cnt; i += 64) peaks[(size_t)p * pcap + i].id = s_start[p] + i;
+  }
+}
+
+// ------------------------------------------------------------------------------
+// 2. PAF scoring + greedy assignment (pafprocess.cpp:46-124, :220-246)
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ int roundpaf(float v) { return (int)((double)v + 0.5); }
+
+__global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, int w, double inv_up,
+                                                          int h1, int pcap,
+                                                          const int32_t* __restrict__ result,
+                                                          int result_words, int32_t* __restrict__ conn,
+                                                          int conn_words) {
+  const int pair_id = blockIdx.x, n = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int32_t* res = result + (size_t)n * result_words;
+  int32_t* cn = conn + (size_t)n * conn_words + (size_t)pair_id * (1 + 3 * pcap);
+
+  extern __shared__ float s_score[];  // [nA * nB] candidate scores, 0 = none
+  __shared__ unsigned char s_usedA[kDecodeMaxPeaks], s_usedB[kDecodeMaxPeaks];
+  __shared__ float s_wbest[4];
+  __shared__ int s_widx[4];
+  __shared__ int s_nconn;
+
+  const int partA = kPairs[pair_id][0], partB = kPairs[pair_id][1];
+  const int chx = kPairNet[pair_id][0], chy = kPairNet[pair_id][1];
+  const int nA = res[kResPartCount + partA], nB = res[kResPartCount + partB];
+  if (tid == 0) s_nconn = 0;
+  if (nA == 0 || nB == 0) {
+    if (tid == 0) cn[0] = 0;
+    return;
+  }
+  const rtpose_peak* pA = reinterpret_cast<const rtpose_peak*>(res + kResPeaks) + (size_t)partA * pcap;
+  const rtpose_peak* pB = reinterpret_cast<const rtpose_peak*>(res + kResPeaks) + (size_t)partB * pcap;
+  for (int i = tid; i < kDecodeMaxPeaks; i += 256) {
+    s_usedA[i] = 0;
+    s_usedB[i] = 0;
+  }
+
+  const int npairs = nA * nB;
+  for (int p = tid; p < npairs; p += 256) {
+    const int a = p / nB, b = p - a * nB;
+    const rtpose_peak A = pA[a], B = pB[b];
+    float cand = 0.f;
+    float vx = (float)(B.x - A.x), vy = (float)(B.y - A.y);
+    const float norm = sqrtf(vx * vx + vy * vy);
+    if (!((double)norm < 1e-12)) {
+      vx = vx / norm;
+      vy = vy / norm;
+      const float step_x = (float)(B.x - A.x) / 10.f;
+      const float step_y = (float)(B.y - A.y) / 10.f;
+      float scores = 0.f;
+      int crit1 = 0;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const int lx = roundpaf((float)A.x + (float)i * step_x);
+        const int ly = roundpaf((float)A.y + (float)i * step_y);
+        // nearest x8 up-sampling of the PAF as an index map (paf_to_pose.py:382)
+        int sx = (int)floor((double)lx * inv_up), sy = (int)floor((double)ly * inv_up);
+        sx = min(max(sx, 0), w - 1);
+        sy = min(max(sy, 0), h - 1);
+        const float px = map_at(paf, n, sy, sx, chx);
+        const float py = map_at(paf, n, sy, sx, chy);
+        const float s = vx * px + vy * py;
+        scores = scores + s;
+        if (s > 0.05f) ++crit1;
+      }
+      const double pen = fmin(0.0, 0.5 * (double)h1 / (double)norm - 1.0);
+      const float crit2 = (float)((double)(scores / 10.f) + pen);
+      if (crit1 > 6 && crit2 > 0.f) cand = crit2;
+    }
+    s_score[p] = cand;
+  }
+  __syncthreads();
+
+  // greedy: repeatedly take the best remaining candidate whose endpoints are
+  // both free == scanning the list sorted by descending score (cpp:96-124);
+  // equal scores resolve to the lower (a, b).
+  const int max_conn = min(nA, nB);
+  for (int it = 0; it < max_conn; ++it) {
+    float best = 0.f;
+    int bidx = 0x7fffffff;
+    for (int p = tid; p < npairs; p += 256) {
+      const float s = s_score[p];
+      if (s > best) {
+        const int a = p / nB, b = p - a * nB;
+        if (!s_usedA[a] && !s_usedB[b]) {
+          best = s;
+          bidx = p;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float ob = __shfl_xor(best, o);
+      const int oi = __shfl_xor(bidx, o);
+      if (ob > best || (ob == best && oi < bidx)) {
+        best = ob;
+        bidx = oi;
+      }
+    }
+    if (lane == 0) {
+      s_wbest[wave] = best;
+      s_widx[wave] = bidx;
+    }
+    __syncthreads();
+    best = s_wbest[0];
+    bidx = s_widx[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (s_wbest[k] > best || (s_wbest[k] == best && s_widx[k] < bidx)) {
+        best = s_wbest[k];
+        bidx = s_widx[k];
+      }
+    if (!(best > 0.f)) break;  // uniform
+    if (tid == 0) {
+      const int a = bidx / nB, b = bidx - a * nB;
+      s_usedA[a] = 1;
+      s_usedB[b] = 1;
+      const int k = s_nconn++;
+      cn[1 + 3 * k + 0] = a;
+      cn[1 + 3 * k + 1] = b;
+      cn[1 + 3 * k + 2] = __float_as_int(best);
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid == 0) cn[0] = s_nconn;
+}
+
+// ------------------------------------------------------------------------------
+// 3. Person grouping + prune (pafprocess.cpp:126-191), one wave per image
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* __restrict__ result,
+                                                   int result_words, const int32_t* __restrict__ conn,
+                                                   int conn_words, int row_cap) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  int32_t* res = result + (size_t)n * result_words;
+  const int32_t* cnb = conn + (size_t)n * conn_words;
+  extern __shared__ float rows[];  // [row_cap][20 + alive]: the reference's `subset`
+
+  __shared__ int s_start[RTPOSE_NUM_PART + 1];
+  if (lane == 0) {
+    int acc = 0;
+    for (int p = 0; p < RTPOSE_NUM_PART; ++p) {
+      s_start[p] = acc;
+      acc += res[kResPartCount + p];
+    }
+    s_start[RTPOSE_NUM_PART] = acc;
+  }
+  __syncthreads();
+  const rtpose_peak* peaks = reinterpret_cast<const rtpose_peak*>(res + kResPeaks);
+  // peak_infos_line[pos] (cpp:38-43): part-major position -> peak
+  auto line_peak = [&](int pos) -> rtpose_peak {
+    int p = 0;
+    while (p + 1 < RTPOSE_NUM_PART && pos >= s_start[p + 1]) ++p;
+    return peaks[(size_t)p * pcap + (pos - s_start[p])];
+  };
+  const int npeaks = s_start[RTPOSE_NUM_PART];
+
+  int nrows = 0;
+  bool overflow = false;
+  for (int pair_id = 0; pair_id < 19; ++pair_id) {
+    const int part1 = kPairs[pair_id][0], part2 = kPairs[pair_id][1];
+    const int32_t* cn = cnb + (size_t)pair_id * (1 + 3 * pcap);
+    const int nconn = cn[0];
+    const rtpose_peak* pA = peaks + (size_t)part1 * pcap;
+    const rtpose_peak* pB = peaks + (size_t)part2 * pcap;
+    for (int c = 0; c < nconn; ++c) {
+      const int ia = cn[1 + 3 * c], ib = cn[1 + 3 * c + 1];
+      const float cscore = __int_as_float(cn[1 + 3 * c + 2]);
+      const float cid1 = (float)pA[ia].id, cid2 = (float)pB[ib].id;
+      // search alive rows in order
+      int found = 0, idx1 = 0, idx2 = 0;
+      for (int r0 = 0; r0 < nrows; r0 += 64) {
+        const int r = r0 + lane;
+        bool hit = false;
+        if (r < nrows && rows[(size_t)r * 21 + 20] != 0.f)
+          hit = rows[(size_t)r * 21 + part1] == cid1 || rows[(size_t)r * 21 + part2] == cid2;
+        unsigned long long m = __ballot(hit);
+        while (m) {
+          const int b = __ffsll((long long)m) - 1;
+          if (found == 0) idx1 = r0 + b;
+          if (found == 1) idx2 = r0 + b;
+          ++found;
+          m &= m - 1;
+        }
+      }
+      const int c2 = (int)cid2;
+      const float s2 = (c2 >= 0 && c2 < npeaks) ? line_peak(c2).score : 0.f;
+      if (found == 1) {
+        float* row = rows + (size_t)idx1 * 21;
+        if (lane == 0 && row[part2] != cid2) {
+          row[part2] = cid2;
+          row[19] = row[19] + 1.f;
+          row[18] = row[18] + (s2 + cscore);
+        }
+      } else if (found == 2) {
+        float* r1 = rows + (size_t)idx1 * 21;
+        float* r2 = rows + (size_t)idx2 * 21;
+        bool both = false;
+        if (lane < 18) both = r1[lane] > 0.f && r2[lane] > 0.f;  // cid 0 reads as absent (cpp:155)
+        const bool membership = __any(both);
+        if (!membership) {
+          if (lane < 18) r1[lane] = r1[lane] + (r2[lane] + 1.f);
+          if (lane == 0) {
+            r1[19] = r1[19] + r2[19];
+            r1[18] = r1[18] + r2[18];
+            r1[18] = r1[18] + cscore;
+            r2[20] = 0.f;  // erase(subset_idx2): order of the survivors is kept
+          }
+        } else if (lane == 0) {
+          r1[part2] = cid2;
+          r1[19] = r1[19] + 1.f;
+          r1[18] = r1[18] + (s2 + cscore);
+        }
+      } else if (found == 0 && pair_id < 18) {
+        if (nrows < row_cap) {
+          float* row = rows + (size_t)nrows * 21;
+          const int c1 = (int)cid1;
+          const float s1 = (c1 >= 0 && c1 < npeaks) ? line_peak(c1).score : 0.f;
+          if (lane < 18) row[lane] = (lane == part1) ? cid1 : ((lane == part2) ? cid2 : -1.f);
+          if (lane == 0) {
+            row[19] = 2.f;
+            row[18] = (s1 + s2) + cscore;
+            row[20] = 1.f;
+          }
+          ++nrows;
+        } else {
+          overflow = true;
+        }
+      }
+      __syncthreads();  // single-wave block: orders the LDS row updates
+    }
+  }
+
+  // prune (cpp:187-191) and emit
+  int nh = 0;
+  int32_t* hparts = res + kResPeaks + 4 * RTPOSE_NUM_PART * pcap;
+  float* hscore = reinterpret_cast<float*>(hparts + (size_t)RTPOSE_NUM_PART * hcap);
+  for (int r = 0; r < nrows; ++r) {
+    const float* row = rows + (size_t)r * 21;
+    if (row[20] == 0.f) continue;
+    if (row[19] < 4.f || row[18] / row[19] < 0.3f) continue;
+    if (nh < hcap) {
+      if (lane < 18) hparts[(size_t)nh * RTPOSE_NUM_PART + lane] = (int)row[lane];
+      if (lane == 0) hscore[nh] = row[18] / row[19];
+      ++nh;
+    } else {
+      overflow = true;
+    }
+  }
+  if (lane == 0) {
+    res[kResHeader + 1] = nh;
+    if (overflow) atomicOr(&res[kResHeader + 2], kOverflowHumans);
+  }
+}
+
+__global__ void clear_header_kernel(int32_t* __restrict__ result, int result_words, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N * kResPeaks) result[(size_t)(i / kResPeaks) * result_words + (i % kResPeaks)] = 0;
+}
+
+static MapView to_view(const float* base, const rtpose_layout* l) {
+  return MapView{base, l->cstride, l->choff, l->ws, l->hs, l->lead};
+}
+
+static int check_cfg(const rtpose_decode_cfg* cfg) {
+  if (!cfg) return fail(RTPOSE_E_INVAL, "decode: cfg is NULL");
+  if (cfg->num_keypoints < 1 || cfg->num_keypoints > RTPOSE_NUM_PART)
+    return fail(RTPOSE_E_INVAL, "decode: num_keypoints must be in [1,18]");
+  if (cfg->upsample < 1 || cfg->upsample > kMaxUp)
+    return fail(RTPOSE_E_INVAL, "decode: upsample must be in [1,%d]", kMaxUp);
+  if (cfg->max_peaks_per_part < 1 || cfg->max_peaks_per_part > kDecodeMaxPeaks)
+    return fail(RTPOSE_E_INVAL, "decode: max_peaks_per_part must be in [1,%d]", kDecodeMaxPeaks);
+  if (cfg->max_humans < 1) return fail(RTPOSE_E_INVAL, "decode: max_humans must be >= 1");
+  return 0;
+}
+
+int nms_launch(const float* heat, const rtpose_layout* lheat, int N, int h, int w,
+               const rtpose_decode_cfg* cfg, void* result, hipStream_t s) {
+  int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (N <= 0 || h <= 0 || w <= 0) return fail(RTPOSE_E_INVAL, "decode: empty batch");
+  const int words = decode_result_words(cfg);
+  int32_t* res = static_cast<int32_t*>(result);
+  hipLaunchKernelGGL(clear_header_kernel, dim3(ceil_div(N * kResPeaks, 256)), dim3(256), 0, s, res, words, N);
+  hipLaunchKernelGGL(nms_refine_kernel, dim3(cfg->num_keypoints, N), dim3(256), 0, s, to_view(heat, lheat),
+                     h, w, cfg->upsample, 1.0 / (double)cfg->upsample, cfg->thresh_heatmap,
+                     cfg->max_peaks_per_part, res, words);
+  hipLaunchKernelGGL(peak_prefix_kernel, dim3(N), dim3(64), 0, s, cfg->max_peaks_per_part, res, words,
+                     cfg->num_keypoints);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// assignment + grouping on peak tables already in `result`
+int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int h, int w, double inv_up,
+                        int h1, const rtpose_decode_cfg* cfg, void* workspace, size_t workspace_bytes,
+                        void* result, hipStream_t s) {
+  if (workspace_bytes < decode_workspace_bytes(cfg, N))
+    return fail(RTPOSE_E_INVAL, "decode: workspace too small");
+  const int pcap = cfg->max_peaks_per_part;
+  const int words = decode_result_words(cfg);
+  const int conn_words = decode_conn_words(cfg);
+  int32_t* res = static_cast<int32_t*>(result);
+  int32_t* conn = static_cast<int32_t*>(workspace);
+  const size_t lds = (size_t)pcap * pcap * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(limb_assign_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 8192));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(limb_assign_kernel, dim3(RTPOSE_NUM_LIMB, N), dim3(256), lds, s, to_view(paf, lpaf), h,
+                     w, inv_up, h1, pcap, res, words, conn, conn_words);
+  const int row_cap = decode_row_cap(cfg);
+  hipLaunchKernelGGL(group_kernel, dim3(N), dim3(64), (size_t)row_cap * 21 * sizeof(float), s, pcap,
+                     cfg->max_humans, res, words, conn, conn_words, row_cap);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace rtpose
+
+using namespace rtpose;
+
+extern "C" {
+
+size_t rtpose_decode_workspace_bytes(const rtpose_decode_cfg* cfg, int N) {
+  if (check_cfg(cfg) || N <= 0) return 0;
+  return decode_workspace_bytes(cfg, N);
+}
+
+size_t rtpose_decode_result_bytes(const rtpose_decode_cfg* cfg, int N) {
+  if (check_cfg(cfg) || N <= 0) return 0;
+  return (size_t)N * decode_result_words(cfg) * sizeof(int32_t);
+}
+
+int rtpose_nms_batch(const float* heat, const rtpose_layout* lheat, int N, int h, int w,
+                     const rtpose_decode_cfg* cfg, void* result, void* stream) {
+  if (!heat || !lheat || !result) return fail(RTPOSE_E_INVAL, "nms: NULL argument");
+  return nms_launch(heat, lheat, N, h, w, cfg, result, as_stream(stream));
+}
+
+int rtpose_decode_batch(const float* heat, const rtpose_layout* lheat, const float* paf,
+                        const rtpose_layout* lpaf, int N, int h, int w, const rtpose_decode_cfg* cfg,
+                        void* workspace, size_t workspace_bytes, void* result, void* stream) {
+  if (!heat || !lheat || !paf || !lpaf || !workspace || !result)
+    return fail(RTPOSE_E_INVAL, "decode: NULL argument");
+  int rc = nms_launch(heat, lheat, N, h, w, cfg, result, as_stream(stream));
+  if (rc) return rc;
+  return assign_group_launch(paf, lpaf, N, h, w, 1.0 / (double)cfg->upsample, h * cfg->upsample, cfg,
+                             workspace, workspace_bytes, result, as_stream(stream));
+}
+
+}  // extern "C"

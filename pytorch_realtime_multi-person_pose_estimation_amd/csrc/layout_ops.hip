@@ -1,0 +1,243 @@
+// HBM-bound data-movement kernels around the conv path: NCHW <-> shared-gap
+// padded NHWC, slice copies, 2x2 max-pool (nn.MaxPool2d(2,2,0),
+// lib/network/rtpose_vgg.py:49-50) and the flip-TTA merge
+// (evaluate/coco_eval.py:197-242).  All are one coalesced pass, float4 on the
+// NHWC side where the slice is 16-byte aligned.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace rtpose {
+
+char* err_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+struct Lay {
+  int cstride, choff, ws, hs, lead;
+};
+static Lay to_lay(const rtpose_layout* l) { return Lay{l->cstride, l->choff, l->ws, l->hs, l->lead}; }
+
+__device__ __forceinline__ size_t lay_off(const Lay& l, int n, int y, int x) {
+  return ((size_t)l.lead + (size_t)(n * l.hs + y) * l.ws + x) * l.cstride + l.choff;
+}
+
+// One thread per (pixel, channel) with channel fastest on the NHWC side; the
+// NCHW side is strided by H*W, served from L2 (tensors here are small or read
+// once).  Used for the 3-channel input image and the 38/19-channel outputs.
+__global__ void nchw_to_layout_kernel(const float* __restrict__ src, float* __restrict__ dst, Lay l,
+                                      int C, int cpad, int N, int H, int W) {
+  const size_t total = (size_t)N * H * W * cpad;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = i % cpad;
+  size_t p = i / cpad;
+  const int x = p % W;
+  p /= W;
+  const int y = p % H;
+  const int n = p / H;
+  const float v = (c < C) ? src[(((size_t)n * C + c) * H + y) * W + x] : 0.f;
+  dst[lay_off(l, n, y, x) + c] = v;
+}
+
+// x fastest on the NCHW side (coalesced writes); the NHWC reads of one wave hit
+// 64 different pixels of the same channel: 64 sectors, but C (<=57) consecutive
+// launches-worth of threads re-use them from L2.
+__global__ void layout_to_nchw_kernel(const float* __restrict__ src, Lay l, float* __restrict__ dst,
+                                      int C, int N, int H, int W) {
+  const size_t total = (size_t)N * C * H * W;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int x = i % W;
+  size_t p = i / W;
+  const int y = p % H;
+  p /= H;
+  const int c = p % C;
+  const int n = p / C;
+  dst[i] = src[lay_off(l, n, y, x) + c];
+}
+
+__global__ void layout_copy_kernel(const float* __restrict__ src, Lay ls, float* __restrict__ dst,
+                                   Lay ld, int C, int N, int H, int W) {
+  const int c4 = C >> 2;
+  const size_t total = (size_t)N * H * W * c4;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (i % c4) * 4;
+  size_t p = i / c4;
+  const int x = p % W;
+  p /= W;
+  const int y = p % H;
+  const int n = p / H;
+  *reinterpret_cast<float4*>(dst + lay_off(ld, n, y, x) + c) =
+      *reinterpret_cast<const float4*>(src + lay_off(ls, n, y, x) + c);
+}
+
+__global__ void layout_copy_scalar_kernel(const float* __restrict__ src, Lay ls,
+                                          float* __restrict__ dst, Lay ld, int C, int N, int H,
+                                          int W) {
+  const size_t total = (size_t)N * H * W * C;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = i % C;
+  size_t p = i / C;
+  const int x = p % W;
+  p /= W;
+  const int y = p % H;
+  const int n = p / H;
+  dst[lay_off(ld, n, y, x) + c] = src[lay_off(ls, n, y, x) + c];
+}
+
+__global__ void maxpool2x2_kernel(const float* __restrict__ src, Lay ls, float* __restrict__ dst,
+                                  Lay ld, int C, int N, int Ho, int Wo) {
+  const int c4 = C >> 2;
+  const size_t total = (size_t)N * Ho * Wo * c4;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (i % c4) * 4;
+  size_t p = i / c4;
+  const int x = p % Wo;
+  p /= Wo;
+  const int y = p % Ho;
+  const int n = p / Ho;
+  const float4 a = *reinterpret_cast<const float4*>(src + lay_off(ls, n, 2 * y, 2 * x) + c);
+  const float4 b = *reinterpret_cast<const float4*>(src + lay_off(ls, n, 2 * y, 2 * x + 1) + c);
+  const float4 d = *reinterpret_cast<const float4*>(src + lay_off(ls, n, 2 * y + 1, 2 * x) + c);
+  const float4 e = *reinterpret_cast<const float4*>(src + lay_off(ls, n, 2 * y + 1, 2 * x + 1) + c);
+  float4 r;
+  r.x = fmaxf(fmaxf(a.x, b.x), fmaxf(d.x, e.x));
+  r.y = fmaxf(fmaxf(a.y, b.y), fmaxf(d.y, e.y));
+  r.z = fmaxf(fmaxf(a.z, b.z), fmaxf(d.z, e.z));
+  r.w = fmaxf(fmaxf(a.w, b.w), fmaxf(d.w, e.w));
+  *reinterpret_cast<float4*>(dst + lay_off(ld, n, y, x) + c) = r;
+}
+
+// handle_paf_and_heat (evaluate/coco_eval.py:197-242): average a map with the
+// x-mirrored, left/right-channel-swapped map of the flipped image; the PAF
+// x components (even channels AFTER the swap gather, :237) change sign.
+__constant__ int kSwapHeat[19] = {0, 1, 5, 6, 7, 2, 3, 4, 11, 12, 13, 8, 9, 10, 15, 14, 17, 16, 18};
+__constant__ int kSwapPaf[38] = {6,  7,  8,  9,  10, 11, 0,  1,  2,  3,  4,  5,  20,
+                                 21, 22, 23, 24, 25, 26, 27, 12, 13, 14, 15, 16, 17,
+                                 18, 19, 28, 29, 32, 33, 30, 31, 36, 37, 34, 35};
+
+__global__ void flip_merge_kernel(const float* __restrict__ heat, const float* __restrict__ heat_f,
+                                  const float* __restrict__ paf, const float* __restrict__ paf_f,
+                                  int N, int h, int w, float* __restrict__ heat_avg,
+                                  float* __restrict__ paf_avg) {
+  const size_t npix = (size_t)N * h * w;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * 57) return;
+  const int c = i % 57;
+  const size_t p = i / 57;
+  const int x = p % w;
+  const size_t row = p / w;  // n*h + y
+  const size_t pf = row * w + (w - 1 - x);
+  if (c < 19) {
+    heat_avg[p * 19 + c] = (heat[p * 19 + c] + heat_f[pf * 19 + kSwapHeat[c]]) / 2.f;
+  } else {
+    const int k = c - 19;
+    // coco_eval.py:237 negates the channels listed in swap_paf[::2] in place
+    // (:236 is a no-op), then :238 gathers with swap_paf: output channel k
+    // reads flipped channel swap_paf[k], negated iff swap_paf[k] is one of the
+    // swap_paf[::2] entries, i.e. iff it is an even channel index.
+    const int sc = kSwapPaf[k];
+    float v = paf_f[pf * 38 + sc];
+    if ((sc & 1) == 0) v = -v;
+    paf_avg[p * 38 + k] = (paf[p * 38 + k] + v) / 2.f;
+  }
+}
+
+static inline unsigned nblocks(size_t total, int threads) {
+  return (unsigned)((total + threads - 1) / threads);
+}
+
+}  // namespace rtpose
+
+using namespace rtpose;
+
+extern "C" {
+
+const char* rtpose_version(void) { return "rtpose_mi355x 0.1 (gfx950)"; }
+const char* rtpose_last_error(void) { return rtpose::err_buf(); }
+
+size_t rtpose_layout_pixels(const rtpose_layout* l, int N, int H, int W) {
+  (void)H;
+  (void)W;
+  return (size_t)l->lead + (size_t)N * l->hs * l->ws + (size_t)40 * l->ws + 256;
+}
+
+int rtpose_nchw_to_layout(const float* src, float* dst, const rtpose_layout* ldst, int C, int cpad,
+                          int N, int H, int W, void* stream) {
+  if (cpad < C || ldst->choff + cpad > ldst->cstride)
+    return fail(RTPOSE_E_INVAL, "nchw_to_layout: bad channel counts");
+  const size_t total = (size_t)N * H * W * cpad;
+  if (!total) return 0;
+  hipLaunchKernelGGL(nchw_to_layout_kernel, dim3(nblocks(total, 256)), dim3(256), 0,
+                     as_stream(stream), src, dst, to_lay(ldst), C, cpad, N, H, W);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_layout_to_nchw(const float* src, const rtpose_layout* lsrc, float* dst, int C, int N, int H,
+                          int W, void* stream) {
+  const size_t total = (size_t)N * H * W * C;
+  if (!total) return 0;
+  hipLaunchKernelGGL(layout_to_nchw_kernel, dim3(nblocks(total, 256)), dim3(256), 0,
+                     as_stream(stream), src, to_lay(lsrc), dst, C, N, H, W);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_layout_copy(const float* src, const rtpose_layout* lsrc, float* dst,
+                       const rtpose_layout* ldst, int C, int N, int H, int W, void* stream) {
+  const bool vec = !(C % 4) && !(lsrc->cstride % 4) && !(lsrc->choff % 4) && !(ldst->cstride % 4) &&
+                   !(ldst->choff % 4);
+  if (vec) {
+    const size_t total = (size_t)N * H * W * (C / 4);
+    if (!total) return 0;
+    hipLaunchKernelGGL(layout_copy_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
+                       src, to_lay(lsrc), dst, to_lay(ldst), C, N, H, W);
+  } else {
+    const size_t total = (size_t)N * H * W * C;
+    if (!total) return 0;
+    hipLaunchKernelGGL(layout_copy_scalar_kernel, dim3(nblocks(total, 256)), dim3(256), 0,
+                       as_stream(stream), src, to_lay(lsrc), dst, to_lay(ldst), C, N, H, W);
+  }
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_maxpool2x2(const float* in, const rtpose_layout* lin, float* out, const rtpose_layout* lout,
+                      int C, int N, int H, int W, void* stream) {
+  if ((C % 4) || (lin->cstride % 4) || (lin->choff % 4) || (lout->cstride % 4) || (lout->choff % 4))
+    return fail(RTPOSE_E_INVAL, "maxpool: channel slices must be 16-byte aligned");
+  const int Ho = H / 2, Wo = W / 2;
+  const size_t total = (size_t)N * Ho * Wo * (C / 4);
+  if (!total) return 0;
+  hipLaunchKernelGGL(maxpool2x2_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), in,
+                     to_lay(lin), out, to_lay(lout), C, N, Ho, Wo);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_flip_merge(const float* heat, const float* heat_flipped, const float* paf,
+                      const float* paf_flipped, int N, int h, int w, float* heat_avg, float* paf_avg,
+                      void* stream) {
+  const size_t total = (size_t)N * h * w * 57;
+  if (!total) return 0;
+  hipLaunchKernelGGL(flip_merge_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
+                     heat, heat_flipped, paf, paf_flipped, N, h, w, heat_avg, paf_avg);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,527 @@
+// Native executor for the rtpose_vgg network (lib/network/rtpose_vgg.py:60-225):
+// builds the launch plan for a given (N, H, W), carves the caller-provided
+// workspace into shared-gap padded NHWC activation buffers, packs weights into
+// the caller-provided weight arena and enqueues the forward
+// (rtpose_model.forward, rtpose_vgg.py:158-198) as a fixed list of launches on
+// one HIP stream.
+//
+// What differs from the reference module graph (same arithmetic, other layout):
+//  * torch.cat([L1, L2, out1], 1) (rtpose_vgg.py:165,171,177,183,189) never
+//    runs: the two branch heads of stage s write straight into channel slices
+//    of one 192-channel buffer laid out [out1 0..127 | PAF 128..165 | heat
+//    166..184 | 7 zero], and the 185-input-channel filters are permuted to that
+//    order when packed.  Two such buffers ping-pong between stages.
+//  * the two branches of a stage (independent, rtpose_vgg.py:163-164) run as
+//    one grouped grid per layer.
+//  * MaxPool2d is fused into the epilogue of the conv in front of it when the
+//    map has even height and width.
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace rtpose {
+int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
+int pack_weights_launch(const float* w, const float* bias, int cout, int cin_src, int k,
+                        const int32_t* cin_map, int cin_packed, float* wp, float* bp, hipStream_t s);
+}  // namespace rtpose
+
+using namespace rtpose;
+
+namespace {
+
+struct Buf {
+  size_t off_floats = 0;  // offset in the workspace
+  size_t floats = 0;
+  rtpose_layout lay{};
+  int C = 0, H = 0, W = 0;
+};
+
+struct ConvW {
+  std::string name;
+  int cout = 0, cin_src = 0, cin_packed = 0, k = 0;
+  bool cat_perm = false;   // input channels follow the cat([L1,L2,out1]) order
+  size_t w_off = 0, b_off = 0;  // float offsets in the weight arena
+};
+
+enum OpKind { OP_INPUT, OP_CONV, OP_POOL, OP_COPY };
+
+struct Op {
+  OpKind kind;
+  std::string name;
+  int H = 0, W = 0;         // spatial size the op runs at
+  // conv
+  int ngroups = 0;
+  int conv_idx[2] = {-1, -1};
+  int in_buf[2] = {-1, -1}, out_buf[2] = {-1, -1};
+  int in_choff[2] = {0, 0}, out_choff[2] = {0, 0};
+  int relu = 0, pool = 0;
+  // pool / copy
+  int C = 0;
+  double flops = 0.0;
+  int ks = 0;
+};
+
+}  // namespace
+
+struct rtpose_net {
+  int N = 0, H = 0, W = 0;       // input
+  int H3 = 0, W3 = 0;            // stride-8 map
+  std::vector<Buf> bufs;
+  std::vector<ConvW> convs;
+  std::vector<Op> ops;
+  size_t ws_floats = 0, wt_floats = 0;
+  size_t catmap_off = 0;         // int32[192] inside the weight arena
+  float* ws = nullptr;
+  float* wt = nullptr;
+  bool bound = false;
+  int keep = 0;
+  int save_buf[6] = {-1, -1, -1, -1, -1, -1};
+  int cat_buf[2] = {-1, -1};
+  int x0_buf = -1;
+  // profiling
+  int profiling = 0;
+  std::vector<hipEvent_t> ev;
+  bool ev_valid = false;
+};
+
+namespace {
+
+constexpr int kCatC = 192;      // [out1 128 | PAF 38 | heat 19 | pad 7]
+constexpr int kCatPaf = 128, kCatHeat = 166;
+
+int add_buf(rtpose_net* n, int C, int P, int H, int W) {
+  Buf b;
+  b.C = C;
+  b.H = H;
+  b.W = W;
+  b.lay.cstride = C;
+  b.lay.choff = 0;
+  b.lay.ws = W + P;
+  b.lay.hs = H + P;
+  b.lay.lead = P * (W + P) + P;
+  b.floats = round_up(rtpose_layout_pixels(&b.lay, n->N, H, W) * (size_t)C, 64);
+  b.off_floats = n->ws_floats;
+  n->ws_floats += b.floats;
+  n->bufs.push_back(b);
+  return (int)n->bufs.size() - 1;
+}
+
+int add_conv_w(rtpose_net* n, const std::string& name, int cout, int cin, int k, bool cat_perm) {
+  ConvW c;
+  c.name = name;
+  c.cout = cout;
+  c.cin_src = cin;
+  c.cin_packed = cat_perm ? kCatC : ceil_div(cin, 8) * 8;
+  c.k = k;
+  c.cat_perm = cat_perm;
+  c.w_off = n->wt_floats;
+  n->wt_floats += round_up(rtpose_packed_weight_floats(cout, c.cin_packed, k), 64);
+  c.b_off = n->wt_floats;
+  n->wt_floats += round_up(rtpose_packed_bias_floats(cout), 64);
+  n->convs.push_back(c);
+  return (int)n->convs.size() - 1;
+}
+
+void add_conv_op(rtpose_net* n, int H, int W, int ngroups, const int* conv_idx, const int* in_buf,
+                 const int* in_choff, const int* out_buf, const int* out_choff, int relu, int pool) {
+  Op o;
+  o.kind = OP_CONV;
+  o.H = H;
+  o.W = W;
+  o.ngroups = ngroups;
+  o.relu = relu;
+  o.pool = pool;
+  double fl = 0;
+  for (int i = 0; i < ngroups; ++i) {
+    o.conv_idx[i] = conv_idx[i];
+    o.in_buf[i] = in_buf[i];
+    o.in_choff[i] = in_choff[i];
+    o.out_buf[i] = out_buf[i];
+    o.out_choff[i] = out_choff[i];
+    const ConvW& c = n->convs[conv_idx[i]];
+    // algorithmic flops: direct-convolution count of the reference nn.Conv2d
+    fl += 2.0 * n->N * H * W * (double)c.cout * c.cin_src * c.k * c.k;
+    o.name += (i ? "+" : "") + c.name;
+  }
+  o.flops = fl;
+  o.ks = n->convs[conv_idx[0]].k;
+  n->ops.push_back(o);
+}
+
+void add_simple_op(rtpose_net* n, OpKind kind, const std::string& name, int H, int W, int in_buf,
+                   int in_choff, int out_buf, int out_choff, int C) {
+  Op o;
+  o.kind = kind;
+  o.name = name;
+  o.H = H;
+  o.W = W;
+  o.in_buf[0] = in_buf;
+  o.in_choff[0] = in_choff;
+  o.out_buf[0] = out_buf;
+  o.out_choff[0] = out_choff;
+  o.C = C;
+  n->ops.push_back(o);
+}
+
+// conv (+pool) writing into a buffer at the pooled or the same resolution
+void plan_vgg_conv(rtpose_net* n, int conv, int H, int W, int in_buf, int out_buf_same,
+                   int out_buf_pooled) {
+  const int zero = 0;
+  if (out_buf_pooled < 0) {
+    add_conv_op(n, H, W, 1, &conv, &in_buf, &zero, &out_buf_same, &zero, 1, 0);
+  } else if (!((H | W) & 1)) {
+    add_conv_op(n, H, W, 1, &conv, &in_buf, &zero, &out_buf_pooled, &zero, 1, 1);
+  } else {
+    add_conv_op(n, H, W, 1, &conv, &in_buf, &zero, &out_buf_same, &zero, 1, 0);
+    add_simple_op(n, OP_POOL, "pool", H, W, out_buf_same, 0, out_buf_pooled, 0,
+                  n->bufs[out_buf_same].C);
+  }
+}
+
+void build_plan(rtpose_net* n) {
+  const int N = n->N;
+  (void)N;
+  const int H0 = n->H, W0 = n->W;
+  const int H1 = H0 / 2, W1 = W0 / 2, H2 = H1 / 2, W2 = W1 / 2, H3 = H2 / 2, W3 = W2 / 2;
+  n->H3 = H3;
+  n->W3 = W3;
+
+  // ---- weights, in the reference's state_dict order (rtpose_vgg.py:141-155) ----
+  // model0: VGG19 first 10 convs + 2 CPM convs (rtpose_vgg.py:69-83)
+  const int vgg_idx[12] = {0, 2, 5, 7, 10, 12, 14, 16, 19, 21, 23, 25};
+  const int vgg_cin[12] = {3, 64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 256};
+  const int vgg_cout[12] = {64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 256, 128};
+  int cw0[12];
+  for (int i = 0; i < 12; ++i)
+    cw0[i] = add_conv_w(n, "model0." + std::to_string(vgg_idx[i]), vgg_cout[i], vgg_cin[i], 3, false);
+  // stages: branch 1 (PAF, 38) for stages 1..6, then branch 2 (heat, 19)
+  int cw1[2][5], cws[2][5][7];
+  for (int b = 0; b < 2; ++b) {
+    const int last = b == 0 ? 38 : 19;
+    const std::string sfx = "_" + std::to_string(b + 1) + ".";
+    // stage 1 (rtpose_vgg.py:95-105)
+    for (int i = 0; i < 5; ++i) {
+      const int cin = i < 4 ? 128 : 512;
+      const int cout = i < 3 ? 128 : (i == 3 ? 512 : last);
+      const int k = i < 3 ? 3 : 1;
+      cw1[b][i] = add_conv_w(n, "model1" + sfx + std::to_string(2 * i), cout, cin, k, false);
+    }
+    // stages 2..6 (rtpose_vgg.py:108-127)
+    for (int s = 2; s <= 6; ++s)
+      for (int i = 0; i < 7; ++i) {
+        const int cin = i == 0 ? 185 : 128;
+        const int cout = i < 6 ? 128 : last;
+        const int k = i < 5 ? 7 : 1;
+        cws[b][s - 2][i] = add_conv_w(n, "model" + std::to_string(s) + sfx + std::to_string(2 * i),
+                                      cout, cin, k, i == 0);
+      }
+  }
+  n->catmap_off = n->wt_floats;
+  n->wt_floats += 256;  // int32[192]
+
+  // ---- activation buffers ------------------------------------------------------
+  const int X0 = add_buf(n, 8, 1, H0, W0);
+  n->x0_buf = X0;
+  const int A1 = add_buf(n, 64, 1, H0, W0);
+  const bool even0 = !((H0 | W0) & 1), even1 = !((H1 | W1) & 1), even2 = !((H2 | W2) & 1);
+  const int A2 = even0 ? -1 : add_buf(n, 64, 0, H0, W0);
+  const int B0 = add_buf(n, 64, 1, H1, W1);
+  const int B1 = add_buf(n, 128, 1, H1, W1);
+  const int B2 = even1 ? -1 : add_buf(n, 128, 0, H1, W1);
+  const int C0 = add_buf(n, 128, 1, H2, W2);
+  const int C1 = add_buf(n, 256, 1, H2, W2);
+  const int C2 = add_buf(n, 256, 1, H2, W2);
+  const int C3 = add_buf(n, 256, 1, H2, W2);
+  const int C4 = even2 ? -1 : add_buf(n, 256, 0, H2, W2);
+  const int D0 = add_buf(n, 256, 1, H3, W3);
+  const int D1 = add_buf(n, 512, 1, H3, W3);
+  const int D2 = add_buf(n, 512, 1, H3, W3);
+  const int D3 = add_buf(n, 256, 1, H3, W3);
+  const int CATa = add_buf(n, kCatC, 3, H3, W3);
+  const int CATb = add_buf(n, kCatC, 3, H3, W3);
+  n->cat_buf[0] = CATa;
+  n->cat_buf[1] = CATb;
+  int T1[2], T2[2], T3[2], T4[2], U[2][6];
+  for (int b = 0; b < 2; ++b) {
+    T1[b] = add_buf(n, 128, 1, H3, W3);
+    T2[b] = add_buf(n, 128, 1, H3, W3);
+    T3[b] = add_buf(n, 128, 0, H3, W3);
+    T4[b] = add_buf(n, 512, 0, H3, W3);
+    for (int i = 0; i < 4; ++i) U[b][i] = add_buf(n, 128, 3, H3, W3);
+    U[b][4] = add_buf(n, 128, 0, H3, W3);
+    U[b][5] = add_buf(n, 128, 0, H3, W3);
+  }
+  for (int s = 0; s < 6; ++s) n->save_buf[s] = add_buf(n, 57, 0, H3, W3);
+
+  // ---- launches ------------------------------------------------------------------
+  add_simple_op(n, OP_INPUT, "nchw_to_nhwc8", H0, W0, -1, 0, X0, 0, 3);
+  plan_vgg_conv(n, cw0[0], H0, W0, X0, A1, -1);
+  plan_vgg_conv(n, cw0[1], H0, W0, A1, A2, B0);
+  plan_vgg_conv(n, cw0[2], H1, W1, B0, B1, -1);
+  plan_vgg_conv(n, cw0[3], H1, W1, B1, B2, C0);
+  plan_vgg_conv(n, cw0[4], H2, W2, C0, C1, -1);
+  plan_vgg_conv(n, cw0[5], H2, W2, C1, C2, -1);
+  plan_vgg_conv(n, cw0[6], H2, W2, C2, C3, -1);
+  plan_vgg_conv(n, cw0[7], H2, W2, C3, C4, D0);
+  plan_vgg_conv(n, cw0[8], H3, W3, D0, D1, -1);
+  plan_vgg_conv(n, cw0[9], H3, W3, D1, D2, -1);
+  plan_vgg_conv(n, cw0[10], H3, W3, D2, D3, -1);
+  {  // conv4_4_CPM -> out1, written once into each concat buffer
+    const int zero = 0;
+    add_conv_op(n, H3, W3, 1, &cw0[11], &D3, &zero, &CATa, &zero, 1, 0);
+    add_simple_op(n, OP_COPY, "out1->cat_b", H3, W3, CATa, 0, CATb, 0, 128);
+  }
+  const int zz[2] = {0, 0};
+  const int head_off[2] = {kCatPaf, kCatHeat};
+  {  // stage 1: reads out1 = CATa[0:128]; heads write CATb
+    const int in0[2] = {CATa, CATa};
+    int ci[2];
+    ci[0] = cw1[0][0]; ci[1] = cw1[1][0];
+    add_conv_op(n, H3, W3, 2, ci, in0, zz, T1, zz, 1, 0);
+    ci[0] = cw1[0][1]; ci[1] = cw1[1][1];
+    add_conv_op(n, H3, W3, 2, ci, T1, zz, T2, zz, 1, 0);
+    ci[0] = cw1[0][2]; ci[1] = cw1[1][2];
+    add_conv_op(n, H3, W3, 2, ci, T2, zz, T3, zz, 1, 0);
+    ci[0] = cw1[0][3]; ci[1] = cw1[1][3];
+    add_conv_op(n, H3, W3, 2, ci, T3, zz, T4, zz, 1, 0);
+    ci[0] = cw1[0][4]; ci[1] = cw1[1][4];
+    const int outb[2] = {CATb, CATb};
+    add_conv_op(n, H3, W3, 2, ci, T4, zz, outb, head_off, 0, 0);
+    add_simple_op(n, OP_COPY, "save1", H3, W3, CATb, kCatPaf, n->save_buf[0], 0, 57);
+  }
+  for (int s = 2; s <= 6; ++s) {
+    const int cin_buf = (s % 2 == 0) ? CATb : CATa;
+    const int cout_buf = (s % 2 == 0) ? CATa : CATb;
+    const int in0[2] = {cin_buf, cin_buf};
+    int ci[2];
+    int u0[2] = {U[0][0], U[1][0]};
+    ci[0] = cws[0][s - 2][0]; ci[1] = cws[1][s - 2][0];
+    add_conv_op(n, H3, W3, 2, ci, in0, zz, u0, zz, 1, 0);
+    for (int i = 1; i < 6; ++i) {
+      const int ui[2] = {U[0][i - 1], U[1][i - 1]};
+      const int uo[2] = {U[0][i], U[1][i]};
+      ci[0] = cws[0][s - 2][i]; ci[1] = cws[1][s - 2][i];
+      add_conv_op(n, H3, W3, 2, ci, ui, zz, uo, zz, 1, 0);
+    }
+    const int ui[2] = {U[0][5], U[1][5]};
+    const int outb[2] = {cout_buf, cout_buf};
+    ci[0] = cws[0][s - 2][6]; ci[1] = cws[1][s - 2][6];
+    add_conv_op(n, H3, W3, 2, ci, ui, zz, outb, head_off, 0, 0);
+    add_simple_op(n, OP_COPY, "save" + std::to_string(s), H3, W3, cout_buf, kCatPaf,
+                  n->save_buf[s - 1], 0, 57);
+  }
+}
+
+rtpose_layout slice(const Buf& b, int choff) {
+  rtpose_layout l = b.lay;
+  l.choff = choff;
+  return l;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtpose_net_create(int N, int H, int W, rtpose_net** out) {
+  if (!out) return fail(RTPOSE_E_INVAL, "net_create: out is NULL");
+  if (N <= 0 || H < 8 || W < 8) return fail(RTPOSE_E_INVAL, "net_create: need N>=1 and H,W>=8");
+  rtpose_net* n = new rtpose_net();
+  n->N = N;
+  n->H = H;
+  n->W = W;
+  build_plan(n);
+  *out = n;
+  return 0;
+}
+
+void rtpose_net_destroy(rtpose_net* net) {
+  if (!net) return;
+  for (hipEvent_t e : net->ev) (void)hipEventDestroy(e);
+  delete net;
+}
+
+size_t rtpose_net_workspace_bytes(const rtpose_net* net) { return net->ws_floats * sizeof(float); }
+size_t rtpose_net_weight_bytes(const rtpose_net* net) { return net->wt_floats * sizeof(float); }
+
+int rtpose_net_bind(rtpose_net* net, void* workspace, size_t workspace_bytes, void* weights,
+                    size_t weight_bytes, int zero_workspace, void* stream) {
+  if (!net || !workspace || !weights) return fail(RTPOSE_E_INVAL, "net_bind: NULL argument");
+  if (workspace_bytes < rtpose_net_workspace_bytes(net) || weight_bytes < rtpose_net_weight_bytes(net))
+    return fail(RTPOSE_E_INVAL, "net_bind: arena too small");
+  if (((uintptr_t)workspace | (uintptr_t)weights) & 255)
+    return fail(RTPOSE_E_INVAL, "net_bind: arenas must be 256-byte aligned");
+  net->ws = static_cast<float*>(workspace);
+  net->wt = static_cast<float*>(weights);
+  hipStream_t s = as_stream(stream);
+  if (zero_workspace) RTPOSE_HIP_CHECK(hipMemsetAsync(workspace, 0, rtpose_net_workspace_bytes(net), s));
+  // channel map of the concat input: packed c -> source channel of cat([L1,L2,out1])
+  int32_t map[kCatC];
+  for (int c = 0; c < kCatC; ++c) {
+    if (c < 128) map[c] = 57 + c;
+    else if (c < kCatHeat) map[c] = c - kCatPaf;
+    else if (c < 185) map[c] = 38 + (c - kCatHeat);
+    else map[c] = -1;
+  }
+  RTPOSE_HIP_CHECK(hipMemcpyAsync(net->wt + net->catmap_off, map, sizeof(map), hipMemcpyHostToDevice, s));
+  RTPOSE_HIP_CHECK(hipStreamSynchronize(s));  // `map` is a stack buffer
+  net->bound = true;
+  return 0;
+}
+
+int rtpose_net_num_convs(const rtpose_net* net) { return (int)net->convs.size(); }
+
+int rtpose_net_conv_info(const rtpose_net* net, int idx, char* name, int name_cap, int* cout, int* cin,
+                         int* k) {
+  if (!net || idx < 0 || idx >= (int)net->convs.size()) return fail(RTPOSE_E_INVAL, "conv_info: bad index");
+  const ConvW& c = net->convs[idx];
+  if (name && name_cap > 0) snprintf(name, name_cap, "%s", c.name.c_str());
+  if (cout) *cout = c.cout;
+  if (cin) *cin = c.cin_src;
+  if (k) *k = c.k;
+  return 0;
+}
+
+int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw, const float* bias, void* stream) {
+  if (!net || !net->bound) return fail(RTPOSE_E_STATE, "net_load_conv: net not bound");
+  if (idx < 0 || idx >= (int)net->convs.size()) return fail(RTPOSE_E_INVAL, "net_load_conv: bad index");
+  const ConvW& c = net->convs[idx];
+  const int32_t* map = c.cat_perm ? reinterpret_cast<const int32_t*>(net->wt + net->catmap_off) : nullptr;
+  return pack_weights_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed, net->wt + c.w_off,
+                             net->wt + c.b_off, as_stream(stream));
+}
+
+int rtpose_net_set_keep_intermediates(rtpose_net* net, int keep) {
+  if (!net) return fail(RTPOSE_E_INVAL, "NULL net");
+  net->keep = keep ? 1 : 0;
+  return 0;
+}
+
+int rtpose_net_set_profiling(rtpose_net* net, int enable) {
+  if (!net) return fail(RTPOSE_E_INVAL, "NULL net");
+  net->profiling = enable ? 1 : 0;
+  if (enable && net->ev.empty()) {
+    net->ev.resize(net->ops.size() + 1);
+    for (auto& e : net->ev) RTPOSE_HIP_CHECK(hipEventCreate(&e));
+  }
+  net->ev_valid = false;
+  return 0;
+}
+
+int rtpose_net_num_launches(const rtpose_net* net) { return (int)net->ops.size(); }
+
+int rtpose_net_launch_info(rtpose_net* net, int i, float* ms, int* k, double* flops, char* name,
+                           int name_cap) {
+  if (!net || i < 0 || i >= (int)net->ops.size()) return fail(RTPOSE_E_INVAL, "launch_info: bad index");
+  const Op& o = net->ops[i];
+  if (k) *k = o.kind == OP_CONV ? o.ks : 0;
+  if (flops) *flops = o.flops;
+  if (name && name_cap > 0) snprintf(name, name_cap, "%s", o.name.c_str());
+  if (ms) {
+    *ms = -1.f;
+    if (net->profiling && net->ev_valid) {
+      float t = 0.f;
+      hipError_t e = hipEventElapsedTime(&t, net->ev[i], net->ev[i + 1]);
+      if (e == hipSuccess) *ms = t;
+    }
+  }
+  return 0;
+}
+
+int rtpose_net_forward(rtpose_net* net, const float* x_nchw, void* stream) {
+  if (!net || !net->bound) return fail(RTPOSE_E_STATE, "net_forward: net not bound");
+  if (!x_nchw) return fail(RTPOSE_E_INVAL, "net_forward: x is NULL");
+  hipStream_t s = as_stream(stream);
+  const int N = net->N;
+  const bool prof = net->profiling && !net->ev.empty();
+  for (size_t i = 0; i < net->ops.size(); ++i) {
+    const Op& o = net->ops[i];
+    if (prof) RTPOSE_HIP_CHECK(hipEventRecord(net->ev[i], s));
+    int rc = 0;
+    switch (o.kind) {
+      case OP_INPUT: {
+        const Buf& b = net->bufs[o.out_buf[0]];
+        rc = rtpose_nchw_to_layout(x_nchw, net->ws + b.off_floats, &b.lay, 3, 8, N, o.H, o.W, stream);
+        break;
+      }
+      case OP_CONV: {
+        rtpose_conv_desc d[2];
+        for (int g = 0; g < o.ngroups; ++g) {
+          const ConvW& c = net->convs[o.conv_idx[g]];
+          const Buf& bi = net->bufs[o.in_buf[g]];
+          const Buf& bo = net->bufs[o.out_buf[g]];
+          d[g].in = net->ws + bi.off_floats;
+          d[g].out = net->ws + bo.off_floats;
+          d[g].w_packed = net->wt + c.w_off;
+          d[g].bias_packed = net->wt + c.b_off;
+          d[g].lin = slice(bi, o.in_choff[g]);
+          d[g].lout = slice(bo, o.out_choff[g]);
+          d[g].cin = c.cin_packed;
+          d[g].cout = c.cout;
+          d[g].k = c.k;
+          d[g].relu = o.relu;
+          d[g].pool = o.pool;
+        }
+        rc = conv2d_launch(d, o.ngroups, N, o.H, o.W, s);
+        break;
+      }
+      case OP_POOL: {
+        const Buf& bi = net->bufs[o.in_buf[0]];
+        const Buf& bo = net->bufs[o.out_buf[0]];
+        rc = rtpose_maxpool2x2(net->ws + bi.off_floats, &bi.lay, net->ws + bo.off_floats, &bo.lay, o.C,
+                               N, o.H, o.W, stream);
+        break;
+      }
+      case OP_COPY: {
+        if (o.name.rfind("save", 0) == 0 && !net->keep) break;
+        const Buf& bi = net->bufs[o.in_buf[0]];
+        const Buf& bo = net->bufs[o.out_buf[0]];
+        const rtpose_layout li = slice(bi, o.in_choff[0]), lo = slice(bo, o.out_choff[0]);
+        rc = rtpose_layout_copy(net->ws + bi.off_floats, &li, net->ws + bo.off_floats, &lo, o.C, N, o.H,
+                                o.W, stream);
+        break;
+      }
+    }
+    if (rc) return rc;
+  }
+  if (prof) {
+    RTPOSE_HIP_CHECK(hipEventRecord(net->ev[net->ops.size()], s));
+    net->ev_valid = true;
+  }
+  return 0;
+}
+
+int rtpose_net_read_output(rtpose_net* net, int which, float* dst_nchw, void* stream) {
+  if (!net || !net->bound) return fail(RTPOSE_E_STATE, "net_read_output: net not bound");
+  if (which < 0 || which > 11 || !dst_nchw) return fail(RTPOSE_E_INVAL, "net_read_output: bad argument");
+  const int stage = which / 2 + 1, br = which % 2;
+  const int C = br == 0 ? 38 : 19;
+  int buf, choff;
+  if (net->keep) {
+    buf = net->save_buf[stage - 1];
+    choff = br == 0 ? 0 : 38;
+  } else {
+    if (stage < 5) return fail(RTPOSE_E_STATE, "net_read_output: stage %d not kept (set keep_intermediates)", stage);
+    buf = (stage % 2 == 0) ? net->cat_buf[0] : net->cat_buf[1];
+    choff = br == 0 ? kCatPaf : kCatHeat;
+  }
+  const Buf& b = net->bufs[buf];
+  const rtpose_layout l = slice(b, choff);
+  return rtpose_layout_to_nchw(net->ws + b.off_floats, &l, dst_nchw, C, net->N, net->H3, net->W3, stream);
+}
+
+int rtpose_net_output_view(const rtpose_net* net, int which, const float** base, rtpose_layout* layout,
+                           int* C, int* H, int* W) {
+  if (!net || !net->bound || which < 0 || which > 1) return fail(RTPOSE_E_INVAL, "output_view: bad argument");
+  const Buf& b = net->bufs[net->cat_buf[0]];  // stage 6 writes CATa
+  if (base) *base = net->ws + b.off_floats;
+  if (layout) *layout = slice(b, which == 0 ? kCatPaf : kCatHeat);
+  if (C) *C = which == 0 ? 38 : 19;
+  if (H) *H = net->H3;
+  if (W) *W = net->W3;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+"""GPU parity of the fp32-MFMA conv kernel (csrc/conv_mfma.hip) against torch's
+CPU conv2d (the ATen arithmetic the reference's nn.Conv2d runs,
+lib/network/rtpose_vgg.py:23-35), called through the C ABI."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # relative to max|ref|; fp32 fma-chain vs ATen summation order
+
+
+def _run_conv(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, seed, groups=1, cin_pad=None):
+    lib, Layout = capi.lib, capi.Layout
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, h, w, generator=g)
+    cin_p = cin_pad or ((cin + 7) // 8 * 8)
+    ws, bs, refs = [], [], []
+    for gi in range(groups):
+        wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        y = F.conv2d(x, wt, b, padding=k // 2)
+        if relu:
+            y = F.relu(y)
+        if pool:
+            y = F.max_pool2d(y, 2, 2, 0)
+        ws.append(wt.to(dev))
+        bs.append(b.to(dev))
+        refs.append(y)
+    stream = capi.current_stream()
+    lin = Layout.padded(cin_p, h, w, pad_in)
+    xin = torch.zeros(lib.rtpose_layout_pixels(C.byref(lin), n, h, w) * cin_p, device=dev)
+    xd = x.to(dev)
+    capi.check(lib.rtpose_nchw_to_layout(capi.ptr(xd), capi.ptr(xin), C.byref(lin), cin, cin_p, n, h, w, stream))
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    cstride_out = cout * groups + 3  # odd stride + channel offsets: exercises slices
+    descs = (capi.ConvDesc * groups)()
+    outs, keep = [], []
+    lout_full = Layout.padded(cstride_out, ho, wo, pad_out)
+    obuf = torch.zeros(lib.rtpose_layout_pixels(C.byref(lout_full), n, ho, wo) * cstride_out, device=dev)
+    for gi in range(groups):
+        wp = torch.zeros(lib.rtpose_packed_weight_floats(cout, cin_p, k), device=dev)
+        bp = torch.zeros(lib.rtpose_packed_bias_floats(cout), device=dev)
+        capi.check(lib.rtpose_pack_conv_weights(capi.ptr(ws[gi]), capi.ptr(bs[gi]), cout, cin, k, None, cin_p,
+                                                capi.ptr(wp), capi.ptr(bp), stream))
+        keep += [wp, bp]
+        d = descs[gi]
+        d.inp, d.w_packed, d.bias_packed, d.out = xin.data_ptr(), wp.data_ptr(), bp.data_ptr(), obuf.data_ptr()
+        d.lin = lin
+        d.lout = Layout.padded(cstride_out, ho, wo, pad_out, choff=gi * cout + 1)
+        d.cin, d.cout, d.k, d.relu, d.pool = cin_p, cout, k, int(relu), int(pool)
+    capi.check(lib.rtpose_conv2d(descs, groups, n, h, w, stream), "rtpose_conv2d")
+    for gi in range(groups):
+        o = torch.empty(n, cout, ho, wo, device=dev)
+        lo = Layout.padded(cstride_out, ho, wo, pad_out, choff=gi * cout + 1)
+        capi.check(lib.rtpose_layout_to_nchw(capi.ptr(obuf), C.byref(lo), capi.ptr(o), cout, n, ho, wo, stream))
+        outs.append(o.cpu())
+    torch.cuda.synchronize()
+    # gaps of the output buffer must still be zero (only real pixels are written)
+    total = obuf.abs().sum().item()
+    inner = sum(o.abs().sum().item() for o in outs)
+    assert abs(total - inner) <= 1e-3 * max(1.0, inner), "conv wrote outside its slice / into the gaps"
+    return outs, refs
+
+
+CASES = [
+    # n, h, w, cin, cout, k, relu, pool, pad_in, pad_out
+    (2, 46, 46, 128, 128, 7, 1, 0, 3, 3),     # Mconv2_stageN: strip mode, exact 128-multiples
+    (1, 46, 49, 192, 128, 7, 1, 0, 3, 3),     # ski.jpg geometry (46x49), 185->192 packed input
+    (3, 23, 17, 128, 38, 1, 0, 0, 0, 3),      # 1x1 head into a padded concat slice, ragged M
+    (2, 46, 46, 512, 19, 1, 0, 0, 0, 0),      # conv5_5_CPM_L2
+    (2, 46, 46, 256, 512, 3, 1, 0, 1, 1),     # conv4_1: 8 N-tiles
+    (1, 46, 46, 128, 128, 3, 1, 0, 3, 1),     # stage-1 conv reading the P=3 concat layout
+    (1, 96, 80, 64, 64, 3, 1, 1, 1, 1),       # 2-D tile mode + fused pool
+    (2, 72, 88, 8, 64, 3, 1, 0, 1, 1),        # conv1_1 (3->8 padded input), ck=8, 2-D tiles
+    (1, 100, 92, 128, 256, 3, 1, 0, 1, 1),    # 2-D tiles with ragged right/bottom edges
+    (1, 70, 66, 128, 128, 7, 1, 0, 3, 0),     # 7x7 in 2-D tile mode (multi-scale maps)
+    (1, 12, 10, 16, 24, 3, 0, 0, 1, 0),       # tiny: one partial block, several images' worth of gap
+    (5, 6, 6, 16, 8, 7, 1, 0, 3, 3),          # strip spanning several images
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_matches_torch_cpu(capi, cuda, case):
+    n, h, w, cin, cout, k, relu, pool, pin, pout = case
+    src_cin = 3 if cin == 8 else (185 if cin == 192 else cin)
+    outs, refs = _run_conv(capi, cuda, n, h, w, src_cin, cout, k, relu, pool, pin, pout, seed=hash(case) % 1000,
+                           cin_pad=cin)
+    ref = refs[0]
+    err = (outs[0] - ref).abs().max().item()
+    assert err <= TOL * max(1.0, ref.abs().max().item()), "max abs err %g" % err
+
+
+def test_grouped_branches(capi, cuda):
+    outs, refs = _run_conv(capi, cuda, 2, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=7, groups=2)
+    for o, r in zip(outs, refs):
+        assert (o - r).abs().max().item() <= TOL * max(1.0, r.abs().max().item())
+
+
+def test_conv_rejects_bad_geometry(capi, cuda):
+    lib = capi.lib
+    d = (capi.ConvDesc * 1)()
+    d[0].k = 5
+    d[0].cin = 16
+    assert lib.rtpose_conv2d(d, 1, 1, 8, 8, None) != 0
+    assert "k must be" in capi.last_error()

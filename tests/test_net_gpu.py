@@ -1,0 +1,73 @@
+"""GPU parity of the whole rtpose_vgg forward (native executor, csrc/net.hip)
+against the oracle restatement (oracle/net_oracle.py) and the committed golden
+vectors produced by the reference module itself (tests/golden/net_small.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "net_small.npz")
+ABS_TOL = 1e-3  # BASELINE.json north_star: heatmaps/PAFs within 1e-3 fp32
+
+
+@pytest.fixture(scope="module")
+def model_and_sd(pkg, cuda):
+    from oracle import net_oracle
+    m = pkg.get_model('vgg19')
+    sd = net_oracle.he_init_state_dict(m, seed=0)
+    m.load_state_dict(sd)
+    m = m.cuda().float().eval()
+    return m, sd
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 64, 72), (1, 3, 56, 40)])
+def test_forward_matches_oracle(model_and_sd, cuda, shape):
+    from oracle import net_oracle
+    m, sd = model_and_sd
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(shape, generator=g) - 0.5
+    (paf_r, heat_r), saved_r = net_oracle.forward(sd, x)
+    with torch.no_grad():
+        (paf, heat), saved = m(x.to(cuda))
+    assert paf.shape == paf_r.shape and heat.shape == heat_r.shape
+    assert len(saved) == 12
+    for i, (a, b) in enumerate(zip(saved, saved_r)):
+        err = (a.cpu() - b).abs().max().item()
+        assert err <= ABS_TOL, "stage output %d: max abs err %g (ref max %g)" % (i, err, b.abs().max().item())
+    # much tighter than the contract in practice
+    assert (paf.cpu() - paf_r).abs().max().item() <= 2e-4 * max(1.0, paf_r.abs().max().item())
+
+
+def test_forward_matches_reference_golden(model_and_sd, cuda):
+    m, sd = model_and_sd
+    z = np.load(GOLD)
+    x = torch.from_numpy(z["x"])
+    with torch.no_grad():
+        (paf, heat), saved = m(x.to(cuda))
+    assert np.abs(paf.cpu().numpy() - z["paf"]).max() <= ABS_TOL
+    assert np.abs(heat.cpu().numpy() - z["heat"]).max() <= ABS_TOL
+    for i in range(12):
+        assert np.abs(saved[i].cpu().numpy() - z["saved%d" % i]).max() <= ABS_TOL
+
+
+def test_cpu_tensor_fails_loudly(model_and_sd, capi):
+    m, _ = model_and_sd
+    with pytest.raises(capi.RtposeError):
+        m(torch.zeros(1, 3, 64, 64))
+
+
+def test_state_dict_roundtrip_repacks(model_and_sd, cuda):
+    m, sd = model_and_sd
+    x = (torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(3)) - 0.5).to(cuda)
+    with torch.no_grad():
+        (p0, _), _ = m(x)
+        sd2 = {k: v * 0.5 for k, v in m.state_dict().items()}
+        m.load_state_dict(sd2)
+        (p1, _), _ = m(x)
+        m.load_state_dict(sd)
+        (p2, _), _ = m(x)
+    assert not torch.allclose(p0, p1)
+    assert torch.equal(p0, p2)
