@@ -1,0 +1,119 @@
+"""Synthetic multi-person heat-map / PAF scenes (input data for tests and bench).
+
+There are no trained weights and no COCO images in this environment, so the
+post-processing is exercised on rasterised stick figures.  The rasterisation
+follows the formulas of the reference's ground-truth generators —
+Gaussian blobs as in lib/datasets/heatmap.py:20-36 (sigma in input pixels,
+stride 8, clipped at exponent 4.6052, sum clipped to 1) and limb unit-vector
+fields as in lib/datasets/paf.py:18-68 (limb width 1 cell, overlaps averaged) —
+restated here in vectorised numpy, plus U(0, noise) noise to break float ties.
+"""
+import numpy as np
+
+# limb -> (partA, partB) and PAF channel pair: lib/pafprocess/pafprocess.h:16-24
+PAIRS = [(1, 2), (1, 5), (2, 3), (3, 4), (5, 6), (6, 7), (1, 8), (8, 9), (9, 10), (1, 11), (11, 12),
+         (12, 13), (1, 0), (0, 14), (14, 16), (0, 15), (15, 17), (2, 16), (5, 17)]
+PAIRS_NET = [(12, 13), (20, 21), (14, 15), (16, 17), (22, 23), (24, 25), (0, 1), (2, 3), (4, 5), (6, 7),
+             (8, 9), (10, 11), (28, 29), (30, 31), (34, 35), (32, 33), (36, 37), (18, 19), (26, 27)]
+
+# a standing figure in unit coordinates (x right, y down), part ids of lib/utils/common.py:5-24
+_TEMPLATE = np.array([
+    [0.00, -0.80],   # 0 nose
+    [0.00, -0.60],   # 1 neck
+    [-0.18, -0.58],  # 2 r shoulder
+    [-0.26, -0.32],  # 3 r elbow
+    [-0.28, -0.08],  # 4 r wrist
+    [0.18, -0.58],   # 5 l shoulder
+    [0.26, -0.32],   # 6 l elbow
+    [0.28, -0.08],   # 7 l wrist
+    [-0.11, -0.05],  # 8 r hip
+    [-0.12, 0.35],   # 9 r knee
+    [-0.12, 0.75],   # 10 r ankle
+    [0.11, -0.05],   # 11 l hip
+    [0.12, 0.35],    # 12 l knee
+    [0.12, 0.75],    # 13 l ankle
+    [-0.04, -0.84],  # 14 r eye
+    [0.04, -0.84],   # 15 l eye
+    [-0.09, -0.80],  # 16 r ear
+    [0.09, -0.80],   # 17 l ear
+])
+
+
+def random_people(rng, n_people, height, width, drop_prob=0.1):
+    """Returns a list of (18,2) float arrays (input-pixel coords, NaN = joint absent)."""
+    people = []
+    for _ in range(n_people):
+        scale = rng.uniform(0.28, 0.5) * height
+        cx = rng.uniform(0.15, 0.85) * width
+        cy = rng.uniform(0.45, 0.6) * height
+        ang = rng.uniform(-0.25, 0.25)
+        rot = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+        pts = (_TEMPLATE + rng.normal(0, 0.015, _TEMPLATE.shape)) @ rot.T * scale + [cx, cy]
+        pts = pts.astype(np.float64)
+        drop = rng.uniform(size=18) < drop_prob
+        outside = (pts[:, 0] < 2) | (pts[:, 0] > width - 3) | (pts[:, 1] < 2) | (pts[:, 1] > height - 3)
+        pts[drop | outside] = np.nan
+        people.append(pts)
+    return people
+
+
+def render(people, height, width, stride=8, sigma=7.0, noise=0.02, rng=None):
+    """-> heat [h,w,19] float32, paf [h,w,38] float32 (HWC, like get_outputs returns)."""
+    h, w = height // stride, width // stride
+    start = stride / 2.0 - 0.5
+    ys, xs = np.mgrid[0:h, 0:w]
+    gx, gy = xs * stride + start, ys * stride + start
+    heat = np.zeros((h, w, 19), np.float64)
+    for pts in people:
+        for j in range(18):
+            if np.isnan(pts[j, 0]):
+                continue
+            e = ((gx - pts[j, 0]) ** 2 + (gy - pts[j, 1]) ** 2) / 2.0 / sigma / sigma
+            heat[:, :, j] += np.where(e <= 4.6052, np.exp(-e), 0.0)
+    heat = np.minimum(heat, 1.0)
+    heat[:, :, 18] = np.maximum(1.0 - heat[:, :, :18].max(axis=2), 0.0)
+    paf = np.zeros((h, w, 38), np.float64)
+    for (a, b), (cx_, cy_) in zip(PAIRS, PAIRS_NET):
+        acc = np.zeros((h, w, 2))
+        cnt = np.zeros((h, w))
+        for pts in people:
+            if np.isnan(pts[a, 0]) or np.isnan(pts[b, 0]):
+                continue
+            ca, cb = pts[a] / stride, pts[b] / stride
+            v = cb - ca
+            nrm = np.linalg.norm(v)
+            if nrm == 0:
+                continue
+            u = v / nrm
+            x0 = max(int(round(min(ca[0], cb[0]) - 1)), 0)
+            x1 = min(int(round(max(ca[0], cb[0]) + 1)), w)
+            y0 = max(int(round(min(ca[1], cb[1]) - 1)), 0)
+            y1 = min(int(round(max(ca[1], cb[1]) + 1)), h)
+            if x1 <= x0 or y1 <= y0:
+                continue
+            yy, xx = np.mgrid[y0:y1, x0:x1]
+            m = np.abs((xx - ca[0]) * u[1] - (yy - ca[1]) * u[0]) < 1
+            acc[y0:y1, x0:x1, 0] += m * u[0]
+            acc[y0:y1, x0:x1, 1] += m * u[1]
+            cnt[y0:y1, x0:x1] += m
+        cnt = np.maximum(cnt, 1)
+        paf[:, :, cx_] = acc[:, :, 0] / cnt
+        paf[:, :, cy_] = acc[:, :, 1] / cnt
+    if noise > 0:
+        rng = rng or np.random.default_rng(0)
+        heat += rng.uniform(0, noise, heat.shape)
+        paf += rng.uniform(-noise, noise, paf.shape)
+    return heat.astype(np.float32), paf.astype(np.float32)
+
+
+def make_batch(n_images, height=368, width=368, seed=1, max_people=8, noise=0.02):
+    """Seeded batch: heat [N,h,w,19], paf [N,h,w,38] float32 + the people lists."""
+    rng = np.random.default_rng(seed)
+    heats, pafs, gt = [], [], []
+    for _ in range(n_images):
+        people = random_people(rng, int(rng.integers(1, max_people + 1)), height, width)
+        hm, pf = render(people, height, width, noise=noise, rng=rng)
+        heats.append(hm)
+        pafs.append(pf)
+        gt.append(people)
+    return np.stack(heats), np.stack(pafs), gt

@@ -1,0 +1,193 @@
+"""GPU parity of the batched decoder (csrc/decode.hip) and the legacy
+pafprocess API (csrc/legacy_pafprocess.hip) against the oracle restatement and
+the golden vectors produced by the reference's own compiled C++."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG_NAME
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "post_scenes.npz")
+
+
+@pytest.fixture(scope="module")
+def dec(pkg):
+    return importlib.import_module(PKG_NAME + ".decode")
+
+
+@pytest.fixture(scope="module")
+def synth(pkg):
+    return importlib.import_module(PKG_NAME + ".synth")
+
+
+def _check_against(rec, jl, parts, score):
+    pk = rec["peaks"]
+    assert pk.shape == jl.shape, (pk.shape, jl.shape)
+    # integer content bit-exact; float scores bit-exact too (same operation order)
+    assert np.array_equal(pk[:, [0, 1, 3, 4]], jl[:, [0, 1, 3, 4]])
+    assert np.array_equal(pk[:, 2].view(np.uint32), jl[:, 2].view(np.uint32)), \
+        "peak scores differ by up to %g" % np.abs(pk[:, 2] - jl[:, 2]).max()
+    assert np.array_equal(rec["parts"], parts)
+    assert np.array_equal(rec["score"].view(np.uint32), score.view(np.uint32)), \
+        "human scores differ by up to %g" % np.abs(rec["score"] - score).max()
+
+
+def test_golden_scenes_one_by_one(dec, cuda):
+    z = np.load(GOLD)
+    for i in range(int(z["n"])):
+        heat = torch.from_numpy(z["heat%d" % i]).to(cuda)[None]
+        paf = torch.from_numpy(z["paf%d" % i]).to(cuda)[None]
+        rec = dec.decode_maps(heat, paf)[0]
+        _check_against(rec, z["jl%d" % i], z["parts%d" % i], z["score%d" % i])
+
+
+def test_batch_vs_oracle(dec, synth, cuda):
+    from oracle import post_oracle as po
+    heat, paf, _ = synth.make_batch(32, seed=5)
+    recs = dec.decode_maps(torch.from_numpy(heat).to(cuda), torch.from_numpy(paf).to(cuda))
+    nh = 0
+    for i in range(32):
+        jl, r = po.paf_to_pose(heat[i], paf[i])
+        _check_against(recs[i], jl, r["parts"], r["score"])
+        nh += len(r["parts"])
+    assert nh > 60  # the scenes really contain people
+
+
+def test_crowded_scene_grows_capacity(dec, synth, cuda):
+    from oracle import post_oracle as po
+    rng = np.random.default_rng(3)
+    people = synth.random_people(rng, 40, 368, 368, drop_prob=0.0)
+    heat, paf = synth.render(people, 368, 368, rng=rng)
+    jl, r = po.paf_to_pose(heat, paf)
+    assert max(np.bincount(jl[:, 4].astype(int))) > 16
+    rec = dec.decode_maps(torch.from_numpy(heat).to(cuda)[None], torch.from_numpy(paf).to(cuda)[None],
+                          max_peaks_per_part=8, max_humans=4)[0]
+    _check_against(rec, jl, r["parts"], r["score"])
+
+
+def test_edge_cases(dec, cuda):
+    from oracle import post_oracle as po
+    # empty maps -> no peaks, no humans
+    heat = torch.zeros(2, 20, 24, 19, device=cuda)
+    paf = torch.zeros(2, 20, 24, 38, device=cuda)
+    for rec in dec.decode_maps(heat, paf):
+        assert rec["peaks"].shape == (0, 5) and rec["parts"].shape == (0, 18)
+    # plateaus, border and corner peaks, value exactly at the threshold
+    h = np.zeros((12, 14, 19), np.float32)
+    h[0, 0, 0] = 0.9
+    h[11, 13, 0] = 0.8
+    h[5, 5, 1] = h[5, 6, 1] = 0.7          # two-pixel plateau: both are peaks
+    h[3, 0, 2] = 0.6
+    h[7, 7, 3] = np.float32(0.1)            # == threshold: rejected
+    h[8, 2, 4] = 0.5
+    h[9, 3, 4] = 0.6                        # diagonal neighbour does not suppress
+    rec = dec.decode_maps(torch.from_numpy(h).to(cuda)[None], torch.zeros(1, 12, 14, 38, device=cuda))[0]
+    jl = po.nms(h)
+    assert len(jl) == 7
+    _check_against(rec, jl, np.zeros((0, 18), np.int32), np.zeros(0, np.float32))
+    # random noise maps (many junk peaks) with a non-square, non-multiple-of-anything size
+    rng = np.random.default_rng(0)
+    hn = rng.uniform(0, 0.3, (2, 13, 29, 19)).astype(np.float32)
+    pn = rng.uniform(-1, 1, (2, 13, 29, 38)).astype(np.float32)
+    recs = dec.decode_maps(torch.from_numpy(hn).to(cuda), torch.from_numpy(pn).to(cuda))
+    for i in range(2):
+        jl, r = po.paf_to_pose(hn[i], pn[i])
+        _check_against(recs[i], jl, r["parts"], r["score"])
+
+
+def test_strided_view_of_padded_buffer(dec, capi, synth, cuda):
+    """The decoder reads the maps where the last conv wrote them: a channel slice
+    of a wider shared-gap padded buffer."""
+    import ctypes as C
+    from oracle import post_oracle as po
+    heat, paf, _ = synth.make_batch(3, height=184, width=200, seed=9)
+    n, h, w, _ = heat.shape
+    lay = capi.Layout.padded(192, h, w, 3)
+    buf = torch.zeros(capi.lib.rtpose_layout_pixels(C.byref(lay), n, h, w) * 192, device=cuda)
+    lpaf = capi.Layout.padded(192, h, w, 3, choff=128)
+    lheat = capi.Layout.padded(192, h, w, 3, choff=166)
+    lib = capi.lib
+    s = capi.current_stream()
+    hp = torch.from_numpy(heat).to(cuda).permute(0, 3, 1, 2).contiguous()
+    pp = torch.from_numpy(paf).to(cuda).permute(0, 3, 1, 2).contiguous()
+    capi.check(lib.rtpose_nchw_to_layout(capi.ptr(hp), capi.ptr(buf), C.byref(lheat), 19, 19, n, h, w, s))
+    capi.check(lib.rtpose_nchw_to_layout(capi.ptr(pp), capi.ptr(buf), C.byref(lpaf), 38, 38, n, h, w, s))
+    cfg = dec.make_cfg()
+    bufs = dec.DecodeBuffers(cfg, n, cuda)
+    dec.decode_enqueue(capi.ptr(buf), lheat, capi.ptr(buf), lpaf, n, h, w, bufs)
+    recs = dec.fetch(bufs)
+    for i in range(n):
+        jl, r = po.paf_to_pose(heat[i], paf[i])
+        _check_against(dec.parse_image(recs[i], cfg), jl, r["parts"], r["score"])
+
+
+def test_legacy_pafprocess_api(pkg, cuda):
+    """Same seven names as the SWIG module; checked against the compiled reference's outputs."""
+    from oracle import post_oracle as po
+    pafprocess = importlib.import_module(PKG_NAME + ".pafprocess")
+    z = np.load(GOLD)
+    for i in range(int(z["n"])):
+        jl = z["jl%d" % i]
+        heat_up = po.upsample_nearest(z["heat%d" % i], 8)
+        paf_up = po.upsample_nearest(z["paf%d" % i], 8)
+        assert pafprocess.process_paf(jl[None], heat_up, paf_up) == 0
+        parts, score = z["parts%d" % i], z["score%d" % i]
+        assert pafprocess.get_num_humans() == len(parts)
+        for hid in range(len(parts)):
+            for p in range(18):
+                assert pafprocess.get_part_cid(hid, p) == parts[hid, p]
+            assert np.float32(pafprocess.get_score(hid)) == score[hid]
+        line = z["line%d" % i]
+        for cid in range(len(jl)):
+            assert (pafprocess.get_part_x(cid), pafprocess.get_part_y(cid)) == tuple(line[cid])
+            assert np.float32(pafprocess.get_part_score(cid)) == jl[cid, 2]
+    # bounds-checked getters instead of the reference's undefined behaviour
+    assert pafprocess.get_part_cid(10 ** 6, 0) == -1 and pafprocess.get_part_x(-5) == -1
+
+
+def test_paf_to_pose_cpp_dropin(pkg, dec, cuda):
+    from oracle import post_oracle as po
+    z = np.load(GOLD)
+    cfg = dec.default_config()
+    heat, paf = z["heat3"], z["paf3"]
+    humans = dec.paf_to_pose_cpp(heat, paf, cfg)
+    parts, score, jl = z["parts3"], z["score3"], z["jl3"]
+    assert len(humans) == len(parts)
+    for hid, hm in enumerate(humans):
+        assert sorted(hm.body_parts) == [p for p in range(18) if parts[hid, p] >= 0]
+        assert np.float32(hm.score) == score[hid]
+        for p, bp in hm.body_parts.items():
+            cid = parts[hid, p]
+            assert bp.x == float(int(jl[cid, 0])) / (heat.shape[1] * 8)
+            assert bp.y == float(int(jl[cid, 1])) / (heat.shape[0] * 8)
+            assert bp.uidx == '%d-%d' % (hid, p)
+
+
+def test_flip_merge(capi, cuda):
+    """handle_paf_and_heat (evaluate/coco_eval.py:197-242) restated in numpy vs the kernel."""
+    rng = np.random.default_rng(1)
+    n, h, w = 2, 9, 11
+    heat, heat_f = [rng.normal(size=(n, h, w, 19)).astype(np.float32) for _ in range(2)]
+    paf, paf_f = [rng.normal(size=(n, h, w, 38)).astype(np.float32) for _ in range(2)]
+    swap_heat = np.array((0, 1, 5, 6, 7, 2, 3, 4, 11, 12, 13, 8, 9, 10, 15, 14, 17, 16, 18))
+    swap_paf = np.array((6, 7, 8, 9, 10, 11, 0, 1, 2, 3, 4, 5, 20, 21, 22, 23, 24, 25, 26, 27, 12, 13, 14, 15,
+                         16, 17, 18, 19, 28, 29, 32, 33, 30, 31, 36, 37, 34, 35))
+    exp_h, exp_p = [], []
+    for i in range(n):
+        fp = paf_f[i][:, ::-1, :].copy()
+        fp[:, :, swap_paf[1::2]] = fp[:, :, swap_paf[1::2]]
+        fp[:, :, swap_paf[::2]] = -fp[:, :, swap_paf[::2]]
+        exp_p.append((paf[i] + fp[:, :, swap_paf]) / 2.)
+        exp_h.append((heat[i] + heat_f[i][:, ::-1, :][:, :, swap_heat]) / 2.)
+    t = [torch.from_numpy(a).to(cuda) for a in (heat, heat_f, paf, paf_f)]
+    oh = torch.empty_like(t[0])
+    op = torch.empty_like(t[2])
+    capi.check(capi.lib.rtpose_flip_merge(capi.ptr(t[0]), capi.ptr(t[1]), capi.ptr(t[2]), capi.ptr(t[3]), n, h, w,
+                                          capi.ptr(oh), capi.ptr(op), capi.current_stream()))
+    assert np.array_equal(oh.cpu().numpy(), np.stack(exp_h).astype(np.float32))
+    assert np.array_equal(op.cpu().numpy(), np.stack(exp_p).astype(np.float32))
