@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py — end-to-end persons-posed FPS at 368x368 (net + pafprocess), the
+metric BASELINE.json names, on the configuration it is quoted on:
+
+    rtpose VGG19 368x368 batch=32 synthetic images, single MI355X, fp32
+
+One "step" = one pass of the whole hot path over one batch that is already
+resident in HBM:  rtpose_vgg forward (92 convs, fp32 MFMA)  ->  scene blend (see
+below)  ->  NMS + bicubic refine  ->  PAF scoring + greedy assignment  ->
+person grouping  ->  [N>1: RCCL all_gather of the result records]  ->  D2H of the
+compact records + stream sync.  Nothing is cached between steps.
+
+Data: synthetic.  Weights: seeded He-init of the reference architecture (no
+checkpoint exists offline).  Because random weights produce no meaningful peaks,
+the maps the decoder consumes are  scene + 1e-3 * net_output  where `scene` is a
+rasterised multi-person stick-figure batch resident in HBM (pkg.synth, 1-8 people
+per image); the blend is an extra elementwise kernel INSIDE the timed region, so
+no work is skipped and the decoder still depends on what the network wrote.
+
+Launch:  python bench.py --gpus 1 --steps K --warmup W
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+                --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+One process per GPU, weak scaling (32 images per GPU), one RCCL all_gather of the
+result records per step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "pytorch_realtime_multi-person_pose_estimation_amd"
+
+BATCH = 32
+SIZE = 368
+GFLOP_PER_IMAGE = 271.868          # 2 x 135.934 GMAC over the 92 convs
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(sample_scenes):
+    """The oracle restatement (torch-CPU fp32 functional net = the ATen ops the reference
+    module runs, + the plain-C post) timed on the host cores of this box: bounded sample."""
+    from oracle import net_oracle, post_oracle
+    pkg = importlib.import_module(PKG)
+    # host threads: os.cpu_count() can exceed what this process may use (cgroup quota /
+    # affinity), and oversubscribing torch's pool is catastrophic, so probe a few pool
+    # sizes on a quarter-size input and keep the fastest
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    m = pkg.get_model('vgg19')
+    sd = net_oracle.he_init_state_dict(m, seed=0)
+    g = torch.Generator().manual_seed(0)
+    probe = torch.rand(1, 3, 184, 184, generator=g) - 0.5
+    best = None
+    for t in sorted({avail, 64, 32, 16, 8}, reverse=True):
+        if t > avail:
+            continue
+        torch.set_num_threads(t)
+        net_oracle.forward(sd, torch.rand(1, 3, 64, 64, generator=g) - 0.5)   # warm the pool
+        t0 = time.perf_counter()
+        net_oracle.forward(sd, probe)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, t)
+        if dt > 20.0:
+            continue
+    cores = best[1]
+    torch.set_num_threads(cores)
+    t_net, n_net = 0.0, 0
+    while n_net < 8 and t_net < 12.0:
+        x = torch.rand(1, 3, SIZE, SIZE, generator=g) - 0.5               # bs=1 like coco_eval.py:105
+        t0 = time.perf_counter()
+        net_oracle.forward(sd, x)
+        t_net += time.perf_counter() - t0
+        n_net += 1
+    heat, paf = sample_scenes
+    t0 = time.perf_counter()
+    for i in range(heat.shape[0]):
+        post_oracle.paf_to_pose(heat[i], paf[i])
+    t_post = (time.perf_counter() - t0) / heat.shape[0]
+    per_img = t_net / n_net + t_post
+    return {"value": round(1.0 / per_img, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d images 368x368 bs=1 through the torch-CPU fp32 oracle net (%.3f s/img, %d threads) + "
+                      "%d synthetic scenes through the C oracle NMS+process_paf (%.2f ms/img, 1 thread)"
+                      % (n_net, t_net / n_net, cores, heat.shape[0], t_post * 1e3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    pkg = importlib.import_module(PKG)
+    par = importlib.import_module(PKG + ".parallel")
+    synth = importlib.import_module(PKG + ".synth")
+    dec = importlib.import_module(PKG + ".decode")
+    pipeline = importlib.import_module(PKG + ".pipeline")
+    lib = pkg._capi.lib
+
+    rank, local_rank, world = par.init_from_env("nccl")
+    if world != args.gpus:
+        log("warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path for the product)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from oracle import net_oracle  # weight initialiser only (seeded He init shared with the tests)
+    model = pkg.get_model('vgg19')
+    model.load_state_dict(net_oracle.he_init_state_dict(model, seed=0))
+    model = model.cuda().float().eval()
+    est = pipeline.PoseEstimator(model)
+
+    g = torch.Generator().manual_seed(rank)
+    x = (torch.rand(BATCH, 3, SIZE, SIZE, generator=g) - 0.5).to(dev)
+    heat_np, paf_np, _ = synth.make_batch(BATCH, SIZE, SIZE, seed=100 + rank)
+    scene = (torch.from_numpy(heat_np).to(dev), torch.from_numpy(paf_np).to(dev))
+
+    def step():
+        bufs = est.enqueue(x, scene)
+        n_local, words = bufs.n, bufs.words
+        if world > 1:
+            allrec = par.gather_records(bufs.result.view(n_local, words), world)
+            host = allrec.cpu()                      # D2H + sync
+        else:
+            host = dec.fetch(bufs)                   # pinned D2H + stream sync
+        return bufs, host
+
+    # capacity check + warm-up (untimed)
+    recs0 = est(x, scene)
+    humans_per_batch = sum(r["parts"].shape[0] for r in recs0)
+    peaks_per_batch = sum(r["n_peaks"] for r in recs0)
+    for _ in range(max(args.warmup, 1) - 1):
+        step()
+
+    plan = model.plan_for(x)
+    lib.rtpose_net_set_profiling(plan.handle, 1)
+    nl = lib.rtpose_net_num_launches(plan.handle)
+    k7_ms, k7_flops, k7_n, net_ms = 0.0, 0.0, 0, 0.0
+
+    torch.cuda.synchronize()
+    par.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bufs, host = step()
+        # per-launch HIP events of this step's forward (recorded on the launch stream)
+        ms, k, fl = C.c_float(), C.c_int(), C.c_double()
+        for i in range(nl):
+            lib.rtpose_net_launch_info(plan.handle, i, C.byref(ms), C.byref(k), C.byref(fl), None, 0)
+            if ms.value > 0:
+                net_ms += ms.value
+                if k.value == 7:
+                    k7_ms += ms.value
+                    k7_flops += fl.value
+                    k7_n += 1
+    torch.cuda.synchronize()
+    par.barrier(dev)
+    elapsed = time.perf_counter() - t0
+    elapsed = par.max_over_ranks(elapsed, dev)
+    lib.rtpose_net_set_profiling(plan.handle, 0)
+
+    flags = int(np.bitwise_or.reduce(np.asarray(host).reshape(-1, bufs.words)[:, dec.RES_HEADER + 2]))
+    if flags:
+        raise SystemExit("decode tables overflowed inside the timed region (flags=%d)" % flags)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        fps = BATCH * world * args.steps / elapsed
+        achieved = k7_flops / (k7_ms * 1e-3) / 1e12 if k7_ms > 0 else 0.0
+        out = {
+            "metric": "end-to-end persons-posed FPS at 368x368 (net+pafprocess)",
+            "value": round(fps, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": "rtpose VGG19 368x368 batch=32 synthetic images, single MI355X, fp32 "
+                                   "(BASELINE.json configs[1]); per-GPU batch 32, one process per GPU",
+                       "global_batch": BATCH * world, "image": [SIZE, SIZE],
+                       "weights": "seeded He init (no checkpoint offline)",
+                       "decoder_input": "synthetic scene + 1e-3 * net output (blend kernel timed)",
+                       "humans_per_batch": humans_per_batch, "peaks_per_batch": peaks_per_batch,
+                       "parallelism": "image-sharded, all_gather of result records only" if world > 1 else "single GPU"},
+            "net_tflops_end_to_end": round(fps / world * GFLOP_PER_IMAGE / 1e3, 2),
+            "net_ms_per_step_events": round(net_ms / args.steps, 3),
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_f32<7,16,0> (7x7 stage convs, 68% of the FLOPs)",
+                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_timed": k7_n,
+                         "flops_per_launch": round(k7_flops / max(k7_n, 1)),
+                         "avg_launch_ms": round(k7_ms / max(k7_n, 1), 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline((heat_np, paf_np))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,6 +134,15 @@ int rtpose_layout_copy(const float* src, const rtpose_layout* lsrc, float* dst,
                        const rtpose_layout* ldst, int C, int N, int H, int W,
                        void* stream);
 
+/* dst(n,y,x,c) = alpha * dst(n,y,x,c) + beta * src[n][y][x][c] over a layout
+ * slice (src dense NHWC).  Not on the reference's path: bench.py and the tests
+ * use it to superimpose rasterised synthetic scenes on the outputs of the
+ * randomly initialised network (no trained weights exist offline), so that the
+ * decoder sees realistic peak counts while still consuming what the net wrote. */
+int rtpose_layout_axpby(float* dst, const rtpose_layout* ldst, const float* src_nhwc,
+                        int C, int N, int H, int W, float alpha, float beta,
+                        void* stream);
+
 /* ------------------------------------------------------------------------
  * 3. The rtpose_vgg network (lib/network/rtpose_vgg.py:60-225)
  *

@@ -72,6 +72,7 @@ _SIGS = {
     "rtpose_nchw_to_layout": (_i, [_vp, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
     "rtpose_layout_to_nchw": (_i, [_vp, _LP, _vp, _i, _i, _i, _i, _vp]),
     "rtpose_layout_copy": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, _i, _vp]),
+    "rtpose_layout_axpby": (_i, [_vp, _LP, _vp, _i, _i, _i, _i, C.c_float, C.c_float, _vp]),
     "rtpose_net_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
     "rtpose_net_destroy": (None, [_vp]),
     "rtpose_net_workspace_bytes": (_sz, [_vp]),

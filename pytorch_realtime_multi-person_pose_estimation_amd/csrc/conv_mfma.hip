@@ -530,7 +530,7 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
 
 int pack_weights_launch(const float* w, const float* bias, int cout, int cin_src, int k,
                         const int32_t* cin_map, int cin_packed, float* wp, float* bp, hipStream_t s) {
-  if (cin_packed % 8 || cin_packed < cin_src && !cin_map)
+  if (cin_packed % 8 || (cin_packed < cin_src && !cin_map))
     return fail(RTPOSE_E_INVAL, "pack: cin_packed must be a multiple of 8 and >= cin_src");
   if (k != 1 && k != 3 && k != 7) return fail(RTPOSE_E_INVAL, "pack: k must be 1, 3 or 7");
   const int coutp = cout_pad(cout);

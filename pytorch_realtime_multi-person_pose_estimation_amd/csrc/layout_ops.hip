@@ -156,6 +156,22 @@ __global__ void flip_merge_kernel(const float* __restrict__ heat, const float* _
   }
 }
 
+// dst(n,y,x,c) = alpha * dst(n,y,x,c) + beta * src_dense[n][y][x][c]
+__global__ void layout_axpby_kernel(float* __restrict__ dst, Lay ld, const float* __restrict__ src, int C,
+                                    int N, int H, int W, float alpha, float beta) {
+  const size_t total = (size_t)N * H * W * C;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = i % C;
+  size_t p = i / C;
+  const int x = p % W;
+  p /= W;
+  const int y = p % H;
+  const int n = p / H;
+  float* d = dst + lay_off(ld, n, y, x) + c;
+  *d = alpha * *d + beta * src[i];
+}
+
 static inline unsigned nblocks(size_t total, int threads) {
   return (unsigned)((total + threads - 1) / threads);
 }
@@ -225,6 +241,16 @@ int rtpose_maxpool2x2(const float* in, const rtpose_layout* lin, float* out, con
   if (!total) return 0;
   hipLaunchKernelGGL(maxpool2x2_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), in,
                      to_lay(lin), out, to_lay(lout), C, N, Ho, Wo);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_layout_axpby(float* dst, const rtpose_layout* ldst, const float* src_nhwc, int C, int N, int H,
+                        int W, float alpha, float beta, void* stream) {
+  const size_t total = (size_t)N * H * W * C;
+  if (!total) return 0;
+  hipLaunchKernelGGL(layout_axpby_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), dst,
+                     to_lay(ldst), src_nhwc, C, N, H, W, alpha, beta);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -1,0 +1,70 @@
+"""Multi-GPU layer: one process per GPU, images sharded, ONE collective.
+
+Images are independent once the reference's process-global decoder state
+(lib/pafprocess/pafprocess.cpp:12-13) is gone, so the path shards with no
+data-path collective: rank r owns the contiguous image range
+[r*N/G, (r+1)*N/G).  The only exchange is the gather of the fixed-capacity
+result records (a few KB per image) — ``torch.distributed`` all_gather, which is
+RCCL over xGMI on the GPU box (backend "nccl") and gloo in the CPU tests.  The
+reference's own multi-GPU mechanism (nn.DataParallel, demo/picture_demo.py:47)
+is not reused.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment (1 process = 1 GPU)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_from_env(backend=None):
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous, balanced [lo, hi) of rank's items (first n_items % world ranks get one more)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_records(local, world=None, group=None):
+    """all_gather of equally shaped int32 record blocks [n_local, words] -> [world*n_local, words]
+    in rank order on every rank (one fused collective per batch, never per image)."""
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    return out
+
+
+def max_over_ranks(value, device):
+    """max of a python float over ranks (bench timing contract)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier(device=None):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if device is not None and device.type == "cuda":
+            dist.barrier(device_ids=[device.index])
+        else:
+            dist.barrier()

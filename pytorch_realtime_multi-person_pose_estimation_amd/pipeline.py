@@ -1,0 +1,82 @@
+"""Batched end-to-end path: device image batch -> rtpose_vgg forward -> pose
+decode -> compact per-image records on the host.
+
+This is what the reference does one image at a time in
+evaluate/coco_eval.py:270-272 / demo/picture_demo.py:57-61
+(get_outputs -> paf_to_pose_cpp), restructured for the GPU: the heat-maps and
+PAFs never leave HBM (the decoder reads them in place, in the layout the last
+conv wrote), and only the fixed-capacity result records cross PCIe.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi, decode as dec
+from ._capi import lib, check, ptr, current_stream
+
+
+class PoseEstimator(object):
+    def __init__(self, model, config=None, max_peaks_per_part=32, max_humans=64):
+        self.model = model
+        self.config = config or dec.default_config()
+        self.max_peaks_per_part = max_peaks_per_part
+        self.max_humans = max_humans
+        self._bufs = {}
+
+    def _buffers(self, n, device):
+        key = (n, device.index, self.max_peaks_per_part, self.max_humans)
+        b = self._bufs.get(key)
+        if b is None:
+            cfg = dec.make_cfg(self.config, self.max_peaks_per_part, self.max_humans)
+            b = dec.DecodeBuffers(cfg, n, device)
+            self._bufs = {key: b}
+        return b
+
+    def enqueue(self, x, scene=None, scene_alpha=1e-3):
+        """Enqueue forward + decode for a device batch x [N,3,H,W]; returns the buffers.
+
+        scene = (heat [N,h,w,19], paf [N,h,w,38]) device tensors: if given, the maps the
+        decoder sees are  scene + scene_alpha * net_output  (bench / tests only: there
+        are no trained weights offline, so realistic peaks are superimposed on what
+        the randomly initialised network wrote; see include/rtpose_mi355x.h)."""
+        m = self.model
+        plan = m.forward_native(x, keep_intermediates=False)
+        n = x.shape[0]
+        pbase, lpaf, _, h, w = m.output_view(plan, 0)
+        hbase, lheat, _, _, _ = m.output_view(plan, 1)
+        if scene is not None:
+            sh, sp = scene
+            s = current_stream()
+            check(lib.rtpose_layout_axpby(hbase, C.byref(lheat), ptr(sh), 19, n, h, w, scene_alpha, 1.0, s))
+            check(lib.rtpose_layout_axpby(pbase, C.byref(lpaf), ptr(sp), 38, n, h, w, scene_alpha, 1.0, s))
+        bufs = self._buffers(n, x.device)
+        dec.decode_enqueue(hbase, lheat, pbase, lpaf, n, h, w, bufs)
+        bufs.map_hw = (h, w)
+        return bufs
+
+    def __call__(self, x, scene=None, scene_alpha=1e-3):
+        """-> list of per-image dicts (decode.parse_image); grows table capacity on overflow."""
+        while True:
+            bufs = self.enqueue(x, scene, scene_alpha)
+            recs = dec.fetch(bufs)
+            flags = int(np.bitwise_or.reduce(recs[:, dec.RES_HEADER + 2]))
+            if flags & dec.OVERFLOW_PEAKS and self.max_peaks_per_part < dec.MAX_PEAKS_LIMIT:
+                self.max_peaks_per_part = min(2 * self.max_peaks_per_part, dec.MAX_PEAKS_LIMIT)
+                continue
+            if flags & dec.OVERFLOW_HUMANS and self.max_humans < 360:
+                self.max_humans = min(2 * self.max_humans, 360)
+                continue
+            if flags:
+                raise _capi.RtposeError("decode tables overflowed at maximum capacity (flags=%d)" % flags)
+            return [dec.parse_image(recs[i], bufs.cfg) for i in range(x.shape[0])]
+
+    def humans(self, x, **kw):
+        """-> list (per image) of list[Human], coordinates normalised like paf_to_pose_cpp."""
+        out = []
+        up = int(self.config.MODEL.DOWNSAMPLE)
+        recs = self(x, **kw)
+        h, w = x.shape[2] // 8, x.shape[3] // 8
+        for r in recs:
+            out.append(dec.humans_from_record(r, w * up, h * up, int(self.config.MODEL.NUM_KEYPOINTS)))
+        return out
