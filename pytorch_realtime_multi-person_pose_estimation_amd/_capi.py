@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librtpose_mi355x.so")
+# RTPOSE_LIB_PATH: developer override to A/B experimental builds of the same library
+LIB_PATH = os.environ.get("RTPOSE_LIB_PATH") or os.path.join(_HERE, "lib", "librtpose_mi355x.so")
 
 NUM_PART = 18
 NUM_LIMB = 19

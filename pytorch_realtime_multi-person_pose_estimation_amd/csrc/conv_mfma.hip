@@ -74,7 +74,6 @@ __device__ __forceinline__ void tile_local_yx(int ml, int tw_log2, int& ty, int&
 template <int KS, int CK, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
   constexpr int P = KS / 2;
-  constexpr int T = KS * KS;
   constexpr int CG = CK / 4;  // 16-byte channel groups per chunk
   constexpr int G = CK / 8;   // 8-deep k groups per chunk (4 MFMAs each)
   constexpr int PPT = PiecesPerTap<KS>::value;
@@ -142,40 +141,52 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
   }
 
   // ---- halo staging helpers -------------------------------------------------
+  // A halo is staged as 16-byte pieces: piece idx = (pixel idx/CG, channel group idx%CG);
+  // thread `tid` owns pieces tid, tid+256, ... ("sets").  LDS image: [group][pixel][4].
+  const int in_cstride = g.in_cstride, in_ws = g.in_ws;
   const float* in_base = g.in + g.in_choff;
-  auto piece_src = [&](int idx, int chunk) -> const float4* {
-    const int pix = idx / CG, j = idx - pix * CG;
+  constexpr int PIXSET = 256 / CG;            // halo pixels covered by one piece set
+  const int pj = tid % CG, ppix0 = tid / CG;  // this thread's group and first pixel
+  const unsigned hw_inv = MODE == 1 ? (65536u + A.hw_lds - 1) / A.hw_lds : 0u;
+  // global float offset (from the chunk's first channel) and LDS float offset of piece
+  // (set, tid).  MODE 0 may run past the halo (never past the buffer: layout slack);
+  // the caller masks the LDS side.
+  auto piece_goff = [&](int set) -> size_t {
+    int pix = set * PIXSET + ppix0;
     int q;
     if (MODE == 0) {
       q = q_origin + pix;
     } else {
-      const int hy = pix / A.hw_lds, hx = pix - hy * A.hw_lds;
-      q = q_origin + hy * g.in_ws + hx;
+      pix = min(pix, np_pix - 1);
+      const int hy = (int)(((unsigned)pix * hw_inv) >> 16), hx = pix - hy * A.hw_lds;
+      q = q_origin + hy * in_ws + hx;
     }
-    return reinterpret_cast<const float4*>(in_base + (size_t)q * g.in_cstride +
-                                           chunk * CK + j * 4);
+    return (size_t)q * in_cstride + pj * 4;
   };
-  auto piece_dst = [&](float* buf, int idx) -> float4* {
-    const int pix = idx / CG, j = idx - pix * CG;
-    return reinterpret_cast<float4*>(buf + (size_t)(j * QS + pix) * 4);
-  };
+  auto piece_loff = [&](int set) -> int { return (pj * QS + set * PIXSET + ppix0) * 4; };
+  // a thread with nothing to park writes its stale registers to a private dummy slot
+  // behind the two buffers, so the park step needs no per-thread branch
+  const int dummy_loff = 2 * buf_floats + tid * 4;
+  const int nsets = (np_total + 255) / 256;  // piece sets per chunk
 
-  // ---- B operand pointers ---------------------------------------------------
+  // ---- B operand pointers (advance one (chunk,tap) block per tap) ---------------
   const int nchunks = A.cin / CK;
-  const int total = nchunks * T;
   const int ncol = blockIdx.y * kConvBN + wn * 32 + l31;
-  const float4* bp = reinterpret_cast<const float4*>(g.w) +
-                     (size_t)kh * g.cout_pad + ncol;
-  const size_t b_it_stride = (size_t)CG * g.cout_pad;  // float4 per (chunk,tap)
-  const size_t b_g_stride = (size_t)2 * g.cout_pad;    // float4 per k-group
-
-  float4 bcur[G];
+  const float4* bq[G];
 #pragma unroll
-  for (int gi = 0; gi < G; ++gi) bcur[gi] = bp[gi * b_g_stride];
+  for (int gi = 0; gi < G; ++gi)
+    bq[gi] = reinterpret_cast<const float4*>(g.w) + (size_t)(2 * gi + kh) * g.cout_pad + ncol;
+  const size_t b_it_stride = (size_t)CG * g.cout_pad;  // float4 per (chunk,tap)
+
+  float4 b0[G], b1[G];
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi) b0[gi] = *bq[gi];
 
   // ---- prologue: halo of chunk 0 ---------------------------------------------
-  for (int idx = tid; idx < np_total; idx += 256)
-    *piece_dst(smem, idx) = *piece_src(idx, 0);
+  for (int set = 0; set < nsets; ++set)
+    if (set * 256 + tid < np_total)
+      *reinterpret_cast<float4*>(smem + piece_loff(set)) =
+          *reinterpret_cast<const float4*>(in_base + piece_goff(set));
   __syncthreads();
 
   floatx16 acc[2];
@@ -184,90 +195,136 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[fm][r] = 0.f;
 
-  int it = 0;
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const float* hb = smem + (chunk & 1) * buf_floats;
-    float* hn = smem + ((chunk + 1) & 1) * buf_floats;
-    const bool has_next = (chunk + 1) < nchunks;
-    float4 hreg[PPT];
+  // LDS float offsets of this lane's A fragments inside a halo buffer: [k-group][m-frag]
+  int afrag[G][2];
 #pragma unroll
-    for (int p = 0; p < PPT; ++p) hreg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm) afrag[gi][fm] = ((2 * gi + kh) * QS + abase[fm]) * 4;
+  const int rowstep = row_lds * 4;  // floats per stencil row in the LDS image
 
-    // A fragments of tap 0 (the barrier that published `hb` is behind us)
-    float4 acur[G][2];
+  // One tap = 8*G MFMAs with the loads for the NEXT tap threaded between them in a
+  // fixed order: B straight from L2, A fragments from LDS (running row address +
+  // immediate column offset), and - in the first rows of a chunk only (STAGE) - PPT
+  // 16-byte pieces per thread of the next chunk's halo, parked in LDS one tap later.
+  // A wave issues MFMAs back to back on its own and the VALU port stays nearly idle:
+  // measured, every VALU instruction in this loop costs MFMA issue slots once two
+  // waves share a SIMD (tools/exp_variants.sh drops one load stream at a time).
+#ifdef RTPOSE_EXP_NO_B
+#define RTPOSE_EXP_B(load, keep) (keep)
+#else
+#define RTPOSE_EXP_B(load, keep) (load)
+#endif
+#ifdef RTPOSE_EXP_NO_A
+#define RTPOSE_EXP_A(load, keep) (keep)
+#else
+#define RTPOSE_EXP_A(load, keep) (load)
+#endif
+#ifdef RTPOSE_EXP_NO_STAGE
+#define RTPOSE_EXP_STAGE 0
+#else
+#define RTPOSE_EXP_STAGE 1
+#endif
+  // memory clobber: loads/stores may not cross (IR + DAG); sched_barrier: nothing may
+  // cross in the machine scheduler
+#define RTPOSE_PIN()                 \
+  asm volatile("" ::: "memory");     \
+  __builtin_amdgcn_sched_barrier(0)
+#define RTPOSE_CONV_STEP(ACUR, BCUR, ANXT, BNXT, KX, STAGE)                                    \
+  {                                                                                            \
+    _Pragma("unroll") for (int n = 0; n < 4 * G; ++n) {                                        \
+      const int gi_ = n >> 2, j_ = n & 3;                                                      \
+      const float bv_[4] = {BCUR[gi_].x, BCUR[gi_].y, BCUR[gi_].z, BCUR[gi_].w};               \
+      const float a0_[4] = {ACUR[gi_][0].x, ACUR[gi_][0].y, ACUR[gi_][0].z, ACUR[gi_][0].w};   \
+      const float a1_[4] = {ACUR[gi_][1].x, ACUR[gi_][1].y, ACUR[gi_][1].z, ACUR[gi_][1].w};   \
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_[j_], bv_[j_], acc[0], 0, 0, 0);        \
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_[j_], bv_[j_], acc[1], 0, 0, 0);        \
+      RTPOSE_PIN();                                                                            \
+      if (n == 0) {                                                                            \
+        _Pragma("unroll") for (int g2 = 0; g2 < G; ++g2) {                                     \
+          bq[g2] += b_it_stride;                                                               \
+          BNXT[g2] = RTPOSE_EXP_B(*bq[g2], BCUR[g2]);                                          \
+        }                                                                                      \
+      }                                                                                        \
+      if (n == 1) {                                                                            \
+        if ((KX) == KS - 1) { /* the next tap starts the next stencil row */                   \
+          _Pragma("unroll") for (int g2 = 0; g2 < G; ++g2) {                                   \
+            arow[g2][0] += rowstep;                                                            \
+            arow[g2][1] += rowstep;                                                            \
+          }                                                                                    \
+        }                                                                                      \
+        if (((STAGE) & RTPOSE_EXP_STAGE) != 0) {                                                     \
+          _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                                    \
+            *reinterpret_cast<float4*>(smem + hl[p]) = hv[p];                                  \
+            const int set = ps * PPT + p;                                                      \
+            hv[p] = *reinterpret_cast<const float4*>(next_base + piece_goff(set));             \
+            hl[p] = (tid < np_total - set * 256) ? hn_off + piece_loff(set) : dummy_loff;      \
+          }                                                                                    \
+          ++ps;                                                                                \
+        }                                                                                      \
+      }                                                                                        \
+      if (n >= 2 && n - 2 < G) {                                                               \
+        _Pragma("unroll") for (int fm = 0; fm < 2; ++fm)                                       \
+          ANXT[n - 2][fm] = RTPOSE_EXP_A(*reinterpret_cast<const float4*>(smem + arow[n - 2][fm] + (((KX) + 1 < KS) ? ((KX) + 1) * 4 : 0)), ACUR[n - 2][fm]); \
+      }                                                                                        \
+      RTPOSE_PIN();                                                                            \
+    }                                                                                          \
+  }
+#define RTPOSE_CONV_ROW(STAGE)                                      \
+  {                                                                 \
+    _Pragma("unroll") for (int kx = 0; kx < KS; ++kx) {             \
+      if ((kx & 1) == 0) {                                          \
+        RTPOSE_CONV_STEP(a0, b0, a1, b1, kx, STAGE)                 \
+      } else {                                                      \
+        RTPOSE_CONV_STEP(a1, b1, a0, b0, kx, STAGE)                 \
+      }                                                             \
+    }                                                               \
+    if (KS & 1) { /* odd taps per row: the live set ended in (a1, b1) */ \
+      _Pragma("unroll") for (int gi = 0; gi < G; ++gi) {            \
+        b0[gi] = b1[gi];                                            \
+        a0[gi][0] = a1[gi][0];                                      \
+        a0[gi][1] = a1[gi][1];                                      \
+      }                                                             \
+    }                                                               \
+  }
+
+  // rows of a chunk whose taps carry the staging code: set s is fetched at tap s and
+  // parked at tap s+1, so nsets+1 taps are needed (the host guarantees they exist)
+  const int stage_rows = min(KS, (nsets + 1 + PPT * KS - 1) / (PPT * KS));
+  float4 hv[PPT];
+  int hl[PPT];
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int hb_off = (chunk & 1) * buf_floats;
+    const int hn_off = ((chunk + 1) & 1) * buf_floats;
+    // the last chunk re-stages itself into the idle buffer (never read): no branch
+    const float* next_base = in_base + (size_t)min(chunk + 1, nchunks - 1) * CK;
+    int ps = 0;
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      hv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      hl[p] = dummy_loff;
+    }
+    // running LDS addresses (floats) of this lane's fragments on the current stencil row
+    int arow[G][2];
+    float4 a0[G][2], a1[G][2];
 #pragma unroll
     for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-      for (int fm = 0; fm < 2; ++fm)
-        acur[gi][fm] = *reinterpret_cast<const float4*>(
-            hb + (size_t)((2 * gi + kh) * QS + abase[fm]) * 4);
-
-    for (int tap = 0; tap < T; ++tap, ++it) {
-      // B prefetch for the next (chunk, tap)
-      float4 bnxt[G];
-      {
-        const int itn = (it + 1 < total) ? it + 1 : it;
-        const float4* bq = bp + (size_t)itn * b_it_stride;
-#pragma unroll
-        for (int gi = 0; gi < G; ++gi) bnxt[gi] = bq[gi * b_g_stride];
+      for (int fm = 0; fm < 2; ++fm) {
+        arow[gi][fm] = hb_off + afrag[gi][fm];
+        a0[gi][fm] = *reinterpret_cast<const float4*>(smem + arow[gi][fm]);  // tap (0,0)
       }
-      // halo of the next chunk: write what was fetched during the previous
-      // tap, fetch the next piece set
-      if (has_next) {
-        if (tap > 0) {
+    int ky = 0;
+    for (; ky < stage_rows; ++ky) RTPOSE_CONV_ROW(1)
+    for (; ky < KS; ++ky) RTPOSE_CONV_ROW(0)
+    // park whatever is still in flight, then publish the buffer
 #pragma unroll
-          for (int p = 0; p < PPT; ++p) {
-            const int idx = ((tap - 1) * PPT + p) * 256 + tid;
-            if (idx < np_total) *piece_dst(hn, idx) = hreg[p];
-          }
-        }
-#pragma unroll
-        for (int p = 0; p < PPT; ++p) {
-          const int idx = (tap * PPT + p) * 256 + tid;
-          if (idx < np_total) hreg[p] = *piece_src(idx, chunk + 1);
-        }
-      }
-      // A prefetch for the next tap of this chunk (same LDS buffer, no barrier)
-      float4 anxt[G][2];
-      {
-        const int tn = (tap + 1 < T) ? tap + 1 : tap;
-        const int ky = tn / KS, kx = tn - ky * KS;
-        const int tapoff = ky * row_lds + kx;
-#pragma unroll
-        for (int gi = 0; gi < G; ++gi)
-#pragma unroll
-          for (int fm = 0; fm < 2; ++fm)
-            anxt[gi][fm] = *reinterpret_cast<const float4*>(
-                hb + (size_t)((2 * gi + kh) * QS + abase[fm] + tapoff) * 4);
-      }
-      // MFMAs of this tap
-#pragma unroll
-      for (int gi = 0; gi < G; ++gi) {
-        const float bv[4] = {bcur[gi].x, bcur[gi].y, bcur[gi].z, bcur[gi].w};
-        const float a0[4] = {acur[gi][0].x, acur[gi][0].y, acur[gi][0].z, acur[gi][0].w};
-        const float a1[4] = {acur[gi][1].x, acur[gi][1].y, acur[gi][1].z, acur[gi][1].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bv[j], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bv[j], acc[1], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int gi = 0; gi < G; ++gi) {
-        bcur[gi] = bnxt[gi];
-        acur[gi][0] = anxt[gi][0];
-        acur[gi][1] = anxt[gi][1];
-      }
-    }
-    if (has_next) {
-#pragma unroll
-      for (int p = 0; p < PPT; ++p) {
-        const int idx = ((T - 1) * PPT + p) * 256 + tid;
-        if (idx < np_total) *piece_dst(hn, idx) = hreg[p];
-      }
-    }
+    for (int p = 0; p < PPT; ++p) *reinterpret_cast<float4*>(smem + hl[p]) = hv[p];
     __syncthreads();
   }
+#undef RTPOSE_CONV_ROW
+#undef RTPOSE_CONV_STEP
+#undef RTPOSE_PIN
 
   // ---- epilogue: bias (+ReLU) (+2x2 max-pool), masked stores -----------------
   const bool col_ok = ncol < g.cout;
@@ -397,7 +454,7 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* p
     const int lb = (kBM - 1) + ((kBM - 1) / W + 1) * (l.ws - W) +
                    ((kBM - 1) / (H * W) + 1) * (l.hs - H) * l.ws + 2 * P * l.ws + 2 * P + 1;
     const int qs = round_qs(lb);
-    const size_t lds = (size_t)2 * cg * qs * 16;
+    const size_t lds = (size_t)2 * cg * qs * 16 + 256 * 16;
     if (ceil_div(qs * cg, 256) > max_pieces || lds > 80 * 1024) strip = false;
     if (strip) {
       pl->mode = 0;
@@ -434,7 +491,7 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* p
   pl->tiles_x = ceil_div(W, tw);
   pl->tiles_y = ceil_div(H, th);
   pl->grid_x = N * pl->tiles_x * pl->tiles_y;
-  pl->lds_bytes = (size_t)2 * cg * pl->qs * 16;
+  pl->lds_bytes = (size_t)2 * cg * pl->qs * 16 + 256 * 16;
   if (ceil_div(pl->qs * cg, 256) > max_pieces)
     return fail(RTPOSE_E_INVAL, "conv halo too large for the staging schedule");
   return 0;
@@ -549,7 +606,8 @@ extern "C" {
 
 size_t rtpose_packed_weight_floats(int cout, int cin, int k) {
   const int cinp = rtpose::ceil_div(cin, 8) * 8;
-  return (size_t)k * k * cinp * rtpose::cout_pad(cout);
+  // + one (chunk, tap) block of slack: the kernel's B prefetch runs one tap ahead
+  return (size_t)(k * k * cinp + 16) * rtpose::cout_pad(cout);
 }
 size_t rtpose_packed_bias_floats(int cout) { return (size_t)rtpose::cout_pad(cout); }
 

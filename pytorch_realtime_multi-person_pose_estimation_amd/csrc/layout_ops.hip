@@ -188,7 +188,9 @@ const char* rtpose_last_error(void) { return rtpose::err_buf(); }
 size_t rtpose_layout_pixels(const rtpose_layout* l, int N, int H, int W) {
   (void)H;
   (void)W;
-  return (size_t)l->lead + (size_t)N * l->hs * l->ws + (size_t)40 * l->ws + 256;
+  // tail slack: 2-D tiles may read up to ~36 rows past the last image, and the strip
+  // mode's staging runs up to 14 piece sets (64 pixels each) past a halo
+  return (size_t)l->lead + (size_t)N * l->hs * l->ws + (size_t)40 * l->ws + 4352;
 }
 
 int rtpose_nchw_to_layout(const float* src, float* dst, const rtpose_layout* ldst, int C, int cpad,

@@ -1,0 +1,83 @@
+"""CPU suite: the C-ABI library loads without a GPU, exports every symbol the
+header declares, and its host-only entry points behave (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "rtpose_mi355x.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b([a-z_0-9]+)\s*\([^;{}]*\)\s*;", src)
+    return sorted(set(n for n in names if not n.startswith("RTPOSE")))
+
+
+def test_every_declared_symbol_is_exported(capi):
+    names = _header_functions()
+    assert len(names) >= 40 and "rtpose_conv2d" in names and "process_paf" in names
+    for n in names:
+        assert hasattr(capi.lib, n), "header declares %s but the library does not export it" % n
+    # and the Python binding table covers the whole header
+    assert set(names) == set(capi.EXPORTED)
+
+
+def test_version_and_sizes(capi):
+    lib = capi.lib
+    assert b"gfx950" in lib.rtpose_version()
+    # packed weights: k*k * cin rounded to 8 * cout rounded to 64
+    assert lib.rtpose_packed_weight_floats(38, 185, 7) == 49 * 192 * 64
+    assert lib.rtpose_packed_weight_floats(64, 3, 3) == 9 * 8 * 64
+    assert lib.rtpose_packed_bias_floats(19) == 64
+    lay = capi.Layout.padded(192, 46, 46, 3)
+    assert (lay.ws, lay.hs, lay.lead) == (49, 49, 3 * 49 + 3)
+    assert lib.rtpose_layout_pixels(C.byref(lay), 32, 46, 46) >= lay.lead + 32 * 49 * 49 + 3
+
+
+def test_net_plan_introspection_matches_reference_state_dict(capi, pkg):
+    lib = capi.lib
+    h = C.c_void_p()
+    capi.check(lib.rtpose_net_create(2, 368, 368, C.byref(h)))
+    try:
+        n = lib.rtpose_net_num_convs(h)
+        assert n == 92                                        # SURVEY: 92 nn.Conv2d
+        m = pkg.get_model('vgg19')
+        convs = m._convs()
+        name = C.create_string_buffer(64)
+        co, ci, k = C.c_int(), C.c_int(), C.c_int()
+        total = 0
+        for i, (nm, mod) in enumerate(convs):
+            capi.check(lib.rtpose_net_conv_info(h, i, name, 64, C.byref(co), C.byref(ci), C.byref(k)))
+            assert name.value.decode() == nm
+            assert tuple(mod.weight.shape) == (co.value, ci.value, k.value, k.value)
+            total += mod.weight.numel() + mod.bias.numel()
+        assert total == 52311446                              # SURVEY §6 parameter count
+        assert lib.rtpose_net_workspace_bytes(h) > 0 and lib.rtpose_net_weight_bytes(h) > total * 4
+        # algorithmic flops of the plan == SURVEY's 271.868 GFLOP/img
+        fl = 0.0
+        f, kk = C.c_double(), C.c_int()
+        for i in range(lib.rtpose_net_num_launches(h)):
+            capi.check(lib.rtpose_net_launch_info(h, i, None, C.byref(kk), C.byref(f), None, 0))
+            fl += f.value
+        assert abs(fl / 2 / 1e9 - 271.868) < 0.01
+        # forward before bind is a loud state error, not a crash
+        assert lib.rtpose_net_forward(h, C.c_void_p(16), None) != 0
+        assert "not bound" in capi.last_error()
+    finally:
+        lib.rtpose_net_destroy(h)
+
+
+def test_bad_arguments_are_rejected_on_the_host(capi):
+    lib = capi.lib
+    h = C.c_void_p()
+    assert lib.rtpose_net_create(0, 368, 368, C.byref(h)) != 0
+    cfg = capi.DecodeCfg(18, 8, 0.1, 100000, 64)
+    assert lib.rtpose_decode_result_bytes(C.byref(cfg), 4) == 0          # capacity above the limit
+    cfg = capi.DecodeCfg(18, 8, 0.1, 32, 64)
+    assert lib.rtpose_decode_result_bytes(C.byref(cfg), 4) == 4 * 4 * (32 + 72 * 32 + 19 * 64)
+    assert lib.rtpose_decode_workspace_bytes(C.byref(cfg), 4) >= 4 * 19 * (1 + 3 * 32) * 4
+    # legacy getters on an empty state: bounds-checked, never UB
+    assert lib.get_part_cid(3, 3) == -1 and lib.get_part_x(0) == -1

@@ -1,0 +1,151 @@
+"""CPU suite: host-side logic (result parsing, drop-in types, state_dict surface,
+sharding + gather over gloo with world_size 2, loud failure without a GPU)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG_NAME, ROOT
+
+
+@pytest.fixture(scope="module")
+def dec(pkg):
+    return importlib.import_module(PKG_NAME + ".decode")
+
+
+def _pack_record(dec, cfg, jl, parts, score):
+    """Build a result record the way the device kernels lay it out (test helper)."""
+    from oracle import post_oracle  # noqa: F401  (tests may use the oracle)
+    pcap, hcap = cfg.max_peaks_per_part, cfg.max_humans
+    words = (32 + 72 * pcap + 19 * hcap + 3) & ~3
+    rec = np.zeros(words, np.int32)
+    rec[0] = len(jl)
+    rec[1] = len(parts)
+    pk = rec[32:32 + 72 * pcap].reshape(18, pcap, 4)
+    for p in range(18):
+        rows = jl[jl[:, 4] == p]
+        rec[8 + p] = len(rows)
+        pk[p, :len(rows), 0] = rows[:, 0].astype(np.int32)
+        pk[p, :len(rows), 1] = rows[:, 1].astype(np.int32)
+        pk[p, :len(rows), 2] = rows[:, 2].copy().view(np.int32)
+        pk[p, :len(rows), 3] = rows[:, 3].astype(np.int32)
+    off = 32 + 72 * pcap
+    rec[off:off + 18 * hcap].reshape(hcap, 18)[:len(parts)] = parts
+    rec[off + 18 * hcap:off + 18 * hcap + len(score)] = score.view(np.int32)
+    return rec
+
+
+def test_parse_record_roundtrip_and_humans(dec):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "post_scenes.npz"))
+    cfg = dec.make_cfg(None, 32, 16)
+    rec = _pack_record(dec, cfg, z["jl3"], z["parts3"], z["score3"])
+    out = dec.parse_image(rec, cfg)
+    assert np.array_equal(out["peaks"], z["jl3"]) and np.array_equal(out["parts"], z["parts3"])
+    assert np.array_equal(out["score"], z["score3"]) and out["flags"] == 0
+    humans = dec.humans_from_record(out, 368, 368)
+    assert len(humans) == len(z["parts3"])
+    h0 = humans[0]
+    assert h0.part_count() == int((z["parts3"][0] >= 0).sum())
+    for p, bp in h0.body_parts.items():
+        assert 0.0 <= bp.x < 1.0 and 0.0 <= bp.y < 1.0 and bp.part_idx == p
+        assert bp.get_part_name().value == p
+    assert h0.get_max_score() == max(b.score for b in h0.body_parts.values())
+    assert "BodyPart:" in str(h0)
+
+
+def test_state_dict_surface_matches_reference_names(pkg):
+    m = pkg.get_model('vgg19')
+    sd = m.state_dict()
+    keys = list(sd)
+    assert len(keys) == 184
+    assert keys[0] == "model0.0.weight" and keys[1] == "model0.0.bias" and keys[24] == "model1_1.0.weight"
+    assert keys[-1] == "model6_2.12.bias"
+    assert tuple(sd["model2_1.0.weight"].shape) == (128, 185, 7, 7)
+    assert tuple(sd["model1_2.8.weight"].shape) == (19, 512, 1, 1)
+    # reference init (:200-222): N(0, 0.01) weights, zero biases
+    assert float(sd["model0.2.bias"].abs().max()) == 0.0
+    assert 0.005 < float(sd["model0.21.weight"].std()) < 0.02
+    with pytest.raises(ValueError):
+        pkg.get_model('mobilenet')
+    # nn.DataParallel wrapping + load_state_dict keep working (demo/picture_demo.py:45-47)
+    dp = torch.nn.DataParallel(m)
+    dp.module.load_state_dict({k: v.clone() for k, v in sd.items()})
+
+
+def test_no_silent_cpu_fallback(pkg, dec, capi):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = pkg.get_model('vgg19')
+    with pytest.raises(capi.RtposeError):
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(capi.RtposeError):
+        dec.paf_to_pose_cpp(np.zeros((8, 8, 19), np.float32), np.zeros((8, 8, 38), np.float32),
+                            dec.default_config())
+    with pytest.raises(capi.RtposeError):
+        dec.decode_maps(torch.zeros(1, 8, 8, 19), torch.zeros(1, 8, 8, 38))
+    pafprocess = importlib.import_module(PKG_NAME + ".pafprocess")
+    with pytest.raises(TypeError):
+        pafprocess.process_paf(np.zeros((4, 5), np.float32), np.zeros((8, 8, 19)), np.zeros((8, 8, 38)))
+    with pytest.raises(capi.RtposeError):   # one peak, no device: loud, no CPU path
+        pafprocess.process_paf(np.array([[[1, 1, .5, 0, 0]]], np.float32), np.zeros((8, 8, 19)), np.zeros((8, 8, 38)))
+
+
+def test_shard_range_partitions(pkg):
+    par = importlib.import_module(PKG_NAME + ".parallel")
+    for n in (0, 1, 7, 32, 5000):
+        for world in (1, 2, 3, 8):
+            spans = [par.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r'''
+import importlib, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+PKG = "pytorch_realtime_multi-person_pose_estimation_amd"
+par = importlib.import_module(PKG + ".parallel"); dec = importlib.import_module(PKG + ".decode")
+synth = importlib.import_module(PKG + ".synth")
+from oracle import post_oracle as po
+from test_host_cpu import _pack_record
+rank, _, world = par.init_from_env("gloo")
+n_total = 6
+heat, paf, _ = synth.make_batch(n_total, 176, 176, seed=77)
+lo, hi = par.shard_range(n_total, rank, world)
+cfg = dec.make_cfg(None, 32, 16)
+local = []
+for i in range(lo, hi):                      # stand-in for the GPU decoder on this rank's shard
+    jl, r = po.paf_to_pose(heat[i], paf[i])
+    local.append(_pack_record(dec, cfg, jl, r["parts"], r["score"]))
+local = torch.from_numpy(np.stack(local))
+allrec = par.gather_records(local, world).numpy()
+t = par.max_over_ranks(float(rank + 1), torch.device("cpu"))
+par.barrier()
+if rank == 0:
+    assert t == float(world)
+    assert allrec.shape[0] == n_total
+    for i in range(n_total):                 # rank order == image order
+        jl, r = po.paf_to_pose(heat[i], paf[i])
+        out = dec.parse_image(allrec[i], cfg)
+        assert np.array_equal(out["peaks"], jl) and np.array_equal(out["parts"], r["parts"])
+    print("GATHER_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_shard_and_gather_gloo(tmp_path):
+    """world_size 2 on CPU (gloo): shard, decode shard (oracle stand-in), all_gather, parse."""
+    import subprocess
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = 29600 + (os.getpid() % 300)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and "GATHER_OK" in p.stdout, p.stdout[-3000:]

@@ -1,0 +1,141 @@
+"""CPU suite: the oracle is pinned to the reference before anything trusts it.
+
+* oracle_process_paf (plain C) == golden vectors produced by the reference's own
+  pafprocess.cpp compiled unmodified, and == that compiled reference directly on
+  many random scenes when oracle/_ref is present (it is git-ignored but travels).
+* oracle_nms peak positions == scipy.ndimage.maximum_filter, the call the reference
+  makes (lib/utils/paf_to_pose.py:34); its bicubic refine == torch CPU bicubic
+  (same A=-0.75 / half-pixel / clamped-tap definition) to ~1e-6 with equal arg-max.
+* net oracle == golden outputs of the reference module (tests/golden/net_small.npz).
+"""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG_NAME
+from oracle import net_oracle
+from oracle import post_oracle as po
+
+GOLD_POST = os.path.join(os.path.dirname(__file__), "golden", "post_scenes.npz")
+GOLD_NET = os.path.join(os.path.dirname(__file__), "golden", "net_small.npz")
+
+
+@pytest.fixture(scope="module")
+def synth(pkg):
+    return importlib.import_module(PKG_NAME + ".synth")
+
+
+def test_process_paf_oracle_matches_reference_golden():
+    z = np.load(GOLD_POST)
+    assert int(z["n"]) >= 5
+    for i in range(int(z["n"])):
+        r = po.process_paf(z["jl%d" % i], z["paf%d" % i], 8)
+        assert np.array_equal(r["parts"], z["parts%d" % i])
+        assert np.array_equal(r["score"].view(np.uint32), z["score%d" % i].view(np.uint32))
+        assert np.array_equal(np.stack([r["line_x"], r["line_y"]], 1), z["line%d" % i])
+
+
+def test_nms_oracle_reproduces_golden_joint_lists():
+    z = np.load(GOLD_POST)
+    for i in range(int(z["n"])):
+        jl = po.nms(z["heat%d" % i])
+        assert np.array_equal(jl.view(np.uint32), z["jl%d" % i].view(np.uint32))
+
+
+@pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_process_paf_oracle_vs_compiled_reference_random(synth):
+    rng = np.random.default_rng(42)
+    hits = 0
+    for trial in range(40):
+        hh, ww = int(rng.integers(12, 47)) * 8, int(rng.integers(12, 50)) * 8
+        people = synth.random_people(rng, int(rng.integers(1, 12)), hh, ww, drop_prob=float(rng.uniform(0, 0.3)))
+        heat, paf = synth.render(people, hh, ww, noise=float(rng.uniform(0.005, 0.08)), rng=rng)
+        jl = po.nms(heat)
+        if len(jl) == 0:
+            continue
+        ref = po.ref_process_paf(jl, po.upsample_nearest(heat, 8), po.upsample_nearest(paf, 8))
+        mine = po.process_paf(jl, paf, 8)
+        assert np.array_equal(ref["parts"], mine["parts"]), trial
+        assert np.array_equal(ref["score"].view(np.uint32), mine["score"].view(np.uint32)), trial
+        assert np.array_equal(ref["line_x"], mine["line_x"]) and np.array_equal(ref["line_y"], mine["line_y"])
+        hits += len(ref["parts"])
+    assert hits > 60
+
+
+@pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_process_paf_oracle_vs_compiled_reference_junk_maps():
+    """Pure-noise maps: hundreds of peaks, long candidate lists, found==2 merges."""
+    rng = np.random.default_rng(7)
+    for trial in range(6):
+        h, w = 20 + trial, 26 - trial
+        heat = rng.uniform(0, 0.35, (h, w, 19)).astype(np.float32)
+        paf = rng.uniform(-0.2, 1.0, (h, w, 38)).astype(np.float32)
+        jl = po.nms(heat)
+        ref = po.ref_process_paf(jl, po.upsample_nearest(heat, 8), po.upsample_nearest(paf, 8))
+        mine = po.process_paf(jl, paf, 8)
+        assert np.array_equal(ref["parts"], mine["parts"])
+        assert np.array_equal(ref["score"].view(np.uint32), mine["score"].view(np.uint32))
+
+
+def test_nms_peaks_match_scipy_find_peaks(synth):
+    heat, _, _ = synth.make_batch(3, 184, 216, seed=21)
+    for b in range(3):
+        jl = po.nms(heat[b])
+        for j in range(18):
+            exp = po.find_peaks_scipy(np.float32(0.1), heat[b][:, :, j])      # [[x, y], ...] row-major
+            mine = jl[jl[:, 4] == j]
+            assert len(exp) == len(mine)
+            # refined coords stay inside the 5x5 window of the low-res peak, in the same order
+            assert np.all(np.abs(mine[:, 0] - (exp[:, 0] * 8 + 3.5)) <= 2 * 8 + 4)
+            assert np.all(np.abs(mine[:, 1] - (exp[:, 1] * 8 + 3.5)) <= 2 * 8 + 4)
+    ids = po.nms(heat[0])[:, 3]
+    assert np.array_equal(ids, np.arange(len(ids), dtype=np.float32))        # running counter :141-142
+
+
+def test_nms_plateau_border_threshold_semantics():
+    h = np.zeros((9, 9, 19), np.float32)
+    h[0, 0, 0] = 0.5                      # corner accepted (reflect border)
+    h[4, 4, 1] = h[4, 5, 1] = 0.4         # plateau: both pixels are peaks
+    h[2, 2, 2] = np.float32(0.1)          # == threshold in float32: rejected
+    h[6, 6, 3] = 0.3
+    h[7, 7, 3] = 0.9                      # diagonal neighbour does not suppress (4-connectivity)
+    jl = po.nms(h)
+    assert [int(v) for v in jl[:, 4]] == [0, 1, 1, 3, 3]
+    for j in range(4):
+        assert len(po.find_peaks_scipy(np.float32(0.1), h[:, :, j])) == int((jl[:, 4] == j).sum())
+
+
+def test_refine_matches_torch_bicubic():
+    rng = np.random.default_rng(5)
+    for _ in range(60):
+        ph, pw = int(rng.integers(3, 6)), int(rng.integers(3, 6))
+        heat = np.zeros((ph, pw, 19), np.float32)
+        patch = rng.uniform(0.0, 0.09, (ph, pw)).astype(np.float32)
+        cy, cx = min(2, ph - 1), min(2, pw - 1)
+        patch[cy, cx] = 0.8
+        heat[:, :, 0] = patch
+        jl = po.nms(heat)
+        assert len(jl) == 1
+        # the whole map is the (clipped) window only if it is <= 5 wide: compare on that window
+        x_min, y_min = max(0, cx - 2), max(0, cy - 2)
+        win = patch[y_min:cy + 3, x_min:cx + 3]
+        up = torch.nn.functional.interpolate(torch.from_numpy(win)[None, None], scale_factor=8, mode='bicubic',
+                                             align_corners=False)[0, 0].numpy()
+        r, c = np.unravel_index(up.argmax(), up.shape)
+        assert (jl[0, 0], jl[0, 1]) == (x_min * 8 + c, y_min * 8 + r)
+        assert abs(jl[0, 2] - up.max()) <= 2e-6
+
+
+def test_net_oracle_reproduces_reference_golden(pkg):
+    z = np.load(GOLD_NET)
+    m = pkg.get_model('vgg19')
+    sd = net_oracle.he_init_state_dict(m, seed=0)
+    (paf, heat), saved = net_oracle.forward(sd, torch.from_numpy(z["x"]))
+    # same ATen CPU kernels, same weights -> agreement to rounding (thread-count dependent order)
+    assert np.abs(paf.numpy() - z["paf"]).max() <= 1e-5
+    assert np.abs(heat.numpy() - z["heat"]).max() <= 1e-5
+    for i in range(12):
+        assert np.abs(saved[i].numpy() - z["saved%d" % i]).max() <= 1e-5

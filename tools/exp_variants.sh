@@ -1,0 +1,23 @@
+#!/bin/bash
+# Builds experimental variants of the library (developer tool): tools/exp/lib_<name>.so
+set -e
+cd "$(dirname "$0")/.."
+SRC=pytorch_realtime_multi-person_pose_estimation_amd/csrc
+mkdir -p tools/exp
+build() { # name flags...
+  name=$1; shift
+  objs=""
+  for f in conv_mfma layout_ops net decode legacy_pafprocess; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$SRC "$@" -c $SRC/$f.hip -o tools/exp/${name}_$f.o &
+    objs="$objs tools/exp/${name}_$f.o"
+  done
+  wait
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/exp/lib_$name.so $objs
+  rm -f $objs
+}
+build base
+build nob -DRTPOSE_EXP_NO_B
+build noa -DRTPOSE_EXP_NO_A
+build nostage -DRTPOSE_EXP_NO_STAGE
+build none -DRTPOSE_EXP_NO_B -DRTPOSE_EXP_NO_A -DRTPOSE_EXP_NO_STAGE
+ls -la tools/exp
