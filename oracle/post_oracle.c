@@ -177,6 +177,128 @@ typedef struct {
 static int roundpaf(float v) { return (int)(v + 0.5); }
 
 /*
+ * std::sort(candidates.begin(), candidates.end(), comp_candidate) as libstdc++ (GCC 11,
+ * bits/stl_algo.h: the third-party code the reference's pafprocess.cpp:97 links against
+ * when built with this image's g++) executes it: introsort = median-of-3 quicksort down
+ * to 16-element runs with a 2*floor(log2 n) depth limit (heap sort beyond it), then one
+ * insertion-sort pass.  Restated from the published algorithm so that the oracle can
+ * reproduce the reference's choice among EQUAL-score candidates too (sort_mode 1);
+ * comp(a, b) = a.score > b.score (pafprocess.cpp:244-246).
+ */
+static int cand_gt(const Cand* a, const Cand* b) { return a->score > b->score; }
+static void cand_swap(Cand* a, Cand* b) {
+  Cand t = *a;
+  *a = *b;
+  *b = t;
+}
+static void std_unguarded_linear_insert(Cand* last) {
+  Cand val = *last;
+  Cand* next = last - 1;
+  while (cand_gt(&val, next)) {
+    *last = *next;
+    last = next;
+    --next;
+  }
+  *last = val;
+}
+static void std_insertion_sort(Cand* first, Cand* last) {
+  if (first == last) return;
+  for (Cand* i = first + 1; i != last; ++i) {
+    if (cand_gt(i, first)) {
+      Cand val = *i;
+      memmove(first + 1, first, sizeof(Cand) * (size_t)(i - first));
+      *first = val;
+    } else {
+      std_unguarded_linear_insert(i);
+    }
+  }
+}
+static void std_push_heap(Cand* first, long hole, long top, Cand value) {
+  long parent = (hole - 1) / 2;
+  while (hole > top && cand_gt(first + parent, &value)) {
+    first[hole] = first[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  first[hole] = value;
+}
+static void std_adjust_heap(Cand* first, long hole, long len, Cand value) {
+  const long top = hole;
+  long child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (cand_gt(first + child, first + (child - 1))) child--;
+    first[hole] = first[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    first[hole] = first[child - 1];
+    hole = child - 1;
+  }
+  std_push_heap(first, hole, top, value);
+}
+static void std_heap_sort(Cand* first, Cand* last) { /* __partial_sort(first, last, last) */
+  const long len = last - first;
+  if (len >= 2)
+    for (long parent = (len - 2) / 2;; --parent) { /* __make_heap */
+      std_adjust_heap(first, parent, len, first[parent]);
+      if (parent == 0) break;
+    }
+  while (last - first > 1) { /* __sort_heap */
+    --last;
+    Cand value = *last;
+    *last = *first;
+    std_adjust_heap(first, 0, last - first, value);
+  }
+}
+static void std_move_median_to_first(Cand* result, Cand* a, Cand* b, Cand* c) {
+  if (cand_gt(a, b)) {
+    if (cand_gt(b, c)) cand_swap(result, b);
+    else if (cand_gt(a, c)) cand_swap(result, c);
+    else cand_swap(result, a);
+  } else if (cand_gt(a, c)) cand_swap(result, a);
+  else if (cand_gt(b, c)) cand_swap(result, c);
+  else cand_swap(result, b);
+}
+static Cand* std_unguarded_partition(Cand* first, Cand* last, Cand* pivot) {
+  for (;;) {
+    while (cand_gt(first, pivot)) ++first;
+    --last;
+    while (cand_gt(pivot, last)) --last;
+    if (!(first < last)) return first;
+    cand_swap(first, last);
+    ++first;
+  }
+}
+static void std_introsort_loop(Cand* first, Cand* last, long depth_limit) {
+  while (last - first > 16) {
+    if (depth_limit == 0) {
+      std_heap_sort(first, last);
+      return;
+    }
+    --depth_limit;
+    Cand* mid = first + (last - first) / 2;
+    std_move_median_to_first(first, first + 1, mid, last - 1);
+    Cand* cut = std_unguarded_partition(first + 1, last, first);
+    std_introsort_loop(cut, last, depth_limit);
+    last = cut;
+  }
+}
+static void std_sort_desc(Cand* first, Cand* last) {
+  if (first == last) return;
+  long n = last - first, lg = 0;
+  while ((n >> (lg + 1)) > 0) ++lg;
+  std_introsort_loop(first, last, lg * 2);
+  if (last - first > 16) {
+    std_insertion_sort(first, first + 16);
+    for (Cand* i = first + 16; i != last; ++i) std_unguarded_linear_insert(i);
+  } else {
+    std_insertion_sort(first, last);
+  }
+}
+
+/*
  * joint_list: float32 [P][5] rows (x, y, score, id(ignored), part) as handed to
  * process_paf (PEAKS macro, pafprocess.cpp:6).  paf: dense HWC [h][w][38] at the
  * network resolution; `up` = up-sampling factor the reference applied before the
@@ -184,10 +306,19 @@ static int roundpaf(float v) { return (int)(v + 0.5); }
  * Outputs: human_parts [max_humans][18] (cid or -1), human_score, and
  * line_xys [P][3] = (x, y, score-as-bits) of peak_infos_line for the getters.
  * Returns the number of humans, -1 if more than max_humans, -2 on bad part id.
+ * Equal-score candidates: see had_ties below.
  */
 int oracle_process_paf(const float* joint_list, int P, const float* paf, int h, int w, int up, int h1,
                        int max_humans, int* human_parts, float* human_score, int* line_x, int* line_y,
-                       float* line_score) {
+                       float* line_score, int* had_ties, int sort_mode) {
+  /* sort_mode 0: ties keep (idx1, idx2) order = the product's documented contract;
+   * sort_mode 1: order candidates exactly as libstdc++'s std::sort would. */
+  /* *had_ties (optional): set when two candidates of one limb have exactly equal
+   * scores.  The reference sorts with std::sort (cpp:97, not stable), so which of
+   * them wins is implementation-defined there; this restatement (and the GPU
+   * kernel) break ties towards the lower (idx1, idx2).  Tests skip the bit-exact
+   * comparison against the compiled reference for such scenes. */
+  if (had_ties) *had_ties = 0;
   /* phase 1 (cpp:24-43) */
   Peak* by_part[NUM_PART];
   int n_part[NUM_PART];
@@ -250,9 +381,17 @@ int oracle_process_paf(const float* joint_list, int P, const float* paf, int h, 
         }
         const double pen = 0.5 * h1 / norm - 1.0;
         const float crit2 = scores / STEP_PAF + (pen < 0.0 ? pen : 0.0);
-        if (crit1 > 6 && crit2 > 0) {
+        if (crit1 > 6 && crit2 > 0 && sort_mode == 1) {
+          cands[nc].idx1 = a;
+          cands[nc].idx2 = b;
+          cands[nc].score = crit2;
+          ++nc;
+        } else if (crit1 > 6 && crit2 > 0) {
           /* keep the list sorted by descending score, ties in insertion order */
           int pos = nc;
+          if (had_ties)
+            for (int t = 0; t < nc; ++t)
+              if (cands[t].score == crit2) *had_ties = 1;
           while (pos > 0 && cands[pos - 1].score < crit2) {
             cands[pos] = cands[pos - 1];
             --pos;
@@ -263,6 +402,7 @@ int oracle_process_paf(const float* joint_list, int P, const float* paf, int h, 
           ++nc;
         }
       }
+    if (sort_mode == 1) std_sort_desc(cands, cands + nc);
     conns[pair] = (Conn*)malloc(sizeof(Conn) * (nA < nB ? nA : nB));
     char* usedA = (char*)calloc(nA, 1);
     char* usedB = (char*)calloc(nB, 1);

@@ -30,7 +30,7 @@ def _post():
     lib.oracle_nms.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _fp]
     lib.oracle_process_paf.restype = C.c_int
     lib.oracle_process_paf.argtypes = [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip,
-                                       _fp, _ip, _ip, _fp]
+                                       _fp, _ip, _ip, _fp, _ip, C.c_int]
     return lib
 
 
@@ -84,8 +84,10 @@ def find_peaks_scipy(thr, img):
     return np.array(np.nonzero(peaks_binary)[::-1]).T
 
 
-def process_paf(joint_list, paf, up=8, max_humans=512):
-    """C restatement.  paf HWC [h,w,38] at network resolution.  Returns dict."""
+def process_paf(joint_list, paf, up=8, max_humans=512, libstdcxx_sort=False):
+    """C restatement.  paf HWC [h,w,38] at network resolution.  Returns dict.
+    libstdcxx_sort=True orders equal-score candidates the way the reference binary's
+    std::sort does (for comparisons with oracle/_ref); False = the product's contract."""
     jl = _f32(joint_list).reshape(-1, 5)
     paf = _f32(paf)
     h, w, _ = paf.shape
@@ -95,13 +97,15 @@ def process_paf(joint_list, paf, up=8, max_humans=512):
     lx = np.zeros(max(p, 1), np.int32)
     ly = np.zeros(max(p, 1), np.int32)
     ls = np.zeros(max(p, 1), np.float32)
+    ties = C.c_int(0)
     n = _post().oracle_process_paf(jl.ctypes.data_as(_fp), p, paf.ctypes.data_as(_fp), h, w, up, h * up,
                                    max_humans, parts.ctypes.data_as(_ip), score.ctypes.data_as(_fp),
-                                   lx.ctypes.data_as(_ip), ly.ctypes.data_as(_ip), ls.ctypes.data_as(_fp))
+                                   lx.ctypes.data_as(_ip), ly.ctypes.data_as(_ip), ls.ctypes.data_as(_fp),
+                                   C.byref(ties), 1 if libstdcxx_sort else 0)
     if n < 0:
         raise RuntimeError("oracle_process_paf failed (%d)" % n)
     return {"parts": parts[:n].copy(), "score": score[:n].copy(), "line_x": lx[:p], "line_y": ly[:p],
-            "line_score": ls[:p]}
+            "line_score": ls[:p], "had_ties": bool(ties.value)}
 
 
 def upsample_nearest(a, up):
@@ -134,5 +138,5 @@ def paf_to_pose(heat, paf, num_keypoints=18, thr=0.1, up=8):
     if jl.shape[0] == 0:
         return jl, {"parts": np.zeros((0, 18), np.int32), "score": np.zeros(0, np.float32),
                     "line_x": np.zeros(0, np.int32), "line_y": np.zeros(0, np.int32),
-                    "line_score": np.zeros(0, np.float32)}
+                    "line_score": np.zeros(0, np.float32), "had_ties": False}
     return jl, process_paf(jl, paf, up)
