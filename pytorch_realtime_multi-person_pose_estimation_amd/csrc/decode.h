@@ -4,7 +4,9 @@
 
 namespace rtpose {
 
-constexpr int kDecodeMaxPeaks = 128;  // per (image, part) table capacity limit
+constexpr int kDecodeMaxPeaks = 1024;  // per (image, part) table capacity limit
+constexpr int kLdsPairs = 110 * 110;   // candidate-score matrix entries that fit in LDS
+constexpr int kLdsRows = 720;          // subset rows (21 floats each) that fit in LDS
 
 // word (4-byte) offsets inside one image's result record
 constexpr int kResHeader = 0;      // [0] n_peaks [1] n_humans [2] overflow flags
@@ -23,15 +25,28 @@ __host__ __device__ inline int decode_result_words(const rtpose_decode_cfg* c) {
 inline int decode_conn_words(const rtpose_decode_cfg* c) {
   return RTPOSE_NUM_LIMB * (1 + 3 * c->max_peaks_per_part);
 }
-// subset rows alive at any time before pruning (LDS resident, 21 floats each)
+// subset rows alive at any time before pruning (21 floats each); LDS resident up to
+// kLdsRows, in the global workspace beyond
 inline int decode_row_cap(const rtpose_decode_cfg* c) {
   int r = 2 * c->max_humans;
   if (r < 64) r = 64;
-  if (r > 720) r = 720;
   return r;
 }
-inline size_t decode_workspace_bytes(const rtpose_decode_cfg* c, int N) {
+// workspace: [conn lists][candidate-score matrices when they exceed LDS][subset rows when
+// they exceed LDS]
+inline size_t decode_ws_conn_bytes(const rtpose_decode_cfg* c, int N) {
   return round_up((size_t)N * decode_conn_words(c) * sizeof(int32_t), 256);
+}
+inline size_t decode_ws_score_bytes(const rtpose_decode_cfg* c, int N) {
+  const size_t p = (size_t)c->max_peaks_per_part;
+  return p * p > (size_t)kLdsPairs ? round_up((size_t)N * RTPOSE_NUM_LIMB * p * p * sizeof(float), 256) : 0;
+}
+inline size_t decode_ws_rows_bytes(const rtpose_decode_cfg* c, int N) {
+  const int r = decode_row_cap(c);
+  return r > kLdsRows ? round_up((size_t)N * r * 21 * sizeof(float), 256) : 0;
+}
+inline size_t decode_workspace_bytes(const rtpose_decode_cfg* c, int N) {
+  return decode_ws_conn_bytes(c, N) + decode_ws_score_bytes(c, N) + decode_ws_rows_bytes(c, N);
 }
 
 int nms_launch(const float* heat, const rtpose_layout* lheat, int N, int h, int w,

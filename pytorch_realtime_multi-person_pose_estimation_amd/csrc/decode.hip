@@ -224,13 +224,13 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
                                                           int h1, int pcap,
                                                           const int32_t* __restrict__ result,
                                                           int result_words, int32_t* __restrict__ conn,
-                                                          int conn_words) {
+                                                          int conn_words, float* __restrict__ score_ws) {
   const int pair_id = blockIdx.x, n = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int32_t* res = result + (size_t)n * result_words;
   int32_t* cn = conn + (size_t)n * conn_words + (size_t)pair_id * (1 + 3 * pcap);
 
-  extern __shared__ float s_score[];  // [nA * nB] candidate scores, 0 = none
+  extern __shared__ float s_score_lds[];  // [nA * nB] candidate scores, 0 = none
   __shared__ unsigned char s_usedA[kDecodeMaxPeaks], s_usedB[kDecodeMaxPeaks];
   __shared__ float s_wbest[4];
   __shared__ int s_widx[4];
@@ -252,6 +252,11 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
   }
 
   const int npairs = nA * nB;
+  // the score matrix lives in LDS unless the tables were grown past what LDS holds
+  // (junk maps with hundreds of peaks per part): then in the global workspace
+  float* s_score = (pcap * pcap <= kLdsPairs)
+                       ? s_score_lds
+                       : score_ws + ((size_t)n * RTPOSE_NUM_LIMB + pair_id) * pcap * pcap;
   for (int p = tid; p < npairs; p += 256) {
     const int a = p / nB, b = p - a * nB;
     const rtpose_peak A = pA[a], B = pB[b];
@@ -285,6 +290,7 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
     }
     s_score[p] = cand;
   }
+  __threadfence_block();
   __syncthreads();
 
   // greedy: repeatedly take the best remaining candidate whose endpoints are
@@ -347,11 +353,14 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
 // ------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* __restrict__ result,
                                                    int result_words, const int32_t* __restrict__ conn,
-                                                   int conn_words, int row_cap) {
+                                                   int conn_words, int row_cap,
+                                                   float* __restrict__ rows_ws) {
   const int n = blockIdx.x, lane = threadIdx.x;
   int32_t* res = result + (size_t)n * result_words;
   const int32_t* cnb = conn + (size_t)n * conn_words;
-  extern __shared__ float rows[];  // [row_cap][20 + alive]: the reference's `subset`
+  extern __shared__ float rows_lds[];
+  // [row_cap][20 + alive]: the reference's `subset`; LDS unless grown past kLdsRows
+  float* rows = row_cap <= kLdsRows ? rows_lds : rows_ws + (size_t)n * row_cap * 21;
 
   __shared__ int s_start[RTPOSE_NUM_PART + 1];
   if (lane == 0) {
@@ -444,7 +453,8 @@ __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* 
           overflow = true;
         }
       }
-      __syncthreads();  // single-wave block: orders the LDS row updates
+      __threadfence_block();
+      __syncthreads();  // single-wave block: orders the row updates
     }
   }
 
@@ -519,18 +529,24 @@ int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int 
   const int conn_words = decode_conn_words(cfg);
   int32_t* res = static_cast<int32_t*>(result);
   int32_t* conn = static_cast<int32_t*>(workspace);
-  const size_t lds = (size_t)pcap * pcap * sizeof(float);
+  char* wsb = static_cast<char*>(workspace);
+  float* score_ws = reinterpret_cast<float*>(wsb + decode_ws_conn_bytes(cfg, N));
+  float* rows_ws = reinterpret_cast<float*>(wsb + decode_ws_conn_bytes(cfg, N) + decode_ws_score_bytes(cfg, N));
+  const size_t lds = pcap * pcap <= kLdsPairs ? (size_t)pcap * pcap * sizeof(float) : 0;
   static bool attr_set = false;
   if (!attr_set) {
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(limb_assign_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 8192));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     attr_set = true;
   }
   hipLaunchKernelGGL(limb_assign_kernel, dim3(RTPOSE_NUM_LIMB, N), dim3(256), lds, s, to_view(paf, lpaf), h,
-                     w, inv_up, h1, pcap, res, words, conn, conn_words);
+                     w, inv_up, h1, pcap, res, words, conn, conn_words, score_ws);
   const int row_cap = decode_row_cap(cfg);
-  hipLaunchKernelGGL(group_kernel, dim3(N), dim3(64), (size_t)row_cap * 21 * sizeof(float), s, pcap,
-                     cfg->max_humans, res, words, conn, conn_words, row_cap);
+  const size_t rows_lds = row_cap <= kLdsRows ? (size_t)row_cap * 21 * sizeof(float) : 0;
+  hipLaunchKernelGGL(group_kernel, dim3(N), dim3(64), rows_lds, s, pcap, cfg->max_humans, res, words, conn,
+                     conn_words, row_cap, rows_ws);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }

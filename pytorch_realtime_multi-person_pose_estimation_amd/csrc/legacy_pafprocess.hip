@@ -138,7 +138,7 @@ int process_paf(int p1, int p2, int p3, float* peaks, int h1, int h2, int h3, fl
     if (rc) return rc;
     RTPOSE_HIP_CHECK(hipMemcpy(host.data(), S.d_res, (size_t)words * 4, hipMemcpyDeviceToHost));
     if (host[kResHeader + 2] & kOverflowHumans) {
-      if (cfg.max_humans >= 360) return fail(RTPOSE_E_CAPACITY, "process_paf: too many candidate persons");
+      if (cfg.max_humans >= 16384) return fail(RTPOSE_E_CAPACITY, "process_paf: too many candidate persons");
       cfg.max_humans *= 2;
       continue;
     }

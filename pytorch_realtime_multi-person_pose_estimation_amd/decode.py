@@ -18,7 +18,8 @@ from .common import Human, BodyPart
 
 RES_HEADER, RES_PART_COUNT, RES_PEAKS = 0, 8, 32
 OVERFLOW_PEAKS, OVERFLOW_HUMANS = 1, 2
-MAX_PEAKS_LIMIT = 128
+MAX_PEAKS_LIMIT = 1024
+MAX_HUMANS_LIMIT = 16384
 
 
 def default_config():
@@ -114,9 +115,9 @@ def decode_maps(heat, paf, config=None, max_peaks_per_part=32, max_humans=64, nm
             max_peaks_per_part = min(2 * max_peaks_per_part, MAX_PEAKS_LIMIT)
             continue
         if flags & OVERFLOW_HUMANS:
-            if max_humans >= 360:
-                raise _capi.RtposeError("more than 360 person candidates in an image")
-            max_humans = min(2 * max_humans, 360)
+            if max_humans >= MAX_HUMANS_LIMIT:
+                raise _capi.RtposeError("more than %d person candidates in an image" % MAX_HUMANS_LIMIT)
+            max_humans = min(2 * max_humans, MAX_HUMANS_LIMIT)
             continue
         return [parse_image(recs[i], cfg) for i in range(n)]
 
@@ -140,6 +141,25 @@ def humans_from_record(rec, up_w, up_h, num_keypoints=18):
             human.score = float(rec["score"][hid])
             humans.append(human)
     return humans
+
+
+def NMS(heatmaps, upsampFactor=1., bool_refine_center=True, bool_gaussian_filt=False, config=None):
+    """Drop-in for lib/utils/paf_to_pose.py:67 — list (per joint type) of [K,4] float64 arrays
+    (x, y, score, id).  Only the reference's default flags are implemented (refine on, Gaussian
+    filter off — the reference never enables it, paf_to_pose.py:67,:121)."""
+    if not bool_refine_center or bool_gaussian_filt:
+        raise NotImplementedError("only bool_refine_center=True, bool_gaussian_filt=False (the reference defaults)")
+    config = config or default_config()
+    cfgc = types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_KEYPOINTS=config.MODEL.NUM_KEYPOINTS,
+                                                             DOWNSAMPLE=int(upsampFactor)),
+                                 TEST=config.TEST)
+    dev = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
+    if dev is None:
+        raise _capi.RtposeError("NMS needs an MI355X (HIP) device; there is no CPU fallback")
+    heat = torch.as_tensor(np.ascontiguousarray(heatmaps, dtype=np.float32)).to(dev)[None]
+    rec = decode_maps(heat, heat.new_zeros(1, heat.shape[1], heat.shape[2], 38), cfgc, nms_only=True)[0]
+    pk = rec["peaks"]
+    return [pk[pk[:, 4] == j][:, :4].astype(np.float64) for j in range(int(config.MODEL.NUM_KEYPOINTS))]
 
 
 def paf_to_pose_cpp(heatmaps, pafs, config):

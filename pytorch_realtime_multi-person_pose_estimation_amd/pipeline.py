@@ -64,8 +64,8 @@ class PoseEstimator(object):
             if flags & dec.OVERFLOW_PEAKS and self.max_peaks_per_part < dec.MAX_PEAKS_LIMIT:
                 self.max_peaks_per_part = min(2 * self.max_peaks_per_part, dec.MAX_PEAKS_LIMIT)
                 continue
-            if flags & dec.OVERFLOW_HUMANS and self.max_humans < 360:
-                self.max_humans = min(2 * self.max_humans, 360)
+            if flags & dec.OVERFLOW_HUMANS and self.max_humans < dec.MAX_HUMANS_LIMIT:
+                self.max_humans = min(2 * self.max_humans, dec.MAX_HUMANS_LIMIT)
                 continue
             if flags:
                 raise _capi.RtposeError("decode tables overflowed at maximum capacity (flags=%d)" % flags)

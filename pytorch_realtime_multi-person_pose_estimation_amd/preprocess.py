@@ -1,0 +1,141 @@
+"""Caller side of the boundary: evaluate/coco_eval.py:get_outputs (:80-114),
+handle_paf_and_heat (:197-242), append_result (:117-154) and the CPU image prep it
+calls (lib/network/im_transform.py:113-134, lib/datasets/preprocessing.py:16-43).
+
+The reference does this prep with cv2 on the host; cv2 is not in this image, so
+``cv2.resize(im, None, fx=s, fy=s)`` (INTER_LINEAR on uint8) is restated from
+OpenCV's published fixed-point algorithm (imgproc/resize.cpp: 11-bit coefficients,
+HResizeLinear -> VResizeLinear with the (x>>4, >>16, +2, >>2) rounding).  Parity of
+that restatement against a real OpenCV build is UNPINNED here; when cv2 is importable
+it is used instead.  The network + decoder that follow run on the GPU.
+"""
+import numpy as np
+import torch
+
+from . import _capi, decode as dec
+from ._capi import lib, check, ptr, current_stream
+
+try:  # pragma: no cover - not in this image
+    import cv2 as _cv2
+except Exception:  # noqa: BLE001
+    _cv2 = None
+
+ORDER_COCO = [0, 15, 14, 17, 16, 5, 2, 6, 3, 7, 4, 11, 8, 12, 9, 13, 10]   # coco_eval.py:52
+
+
+def _cv_round(x):
+    return int(np.rint(x))          # cvRound: round half to even
+
+
+def resize_linear_u8(im, fx, fy):
+    """cv2.resize(im, None, fx=fx, fy=fy) for uint8 HxWxC (INTER_LINEAR)."""
+    if _cv2 is not None:
+        return _cv2.resize(im, None, fx=fx, fy=fy)
+    h, w = im.shape[:2]
+    dw, dh = _cv_round(w * fx), _cv_round(h * fy)
+    sx_scale, sy_scale = 1.0 / fx, 1.0 / fy
+
+    def coeffs(dn, sn, scale):
+        d = np.arange(dn, dtype=np.float64)
+        f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0
+        f[lo], s[lo] = 0.0, 0
+        hi = s >= sn - 1
+        f[hi], s[hi] = 0.0, sn - 1
+        a1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        a0 = np.rint((np.float32(1.0) - f) * np.float32(2048)).astype(np.int64)
+        return s, np.minimum(s + 1, sn - 1), a0, a1
+
+    x0, x1, ax0, ax1 = coeffs(dw, w, sx_scale)
+    y0, y1, ay0, ay1 = coeffs(dh, h, sy_scale)
+    src = im.astype(np.int64)
+    if src.ndim == 2:
+        src = src[:, :, None]
+    hor = src[:, x0, :] * ax0[None, :, None] + src[:, x1, :] * ax1[None, :, None]      # int, x2048
+    s0, s1 = hor[y0], hor[y1]
+    out = ((((ay0[:, None, None] * (s0 >> 4)) >> 16) + ((ay1[:, None, None] * (s1 >> 4)) >> 16) + 2) >> 2)
+    out = np.clip(out, 0, 255).astype(np.uint8)
+    return out if im.ndim == 3 else out[:, :, 0]
+
+
+def _factor_closest(num, factor, is_ceil=True):
+    num = np.ceil(float(num) / factor) if is_ceil else np.floor(float(num) / factor)
+    return int(num) * factor
+
+
+def crop_with_factor(im, dest_size=None, factor=32, is_ceil=True):
+    """im_transform.py:119-134: short side -> dest_size, zero-pad right/bottom to a multiple of factor."""
+    im_scale = float(dest_size) / np.min(im.shape[0:2])
+    im = resize_linear_u8(im, im_scale, im_scale)
+    h, w, c = im.shape
+    new_h, new_w = _factor_closest(h, factor, is_ceil), _factor_closest(w, factor, is_ceil)
+    im_croped = np.zeros([new_h, new_w, c], dtype=im.dtype)
+    im_croped[0:h, 0:w, :] = im
+    return im_croped, im_scale, im.shape
+
+
+def rtpose_preprocess(image):
+    """preprocessing.py:16-21"""
+    image = image.astype(np.float32)
+    image = image / 256. - 0.5
+    return image.transpose((2, 0, 1)).astype(np.float32)
+
+
+def vgg_preprocess(image):
+    """preprocessing.py:32-43 (BGR -> RGB, /255, ImageNet mean/std)"""
+    image = image.astype(np.float32) / 255.
+    means, stds = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    out = image.copy()[:, :, ::-1]
+    for i in range(3):
+        out[:, :, i] = out[:, :, i] - means[i]
+        out[:, :, i] = out[:, :, i] / stds[i]
+    return out.transpose((2, 0, 1)).astype(np.float32)
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") else model
+
+
+def get_outputs(img, model, preprocess, config=None):
+    """coco_eval.py:80-114: BGR uint8 image -> (paf [h,w,38], heatmap [h,w,19], im_scale), HWC float32."""
+    config = config or dec.default_config()
+    im_croped, im_scale, _ = crop_with_factor(img, int(config.DATASET.IMAGE_SIZE),
+                                              factor=int(config.MODEL.DOWNSAMPLE), is_ceil=True)
+    if preprocess == 'rtpose':
+        im_data = rtpose_preprocess(im_croped)
+    elif preprocess == 'vgg':
+        im_data = vgg_preprocess(im_croped)
+    else:
+        raise ValueError("preprocess must be 'rtpose' or 'vgg'")
+    batch = torch.from_numpy(np.expand_dims(im_data, 0)).cuda().float()
+    predicted_outputs, _ = model(batch)
+    output1, output2 = predicted_outputs[-2], predicted_outputs[-1]
+    heatmap = output2.cpu().data.numpy().transpose(0, 2, 3, 1)[0]
+    paf = output1.cpu().data.numpy().transpose(0, 2, 3, 1)[0]
+    return paf, heatmap, im_scale
+
+
+def handle_paf_and_heat(normal_heat, flipped_heat, normal_paf, flipped_paf):
+    """coco_eval.py:197-242 on the GPU (csrc/layout_ops.hip:flip_merge_kernel)."""
+    dev = torch.device('cuda', torch.cuda.current_device())
+    t = [torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(dev)[None]
+         for a in (normal_heat, flipped_heat, normal_paf, flipped_paf)]
+    h, w = t[0].shape[1], t[0].shape[2]
+    oh, op = torch.empty_like(t[0]), torch.empty_like(t[2])
+    check(lib.rtpose_flip_merge(ptr(t[0]), ptr(t[1]), ptr(t[2]), ptr(t[3]), 1, h, w, ptr(oh), ptr(op),
+                                current_stream()), "rtpose_flip_merge")
+    return op[0].cpu().numpy(), oh[0].cpu().numpy()
+
+
+def append_result(image_id, humans, upsample_keypoints, outputs, num_keypoints=18):
+    """coco_eval.py:117-154: COCO keypoint-results records (score hard-coded to 1.0 there)."""
+    for human in humans:
+        keypoints = np.zeros((18, 3))
+        for i in range(num_keypoints):
+            if i in human.body_parts:
+                bp = human.body_parts[i]
+                keypoints[i] = (bp.x * upsample_keypoints[1] + 0.5, bp.y * upsample_keypoints[0] + 0.5, 1)
+        outputs.append({"image_id": image_id, "category_id": 1, "score": 1.,
+                        "keypoints": list(keypoints[ORDER_COCO, :].reshape(51))})

@@ -1,0 +1,86 @@
+"""The reference's own call sequence (demo/picture_demo.py:45-61, evaluate/coco_eval.py:270-272)
+executed against the drop-in import tree on the GPU, checked stage by stage against the oracle."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG_NAME, ROOT
+
+pytestmark = pytest.mark.gpu
+
+COMPAT = os.path.join(ROOT, PKG_NAME, "compat")
+
+
+@pytest.fixture(scope="module")
+def compat():
+    sys.path.insert(0, COMPAT)
+    yield
+    sys.path.remove(COMPAT)
+
+
+def test_picture_demo_flow(compat, cuda):
+    from lib.network.rtpose_vgg import get_model                      # picture_demo.py:21
+    from evaluate.coco_eval import get_outputs, handle_paf_and_heat    # :23
+    from lib.utils.common import Human, BodyPart, draw_humans          # :24
+    from lib.utils.paf_to_pose import paf_to_pose_cpp                  # :25
+    from lib.config import cfg                                         # :26
+    from oracle import net_oracle, post_oracle as po
+    pre = importlib.import_module(PKG_NAME + ".preprocess")
+
+    model = get_model('vgg19')
+    sd = net_oracle.he_init_state_dict(model, seed=0)
+    model.load_state_dict(sd)                                          # :46
+    model = torch.nn.DataParallel(model).cuda()                        # :47
+    model.float()
+    model.eval()
+
+    rng = np.random.default_rng(0)
+    ori = rng.integers(0, 256, (337, 356, 3), dtype=np.uint8)          # ski.jpg aspect (674x712) at half size
+    with torch.no_grad():
+        paf, heatmap, im_scale = get_outputs(ori, model, 'rtpose')     # :57-58
+    assert abs(im_scale - 368.0 / 337) < 1e-12
+    assert paf.shape == (46, 49, 38) and heatmap.shape == (46, 49, 19) and paf.dtype == np.float32
+
+    im_croped, _, _ = pre.crop_with_factor(ori, 368, factor=8, is_ceil=True)
+    x = torch.from_numpy(pre.rtpose_preprocess(im_croped)[None])
+    (paf_r, heat_r), _ = net_oracle.forward(sd, x)
+    assert np.abs(paf - paf_r[0].permute(1, 2, 0).numpy()).max() <= 1e-3
+    assert np.abs(heatmap - heat_r[0].permute(1, 2, 0).numpy()).max() <= 1e-3
+
+    humans = paf_to_pose_cpp(heatmap, paf, cfg)                        # :61
+    jl, r = po.paf_to_pose(heatmap, paf)                               # oracle on the SAME maps
+    assert len(humans) == len(r["parts"])
+    for hid, hm in enumerate(humans):
+        assert isinstance(hm, Human)
+        assert sorted(hm.body_parts) == [p for p in range(18) if r["parts"][hid, p] >= 0]
+        for p, bp in hm.body_parts.items():
+            assert isinstance(bp, BodyPart)
+            cid = r["parts"][hid, p]
+            assert (bp.x, bp.y) == (float(int(jl[cid, 0])) / (49 * 8), float(int(jl[cid, 1])) / (46 * 8))
+    out = draw_humans(ori, humans, imgcopy=True)                       # :63
+    assert out.shape == ori.shape
+
+    # flip TTA helper imported by the demo (coco_eval.py:197-242)
+    with torch.no_grad():
+        paf_f, heat_f, _ = get_outputs(ori[:, ::-1, :].copy(), model, 'rtpose')
+    avg_paf, avg_heat = handle_paf_and_heat(heatmap, heat_f, paf, paf_f)
+    assert avg_paf.shape == paf.shape and avg_heat.shape == heatmap.shape
+    assert np.isfinite(avg_paf).all()
+
+
+def test_nms_dropin_matches_oracle(compat, cuda):
+    from lib.utils.paf_to_pose import NMS
+    from lib.config import cfg
+    from oracle import post_oracle as po
+    z = np.load(os.path.join(ROOT, "tests", "golden", "post_scenes.npz"))
+    heat = z["heat2"]
+    per_type = NMS(heat, upsampFactor=cfg.MODEL.DOWNSAMPLE, config=cfg)   # paf_to_pose.py:374
+    jl = z["jl2"]
+    assert len(per_type) == 18
+    for j, arr in enumerate(per_type):
+        exp = jl[jl[:, 4] == j][:, :4]
+        assert arr.dtype == np.float64 and np.array_equal(arr.astype(np.float32), exp)

@@ -149,3 +149,31 @@ def test_two_rank_shard_and_gather_gloo(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
     assert p.returncode == 0 and "GATHER_OK" in p.stdout, p.stdout[-3000:]
+
+
+def test_resize_linear_restatement_close_to_float_bilinear(pkg):
+    """cv2.resize INTER_LINEAR (uint8, fixed point) restatement: identity at scale 1, within
+    1 LSB of a float half-pixel bilinear elsewhere, and the ski.jpg geometry of SURVEY §3.1."""
+    pre = importlib.import_module(PKG_NAME + ".preprocess")
+    rng = np.random.default_rng(0)
+    im = rng.integers(0, 256, (67, 71, 3), dtype=np.uint8)
+    assert np.array_equal(pre.resize_linear_u8(im, 1.0, 1.0), im)
+    s = 368.0 / 674
+    big = rng.integers(0, 256, (674, 712, 3), dtype=np.uint8)
+    out = pre.resize_linear_u8(big, s, s)
+    assert out.shape == (368, 389, 3)
+    t = torch.from_numpy(big).permute(2, 0, 1)[None].float()
+    ys = (np.arange(368) + 0.5) / s - 0.5
+    xs = (np.arange(389) + 0.5) / s - 0.5
+    y0 = np.clip(np.floor(ys).astype(int), 0, 673); x0 = np.clip(np.floor(xs).astype(int), 0, 711)
+    y1 = np.minimum(y0 + 1, 673); x1 = np.minimum(x0 + 1, 711)
+    fy = np.clip(ys - np.floor(ys), 0, 1)[:, None, None]; fx = np.clip(xs - np.floor(xs), 0, 1)[None, :, None]
+    fy[ys < 0] = 0; fx[:, xs < 0] = 0
+    b = big.astype(np.float64)
+    ref = (b[y0][:, x0] * (1 - fx) + b[y0][:, x1] * fx) * (1 - fy) + (b[y1][:, x0] * (1 - fx) + b[y1][:, x1] * fx) * fy
+    assert np.abs(out.astype(np.float64) - ref).max() <= 1.0
+    cropped, scale, shape = pre.crop_with_factor(big, 368, factor=8, is_ceil=True)
+    assert cropped.shape == (368, 392, 3) and shape == (368, 389, 3) and abs(scale - s) < 1e-15
+    assert not cropped[:, 389:].any()
+    x = pre.rtpose_preprocess(cropped)
+    assert x.shape == (3, 368, 392) and x.dtype == np.float32 and -0.5 <= x.min() and x.max() < 0.5
