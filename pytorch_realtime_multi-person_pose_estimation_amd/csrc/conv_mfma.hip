@@ -28,11 +28,22 @@
 //    hides under the other's MFMAs.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace rtpose {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+// Explicit global address space: if clang loses track of a pointer's provenance it
+// falls back to FLAT loads, which also tick lgkmcnt and drag every LDS read behind a
+// full `s_waitcnt vmcnt(0) lgkmcnt(0)` (seen in the tap loop; cost several %).
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef const floatx4 __attribute__((address_space(1)))* gcf4_t;
+__device__ __forceinline__ float4 gload4(const void* p) {
+  const floatx4 v = *(gcf4_t)(unsigned long long)(p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
 
 struct ConvGroup {
   const float* in;
@@ -71,8 +82,13 @@ __device__ __forceinline__ void tile_local_yx(int ml, int tw_log2, int& ty, int&
   tx = ((qi & ((1 << hw_log2) - 1)) << 1) + (ml & 1);
 }
 
-template <int KS, int CK, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
+// NBUF = 2: the next channel chunk's halo is fetched underneath the MFMAs into a second
+//           LDS buffer (2 blocks per CU).
+// NBUF = 1: one halo buffer, re-filled between chunks behind a barrier; half the LDS and
+//           <= 128 VGPRs, so 4 blocks share a CU and hide each other's refills
+//           (occupancy instead of software pipelining).
+template <int KS, int CK, int MODE, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const ConvArgs A) {
   constexpr int P = KS / 2;
   constexpr int CG = CK / 4;  // 16-byte channel groups per chunk
   constexpr int G = CK / 8;   // 8-deep k groups per chunk (4 MFMAs each)
@@ -88,7 +104,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
 
   const ConvGroup& g = A.g[blockIdx.z];
   const int QS = A.qs;
-  const int buf_floats = CG * QS * 4;
 
   // ---- block -> tile -------------------------------------------------------
   int m0 = 0, n_img = 0, y0 = 0, x0 = 0;  // MODE 0 uses m0; MODE 1 uses the rest
@@ -163,10 +178,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
     }
     return (size_t)q * in_cstride + pj * 4;
   };
-  auto piece_loff = [&](int set) -> int { return (pj * QS + set * PIXSET + ppix0) * 4; };
+  // LDS offsets are kept in float4 units: the compiler then knows every access is
+  // 16-byte aligned and emits ds_read_b128 / ds_write_b128 (with float offsets it fell
+  // back to ds_read2_b32 pairs: 2x the instructions and 4-way bank conflicts)
+  float4* smem4 = reinterpret_cast<float4*>(smem);
+  const int buf4 = CG * QS;  // float4 per halo buffer
+  auto piece_loff = [&](int set) -> int { return pj * QS + set * PIXSET + ppix0; };
   // a thread with nothing to park writes its stale registers to a private dummy slot
   // behind the two buffers, so the park step needs no per-thread branch
-  const int dummy_loff = 2 * buf_floats + tid * 4;
+  const int dummy_loff = NBUF * buf4 + tid;
   const int nsets = (np_total + 255) / 256;  // piece sets per chunk
 
   // ---- B operand pointers (advance one (chunk,tap) block per tap) ---------------
@@ -178,16 +198,33 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
     bq[gi] = reinterpret_cast<const float4*>(g.w) + (size_t)(2 * gi + kh) * g.cout_pad + ncol;
   const size_t b_it_stride = (size_t)CG * g.cout_pad;  // float4 per (chunk,tap)
 
-  float4 b0[G], b1[G];
+  // B lives in three register sets: the tap being multiplied, the next one, and the one
+  // in flight from L2 (two taps of lead: one tap was not enough to cover L2 latency
+  // under load - dropping the B loads was worth +7% on the 7x7 layers)
+  float4 s0[G], s1[G], s2[G];
 #pragma unroll
-  for (int gi = 0; gi < G; ++gi) b0[gi] = *bq[gi];
+  for (int gi = 0; gi < G; ++gi) {
+    s0[gi] = gload4(bq[gi]);
+    bq[gi] += b_it_stride;
+    s1[gi] = gload4(bq[gi]);
+  }
 
-  // ---- prologue: halo of chunk 0 ---------------------------------------------
-  for (int set = 0; set < nsets; ++set)
-    if (set * 256 + tid < np_total)
-      *reinterpret_cast<float4*>(smem + piece_loff(set)) =
-          *reinterpret_cast<const float4*>(in_base + piece_goff(set));
-  __syncthreads();
+  // ---- halo fill used by the prologue (NBUF 2) / before every chunk (NBUF 1) ------
+  auto fill_halo = [&](const float* src) {
+    for (int set0 = 0; set0 < nsets; set0 += 4) {
+      float4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)  // 4 loads in flight per thread
+        if ((set0 + u) * 256 + tid < np_total) t[u] = gload4(src + piece_goff(set0 + u));
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if ((set0 + u) * 256 + tid < np_total) smem4[piece_loff(set0 + u)] = t[u];
+    }
+  };
+  if (NBUF == 2) {
+    fill_halo(in_base);
+    __syncthreads();
+  }
 
   floatx16 acc[2];
 #pragma unroll
@@ -195,13 +232,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[fm][r] = 0.f;
 
-  // LDS float offsets of this lane's A fragments inside a halo buffer: [k-group][m-frag]
+  // LDS float4 offsets of this lane's A fragments inside a halo buffer: [k-group][m-frag]
   int afrag[G][2];
 #pragma unroll
   for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-    for (int fm = 0; fm < 2; ++fm) afrag[gi][fm] = ((2 * gi + kh) * QS + abase[fm]) * 4;
-  const int rowstep = row_lds * 4;  // floats per stencil row in the LDS image
+    for (int fm = 0; fm < 2; ++fm) afrag[gi][fm] = (2 * gi + kh) * QS + abase[fm];
+  const int rowstep = row_lds;  // float4 per stencil row in the LDS image
 
   // One tap = 8*G MFMAs with the loads for the NEXT tap threaded between them in a
   // fixed order: B straight from L2, A fragments from LDS (running row address +
@@ -210,6 +247,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
   // A wave issues MFMAs back to back on its own and the VALU port stays nearly idle:
   // measured, every VALU instruction in this loop costs MFMA issue slots once two
   // waves share a SIMD (tools/exp_variants.sh drops one load stream at a time).
+  // which B register (k-group) is fetched after MFMA pair n (-1 = none)
+#ifdef RTPOSE_EXP_BSPREAD
+#define RTPOSE_EXP_BSLOT(n) (((n) % 4 == 0 && (n) / 4 < G) ? (n) / 4 : -1)
+#else
+#define RTPOSE_EXP_BSLOT(n) (((n) == 0) ? 0 : (((n) == 1 && G > 1) ? 1 : (((n) == 5 && G > 2) ? 2 : (((n) == 6 && G > 3) ? 3 : -1))))
+#endif
 #ifdef RTPOSE_EXP_NO_B
 #define RTPOSE_EXP_B(load, keep) (keep)
 #else
@@ -230,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
 #define RTPOSE_PIN()                 \
   asm volatile("" ::: "memory");     \
   __builtin_amdgcn_sched_barrier(0)
-#define RTPOSE_CONV_STEP(ACUR, BCUR, ANXT, BNXT, KX, STAGE)                                    \
+#define RTPOSE_CONV_STEP(ACUR, ANXT, BCUR, BLOAD, KX, STAGE)                                   \
   {                                                                                            \
     _Pragma("unroll") for (int n = 0; n < 4 * G; ++n) {                                        \
       const int gi_ = n >> 2, j_ = n & 3;                                                      \
@@ -240,11 +283,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_[j_], bv_[j_], acc[0], 0, 0, 0);        \
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_[j_], bv_[j_], acc[1], 0, 0, 0);        \
       RTPOSE_PIN();                                                                            \
-      if (n == 0) {                                                                            \
-        _Pragma("unroll") for (int g2 = 0; g2 < G; ++g2) {                                     \
-          bq[g2] += b_it_stride;                                                               \
-          BNXT[g2] = RTPOSE_EXP_B(*bq[g2], BCUR[g2]);                                          \
-        }                                                                                      \
+      if (RTPOSE_EXP_BSLOT(n) >= 0) {                                                          \
+        const int g2 = RTPOSE_EXP_BSLOT(n);                                                    \
+        bq[g2] += b_it_stride;                                                                 \
+        BLOAD[g2] = RTPOSE_EXP_B(gload4(bq[g2]), BCUR[g2]);                                           \
       }                                                                                        \
       if (n == 1) {                                                                            \
         if ((KX) == KS - 1) { /* the next tap starts the next stencil row */                   \
@@ -255,9 +297,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
         }                                                                                      \
         if (((STAGE) & RTPOSE_EXP_STAGE) != 0) {                                                     \
           _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                                    \
-            *reinterpret_cast<float4*>(smem + hl[p]) = hv[p];                                  \
+            smem4[hl[p]] = hv[p];                                                              \
             const int set = ps * PPT + p;                                                      \
-            hv[p] = *reinterpret_cast<const float4*>(next_base + piece_goff(set));             \
+            hv[p] = gload4(next_base + piece_goff(set));                                       \
             hl[p] = (tid < np_total - set * 256) ? hn_off + piece_loff(set) : dummy_loff;      \
           }                                                                                    \
           ++ps;                                                                                \
@@ -265,27 +307,48 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
       }                                                                                        \
       if (n >= 2 && n - 2 < G) {                                                               \
         _Pragma("unroll") for (int fm = 0; fm < 2; ++fm)                                       \
-          ANXT[n - 2][fm] = RTPOSE_EXP_A(*reinterpret_cast<const float4*>(smem + arow[n - 2][fm] + (((KX) + 1 < KS) ? ((KX) + 1) * 4 : 0)), ACUR[n - 2][fm]); \
+          ANXT[n - 2][fm] = RTPOSE_EXP_A(smem4[arow[n - 2][fm] + (((KX) + 1 < KS) ? (KX) + 1 : 0)], ACUR[n - 2][fm]); \
       }                                                                                        \
       RTPOSE_PIN();                                                                            \
     }                                                                                          \
   }
-#define RTPOSE_CONV_ROW(STAGE)                                      \
-  {                                                                 \
-    _Pragma("unroll") for (int kx = 0; kx < KS; ++kx) {             \
-      if ((kx & 1) == 0) {                                          \
-        RTPOSE_CONV_STEP(a0, b0, a1, b1, kx, STAGE)                 \
-      } else {                                                      \
-        RTPOSE_CONV_STEP(a1, b1, a0, b0, kx, STAGE)                 \
-      }                                                             \
-    }                                                               \
-    if (KS & 1) { /* odd taps per row: the live set ended in (a1, b1) */ \
-      _Pragma("unroll") for (int gi = 0; gi < G; ++gi) {            \
-        b0[gi] = b1[gi];                                            \
-        a0[gi][0] = a1[gi][0];                                      \
-        a0[gi][1] = a1[gi][1];                                      \
-      }                                                             \
-    }                                                               \
+#define RTPOSE_CONV_ROW(STAGE)                                                  \
+  {                                                                             \
+    _Pragma("unroll") for (int kx = 0; kx < KS; ++kx) {                         \
+      /* A sets alternate (kx & 1); B sets rotate (kx % 3): multiply s[kx%3],  */ \
+      /* fill s[(kx+2)%3] with the tap two ahead                               */ \
+      if (kx % 6 == 0) {                                                        \
+        RTPOSE_CONV_STEP(a0, a1, s0, s2, kx, STAGE)                             \
+      } else if (kx % 6 == 1) {                                                 \
+        RTPOSE_CONV_STEP(a1, a0, s1, s0, kx, STAGE)                             \
+      } else if (kx % 6 == 2) {                                                 \
+        RTPOSE_CONV_STEP(a0, a1, s2, s1, kx, STAGE)                             \
+      } else if (kx % 6 == 3) {                                                 \
+        RTPOSE_CONV_STEP(a1, a0, s0, s2, kx, STAGE)                             \
+      } else if (kx % 6 == 4) {                                                 \
+        RTPOSE_CONV_STEP(a0, a1, s1, s0, kx, STAGE)                             \
+      } else {                                                                  \
+        RTPOSE_CONV_STEP(a1, a0, s2, s1, kx, STAGE)                             \
+      }                                                                         \
+    }                                                                           \
+    /* re-normalise the register roles for the next row (a few v_mov per row) */ \
+    _Pragma("unroll") for (int gi = 0; gi < G; ++gi) {                          \
+      if (KS & 1) {                                                             \
+        a0[gi][0] = a1[gi][0];                                                  \
+        a0[gi][1] = a1[gi][1];                                                  \
+      }                                                                         \
+      if (KS % 3 == 1) {                                                        \
+        const float4 t_ = s0[gi];                                               \
+        s0[gi] = s1[gi];                                                        \
+        s1[gi] = s2[gi];                                                        \
+        s2[gi] = t_;                                                            \
+      } else if (KS % 3 == 2) {                                                 \
+        const float4 t_ = s2[gi];                                               \
+        s2[gi] = s1[gi];                                                        \
+        s1[gi] = s0[gi];                                                        \
+        s0[gi] = t_;                                                            \
+      }                                                                         \
+    }                                                                           \
   }
 
   // rows of a chunk whose taps carry the staging code: set s is fetched at tap s and
@@ -294,8 +357,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
   float4 hv[PPT];
   int hl[PPT];
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const int hb_off = (chunk & 1) * buf_floats;
-    const int hn_off = ((chunk + 1) & 1) * buf_floats;
+    if (NBUF == 1) {  // every wave is past the previous chunk (barrier at the loop end)
+      fill_halo(in_base + (size_t)chunk * CK);
+      __syncthreads();
+    }
+#ifdef RTPOSE_EXP_STAGGER
+    // de-phase the four waves of the block after every barrier so that their B loads
+    // do not hit the vector-memory path in the same cycles
+    if (wave == 1) __builtin_amdgcn_s_sleep(RTPOSE_EXP_STAGGER);
+    if (wave == 2) __builtin_amdgcn_s_sleep(2 * RTPOSE_EXP_STAGGER);
+    if (wave == 3) __builtin_amdgcn_s_sleep(3 * RTPOSE_EXP_STAGGER);
+#endif
+    const int hb_off = NBUF == 2 ? (chunk & 1) * buf4 : 0;
+    const int hn_off = NBUF == 2 ? ((chunk + 1) & 1) * buf4 : 0;
     // the last chunk re-stages itself into the idle buffer (never read): no branch
     const float* next_base = in_base + (size_t)min(chunk + 1, nchunks - 1) * CK;
     int ps = 0;
@@ -304,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
       hv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
       hl[p] = dummy_loff;
     }
-    // running LDS addresses (floats) of this lane's fragments on the current stencil row
+    // running LDS addresses (float4 units) of this lane's fragments on the current stencil row
     int arow[G][2];
     float4 a0[G][2], a1[G][2];
 #pragma unroll
@@ -312,14 +386,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_f32(const ConvArgs A) {
 #pragma unroll
       for (int fm = 0; fm < 2; ++fm) {
         arow[gi][fm] = hb_off + afrag[gi][fm];
-        a0[gi][fm] = *reinterpret_cast<const float4*>(smem + arow[gi][fm]);  // tap (0,0)
+        a0[gi][fm] = smem4[arow[gi][fm]];  // tap (0,0)
       }
     int ky = 0;
-    for (; ky < stage_rows; ++ky) RTPOSE_CONV_ROW(1)
+    if (NBUF == 2)
+      for (; ky < stage_rows; ++ky) RTPOSE_CONV_ROW(1)
     for (; ky < KS; ++ky) RTPOSE_CONV_ROW(0)
-    // park whatever is still in flight, then publish the buffer
+    if (NBUF == 2) {  // park whatever is still in flight, then publish the buffer
 #pragma unroll
-    for (int p = 0; p < PPT; ++p) *reinterpret_cast<float4*>(smem + hl[p]) = hv[p];
+      for (int p = 0; p < PPT; ++p) smem4[hl[p]] = hv[p];
+    }
     __syncthreads();
   }
 #undef RTPOSE_CONV_ROW
@@ -424,9 +500,10 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __
 static int conv_ck(int cin) { return (cin % 16 == 0) ? 16 : 8; }
 
 struct ConvPlan {
-  int mode, ck, qs, hw_lds, tw_log2, tiles_x, tiles_y, grid_x;
+  int mode, ck, qs, hw_lds, tw_log2, tiles_x, tiles_y, grid_x, nbuf;
   size_t lds_bytes;
 };
+static int g_force_nbuf = 0;  // developer override (RTPOSE_CONV_NBUF=1|2)
 
 // LDS plane size: pixel count rounded so that the 4 channel-group planes of one
 // pixel land in different 16-byte bank slots on the staging writes.
@@ -448,14 +525,21 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* p
   const int M = N * H * W;
   const int max_pieces = (d.k == 1) ? PiecesPerTap<1>::value : d.k * d.k;  // per thread
   const int cg = pl->ck / 4;
+  if (!g_force_nbuf) {
+    const char* e = getenv("RTPOSE_CONV_NBUF");
+    g_force_nbuf = e ? atoi(e) : -1;
+  }
+  // 1x1 layers have one tap per chunk: nothing to hide a second buffer's fill under,
+  // so they take the single-buffer / 4-blocks-per-CU variant (measured 42.7 vs 32.6 TF/s)
+  pl->nbuf = (g_force_nbuf == 1 || g_force_nbuf == 2) ? g_force_nbuf : (d.k == 1 ? 1 : 2);
   bool strip = (W <= 64) && !d.pool;
   if (strip) {
     const rtpose_layout& l = d.lin;
     const int lb = (kBM - 1) + ((kBM - 1) / W + 1) * (l.ws - W) +
                    ((kBM - 1) / (H * W) + 1) * (l.hs - H) * l.ws + 2 * P * l.ws + 2 * P + 1;
     const int qs = round_qs(lb);
-    const size_t lds = (size_t)2 * cg * qs * 16 + 256 * 16;
-    if (ceil_div(qs * cg, 256) > max_pieces || lds > 80 * 1024) strip = false;
+    const size_t lds = (size_t)pl->nbuf * cg * qs * 16 + (pl->nbuf == 2 ? 256 * 16 : 0);
+    if ((pl->nbuf == 2 && ceil_div(qs * cg, 256) > max_pieces) || lds > 80 * 1024) strip = false;
     if (strip) {
       pl->mode = 0;
       pl->qs = qs;
@@ -491,16 +575,16 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* p
   pl->tiles_x = ceil_div(W, tw);
   pl->tiles_y = ceil_div(H, th);
   pl->grid_x = N * pl->tiles_x * pl->tiles_y;
-  pl->lds_bytes = (size_t)2 * cg * pl->qs * 16 + 256 * 16;
-  if (ceil_div(pl->qs * cg, 256) > max_pieces)
+  pl->lds_bytes = (size_t)pl->nbuf * cg * pl->qs * 16 + (pl->nbuf == 2 ? 256 * 16 : 0);
+  if (pl->nbuf == 2 && ceil_div(pl->qs * cg, 256) > max_pieces)
     return fail(RTPOSE_E_INVAL, "conv halo too large for the staging schedule");
   return 0;
 }
 
-template <int KS, int CK, int MODE>
+template <int KS, int CK, int MODE, int NBUF>
 static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = conv_mfma_f32<KS, CK, MODE>;
+  auto kern = conv_mfma_f32<KS, CK, MODE, NBUF>;
   if (!attr_set) {
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -566,9 +650,11 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
   a.tiles_x = pl.tiles_x;
   a.tiles_y = pl.tiles_y;
   dim3 grid(pl.grid_x, cout_pad(d0.cout) / kConvBN, ngroups);
-#define RTPOSE_CONV_CASE(KS_, CK_, MODE_)                     \
-  if (d0.k == KS_ && pl.ck == CK_ && pl.mode == MODE_)        \
-    return launch_inst<KS_, CK_, MODE_>(a, grid, pl.lds_bytes, s);
+#define RTPOSE_CONV_CASE(KS_, CK_, MODE_)                                  \
+  if (d0.k == KS_ && pl.ck == CK_ && pl.mode == MODE_) {                   \
+    if (pl.nbuf == 1) return launch_inst<KS_, CK_, MODE_, 1>(a, grid, pl.lds_bytes, s); \
+    return launch_inst<KS_, CK_, MODE_, 2>(a, grid, pl.lds_bytes, s);      \
+  }
   RTPOSE_CONV_CASE(3, 8, 0)
   RTPOSE_CONV_CASE(3, 8, 1)
   RTPOSE_CONV_CASE(3, 16, 0)
@@ -606,8 +692,8 @@ extern "C" {
 
 size_t rtpose_packed_weight_floats(int cout, int cin, int k) {
   const int cinp = rtpose::ceil_div(cin, 8) * 8;
-  // + one (chunk, tap) block of slack: the kernel's B prefetch runs one tap ahead
-  return (size_t)(k * k * cinp + 16) * rtpose::cout_pad(cout);
+  // + two (chunk, tap) blocks of slack: the kernel's B prefetch runs two taps ahead
+  return (size_t)(k * k * cinp + 32) * rtpose::cout_pad(cout);
 }
 size_t rtpose_packed_bias_floats(int cout) { return (size_t)rtpose::cout_pad(cout); }
 

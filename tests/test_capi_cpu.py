@@ -28,9 +28,9 @@ def test_every_declared_symbol_is_exported(capi):
 def test_version_and_sizes(capi):
     lib = capi.lib
     assert b"gfx950" in lib.rtpose_version()
-    # packed weights: (k*k * cin rounded to 8 + one tap of prefetch slack) * cout rounded to 64
-    assert lib.rtpose_packed_weight_floats(38, 185, 7) == (49 * 192 + 16) * 64
-    assert lib.rtpose_packed_weight_floats(64, 3, 3) == (9 * 8 + 16) * 64
+    # packed weights: (k*k * cin rounded to 8 + two taps of prefetch slack) * cout rounded to 64
+    assert lib.rtpose_packed_weight_floats(38, 185, 7) == (49 * 192 + 32) * 64
+    assert lib.rtpose_packed_weight_floats(64, 3, 3) == (9 * 8 + 32) * 64
     assert lib.rtpose_packed_bias_floats(19) == 64
     lay = capi.Layout.padded(192, 46, 46, 3)
     assert (lay.ws, lay.hs, lay.lead) == (49, 49, 3 * 49 + 3)

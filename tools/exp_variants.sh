@@ -17,7 +17,8 @@ build() { # name flags...
 }
 build base
 build nob -DRTPOSE_EXP_NO_B
-build noa -DRTPOSE_EXP_NO_A
-build nostage -DRTPOSE_EXP_NO_STAGE
-build none -DRTPOSE_EXP_NO_B -DRTPOSE_EXP_NO_A -DRTPOSE_EXP_NO_STAGE
+build stag1 -DRTPOSE_EXP_STAGGER=1
+build stag4 -DRTPOSE_EXP_STAGGER=4
+build bspread -DRTPOSE_EXP_BSPREAD
+build bspread_stag2 -DRTPOSE_EXP_BSPREAD -DRTPOSE_EXP_STAGGER=2
 ls -la tools/exp
