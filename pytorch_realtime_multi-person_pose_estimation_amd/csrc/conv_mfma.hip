@@ -64,6 +64,7 @@ struct ConvArgs {
   int hw_lds;         // MODE 1: LDS row stride of the halo (pixels)
   int tw_log2;        // MODE 1: log2(tile width); tile height = 128 >> tw_log2
   int tiles_x, tiles_y;
+  int mtiles, ntiles, nbig;  // MODE 0 block-id decoding (see conv_mfma_f32)
 };
 
 constexpr int kBM = 128;
@@ -87,14 +88,17 @@ __device__ __forceinline__ void tile_local_yx(int ml, int tw_log2, int& ty, int&
 // NBUF = 1: one halo buffer, re-filled between chunks behind a barrier; half the LDS and
 //           <= 128 VGPRs, so 4 blocks share a CU and hide each other's refills
 //           (occupancy instead of software pipelining).
-template <int KS, int CK, int MODE, int NBUF>
-__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const ConvArgs A) {
+// MF = 32-row M fragments per wave: 2 = the normal 128-pixel block tile, 1 = a 64-pixel
+// half tile used only for the last, partial wave of blocks of a strip-mode launch (tail
+// quantisation: see plan_conv).
+template <int KS, int CK, int MODE, int NBUF, int MF>
+__device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g, const int m0_arg,
+                                          const int ntile, float* smem) {
   constexpr int P = KS / 2;
+  constexpr int BMT = 64 * MF;  // pixels per block tile
   constexpr int CG = CK / 4;  // 16-byte channel groups per chunk
   constexpr int G = CK / 8;   // 8-deep k groups per chunk (4 MFMAs each)
   constexpr int PPT = PiecesPerTap<KS>::value;
-
-  extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -102,7 +106,6 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const Co
   const int wm = wave & 1, wn = wave >> 1;
   const int l31 = lane & 31, kh = lane >> 5;
 
-  const ConvGroup& g = A.g[blockIdx.z];
   const int QS = A.qs;
 
   // ---- block -> tile -------------------------------------------------------
@@ -110,12 +113,12 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const Co
   int q_origin, np_pix, row_lds;
   int qc0 = 0;
   if (MODE == 0) {
-    m0 = blockIdx.x * kBM;
+    m0 = m0_arg;
     const int HW = A.H * A.W;
     const int n = m0 / HW, r = m0 - n * HW;
     const int y = r / A.W, x = r - y * A.W;
     qc0 = g.in_lead + (n * g.in_hs + y) * g.in_ws + x;
-    int ml = min(m0 + kBM, A.M) - 1;
+    int ml = min(m0 + BMT, A.M) - 1;
     const int n2 = ml / HW, r2 = ml - n2 * HW;
     const int y2 = r2 / A.W, x2 = r2 - y2 * A.W;
     const int qcl = g.in_lead + (n2 * g.in_hs + y2) * g.in_ws + x2;
@@ -138,10 +141,10 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const Co
   const int np_total = np_pix * CG;  // 16-byte pieces per chunk
 
   // ---- per-lane A fragment bases (LDS pixel index of this lane's row) ------
-  int abase[2];
+  int abase[MF];
 #pragma unroll
-  for (int fm = 0; fm < 2; ++fm) {
-    const int ml = wm * 64 + fm * 32 + l31;
+  for (int fm = 0; fm < MF; ++fm) {
+    const int ml = wm * (32 * MF) + fm * 32 + l31;
     if (MODE == 0) {
       const int m = min(m0 + ml, A.M - 1);
       const int HW = A.H * A.W;
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const Co
 
   // ---- B operand pointers (advance one (chunk,tap) block per tap) ---------------
   const int nchunks = A.cin / CK;
-  const int ncol = blockIdx.y * kConvBN + wn * 32 + l31;
+  const int ncol = ntile * kConvBN + wn * 32 + l31;
   const float4* bq[G];
 #pragma unroll
   for (int gi = 0; gi < G; ++gi)
@@ -226,18 +229,18 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const Co
     __syncthreads();
   }
 
-  floatx16 acc[2];
+  floatx16 acc[MF];
 #pragma unroll
-  for (int fm = 0; fm < 2; ++fm)
+  for (int fm = 0; fm < MF; ++fm)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[fm][r] = 0.f;
 
   // LDS float4 offsets of this lane's A fragments inside a halo buffer: [k-group][m-frag]
-  int afrag[G][2];
+  int afrag[G][MF];
 #pragma unroll
   for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-    for (int fm = 0; fm < 2; ++fm) afrag[gi][fm] = (2 * gi + kh) * QS + abase[fm];
+    for (int fm = 0; fm < MF; ++fm) afrag[gi][fm] = (2 * gi + kh) * QS + abase[fm];
   const int rowstep = row_lds;  // float4 per stencil row in the LDS image
 
   // One tap = 8*G MFMAs with the loads for the NEXT tap threaded between them in a
@@ -278,10 +281,10 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const Co
     _Pragma("unroll") for (int n = 0; n < 4 * G; ++n) {                                        \
       const int gi_ = n >> 2, j_ = n & 3;                                                      \
       const float bv_[4] = {BCUR[gi_].x, BCUR[gi_].y, BCUR[gi_].z, BCUR[gi_].w};               \
-      const float a0_[4] = {ACUR[gi_][0].x, ACUR[gi_][0].y, ACUR[gi_][0].z, ACUR[gi_][0].w};   \
-      const float a1_[4] = {ACUR[gi_][1].x, ACUR[gi_][1].y, ACUR[gi_][1].z, ACUR[gi_][1].w};   \
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_[j_], bv_[j_], acc[0], 0, 0, 0);        \
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_[j_], bv_[j_], acc[1], 0, 0, 0);        \
+      _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) {                                      \
+        const float av_[4] = {ACUR[gi_][fm].x, ACUR[gi_][fm].y, ACUR[gi_][fm].z, ACUR[gi_][fm].w}; \
+        acc[fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[j_], bv_[j_], acc[fm], 0, 0, 0);    \
+      }                                                                                        \
       RTPOSE_PIN();                                                                            \
       if (RTPOSE_EXP_BSLOT(n) >= 0) {                                                          \
         const int g2 = RTPOSE_EXP_BSLOT(n);                                                    \
@@ -290,10 +293,8 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const Co
       }                                                                                        \
       if (n == 1) {                                                                            \
         if ((KX) == KS - 1) { /* the next tap starts the next stencil row */                   \
-          _Pragma("unroll") for (int g2 = 0; g2 < G; ++g2) {                                   \
-            arow[g2][0] += rowstep;                                                            \
-            arow[g2][1] += rowstep;                                                            \
-          }                                                                                    \
+          _Pragma("unroll") for (int g2 = 0; g2 < G; ++g2)                                     \
+            _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) arow[g2][fm] += rowstep;         \
         }                                                                                      \
         if (((STAGE) & RTPOSE_EXP_STAGE) != 0) {                                                     \
           _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                                    \
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const Co
         }                                                                                      \
       }                                                                                        \
       if (n >= 2 && n - 2 < G) {                                                               \
-        _Pragma("unroll") for (int fm = 0; fm < 2; ++fm)                                       \
+        _Pragma("unroll") for (int fm = 0; fm < MF; ++fm)                                      \
           ANXT[n - 2][fm] = RTPOSE_EXP_A(smem4[arow[n - 2][fm] + (((KX) + 1 < KS) ? (KX) + 1 : 0)], ACUR[n - 2][fm]); \
       }                                                                                        \
       RTPOSE_PIN();                                                                            \
@@ -334,8 +335,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const Co
     /* re-normalise the register roles for the next row (a few v_mov per row) */ \
     _Pragma("unroll") for (int gi = 0; gi < G; ++gi) {                          \
       if (KS & 1) {                                                             \
-        a0[gi][0] = a1[gi][0];                                                  \
-        a0[gi][1] = a1[gi][1];                                                  \
+        _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) a0[gi][fm] = a1[gi][fm]; \
       }                                                                         \
       if (KS % 3 == 1) {                                                        \
         const float4 t_ = s0[gi];                                               \
@@ -379,12 +379,12 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const Co
       hl[p] = dummy_loff;
     }
     // running LDS addresses (float4 units) of this lane's fragments on the current stencil row
-    int arow[G][2];
-    float4 a0[G][2], a1[G][2];
+    int arow[G][MF];
+    float4 a0[G][MF], a1[G][MF];
 #pragma unroll
     for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-      for (int fm = 0; fm < 2; ++fm) {
+      for (int fm = 0; fm < MF; ++fm) {
         arow[gi][fm] = hb_off + afrag[gi][fm];
         a0[gi][fm] = smem4[arow[gi][fm]];  // tap (0,0)
       }
@@ -408,11 +408,11 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const Co
   float* out_base = g.out + g.out_choff + ncol;
   if (!A.pool) {
 #pragma unroll
-    for (int fm = 0; fm < 2; ++fm) {
+    for (int fm = 0; fm < MF; ++fm) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         // rows rg*8 + 4*kh + {0,1,2,3}
-        const int ml0 = wm * 64 + fm * 32 + rg * 8 + 4 * kh;
+        const int ml0 = wm * (32 * MF) + fm * 32 + rg * 8 + 4 * kh;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int ml = ml0 + rr;
@@ -448,10 +448,10 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const Co
     const int Ho = A.H >> 1, Wo = A.W >> 1;
     const int hw_log2 = A.tw_log2 - 1;
 #pragma unroll
-    for (int fm = 0; fm < 2; ++fm) {
+    for (int fm = 0; fm < MF; ++fm) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int ml0 = wm * 64 + fm * 32 + rg * 8 + 4 * kh;
+        const int ml0 = wm * (32 * MF) + fm * 32 + rg * 8 + 4 * kh;
         const int qi = ml0 >> 2;
         const int py = (y0 >> 1) + (qi >> hw_log2);
         const int px = (x0 >> 1) + (qi & ((1 << hw_log2) - 1));
@@ -463,6 +463,32 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const Co
           out_base[q * g.out_cstride] = v;
         }
       }
+    }
+  }
+}
+
+// Kernel: block id -> (group, N tile, M tile).  MODE 1 uses the 3-D grid directly.  MODE 0
+// (strip) uses a 1-D grid so that the LAST blocks of the launch can be half tiles: ids
+// [0, nbig) are 128-pixel tiles in (m fastest, then n tile, then group) order, the rest
+// are pairs of 64-pixel halves of the remaining tiles (dispatched last = the tail).
+template <int KS, int CK, int MODE, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const ConvArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (MODE == 1) {
+    conv_tile<KS, CK, MODE, NBUF, 2>(A, A.g[blockIdx.z], 0, blockIdx.y, smem);
+  } else {
+    const int L = blockIdx.x;
+    const bool small = L >= A.nbig;
+    const int bi = small ? A.nbig + ((L - A.nbig) >> 1) : L;
+    const int mt = bi % A.mtiles;
+    const int r = bi / A.mtiles;
+    const int nt = r % A.ntiles;
+    const int grp = r / A.ntiles;
+    if (!small) {
+      conv_tile<KS, CK, MODE, NBUF, 2>(A, A.g[grp], mt * kBM, nt, smem);
+    } else {
+      const int m0 = mt * kBM + ((L - A.nbig) & 1) * (kBM / 2);
+      if (m0 < A.M) conv_tile<KS, CK, MODE, NBUF, 1>(A, A.g[grp], m0, nt, smem);
     }
   }
 }
@@ -650,6 +676,30 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
   a.tiles_x = pl.tiles_x;
   a.tiles_y = pl.tiles_y;
   dim3 grid(pl.grid_x, cout_pad(d0.cout) / kConvBN, ngroups);
+  if (pl.mode == 0) {
+    // Tail quantisation: `total` equal tiles on `slots` co-resident block slots run in
+    // lock-step rounds; a last round with few blocks leaves most CUs idle for a whole
+    // tile time.  When that remainder is small, split its tiles into two 64-pixel halves
+    // (twice the blocks, half the time).  32x46x46, cout 128 x 2 branches: 2116 tiles =
+    // 4 x 512 + 68 -> the last 68 become 136 halves.
+    static int n_cu = 0;
+    if (!n_cu) {
+      hipDeviceProp_t prop;
+      int dev = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        n_cu = prop.multiProcessorCount;
+      if (n_cu <= 0) n_cu = 256;
+    }
+    const int slots = n_cu * (pl.nbuf == 1 ? 4 : 2);
+    const int total = (int)(grid.x * grid.y * grid.z);
+    const int rem = total % slots;
+    a.mtiles = (int)grid.x;
+    a.ntiles = (int)grid.y;
+    a.nbig = total;
+    const char* e = getenv("RTPOSE_CONV_NO_HALF_TILES");
+    if (total > slots && rem > 0 && 2 * rem <= n_cu && !(e && e[0] == '1')) a.nbig = total - rem;
+    grid = dim3((unsigned)(a.nbig + 2 * (total - a.nbig)), 1, 1);
+  }
 #define RTPOSE_CONV_CASE(KS_, CK_, MODE_)                                  \
   if (d0.k == KS_ && pl.ck == CK_ && pl.mode == MODE_) {                   \
     if (pl.nbuf == 1) return launch_inst<KS_, CK_, MODE_, 1>(a, grid, pl.lds_bytes, s); \
