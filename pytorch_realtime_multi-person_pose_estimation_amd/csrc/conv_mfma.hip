@@ -300,8 +300,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
           _Pragma("unroll") for (int p = 0; p < PPT; ++p) {                                    \
             smem4[hl[p]] = hv[p];                                                              \
             const int set = ps * PPT + p;                                                      \
-            hv[p] = gload4(next_base + piece_goff(set));                                       \
-            hl[p] = (tid < np_total - set * 256) ? hn_off + piece_loff(set) : dummy_loff;      \
+            if (set < nsets) { /* uniform: sets past the halo are not fetched at all */        \
+              hv[p] = gload4(next_base + piece_goff(set));                                     \
+              hl[p] = (tid < np_total - set * 256) ? hn_off + piece_loff(set) : dummy_loff;    \
+            } else {                                                                           \
+              hv[p] = make_float4(0.f, 0.f, 0.f, 0.f);                                         \
+              hl[p] = dummy_loff;                                                              \
+            }                                                                                  \
           }                                                                                    \
           ++ps;                                                                                \
         }                                                                                      \
