@@ -107,6 +107,10 @@ typedef struct rtpose_conv_desc {
   int32_t relu; /* 0/1                                                      */
   int32_t pool; /* 0, or 1 = fuse MaxPool2d(2,2,0): `lout` is then the
                    half-resolution layout (rtpose_vgg.py:49-50)             */
+  const int32_t* out_cmap; /* device int32[cout] or NULL: output channel n is
+                   written at channel out_cmap[n] of the pixel (absolute, lout.choff
+                   ignored) - folds channel_shuffle / concat of the ShuffleNetV2
+                   blocks (rtpose_shufflenetV2.py:56-62) into the store        */
 } rtpose_conv_desc;
 
 /* Launch one conv, or `ngroups` (<= 2) convs of identical geometry in one
@@ -133,6 +137,31 @@ int rtpose_layout_to_nchw(const float* src, const rtpose_layout* lsrc,
 int rtpose_layout_copy(const float* src, const rtpose_layout* lsrc, float* dst,
                        const rtpose_layout* ldst, int C, int N, int H, int W,
                        void* stream);
+
+/* ---- ShuffleNetV2 building blocks (lib/network/rtpose_shufflenetV2.py) -------
+ * All HBM-bound, one pass.  BatchNorm (eval) is folded into weights/bias by the host. */
+/* NCHW -> layout with a per-channel affine (the input BatchNorm2d(3), :96);
+ * scale/shift: device float[C] or NULL. */
+int rtpose_nchw_to_layout_affine(const float* src_nchw, float* dst, const rtpose_layout* ldst,
+                                 int C, int cpad, int N, int H, int W, const float* scale,
+                                 const float* shift, void* stream);
+/* dense 3x3 stride-2 pad-1 conv for a tiny input channel count (stem, :97):
+ * w packed [ky][kx][cin_pad][cout] fp32, cout % 4 == 0, bias[cout], fused ReLU. */
+int rtpose_stem_conv3x3_s2(const float* in, const rtpose_layout* lin, const float* w,
+                           const float* bias, float* out, const rtpose_layout* lout,
+                           int cin_pad, int cout, int N, int H, int W, int relu, void* stream);
+/* MaxPool2d(3, 2, 0, ceil_mode=True) (:98) */
+int rtpose_maxpool3x3s2_ceil(const float* in, const rtpose_layout* lin, float* out,
+                             const rtpose_layout* lout, int C, int N, int H, int W, void* stream);
+/* depthwise 3x3, pad 1, stride 1 or 2 (+bias, no activation) (:35-38, :48-50);
+ * w [9][C] fp32 (tap-major), C % 4 == 0, input layout gap >= 1. */
+int rtpose_dwconv3x3(const float* in, const rtpose_layout* lin, const float* w, const float* bias,
+                     float* out, const rtpose_layout* lout, int C, int N, int H, int W, int stride,
+                     void* stream);
+/* dst[.., cmap[c]] = src[.., c] for c < C (cmap: device int32[C], absolute dst channel) */
+int rtpose_layout_copy_cmap(const float* src, const rtpose_layout* lsrc, float* dst,
+                            const rtpose_layout* ldst, int C, const int32_t* cmap, int N, int H,
+                            int W, void* stream);
 
 /* dst(n,y,x,c) = alpha * dst(n,y,x,c) + beta * src[n][y][x][c] over a layout
  * slice (src dense NHWC).  Not on the reference's path: bench.py and the tests
@@ -192,6 +221,36 @@ int rtpose_net_num_launches(const rtpose_net* net);
  * LAST forward, its conv kernel size (0 = not a conv), and algorithmic flops. */
 int rtpose_net_launch_info(rtpose_net* net, int i, float* ms, int* k,
                            double* flops, char* name, int name_cap);
+
+/* ------------------------------------------------------------------------
+ * 3b. The ShuffleNetV2 x1.0 pose network (lib/network/rtpose_shufflenetV2.py:80-148,
+ *     BASELINE config 4).  Same ownership rules as rtpose_net.  The host folds eval-mode
+ *     BatchNorm into each conv and loads layers in rtpose_shufflenet_layer_info order
+ *     (names are the reference state_dict prefixes, e.g. "network.3.0.conv0.1").
+ * ---------------------------------------------------------------------- */
+typedef struct rtpose_shufflenet rtpose_shufflenet;
+int rtpose_shufflenet_create(int N, int H, int W, rtpose_shufflenet** out);
+void rtpose_shufflenet_destroy(rtpose_shufflenet* net);
+size_t rtpose_shufflenet_workspace_bytes(const rtpose_shufflenet* net);
+size_t rtpose_shufflenet_weight_bytes(const rtpose_shufflenet* net);
+int rtpose_shufflenet_bind(rtpose_shufflenet* net, void* workspace, size_t workspace_bytes,
+                           void* weights, size_t weight_bytes, int zero_workspace, void* stream);
+int rtpose_shufflenet_num_layers(const rtpose_shufflenet* net);
+/* kind: 0 = input affine (w = scale[3], b = shift[3]), 1 = stem conv [24,3,3,3],
+ * 2 = depthwise [C,1,3,3], 3 = pointwise [cout,cin,1,1] */
+int rtpose_shufflenet_layer_info(const rtpose_shufflenet* net, int idx, char* name, int name_cap,
+                                 int* kind, int* cout, int* cin);
+int rtpose_shufflenet_load(rtpose_shufflenet* net, int idx, const float* w, const float* b,
+                           void* stream);
+int rtpose_shufflenet_forward(rtpose_shufflenet* net, const float* x_nchw, void* stream);
+/* which: 0 = PAF (38), 1 = heat-map (19) */
+int rtpose_shufflenet_read_output(rtpose_shufflenet* net, int which, float* dst_nchw, void* stream);
+int rtpose_shufflenet_output_view(const rtpose_shufflenet* net, int which, const float** base,
+                                  rtpose_layout* layout, int* C, int* H, int* W);
+int rtpose_shufflenet_set_profiling(rtpose_shufflenet* net, int enable);
+int rtpose_shufflenet_num_launches(const rtpose_shufflenet* net);
+int rtpose_shufflenet_launch_info(rtpose_shufflenet* net, int i, float* ms, double* flops, char* name,
+                                  int name_cap);
 
 /* ------------------------------------------------------------------------
  * 4. Batched pose decoding on the device

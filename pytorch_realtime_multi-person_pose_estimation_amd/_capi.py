@@ -38,7 +38,8 @@ class Layout(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [("inp", C.c_void_p), ("w_packed", C.c_void_p), ("bias_packed", C.c_void_p),
                 ("out", C.c_void_p), ("lin", Layout), ("lout", Layout), ("cin", C.c_int32),
-                ("cout", C.c_int32), ("k", C.c_int32), ("relu", C.c_int32), ("pool", C.c_int32)]
+                ("cout", C.c_int32), ("k", C.c_int32), ("relu", C.c_int32), ("pool", C.c_int32),
+                ("out_cmap", C.c_void_p)]
 
 
 class DecodeCfg(C.Structure):
@@ -73,6 +74,11 @@ _SIGS = {
     "rtpose_nchw_to_layout": (_i, [_vp, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
     "rtpose_layout_to_nchw": (_i, [_vp, _LP, _vp, _i, _i, _i, _i, _vp]),
     "rtpose_layout_copy": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, _i, _vp]),
+    "rtpose_nchw_to_layout_affine": (_i, [_vp, _vp, _LP, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "rtpose_stem_conv3x3_s2": (_i, [_vp, _LP, _vp, _vp, _vp, _LP, _i, _i, _i, _i, _i, _i, _vp]),
+    "rtpose_maxpool3x3s2_ceil": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, _i, _vp]),
+    "rtpose_dwconv3x3": (_i, [_vp, _LP, _vp, _vp, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
+    "rtpose_layout_copy_cmap": (_i, [_vp, _LP, _vp, _LP, _i, _vp, _i, _i, _i, _vp]),
     "rtpose_layout_axpby": (_i, [_vp, _LP, _vp, _i, _i, _i, _i, C.c_float, C.c_float, _vp]),
     "rtpose_net_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
     "rtpose_net_destroy": (None, [_vp]),
@@ -89,6 +95,20 @@ _SIGS = {
     "rtpose_net_set_profiling": (_i, [_vp, _i]),
     "rtpose_net_num_launches": (_i, [_vp]),
     "rtpose_net_launch_info": (_i, [_vp, _i, C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(C.c_double), C.c_char_p, _i]),
+    "rtpose_shufflenet_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
+    "rtpose_shufflenet_destroy": (None, [_vp]),
+    "rtpose_shufflenet_workspace_bytes": (_sz, [_vp]),
+    "rtpose_shufflenet_weight_bytes": (_sz, [_vp]),
+    "rtpose_shufflenet_bind": (_i, [_vp, _vp, _sz, _vp, _sz, _i, _vp]),
+    "rtpose_shufflenet_num_layers": (_i, [_vp]),
+    "rtpose_shufflenet_layer_info": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "rtpose_shufflenet_load": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "rtpose_shufflenet_forward": (_i, [_vp, _vp, _vp]),
+    "rtpose_shufflenet_read_output": (_i, [_vp, _i, _vp, _vp]),
+    "rtpose_shufflenet_output_view": (_i, [_vp, _i, C.POINTER(_vp), _LP, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "rtpose_shufflenet_set_profiling": (_i, [_vp, _i]),
+    "rtpose_shufflenet_num_launches": (_i, [_vp]),
+    "rtpose_shufflenet_launch_info": (_i, [_vp, _i, C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_char_p, _i]),
     "rtpose_decode_workspace_bytes": (_sz, [C.POINTER(DecodeCfg), _i]),
     "rtpose_decode_result_bytes": (_sz, [C.POINTER(DecodeCfg), _i]),
     "rtpose_decode_batch": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, C.POINTER(DecodeCfg), _vp, _sz, _vp, _vp]),

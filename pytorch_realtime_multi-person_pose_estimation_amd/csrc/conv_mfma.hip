@@ -53,6 +53,7 @@ struct ConvGroup {
   int in_cstride, in_choff, in_ws, in_hs, in_lead;
   int out_cstride, out_choff, out_ws, out_hs, out_lead;
   int cout, cout_pad;
+  const int32_t* out_cmap;  // optional output-channel scatter (see rtpose_conv_desc)
 };
 
 struct ConvArgs {
@@ -410,7 +411,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   // ---- epilogue: bias (+ReLU) (+2x2 max-pool), masked stores -----------------
   const bool col_ok = ncol < g.cout;
   const float bias = g.bias[ncol];  // bias is padded to cout_pad
-  float* out_base = g.out + g.out_choff + ncol;
+  float* out_base = g.out + ((g.out_cmap && col_ok) ? g.out_cmap[ncol] : g.out_choff + ncol);
   if (!A.pool) {
 #pragma unroll
     for (int fm = 0; fm < MF; ++fm) {
@@ -663,6 +664,7 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
     g.out_lead = di.lout.lead;
     g.cout = di.cout;
     g.cout_pad = cout_pad(di.cout);
+    g.out_cmap = di.out_cmap;
   }
   if (d0.pool && ((H | W) & 1)) return fail(RTPOSE_E_INVAL, "conv2d: fused pool needs even H and W");
   ConvPlan pl;

@@ -172,6 +172,144 @@ __global__ void layout_axpby_kernel(float* __restrict__ dst, Lay ld, const float
   *d = alpha * *d + beta * src[i];
 }
 
+// ---- ShuffleNetV2 building blocks (lib/network/rtpose_shufflenetV2.py) ----------------
+// NCHW -> layout with y = x * scale[c] + shift[c] (BatchNorm2d(3) on the input, :96).
+__global__ void nchw_to_layout_affine_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                             Lay l, int C, int cpad, int N, int H, int W,
+                                             const float* __restrict__ scale,
+                                             const float* __restrict__ shift) {
+  const size_t total = (size_t)N * H * W * cpad;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = i % cpad;
+  size_t p = i / cpad;
+  const int x = p % W;
+  p /= W;
+  const int y = p % H;
+  const int n = p / H;
+  float v = 0.f;
+  if (c < C) {
+    v = src[(((size_t)n * C + c) * H + y) * W + x];
+    if (scale) v = v * scale[c] + shift[c];
+  }
+  dst[lay_off(l, n, y, x) + c] = v;
+}
+
+// 3x3 stride-2 pad-1 dense conv, tiny cin (stem 3->24, :97).  One thread = one output
+// pixel x 4 output channels; w[ky][kx][cin_pad][cout].  The input layout's zero gaps are
+// the padding, so no bounds tests (the top/left halo of pixel (0,0) is the lead gap).
+__global__ void stem_conv3x3_s2_kernel(const float* __restrict__ in, Lay li, const float* __restrict__ w,
+                                       const float* __restrict__ bias, float* __restrict__ out, Lay lo,
+                                       int cin_pad, int cout, int N, int Ho, int Wo, int relu) {
+  const int c4 = cout >> 2;
+  const size_t total = (size_t)N * Ho * Wo * c4;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int co = (i % c4) * 4;
+  size_t p = i / c4;
+  const int x = p % Wo;
+  p /= Wo;
+  const int y = p % Ho;
+  const int n = p / Ho;
+  float4 acc = *reinterpret_cast<const float4*>(bias + co);
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) {
+      // input pixel (2y+ky-1, 2x+kx-1): offsets of -1 land in the layout gaps
+      const float* ip = in + (long long)lay_off(li, n, 2 * y + ky, 2 * x + kx) -
+                        (long long)(li.ws + 1) * li.cstride;
+      const float* wp = w + ((size_t)(ky * 3 + kx) * cin_pad) * cout + co;
+      for (int c = 0; c < cin_pad; ++c) {
+        const float v = ip[c];
+        const float4 ww = *reinterpret_cast<const float4*>(wp + (size_t)c * cout);
+        acc.x += v * ww.x;
+        acc.y += v * ww.y;
+        acc.z += v * ww.z;
+        acc.w += v * ww.w;
+      }
+    }
+  if (relu) {
+    acc.x = fmaxf(acc.x, 0.f);
+    acc.y = fmaxf(acc.y, 0.f);
+    acc.z = fmaxf(acc.z, 0.f);
+    acc.w = fmaxf(acc.w, 0.f);
+  }
+  *reinterpret_cast<float4*>(out + lay_off(lo, n, y, x) + co) = acc;
+}
+
+// MaxPool2d(3, 2, 0, ceil_mode=True): windows are clipped to the input.
+__global__ void maxpool3x3s2_ceil_kernel(const float* __restrict__ src, Lay ls, float* __restrict__ dst,
+                                         Lay ld, int C, int N, int H, int W, int Ho, int Wo) {
+  const int c4 = C >> 2;
+  const size_t total = (size_t)N * Ho * Wo * c4;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (i % c4) * 4;
+  size_t p = i / c4;
+  const int x = p % Wo;
+  p /= Wo;
+  const int y = p % Ho;
+  const int n = p / Ho;
+  float4 r = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  for (int dy = 0; dy < 3; ++dy)
+    for (int dx = 0; dx < 3; ++dx) {
+      const int yy = 2 * y + dy, xx = 2 * x + dx;
+      if (yy < H && xx < W) {
+        const float4 v = *reinterpret_cast<const float4*>(src + lay_off(ls, n, yy, xx) + c);
+        r.x = fmaxf(r.x, v.x);
+        r.y = fmaxf(r.y, v.y);
+        r.z = fmaxf(r.z, v.z);
+        r.w = fmaxf(r.w, v.w);
+      }
+    }
+  *reinterpret_cast<float4*>(dst + lay_off(ld, n, y, x) + c) = r;
+}
+
+// depthwise 3x3, pad 1 (the input layout's zero gaps), stride 1 or 2, + bias; w[9][C].
+__global__ void dwconv3x3_kernel(const float* __restrict__ in, Lay li, const float* __restrict__ w,
+                                 const float* __restrict__ bias, float* __restrict__ out, Lay lo, int C,
+                                 int N, int Ho, int Wo, int stride) {
+  const int c4 = C >> 2;
+  const size_t total = (size_t)N * Ho * Wo * c4;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (i % c4) * 4;
+  size_t p = i / c4;
+  const int x = p % Wo;
+  p /= Wo;
+  const int y = p % Ho;
+  const int n = p / Ho;
+  float4 acc = *reinterpret_cast<const float4*>(bias + c);
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const float* ip = in + (long long)lay_off(li, n, stride * y + ky, stride * x + kx) -
+                        (long long)(li.ws + 1) * li.cstride + c;
+      const float4 v = *reinterpret_cast<const float4*>(ip);
+      const float4 ww = *reinterpret_cast<const float4*>(w + (size_t)(ky * 3 + kx) * C + c);
+      acc.x += v.x * ww.x;
+      acc.y += v.y * ww.y;
+      acc.z += v.z * ww.z;
+      acc.w += v.w * ww.w;
+    }
+  *reinterpret_cast<float4*>(out + lay_off(lo, n, y, x) + c) = acc;
+}
+
+__global__ void layout_copy_cmap_kernel(const float* __restrict__ src, Lay ls, float* __restrict__ dst,
+                                        Lay ld, int C, const int32_t* __restrict__ cmap, int N, int H,
+                                        int W) {
+  const size_t total = (size_t)N * H * W * C;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = i % C;
+  size_t p = i / C;
+  const int x = p % W;
+  p /= W;
+  const int y = p % H;
+  const int n = p / H;
+  dst[lay_off(ld, n, y, x) - ld.choff + cmap[c]] = src[lay_off(ls, n, y, x) + c];
+}
+
 static inline unsigned nblocks(size_t total, int threads) {
   return (unsigned)((total + threads - 1) / threads);
 }
@@ -243,6 +381,72 @@ int rtpose_maxpool2x2(const float* in, const rtpose_layout* lin, float* out, con
   if (!total) return 0;
   hipLaunchKernelGGL(maxpool2x2_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), in,
                      to_lay(lin), out, to_lay(lout), C, N, Ho, Wo);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_nchw_to_layout_affine(const float* src, float* dst, const rtpose_layout* ldst, int C, int cpad,
+                                 int N, int H, int W, const float* scale, const float* shift,
+                                 void* stream) {
+  if (cpad < C || ldst->choff + cpad > ldst->cstride || (scale && !shift))
+    return fail(RTPOSE_E_INVAL, "nchw_to_layout_affine: bad arguments");
+  const size_t total = (size_t)N * H * W * cpad;
+  if (!total) return 0;
+  hipLaunchKernelGGL(nchw_to_layout_affine_kernel, dim3(nblocks(total, 256)), dim3(256), 0,
+                     as_stream(stream), src, dst, to_lay(ldst), C, cpad, N, H, W, scale, shift);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_stem_conv3x3_s2(const float* in, const rtpose_layout* lin, const float* w, const float* bias,
+                           float* out, const rtpose_layout* lout, int cin_pad, int cout, int N, int H,
+                           int W, int relu, void* stream) {
+  if ((cout % 4) || (lout->cstride % 4) || (lout->choff % 4) || lin->ws < W + 1 || lin->hs < H + 1 ||
+      lin->lead < lin->ws + 1 || lin->choff + cin_pad > lin->cstride)
+    return fail(RTPOSE_E_INVAL, "stem_conv: unsupported layout / channel count");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const size_t total = (size_t)N * Ho * Wo * (cout / 4);
+  if (!total) return 0;
+  hipLaunchKernelGGL(stem_conv3x3_s2_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), in,
+                     to_lay(lin), w, bias, out, to_lay(lout), cin_pad, cout, N, Ho, Wo, relu);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_maxpool3x3s2_ceil(const float* in, const rtpose_layout* lin, float* out, const rtpose_layout* lout,
+                             int C, int N, int H, int W, void* stream) {
+  if ((C % 4) || (lin->cstride % 4) || (lin->choff % 4) || (lout->cstride % 4) || (lout->choff % 4) || H < 3 ||
+      W < 3)
+    return fail(RTPOSE_E_INVAL, "maxpool3x3s2: channel slices must be 16-byte aligned, H,W >= 3");
+  const int Ho = (H - 3 + 1) / 2 + 1, Wo = (W - 3 + 1) / 2 + 1;  // ceil((H-3)/2)+1
+  const size_t total = (size_t)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_ceil_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), in,
+                     to_lay(lin), out, to_lay(lout), C, N, H, W, Ho, Wo);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_dwconv3x3(const float* in, const rtpose_layout* lin, const float* w, const float* bias, float* out,
+                     const rtpose_layout* lout, int C, int N, int H, int W, int stride, void* stream) {
+  if ((C % 4) || (lin->cstride % 4) || (lin->choff % 4) || (lout->cstride % 4) || (lout->choff % 4) ||
+      (stride != 1 && stride != 2) || lin->ws < W + 1 || lin->hs < H + 1 || lin->lead < lin->ws + 1)
+    return fail(RTPOSE_E_INVAL, "dwconv3x3: unsupported layout / stride");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const size_t total = (size_t)N * Ho * Wo * (C / 4);
+  if (!total) return 0;
+  hipLaunchKernelGGL(dwconv3x3_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), in,
+                     to_lay(lin), w, bias, out, to_lay(lout), C, N, Ho, Wo, stride);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_layout_copy_cmap(const float* src, const rtpose_layout* lsrc, float* dst, const rtpose_layout* ldst,
+                            int C, const int32_t* cmap, int N, int H, int W, void* stream) {
+  if (!cmap) return fail(RTPOSE_E_INVAL, "layout_copy_cmap: cmap is NULL");
+  const size_t total = (size_t)N * H * W * C;
+  if (!total) return 0;
+  hipLaunchKernelGGL(layout_copy_cmap_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), src,
+                     to_lay(lsrc), dst, to_lay(ldst), C, cmap, N, H, W);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -463,6 +463,7 @@ int rtpose_net_forward(rtpose_net* net, const float* x_nchw, void* stream) {
           d[g].k = c.k;
           d[g].relu = o.relu;
           d[g].pool = o.pool;
+          d[g].out_cmap = nullptr;
         }
         rc = conv2d_launch(d, o.ngroups, N, o.H, o.W, s);
         break;

@@ -1,0 +1,585 @@
+// Native executor for the ShuffleNetV2 x1.0 pose network
+// (lib/network/rtpose_shufflenetV2.py: BasicBlock :22-63, Network :80-148) —
+// BASELINE config 4, the small-model / memory-bound path.
+//
+// Same design rules as net.hip: fixed launch list for (N,H,W), caller-owned workspace
+// and weight arena, shared-gap padded NHWC activations.  Specific to this network:
+//  * BatchNorm (eval) is folded into the conv weights/bias by the host; only the input
+//    BatchNorm2d(3) (:96) stays an explicit per-channel affine, applied while converting
+//    NCHW -> NHWC (it sits in front of a zero-padded conv, so it cannot be folded).
+//  * torch.cat + channel_shuffle(2) (:56-62) never run: the two producers of a block
+//    write their channels directly at the interleaved (even / odd) positions of the next
+//    buffer - the 1x1 convs through the conv kernel's out_cmap, the pass-through half
+//    through one strided copy.
+//  * Stage buffers keep each half padded to a multiple of 8 channels ([h | pad | h | pad])
+//    so both halves are 16-byte aligned slices for the MFMA 1x1 kernel; logical channel j
+//    lives at physical f(j) = j < h ? j : hp + j - h.  Reading a whole such buffer (first
+//    block of the next stage) goes through cin_map at weight-pack time.
+//  * `downsample` leaks out of stage 1 in the reference (:113-117): the first block of
+//    BOTH stride-1 stages is the two-branch block.  Reproduced.
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace rtpose {
+int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
+int pack_weights_launch(const float* w, const float* bias, int cout, int cin_src, int k,
+                        const int32_t* cin_map, int cin_packed, float* wp, float* bp, hipStream_t s);
+
+// w[C][1][3][3] (+bias[C]) -> wp[9][cphys], bp[cphys]; phys channel p reads logical pmap[p] (-1: zero)
+__global__ void pack_dw_kernel(const float* __restrict__ w, const float* __restrict__ b, int C,
+                               const int32_t* __restrict__ pmap, int cphys, float* __restrict__ wp,
+                               float* __restrict__ bp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 10 * cphys) return;
+  const int t = i / cphys, p = i - t * cphys;
+  const int c = pmap ? pmap[p] : (p < C ? p : -1);
+  if (t < 9)
+    wp[i] = (c >= 0 && c < C) ? w[c * 9 + t] : 0.f;
+  else
+    bp[p] = (c >= 0 && c < C && b) ? b[c] : 0.f;
+}
+
+// w[cout][cin][3][3] -> wp[ky][kx][cin_pad][cout]
+__global__ void pack_stem_kernel(const float* __restrict__ w, int cout, int cin, int cin_pad,
+                                 float* __restrict__ wp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 9 * cin_pad * cout) return;
+  const int co = i % cout;
+  int r = i / cout;
+  const int c = r % cin_pad;
+  const int t = r / cin_pad;
+  wp[i] = c < cin ? w[((size_t)co * cin + c) * 9 + t] : 0.f;
+}
+}  // namespace rtpose
+
+using namespace rtpose;
+
+namespace {
+
+enum LKind { L_AFFINE, L_STEM, L_DW, L_PW };
+
+struct SLayer {
+  LKind kind;
+  std::string name;
+  int cout = 0, cin = 0;      // logical
+  int cin_packed = 0;         // L_PW: packed input channels; L_DW: physical channels
+  int map_id = -1;            // index into maps (cin_map for PW, phys->logical for DW), -1 identity
+  size_t w_off = 0, b_off = 0;
+};
+
+struct SBuf {
+  size_t off = 0;
+  rtpose_layout lay{};
+  int C = 0, H = 0, W = 0;
+};
+
+enum OKind { O_INPUT, O_STEM, O_POOL3, O_DW, O_PW, O_COPYMAP };
+
+struct SOp {
+  OKind kind;
+  std::string name;
+  int H = 0, W = 0;            // input spatial size of the op
+  int ngroups = 1;
+  int layer[2] = {-1, -1};
+  int in_buf[2] = {-1, -1}, in_choff[2] = {0, 0};
+  int out_buf[2] = {-1, -1}, out_choff[2] = {0, 0};
+  int cmap[2] = {-1, -1};      // map ids (out_cmap / copy map)
+  int relu = 0, stride = 1, C = 0;
+  double flops = 0;
+};
+
+struct Map {
+  std::vector<int32_t> v;
+  size_t off = 0;  // float-slot offset in the weight arena
+};
+
+}  // namespace
+
+struct rtpose_shufflenet {
+  int N = 0, H = 0, W = 0, Hm = 0, Wm = 0;  // Hm x Wm: stride-8 maps
+  std::vector<SBuf> bufs;
+  std::vector<SLayer> layers;
+  std::vector<SOp> ops;
+  std::vector<Map> maps;
+  size_t ws_floats = 0, wt_floats = 0;
+  float* ws = nullptr;
+  float* wt = nullptr;
+  bool bound = false;
+  int out_buf = -1;
+  int profiling = 0;
+  std::vector<hipEvent_t> ev;
+  bool ev_valid = false;
+};
+
+namespace {
+
+int add_buf(rtpose_shufflenet* n, int C, int P, int H, int W) {
+  SBuf b;
+  b.C = C;
+  b.H = H;
+  b.W = W;
+  b.lay.cstride = C;
+  b.lay.choff = 0;
+  b.lay.ws = W + P;
+  b.lay.hs = H + P;
+  b.lay.lead = P * (W + P) + P;
+  b.off = n->ws_floats;
+  n->ws_floats += round_up(rtpose_layout_pixels(&b.lay, n->N, H, W) * (size_t)C, 64);
+  n->bufs.push_back(b);
+  return (int)n->bufs.size() - 1;
+}
+
+int add_map(rtpose_shufflenet* n, const std::vector<int32_t>& v) {
+  Map m;
+  m.v = v;
+  m.off = n->wt_floats;
+  n->wt_floats += round_up(v.size(), 64);
+  n->maps.push_back(m);
+  return (int)n->maps.size() - 1;
+}
+
+int add_layer(rtpose_shufflenet* n, LKind kind, const std::string& name, int cout, int cin, int cin_packed,
+              int map_id) {
+  SLayer l;
+  l.kind = kind;
+  l.name = name;
+  l.cout = cout;
+  l.cin = cin;
+  l.cin_packed = cin_packed;
+  l.map_id = map_id;
+  l.w_off = n->wt_floats;
+  size_t wf = 0, bf = 0;
+  switch (kind) {
+    case L_AFFINE: wf = 64; bf = 64; break;
+    case L_STEM: wf = (size_t)9 * 8 * cout; bf = cout; break;
+    case L_DW: wf = (size_t)9 * cin_packed; bf = cin_packed; break;
+    case L_PW: wf = rtpose_packed_weight_floats(cout, cin_packed, 1); bf = rtpose_packed_bias_floats(cout); break;
+  }
+  n->wt_floats += round_up(wf, 64);
+  l.b_off = n->wt_floats;
+  n->wt_floats += round_up(bf, 64);
+  n->layers.push_back(l);
+  return (int)n->layers.size() - 1;
+}
+
+int up8(int v) { return (v + 7) / 8 * 8; }
+
+// logical -> physical channel of a stage buffer with halves of h channels padded to hp
+int fphys(int j, int h, int hp) { return j < h ? j : hp + (j - h); }
+
+void add_pw(rtpose_shufflenet* n, const std::string& name, int H, int W, int layer, int in_buf, int in_choff,
+            int out_buf, int out_choff, int cmap, int relu) {
+  SOp o;
+  o.kind = O_PW;
+  o.name = name;
+  o.H = H;
+  o.W = W;
+  o.layer[0] = layer;
+  o.in_buf[0] = in_buf;
+  o.in_choff[0] = in_choff;
+  o.out_buf[0] = out_buf;
+  o.out_choff[0] = out_choff;
+  o.cmap[0] = cmap;
+  o.relu = relu;
+  const SLayer& l = n->layers[layer];
+  o.flops = 2.0 * n->N * H * W * (double)l.cout * l.cin;
+  n->ops.push_back(o);
+}
+
+void add_dw(rtpose_shufflenet* n, const std::string& name, int H, int W, int layer, int in_buf, int out_buf,
+            int stride) {
+  SOp o;
+  o.kind = O_DW;
+  o.name = name;
+  o.H = H;
+  o.W = W;
+  o.layer[0] = layer;
+  o.in_buf[0] = in_buf;
+  o.out_buf[0] = out_buf;
+  o.stride = stride;
+  const SLayer& l = n->layers[layer];
+  o.C = l.cin_packed;
+  o.flops = 2.0 * n->N * ((H - 1) / stride + 1) * ((W - 1) / stride + 1) * (double)l.cin * 9;
+  n->ops.push_back(o);
+}
+
+void build(rtpose_shufflenet* n) {
+  const int H0 = n->H, W0 = n->W;
+  const int H1 = (H0 - 1) / 2 + 1, W1 = (W0 - 1) / 2 + 1;          // stem 3x3 s2 p1
+  const int H2 = (H1 - 3 + 1) / 2 + 1, W2 = (W1 - 3 + 1) / 2 + 1;  // maxpool 3/2 ceil
+  const int H3 = (H2 - 1) / 2 + 1, W3 = (W2 - 1) / 2 + 1;          // stage 2 first block s2
+  n->Hm = H3;
+  n->Wm = W3;
+
+  // ---- stem -----------------------------------------------------------------------
+  const int L_aff = add_layer(n, L_AFFINE, "network.0", 3, 3, 8, -1);
+  const int L_stem = add_layer(n, L_STEM, "network.1", 24, 3, 8, -1);
+  const int X0 = add_buf(n, 8, 1, H0, W0);
+  const int S1 = add_buf(n, 24, 0, H1, W1);
+  const int X1 = add_buf(n, 24, 1, H2, W2);
+  {
+    SOp o;
+    o.kind = O_INPUT;
+    o.name = "nchw->nhwc8 + data/bn";
+    o.H = H0;
+    o.W = W0;
+    o.layer[0] = L_aff;
+    o.out_buf[0] = X0;
+    n->ops.push_back(o);
+    SOp s;
+    s.kind = O_STEM;
+    s.name = "stage1/conv";
+    s.H = H0;
+    s.W = W0;
+    s.layer[0] = L_stem;
+    s.in_buf[0] = X0;
+    s.out_buf[0] = S1;
+    s.relu = 1;
+    s.flops = 2.0 * n->N * H1 * W1 * 24.0 * 27;
+    n->ops.push_back(s);
+    SOp p;
+    p.kind = O_POOL3;
+    p.name = "stage1/pool";
+    p.H = H1;
+    p.W = W1;
+    p.in_buf[0] = S1;
+    p.out_buf[0] = X1;
+    p.C = 24;
+    n->ops.push_back(p);
+  }
+
+  // ---- stages ------------------------------------------------------------------------
+  const int widths[3] = {116, 232, 464};
+  const int nblocks[3] = {4, 8, 4};
+  int in_buf = X1, in_c = 24, in_h = 24, in_hp = 24;  // previous buffer: logical C, half h, padded hp
+  bool in_is_stage = false;
+  int Hc = H2, Wc = W2;
+  for (int si = 0; si < 3; ++si) {
+    const int C = widths[si], h = C / 2, hp = up8(h);
+    const int stride = si == 0 ? 2 : 1;
+    const int Ho = si == 0 ? H3 : Hc, Wo = si == 0 ? W3 : Wc;
+    const std::string sp = "network." + std::to_string(3 + si) + ".";
+    // two ping-pong stage buffers (P = 1: the next stage's first block runs a dw conv on them)
+    const int SA = add_buf(n, 2 * hp, 1, Ho, Wo), SB = add_buf(n, 2 * hp, 1, Ho, Wo);
+    std::vector<int32_t> even(h), odd(h);
+    for (int i = 0; i < h; ++i) {
+      even[i] = fphys(2 * i, h, hp);
+      odd[i] = fphys(2 * i + 1, h, hp);
+    }
+    const int M_even = add_map(n, even), M_odd = add_map(n, odd);
+    // temporaries
+    const int in_phys = in_is_stage ? 2 * in_hp : in_c;
+    const int T0 = add_buf(n, in_phys, 0, Ho, Wo);      // conv0 branch after dw
+    const int T1a = add_buf(n, hp, 1, Hc, Wc);          // first block: 1x1 at the INPUT resolution
+    const int T1 = add_buf(n, hp, 1, Ho, Wo);
+    const int T2 = add_buf(n, hp, 0, Ho, Wo);
+
+    // -- block 0: two-branch (reference :47-53, :60-61) --
+    {
+      const std::string bp = sp + "0.";
+      int M_in = -1, M_inphys = -1;
+      if (in_is_stage) {  // input buffer holds [h' | pad | h' | pad]
+        std::vector<int32_t> m(in_phys, -1);
+        for (int j = 0; j < in_c; ++j) m[fphys(j, in_h, in_hp)] = j;
+        M_in = add_map(n, m);
+        M_inphys = M_in;
+      }
+      const int l_c00 = add_layer(n, L_DW, bp + "conv0.0", in_c, in_c, in_phys, M_inphys);
+      const int l_c01 = add_layer(n, L_PW, bp + "conv0.1", h, in_c, up8(in_phys), M_in);
+      const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, in_c, up8(in_phys), M_in);
+      const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, hp, -1);
+      const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, hp, -1);
+      add_dw(n, bp + "conv0.0", Hc, Wc, l_c00, in_buf, T0, stride);
+      add_pw(n, bp + "conv0.1", Ho, Wo, l_c01, T0, 0, SA, 0, M_even, 1);
+      add_pw(n, bp + "conv.0", Hc, Wc, l_c0, in_buf, 0, T1a, 0, -1, 1);
+      add_dw(n, bp + "conv.1", Hc, Wc, l_c1, T1a, T2, stride);
+      add_pw(n, bp + "conv.2", Ho, Wo, l_c2, T2, 0, SA, 0, M_odd, 1);
+    }
+    int cur = SA, nxt = SB;
+    // -- blocks 1..: pass-through half + processed half (reference :31-39, :56-59) --
+    for (int b = 1; b < nblocks[si]; ++b) {
+      const std::string bp = sp + std::to_string(b) + ".";
+      const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, h, hp, -1);
+      const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, hp, -1);
+      const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, hp, -1);
+      SOp c;
+      c.kind = O_COPYMAP;
+      c.name = bp + "x1->even";
+      c.H = Ho;
+      c.W = Wo;
+      c.in_buf[0] = cur;
+      c.out_buf[0] = nxt;
+      c.cmap[0] = M_even;
+      c.C = h;
+      n->ops.push_back(c);
+      add_pw(n, bp + "conv.0", Ho, Wo, l_c0, cur, hp, T1, 0, -1, 1);
+      add_dw(n, bp + "conv.1", Ho, Wo, l_c1, T1, T2, 1);
+      add_pw(n, bp + "conv.2", Ho, Wo, l_c2, T2, 0, nxt, 0, M_odd, 1);
+      std::swap(cur, nxt);
+    }
+    in_buf = cur;
+    in_c = C;
+    in_h = h;
+    in_hp = hp;
+    in_is_stage = true;
+    Hc = Ho;
+    Wc = Wo;
+  }
+
+  // ---- conv5 + heads -------------------------------------------------------------------
+  {
+    std::vector<int32_t> m(2 * in_hp, -1);
+    for (int j = 0; j < in_c; ++j) m[fphys(j, in_h, in_hp)] = j;
+    const int M_in = add_map(n, m);
+    const int l5 = add_layer(n, L_PW, "network.6", 1024, in_c, up8(2 * in_hp), M_in);
+    const int lp = add_layer(n, L_PW, "paf", 38, 1024, 1024, -1);
+    const int lh = add_layer(n, L_PW, "heatmap", 19, 1024, 1024, -1);
+    const int F = add_buf(n, 1024, 0, Hc, Wc);
+    const int OUT = add_buf(n, 64, 0, Hc, Wc);  // [PAF 0..37 | 2 pad | heat 40..58 | pad]
+    n->out_buf = OUT;
+    add_pw(n, "conv5", Hc, Wc, l5, in_buf, 0, F, 0, -1, 1);
+    SOp o;
+    o.kind = O_PW;
+    o.name = "paf+heatmap";
+    o.H = Hc;
+    o.W = Wc;
+    o.ngroups = 2;
+    o.layer[0] = lp;
+    o.layer[1] = lh;
+    o.in_buf[0] = o.in_buf[1] = F;
+    o.out_buf[0] = o.out_buf[1] = OUT;
+    o.out_choff[0] = 0;
+    o.out_choff[1] = 40;
+    o.relu = 0;
+    o.flops = 2.0 * n->N * Hc * Wc * 1024.0 * 57;
+    n->ops.push_back(o);
+  }
+}
+
+rtpose_layout slice(const SBuf& b, int choff) {
+  rtpose_layout l = b.lay;
+  l.choff = choff;
+  return l;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtpose_shufflenet_create(int N, int H, int W, rtpose_shufflenet** out) {
+  if (!out || N <= 0 || H < 32 || W < 32) return fail(RTPOSE_E_INVAL, "shufflenet_create: need N>=1, H,W>=32");
+  rtpose_shufflenet* n = new rtpose_shufflenet();
+  n->N = N;
+  n->H = H;
+  n->W = W;
+  build(n);
+  *out = n;
+  return 0;
+}
+
+void rtpose_shufflenet_destroy(rtpose_shufflenet* n) {
+  if (!n) return;
+  for (hipEvent_t e : n->ev) (void)hipEventDestroy(e);
+  delete n;
+}
+
+size_t rtpose_shufflenet_workspace_bytes(const rtpose_shufflenet* n) { return n->ws_floats * 4; }
+size_t rtpose_shufflenet_weight_bytes(const rtpose_shufflenet* n) { return n->wt_floats * 4; }
+
+int rtpose_shufflenet_bind(rtpose_shufflenet* n, void* workspace, size_t ws_bytes, void* weights,
+                           size_t wt_bytes, int zero_workspace, void* stream) {
+  if (!n || !workspace || !weights) return fail(RTPOSE_E_INVAL, "shufflenet_bind: NULL argument");
+  if (ws_bytes < n->ws_floats * 4 || wt_bytes < n->wt_floats * 4)
+    return fail(RTPOSE_E_INVAL, "shufflenet_bind: arena too small");
+  n->ws = static_cast<float*>(workspace);
+  n->wt = static_cast<float*>(weights);
+  hipStream_t s = as_stream(stream);
+  if (zero_workspace) RTPOSE_HIP_CHECK(hipMemsetAsync(workspace, 0, n->ws_floats * 4, s));
+  for (const Map& m : n->maps)
+    RTPOSE_HIP_CHECK(hipMemcpyAsync(n->wt + m.off, m.v.data(), m.v.size() * 4, hipMemcpyHostToDevice, s));
+  RTPOSE_HIP_CHECK(hipStreamSynchronize(s));
+  n->bound = true;
+  return 0;
+}
+
+int rtpose_shufflenet_num_layers(const rtpose_shufflenet* n) { return (int)n->layers.size(); }
+
+/* kind: 0 input affine (w = scale[3], b = shift[3]); 1 stem conv [24,3,3,3]; 2 depthwise [C,1,3,3];
+ * 3 pointwise [cout,cin,1,1].  BatchNorm already folded by the caller. */
+int rtpose_shufflenet_layer_info(const rtpose_shufflenet* n, int idx, char* name, int name_cap, int* kind,
+                                 int* cout, int* cin) {
+  if (!n || idx < 0 || idx >= (int)n->layers.size()) return fail(RTPOSE_E_INVAL, "layer_info: bad index");
+  const SLayer& l = n->layers[idx];
+  if (name && name_cap > 0) snprintf(name, name_cap, "%s", l.name.c_str());
+  if (kind) *kind = (int)l.kind;
+  if (cout) *cout = l.cout;
+  if (cin) *cin = l.cin;
+  return 0;
+}
+
+int rtpose_shufflenet_load(rtpose_shufflenet* n, int idx, const float* w, const float* b, void* stream) {
+  if (!n || !n->bound) return fail(RTPOSE_E_STATE, "shufflenet_load: not bound");
+  if (idx < 0 || idx >= (int)n->layers.size() || !w) return fail(RTPOSE_E_INVAL, "shufflenet_load: bad argument");
+  const SLayer& l = n->layers[idx];
+  hipStream_t s = as_stream(stream);
+  const int32_t* map = l.map_id >= 0 ? reinterpret_cast<const int32_t*>(n->wt + n->maps[l.map_id].off) : nullptr;
+  switch (l.kind) {
+    case L_AFFINE:
+      RTPOSE_HIP_CHECK(hipMemcpyAsync(n->wt + l.w_off, w, 3 * 4, hipMemcpyDeviceToDevice, s));
+      RTPOSE_HIP_CHECK(hipMemcpyAsync(n->wt + l.b_off, b, 3 * 4, hipMemcpyDeviceToDevice, s));
+      return 0;
+    case L_STEM: {
+      const int total = 9 * 8 * l.cout;
+      hipLaunchKernelGGL(pack_stem_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, w, l.cout, l.cin, 8,
+                         n->wt + l.w_off);
+      RTPOSE_HIP_CHECK(hipMemcpyAsync(n->wt + l.b_off, b, (size_t)l.cout * 4, hipMemcpyDeviceToDevice, s));
+      RTPOSE_HIP_CHECK(hipGetLastError());
+      return 0;
+    }
+    case L_DW: {
+      const int total = 10 * l.cin_packed;
+      hipLaunchKernelGGL(pack_dw_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, w, b, l.cin, map,
+                         l.cin_packed, n->wt + l.w_off, n->wt + l.b_off);
+      RTPOSE_HIP_CHECK(hipGetLastError());
+      return 0;
+    }
+    case L_PW:
+      return pack_weights_launch(w, b, l.cout, l.cin, 1, map, l.cin_packed, n->wt + l.w_off, n->wt + l.b_off, s);
+  }
+  return 0;
+}
+
+int rtpose_shufflenet_set_profiling(rtpose_shufflenet* n, int enable) {
+  if (!n) return fail(RTPOSE_E_INVAL, "NULL net");
+  n->profiling = enable ? 1 : 0;
+  if (enable && n->ev.empty()) {
+    n->ev.resize(n->ops.size() + 1);
+    for (auto& e : n->ev) RTPOSE_HIP_CHECK(hipEventCreate(&e));
+  }
+  n->ev_valid = false;
+  return 0;
+}
+
+int rtpose_shufflenet_num_launches(const rtpose_shufflenet* n) { return (int)n->ops.size(); }
+
+int rtpose_shufflenet_launch_info(rtpose_shufflenet* n, int i, float* ms, double* flops, char* name,
+                                  int name_cap) {
+  if (!n || i < 0 || i >= (int)n->ops.size()) return fail(RTPOSE_E_INVAL, "launch_info: bad index");
+  const SOp& o = n->ops[i];
+  if (flops) *flops = o.flops;
+  if (name && name_cap > 0) snprintf(name, name_cap, "%s", o.name.c_str());
+  if (ms) {
+    *ms = -1.f;
+    float t = 0.f;
+    if (n->profiling && n->ev_valid && hipEventElapsedTime(&t, n->ev[i], n->ev[i + 1]) == hipSuccess) *ms = t;
+  }
+  return 0;
+}
+
+int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* stream) {
+  if (!n || !n->bound) return fail(RTPOSE_E_STATE, "shufflenet_forward: not bound");
+  if (!x_nchw) return fail(RTPOSE_E_INVAL, "shufflenet_forward: x is NULL");
+  hipStream_t s = as_stream(stream);
+  const bool prof = n->profiling && !n->ev.empty();
+  auto imap = [&](int id) -> const int32_t* {
+    return id >= 0 ? reinterpret_cast<const int32_t*>(n->wt + n->maps[id].off) : nullptr;
+  };
+  for (size_t i = 0; i < n->ops.size(); ++i) {
+    const SOp& o = n->ops[i];
+    if (prof) RTPOSE_HIP_CHECK(hipEventRecord(n->ev[i], s));
+    int rc = 0;
+    switch (o.kind) {
+      case O_INPUT: {
+        const SBuf& b = n->bufs[o.out_buf[0]];
+        const SLayer& l = n->layers[o.layer[0]];
+        rc = rtpose_nchw_to_layout_affine(x_nchw, n->ws + b.off, &b.lay, 3, 8, n->N, o.H, o.W, n->wt + l.w_off,
+                                          n->wt + l.b_off, stream);
+        break;
+      }
+      case O_STEM: {
+        const SBuf& bi = n->bufs[o.in_buf[0]];
+        const SBuf& bo = n->bufs[o.out_buf[0]];
+        const SLayer& l = n->layers[o.layer[0]];
+        rc = rtpose_stem_conv3x3_s2(n->ws + bi.off, &bi.lay, n->wt + l.w_off, n->wt + l.b_off, n->ws + bo.off,
+                                    &bo.lay, 8, l.cout, n->N, o.H, o.W, o.relu, stream);
+        break;
+      }
+      case O_POOL3: {
+        const SBuf& bi = n->bufs[o.in_buf[0]];
+        const SBuf& bo = n->bufs[o.out_buf[0]];
+        rc = rtpose_maxpool3x3s2_ceil(n->ws + bi.off, &bi.lay, n->ws + bo.off, &bo.lay, o.C, n->N, o.H, o.W, stream);
+        break;
+      }
+      case O_DW: {
+        const SBuf& bi = n->bufs[o.in_buf[0]];
+        const SBuf& bo = n->bufs[o.out_buf[0]];
+        const SLayer& l = n->layers[o.layer[0]];
+        rc = rtpose_dwconv3x3(n->ws + bi.off, &bi.lay, n->wt + l.w_off, n->wt + l.b_off, n->ws + bo.off, &bo.lay,
+                              o.C, n->N, o.H, o.W, o.stride, stream);
+        break;
+      }
+      case O_COPYMAP: {
+        const SBuf& bi = n->bufs[o.in_buf[0]];
+        const SBuf& bo = n->bufs[o.out_buf[0]];
+        rc = rtpose_layout_copy_cmap(n->ws + bi.off, &bi.lay, n->ws + bo.off, &bo.lay, o.C, imap(o.cmap[0]), n->N,
+                                     o.H, o.W, stream);
+        break;
+      }
+      case O_PW: {
+        rtpose_conv_desc d[2];
+        for (int g = 0; g < o.ngroups; ++g) {
+          const SLayer& l = n->layers[o.layer[g]];
+          const SBuf& bi = n->bufs[o.in_buf[g]];
+          const SBuf& bo = n->bufs[o.out_buf[g]];
+          d[g].in = n->ws + bi.off;
+          d[g].out = n->ws + bo.off;
+          d[g].w_packed = n->wt + l.w_off;
+          d[g].bias_packed = n->wt + l.b_off;
+          d[g].lin = slice(bi, o.in_choff[g]);
+          d[g].lout = slice(bo, o.out_choff[g]);
+          d[g].cin = l.cin_packed;
+          d[g].cout = l.cout;
+          d[g].k = 1;
+          d[g].relu = o.relu;
+          d[g].pool = 0;
+          d[g].out_cmap = imap(o.cmap[g]);
+        }
+        rc = conv2d_launch(d, o.ngroups, n->N, o.H, o.W, s);
+        break;
+      }
+    }
+    if (rc) return rc;
+  }
+  if (prof) {
+    RTPOSE_HIP_CHECK(hipEventRecord(n->ev[n->ops.size()], s));
+    n->ev_valid = true;
+  }
+  return 0;
+}
+
+/* which: 0 = PAF (38 ch), 1 = heat-map (19 ch) -> dense NCHW */
+int rtpose_shufflenet_read_output(rtpose_shufflenet* n, int which, float* dst_nchw, void* stream) {
+  if (!n || !n->bound || which < 0 || which > 1 || !dst_nchw)
+    return fail(RTPOSE_E_INVAL, "shufflenet_read_output: bad argument");
+  const SBuf& b = n->bufs[n->out_buf];
+  const rtpose_layout l = slice(b, which == 0 ? 0 : 40);
+  return rtpose_layout_to_nchw(n->ws + b.off, &l, dst_nchw, which == 0 ? 38 : 19, n->N, n->Hm, n->Wm, stream);
+}
+
+int rtpose_shufflenet_output_view(const rtpose_shufflenet* n, int which, const float** base, rtpose_layout* layout,
+                                  int* C, int* H, int* W) {
+  if (!n || !n->bound || which < 0 || which > 1) return fail(RTPOSE_E_INVAL, "output_view: bad argument");
+  const SBuf& b = n->bufs[n->out_buf];
+  if (base) *base = n->ws + b.off;
+  if (layout) *layout = slice(b, which == 0 ? 0 : 40);
+  if (C) *C = which == 0 ? 38 : 19;
+  if (H) *H = n->Hm;
+  if (W) *W = n->Wm;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+"""GPU parity of the ShuffleNetV2 x1.0 pose network (csrc/shufflenet.hip + the building-block
+kernels in csrc/layout_ops.hip) against the oracle restatement and the golden outputs of the
+reference module (imported unmodified through the slim stub; parity unpinned w.r.t. the real slim)."""
+import ctypes as C
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import PKG_NAME
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "shufflenet_small.npz")
+
+
+@pytest.fixture(scope="module")
+def net_sd(pkg, cuda):
+    from oracle import shufflenet_oracle as so
+    sn = importlib.import_module(PKG_NAME + ".shufflenet")
+    m = sn.Network(1.0)
+    sd = so.seeded_state_dict(m, seed=0)
+    m.load_state_dict(sd)
+    return m.cuda().eval(), sd
+
+
+def test_state_dict_keys_match_reference_golden_order(pkg):
+    sn = importlib.import_module(PKG_NAME + ".shufflenet")
+    m = sn.Network(1.0)
+    keys = list(m.state_dict())
+    assert keys[0] == "paf.weight" and keys[4] == "network.0.weight" and "network.3.0.conv0.1.0.weight" in keys
+    assert keys[-1] == "network.6.1.num_batches_tracked" and len(keys) == 345
+    assert sum(p.numel() for p in m.parameters()) == 1312035
+
+
+def test_forward_matches_reference_golden(net_sd, cuda):
+    m, sd = net_sd
+    z = np.load(GOLD)
+    with torch.no_grad():
+        (paf, heat), _ = m(torch.from_numpy(z["x"]).to(cuda))
+    assert paf.shape == z["paf"].shape and heat.shape == z["heat"].shape
+    assert np.abs(paf.cpu().numpy() - z["paf"]).max() <= 1e-3
+    assert np.abs(heat.cpu().numpy() - z["heat"]).max() <= 1e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 128, 160), (1, 3, 368, 368), (3, 3, 72, 88)])
+def test_forward_matches_oracle(net_sd, cuda, shape):
+    from oracle import shufflenet_oracle as so
+    m, sd = net_sd
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(5)) - 0.5
+    paf_r, heat_r = so.forward(sd, x)
+    with torch.no_grad():
+        (paf, heat), _ = m(x.to(cuda))
+    assert paf.shape == paf_r.shape
+    scale = max(1.0, paf_r.abs().max().item(), heat_r.abs().max().item())
+    assert (paf.cpu() - paf_r).abs().max().item() <= 1e-3 * scale
+    assert (heat.cpu() - heat_r).abs().max().item() <= 1e-3 * scale
+
+
+def test_building_blocks(capi, cuda):
+    """dw 3x3 (s1/s2), 3x3-s2 ceil max-pool and the stem conv against torch CPU."""
+    lib, Layout = capi.lib, capi.Layout
+    s = capi.current_stream()
+    g = torch.Generator().manual_seed(0)
+    n, h, w, c = 2, 23, 30, 24
+    x = torch.randn(n, c, h, w, generator=g)
+    lin = Layout.padded(c, h, w, 1)
+    buf = torch.zeros(lib.rtpose_layout_pixels(C.byref(lin), n, h, w) * c, device=cuda)
+    xd = x.to(cuda)
+    capi.check(lib.rtpose_nchw_to_layout(capi.ptr(xd), capi.ptr(buf), C.byref(lin), c, c, n, h, w, s))
+    for stride in (1, 2):
+        wt = torch.randn(c, 1, 3, 3, generator=g)
+        b = torch.randn(c, generator=g)
+        ref = F.conv2d(x, wt, b, stride, 1, 1, c)
+        ho, wo = ref.shape[2], ref.shape[3]
+        wp = wt.view(c, 9).t().contiguous().to(cuda)           # [9][C]
+        bd = b.to(cuda)
+        lout = Layout.dense(c, ho, wo)
+        ob = torch.zeros(n * ho * wo * c + 64, device=cuda)
+        capi.check(lib.rtpose_dwconv3x3(capi.ptr(buf), C.byref(lin), capi.ptr(wp), capi.ptr(bd), capi.ptr(ob),
+                                        C.byref(lout), c, n, h, w, stride, s))
+        got = ob[:n * ho * wo * c].view(n, ho, wo, c).permute(0, 3, 1, 2).cpu()
+        assert (got - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    # max-pool 3/2 ceil
+    ref = F.max_pool2d(x, 3, 2, 0, ceil_mode=True)
+    ho, wo = ref.shape[2], ref.shape[3]
+    lout = Layout.dense(c, ho, wo)
+    ob = torch.zeros(n * ho * wo * c + 64, device=cuda)
+    capi.check(lib.rtpose_maxpool3x3s2_ceil(capi.ptr(buf), C.byref(lin), capi.ptr(ob), C.byref(lout), c, n, h, w, s))
+    assert torch.equal(ob[:n * ho * wo * c].view(n, ho, wo, c).permute(0, 3, 1, 2).cpu(), ref)
+    # stem: affine input + 3x3 s2 conv 3->24 + relu
+    x3 = torch.randn(n, 3, h, w, generator=g)
+    sc, sh = torch.rand(3, generator=g) + 0.5, torch.randn(3, generator=g)
+    wt = torch.randn(24, 3, 3, 3, generator=g) * 0.3
+    b = torch.randn(24, generator=g)
+    ref = F.relu(F.conv2d(x3 * sc.view(1, 3, 1, 1) + sh.view(1, 3, 1, 1), wt, b, 2, 1))
+    l8 = Layout.padded(8, h, w, 1)
+    b8 = torch.zeros(lib.rtpose_layout_pixels(C.byref(l8), n, h, w) * 8, device=cuda)
+    x3d, scd, shd = x3.to(cuda), sc.to(cuda), sh.to(cuda)
+    capi.check(lib.rtpose_nchw_to_layout_affine(capi.ptr(x3d), capi.ptr(b8), C.byref(l8), 3, 8, n, h, w,
+                                                capi.ptr(scd), capi.ptr(shd), s))
+    wp = torch.zeros(3, 3, 8, 24)
+    wp[:, :, :3, :] = wt.permute(2, 3, 1, 0)
+    wpd, bd = wp.contiguous().to(cuda), b.to(cuda)
+    ho, wo = ref.shape[2], ref.shape[3]
+    lout = Layout.dense(24, ho, wo)
+    ob = torch.zeros(n * ho * wo * 24 + 64, device=cuda)
+    capi.check(lib.rtpose_stem_conv3x3_s2(capi.ptr(b8), C.byref(l8), capi.ptr(wpd), capi.ptr(bd), capi.ptr(ob),
+                                          C.byref(lout), 8, 24, n, h, w, 1, s))
+    got = ob[:n * ho * wo * 24].view(n, ho, wo, 24).permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_decoder_reads_shufflenet_output_in_place(net_sd, capi, cuda):
+    """The pose decoder consumes the heads' output buffer where they wrote it."""
+    dec = importlib.import_module(PKG_NAME + ".decode")
+    from oracle import post_oracle as po
+    m, _ = net_sd
+    x = (torch.rand(2, 3, 184, 184, generator=torch.Generator().manual_seed(7)) - 0.5).to(cuda)
+    with torch.no_grad():
+        (paf, heat), _ = m(x)
+    plan = m.plan_for(x)
+    lib = capi.lib
+    base, lay, c, h, w = C.c_void_p(), capi.Layout(), C.c_int(), C.c_int(), C.c_int()
+    capi.check(lib.rtpose_shufflenet_output_view(plan.handle, 1, C.byref(base), C.byref(lay), C.byref(c), C.byref(h), C.byref(w)))
+    pbase, play = C.c_void_p(), capi.Layout()
+    capi.check(lib.rtpose_shufflenet_output_view(plan.handle, 0, C.byref(pbase), C.byref(play), None, None, None))
+    cfg = dec.make_cfg(None, 64, 64)
+    while True:
+        bufs = dec.DecodeBuffers(cfg, 2, cuda)
+        dec.decode_enqueue(base, lay, pbase, play, 2, h.value, w.value, bufs)
+        recs = dec.fetch(bufs)
+        if not int(np.bitwise_or.reduce(recs[:, 2])):
+            break
+        cfg = dec.make_cfg(None, min(cfg.max_peaks_per_part * 2, 1024), min(cfg.max_humans * 2, 16384))
+    for i in range(2):
+        hm = heat[i].permute(1, 2, 0).contiguous().cpu().numpy()
+        pf = paf[i].permute(1, 2, 0).contiguous().cpu().numpy()
+        jl, r = po.paf_to_pose(hm, pf)
+        out = dec.parse_image(recs[i], cfg)
+        assert np.array_equal(out["peaks"], jl) and np.array_equal(out["parts"], r["parts"])

@@ -7,7 +7,7 @@ mkdir -p tools/exp
 build() { # name flags...
   name=$1; shift
   objs=""
-  for f in conv_mfma layout_ops net decode legacy_pafprocess; do
+  for f in conv_mfma layout_ops net shufflenet decode legacy_pafprocess; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$SRC "$@" -c $SRC/$f.hip -o tools/exp/${name}_$f.o &
     objs="$objs tools/exp/${name}_$f.o"
   done
