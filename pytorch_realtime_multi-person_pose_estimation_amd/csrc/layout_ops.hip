@@ -195,45 +195,60 @@ __global__ void nchw_to_layout_affine_kernel(const float* __restrict__ src, floa
   dst[lay_off(l, n, y, x) + c] = v;
 }
 
-// 3x3 stride-2 pad-1 dense conv, tiny cin (stem 3->24, :97).  One thread = one output
-// pixel x 4 output channels; w[ky][kx][cin_pad][cout].  The input layout's zero gaps are
-// the padding, so no bounds tests (the top/left halo of pixel (0,0) is the lead gap).
+// 3x3 stride-2 pad-1 dense conv, tiny cin (stem 3->24, :97).  HBM-bound: one thread = one
+// output pixel x ALL output channels (COUT/4 float4 accumulators), the 9 x 8-channel input
+// taps are two float4 loads each, and the weight index depends on loop counters only, so
+// the weights arrive through the scalar cache (s_load), not the vector path.
+// w[ky][kx][8][COUT].  The input layout's zero gaps are the padding: no bounds tests.
+template <int COUT>
 __global__ void stem_conv3x3_s2_kernel(const float* __restrict__ in, Lay li, const float* __restrict__ w,
                                        const float* __restrict__ bias, float* __restrict__ out, Lay lo,
-                                       int cin_pad, int cout, int N, int Ho, int Wo, int relu) {
-  const int c4 = cout >> 2;
-  const size_t total = (size_t)N * Ho * Wo * c4;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int co = (i % c4) * 4;
-  size_t p = i / c4;
+                                       int N, int Ho, int Wo, int relu) {
+  constexpr int C4 = COUT / 4;
+  const size_t total = (size_t)N * Ho * Wo;
+  size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= total) return;
   const int x = p % Wo;
   p /= Wo;
   const int y = p % Ho;
   const int n = p / Ho;
-  float4 acc = *reinterpret_cast<const float4*>(bias + co);
+  float4 acc[C4];
+#pragma unroll
+  for (int j = 0; j < C4; ++j) acc[j] = *reinterpret_cast<const float4*>(bias + 4 * j);
+#pragma unroll
   for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       // input pixel (2y+ky-1, 2x+kx-1): offsets of -1 land in the layout gaps
       const float* ip = in + (long long)lay_off(li, n, 2 * y + ky, 2 * x + kx) -
                         (long long)(li.ws + 1) * li.cstride;
-      const float* wp = w + ((size_t)(ky * 3 + kx) * cin_pad) * cout + co;
-      for (int c = 0; c < cin_pad; ++c) {
-        const float v = ip[c];
-        const float4 ww = *reinterpret_cast<const float4*>(wp + (size_t)c * cout);
-        acc.x += v * ww.x;
-        acc.y += v * ww.y;
-        acc.z += v * ww.z;
-        acc.w += v * ww.w;
-      }
+      const float4 v0 = *reinterpret_cast<const float4*>(ip);
+      const float4 v1 = *reinterpret_cast<const float4*>(ip + 4);
+      const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      const float* wp = w + (size_t)(ky * 3 + kx) * 8 * COUT;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int j = 0; j < C4; ++j) {
+          const float4 ww = *reinterpret_cast<const float4*>(wp + c * COUT + 4 * j);
+          acc[j].x += v[c] * ww.x;
+          acc[j].y += v[c] * ww.y;
+          acc[j].z += v[c] * ww.z;
+          acc[j].w += v[c] * ww.w;
+        }
     }
-  if (relu) {
-    acc.x = fmaxf(acc.x, 0.f);
-    acc.y = fmaxf(acc.y, 0.f);
-    acc.z = fmaxf(acc.z, 0.f);
-    acc.w = fmaxf(acc.w, 0.f);
+  float* op = out + lay_off(lo, n, y, x);
+#pragma unroll
+  for (int j = 0; j < C4; ++j) {
+    float4 a = acc[j];
+    if (relu) {
+      a.x = fmaxf(a.x, 0.f);
+      a.y = fmaxf(a.y, 0.f);
+      a.z = fmaxf(a.z, 0.f);
+      a.w = fmaxf(a.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(op + 4 * j) = a;
   }
-  *reinterpret_cast<float4*>(out + lay_off(lo, n, y, x) + co) = acc;
 }
 
 // MaxPool2d(3, 2, 0, ceil_mode=True): windows are clipped to the input.
@@ -293,6 +308,28 @@ __global__ void dwconv3x3_kernel(const float* __restrict__ in, Lay li, const flo
       acc.w += v.w * ww.w;
     }
   *reinterpret_cast<float4*>(out + lay_off(lo, n, y, x) + c) = acc;
+}
+
+// 4 consecutive source channels per thread (one 16-byte load), 4 mapped 4-byte stores
+__global__ void layout_copy_cmap4_kernel(const float* __restrict__ src, Lay ls, float* __restrict__ dst,
+                                         Lay ld, int C, const int32_t* __restrict__ cmap, int N, int H,
+                                         int W) {
+  const int c4 = (C + 3) >> 2;
+  const size_t total = (size_t)N * H * W * c4;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (i % c4) * 4;
+  size_t p = i / c4;
+  const int x = p % W;
+  p /= W;
+  const int y = p % H;
+  const int n = p / H;
+  const float4 v = *reinterpret_cast<const float4*>(src + lay_off(ls, n, y, x) + c);
+  float* d = dst + lay_off(ld, n, y, x) - ld.choff;
+  const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (c + k < C) d[cmap[c + k]] = vv[k];
 }
 
 __global__ void layout_copy_cmap_kernel(const float* __restrict__ src, Lay ls, float* __restrict__ dst,
@@ -404,11 +441,13 @@ int rtpose_stem_conv3x3_s2(const float* in, const rtpose_layout* lin, const floa
   if ((cout % 4) || (lout->cstride % 4) || (lout->choff % 4) || lin->ws < W + 1 || lin->hs < H + 1 ||
       lin->lead < lin->ws + 1 || lin->choff + cin_pad > lin->cstride)
     return fail(RTPOSE_E_INVAL, "stem_conv: unsupported layout / channel count");
+  if (cin_pad != 8 || cout != 24 || (lin->cstride % 4) || (lin->choff % 4))
+    return fail(RTPOSE_E_INVAL, "stem_conv: only cin_pad = 8, cout = 24 is instantiated");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  const size_t total = (size_t)N * Ho * Wo * (cout / 4);
+  const size_t total = (size_t)N * Ho * Wo;
   if (!total) return 0;
-  hipLaunchKernelGGL(stem_conv3x3_s2_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), in,
-                     to_lay(lin), w, bias, out, to_lay(lout), cin_pad, cout, N, Ho, Wo, relu);
+  hipLaunchKernelGGL(stem_conv3x3_s2_kernel<24>, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), in,
+                     to_lay(lin), w, bias, out, to_lay(lout), N, Ho, Wo, relu);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -445,8 +484,16 @@ int rtpose_layout_copy_cmap(const float* src, const rtpose_layout* lsrc, float* 
   if (!cmap) return fail(RTPOSE_E_INVAL, "layout_copy_cmap: cmap is NULL");
   const size_t total = (size_t)N * H * W * C;
   if (!total) return 0;
-  hipLaunchKernelGGL(layout_copy_cmap_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), src,
-                     to_lay(lsrc), dst, to_lay(ldst), C, cmap, N, H, W);
+  // the source slice may be read 16 bytes at a time when it is aligned and either a
+  // multiple of 4 wide or followed by readable (padding) channels inside the pixel
+  if (!(lsrc->cstride % 4) && !(lsrc->choff % 4) && lsrc->choff + ((C + 3) & ~3) <= lsrc->cstride) {
+    const size_t t4 = (size_t)N * H * W * ((C + 3) / 4);
+    hipLaunchKernelGGL(layout_copy_cmap4_kernel, dim3(nblocks(t4, 256)), dim3(256), 0, as_stream(stream), src,
+                       to_lay(lsrc), dst, to_lay(ldst), C, cmap, N, H, W);
+  } else {
+    hipLaunchKernelGGL(layout_copy_cmap_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), src,
+                       to_lay(lsrc), dst, to_lay(ldst), C, cmap, N, H, W);
+  }
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }

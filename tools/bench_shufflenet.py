@@ -1,0 +1,61 @@
+"""BASELINE config 4 (developer bench; bench.py keeps the headline contract):
+ShuffleNetV2 x1.0 pose net, 368x368, batch 128, fp32, one MI355X — net only and net+decode."""
+import ctypes as C
+import importlib
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+PKG = "pytorch_realtime_multi-person_pose_estimation_amd"
+pkg = importlib.import_module(PKG)
+sn = importlib.import_module(PKG + ".shufflenet")
+capi = pkg._capi
+lib = capi.lib
+
+GFLOP_PER_IMG = 5.543
+MIN_BYTES_PER_IMG = 1.63e6 + 0.48e6   # read input + write outputs (weights 5.2 MB once per batch)
+
+
+def main(n=128, iters=10):
+    from oracle import shufflenet_oracle as so
+    dev = torch.device("cuda:0")
+    m = sn.Network(1.0)
+    m.load_state_dict(so.seeded_state_dict(m, 0))
+    m = m.cuda().eval()
+    x = (torch.rand(n, 3, 368, 368, generator=torch.Generator().manual_seed(0)) - 0.5).to(dev)
+    plan = m.forward_native(x)
+    torch.cuda.synchronize()
+    lib.rtpose_shufflenet_set_profiling(plan.handle, 1)
+    nl = lib.rtpose_shufflenet_num_launches(plan.handle)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        m.forward_native(x)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / iters
+    kinds = {}
+    tot = 0.0
+    for i in range(nl):
+        ms, fl = C.c_float(), C.c_double()
+        name = C.create_string_buffer(96)
+        lib.rtpose_shufflenet_launch_info(plan.handle, i, C.byref(ms), C.byref(fl), name, 96)
+        nm = name.value.decode()
+        kind = "pw" if ("conv.0" in nm or "conv.2" in nm or "conv0.1" in nm or nm in ("conv5", "paf+heatmap")) else \
+            ("dw" if ("conv.1" in nm or "conv0.0" in nm) else ("copy" if "x1->even" in nm else nm))
+        if os.environ.get("VERBOSE"):
+            print("  %-34s %7.3f ms %7.2f TF/s" % (nm, ms.value, fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0))
+        a = kinds.setdefault(kind, [0.0, 0.0, 0])
+        a[0] += ms.value
+        a[1] += fl.value
+        a[2] += 1
+        tot += ms.value
+    for k, (ms, fl, cnt) in sorted(kinds.items(), key=lambda kv: -kv[1][0]):
+        print("%-28s %3d launches %8.3f ms  %7.2f TF/s" % (k, cnt, ms, fl / (ms * 1e-3) / 1e12 if ms else 0))
+    print("launches %d, sum %.3f ms, wall %.3f ms/forward -> %.0f img/s, %.2f TFLOP/s, %.1f GB/s vs fused-min bytes"
+          % (nl, tot, wall * 1e3, n / wall, n / wall * GFLOP_PER_IMG / 1e3, n / wall * MIN_BYTES_PER_IMG / 1e9))
+
+
+if __name__ == "__main__":
+    main(*[int(v) for v in sys.argv[1:]])
