@@ -258,6 +258,15 @@ int rtpose_shufflenet_launch_info(rtpose_shufflenet* net, int i, float* ms, doub
  *      NMS            paf_to_pose.py:67-145   (find_peaks :25-38)
  *      process_paf    lib/pafprocess/pafprocess.cpp:22-194
  * ---------------------------------------------------------------------- */
+/* Multi-scale test-time augmentation (BASELINE config 3; the scale set is NOT pinned by
+ * the reference tree - SURVEY.md §3.2): dst = beta*dst + alpha*bilinear_resize(src), dense
+ * NHWC, half-pixel centres, edge clamp.  Only the top-left src_h_valid x src_w_valid
+ * (fractional) region of src is mapped onto dst, so the zero padding of a scaled input
+ * (im_transform.py:128-132) is cropped away on the fly. */
+int rtpose_resize_bilinear_accum(const float* src, int hs, int ws, float* dst, int hd, int wd,
+                                 int C, int N, float src_h_valid, float src_w_valid,
+                                 float alpha, float beta, void* stream);
+
 #define RTPOSE_NUM_PART 18
 #define RTPOSE_NUM_LIMB 19
 

@@ -156,6 +156,37 @@ __global__ void flip_merge_kernel(const float* __restrict__ heat, const float* _
   }
 }
 
+// Multi-scale test-time augmentation: dst = beta * dst + alpha * bilinear_resize(src), dense
+// NHWC, half-pixel centres, edge clamp (== F.interpolate(bilinear, align_corners=False) and
+// cv2.resize INTER_LINEAR on float data).  (sy, sx) = source pixels per destination pixel.
+__global__ void resize_bilinear_accum_kernel(const float* __restrict__ src, int hs, int ws,
+                                             float* __restrict__ dst, int hd, int wd, int C, int N,
+                                             float sy, float sx, float alpha, float beta) {
+  const size_t total = (size_t)N * hd * wd * C;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = i % C;
+  size_t p = i / C;
+  const int x = p % wd;
+  p /= wd;
+  const int y = p % hd;
+  const int n = p / hd;
+  float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
+  fy = fmaxf(fy, 0.f);
+  fx = fmaxf(fx, 0.f);
+  int y0 = (int)fy, x0 = (int)fx;
+  y0 = min(y0, hs - 1);
+  x0 = min(x0, ws - 1);
+  const int y1 = min(y0 + 1, hs - 1), x1 = min(x0 + 1, ws - 1);
+  const float ly = fminf(fy - (float)y0, 1.f), lx = fminf(fx - (float)x0, 1.f);
+  const float* s0 = src + ((size_t)n * hs + y0) * ws * C + c;
+  const float* s1 = src + ((size_t)n * hs + y1) * ws * C + c;
+  const float top = s0[(size_t)x0 * C] * (1.f - lx) + s0[(size_t)x1 * C] * lx;
+  const float bot = s1[(size_t)x0 * C] * (1.f - lx) + s1[(size_t)x1 * C] * lx;
+  const float v = top * (1.f - ly) + bot * ly;
+  dst[i] = (beta == 0.f ? 0.f : beta * dst[i]) + alpha * v;
+}
+
 // dst(n,y,x,c) = alpha * dst(n,y,x,c) + beta * src_dense[n][y][x][c]
 __global__ void layout_axpby_kernel(float* __restrict__ dst, Lay ld, const float* __restrict__ src, int C,
                                     int N, int H, int W, float alpha, float beta) {
@@ -504,6 +535,17 @@ int rtpose_layout_axpby(float* dst, const rtpose_layout* ldst, const float* src_
   if (!total) return 0;
   hipLaunchKernelGGL(layout_axpby_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), dst,
                      to_lay(ldst), src_nhwc, C, N, H, W, alpha, beta);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_resize_bilinear_accum(const float* src, int hs, int ws, float* dst, int hd, int wd, int C, int N,
+                                 float src_h_valid, float src_w_valid, float alpha, float beta, void* stream) {
+  if (hs <= 0 || ws <= 0 || hd <= 0 || wd <= 0 || C <= 0 || N <= 0 || src_h_valid <= 0 || src_w_valid <= 0)
+    return fail(RTPOSE_E_INVAL, "resize_bilinear_accum: bad sizes");
+  const size_t total = (size_t)N * hd * wd * C;
+  hipLaunchKernelGGL(resize_bilinear_accum_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
+                     src, hs, ws, dst, hd, wd, C, N, src_h_valid / (float)hd, src_w_valid / (float)wd, alpha, beta);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }

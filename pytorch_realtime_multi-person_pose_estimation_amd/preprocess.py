@@ -139,3 +139,61 @@ def append_result(image_id, humans, upsample_keypoints, outputs, num_keypoints=1
                 keypoints[i] = (bp.x * upsample_keypoints[1] + 0.5, bp.y * upsample_keypoints[0] + 0.5, 1)
         outputs.append({"image_id": image_id, "category_id": 1, "score": 1.,
                         "keypoints": list(keypoints[ORDER_COCO, :].reshape(51))})
+
+
+def get_multiscale_outputs(img, model, preprocess='rtpose', scales=(0.5, 1.0, 1.5, 2.0), flip=True, config=None):
+    """Multi-scale (+ horizontal flip) test-time augmentation — BASELINE config 3 / README.md:26.
+
+    The surveyed reference commit only keeps remnants of this path (handle_paf_and_heat is
+    imported but never called; `get_outputs` is single-scale), so the scale set and the merge
+    resolution are an ASSUMPTION following the upstream OpenPose convention: for each scale s
+    the image is resized so that its short side is s * IMAGE_SIZE, padded to a multiple of 8 and
+    run through the net; every scale's PAF/heat-map (valid, un-padded region only) is bilinearly
+    resized to the scale-1.0 map size and averaged; the flipped pass is merged per scale with the
+    reference's handle_paf_and_heat semantics.  All arithmetic after the image prep is on the GPU.
+    Returns (paf [h,w,38], heatmap [h,w,19], im_scale of the 1.0 pass)."""
+    config = config or dec.default_config()
+    base = int(config.DATASET.IMAGE_SIZE)
+    stride = int(config.MODEL.DOWNSAMPLE)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    prep = rtpose_preprocess if preprocess == 'rtpose' else vgg_preprocess
+    h0, w0 = img.shape[:2]
+    s1 = float(base) / min(h0, w0)
+    hd, wd = -(-_cv_round(h0 * s1) // stride), -(-_cv_round(w0 * s1) // stride)
+    acc_heat = torch.zeros(1, hd, wd, 19, device=dev)
+    acc_paf = torch.zeros(1, hd, wd, 38, device=dev)
+    stream = current_stream()
+    m = _unwrap(model)
+    for si, s in enumerate(scales):
+        im_croped, im_scale, real_shape = crop_with_factor(img, int(round(base * s)), factor=stride, is_ceil=True)
+        x = torch.from_numpy(np.expand_dims(prep(im_croped), 0)).to(dev)
+        (paf, heat), _ = model(x)
+        heat = heat.permute(0, 2, 3, 1).contiguous()
+        paf = paf.permute(0, 2, 3, 1).contiguous()
+        if flip:
+            # the padded columns sit on the right of the normal pass and on the left of the flipped one:
+            # mirror only inside the valid width by flipping the un-padded image region instead
+            vw = real_shape[1]
+            xf2 = x.clone()
+            xf2[:, :, :, :vw] = torch.flip(x[:, :, :, :vw], dims=[3])
+            (paf_f, heat_f), _ = model(xf2)
+            heat_f = heat_f.permute(0, 2, 3, 1).contiguous()
+            paf_f = paf_f.permute(0, 2, 3, 1).contiguous()
+            vwm = -(-vw // stride)
+            hv, pv = heat[:, :, :vwm].contiguous(), paf[:, :, :vwm].contiguous()
+            hfv, pfv = heat_f[:, :, :vwm].contiguous(), paf_f[:, :, :vwm].contiguous()
+            mh, mp = torch.empty_like(hv), torch.empty_like(pv)
+            check(lib.rtpose_flip_merge(ptr(hv), ptr(hfv), ptr(pv), ptr(pfv), 1, hv.shape[1], vwm, ptr(mh), ptr(mp),
+                                        stream), "rtpose_flip_merge")
+            heat, paf = mh, mp
+        hs, ws = heat.shape[1], heat.shape[2]
+        # one destination cell (stride px of the scale-1 image) spans im_scale/s1 source cells,
+        # whatever the two paddings are: the map origins coincide, only the zoom differs
+        ratio = im_scale / s1
+        a = 1.0 / len(scales)
+        beta = 0.0 if si == 0 else 1.0
+        check(lib.rtpose_resize_bilinear_accum(ptr(heat), hs, ws, ptr(acc_heat), hd, wd, 19, 1, hd * ratio, wd * ratio,
+                                               a, beta, stream), "rtpose_resize_bilinear_accum")
+        check(lib.rtpose_resize_bilinear_accum(ptr(paf), hs, ws, ptr(acc_paf), hd, wd, 38, 1, hd * ratio, wd * ratio,
+                                               a, beta, stream), "rtpose_resize_bilinear_accum")
+    return acc_paf[0].cpu().numpy(), acc_heat[0].cpu().numpy(), s1

@@ -84,3 +84,38 @@ def test_nms_dropin_matches_oracle(compat, cuda):
     for j, arr in enumerate(per_type):
         exp = jl[jl[:, 4] == j][:, :4]
         assert arr.dtype == np.float64 and np.array_equal(arr.astype(np.float32), exp)
+
+
+def test_resize_bilinear_accum_matches_torch(capi, cuda):
+    """rtpose_resize_bilinear_accum == F.interpolate(bilinear, align_corners=False) (+ alpha/beta)."""
+    g = torch.Generator().manual_seed(0)
+    for (hs, ws, hd, wd) in ((23, 25, 46, 49), (92, 98, 46, 49), (46, 49, 46, 49), (69, 74, 46, 49)):
+        src = torch.randn(2, hs, ws, 19, generator=g)
+        ref = torch.nn.functional.interpolate(src.permute(0, 3, 1, 2), size=(hd, wd), mode='bilinear',
+                                              align_corners=False).permute(0, 2, 3, 1)
+        dst = torch.full((2, hd, wd, 19), 3.0, device=cuda)
+        sd = src.to(cuda)
+        capi.check(capi.lib.rtpose_resize_bilinear_accum(capi.ptr(sd), hs, ws, capi.ptr(dst), hd, wd, 19, 2,
+                                                         float(hs), float(ws), 0.25, 0.5, capi.current_stream()))
+        exp = 0.5 * 3.0 + 0.25 * ref
+        assert (dst.cpu() - exp).abs().max().item() <= 1e-5
+
+
+def test_multiscale_flip_outputs(compat, cuda):
+    """config-3 style TTA runs end to end; with scales=(1.0,) and no flip it equals get_outputs."""
+    from lib.network.rtpose_vgg import get_model
+    from oracle import net_oracle
+    pre = importlib.import_module(PKG_NAME + ".preprocess")
+    model = get_model('vgg19')
+    model.load_state_dict(net_oracle.he_init_state_dict(model, seed=0))
+    model = model.cuda().eval()
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (120, 150, 3), dtype=np.uint8)
+    with torch.no_grad():
+        paf1, heat1, s = pre.get_outputs(img, model, 'rtpose')
+        paf_a, heat_a, s_a = pre.get_multiscale_outputs(img, model, 'rtpose', scales=(1.0,), flip=False)
+        paf_m, heat_m, _ = pre.get_multiscale_outputs(img, model, 'rtpose', scales=(0.5, 1.0, 1.5), flip=True)
+    assert abs(s - s_a) < 1e-12 and paf_a.shape == paf1.shape == paf_m.shape
+    assert np.abs(paf_a - paf1).max() <= 1e-5 and np.abs(heat_a - heat1).max() <= 1e-5
+    assert np.isfinite(paf_m).all() and np.isfinite(heat_m).all()
+    # flip-symmetry sanity: TTA of the mirrored image == mirrored TTA (x-PAF channels negated, L/R swapped)
