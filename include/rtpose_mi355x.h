@@ -204,6 +204,10 @@ int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw,
                          const float* bias, void* stream);
 /* Enqueue the whole forward on `stream`: x is dense NCHW fp32 [N,3,H,W]. */
 int rtpose_net_forward(rtpose_net* net, const float* x_nchw, void* stream);
+/* The net's own NHWC8 input buffer, for producers that write it directly
+ * (rtpose_preprocess_u8), and the forward that then skips the NCHW conversion. */
+int rtpose_net_input_view(const rtpose_net* net, float** base, rtpose_layout* layout);
+int rtpose_net_forward_prepared(rtpose_net* net, void* stream);
 /* Copy stage output `which` (0..11 = saved_for_loss order: out1_1, out1_2,
  * ... out6_1, out6_2; rtpose_vgg.py:166-196) as dense NCHW.  Only the last
  * two survive a forward unless keep_intermediates was set. */
@@ -258,6 +262,14 @@ int rtpose_shufflenet_launch_info(rtpose_shufflenet* net, int i, float* ms, doub
  *      NMS            paf_to_pose.py:67-145   (find_peaks :25-38)
  *      process_paf    lib/pafprocess/pafprocess.cpp:22-194
  * ---------------------------------------------------------------------- */
+/* Fused image prep on the device (caller side of get_outputs, evaluate/coco_eval.py:87-94):
+ * uint8 BGR HWC image (device) -> cv2.resize(fx=fy=im_scale, INTER_LINEAR, 11-bit fixed point) ->
+ * zero pad to Hn x Wn -> rtpose (mode 0) / vgg (mode 1) normalisation -> image n_index of an
+ * NHWC8 layout buffer (e.g. rtpose_net_input_view).  hr x wr = cvRound(h0*s) x cvRound(w0*s). */
+int rtpose_preprocess_u8(const unsigned char* img_bgr, int h0, int w0, double im_scale, int mode,
+                         float* dst, const rtpose_layout* ldst, int n_index, int Hn, int Wn, int hr,
+                         int wr, void* stream);
+
 /* Multi-scale test-time augmentation (BASELINE config 3; the scale set is NOT pinned by
  * the reference tree - SURVEY.md §3.2): dst = beta*dst + alpha*bilinear_resize(src), dense
  * NHWC, half-pixel centres, edge clamp.  Only the top-left src_h_valid x src_w_valid

@@ -156,6 +156,64 @@ __global__ void flip_merge_kernel(const float* __restrict__ heat, const float* _
   }
 }
 
+// Fused caller-side image prep: crop_with_factor + rtpose/vgg_preprocess
+// (lib/network/im_transform.py:119-134, lib/datasets/preprocessing.py:16-43) on the device:
+// uint8 BGR HWC image -> cv2.resize(fx=fy=scale, INTER_LINEAR) in OpenCV's 11-bit fixed point
+// -> zero pad to the network size -> normalise -> the net's NHWC8 input buffer.  Integer
+// arithmetic identical to preprocess.resize_linear_u8 (the numpy restatement): bit-exact.
+__device__ __forceinline__ void lin_coeff(int d, int sn, double scale, int& s0, int& s1, int& a0, int& a1) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) {
+    f = 0.f;
+    s = 0;
+  }
+  if (s >= sn - 1) {
+    f = 0.f;
+    s = sn - 1;
+  }
+  s0 = s;
+  s1 = min(s + 1, sn - 1);
+  a1 = (int)rintf(f * 2048.f);
+  a0 = (int)rintf((1.f - f) * 2048.f);
+}
+
+__global__ void preprocess_u8_kernel(const unsigned char* __restrict__ img, int h0, int w0, double inv_scale,
+                                     int mode, float* __restrict__ dst, Lay ld, int n, int Hn, int Wn,
+                                     int hr, int wr) {
+  const size_t total = (size_t)Hn * Wn;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int x = i % Wn, y = i / Wn;
+  int px[3] = {0, 0, 0};  // padded area: pixel value 0 (im_transform.py:130-131)
+  if (y < hr && x < wr) {
+    int x0, x1, ax0, ax1, y0, y1, ay0, ay1;
+    lin_coeff(x, w0, inv_scale, x0, x1, ax0, ax1);
+    lin_coeff(y, h0, inv_scale, y0, y1, ay0, ay1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int s00 = img[((size_t)y0 * w0 + x0) * 3 + c], s01 = img[((size_t)y0 * w0 + x1) * 3 + c];
+      const int s10 = img[((size_t)y1 * w0 + x0) * 3 + c], s11 = img[((size_t)y1 * w0 + x1) * 3 + c];
+      const int r0 = s00 * ax0 + s01 * ax1, r1 = s10 * ax0 + s11 * ax1;
+      int v = ((((ay0 * (r0 >> 4)) >> 16) + ((ay1 * (r1 >> 4)) >> 16) + 2) >> 2);
+      px[c] = min(max(v, 0), 255);
+    }
+  }
+  float o[3];
+  if (mode == 0) {  // rtpose_preprocess: x / 256 - 0.5, channel order kept (BGR)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = (float)px[c] / 256.f - 0.5f;
+  } else {          // vgg_preprocess: RGB, /255, ImageNet mean/std
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = ((float)px[2 - c] / 255.f - mean[c]) / sd[c];
+  }
+  float* d = dst + lay_off(ld, n, y, x);
+  *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], 0.f);
+  *reinterpret_cast<float4*>(d + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // Multi-scale test-time augmentation: dst = beta * dst + alpha * bilinear_resize(src), dense
 // NHWC, half-pixel centres, edge clamp (== F.interpolate(bilinear, align_corners=False) and
 // cv2.resize INTER_LINEAR on float data).  (sy, sx) = source pixels per destination pixel.
@@ -535,6 +593,18 @@ int rtpose_layout_axpby(float* dst, const rtpose_layout* ldst, const float* src_
   if (!total) return 0;
   hipLaunchKernelGGL(layout_axpby_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), dst,
                      to_lay(ldst), src_nhwc, C, N, H, W, alpha, beta);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_preprocess_u8(const unsigned char* img_bgr, int h0, int w0, double im_scale, int mode, float* dst,
+                         const rtpose_layout* ldst, int n_index, int Hn, int Wn, int hr, int wr, void* stream) {
+  if (!img_bgr || !dst || h0 <= 0 || w0 <= 0 || im_scale <= 0 || Hn < hr || Wn < wr || (mode != 0 && mode != 1) ||
+      ldst->cstride < 8 || (ldst->cstride % 4) || (ldst->choff % 4))
+    return fail(RTPOSE_E_INVAL, "preprocess_u8: bad arguments");
+  const size_t total = (size_t)Hn * Wn;
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), img_bgr, h0,
+                     w0, 1.0 / im_scale, mode, dst, to_lay(ldst), n_index, Hn, Wn, hr, wr);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -430,9 +430,25 @@ int rtpose_net_launch_info(rtpose_net* net, int i, float* ms, int* k, double* fl
   return 0;
 }
 
+static int net_forward_impl(rtpose_net* net, const float* x_nchw, void* stream);
+
 int rtpose_net_forward(rtpose_net* net, const float* x_nchw, void* stream) {
-  if (!net || !net->bound) return fail(RTPOSE_E_STATE, "net_forward: net not bound");
   if (!x_nchw) return fail(RTPOSE_E_INVAL, "net_forward: x is NULL");
+  return net_forward_impl(net, x_nchw, stream);
+}
+
+int rtpose_net_forward_prepared(rtpose_net* net, void* stream) { return net_forward_impl(net, nullptr, stream); }
+
+int rtpose_net_input_view(const rtpose_net* net, float** base, rtpose_layout* layout) {
+  if (!net || !net->bound) return fail(RTPOSE_E_STATE, "net_input_view: net not bound");
+  const Buf& b = net->bufs[net->x0_buf];
+  if (base) *base = net->ws + b.off_floats;
+  if (layout) *layout = b.lay;
+  return 0;
+}
+
+static int net_forward_impl(rtpose_net* net, const float* x_nchw, void* stream) {
+  if (!net || !net->bound) return fail(RTPOSE_E_STATE, "net_forward: net not bound");
   hipStream_t s = as_stream(stream);
   const int N = net->N;
   const bool prof = net->profiling && !net->ev.empty();
@@ -442,6 +458,7 @@ int rtpose_net_forward(rtpose_net* net, const float* x_nchw, void* stream) {
     int rc = 0;
     switch (o.kind) {
       case OP_INPUT: {
+        if (!x_nchw) break;  // forward_prepared: the input buffer was written by the caller
         const Buf& b = net->bufs[o.out_buf[0]];
         rc = rtpose_nchw_to_layout(x_nchw, net->ws + b.off_floats, &b.lay, 3, 8, N, o.H, o.W, stream);
         break;

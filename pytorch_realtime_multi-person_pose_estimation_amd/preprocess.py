@@ -117,6 +117,35 @@ def get_outputs(img, model, preprocess, config=None):
     return paf, heatmap, im_scale
 
 
+def get_outputs_gpu(img, model, preprocess, config=None):
+    """get_outputs with the image prep on the GPU too: the uint8 image is
+    uploaded as is (3 B/pixel instead of 12) and ONE kernel does resize + pad + normalise +
+    NHWC packing straight into the network's input buffer.  Same return values as get_outputs;
+    the resized pixels are bit-identical to resize_linear_u8."""
+    import ctypes as C
+    config = config or dec.default_config()
+    size, factor = int(config.DATASET.IMAGE_SIZE), int(config.MODEL.DOWNSAMPLE)
+    h0, w0 = img.shape[:2]
+    im_scale = float(size) / min(h0, w0)
+    hr, wr = _cv_round(h0 * im_scale), _cv_round(w0 * im_scale)
+    hn, wn = _factor_closest(hr, factor), _factor_closest(wr, factor)
+    m = _unwrap(model)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    img_d = torch.from_numpy(np.ascontiguousarray(img, dtype=np.uint8)).to(dev)
+    plan = m.plan_for(torch.empty((1, 3, hn, wn), device=dev))
+    base, lay = C.c_void_p(), _capi.Layout()
+    check(lib.rtpose_net_input_view(plan.handle, C.byref(base), C.byref(lay)), "rtpose_net_input_view")
+    mode = {'rtpose': 0, 'vgg': 1}[preprocess]
+    s = current_stream()
+    check(lib.rtpose_preprocess_u8(ptr(img_d), h0, w0, im_scale, mode, base, C.byref(lay), 0, hn, wn, hr, wr, s),
+          "rtpose_preprocess_u8")
+    check(lib.rtpose_net_set_keep_intermediates(plan.handle, 0))
+    check(lib.rtpose_net_forward_prepared(plan.handle, s), "rtpose_net_forward_prepared")
+    paf = m.read_output(plan, 10).cpu().numpy().transpose(0, 2, 3, 1)[0]
+    heatmap = m.read_output(plan, 11).cpu().numpy().transpose(0, 2, 3, 1)[0]
+    return paf, heatmap, im_scale
+
+
 def handle_paf_and_heat(normal_heat, flipped_heat, normal_paf, flipped_paf):
     """coco_eval.py:197-242 on the GPU (csrc/layout_ops.hip:flip_merge_kernel)."""
     dev = torch.device('cuda', torch.cuda.current_device())

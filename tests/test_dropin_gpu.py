@@ -119,3 +119,39 @@ def test_multiscale_flip_outputs(compat, cuda):
     assert np.abs(paf_a - paf1).max() <= 1e-5 and np.abs(heat_a - heat1).max() <= 1e-5
     assert np.isfinite(paf_m).all() and np.isfinite(heat_m).all()
     # flip-symmetry sanity: TTA of the mirrored image == mirrored TTA (x-PAF channels negated, L/R swapped)
+
+
+def test_gpu_preprocess_bit_exact_and_same_outputs(compat, capi, cuda):
+    """rtpose_preprocess_u8 == crop_with_factor + rtpose/vgg_preprocess (numpy restatement), bit for bit,
+    and get_outputs_gpu == get_outputs."""
+    import ctypes as C
+    from lib.network.rtpose_vgg import get_model
+    from oracle import net_oracle
+    pre = importlib.import_module(PKG_NAME + ".preprocess")
+    lib = capi.lib
+    rng = np.random.default_rng(2)
+    for (h0, w0), mode in (((337, 356), 'rtpose'), ((200, 150), 'vgg'), ((368, 368), 'rtpose'), ((97, 233), 'vgg')):
+        img = rng.integers(0, 256, (h0, w0, 3), dtype=np.uint8)
+        crop, scale, real = pre.crop_with_factor(img, 368, factor=8, is_ceil=True)
+        ref = (pre.rtpose_preprocess if mode == 'rtpose' else pre.vgg_preprocess)(crop)      # [3, hn, wn]
+        hn, wn = crop.shape[:2]
+        lay = capi.Layout.padded(8, hn, wn, 1)
+        buf = torch.zeros(lib.rtpose_layout_pixels(C.byref(lay), 1, hn, wn) * 8, device=cuda)
+        img_d = torch.from_numpy(img).to(cuda)
+        capi.check(lib.rtpose_preprocess_u8(capi.ptr(img_d), h0, w0, scale, 0 if mode == 'rtpose' else 1, capi.ptr(buf),
+                                            C.byref(lay), 0, hn, wn, real[0], real[1], capi.current_stream()))
+        out = torch.empty(1, 3, hn, wn, device=cuda)
+        capi.check(lib.rtpose_layout_to_nchw(capi.ptr(buf), C.byref(lay), capi.ptr(out), 3, 1, hn, wn, capi.current_stream()))
+        got = out[0].cpu().numpy()
+        if mode == 'rtpose':
+            assert np.array_equal(got, ref)
+        else:   # float division order: numpy divides the whole array by 255. then subtracts / divides
+            assert np.abs(got - ref).max() <= 2e-7
+    model = get_model('vgg19')
+    model.load_state_dict(net_oracle.he_init_state_dict(model, seed=0))
+    model = model.cuda().eval()
+    img = rng.integers(0, 256, (150, 190, 3), dtype=np.uint8)
+    with torch.no_grad():
+        paf_a, heat_a, s_a = pre.get_outputs(img, model, 'rtpose')
+        paf_b, heat_b, s_b = pre.get_outputs_gpu(img, model, 'rtpose')
+    assert s_a == s_b and np.array_equal(paf_a, paf_b) and np.array_equal(heat_a, heat_b)
