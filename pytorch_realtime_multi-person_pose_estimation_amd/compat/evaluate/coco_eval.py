@@ -11,6 +11,14 @@ ORDER_COCO = _pre.ORDER_COCO
 handle_paf_and_heat = _pre.handle_paf_and_heat
 
 
+_oks = module("oks_eval")
+
+
+def eval_coco(outputs, annFile, imgIds):
+    """coco_eval.py:55-75 without pycocotools: OKS AP @[.5:.95] (stats[0])."""
+    return _oks.eval_coco(outputs, annFile, imgIds)
+
+
 def get_outputs(img, model, preprocess):
     return _pre.get_outputs(img, model, preprocess, cfg)
 

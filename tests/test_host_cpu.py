@@ -177,3 +177,65 @@ def test_resize_linear_restatement_close_to_float_bilinear(pkg):
     assert not cropped[:, 389:].any()
     x = pre.rtpose_preprocess(cropped)
     assert x.shape == (3, 368, 392) and x.dtype == np.float32 and -0.5 <= x.min() and x.max() < 0.5
+
+
+def _fake_person(rng, img_id, ann_id, cx, cy, size):
+    kp = np.zeros((17, 3))
+    kp[:, 0] = cx + rng.uniform(-0.3, 0.3, 17) * size
+    kp[:, 1] = cy + rng.uniform(-0.5, 0.5, 17) * size
+    kp[:, 2] = 2
+    kp[rng.uniform(size=17) < 0.2, 2] = 0
+    x0, y0 = kp[:, 0].min(), kp[:, 1].min()
+    bw, bh = kp[:, 0].max() - x0, kp[:, 1].max() - y0
+    return {"image_id": img_id, "id": ann_id, "category_id": 1, "iscrowd": 0, "keypoints": list(kp.reshape(51)),
+            "num_keypoints": int((kp[:, 2] > 0).sum()), "bbox": [x0, y0, bw, bh], "area": float(bw * bh)}
+
+
+def test_oks_evaluator_properties(pkg):
+    """OKS/AP stand-in for pycocotools (coco_eval.py:55-75): exact detections -> AP 1; jitter lowers
+    AP monotonically; a detection on the wrong person scores ~0; crowd GT is ignored."""
+    oe = importlib.import_module(PKG_NAME + ".oks_eval")
+    rng = np.random.default_rng(0)
+    gts, aid = [], 0
+    for img in range(12):
+        for _ in range(int(rng.integers(1, 4))):
+            aid += 1
+            gts.append(_fake_person(rng, img, aid, rng.uniform(100, 500), rng.uniform(100, 400), rng.uniform(60, 200)))
+
+    def dets(jitter):
+        out = []
+        for g in gts:
+            k = np.array(g["keypoints"]).reshape(17, 3).copy()
+            k[:, :2] += rng.normal(0, jitter, (17, 2)) * np.sqrt(g["area"])
+            k[:, 2] = 1
+            out.append({"image_id": g["image_id"], "category_id": 1, "keypoints": list(k.reshape(51)), "score": 1.0})
+        return out
+
+    perfect = oe.evaluate(gts, dets(0.0))
+    assert abs(perfect["AP"] - 1.0) < 1e-9 and abs(perfect["AP50"] - 1.0) < 1e-9
+    a1, a2, a3 = (oe.evaluate(gts, dets(j))["AP"] for j in (0.01, 0.05, 0.2))
+    assert 1.0 >= a1 > a2 > a3 >= 0.0 and a1 > 0.9 and a3 < 0.3
+    # OKS of identical keypoints is 1, of far-away keypoints ~0
+    g = gts[0]
+    d_same = {"keypoints": g["keypoints"], "score": 1}
+    far = np.array(g["keypoints"]).reshape(17, 3).copy()
+    far[:, :2] += 5000
+    assert abs(oe.compute_oks([g], [d_same])[0, 0] - 1.0) < 1e-12
+    assert oe.compute_oks([g], [{"keypoints": list(far.reshape(51)), "score": 1}])[0, 0] < 1e-6
+    # crowd ground truth neither counts as a miss nor as a false positive when matched
+    crowd = dict(gts[0], iscrowd=1)
+    res = oe.evaluate([crowd] + gts[1:], dets(0.0))
+    assert abs(res["AP"] - 1.0) < 1e-9
+    # append_result keeps the reference's COCO order and +0.5 offsets (coco_eval.py:117-154)
+    pre = importlib.import_module(PKG_NAME + ".preprocess")
+    common = importlib.import_module(PKG_NAME + ".common")
+    h = common.Human([])
+    h.body_parts[0] = common.BodyPart('0-0', 0, 0.5, 0.25, 0.9)
+    h.body_parts[16] = common.BodyPart('0-16', 16, 0.1, 0.2, 0.8)
+    outs = []
+    pre.append_result(42, [h], (400, 600), outs)
+    kp = np.array(outs[0]["keypoints"]).reshape(17, 3)
+    assert outs[0]["image_id"] == 42 and outs[0]["score"] == 1.0
+    assert tuple(kp[0]) == (0.5 * 600 + 0.5, 0.25 * 400 + 0.5, 1)          # nose -> COCO 0
+    assert tuple(kp[4]) == (0.1 * 600 + 0.5, 0.2 * 400 + 0.5, 1)           # our 16 (REar) -> COCO index 4
+    assert kp[:, 2].sum() == 2
