@@ -100,6 +100,19 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   constexpr int CG = CK / 4;  // 16-byte channel groups per chunk
   constexpr int G = CK / 8;   // 8-deep k groups per chunk (4 MFMAs each)
   constexpr int PPT = PiecesPerTap<KS>::value;
+  // 1x1 convs have no spatial taps to re-use a halo over.  The tap loop can instead walk
+  // the channel axis: one LDS buffer holds TB consecutive CK-channel sub-chunks of the pixel
+  // tile ([TB*CG planes][pixel][4]) and tap t multiplies sub-chunk t, with the k x k
+  // machinery (B/A prefetch, next buffer staged under the MFMAs) unchanged.  Measured with
+  // TB = 4 (double-buffered, 2 blocks/CU): SLOWER than TB = 1 single-buffered at 4 blocks/CU
+  // (VGG 1x1 layers 1.27 vs 1.04 ms, ShuffleNetV2 pointwise 13.6 vs 12.7 ms): these GEMMs
+  // are short (K = 24..512), so per-block prologue/epilogue latency dominates and is hidden
+  // better by occupancy than by in-block pipelining.  TB stays a knob for a future
+  // multi-tile (persistent) 1x1 kernel.
+  constexpr int TB = 1;
+  constexpr int CGB = CG * TB;              // channel-group planes per LDS buffer
+  constexpr int TAPS = (KS == 1) ? TB : KS; // taps per "row" of the tap loop
+  constexpr int ROWS = (KS == 1) ? 1 : KS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -139,7 +152,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     np_pix = (TH + 2 * P) * A.hw_lds;
     row_lds = A.hw_lds;
   }
-  const int np_total = np_pix * CG;  // 16-byte pieces per chunk
+  const int np_total = np_pix * CGB;  // 16-byte pieces per LDS buffer
 
   // ---- per-lane A fragment bases (LDS pixel index of this lane's row) ------
   int abase[MF];
@@ -164,8 +177,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   // thread `tid` owns pieces tid, tid+256, ... ("sets").  LDS image: [group][pixel][4].
   const int in_cstride = g.in_cstride, in_ws = g.in_ws;
   const float* in_base = g.in + g.in_choff;
-  constexpr int PIXSET = 256 / CG;            // halo pixels covered by one piece set
-  const int pj = tid % CG, ppix0 = tid / CG;  // this thread's group and first pixel
+  constexpr int PIXSET = 256 / CGB;             // halo pixels covered by one piece set
+  const int pj = tid % CGB, ppix0 = tid / CGB;  // this thread's group and first pixel
   const unsigned hw_inv = MODE == 1 ? (65536u + A.hw_lds - 1) / A.hw_lds : 0u;
   // global float offset (from the chunk's first channel) and LDS float offset of piece
   // (set, tid).  MODE 0 may run past the halo (never past the buffer: layout slack);
@@ -186,7 +199,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   // 16-byte aligned and emits ds_read_b128 / ds_write_b128 (with float offsets it fell
   // back to ds_read2_b32 pairs: 2x the instructions and 4-way bank conflicts)
   float4* smem4 = reinterpret_cast<float4*>(smem);
-  const int buf4 = CG * QS;  // float4 per halo buffer
+  const int buf4 = CGB * QS;  // float4 per halo buffer
   auto piece_loff = [&](int set) -> int { return pj * QS + set * PIXSET + ppix0; };
   // a thread with nothing to park writes its stale registers to a private dummy slot
   // behind the two buffers, so the park step needs no per-thread branch
@@ -214,19 +227,21 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   }
 
   // ---- halo fill used by the prologue (NBUF 2) / before every chunk (NBUF 1) ------
-  auto fill_halo = [&](const float* src) {
+  auto fill_halo = [&](const float* src, int ntaps) {  // ntaps: sub-chunks that exist in this buffer
+    const bool ch_ok = pj < ntaps * CG;
     for (int set0 = 0; set0 < nsets; set0 += 4) {
       float4 t[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u)  // 4 loads in flight per thread
-        if ((set0 + u) * 256 + tid < np_total) t[u] = gload4(src + piece_goff(set0 + u));
+        if (ch_ok && (set0 + u) * 256 + tid < np_total) t[u] = gload4(src + piece_goff(set0 + u));
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if ((set0 + u) * 256 + tid < np_total) smem4[piece_loff(set0 + u)] = t[u];
+        if (ch_ok && (set0 + u) * 256 + tid < np_total) smem4[piece_loff(set0 + u)] = t[u];
     }
   };
+  const int nbig = (nchunks + TB - 1) / TB;  // LDS buffer fills per block
   if (NBUF == 2) {
-    fill_halo(in_base);
+    fill_halo(in_base, min(TB, nchunks));
     __syncthreads();
   }
 
@@ -242,7 +257,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   for (int gi = 0; gi < G; ++gi)
 #pragma unroll
     for (int fm = 0; fm < MF; ++fm) afrag[gi][fm] = (2 * gi + kh) * QS + abase[fm];
-  const int rowstep = row_lds;  // float4 per stencil row in the LDS image
+  // float4 between consecutive taps' A fragments: one stencil row (k x k) or CG planes (1x1)
+  const int rowstep = KS == 1 ? CG * QS : row_lds;
 
   // One tap = 8*G MFMAs with the loads for the NEXT tap threaded between them in a
   // fixed order: B straight from L2, A fragments from LDS (running row address +
@@ -293,7 +309,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
         BLOAD[g2] = RTPOSE_EXP_B(gload4(bq[g2]), BCUR[g2]);                                           \
       }                                                                                        \
       if (n == 1) {                                                                            \
-        if ((KX) == KS - 1) { /* the next tap starts the next stencil row */                   \
+        if (KS == 1 || (KX) == KS - 1) { /* next tap: next sub-chunk (1x1) / next stencil row */ \
           _Pragma("unroll") for (int g2 = 0; g2 < G; ++g2)                                     \
             _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) arow[g2][fm] += rowstep;         \
         }                                                                                      \
@@ -303,7 +319,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
             const int set = ps * PPT + p;                                                      \
             if (set < nsets) { /* uniform: sets past the halo are not fetched at all */        \
               hv[p] = gload4(next_base + piece_goff(set));                                     \
-              hl[p] = (tid < np_total - set * 256) ? hn_off + piece_loff(set) : dummy_loff;    \
+              hl[p] = (next_ch_ok && tid < np_total - set * 256) ? hn_off + piece_loff(set) : dummy_loff; \
             } else {                                                                           \
               hv[p] = make_float4(0.f, 0.f, 0.f, 0.f);                                         \
               hl[p] = dummy_loff;                                                              \
@@ -314,17 +330,18 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
       }                                                                                        \
       if (n >= 2 && n - 2 < G) {                                                               \
         _Pragma("unroll") for (int fm = 0; fm < MF; ++fm)                                      \
-          ANXT[n - 2][fm] = RTPOSE_EXP_A(smem4[arow[n - 2][fm] + (((KX) + 1 < KS) ? (KX) + 1 : 0)], ACUR[n - 2][fm]); \
+          ANXT[n - 2][fm] = RTPOSE_EXP_A(smem4[arow[n - 2][fm] + ((KS > 1 && (KX) + 1 < KS) ? (KX) + 1 : 0)], ACUR[n - 2][fm]); \
       }                                                                                        \
       RTPOSE_PIN();                                                                            \
     }                                                                                          \
   }
 #define RTPOSE_CONV_ROW(STAGE)                                                  \
   {                                                                             \
-    _Pragma("unroll") for (int kx = 0; kx < KS; ++kx) {                         \
+    _Pragma("unroll") for (int kx = 0; kx < TAPS; ++kx) {                       \
       /* A sets alternate (kx & 1); B sets rotate (kx % 3): multiply s[kx%3],  */ \
       /* fill s[(kx+2)%3] with the tap two ahead                               */ \
-      if (kx % 6 == 0) {                                                        \
+      if (KS == 1 && kx >= nt) { /* short last buffer of a 1x1 conv */          \
+      } else if (kx % 6 == 0) {                                                 \
         RTPOSE_CONV_STEP(a0, a1, s0, s2, kx, STAGE)                             \
       } else if (kx % 6 == 1) {                                                 \
         RTPOSE_CONV_STEP(a1, a0, s1, s0, kx, STAGE)                             \
@@ -340,15 +357,15 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     }                                                                           \
     /* re-normalise the register roles for the next row (a few v_mov per row) */ \
     _Pragma("unroll") for (int gi = 0; gi < G; ++gi) {                          \
-      if (KS & 1) {                                                             \
+      if (TAPS & 1) {                                                           \
         _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) a0[gi][fm] = a1[gi][fm]; \
       }                                                                         \
-      if (KS % 3 == 1) {                                                        \
+      if (TAPS % 3 == 1) {                                                      \
         const float4 t_ = s0[gi];                                               \
         s0[gi] = s1[gi];                                                        \
         s1[gi] = s2[gi];                                                        \
         s2[gi] = t_;                                                            \
-      } else if (KS % 3 == 2) {                                                 \
+      } else if (TAPS % 3 == 2) {                                               \
         const float4 t_ = s2[gi];                                               \
         s2[gi] = s1[gi];                                                        \
         s1[gi] = s0[gi];                                                        \
@@ -359,12 +376,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
 
   // rows of a chunk whose taps carry the staging code: set s is fetched at tap s and
   // parked at tap s+1, so nsets+1 taps are needed (the host guarantees they exist)
-  const int stage_rows = min(KS, (nsets + 1 + PPT * KS - 1) / (PPT * KS));
+  const int stage_rows = min(ROWS, (nsets + 1 + PPT * TAPS - 1) / (PPT * TAPS));
   float4 hv[PPT];
   int hl[PPT];
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
+  for (int chunk = 0; chunk < nbig; ++chunk) {   // one LDS buffer (TB sub-chunks of CK channels) per turn
+    const int nt = min(TB, nchunks - chunk * TB);  // taps that exist in this buffer (1x1 only: < TB at the end)
+    (void)nt;
     if (NBUF == 1) {  // every wave is past the previous chunk (barrier at the loop end)
-      fill_halo(in_base + (size_t)chunk * CK);
+      fill_halo(in_base + (size_t)chunk * TB * CK, nt);
       __syncthreads();
     }
 #ifdef RTPOSE_EXP_STAGGER
@@ -377,7 +396,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     const int hb_off = NBUF == 2 ? (chunk & 1) * buf4 : 0;
     const int hn_off = NBUF == 2 ? ((chunk + 1) & 1) * buf4 : 0;
     // the last chunk re-stages itself into the idle buffer (never read): no branch
-    const float* next_base = in_base + (size_t)min(chunk + 1, nchunks - 1) * CK;
+    const int chunk_next = min(chunk + 1, nbig - 1);
+    const float* next_base = in_base + (size_t)chunk_next * TB * CK;
+    const bool next_ch_ok = pj < min(TB, nchunks - chunk_next * TB) * CG;
+    (void)next_ch_ok;
     int ps = 0;
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
@@ -397,7 +419,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     int ky = 0;
     if (NBUF == 2)
       for (; ky < stage_rows; ++ky) RTPOSE_CONV_ROW(1)
-    for (; ky < KS; ++ky) RTPOSE_CONV_ROW(0)
+    for (; ky < ROWS; ++ky) RTPOSE_CONV_ROW(0)
     if (NBUF == 2) {  // park whatever is still in flight, then publish the buffer
 #pragma unroll
       for (int p = 0; p < PPT; ++p) smem4[hl[p]] = hv[p];
@@ -555,14 +577,15 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* p
   const int P = d.k / 2;
   pl->ck = conv_ck(d.cin);
   const int M = N * H * W;
-  const int max_pieces = (d.k == 1) ? PiecesPerTap<1>::value : d.k * d.k;  // per thread
-  const int cg = pl->ck / 4;
+  // piece sets per thread that fit the staging schedule (set s fetched at tap s, parked at s+1)
+  const int max_pieces = (d.k == 1) ? PiecesPerTap<1>::value : d.k * d.k - 1;
+  const int cg = pl->ck / 4;  // channel-group planes per LDS buffer (x TB for 1x1, TB = 1 today)
   if (!g_force_nbuf) {
     const char* e = getenv("RTPOSE_CONV_NBUF");
     g_force_nbuf = e ? atoi(e) : -1;
   }
-  // 1x1 layers have one tap per chunk: nothing to hide a second buffer's fill under,
-  // so they take the single-buffer / 4-blocks-per-CU variant (measured 42.7 vs 32.6 TF/s)
+  // 1x1 layers: single halo buffer, 4 blocks per CU (occupancy hides the refill latency of
+  // these short-K GEMMs better than a second buffer: 42.7 vs 32.6 TF/s); k x k: double buffer
   pl->nbuf = (g_force_nbuf == 1 || g_force_nbuf == 2) ? g_force_nbuf : (d.k == 1 ? 1 : 2);
   bool strip = (W <= 64) && !d.pool;
   if (strip) {
@@ -619,7 +642,7 @@ static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) 
   auto kern = conv_mfma_f32<KS, CK, MODE, NBUF>;
   if (!attr_set) {
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
