@@ -65,7 +65,8 @@ struct ConvArgs {
   int hw_lds;         // MODE 1: LDS row stride of the halo (pixels)
   int tw_log2;        // MODE 1: log2(tile width); tile height = 128 >> tw_log2
   int tiles_x, tiles_y;
-  int mtiles, ntiles, nbig;  // MODE 0 block-id decoding (see conv_mfma_f32)
+  int mtiles, ntiles, nbig;  // block-id decoding (see conv_mfma_f32)
+  int ncombo, xcd_remap;
 };
 
 constexpr int kBM = 128;
@@ -92,13 +93,17 @@ __device__ __forceinline__ void tile_local_yx(int ml, int tw_log2, int& ty, int&
 // MF = 32-row M fragments per wave: 2 = the normal 128-pixel block tile, 1 = a 64-pixel
 // half tile used only for the last, partial wave of blocks of a strip-mode launch (tail
 // quantisation: see plan_conv).
-template <int KS, int CK, int MODE, int NBUF, int MF>
+// NF = 32-column N fragments per wave: 1 -> block tile 128 x 64, 2 -> 128 x 128 (wave tile
+// 64 x 64).  NF = 2 halves the B (weight) and A (LDS) operand bytes per MFMA; measured, the B
+// loads cost ~4.6 % of the forward and half of them ~2 %.
+template <int KS, int CK, int MODE, int NBUF, int MF, int NF>
 __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g, const int m0_arg,
                                           const int ntile, float* smem) {
   constexpr int P = KS / 2;
   constexpr int BMT = 64 * MF;  // pixels per block tile
   constexpr int CG = CK / 4;  // 16-byte channel groups per chunk
   constexpr int G = CK / 8;   // 8-deep k groups per chunk (4 MFMAs each)
+  constexpr int GB = G * NF;  // B registers (float4) per tap: [n-fragment][k-group]
   constexpr int PPT = PiecesPerTap<KS>::value;
   // 1x1 convs have no spatial taps to re-use a halo over.  The tap loop can instead walk
   // the channel axis: one LDS buffer holds TB consecutive CK-channel sub-chunks of the pixel
@@ -140,7 +145,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     np_pix = qcl + P * g.in_ws + P - q_origin + 1;
     row_lds = g.in_ws;
   } else {
-    int b = blockIdx.x;
+    int b = m0_arg;  // MODE 1: the tile index
     const int txi = b % A.tiles_x;
     b /= A.tiles_x;
     const int tyi = b % A.tiles_y;
@@ -208,19 +213,21 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
 
   // ---- B operand pointers (advance one (chunk,tap) block per tap) ---------------
   const int nchunks = A.cin / CK;
-  const int ncol = ntile * kConvBN + wn * 32 + l31;
-  const float4* bq[G];
+  const int ncol = ntile * (kConvBN * NF) + wn * (32 * NF) + l31;  // column of n-fragment 0
+  const float4* bq[GB];
 #pragma unroll
-  for (int gi = 0; gi < G; ++gi)
-    bq[gi] = reinterpret_cast<const float4*>(g.w) + (size_t)(2 * gi + kh) * g.cout_pad + ncol;
+  for (int fn = 0; fn < NF; ++fn)
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi)
+      bq[fn * G + gi] = reinterpret_cast<const float4*>(g.w) + (size_t)(2 * gi + kh) * g.cout_pad + ncol + fn * 32;
   const size_t b_it_stride = (size_t)CG * g.cout_pad;  // float4 per (chunk,tap)
 
   // B lives in three register sets: the tap being multiplied, the next one, and the one
   // in flight from L2 (two taps of lead: one tap was not enough to cover L2 latency
   // under load - dropping the B loads was worth +7% on the 7x7 layers)
-  float4 s0[G], s1[G], s2[G];
+  float4 s0[GB], s1[GB], s2[GB];
 #pragma unroll
-  for (int gi = 0; gi < G; ++gi) {
+  for (int gi = 0; gi < GB; ++gi) {
     s0[gi] = gload4(bq[gi]);
     bq[gi] += b_it_stride;
     s1[gi] = gload4(bq[gi]);
@@ -245,11 +252,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     __syncthreads();
   }
 
-  floatx16 acc[MF];
+  floatx16 acc[MF][NF];
 #pragma unroll
   for (int fm = 0; fm < MF; ++fm)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[fm][r] = 0.f;
+    for (int fn = 0; fn < NF; ++fn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[fm][fn][r] = 0.f;
 
   // LDS float4 offsets of this lane's A fragments inside a halo buffer: [k-group][m-frag]
   int afrag[G][MF];
@@ -269,9 +278,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   // waves share a SIMD (tools/exp_variants.sh drops one load stream at a time).
   // which B register (k-group) is fetched after MFMA pair n (-1 = none)
 #ifdef RTPOSE_EXP_BSPREAD
-#define RTPOSE_EXP_BSLOT(n) (((n) % 4 == 0 && (n) / 4 < G) ? (n) / 4 : -1)
+#define RTPOSE_EXP_BSLOT(n) (((n) % 2 == 0 && (n) / 2 < GB) ? (n) / 2 : -1)
 #else
-#define RTPOSE_EXP_BSLOT(n) (((n) == 0) ? 0 : (((n) == 1 && G > 1) ? 1 : (((n) == 5 && G > 2) ? 2 : (((n) == 6 && G > 3) ? 3 : -1))))
+#define RTPOSE_EXP_BSLOT(n) (((n) < GB) ? (n) : -1)
+#endif
+#ifdef RTPOSE_EXP_HALF_B_ON
+#define RTPOSE_EXP_HALF_B 1
+#else
+#define RTPOSE_EXP_HALF_B 0
 #endif
 #ifdef RTPOSE_EXP_NO_B
 #define RTPOSE_EXP_B(load, keep) (keep)
@@ -297,16 +311,19 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   {                                                                                            \
     _Pragma("unroll") for (int n = 0; n < 4 * G; ++n) {                                        \
       const int gi_ = n >> 2, j_ = n & 3;                                                      \
-      const float bv_[4] = {BCUR[gi_].x, BCUR[gi_].y, BCUR[gi_].z, BCUR[gi_].w};               \
-      _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) {                                      \
-        const float av_[4] = {ACUR[gi_][fm].x, ACUR[gi_][fm].y, ACUR[gi_][fm].z, ACUR[gi_][fm].w}; \
-        acc[fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[j_], bv_[j_], acc[fm], 0, 0, 0);    \
+      _Pragma("unroll") for (int fn = 0; fn < NF; ++fn) {                                      \
+        const float bv_[4] = {BCUR[fn * G + gi_].x, BCUR[fn * G + gi_].y, BCUR[fn * G + gi_].z, \
+                              BCUR[fn * G + gi_].w};                                           \
+        _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) {                                    \
+          const float av_[4] = {ACUR[gi_][fm].x, ACUR[gi_][fm].y, ACUR[gi_][fm].z, ACUR[gi_][fm].w}; \
+          acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[j_], bv_[j_], acc[fm][fn], 0, 0, 0); \
+        }                                                                                      \
       }                                                                                        \
       RTPOSE_PIN();                                                                            \
       if (RTPOSE_EXP_BSLOT(n) >= 0) {                                                          \
         const int g2 = RTPOSE_EXP_BSLOT(n);                                                    \
         bq[g2] += b_it_stride;                                                                 \
-        BLOAD[g2] = RTPOSE_EXP_B(gload4(bq[g2]), BCUR[g2]);                                           \
+        BLOAD[g2] = (RTPOSE_EXP_HALF_B && g2 >= 1) ? BCUR[g2] : RTPOSE_EXP_B(gload4(bq[g2]), BCUR[g2]); \
       }                                                                                        \
       if (n == 1) {                                                                            \
         if (KS == 1 || (KX) == KS - 1) { /* next tap: next sub-chunk (1x1) / next stencil row */ \
@@ -356,10 +373,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
       }                                                                         \
     }                                                                           \
     /* re-normalise the register roles for the next row (a few v_mov per row) */ \
-    _Pragma("unroll") for (int gi = 0; gi < G; ++gi) {                          \
-      if (TAPS & 1) {                                                           \
+    if (TAPS & 1) {                                                             \
+      _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                          \
         _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) a0[gi][fm] = a1[gi][fm]; \
-      }                                                                         \
+    }                                                                           \
+    _Pragma("unroll") for (int gi = 0; gi < GB; ++gi) {                         \
       if (TAPS % 3 == 1) {                                                      \
         const float4 t_ = s0[gi];                                               \
         s0[gi] = s1[gi];                                                        \
@@ -431,9 +449,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
 #undef RTPOSE_PIN
 
   // ---- epilogue: bias (+ReLU) (+2x2 max-pool), masked stores -----------------
-  const bool col_ok = ncol < g.cout;
-  const float bias = g.bias[ncol];  // bias is padded to cout_pad
-  float* out_base = g.out + ((g.out_cmap && col_ok) ? g.out_cmap[ncol] : g.out_choff + ncol);
+#pragma unroll
+  for (int fn = 0; fn < NF; ++fn) {
+  const int ncolf = ncol + fn * 32;
+  const bool col_ok = ncolf < g.cout;
+  const float bias = g.bias[ncolf];  // bias is padded to cout_pad
+  float* out_base = g.out + ((g.out_cmap && col_ok) ? g.out_cmap[ncolf] : g.out_choff + ncolf);
   if (!A.pool) {
 #pragma unroll
     for (int fm = 0; fm < MF; ++fm) {
@@ -462,7 +483,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
             x = x0 + tx;
             ok = (y < A.H) && (x < A.W);
           }
-          float v = acc[fm][rg * 4 + rr] + bias;
+          float v = acc[fm][fn][rg * 4 + rr] + bias;
           if (A.relu) v = fmaxf(v, 0.f);
           if (ok && col_ok) {
             const size_t q = (size_t)g.out_lead + (size_t)(n * g.out_hs + y) * g.out_ws + x;
@@ -483,8 +504,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
         const int qi = ml0 >> 2;
         const int py = (y0 >> 1) + (qi >> hw_log2);
         const int px = (x0 >> 1) + (qi & ((1 << hw_log2) - 1));
-        float v = fmaxf(fmaxf(acc[fm][rg * 4 + 0], acc[fm][rg * 4 + 1]),
-                        fmaxf(acc[fm][rg * 4 + 2], acc[fm][rg * 4 + 3])) + bias;
+        float v = fmaxf(fmaxf(acc[fm][fn][rg * 4 + 0], acc[fm][fn][rg * 4 + 1]),
+                        fmaxf(acc[fm][fn][rg * 4 + 2], acc[fm][fn][rg * 4 + 3])) + bias;
         if (A.relu) v = fmaxf(v, 0.f);
         if (py < Ho && px < Wo && col_ok) {
           const size_t q = (size_t)g.out_lead + (size_t)(n_img * g.out_hs + py) * g.out_ws + px;
@@ -493,31 +514,41 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
       }
     }
   }
+  }  // fn
 }
 
-// Kernel: block id -> (group, N tile, M tile).  MODE 1 uses the 3-D grid directly.  MODE 0
-// (strip) uses a 1-D grid so that the LAST blocks of the launch can be half tiles: ids
-// [0, nbig) are 128-pixel tiles in (m fastest, then n tile, then group) order, the rest
-// are pairs of 64-pixel halves of the remaining tiles (dispatched last = the tail).
-template <int KS, int CK, int MODE, int NBUF>
+// Kernel: 1-D grid, block id -> (group, N tile, M tile).
+//  * XCD-aware order (xcd_remap): the dispatcher places block b on XCD b % 8 (observed; used
+//    for speed only).  Ids are laid out so that the (group, N tile) combinations of ONE M tile
+//    are consecutive slots of ONE XCD: they run together and share that tile's input halo in
+//    the XCD's L2 instead of each re-reading it from MALL/HBM (8 N tiles x 1.75 halo overlap
+//    = 14 reads of every input pixel of conv4_2 before this).
+//  * MODE 0 (strip) tail: ids [0, nbig) are 128-pixel tiles; the rest are pairs of 64-pixel
+//    halves of the remaining tiles, dispatched last (see plan in conv2d_launch).
+template <int KS, int CK, int MODE, int NBUF, int NF>
 __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const ConvArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (MODE == 1) {
-    conv_tile<KS, CK, MODE, NBUF, 2>(A, A.g[blockIdx.z], 0, blockIdx.y, smem);
+  const int L = blockIdx.x;
+  const bool small = MODE == 0 && L >= A.nbig;
+  const int bi = small ? A.nbig + ((L - A.nbig) >> 1) : L;
+  int mt, c;
+  if (A.xcd_remap) {
+    const int xcd = bi & 7, j = bi >> 3;
+    c = j % A.ncombo;
+    mt = (j / A.ncombo) * 8 + xcd;
   } else {
-    const int L = blockIdx.x;
-    const bool small = L >= A.nbig;
-    const int bi = small ? A.nbig + ((L - A.nbig) >> 1) : L;
-    const int mt = bi % A.mtiles;
-    const int r = bi / A.mtiles;
-    const int nt = r % A.ntiles;
-    const int grp = r / A.ntiles;
-    if (!small) {
-      conv_tile<KS, CK, MODE, NBUF, 2>(A, A.g[grp], mt * kBM, nt, smem);
-    } else {
-      const int m0 = mt * kBM + ((L - A.nbig) & 1) * (kBM / 2);
-      if (m0 < A.M) conv_tile<KS, CK, MODE, NBUF, 1>(A, A.g[grp], m0, nt, smem);
-    }
+    mt = bi % A.mtiles;
+    c = bi / A.mtiles;
+  }
+  if (mt >= A.mtiles) return;  // padding ids of the remapped order
+  const int nt = c % A.ntiles, grp = c / A.ntiles;
+  if (MODE == 1) {
+    conv_tile<KS, CK, MODE, NBUF, 2, NF>(A, A.g[grp], mt, nt, smem);
+  } else if (!small) {
+    conv_tile<KS, CK, MODE, NBUF, 2, NF>(A, A.g[grp], mt * kBM, nt, smem);
+  } else {
+    const int m0 = mt * kBM + ((L - A.nbig) & 1) * (kBM / 2);
+    if (m0 < A.M) conv_tile<KS, CK, MODE, NBUF, 1, NF>(A, A.g[grp], m0, nt, smem);
   }
 }
 
@@ -554,7 +585,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __
 static int conv_ck(int cin) { return (cin % 16 == 0) ? 16 : 8; }
 
 struct ConvPlan {
-  int mode, ck, qs, hw_lds, tw_log2, tiles_x, tiles_y, grid_x, nbuf;
+  int mode, ck, qs, hw_lds, tw_log2, tiles_x, tiles_y, grid_x, nbuf, nf;
   size_t lds_bytes;
 };
 static int g_force_nbuf = 0;  // developer override (RTPOSE_CONV_NBUF=1|2)
@@ -636,10 +667,10 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* p
   return 0;
 }
 
-template <int KS, int CK, int MODE, int NBUF>
+template <int KS, int CK, int MODE, int NBUF, int NF>
 static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = conv_mfma_f32<KS, CK, MODE, NBUF>;
+  auto kern = conv_mfma_f32<KS, CK, MODE, NBUF, NF>;
   if (!attr_set) {
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -705,35 +736,53 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
   a.tw_log2 = pl.tw_log2;
   a.tiles_x = pl.tiles_x;
   a.tiles_y = pl.tiles_y;
-  dim3 grid(pl.grid_x, cout_pad(d0.cout) / kConvBN, ngroups);
+  // ---- 1-D grid: id order, XCD-aware remap, half-tile tail ------------------------------
+  static int n_cu = 0, xcd_remap_env = -1;
+  if (!n_cu) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+    const char* e = getenv("RTPOSE_CONV_XCD_REMAP");
+    xcd_remap_env = e ? atoi(e) : 1;
+  }
+  a.mtiles = pl.grid_x;
+  // 128-wide N tiles (wave tile 64 x 64, NF = 2) are available behind RTPOSE_CONV_NF=2 but
+  // NOT the default: measured on the 32 x 368 x 368 workload they help the 8-N-tile 3x3
+  // layers by ~3 % (conv4_1/4_2) and lose 11 % on the 7x7 stage convs (fewer, longer blocks:
+  // worse tail, and 32 MFMAs between filler slots) - 427 vs 464 img/s overall.
+  static int nf_env = 0;
+  if (!nf_env) {
+    const char* e = getenv("RTPOSE_CONV_NF");
+    nf_env = e ? atoi(e) : 1;
+  }
+  pl.nf = (nf_env == 2 && d0.k != 1 && pl.ck == 16 && pl.nbuf == 2 && cout_pad(d0.cout) % 128 == 0) ? 2 : 1;
+  a.ntiles = cout_pad(d0.cout) / (kConvBN * pl.nf);
+  a.ncombo = a.ntiles * ngroups;
+  a.xcd_remap = (xcd_remap_env != 0 && a.ncombo > 1 && a.mtiles >= 64) ? 1 : 0;
+  const long ids = a.xcd_remap ? (long)8 * a.ncombo * ceil_div(a.mtiles, 8) : (long)a.mtiles * a.ncombo;
+  if (ids > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv2d: grid too large");
+  a.nbig = (int)ids;
   if (pl.mode == 0) {
-    // Tail quantisation: `total` equal tiles on `slots` co-resident block slots run in
-    // lock-step rounds; a last round with few blocks leaves most CUs idle for a whole
-    // tile time.  When that remainder is small, split its tiles into two 64-pixel halves
-    // (twice the blocks, half the time).  32x46x46, cout 128 x 2 branches: 2116 tiles =
-    // 4 x 512 + 68 -> the last 68 become 136 halves.
-    static int n_cu = 0;
-    if (!n_cu) {
-      hipDeviceProp_t prop;
-      int dev = 0;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-        n_cu = prop.multiProcessorCount;
-      if (n_cu <= 0) n_cu = 256;
-    }
+    // Tail quantisation: equal tiles on `slots` co-resident block slots run in lock-step
+    // rounds; a last round with few blocks leaves most CUs idle for a whole tile time.  When
+    // that remainder is small, its tiles are split into two 64-pixel halves (twice the blocks,
+    // half the time).  32x46x46, cout 128 x 2 branches: 2116 tiles = 4 x 512 + 68 -> the last
+    // 68 become 136 halves.
     const int slots = n_cu * (pl.nbuf == 1 ? 4 : 2);
-    const int total = (int)(grid.x * grid.y * grid.z);
+    const int total = (int)ids;
     const int rem = total % slots;
-    a.mtiles = (int)grid.x;
-    a.ntiles = (int)grid.y;
-    a.nbig = total;
     const char* e = getenv("RTPOSE_CONV_NO_HALF_TILES");
     if (total > slots && rem > 0 && 2 * rem <= n_cu && !(e && e[0] == '1')) a.nbig = total - rem;
-    grid = dim3((unsigned)(a.nbig + 2 * (total - a.nbig)), 1, 1);
   }
+  dim3 grid((unsigned)(a.nbig + 2 * (ids - a.nbig)), 1, 1);
 #define RTPOSE_CONV_CASE(KS_, CK_, MODE_)                                  \
   if (d0.k == KS_ && pl.ck == CK_ && pl.mode == MODE_) {                   \
-    if (pl.nbuf == 1) return launch_inst<KS_, CK_, MODE_, 1>(a, grid, pl.lds_bytes, s); \
-    return launch_inst<KS_, CK_, MODE_, 2>(a, grid, pl.lds_bytes, s);      \
+    if (pl.nbuf == 1) return launch_inst<KS_, CK_, MODE_, 1, 1>(a, grid, pl.lds_bytes, s); \
+    if (pl.nf == 2 && KS_ != 1 && CK_ == 16)                               \
+      return launch_inst<KS_, CK_, MODE_, 2, (KS_ != 1 && CK_ == 16) ? 2 : 1>(a, grid, pl.lds_bytes, s); \
+    return launch_inst<KS_, CK_, MODE_, 2, 1>(a, grid, pl.lds_bytes, s);   \
   }
   RTPOSE_CONV_CASE(3, 8, 0)
   RTPOSE_CONV_CASE(3, 8, 1)

@@ -17,8 +17,6 @@ build() { # name flags...
 }
 build base
 build nob -DRTPOSE_EXP_NO_B
-build stag1 -DRTPOSE_EXP_STAGGER=1
-build stag4 -DRTPOSE_EXP_STAGGER=4
-build bspread -DRTPOSE_EXP_BSPREAD
-build bspread_stag2 -DRTPOSE_EXP_BSPREAD -DRTPOSE_EXP_STAGGER=2
+build halfb -DRTPOSE_EXP_HALF_B_ON
+build noa -DRTPOSE_EXP_NO_A
 ls -la tools/exp
