@@ -67,6 +67,8 @@ struct ConvArgs {
   int tiles_x, tiles_y;
   int mtiles, ntiles, nbig;  // block-id decoding (see conv_mfma_f32)
   int ncombo, xcd_remap;
+  int dephase_mode;          // 0 off, 1: ids [n_cu, 2 n_cu), 2: odd ids (first wave of blocks only)
+  int dephase_cycles, n_cu;  // start-up delay that puts the 2 blocks of a CU half a tile apart
 };
 
 constexpr int kBM = 128;
@@ -529,6 +531,14 @@ template <int KS, int CK, int MODE, int NBUF, int NF>
 __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const ConvArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int L = blockIdx.x;
+  // Equal tiles keep the two co-resident blocks of a CU in lock step, so their prologues
+  // (first halo fill, ~2 us of exposed latency) and epilogues coincide instead of hiding
+  // under each other's MFMAs.  Half of the first wave of blocks starts half a tile late.
+  if (A.dephase_mode && L < 2 * A.n_cu &&
+      (A.dephase_mode == 1 ? L >= A.n_cu : (L & 1))) {
+    const long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < A.dephase_cycles) __builtin_amdgcn_s_sleep(32);
+  }
   const bool small = MODE == 0 && L >= A.nbig;
   const int bi = small ? A.nbig + ((L - A.nbig) >> 1) : L;
   int mt, c;
@@ -775,8 +785,23 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
     const int rem = total % slots;
     const char* e = getenv("RTPOSE_CONV_NO_HALF_TILES");
     if (total > slots && rem > 0 && 2 * rem <= n_cu && !(e && e[0] == '1')) a.nbig = total - rem;
+    // small batches (e.g. the reference's own one-image-at-a-time flow): fewer tiles than
+    // CUs -> every tile is split, doubling the number of busy CUs
+    if (total <= n_cu && !(e && e[0] == '1')) a.nbig = 0;
   }
   dim3 grid((unsigned)(a.nbig + 2 * (ids - a.nbig)), 1, 1);
+  {
+    static int dephase_env = -1;
+    if (dephase_env < 0) {
+      const char* e = getenv("RTPOSE_CONV_DEPHASE");
+      dephase_env = e ? atoi(e) : 0;
+    }
+    a.dephase_mode = (pl.nbuf == 2 && (long)grid.x > 4L * n_cu) ? dephase_env : 0;
+    a.n_cu = n_cu;
+    // half of a co-resident pair's tile time: taps x 16 MFMAs x 64 cycles x 2 blocks / 2
+    const long taps = (long)(d0.cin / pl.ck) * d0.k * d0.k;
+    a.dephase_cycles = (int)(taps * 16 * 64);
+  }
 #define RTPOSE_CONV_CASE(KS_, CK_, MODE_)                                  \
   if (d0.k == KS_ && pl.ck == CK_ && pl.mode == MODE_) {                   \
     if (pl.nbuf == 1) return launch_inst<KS_, CK_, MODE_, 1, 1>(a, grid, pl.lds_bytes, s); \
