@@ -98,12 +98,60 @@ def cpu_baseline(sample_scenes):
                       % (n_net, t_net / n_net, cores, heat.shape[0], t_post * 1e3)}
 
 
+def measure_traffic(timeout_s=150):
+    """HBM/fabric bytes per launch of the dominant (7x7) kernel from the rocprofv3 PMC counters,
+    collected as MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE
+    `--pmc` passes (they do not fit one pass), with `--kernel-trace` only, FETCH_SIZE doubled
+    (gfx950 counts the 128-B requests of wide coalesced reads as 64 B).  Each pass profiles one
+    warm + one measured forward of the same 32 x 368 x 368 workload in a child process.  Any
+    failure -> None (the FPS line never depends on the profiler)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tool = os.path.join(ROOT, "tools", "profile_layers.py")
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="rtpose_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            env = dict(os.environ, TMPDIR="/tmp")
+            p = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "t", "--", sys.executable, tool,
+                                str(BATCH), str(SIZE), str(SIZE), "1"], cwd="/tmp", env=env, timeout=timeout_s,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            if p.returncode != 0:
+                return None
+            db = None
+            for r, _, files in os.walk(d):
+                for f in files:
+                    if f.endswith(".db"):
+                        db = os.path.join(r, f)
+            if not db:
+                return None
+            cur = sqlite3.connect(db).cursor()
+            row = cur.execute("select sum(value), count(distinct dispatch_id) from counters_collection "
+                              "where counter_name = ? and kernel_name like '%conv_mfma_f32<7, 16, 0%'", (counter,)).fetchone()
+            if not row or not row[1]:
+                return None
+            out[counter] = float(row[0]) / float(row[1]) * 1024.0      # KiB per launch -> bytes
+        return {"fetch_bytes": 2.0 * out["FETCH_SIZE"], "write_bytes": out["WRITE_SIZE"],
+                "note": "per launch; FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE uncalibrated"}
+    except Exception:   # noqa: BLE001  (profiler trouble must never take the bench down)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes")
     args = ap.parse_args()
 
     pkg = importlib.import_module(PKG)
@@ -204,6 +252,13 @@ def main():
                          "flops_per_launch": round(k7_flops / max(k7_n, 1)),
                          "avg_launch_ms": round(k7_ms / max(k7_n, 1), 4)},
         }
+        if world == 1 and not args.no_traffic and "ROCPROF" not in "".join(os.environ.keys()).upper():
+            # free this process's GPU memory pressure is irrelevant (288 GB); the child runs its own plan
+            tr = measure_traffic()
+            if tr:
+                out["roofline"]["traffic"] = round(tr["fetch_bytes"] + tr["write_bytes"])
+                out["roofline"]["traffic_detail"] = tr
+                out["roofline"]["algorithmic_bytes_per_launch"] = 76_000_000
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline((heat_np, paf_np))
         else:
