@@ -118,6 +118,32 @@ typedef struct rtpose_conv_desc {
 int rtpose_conv2d(const rtpose_conv_desc* d, int ngroups, int N, int H, int W,
                   void* stream);
 
+/* ---- bf16 variant (BASELINE config 3: "bf16, multi-scale x4 + flip") ----------------
+ * Same modules, bf16 activations and weights, fp32 accumulate
+ * (v_mfma_f32_32x32x16_bf16), bias/ReLU/pool in fp32, output rounded to bf16
+ * (round-to-nearest-even) or written as fp32 (out_f32 != 0).  The reference has no
+ * reduced-precision path; the contract is pinned by oracle/net_oracle.py
+ * (forward_bf16_emulated).  In a desc used here `in`, `w_packed` and `out` point at 2-byte
+ * elements (out: 4-byte when out_f32) and the layouts count ELEMENTS per pixel; input slices
+ * are multiples of 8 elements, cin a multiple of 16. */
+size_t rtpose_packed_weight_bytes_bf16(int cout, int cin, int k);
+int rtpose_pack_conv_weights_bf16(const float* w_oihw, const float* bias, int cout,
+                                  int cin_src, int k, const int32_t* cin_map,
+                                  int cin_packed, void* w_packed, float* bias_packed,
+                                  void* stream);
+int rtpose_conv2d_bf16(const rtpose_conv_desc* d, int ngroups, int N, int H, int W,
+                       int out_f32, void* stream);
+/* dense NCHW fp32 -> bf16 layout slice (channels [C, cpad) zero; cpad % 8 == 0) */
+int rtpose_nchw_to_layout_bf16(const float* src_nchw, void* dst, const rtpose_layout* ldst,
+                               int C, int cpad, int N, int H, int W, void* stream);
+/* fp32 layout slice -> bf16 layout slice, and back */
+int rtpose_layout_f32_to_bf16(const float* src, const rtpose_layout* lsrc, void* dst,
+                              const rtpose_layout* ldst, int C, int cpad, int N, int H,
+                              int W, void* stream);
+int rtpose_layout_bf16_to_f32(const void* src, const rtpose_layout* lsrc, float* dst,
+                              const rtpose_layout* ldst, int C, int N, int H, int W,
+                              void* stream);
+
 /* MaxPool2d(kernel 2, stride 2, pad 0) between two layouts
  * (rtpose_vgg.py:49-50; floor semantics of nn.MaxPool2d). */
 int rtpose_maxpool2x2(const float* in, const rtpose_layout* lin, float* out,
@@ -186,6 +212,13 @@ int rtpose_layout_axpby(float* dst, const rtpose_layout* ldst, const float* src_
 typedef struct rtpose_net rtpose_net;
 
 int rtpose_net_create(int N, int H, int W, rtpose_net** out);
+/* dtype: arithmetic of the plan.  RTPOSE_DTYPE_BF16 = bf16 activations/weights with fp32
+ * accumulation (H, W multiples of 8); inputs, stage-output records and the final PAF /
+ * heat-map stay fp32 at the API.  Weight arenas of the two dtypes are NOT interchangeable. */
+#define RTPOSE_DTYPE_F32 0
+#define RTPOSE_DTYPE_BF16 1
+int rtpose_net_create_ex(int N, int H, int W, int dtype, rtpose_net** out);
+int rtpose_net_dtype(const rtpose_net* net);
 void rtpose_net_destroy(rtpose_net* net);
 size_t rtpose_net_workspace_bytes(const rtpose_net* net);
 size_t rtpose_net_weight_bytes(const rtpose_net* net);

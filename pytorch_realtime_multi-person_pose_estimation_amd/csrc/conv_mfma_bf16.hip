@@ -1,0 +1,728 @@
+// bf16 implicit-GEMM convolution for gfx950 (MI355X): bf16 activations and weights,
+// fp32 accumulate (v_mfma_f32_32x32x16_bf16), fused bias (+ReLU) (+2x2 max-pool), output
+// rounded to bf16 (round-to-nearest-even) or kept fp32 (network heads).
+//
+// BASELINE config 3 ("bf16, multi-scale x4 + flip") path of the same nn.Conv2d / nn.ReLU /
+// nn.MaxPool2d modules the fp32 kernel (conv_mfma.hip) stands in for
+// (lib/network/rtpose_vgg.py:23-35, :49-55).  The reference has no reduced-precision path;
+// the contract here is "bf16 operands, exact products, fp32 accumulation", checked against
+// oracle/net_oracle.py:forward_bf16_emulated.
+//
+// Same design as the fp32 kernel - shared-gap padded NHWC (now 2 bytes per channel), one LDS
+// halo per channel chunk re-used by all k*k taps, weights straight from L2 with a two-tap
+// register prefetch, one barrier per chunk - re-balanced for a matrix pipe that is 16x
+// faster per byte:
+//  * a 16-byte piece is 8 channels = exactly one lane's share of a K=16 MFMA step, so the
+//    A fragment is still ONE ds_read_b128 and the B fragment ONE 16-byte global load, but
+//    they now feed a single 32-cycle MFMA instead of four 64-cycle ones;
+//  * therefore the wave tile is 64 x 64 (block 128 x 128, 4 waves 2 x 2): each A piece is
+//    used by 2 and each B piece by 2 MFMAs, which keeps LDS reads (256 B/clk/CU) at 25 % and
+//    the L1 -> register path (64 B/clk/CU) just within budget;
+//  * B addresses are a uniform (SGPR) base plus a per-lane 32-bit offset: no VALU in the
+//    tap loop for them;
+//  * the next chunk's halo pieces travel through a 3-deep register ring (fetched at tap t,
+//    parked in LDS at tap t+3): a tap is only 256 cycles, shorter than an HBM/MALL miss.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "common.h"
+
+namespace rtpose {
+namespace bf {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef const floatx4 __attribute__((address_space(1)))* gcf4_t;
+// explicit global address space (see conv_mfma.hip: FLAT loads drag LDS reads behind vmcnt)
+__device__ __forceinline__ float4 gload4(const void* p) {
+  const floatx4 v = *(gcf4_t)(unsigned long long)(p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ bf16x8 as_bf8(const float4& v) {
+  const floatx4 t = {v.x, v.y, v.z, v.w};
+  return __builtin_bit_cast(bf16x8, t);
+}
+__device__ __forceinline__ unsigned short to_bf16(float v) {
+  return __builtin_bit_cast(unsigned short, (__bf16)v);  // v_cvt_pk_bf16_f32: RNE
+}
+
+struct ConvGroup {
+  const unsigned short* in;  // bf16 activations
+  const float4* w;           // packed bf16 weights, 16-byte pieces
+  const float* bias;         // fp32, padded to cout_pad
+  void* out;                 // bf16 or fp32 activations
+  int in_cstride, in_choff, in_ws, in_hs, in_lead;  // channel counts in ELEMENTS
+  int out_cstride, out_choff, out_ws, out_hs, out_lead;
+  int cout, cout_pad;
+  const int32_t* out_cmap;
+};
+
+struct ConvArgs {
+  ConvGroup g[2];
+  int N, H, W, M;
+  int cin;  // packed input channels (multiple of the chunk size)
+  int relu, pool, out_f32;
+  int qs;       // LDS pixels per piece plane
+  int hw_lds;   // MODE 1: LDS row stride of the halo (pixels)
+  int tw_log2;  // MODE 1: log2(tile width); tile height = 128 >> tw_log2
+  int tiles_x, tiles_y;
+  int mtiles, ntiles, nbig, ncombo, xcd_remap;
+};
+
+constexpr int kBM = 128;
+constexpr int kHD = 3;  // depth of the halo staging ring (taps between fetch and park)
+
+__device__ __forceinline__ void tile_local_yx(int ml, int tw_log2, int& ty, int& tx) {
+  const int qi = ml >> 2;
+  const int hw_log2 = tw_log2 - 1;
+  ty = ((qi >> hw_log2) << 1) + ((ml >> 1) & 1);
+  tx = ((qi & ((1 << hw_log2) - 1)) << 1) + (ml & 1);
+}
+
+// KS: kernel size; CK: channels per LDS chunk (16, 32 or 64); MODE 0 strip / 1 2-D tile;
+// NBUF 2: next chunk staged under the MFMAs, NBUF 1: refilled between chunks (1x1 layers);
+// MF / NF: 32-row / 32-column fragments per wave (block tile 64*MF x 64*NF).
+template <int KS, int CK, int MODE, int NBUF, int MF, int NF>
+__device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g, const int m0_arg,
+                                          const int ntile, float* smem) {
+  constexpr int P = KS / 2;
+  constexpr int BMT = 64 * MF;
+  constexpr int CG = CK / 8;   // 16-byte pieces (8 channels) per pixel per chunk
+  constexpr int G = CK / 16;   // K=16 MFMA steps per tap
+  constexpr int GB = G * NF;   // B registers (float4) per tap: [n-fragment][k-step]
+  constexpr int TAPS = KS, ROWS = KS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int QS = A.qs;
+
+  // ---- block -> tile ---------------------------------------------------------------
+  int m0 = 0, n_img = 0, y0 = 0, x0 = 0;
+  int q_origin, np_pix, row_lds;
+  int qc0 = 0;
+  if (MODE == 0) {
+    m0 = m0_arg;
+    const int HW = A.H * A.W;
+    const int n = m0 / HW, r = m0 - n * HW;
+    const int y = r / A.W, x = r - y * A.W;
+    qc0 = g.in_lead + (n * g.in_hs + y) * g.in_ws + x;
+    const int ml = min(m0 + BMT, A.M) - 1;
+    const int n2 = ml / HW, r2 = ml - n2 * HW;
+    const int y2 = r2 / A.W, x2 = r2 - y2 * A.W;
+    const int qcl = g.in_lead + (n2 * g.in_hs + y2) * g.in_ws + x2;
+    q_origin = qc0 - P * g.in_ws - P;
+    np_pix = qcl + P * g.in_ws + P - q_origin + 1;
+    row_lds = g.in_ws;
+  } else {
+    int b = m0_arg;
+    const int txi = b % A.tiles_x;
+    b /= A.tiles_x;
+    const int tyi = b % A.tiles_y;
+    n_img = b / A.tiles_y;
+    const int TW = 1 << A.tw_log2, TH = kBM >> A.tw_log2;
+    y0 = tyi * TH;
+    x0 = txi * TW;
+    q_origin = g.in_lead + (n_img * g.in_hs + y0 - P) * g.in_ws + x0 - P;
+    np_pix = (TH + 2 * P) * A.hw_lds;
+    row_lds = A.hw_lds;
+  }
+  const int np_total = np_pix * CG;  // 16-byte pieces per LDS buffer
+
+  // ---- per-lane A fragment bases (LDS pixel index of this lane's row) ----------------
+  int abase[MF];
+#pragma unroll
+  for (int fm = 0; fm < MF; ++fm) {
+    const int ml = wm * (32 * MF) + fm * 32 + l31;
+    if (MODE == 0) {
+      const int m = min(m0 + ml, A.M - 1);
+      const int HW = A.H * A.W;
+      const int n = m / HW, r = m - n * HW;
+      const int y = r / A.W, x = r - y * A.W;
+      abase[fm] = g.in_lead + (n * g.in_hs + y) * g.in_ws + x - qc0;
+    } else {
+      int ty, tx;
+      tile_local_yx(ml, A.tw_log2, ty, tx);
+      abase[fm] = ty * A.hw_lds + tx;
+    }
+  }
+
+  // ---- halo staging helpers: piece idx = (pixel idx / CG, piece idx % CG) ------------
+  const int in_cs4 = g.in_cstride >> 3, in_ws = g.in_ws;  // 16-byte pieces per pixel
+  const float4* in_base = reinterpret_cast<const float4*>(g.in + g.in_choff);
+  constexpr int PIXSET = 256 / CG;
+  const int pj = tid % CG, ppix0 = tid / CG;
+  const unsigned hw_inv = MODE == 1 ? (65536u + A.hw_lds - 1) / A.hw_lds : 0u;
+  auto piece_goff = [&](int set) -> size_t {  // float4 offset from the chunk's first piece
+    int pix = set * PIXSET + ppix0;
+    int q;
+    if (MODE == 0) {
+      q = q_origin + pix;
+    } else {
+      pix = min(pix, np_pix - 1);
+      const int hy = (int)(((unsigned)pix * hw_inv) >> 16), hx = pix - hy * A.hw_lds;
+      q = q_origin + hy * in_ws + hx;
+    }
+    return (size_t)q * in_cs4 + pj;
+  };
+  float4* smem4 = reinterpret_cast<float4*>(smem);
+  const int buf4 = CG * QS;
+  auto piece_loff = [&](int set) -> int { return pj * QS + set * PIXSET + ppix0; };
+  const int dummy_loff = NBUF * buf4 + tid;
+  const int nsets = (np_total + 255) / 256;
+
+  // ---- B operand: uniform base + per-lane byte offset --------------------------------
+  const int nchunks = A.cin / CK;
+  const int ncol = ntile * (kConvBN * NF) + wn * (32 * NF) + l31;
+  const unsigned lane_b = (unsigned)(kh * g.cout_pad + ncol) * 16u;
+  const size_t b_it_bytes = (size_t)CG * g.cout_pad * 16;  // bytes per (chunk, tap)
+  const unsigned b_k_bytes = (unsigned)(2 * g.cout_pad) * 16u;  // bytes per k-step
+  const char* wb = reinterpret_cast<const char*>(g.w);  // uniform; points at the tap being fetched
+#define RTPOSE_BLOAD(fn_, gi_) gload4(wb + (size_t)((gi_) * b_k_bytes + (fn_) * 512u) + lane_b)
+
+  float4 s0[GB], s1[GB], s2[GB];
+#pragma unroll
+  for (int fn = 0; fn < NF; ++fn)
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) s0[fn * G + gi] = RTPOSE_BLOAD(fn, gi);
+  wb += b_it_bytes;
+#pragma unroll
+  for (int fn = 0; fn < NF; ++fn)
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) s1[fn * G + gi] = RTPOSE_BLOAD(fn, gi);
+  wb += b_it_bytes;
+
+  auto fill_halo = [&](const float4* src) {
+    for (int set0 = 0; set0 < nsets; set0 += 4) {
+      float4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if ((set0 + u) * 256 + tid < np_total) t[u] = gload4(src + piece_goff(set0 + u));
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if ((set0 + u) * 256 + tid < np_total) smem4[piece_loff(set0 + u)] = t[u];
+    }
+  };
+  if (NBUF == 2) {
+    fill_halo(in_base);
+    __syncthreads();
+  }
+
+  floatx16 acc[MF][NF];
+#pragma unroll
+  for (int fm = 0; fm < MF; ++fm)
+#pragma unroll
+    for (int fn = 0; fn < NF; ++fn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[fm][fn][r] = 0.f;
+
+  int afrag[G][MF];
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+    for (int fm = 0; fm < MF; ++fm) afrag[gi][fm] = (2 * gi + kh) * QS + abase[fm];
+  const int rowstep = row_lds;
+
+#define RTPOSE_PIN()             \
+  asm volatile("" ::: "memory"); \
+  __builtin_amdgcn_sched_barrier(0)
+  // One tap = G K-steps of MF*NF MFMAs; after K-step n: the B pieces of step n for the tap
+  // two ahead, then the A pieces of step n for the next tap, then (last step, staged rows
+  // only) one halo piece parked and one fetched.
+#define RTPOSE_CONV_STEP(ACUR, ANXT, BCUR, BLOAD, KX, STAGE)                                   \
+  {                                                                                            \
+    _Pragma("unroll") for (int n = 0; n < G; ++n) {                                            \
+      _Pragma("unroll") for (int fn = 0; fn < NF; ++fn) {                                      \
+        _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) {                                    \
+          acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(ACUR[n][fm]),           \
+                                                                as_bf8(BCUR[fn * G + n]),      \
+                                                                acc[fm][fn], 0, 0, 0);         \
+        }                                                                                      \
+      }                                                                                        \
+      RTPOSE_PIN();                                                                            \
+      _Pragma("unroll") for (int fn = 0; fn < NF; ++fn) BLOAD[fn * G + n] = RTPOSE_BLOAD(fn, n); \
+      if (n == G - 1) wb += b_it_bytes;                                                        \
+      if (KS > 1) {                                                                            \
+        if (n == 0 && (KX) == KS - 1) { /* next tap starts the next stencil row */             \
+          _Pragma("unroll") for (int g2 = 0; g2 < G; ++g2)                                     \
+            _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) arow[g2][fm] += rowstep;         \
+        }                                                                                      \
+        _Pragma("unroll") for (int fm = 0; fm < MF; ++fm)                                      \
+          ANXT[n][fm] = smem4[arow[n][fm] + (((KX) + 1 < KS) ? (KX) + 1 : 0)];                 \
+      }                                                                                        \
+      if ((STAGE) != 0 && n == G - 1) {                                                        \
+        smem4[hl[0]] = hv[0];                                                                  \
+        _Pragma("unroll") for (int d = 0; d + 1 < kHD; ++d) {                                  \
+          hv[d] = hv[d + 1];                                                                   \
+          hl[d] = hl[d + 1];                                                                   \
+        }                                                                                      \
+        if (ps < nsets) { /* uniform */                                                        \
+          hv[kHD - 1] = gload4(next_base + piece_goff(ps));                                    \
+          hl[kHD - 1] = (tid < np_total - ps * 256) ? hn_off + piece_loff(ps) : dummy_loff;    \
+        } else {                                                                               \
+          hv[kHD - 1] = make_float4(0.f, 0.f, 0.f, 0.f);                                       \
+          hl[kHD - 1] = dummy_loff;                                                            \
+        }                                                                                      \
+        ++ps;                                                                                  \
+      }                                                                                        \
+      RTPOSE_PIN();                                                                            \
+    }                                                                                          \
+  }
+#define RTPOSE_CONV_ROW(STAGE)                                                  \
+  {                                                                             \
+    _Pragma("unroll") for (int kx = 0; kx < TAPS; ++kx) {                       \
+      if (kx % 6 == 0) {                                                        \
+        RTPOSE_CONV_STEP(a0, a1, s0, s2, kx, STAGE)                             \
+      } else if (kx % 6 == 1) {                                                 \
+        RTPOSE_CONV_STEP(a1, a0, s1, s0, kx, STAGE)                             \
+      } else if (kx % 6 == 2) {                                                 \
+        RTPOSE_CONV_STEP(a0, a1, s2, s1, kx, STAGE)                             \
+      } else if (kx % 6 == 3) {                                                 \
+        RTPOSE_CONV_STEP(a1, a0, s0, s2, kx, STAGE)                             \
+      } else if (kx % 6 == 4) {                                                 \
+        RTPOSE_CONV_STEP(a0, a1, s1, s0, kx, STAGE)                             \
+      } else {                                                                  \
+        RTPOSE_CONV_STEP(a1, a0, s2, s1, kx, STAGE)                             \
+      }                                                                         \
+    }                                                                           \
+    if (KS > 1 && (TAPS & 1)) {                                                 \
+      _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                          \
+        _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) a0[gi][fm] = a1[gi][fm]; \
+    }                                                                           \
+    _Pragma("unroll") for (int gi = 0; gi < GB; ++gi) {                         \
+      if (TAPS % 3 == 1) {                                                      \
+        const float4 t_ = s0[gi];                                               \
+        s0[gi] = s1[gi];                                                        \
+        s1[gi] = s2[gi];                                                        \
+        s2[gi] = t_;                                                            \
+      } else if (TAPS % 3 == 2) {                                               \
+        const float4 t_ = s2[gi];                                               \
+        s2[gi] = s1[gi];                                                        \
+        s1[gi] = s0[gi];                                                        \
+        s0[gi] = t_;                                                            \
+      }                                                                         \
+    }                                                                           \
+  }
+
+  // rows of a chunk whose taps carry the staging code: one piece set is fetched per tap;
+  // whatever is still in the ring at the end of the chunk is parked before the barrier
+  const int stage_rows = min(ROWS, (nsets + TAPS - 1) / TAPS);
+  float4 hv[kHD];
+  int hl[kHD];
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    if (NBUF == 1) {  // every wave is past the previous chunk (barrier at the loop end)
+      fill_halo(in_base + (size_t)chunk * CG);
+      __syncthreads();
+    }
+    const int hb_off = NBUF == 2 ? (chunk & 1) * buf4 : 0;
+    const int hn_off = NBUF == 2 ? ((chunk + 1) & 1) * buf4 : 0;
+    // the last chunk re-stages itself into the idle buffer (never read): no branch
+    const int chunk_next = min(chunk + 1, nchunks - 1);
+    const float4* next_base = in_base + (size_t)chunk_next * CG;
+    (void)next_base;
+    (void)hn_off;
+    int ps = 0;
+#pragma unroll
+    for (int d = 0; d < kHD; ++d) {
+      hv[d] = make_float4(0.f, 0.f, 0.f, 0.f);
+      hl[d] = dummy_loff;
+    }
+    int arow[G][MF];
+    float4 a0[G][MF], a1[G][MF];
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+      for (int fm = 0; fm < MF; ++fm) {
+        arow[gi][fm] = hb_off + afrag[gi][fm];
+        a0[gi][fm] = smem4[arow[gi][fm]];  // tap (0,0)
+        a1[gi][fm] = a0[gi][fm];
+      }
+    int ky = 0;
+    if (NBUF == 2)
+      for (; ky < stage_rows; ++ky) RTPOSE_CONV_ROW(1)
+    for (; ky < ROWS; ++ky) RTPOSE_CONV_ROW(0)
+    if (NBUF == 2) {
+#pragma unroll
+      for (int d = 0; d < kHD; ++d) smem4[hl[d]] = hv[d];
+    }
+    __syncthreads();
+  }
+#undef RTPOSE_CONV_ROW
+#undef RTPOSE_CONV_STEP
+#undef RTPOSE_PIN
+#undef RTPOSE_BLOAD
+
+  // ---- epilogue: bias (+ReLU) (+2x2 max-pool), masked stores, bf16 (RNE) or fp32 ---------
+  unsigned short* out_h = reinterpret_cast<unsigned short*>(g.out);
+  float* out_f = reinterpret_cast<float*>(g.out);
+#pragma unroll
+  for (int fn = 0; fn < NF; ++fn) {
+    const int ncolf = ncol + fn * 32;
+    const bool col_ok = ncolf < g.cout;
+    const float bias = g.bias[ncolf];  // bias is padded to cout_pad
+    const int och = (g.out_cmap && col_ok) ? g.out_cmap[ncolf] : g.out_choff + ncolf;
+    if (!A.pool) {
+#pragma unroll
+      for (int fm = 0; fm < MF; ++fm) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int ml0 = wm * (32 * MF) + fm * 32 + rg * 8 + 4 * kh;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int ml = ml0 + rr;
+            int n, y, x;
+            bool ok;
+            if (MODE == 0) {
+              const int m = m0 + ml;
+              ok = m < A.M;
+              const int HW = A.H * A.W;
+              n = m / HW;
+              const int r = m - n * HW;
+              y = r / A.W;
+              x = r - y * A.W;
+            } else {
+              int ty, tx;
+              tile_local_yx(ml, A.tw_log2, ty, tx);
+              n = n_img;
+              y = y0 + ty;
+              x = x0 + tx;
+              ok = (y < A.H) && (x < A.W);
+            }
+            float v = acc[fm][fn][rg * 4 + rr] + bias;
+            if (A.relu) v = fmaxf(v, 0.f);
+            if (ok && col_ok) {
+              const size_t q = (size_t)g.out_lead + (size_t)(n * g.out_hs + y) * g.out_ws + x;
+              if (A.out_f32) out_f[q * g.out_cstride + och] = v;
+              else out_h[q * g.out_cstride + och] = to_bf16(v);
+            }
+          }
+        }
+      }
+    } else {
+      const int Ho = A.H >> 1, Wo = A.W >> 1;
+      const int hw_log2 = A.tw_log2 - 1;
+#pragma unroll
+      for (int fm = 0; fm < MF; ++fm) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int ml0 = wm * (32 * MF) + fm * 32 + rg * 8 + 4 * kh;
+          const int qi = ml0 >> 2;
+          const int py = (y0 >> 1) + (qi >> hw_log2);
+          const int px = (x0 >> 1) + (qi & ((1 << hw_log2) - 1));
+          float v = fmaxf(fmaxf(acc[fm][fn][rg * 4 + 0], acc[fm][fn][rg * 4 + 1]),
+                          fmaxf(acc[fm][fn][rg * 4 + 2], acc[fm][fn][rg * 4 + 3])) + bias;
+          if (A.relu) v = fmaxf(v, 0.f);
+          if (py < Ho && px < Wo && col_ok) {
+            const size_t q = (size_t)g.out_lead + (size_t)(n_img * g.out_hs + py) * g.out_ws + px;
+            if (A.out_f32) out_f[q * g.out_cstride + och] = v;
+            else out_h[q * g.out_cstride + och] = to_bf16(v);
+          }
+        }
+      }
+    }
+  }
+}
+
+// 1-D grid, block id -> (group, N tile, M tile); XCD-aware order and half-tile tail exactly
+// as conv_mfma_f32 (conv_mfma.hip).
+template <int KS, int CK, int MODE, int NBUF, int NF>
+__global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int L = blockIdx.x;
+  const bool small = MODE == 0 && L >= A.nbig;
+  const int bi = small ? A.nbig + ((L - A.nbig) >> 1) : L;
+  int mt, c;
+  if (A.xcd_remap) {
+    const int xcd = bi & 7, j = bi >> 3;
+    c = j % A.ncombo;
+    mt = (j / A.ncombo) * 8 + xcd;
+  } else {
+    mt = bi % A.mtiles;
+    c = bi / A.mtiles;
+  }
+  if (mt >= A.mtiles) return;
+  const int nt = c % A.ntiles, grp = c / A.ntiles;
+  if (MODE == 1) {
+    conv_tile<KS, CK, MODE, NBUF, 2, NF>(A, A.g[grp], mt, nt, smem);
+  } else if (!small) {
+    conv_tile<KS, CK, MODE, NBUF, 2, NF>(A, A.g[grp], mt * kBM, nt, smem);
+  } else {
+    const int m0 = mt * kBM + ((L - A.nbig) & 1) * (kBM / 2);
+    if (m0 < A.M) conv_tile<KS, CK, MODE, NBUF, 1, NF>(A, A.g[grp], m0, nt, smem);
+  }
+}
+
+// ---- weight packing: packed[chunk][tap][piece][cout_pad][8 bf16] <- w[cout][cin_src][k][k] ----
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                         int cout, int cin_src, int k, const int32_t* __restrict__ cin_map,
+                                         int cin_packed, int ck, int coutp, unsigned short* __restrict__ wp,
+                                         float* __restrict__ bp) {
+  const int T = k * k;
+  const size_t total = (size_t)T * cin_packed * coutp;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)coutp) bp[i] = (i < (size_t)cout && bias) ? bias[i] : 0.f;
+  if (i >= total) return;
+  const int e = i & 7;
+  size_t r = i >> 3;
+  const int n = r % coutp;
+  r /= coutp;
+  const int cg = r % (ck / 8);
+  r /= (ck / 8);
+  const int tap = r % T;
+  const int chunk = r / T;
+  const int c = chunk * ck + cg * 8 + e;
+  const int src = cin_map ? cin_map[c] : (c < cin_src ? c : -1);
+  float v = 0.f;
+  if (n < cout && src >= 0 && src < cin_src) {
+    const int ky = tap / k, kx = tap - ky * k;
+    v = w[(((size_t)n * cin_src + src) * k + ky) * k + kx];
+  }
+  wp[i] = to_bf16(v);
+}
+
+// ---- host side ----------------------------------------------------------------------------
+// channels per LDS chunk; the packed weight order depends on it, so pack and launch share it
+static int conv_ck(int cin, int k) {
+  if (cin % 32) return 16;
+  return (k == 1 && cin % 64 == 0) ? 64 : 32;
+}
+
+struct ConvPlan {
+  int mode, ck, qs, hw_lds, tw_log2, tiles_x, tiles_y, grid_x, nbuf, nf;
+  size_t lds_bytes;
+};
+
+static int round_qs(int npix) {
+  int qs = npix;
+  while ((qs & 3) != 2) ++qs;
+  return qs;
+}
+static int halo_row_lds(int tw, int p) {
+  int w = tw + 2 * p;
+  while ((w & 15) != 8) ++w;
+  return w;
+}
+
+static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* pl) {
+  const int P = d.k / 2;
+  pl->ck = conv_ck(d.cin, d.k);
+  const int M = N * H * W;
+  const int max_sets = d.k * d.k;  // one piece set per tap, the ring is flushed at the chunk end
+  const int cg = pl->ck / 8;
+  pl->nbuf = d.k == 1 ? 1 : 2;
+  const size_t tail = pl->nbuf == 2 ? 256 * 16 : 0;  // dummy park slots
+  bool strip = (W <= 64) && !d.pool;
+  if (strip) {
+    const rtpose_layout& l = d.lin;
+    const int lb = (kBM - 1) + ((kBM - 1) / W + 1) * (l.ws - W) +
+                   ((kBM - 1) / (H * W) + 1) * (l.hs - H) * l.ws + 2 * P * l.ws + 2 * P + 1;
+    const int qs = round_qs(lb);
+    const size_t lds = (size_t)pl->nbuf * cg * qs * 16 + tail;
+    if ((pl->nbuf == 2 && ceil_div(qs * cg, 256) > max_sets) || lds > 80 * 1024) strip = false;
+    if (strip) {
+      pl->mode = 0;
+      pl->qs = qs;
+      pl->hw_lds = 0;
+      pl->tw_log2 = 0;
+      pl->tiles_x = pl->tiles_y = 0;
+      pl->grid_x = ceil_div(M, kBM);
+      pl->lds_bytes = lds;
+      return 0;
+    }
+  }
+  int best_tw = 0;
+  long best_cost = -1;
+  for (int twl = 2; twl <= 6; ++twl) {
+    const int tw = 1 << twl, th = kBM >> twl;
+    if (th < 2) continue;
+    const long cost = (long)ceil_div(W, tw) * ceil_div(H, th);
+    const long halo = (long)(th + 2 * P) * halo_row_lds(tw, P);
+    const long key = cost * 100000 + halo;
+    if (best_cost < 0 || key < best_cost) {
+      best_cost = key;
+      best_tw = twl;
+    }
+  }
+  const int tw = 1 << best_tw, th = kBM >> best_tw;
+  pl->mode = 1;
+  pl->tw_log2 = best_tw;
+  pl->hw_lds = halo_row_lds(tw, P);
+  const int npix = (th + 2 * P) * pl->hw_lds;
+  pl->qs = round_qs(npix);
+  pl->tiles_x = ceil_div(W, tw);
+  pl->tiles_y = ceil_div(H, th);
+  pl->grid_x = N * pl->tiles_x * pl->tiles_y;
+  pl->lds_bytes = (size_t)pl->nbuf * cg * pl->qs * 16 + tail;
+  if (pl->nbuf == 2 && ceil_div(pl->qs * cg, 256) > max_sets)
+    return fail(RTPOSE_E_INVAL, "conv bf16: halo too large for the staging schedule");
+  if (pl->lds_bytes > 80 * 1024) return fail(RTPOSE_E_INVAL, "conv bf16: halo exceeds the LDS budget");
+  return 0;
+}
+
+template <int KS, int CK, int MODE, int NBUF, int NF>
+static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = conv_mfma_bf16<KS, CK, MODE, NBUF, NF>;
+  if (!attr_set) {
+    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace bf
+
+// d[i].in / w_packed / out point at bf16 data (out: fp32 when out_f32); layouts count bf16
+// ELEMENTS per pixel.
+int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, int out_f32,
+                       hipStream_t s) {
+  using namespace bf;
+  if (!d || ngroups < 1 || ngroups > 2) return fail(RTPOSE_E_INVAL, "conv2d_bf16: ngroups must be 1 or 2");
+  const rtpose_conv_desc& d0 = d[0];
+  if (d0.k != 1 && d0.k != 3 && d0.k != 7) return fail(RTPOSE_E_INVAL, "conv2d_bf16: k must be 1, 3 or 7");
+  if (d0.cin % 16 != 0 || d0.cin <= 0) return fail(RTPOSE_E_INVAL, "conv2d_bf16: cin must be a multiple of 16");
+  if (N <= 0 || H <= 0 || W <= 0) return fail(RTPOSE_E_INVAL, "conv2d_bf16: empty tensor");
+  const int P = d0.k / 2;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < ngroups; ++i) {
+    const rtpose_conv_desc& di = d[i];
+    if (di.k != d0.k || di.cin != d0.cin || di.relu != d0.relu || di.pool != d0.pool ||
+        cout_pad(di.cout) != cout_pad(d0.cout) || di.lin.ws != d0.lin.ws || di.lin.hs != d0.lin.hs)
+      return fail(RTPOSE_E_INVAL, "conv2d_bf16: grouped convs must share geometry");
+    if (di.lin.ws < W + P || di.lin.hs < H + P || di.lin.lead < P * di.lin.ws + P)
+      return fail(RTPOSE_E_INVAL, "conv2d_bf16: input layout gap smaller than the conv padding");
+    if ((di.lin.cstride % 8) || (di.lin.choff % 8))
+      return fail(RTPOSE_E_INVAL, "conv2d_bf16: input slice must be 16-byte aligned");
+    if (di.lin.choff + di.cin > di.lin.cstride)
+      return fail(RTPOSE_E_INVAL, "conv2d_bf16: input slice exceeds cstride");
+    ConvGroup& g = a.g[i];
+    g.in = reinterpret_cast<const unsigned short*>(di.in);
+    g.w = reinterpret_cast<const float4*>(di.w_packed);
+    g.bias = di.bias_packed;
+    g.out = di.out;
+    g.in_cstride = di.lin.cstride;
+    g.in_choff = di.lin.choff;
+    g.in_ws = di.lin.ws;
+    g.in_hs = di.lin.hs;
+    g.in_lead = di.lin.lead;
+    g.out_cstride = di.lout.cstride;
+    g.out_choff = di.lout.choff;
+    g.out_ws = di.lout.ws;
+    g.out_hs = di.lout.hs;
+    g.out_lead = di.lout.lead;
+    g.cout = di.cout;
+    g.cout_pad = cout_pad(di.cout);
+    g.out_cmap = di.out_cmap;
+  }
+  if (d0.pool && ((H | W) & 1)) return fail(RTPOSE_E_INVAL, "conv2d_bf16: fused pool needs even H and W");
+  ConvPlan pl;
+  int rc = plan_conv(d0, N, H, W, &pl);
+  if (rc) return rc;
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.M = N * H * W;
+  a.cin = d0.cin;
+  a.relu = d0.relu;
+  a.pool = d0.pool;
+  a.out_f32 = out_f32 ? 1 : 0;
+  a.qs = pl.qs;
+  a.hw_lds = pl.hw_lds;
+  a.tw_log2 = pl.tw_log2;
+  a.tiles_x = pl.tiles_x;
+  a.tiles_y = pl.tiles_y;
+  static int n_cu = 0;
+  if (!n_cu) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  a.mtiles = pl.grid_x;
+  const int coutp = cout_pad(d0.cout);
+  pl.nf = (d0.k != 1 && coutp % 128 == 0) ? 2 : 1;
+  a.ntiles = coutp / (kConvBN * pl.nf);
+  a.ncombo = a.ntiles * ngroups;
+  a.xcd_remap = (a.ncombo > 1 && a.mtiles >= 64) ? 1 : 0;
+  const long ids = a.xcd_remap ? (long)8 * a.ncombo * ceil_div(a.mtiles, 8) : (long)a.mtiles * a.ncombo;
+  if (ids > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv2d_bf16: grid too large");
+  a.nbig = (int)ids;
+  if (pl.mode == 0) {  // tail quantisation, see conv_mfma.hip
+    const int slots = n_cu * 2;
+    const int total = (int)ids;
+    const int rem = total % slots;
+    if (total > slots && rem > 0 && 2 * rem <= n_cu) a.nbig = total - rem;
+    if (total <= n_cu) a.nbig = 0;
+  }
+  dim3 grid((unsigned)(a.nbig + 2 * (ids - a.nbig)), 1, 1);
+#define RTPOSE_CONV_CASE(KS_, CK_, MODE_, NBUF_)                                                  \
+  if (d0.k == KS_ && pl.ck == CK_ && pl.mode == MODE_) {                                          \
+    if (pl.nf == 2) return launch_inst<KS_, CK_, MODE_, NBUF_, (KS_ != 1) ? 2 : 1>(a, grid, pl.lds_bytes, s); \
+    return launch_inst<KS_, CK_, MODE_, NBUF_, 1>(a, grid, pl.lds_bytes, s);                       \
+  }
+  RTPOSE_CONV_CASE(3, 16, 0, 2)
+  RTPOSE_CONV_CASE(3, 16, 1, 2)
+  RTPOSE_CONV_CASE(3, 32, 0, 2)
+  RTPOSE_CONV_CASE(3, 32, 1, 2)
+  RTPOSE_CONV_CASE(7, 32, 0, 2)
+  RTPOSE_CONV_CASE(7, 32, 1, 2)
+  RTPOSE_CONV_CASE(7, 16, 0, 2)
+  RTPOSE_CONV_CASE(7, 16, 1, 2)
+  RTPOSE_CONV_CASE(1, 16, 0, 1)
+  RTPOSE_CONV_CASE(1, 16, 1, 1)
+  RTPOSE_CONV_CASE(1, 32, 0, 1)
+  RTPOSE_CONV_CASE(1, 32, 1, 1)
+  RTPOSE_CONV_CASE(1, 64, 0, 1)
+  RTPOSE_CONV_CASE(1, 64, 1, 1)
+#undef RTPOSE_CONV_CASE
+  return fail(RTPOSE_E_INVAL, "conv2d_bf16: no kernel instance for k=%d ck=%d mode=%d", d0.k, pl.ck, pl.mode);
+}
+
+int pack_weights_bf16_launch(const float* w, const float* bias, int cout, int cin_src, int k,
+                             const int32_t* cin_map, int cin_packed, void* wp, float* bp, hipStream_t s) {
+  if (cin_packed % 16 || (cin_packed < cin_src && !cin_map))
+    return fail(RTPOSE_E_INVAL, "pack_bf16: cin_packed must be a multiple of 16 and >= cin_src");
+  if (k != 1 && k != 3 && k != 7) return fail(RTPOSE_E_INVAL, "pack_bf16: k must be 1, 3 or 7");
+  const int coutp = cout_pad(cout);
+  const size_t total = (size_t)k * k * cin_packed * coutp;
+  const int threads = 256;
+  const unsigned blocks = (unsigned)((total + threads - 1) / threads);
+  hipLaunchKernelGGL(bf::pack_weights_bf16_kernel, dim3(blocks), dim3(threads), 0, s, w, bias, cout, cin_src,
+                     k, cin_map, cin_packed, bf::conv_ck(cin_packed, k), coutp,
+                     reinterpret_cast<unsigned short*>(wp), bp);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace rtpose
+
+extern "C" {
+
+size_t rtpose_packed_weight_bytes_bf16(int cout, int cin, int k) {
+  const int cinp = rtpose::ceil_div(cin, 16) * 16;
+  // + two (chunk, tap) blocks of slack (<= 64 channels each): the B prefetch runs two taps ahead
+  return (size_t)(k * k * cinp + 128) * rtpose::cout_pad(cout) * 2;
+}
+
+int rtpose_pack_conv_weights_bf16(const float* w_oihw, const float* bias, int cout, int cin_src, int k,
+                                  const int32_t* cin_map, int cin_packed, void* w_packed,
+                                  float* bias_packed, void* stream) {
+  return rtpose::pack_weights_bf16_launch(w_oihw, bias, cout, cin_src, k, cin_map, cin_packed, w_packed,
+                                          bias_packed, rtpose::as_stream(stream));
+}
+
+int rtpose_conv2d_bf16(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, int out_f32,
+                       void* stream) {
+  return rtpose::conv2d_bf16_launch(d, ngroups, N, H, W, out_f32, rtpose::as_stream(stream));
+}
+
+}  // extern "C"

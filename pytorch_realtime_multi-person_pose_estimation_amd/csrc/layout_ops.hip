@@ -440,6 +440,67 @@ static inline unsigned nblocks(size_t total, int threads) {
   return (unsigned)((total + threads - 1) / threads);
 }
 
+
+// ---- bf16 activation buffers (conv_mfma_bf16.hip): conversions at the edges of the net ----
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float v) {
+  return __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) {
+  return __uint_as_float((unsigned)h << 16);
+}
+
+// One thread per (pixel, 8-channel piece): 16-byte stores.  src is dense NCHW fp32 (SRC_NCHW)
+// or a layout slice; channels [C, cpad) are written as zero.
+template <bool SRC_NCHW>
+__global__ void to_bf16_layout_kernel(const float* __restrict__ src, Lay ls, unsigned short* __restrict__ dst,
+                                      Lay ld, int C, int cpad, int N, int H, int W) {
+  const int pieces = cpad >> 3;
+  const size_t total = (size_t)N * H * W * pieces;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  size_t p;
+  int pc;
+  if (SRC_NCHW) {  // x fastest: coalesced reads of each channel plane
+    p = i % ((size_t)N * H * W);
+    pc = (int)(i / ((size_t)N * H * W));
+  } else {
+    pc = (int)(i % pieces);
+    p = i / pieces;
+  }
+  const int x = p % W;
+  size_t r = p / W;
+  const int y = r % H;
+  const int n = (int)(r / H);
+  unsigned short v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = pc * 8 + e;
+    float f = 0.f;
+    if (c < C) f = SRC_NCHW ? src[(((size_t)n * C + c) * H + y) * W + x] : src[lay_off(ls, n, y, x) + c];
+    v[e] = f32_to_bf16_rne(f);
+  }
+  uint4 o;
+  o.x = v[0] | ((unsigned)v[1] << 16);
+  o.y = v[2] | ((unsigned)v[3] << 16);
+  o.z = v[4] | ((unsigned)v[5] << 16);
+  o.w = v[6] | ((unsigned)v[7] << 16);
+  *reinterpret_cast<uint4*>(dst + lay_off(ld, n, y, x) + pc * 8) = o;
+}
+
+__global__ void layout_bf16_to_f32_kernel(const unsigned short* __restrict__ src, Lay ls,
+                                          float* __restrict__ dst, Lay ld, int C, int N, int H, int W) {
+  const size_t total = (size_t)N * H * W * C;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = i % C;
+  size_t p = i / C;
+  const int x = p % W;
+  p /= W;
+  const int y = p % H;
+  const int n = p / H;
+  dst[lay_off(ld, n, y, x) + c] = bf16_to_f32(src[lay_off(ls, n, y, x) + c]);
+}
+
 }  // namespace rtpose
 
 using namespace rtpose;
@@ -627,6 +688,41 @@ int rtpose_flip_merge(const float* heat, const float* heat_flipped, const float*
   if (!total) return 0;
   hipLaunchKernelGGL(flip_merge_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
                      heat, heat_flipped, paf, paf_flipped, N, h, w, heat_avg, paf_avg);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+
+int rtpose_nchw_to_layout_bf16(const float* src_nchw, void* dst, const rtpose_layout* ldst, int C, int cpad,
+                               int N, int H, int W, void* stream) {
+  if ((cpad % 8) || (ldst->cstride % 8) || (ldst->choff % 8) || cpad < C)
+    return fail(RTPOSE_E_INVAL, "nchw_to_layout_bf16: slice must be 16-byte aligned, cpad >= C");
+  const size_t total = (size_t)N * H * W * (cpad / 8);
+  if (!total) return 0;
+  hipLaunchKernelGGL(to_bf16_layout_kernel<true>, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
+                     src_nchw, Lay{}, static_cast<unsigned short*>(dst), to_lay(ldst), C, cpad, N, H, W);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_layout_f32_to_bf16(const float* src, const rtpose_layout* lsrc, void* dst,
+                              const rtpose_layout* ldst, int C, int cpad, int N, int H, int W, void* stream) {
+  if ((cpad % 8) || (ldst->cstride % 8) || (ldst->choff % 8) || cpad < C)
+    return fail(RTPOSE_E_INVAL, "layout_f32_to_bf16: slice must be 16-byte aligned, cpad >= C");
+  const size_t total = (size_t)N * H * W * (cpad / 8);
+  if (!total) return 0;
+  hipLaunchKernelGGL(to_bf16_layout_kernel<false>, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
+                     src, to_lay(lsrc), static_cast<unsigned short*>(dst), to_lay(ldst), C, cpad, N, H, W);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_layout_bf16_to_f32(const void* src, const rtpose_layout* lsrc, float* dst, const rtpose_layout* ldst,
+                              int C, int N, int H, int W, void* stream) {
+  const size_t total = (size_t)N * H * W * C;
+  if (!total) return 0;
+  hipLaunchKernelGGL(layout_bf16_to_f32_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
+                     static_cast<const unsigned short*>(src), to_lay(lsrc), dst, to_lay(ldst), C, N, H, W);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -26,6 +26,11 @@ namespace rtpose {
 int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
 int pack_weights_launch(const float* w, const float* bias, int cout, int cin_src, int k,
                         const int32_t* cin_map, int cin_packed, float* wp, float* bp, hipStream_t s);
+// bf16 path (conv_mfma_bf16.hip)
+int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, int out_f32,
+                       hipStream_t s);
+int pack_weights_bf16_launch(const float* w, const float* bias, int cout, int cin_src, int k,
+                             const int32_t* cin_map, int cin_packed, void* wp, float* bp, hipStream_t s);
 }  // namespace rtpose
 
 using namespace rtpose;
@@ -58,6 +63,7 @@ struct Op {
   int in_buf[2] = {-1, -1}, out_buf[2] = {-1, -1};
   int in_choff[2] = {0, 0}, out_choff[2] = {0, 0};
   int relu = 0, pool = 0;
+  int out_f32 = 0;          // bf16 plans: this conv writes fp32 (the final stage heads)
   // pool / copy
   int C = 0;
   double flops = 0.0;
@@ -68,6 +74,8 @@ struct Op {
 
 struct rtpose_net {
   int N = 0, H = 0, W = 0;       // input
+  int bf16 = 0;                  // 1: bf16 activations/weights, fp32 accumulate (BASELINE config 3)
+  int x0f_buf = -1;              // bf16 plans: fp32 NHWC8 staging buffer for rtpose_preprocess_u8
   int H3 = 0, W3 = 0;            // stride-8 map
   std::vector<Buf> bufs;
   std::vector<ConvW> convs;
@@ -92,7 +100,7 @@ namespace {
 constexpr int kCatC = 192;      // [out1 128 | PAF 38 | heat 19 | pad 7]
 constexpr int kCatPaf = 128, kCatHeat = 166;
 
-int add_buf(rtpose_net* n, int C, int P, int H, int W) {
+int add_buf(rtpose_net* n, int C, int P, int H, int W, bool f32 = false) {
   Buf b;
   b.C = C;
   b.H = H;
@@ -102,7 +110,9 @@ int add_buf(rtpose_net* n, int C, int P, int H, int W) {
   b.lay.ws = W + P;
   b.lay.hs = H + P;
   b.lay.lead = P * (W + P) + P;
-  b.floats = round_up(rtpose_layout_pixels(&b.lay, n->N, H, W) * (size_t)C, 64);
+  // bf16 plans keep activations as 2-byte elements (C is even for every such buffer)
+  const size_t per_px = (n->bf16 && !f32) ? (size_t)C / 2 : (size_t)C;
+  b.floats = round_up(rtpose_layout_pixels(&b.lay, n->N, H, W) * per_px, 64);
   b.off_floats = n->ws_floats;
   n->ws_floats += b.floats;
   n->bufs.push_back(b);
@@ -114,11 +124,12 @@ int add_conv_w(rtpose_net* n, const std::string& name, int cout, int cin, int k,
   c.name = name;
   c.cout = cout;
   c.cin_src = cin;
-  c.cin_packed = cat_perm ? kCatC : ceil_div(cin, 8) * 8;
+  c.cin_packed = cat_perm ? kCatC : (n->bf16 ? ceil_div(cin, 16) * 16 : ceil_div(cin, 8) * 8);
   c.k = k;
   c.cat_perm = cat_perm;
   c.w_off = n->wt_floats;
-  n->wt_floats += round_up(rtpose_packed_weight_floats(cout, c.cin_packed, k), 64);
+  n->wt_floats += round_up(n->bf16 ? rtpose_packed_weight_bytes_bf16(cout, c.cin_packed, k) / 4
+                                   : rtpose_packed_weight_floats(cout, c.cin_packed, k), 64);
   c.b_off = n->wt_floats;
   n->wt_floats += round_up(rtpose_packed_bias_floats(cout), 64);
   n->convs.push_back(c);
@@ -223,8 +234,9 @@ void build_plan(rtpose_net* n) {
   n->wt_floats += 256;  // int32[192]
 
   // ---- activation buffers ------------------------------------------------------
-  const int X0 = add_buf(n, 8, 1, H0, W0);
+  const int X0 = add_buf(n, n->bf16 ? 16 : 8, 1, H0, W0);
   n->x0_buf = X0;
+  if (n->bf16) n->x0f_buf = add_buf(n, 8, 1, H0, W0, true);
   const int A1 = add_buf(n, 64, 1, H0, W0);
   const bool even0 = !((H0 | W0) & 1), even1 = !((H1 | W1) & 1), even2 = !((H2 | W2) & 1);
   const int A2 = even0 ? -1 : add_buf(n, 64, 0, H0, W0);
@@ -254,7 +266,7 @@ void build_plan(rtpose_net* n) {
     U[b][4] = add_buf(n, 128, 0, H3, W3);
     U[b][5] = add_buf(n, 128, 0, H3, W3);
   }
-  for (int s = 0; s < 6; ++s) n->save_buf[s] = add_buf(n, 57, 0, H3, W3);
+  for (int s = 0; s < 6; ++s) n->save_buf[s] = add_buf(n, 57, 0, H3, W3, true);  // always fp32
 
   // ---- launches ------------------------------------------------------------------
   add_simple_op(n, OP_INPUT, "nchw_to_nhwc8", H0, W0, -1, 0, X0, 0, 3);
@@ -307,8 +319,16 @@ void build_plan(rtpose_net* n) {
       add_conv_op(n, H3, W3, 2, ci, ui, zz, uo, zz, 1, 0);
     }
     const int ui[2] = {U[0][5], U[1][5]};
-    const int outb[2] = {cout_buf, cout_buf};
     ci[0] = cws[0][s - 2][6]; ci[1] = cws[1][s - 2][6];
+    if (n->bf16 && s == 6) {
+      // the decoder and the TTA merge read fp32: the last heads skip the bf16 concat buffer
+      const int outb[2] = {n->save_buf[5], n->save_buf[5]};
+      const int off57[2] = {0, 38};
+      add_conv_op(n, H3, W3, 2, ci, ui, zz, outb, off57, 0, 0);
+      n->ops.back().out_f32 = 1;
+      continue;
+    }
+    const int outb[2] = {cout_buf, cout_buf};
     add_conv_op(n, H3, W3, 2, ci, ui, zz, outb, head_off, 0, 0);
     add_simple_op(n, OP_COPY, "save" + std::to_string(s), H3, W3, cout_buf, kCatPaf,
                   n->save_buf[s - 1], 0, 57);
@@ -325,17 +345,29 @@ rtpose_layout slice(const Buf& b, int choff) {
 
 extern "C" {
 
-int rtpose_net_create(int N, int H, int W, rtpose_net** out) {
+int rtpose_net_create_ex(int N, int H, int W, int dtype, rtpose_net** out) {
   if (!out) return fail(RTPOSE_E_INVAL, "net_create: out is NULL");
   if (N <= 0 || H < 8 || W < 8) return fail(RTPOSE_E_INVAL, "net_create: need N>=1 and H,W>=8");
+  if (dtype != RTPOSE_DTYPE_F32 && dtype != RTPOSE_DTYPE_BF16)
+    return fail(RTPOSE_E_INVAL, "net_create: dtype must be RTPOSE_DTYPE_F32 or RTPOSE_DTYPE_BF16");
+  if (dtype == RTPOSE_DTYPE_BF16 && ((H | W) & 7))
+    return fail(RTPOSE_E_INVAL, "net_create: the bf16 plan needs H and W to be multiples of 8 "
+                                "(crop_with_factor pads to that, im_transform.py:128-132)");
   rtpose_net* n = new rtpose_net();
   n->N = N;
   n->H = H;
   n->W = W;
+  n->bf16 = dtype == RTPOSE_DTYPE_BF16;
   build_plan(n);
   *out = n;
   return 0;
 }
+
+int rtpose_net_create(int N, int H, int W, rtpose_net** out) {
+  return rtpose_net_create_ex(N, H, W, RTPOSE_DTYPE_F32, out);
+}
+
+int rtpose_net_dtype(const rtpose_net* net) { return net && net->bf16 ? RTPOSE_DTYPE_BF16 : RTPOSE_DTYPE_F32; }
 
 void rtpose_net_destroy(rtpose_net* net) {
   if (!net) return;
@@ -389,6 +421,9 @@ int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw, const fl
   if (idx < 0 || idx >= (int)net->convs.size()) return fail(RTPOSE_E_INVAL, "net_load_conv: bad index");
   const ConvW& c = net->convs[idx];
   const int32_t* map = c.cat_perm ? reinterpret_cast<const int32_t*>(net->wt + net->catmap_off) : nullptr;
+  if (net->bf16)
+    return pack_weights_bf16_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed,
+                                    net->wt + c.w_off, net->wt + c.b_off, as_stream(stream));
   return pack_weights_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed, net->wt + c.w_off,
                              net->wt + c.b_off, as_stream(stream));
 }
@@ -441,7 +476,8 @@ int rtpose_net_forward_prepared(rtpose_net* net, void* stream) { return net_forw
 
 int rtpose_net_input_view(const rtpose_net* net, float** base, rtpose_layout* layout) {
   if (!net || !net->bound) return fail(RTPOSE_E_STATE, "net_input_view: net not bound");
-  const Buf& b = net->bufs[net->x0_buf];
+  // bf16 plans expose an fp32 staging buffer; forward_prepared converts it
+  const Buf& b = net->bufs[net->bf16 ? net->x0f_buf : net->x0_buf];
   if (base) *base = net->ws + b.off_floats;
   if (layout) *layout = b.lay;
   return 0;
@@ -458,8 +494,18 @@ static int net_forward_impl(rtpose_net* net, const float* x_nchw, void* stream) 
     int rc = 0;
     switch (o.kind) {
       case OP_INPUT: {
-        if (!x_nchw) break;  // forward_prepared: the input buffer was written by the caller
         const Buf& b = net->bufs[o.out_buf[0]];
+        if (net->bf16) {
+          if (x_nchw) {
+            rc = rtpose_nchw_to_layout_bf16(x_nchw, net->ws + b.off_floats, &b.lay, 3, 16, N, o.H, o.W, stream);
+          } else {
+            const Buf& bs = net->bufs[net->x0f_buf];
+            rc = rtpose_layout_f32_to_bf16(net->ws + bs.off_floats, &bs.lay, net->ws + b.off_floats, &b.lay, 3,
+                                           16, N, o.H, o.W, stream);
+          }
+          break;
+        }
+        if (!x_nchw) break;  // forward_prepared: the input buffer was written by the caller
         rc = rtpose_nchw_to_layout(x_nchw, net->ws + b.off_floats, &b.lay, 3, 8, N, o.H, o.W, stream);
         break;
       }
@@ -482,7 +528,8 @@ static int net_forward_impl(rtpose_net* net, const float* x_nchw, void* stream) 
           d[g].pool = o.pool;
           d[g].out_cmap = nullptr;
         }
-        rc = conv2d_launch(d, o.ngroups, N, o.H, o.W, s);
+        rc = net->bf16 ? conv2d_bf16_launch(d, o.ngroups, N, o.H, o.W, o.out_f32, s)
+                       : conv2d_launch(d, o.ngroups, N, o.H, o.W, s);
         break;
       }
       case OP_POOL: {
@@ -493,10 +540,22 @@ static int net_forward_impl(rtpose_net* net, const float* x_nchw, void* stream) 
         break;
       }
       case OP_COPY: {
-        if (o.name.rfind("save", 0) == 0 && !net->keep) break;
+        const bool is_save = o.name.rfind("save", 0) == 0;
+        if (is_save && !net->keep) break;
         const Buf& bi = net->bufs[o.in_buf[0]];
         const Buf& bo = net->bufs[o.out_buf[0]];
-        const rtpose_layout li = slice(bi, o.in_choff[0]), lo = slice(bo, o.out_choff[0]);
+        rtpose_layout li = slice(bi, o.in_choff[0]), lo = slice(bo, o.out_choff[0]);
+        if (net->bf16 && is_save) {  // bf16 concat slice -> fp32 record of the stage outputs
+          rc = rtpose_layout_bf16_to_f32(net->ws + bi.off_floats, &li, net->ws + bo.off_floats, &lo, o.C, N,
+                                         o.H, o.W, stream);
+          break;
+        }
+        if (net->bf16) {  // bf16 -> bf16: move channel pairs as 4-byte words
+          li.cstride /= 2; li.choff /= 2; lo.cstride /= 2; lo.choff /= 2;
+          rc = rtpose_layout_copy(net->ws + bi.off_floats, &li, net->ws + bo.off_floats, &lo, o.C / 2, N, o.H,
+                                  o.W, stream);
+          break;
+        }
         rc = rtpose_layout_copy(net->ws + bi.off_floats, &li, net->ws + bo.off_floats, &lo, o.C, N, o.H,
                                 o.W, stream);
         break;
@@ -517,7 +576,12 @@ int rtpose_net_read_output(rtpose_net* net, int which, float* dst_nchw, void* st
   const int stage = which / 2 + 1, br = which % 2;
   const int C = br == 0 ? 38 : 19;
   int buf, choff;
-  if (net->keep) {
+  if (net->bf16 && (net->keep || stage == 6)) {
+    buf = net->save_buf[stage - 1];
+    choff = br == 0 ? 0 : 38;
+  } else if (net->bf16) {
+    return fail(RTPOSE_E_STATE, "net_read_output: bf16 plan keeps only stage 6 (set keep_intermediates)");
+  } else if (net->keep) {
     buf = net->save_buf[stage - 1];
     choff = br == 0 ? 0 : 38;
   } else {
@@ -533,9 +597,10 @@ int rtpose_net_read_output(rtpose_net* net, int which, float* dst_nchw, void* st
 int rtpose_net_output_view(const rtpose_net* net, int which, const float** base, rtpose_layout* layout,
                            int* C, int* H, int* W) {
   if (!net || !net->bound || which < 0 || which > 1) return fail(RTPOSE_E_INVAL, "output_view: bad argument");
-  const Buf& b = net->bufs[net->cat_buf[0]];  // stage 6 writes CATa
+  // stage 6 writes CATa (fp32 plans) / the fp32 stage-6 record (bf16 plans)
+  const Buf& b = net->bufs[net->bf16 ? net->save_buf[5] : net->cat_buf[0]];
   if (base) *base = net->ws + b.off_floats;
-  if (layout) *layout = slice(b, which == 0 ? kCatPaf : kCatHeat);
+  if (layout) *layout = net->bf16 ? slice(b, which == 0 ? 0 : 38) : slice(b, which == 0 ? kCatPaf : kCatHeat);
   if (C) *C = which == 0 ? 38 : 19;
   if (H) *H = net->H3;
   if (W) *W = net->W3;

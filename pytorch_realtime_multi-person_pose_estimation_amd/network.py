@@ -51,11 +51,12 @@ def _sequential(table, relu_after_last):
 class _Plan(object):
     """One native executor instance (fixed N, H, W) + its workspace."""
 
-    def __init__(self, n, h, w, weights, device):
+    def __init__(self, n, h, w, weights, device, dtype=_capi.DTYPE_F32):
         handle = C.c_void_p()
-        check(lib.rtpose_net_create(n, h, w, C.byref(handle)), "rtpose_net_create")
+        check(lib.rtpose_net_create_ex(n, h, w, dtype, C.byref(handle)), "rtpose_net_create_ex")
         self.handle = handle
         self.shape = (n, h, w)
+        self.dtype = dtype
         ws_bytes = lib.rtpose_net_workspace_bytes(handle)
         self.workspace = torch.empty(ws_bytes // 4 + 64, dtype=torch.float32, device=device)
         check(lib.rtpose_net_bind(handle, ptr(self.workspace), ws_bytes, ptr(weights),
@@ -83,9 +84,19 @@ class RtposeVGG(nn.Module):
             setattr(self, 'model%d_2' % s, _sequential(_stage1(19) if s == 1 else _stage_t(19), False))
         self._initialize_weights_norm()
         self._plans = {}
-        self._weights = None
-        self._weights_key = None
+        self._weights = {}       # compute dtype -> packed weight arena
+        self._weights_key = {}   # compute dtype -> parameter versions the arena was packed from
         self.keep_intermediates = True   # reference forward returns all 12 stage outputs
+        self.compute_dtype = 'fp32'
+
+    def set_compute_dtype(self, dtype):
+        """'fp32' (reference arithmetic, v_mfma_f32_32x32x2_f32) or 'bf16' (BASELINE config 3:
+        bf16 operands, fp32 accumulate, v_mfma_f32_32x32x16_bf16).  Parameters, inputs and
+        outputs stay fp32 tensors either way."""
+        if dtype not in ('fp32', 'bf16'):
+            raise ValueError("compute dtype must be 'fp32' or 'bf16'")
+        self.compute_dtype = dtype
+        return self
 
     def _initialize_weights_norm(self):
         # reference :200-222: N(0, 0.01) weights, zero bias
@@ -109,7 +120,7 @@ class RtposeVGG(nn.Module):
     def _sync_weights(self, plan, device):
         convs = self._convs()
         key = tuple((m.weight._version, m.bias._version, m.weight.data_ptr()) for _, m in convs)
-        if key == self._weights_key:
+        if key == self._weights_key.get(plan.dtype):
             return
         n = lib.rtpose_net_num_convs(plan.handle)
         if n != len(convs):
@@ -129,7 +140,7 @@ class RtposeVGG(nn.Module):
                 b = b.to(device=device, dtype=torch.float32).contiguous()
             check(lib.rtpose_net_load_conv(plan.handle, i, ptr(w), ptr(b), stream), "rtpose_net_load_conv")
         torch.cuda.current_stream().synchronize()  # temporaries above may be freed
-        self._weights_key = key
+        self._weights_key[plan.dtype] = key
 
     def plan_for(self, x):
         if not x.is_cuda:
@@ -139,18 +150,22 @@ class RtposeVGG(nn.Module):
         n, c, h, w = x.shape
         if c != 3:
             raise _capi.RtposeError("expected NCHW input with 3 channels")
-        key = (n, h, w, x.device.index)
+        dtype = _capi.DTYPE_BF16 if self.compute_dtype == 'bf16' else _capi.DTYPE_F32
+        key = (n, h, w, x.device.index, dtype)
         plan = self._plans.get(key)
         if plan is None:
-            if self._weights is None or self._weights.device != x.device:
+            weights = self._weights.get(dtype)
+            if weights is None or weights.device != x.device:
                 probe = C.c_void_p()
-                check(lib.rtpose_net_create(1, 8, 8, C.byref(probe)))
+                check(lib.rtpose_net_create_ex(1, 8, 8, dtype, C.byref(probe)))
                 wb = lib.rtpose_net_weight_bytes(probe)
                 lib.rtpose_net_destroy(probe)
-                self._weights = torch.zeros(wb // 4 + 64, dtype=torch.float32, device=x.device)
-                self._weights_key = None
-                self._plans.clear()
-            plan = _Plan(n, h, w, self._weights, x.device)
+                weights = torch.zeros(wb // 4 + 64, dtype=torch.float32, device=x.device)
+                self._weights[dtype] = weights
+                self._weights_key.pop(dtype, None)
+                for k in [k for k in self._plans if k[4] == dtype]:
+                    del self._plans[k]
+            plan = _Plan(n, h, w, weights, x.device, dtype)
             if len(self._plans) >= 8:   # bound the workspace kept alive
                 self._plans.pop(next(iter(self._plans)))
             self._plans[key] = plan

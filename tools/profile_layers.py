@@ -12,12 +12,13 @@ capi = pkg._capi
 lib = capi.lib
 
 
-def main(n=32, h=368, w=368, iters=5):
+def main(n=32, h=368, w=368, iters=5, dtype='fp32'):
     dev = torch.device("cuda:0")
     m = pkg.get_model('vgg19')
     from oracle import net_oracle
     m.load_state_dict(net_oracle.he_init_state_dict(m, 0))
     m = m.cuda().eval()
+    m.set_compute_dtype(dtype)
     x = (torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(0)) - 0.5).to(dev)
     plan = m.forward_native(x)
     torch.cuda.synchronize()
@@ -55,5 +56,5 @@ def main(n=32, h=368, w=368, iters=5):
 
 
 if __name__ == "__main__":
-    a = [int(v) for v in sys.argv[1:]]
-    main(*a)
+    a = [int(v) for v in sys.argv[1:5]]
+    main(*a, **({'dtype': sys.argv[5]} if len(sys.argv) > 5 else {}))
