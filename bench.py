@@ -42,6 +42,7 @@ BATCH = 32
 SIZE = 368
 GFLOP_PER_IMAGE = 271.868          # 2 x 135.934 GMAC over the 92 convs
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (--dtype bf16 only)
 
 
 def log(*a):
@@ -98,7 +99,7 @@ def cpu_baseline(sample_scenes):
                       % (n_net, t_net / n_net, cores, heat.shape[0], t_post * 1e3)}
 
 
-def measure_traffic(timeout_s=150):
+def measure_traffic(timeout_s=150, dtype="fp32"):
     """HBM/fabric bytes per launch of the dominant (7x7) kernel from the rocprofv3 PMC counters,
     collected as MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE
     `--pmc` passes (they do not fit one pass), with `--kernel-trace` only, FETCH_SIZE doubled
@@ -120,7 +121,7 @@ def measure_traffic(timeout_s=150):
             d = os.path.join(tmp, counter)
             env = dict(os.environ, TMPDIR="/tmp")
             p = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "t", "--", sys.executable, tool,
-                                str(BATCH), str(SIZE), str(SIZE), "1"], cwd="/tmp", env=env, timeout=timeout_s,
+                                str(BATCH), str(SIZE), str(SIZE), "1", dtype], cwd="/tmp", env=env, timeout=timeout_s,
                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             if p.returncode != 0:
                 return None
@@ -133,7 +134,8 @@ def measure_traffic(timeout_s=150):
                 return None
             cur = sqlite3.connect(db).cursor()
             row = cur.execute("select sum(value), count(distinct dispatch_id) from counters_collection "
-                              "where counter_name = ? and kernel_name like '%conv_mfma_f32<7, 16, 0%'", (counter,)).fetchone()
+                              "where counter_name = ? and kernel_name like ?",
+                              (counter, "%conv_mfma_bf16<7, 32, 0%" if dtype == "bf16" else "%conv_mfma_f32<7, 16, 0%")).fetchone()
             if not row or not row[1]:
                 return None
             out[counter] = float(row[0]) / float(row[1]) * 1024.0      # KiB per launch -> bytes
@@ -152,6 +154,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes")
+    ap.add_argument("--dtype", choices=("fp32", "bf16"), default="fp32",
+                    help="fp32 = BASELINE.json configs[1] (the contract, default); bf16 = the configs[2] "
+                         "arithmetic (bf16 operands, fp32 accumulate) on the same workload, for reference")
     args = ap.parse_args()
 
     pkg = importlib.import_module(PKG)
@@ -173,6 +178,9 @@ def main():
     model = pkg.get_model('vgg19')
     model.load_state_dict(net_oracle.he_init_state_dict(model, seed=0))
     model = model.cuda().float().eval()
+    model.set_compute_dtype(args.dtype)
+    bf16 = args.dtype == "bf16"
+    peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
     est = pipeline.PoseEstimator(model)
 
     g = torch.Generator().manual_seed(rank)
@@ -235,9 +243,12 @@ def main():
             "metric": "end-to-end persons-posed FPS at 368x368 (net+pafprocess)",
             "value": round(fps, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
-            "config": {"workload": "rtpose VGG19 368x368 batch=32 synthetic images, single MI355X, fp32 "
-                                   "(BASELINE.json configs[1]); per-GPU batch 32, one process per GPU",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": ("rtpose VGG19 368x368 batch=32 synthetic images, single MI355X, bf16 operands / "
+                                    "fp32 accumulate (NOT the contract config: BASELINE.json configs[1] is fp32)"
+                                    if bf16 else
+                                    "rtpose VGG19 368x368 batch=32 synthetic images, single MI355X, fp32 "
+                                    "(BASELINE.json configs[1]); per-GPU batch 32, one process per GPU"),
                        "global_batch": BATCH * world, "image": [SIZE, SIZE],
                        "weights": "seeded He init (no checkpoint offline)",
                        "decoder_input": "synthetic scene + 1e-3 * net output (blend kernel timed)",
@@ -245,20 +256,22 @@ def main():
                        "parallelism": "image-sharded, all_gather of result records only" if world > 1 else "single GPU"},
             "net_tflops_end_to_end": round(fps / world * GFLOP_PER_IMAGE / 1e3, 2),
             "net_ms_per_step_events": round(net_ms / args.steps, 3),
-            "roofline": {"bound": "mfma", "kernel": "conv_mfma_f32<7,16,0> (7x7 stage convs, 68% of the FLOPs)",
-                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "roofline": {"bound": "mfma",
+                         "kernel": ("conv_mfma_bf16<7,32,0>" if bf16 else "conv_mfma_f32<7,16,0>") +
+                                   " (7x7 stage convs, 68% of the FLOPs)",
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
                          "launches_timed": k7_n,
                          "flops_per_launch": round(k7_flops / max(k7_n, 1)),
                          "avg_launch_ms": round(k7_ms / max(k7_n, 1), 4)},
         }
         if world == 1 and not args.no_traffic and "ROCPROF" not in "".join(os.environ.keys()).upper():
             # free this process's GPU memory pressure is irrelevant (288 GB); the child runs its own plan
-            tr = measure_traffic()
+            tr = measure_traffic(dtype=args.dtype)
             if tr:
                 out["roofline"]["traffic"] = round(tr["fetch_bytes"] + tr["write_bytes"])
                 out["roofline"]["traffic_detail"] = tr
-                out["roofline"]["algorithmic_bytes_per_launch"] = 76_000_000
+                out["roofline"]["algorithmic_bytes_per_launch"] = 38_000_000 if bf16 else 76_000_000
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline((heat_np, paf_np))
         else:

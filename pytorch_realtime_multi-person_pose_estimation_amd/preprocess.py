@@ -196,25 +196,27 @@ def get_multiscale_outputs(img, model, preprocess='rtpose', scales=(0.5, 1.0, 1.
     for si, s in enumerate(scales):
         im_croped, im_scale, real_shape = crop_with_factor(img, int(round(base * s)), factor=stride, is_ceil=True)
         x = torch.from_numpy(np.expand_dims(prep(im_croped), 0)).to(dev)
-        (paf, heat), _ = model(x)
-        heat = heat.permute(0, 2, 3, 1).contiguous()
-        paf = paf.permute(0, 2, 3, 1).contiguous()
         if flip:
             # the padded columns sit on the right of the normal pass and on the left of the flipped one:
-            # mirror only inside the valid width by flipping the un-padded image region instead
+            # mirror only inside the valid width by flipping the un-padded image region instead;
+            # both passes of a scale run as ONE batch of 2
             vw = real_shape[1]
-            xf2 = x.clone()
-            xf2[:, :, :, :vw] = torch.flip(x[:, :, :, :vw], dims=[3])
-            (paf_f, heat_f), _ = model(xf2)
-            heat_f = heat_f.permute(0, 2, 3, 1).contiguous()
-            paf_f = paf_f.permute(0, 2, 3, 1).contiguous()
+            xb = torch.cat([x, x], 0)
+            xb[1, :, :, :vw] = torch.flip(x[0, :, :, :vw], dims=[2])
+            (paf2, heat2), _ = model(xb)
+            heat2 = heat2.permute(0, 2, 3, 1)
+            paf2 = paf2.permute(0, 2, 3, 1)
             vwm = -(-vw // stride)
-            hv, pv = heat[:, :, :vwm].contiguous(), paf[:, :, :vwm].contiguous()
-            hfv, pfv = heat_f[:, :, :vwm].contiguous(), paf_f[:, :, :vwm].contiguous()
+            hv, pv = heat2[0:1, :, :vwm].contiguous(), paf2[0:1, :, :vwm].contiguous()
+            hfv, pfv = heat2[1:2, :, :vwm].contiguous(), paf2[1:2, :, :vwm].contiguous()
             mh, mp = torch.empty_like(hv), torch.empty_like(pv)
             check(lib.rtpose_flip_merge(ptr(hv), ptr(hfv), ptr(pv), ptr(pfv), 1, hv.shape[1], vwm, ptr(mh), ptr(mp),
                                         stream), "rtpose_flip_merge")
             heat, paf = mh, mp
+        else:
+            (paf, heat), _ = model(x)
+            heat = heat.permute(0, 2, 3, 1).contiguous()
+            paf = paf.permute(0, 2, 3, 1).contiguous()
         hs, ws = heat.shape[1], heat.shape[2]
         # one destination cell (stride px of the scale-1 image) spans im_scale/s1 source cells,
         # whatever the two paddings are: the map origins coincide, only the zoom differs
