@@ -303,6 +303,12 @@ int rtpose_preprocess_u8(const unsigned char* img_bgr, int h0, int w0, double im
                          float* dst, const rtpose_layout* ldst, int n_index, int Hn, int Wn, int hr,
                          int wr, void* stream);
 
+/* Same, with flip != 0 writing the x-mirrored RESIZED image (columns [0, wr) mirrored, the
+ * zero padding stays on the right): the second pass of flip test-time augmentation. */
+int rtpose_preprocess_u8_flip(const unsigned char* img_bgr, int h0, int w0, double im_scale, int mode,
+                              float* dst, const rtpose_layout* ldst, int n_index, int Hn, int Wn, int hr,
+                              int wr, int flip, void* stream);
+
 /* Multi-scale test-time augmentation (BASELINE config 3; the scale set is NOT pinned by
  * the reference tree - SURVEY.md §3.2): dst = beta*dst + alpha*bilinear_resize(src), dense
  * NHWC, half-pixel centres, edge clamp.  Only the top-left src_h_valid x src_w_valid
@@ -311,6 +317,17 @@ int rtpose_preprocess_u8(const unsigned char* img_bgr, int h0, int w0, double im
 int rtpose_resize_bilinear_accum(const float* src, int hs, int ws, float* dst, int hd, int wd,
                                  int C, int N, float src_h_valid, float src_w_valid,
                                  float alpha, float beta, void* stream);
+
+/* One scale of batched multi-scale (+flip) TTA, fused: heat/paf are the network's own output
+ * views (rtpose_net_output_view) of a batch of 2B images - [0,B) normal, [B,2B) mirrored
+ * (B images if flip == 0).  Forms the handle_paf_and_heat average (coco_eval.py:197-242;
+ * mirror inside the first w_valid columns) and accumulates
+ *   acc = beta * acc + alpha * bilinear_resize(average)   (dense [B,hd,wd,19] / [B,hd,wd,38])
+ * exactly as rtpose_flip_merge followed by rtpose_resize_bilinear_accum would. */
+int rtpose_tta_accumulate(const float* heat, const rtpose_layout* lheat, const float* paf,
+                          const rtpose_layout* lpaf, int B, int hs, int w_valid, float* acc_heat,
+                          float* acc_paf, int hd, int wd, float src_h_valid, float src_w_valid,
+                          float alpha, float beta, int flip, void* stream);
 
 #define RTPOSE_NUM_PART 18
 #define RTPOSE_NUM_LIMB 19

@@ -123,6 +123,9 @@ _SIGS = {
     "rtpose_decode_batch": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, C.POINTER(DecodeCfg), _vp, _sz, _vp, _vp]),
     "rtpose_nms_batch": (_i, [_vp, _LP, _i, _i, _i, C.POINTER(DecodeCfg), _vp, _vp]),
     "rtpose_preprocess_u8": (_i, [_vp, _i, _i, C.c_double, _i, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
+    "rtpose_preprocess_u8_flip": (_i, [_vp, _i, _i, C.c_double, _i, _vp, _LP, _i, _i, _i, _i, _i, _i, _vp]),
+    "rtpose_tta_accumulate": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, _vp, _vp, _i, _i, C.c_float, C.c_float,
+                                   C.c_float, C.c_float, _i, _vp]),
     "rtpose_net_input_view": (_i, [_vp, C.POINTER(_vp), _LP]),
     "rtpose_net_forward_prepared": (_i, [_vp, _vp]),
     "rtpose_resize_bilinear_accum": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),

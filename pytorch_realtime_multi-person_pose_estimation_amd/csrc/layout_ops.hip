@@ -181,7 +181,7 @@ __device__ __forceinline__ void lin_coeff(int d, int sn, double scale, int& s0, 
 
 __global__ void preprocess_u8_kernel(const unsigned char* __restrict__ img, int h0, int w0, double inv_scale,
                                      int mode, float* __restrict__ dst, Lay ld, int n, int Hn, int Wn,
-                                     int hr, int wr) {
+                                     int hr, int wr, int flip) {
   const size_t total = (size_t)Hn * Wn;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -189,7 +189,8 @@ __global__ void preprocess_u8_kernel(const unsigned char* __restrict__ img, int 
   int px[3] = {0, 0, 0};  // padded area: pixel value 0 (im_transform.py:130-131)
   if (y < hr && x < wr) {
     int x0, x1, ax0, ax1, y0, y1, ay0, ay1;
-    lin_coeff(x, w0, inv_scale, x0, x1, ax0, ax1);
+    // flip: this destination column shows the x-mirrored RESIZED image (valid region only)
+    lin_coeff(flip ? wr - 1 - x : x, w0, inv_scale, x0, x1, ax0, ax1);
     lin_coeff(y, h0, inv_scale, y0, y1, ay0, ay1);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -243,6 +244,53 @@ __global__ void resize_bilinear_accum_kernel(const float* __restrict__ src, int 
   const float bot = s1[(size_t)x0 * C] * (1.f - lx) + s1[(size_t)x1 * C] * lx;
   const float v = top * (1.f - ly) + bot * ly;
   dst[i] = (beta == 0.f ? 0.f : beta * dst[i]) + alpha * v;
+}
+
+// Fused test-time-augmentation merge for one scale (BASELINE config 3): reads the stage-6 maps
+// of B normal passes (images [0,B)) and, if flip, B x-mirrored passes (images [B,2B)) where the
+// net wrote them, forms handle_paf_and_heat's average (evaluate/coco_eval.py:197-242; mirror
+// inside the first wv columns only, left/right channel swap, PAF x sign) at the four
+// bilinear taps and accumulates alpha * resize(...) into the dense scale-1 maps.  Same
+// expressions as flip_merge_kernel followed by resize_bilinear_accum_kernel.
+__global__ void tta_accumulate_kernel(const float* __restrict__ heat, Lay lh, const float* __restrict__ paf,
+                                      Lay lp, int B, int hs, int wv, float* __restrict__ acc_heat,
+                                      float* __restrict__ acc_paf, int hd, int wd, float sy, float sx,
+                                      float alpha, float beta, int flip) {
+  const size_t total = (size_t)B * hd * wd * 57;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c57 = i % 57;
+  size_t p = i / 57;
+  const int x = p % wd;
+  size_t r = p / wd;
+  const int y = r % hd;
+  const int b = (int)(r / hd);
+  float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
+  fy = fmaxf(fy, 0.f);
+  fx = fmaxf(fx, 0.f);
+  int y0 = (int)fy, x0 = (int)fx;
+  y0 = min(y0, hs - 1);
+  x0 = min(x0, wv - 1);
+  const int y1 = min(y0 + 1, hs - 1), x1 = min(x0 + 1, wv - 1);
+  const float ly = fminf(fy - (float)y0, 1.f), lx = fminf(fx - (float)x0, 1.f);
+  const bool is_heat = c57 < 19;
+  const int c = is_heat ? c57 : c57 - 19;
+  const float* src = is_heat ? heat : paf;
+  const Lay& l = is_heat ? lh : lp;
+  const int sc = is_heat ? kSwapHeat[c] : kSwapPaf[c];
+  const bool neg = !is_heat && (sc & 1) == 0;
+  auto tap = [&](int yy, int xx) -> float {
+    const float a = src[lay_off(l, b, yy, xx) + c];
+    if (!flip) return a;
+    float v = src[lay_off(l, B + b, yy, wv - 1 - xx) + sc];
+    if (neg) v = -v;
+    return (a + v) / 2.f;
+  };
+  const float top = tap(y0, x0) * (1.f - lx) + tap(y0, x1) * lx;
+  const float bot = tap(y1, x0) * (1.f - lx) + tap(y1, x1) * lx;
+  const float v = top * (1.f - ly) + bot * ly;
+  float* d = is_heat ? acc_heat + p * 19 + c : acc_paf + p * 38 + c;
+  *d = (beta == 0.f ? 0.f : beta * *d) + alpha * v;
 }
 
 // dst(n,y,x,c) = alpha * dst(n,y,x,c) + beta * src_dense[n][y][x][c]
@@ -658,16 +706,22 @@ int rtpose_layout_axpby(float* dst, const rtpose_layout* ldst, const float* src_
   return 0;
 }
 
-int rtpose_preprocess_u8(const unsigned char* img_bgr, int h0, int w0, double im_scale, int mode, float* dst,
-                         const rtpose_layout* ldst, int n_index, int Hn, int Wn, int hr, int wr, void* stream) {
+int rtpose_preprocess_u8_flip(const unsigned char* img_bgr, int h0, int w0, double im_scale, int mode, float* dst,
+                              const rtpose_layout* ldst, int n_index, int Hn, int Wn, int hr, int wr, int flip,
+                              void* stream) {
   if (!img_bgr || !dst || h0 <= 0 || w0 <= 0 || im_scale <= 0 || Hn < hr || Wn < wr || (mode != 0 && mode != 1) ||
       ldst->cstride < 8 || (ldst->cstride % 4) || (ldst->choff % 4))
     return fail(RTPOSE_E_INVAL, "preprocess_u8: bad arguments");
   const size_t total = (size_t)Hn * Wn;
   hipLaunchKernelGGL(preprocess_u8_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), img_bgr, h0,
-                     w0, 1.0 / im_scale, mode, dst, to_lay(ldst), n_index, Hn, Wn, hr, wr);
+                     w0, 1.0 / im_scale, mode, dst, to_lay(ldst), n_index, Hn, Wn, hr, wr, flip ? 1 : 0);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
+}
+
+int rtpose_preprocess_u8(const unsigned char* img_bgr, int h0, int w0, double im_scale, int mode, float* dst,
+                         const rtpose_layout* ldst, int n_index, int Hn, int Wn, int hr, int wr, void* stream) {
+  return rtpose_preprocess_u8_flip(img_bgr, h0, w0, im_scale, mode, dst, ldst, n_index, Hn, Wn, hr, wr, 0, stream);
 }
 
 int rtpose_resize_bilinear_accum(const float* src, int hs, int ws, float* dst, int hd, int wd, int C, int N,
@@ -677,6 +731,21 @@ int rtpose_resize_bilinear_accum(const float* src, int hs, int ws, float* dst, i
   const size_t total = (size_t)N * hd * wd * C;
   hipLaunchKernelGGL(resize_bilinear_accum_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
                      src, hs, ws, dst, hd, wd, C, N, src_h_valid / (float)hd, src_w_valid / (float)wd, alpha, beta);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_tta_accumulate(const float* heat, const rtpose_layout* lheat, const float* paf,
+                          const rtpose_layout* lpaf, int B, int hs, int w_valid, float* acc_heat, float* acc_paf,
+                          int hd, int wd, float src_h_valid, float src_w_valid, float alpha, float beta, int flip,
+                          void* stream) {
+  if (!heat || !paf || !acc_heat || !acc_paf || B <= 0 || hs <= 0 || w_valid <= 0 || hd <= 0 || wd <= 0 ||
+      src_h_valid <= 0 || src_w_valid <= 0)
+    return fail(RTPOSE_E_INVAL, "tta_accumulate: bad arguments");
+  const size_t total = (size_t)B * hd * wd * 57;
+  hipLaunchKernelGGL(tta_accumulate_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), heat,
+                     to_lay(lheat), paf, to_lay(lpaf), B, hs, w_valid, acc_heat, acc_paf, hd, wd,
+                     src_h_valid / (float)hd, src_w_valid / (float)wd, alpha, beta, flip ? 1 : 0);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }

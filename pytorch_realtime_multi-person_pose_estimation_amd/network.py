@@ -71,6 +71,15 @@ class _Plan(object):
             pass
 
 
+class _ShapeOnly(object):
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _capi.RtposeError("rtpose_vgg plans exist only on an MI355X (HIP) device; got %s" % device)
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+
+
 class RtposeVGG(nn.Module):
     """Drop-in for the module built by reference ``get_model('vgg19')``."""
 
@@ -150,6 +159,12 @@ class RtposeVGG(nn.Module):
         n, c, h, w = x.shape
         if c != 3:
             raise _capi.RtposeError("expected NCHW input with 3 channels")
+        return self.plan_for_shape(n, h, w, x.device)
+
+    def plan_for_shape(self, n, h, w, device):
+        """The executor instance for N x 3 x H x W inputs on `device` (created on first use);
+        for callers that fill the plan's input buffer themselves (rtpose_preprocess_u8)."""
+        x = _ShapeOnly(device)
         dtype = _capi.DTYPE_BF16 if self.compute_dtype == 'bf16' else _capi.DTYPE_F32
         key = (n, h, w, x.device.index, dtype)
         plan = self._plans.get(key)

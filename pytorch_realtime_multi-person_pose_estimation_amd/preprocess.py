@@ -228,3 +228,56 @@ def get_multiscale_outputs(img, model, preprocess='rtpose', scales=(0.5, 1.0, 1.
         check(lib.rtpose_resize_bilinear_accum(ptr(paf), hs, ws, ptr(acc_paf), hd, wd, 38, 1, hd * ratio, wd * ratio,
                                                a, beta, stream), "rtpose_resize_bilinear_accum")
     return acc_paf[0].cpu().numpy(), acc_heat[0].cpu().numpy(), s1
+
+
+def get_multiscale_outputs_batch(imgs, model, preprocess='rtpose', scales=(0.5, 1.0, 1.5, 2.0), flip=True,
+                                 config=None):
+    """Batched, GPU-resident form of get_multiscale_outputs (BASELINE config 3): B uint8 BGR images
+    of one size are uploaded once (3 B/pixel); per scale ONE kernel per image resizes + pads +
+    normalises it (and its mirror image) straight into the input buffer of a 2B-image plan, one
+    forward runs all of them, and one fused kernel (rtpose_tta_accumulate) does the flip merge,
+    the resize to the scale-1 map and the running average where the net wrote its outputs.
+    Same arithmetic as get_multiscale_outputs, image by image.
+    Returns DEVICE tensors (paf [B,h,w,38], heat [B,h,w,19]) and the scale-1 im_scale - feed them
+    to decode.decode_maps."""
+    import ctypes as C
+    config = config or dec.default_config()
+    base = int(config.DATASET.IMAGE_SIZE)
+    stride = int(config.MODEL.DOWNSAMPLE)
+    imgs = np.ascontiguousarray(np.stack([np.asarray(i, dtype=np.uint8) for i in imgs]))
+    B, h0, w0 = imgs.shape[:3]
+    dev = torch.device('cuda', torch.cuda.current_device())
+    m = _unwrap(model)
+    img_d = torch.from_numpy(imgs).to(dev)
+    s1 = float(base) / min(h0, w0)
+    hd, wd = -(-_cv_round(h0 * s1) // stride), -(-_cv_round(w0 * s1) // stride)
+    acc_heat = torch.empty(B, hd, wd, 19, device=dev)
+    acc_paf = torch.empty(B, hd, wd, 38, device=dev)
+    stream = current_stream()
+    mode = {'rtpose': 0, 'vgg': 1}[preprocess]
+    nb = 2 * B if flip else B
+    img_bytes = h0 * w0 * 3
+    for si, s in enumerate(scales):
+        im_scale = float(int(round(base * s))) / min(h0, w0)          # crop_with_factor, im_transform.py:124
+        hr, wr = _cv_round(h0 * im_scale), _cv_round(w0 * im_scale)
+        hn, wn = _factor_closest(hr, stride), _factor_closest(wr, stride)
+        plan = m.plan_for_shape(nb, hn, wn, dev)
+        ibase, ilay = C.c_void_p(), _capi.Layout()
+        check(lib.rtpose_net_input_view(plan.handle, C.byref(ibase), C.byref(ilay)), "rtpose_net_input_view")
+        for b in range(B):
+            src = C.c_void_p(img_d.data_ptr() + b * img_bytes)
+            check(lib.rtpose_preprocess_u8_flip(src, h0, w0, im_scale, mode, ibase, C.byref(ilay), b, hn, wn, hr, wr,
+                                                0, stream), "rtpose_preprocess_u8_flip")
+            if flip:
+                check(lib.rtpose_preprocess_u8_flip(src, h0, w0, im_scale, mode, ibase, C.byref(ilay), B + b, hn, wn,
+                                                    hr, wr, 1, stream), "rtpose_preprocess_u8_flip")
+        check(lib.rtpose_net_set_keep_intermediates(plan.handle, 0))
+        check(lib.rtpose_net_forward_prepared(plan.handle, stream), "rtpose_net_forward_prepared")
+        pbase, lpaf, _, hs, ws = m.output_view(plan, 0)
+        hbase, lheat, _, _, _ = m.output_view(plan, 1)
+        wv = -(-wr // stride) if flip else ws
+        ratio = im_scale / s1
+        check(lib.rtpose_tta_accumulate(hbase, C.byref(lheat), pbase, C.byref(lpaf), B, hs, wv, ptr(acc_heat),
+                                        ptr(acc_paf), hd, wd, hd * ratio, wd * ratio, 1.0 / len(scales),
+                                        0.0 if si == 0 else 1.0, 1 if flip else 0, stream), "rtpose_tta_accumulate")
+    return acc_paf, acc_heat, s1

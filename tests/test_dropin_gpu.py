@@ -155,3 +155,39 @@ def test_gpu_preprocess_bit_exact_and_same_outputs(compat, capi, cuda):
         paf_a, heat_a, s_a = pre.get_outputs(img, model, 'rtpose')
         paf_b, heat_b, s_b = pre.get_outputs_gpu(img, model, 'rtpose')
     assert s_a == s_b and np.array_equal(paf_a, paf_b) and np.array_equal(heat_a, heat_b)
+
+
+def test_multiscale_batch_matches_per_image(compat, cuda):
+    """The batched GPU-resident TTA (uint8 upload, flip in the resize kernel, fused merge kernel)
+    computes the same maps as the per-image host-prepared path, image by image, in fp32 and in
+    bf16; the decoder consumes its device tensors directly."""
+    from lib.network.rtpose_vgg import get_model
+    from oracle import net_oracle
+    pre = importlib.import_module(PKG_NAME + ".preprocess")
+    dec = importlib.import_module(PKG_NAME + ".decode")
+    model = get_model('vgg19')
+    model.load_state_dict(net_oracle.he_init_state_dict(model, seed=0))
+    model = model.cuda().eval()
+    rng = np.random.default_rng(7)
+    imgs = [rng.integers(0, 256, (131, 150, 3), dtype=np.uint8) for _ in range(3)]
+    scales = (0.5, 1.0, 1.5)
+    for dt, tol in (('fp32', 2e-6), ('bf16', 2e-6)):
+        model.set_compute_dtype(dt)
+        try:
+            with torch.no_grad():
+                paf_b, heat_b, s_b = pre.get_multiscale_outputs_batch(imgs, model, 'rtpose', scales=scales, flip=True)
+                for i, img in enumerate(imgs):
+                    paf_i, heat_i, s_i = pre.get_multiscale_outputs(img, model, 'rtpose', scales=scales, flip=True)
+                    assert s_i == s_b and paf_i.shape == tuple(paf_b.shape[1:])
+                    scale = max(1.0, np.abs(paf_i).max())
+                    assert np.abs(paf_b[i].cpu().numpy() - paf_i).max() <= tol * scale, dt
+                    assert np.abs(heat_b[i].cpu().numpy() - heat_i).max() <= tol * scale, dt
+                # no-flip variant against the same reference path
+                paf_n, heat_n, _ = pre.get_multiscale_outputs_batch(imgs[:1], model, 'rtpose', scales=scales, flip=False)
+                paf_r, heat_r, _ = pre.get_multiscale_outputs(imgs[0], model, 'rtpose', scales=scales, flip=False)
+                assert np.abs(paf_n[0].cpu().numpy() - paf_r).max() <= tol * max(1.0, np.abs(paf_r).max())
+                assert np.abs(heat_n[0].cpu().numpy() - heat_r).max() <= tol * max(1.0, np.abs(heat_r).max())
+        finally:
+            model.set_compute_dtype('fp32')
+    recs = dec.decode_maps(heat_b, paf_b)
+    assert len(recs) == 3 and all(r["flags"] == 0 or r["n_peaks"] > 0 for r in recs)
