@@ -40,6 +40,16 @@ __device__ __forceinline__ float4 gload4(const void* p) {
   const floatx4 v = *(gcf4_t)(unsigned long long)(p);
   return make_float4(v[0], v[1], v[2], v[3]);
 }
+typedef floatx4 __attribute__((address_space(1)))* gf4_t;
+__device__ __forceinline__ void gstore4(void* p, const float4& v) {
+  const floatx4 t = {v.x, v.y, v.z, v.w};
+  *(gf4_t)(unsigned long long)(p) = t;
+}
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ bf16x8 as_bf8(const float4& v) {
   const floatx4 t = {v.x, v.y, v.z, v.w};
   return __builtin_bit_cast(bf16x8, t);
@@ -64,6 +74,7 @@ struct ConvArgs {
   int N, H, W, M;
   int cin;  // packed input channels (multiple of the chunk size)
   int relu, pool, out_f32;
+  int vec_store;  // bf16 output, full N tiles, 16-byte aligned slices: transposed epilogue
   int qs;       // LDS pixels per piece plane
   int hw_lds;   // MODE 1: LDS row stride of the halo (pixels)
   int tw_log2;  // MODE 1: log2(tile width); tile height = 128 >> tw_log2
@@ -73,6 +84,10 @@ struct ConvArgs {
 
 constexpr int kBM = 128;
 constexpr int kHD = 3;  // depth of the halo staging ring (taps between fetch and park)
+// Epilogue slab: each wave transposes its (up to) 64 x 64 bf16 tile through LDS so that a lane
+// stores 16 bytes (8 output channels of one pixel) instead of 64 scattered 2-byte values -
+// measured, the scalar epilogue cost 25-30 % of a 7x7 layer at bf16 MFMA speed.
+constexpr int kSlabBytes = 128 * 80;  // per wave: max over (rows 32*MF) x (pitch 64*NF + 16)
 
 __device__ __forceinline__ void tile_local_yx(int ml, int tw_log2, int& ty, int& tx) {
   const int qi = ml >> 2;
@@ -83,21 +98,30 @@ __device__ __forceinline__ void tile_local_yx(int ml, int tw_log2, int& ty, int&
 
 // KS: kernel size; CK: channels per LDS chunk (16, 32 or 64); MODE 0 strip / 1 2-D tile;
 // NBUF 2: next chunk staged under the MFMAs, NBUF 1: refilled between chunks (1x1 layers);
-// MF / NF: 32-row / 32-column fragments per wave (block tile 64*MF x 64*NF).
-template <int KS, int CK, int MODE, int NBUF, int MF, int NF>
+// WM: waves along M (the block's 4 waves form WM x 4/WM); MF / NF: 32-row / 32-column fragments
+// per wave (block tile 32*MF*WM pixels x 32*NF*4/WM channels).  The 128 x 128 block tile exists
+// in two arrangements: 2 x 2 waves of 64 x 64 (MF = NF = 2) and 1 x 4 waves of 128 x 32
+// (MF = 4, NF = 1).  The second halves the B (weight) bytes a CU pulls through its L1 per MFMA
+// - every wave reads all A fragments from LDS instead, which has 4x the L1's bandwidth.
+template <int KS, int CK, int MODE, int NBUF, int WM, int MF, int NF>
 __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g, const int m0_arg,
                                           const int ntile, float* smem) {
   constexpr int P = KS / 2;
-  constexpr int BMT = 64 * MF;
+  constexpr int BMT = 32 * MF * WM;
+  constexpr int BN = 32 * NF * (4 / WM);  // output channels per block
   constexpr int CG = CK / 8;   // 16-byte pieces (8 channels) per pixel per chunk
   constexpr int G = CK / 16;   // K=16 MFMA steps per tap
   constexpr int GB = G * NF;   // B registers (float4) per tap: [n-fragment][k-step]
+  // B register ring: the tap being multiplied + RB-1 taps in flight from L2.  Two taps of
+  // lead (RB = 3) left the waves waiting on vmcnt once two blocks share a CU; the narrow-N
+  // arrangement (NF = 1) has the registers for four.
+  constexpr int RB = (NF == 1 && CK <= 32) ? 5 : 3;
   constexpr int TAPS = KS, ROWS = KS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WM, wn = wave / WM;
   const int l31 = lane & 31, kh = lane >> 5;
   const int QS = A.qs;
 
@@ -175,26 +199,32 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   const int dummy_loff = NBUF * buf4 + tid;
   const int nsets = (np_total + 255) / 256;
 
-  // ---- B operand: uniform base + per-lane byte offset --------------------------------
+  // ---- B operand: buffer loads = SGPR resource + SGPR tap/k-step offset + per-lane VGPR
+  //      offset, so the tap loop spends no VALU and no address registers on them; reads past
+  //      the packed filter (the prefetch runs RB-1 taps ahead) return zero by the bounds check
   const int nchunks = A.cin / CK;
-  const int ncol = ntile * (kConvBN * NF) + wn * (32 * NF) + l31;
+  const int ncol = ntile * BN + wn * (32 * NF) + l31;
   const unsigned lane_b = (unsigned)(kh * g.cout_pad + ncol) * 16u;
-  const size_t b_it_bytes = (size_t)CG * g.cout_pad * 16;  // bytes per (chunk, tap)
-  const unsigned b_k_bytes = (unsigned)(2 * g.cout_pad) * 16u;  // bytes per k-step
-  const char* wb = reinterpret_cast<const char*>(g.w);  // uniform; points at the tap being fetched
-#define RTPOSE_BLOAD(fn_, gi_) gload4(wb + (size_t)((gi_) * b_k_bytes + (fn_) * 512u) + lane_b)
+  const unsigned b_it_bytes = (unsigned)(CG * g.cout_pad) * 16u;  // bytes per (chunk, tap)
+  const unsigned b_k_bytes = (unsigned)(2 * g.cout_pad) * 16u;    // bytes per k-step
+  const unsigned w_bytes = (unsigned)nchunks * (KS * KS) * b_it_bytes;
+  const __amdgpu_buffer_rsrc_t wrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(g.w), 0, (int)w_bytes, 0x00020000);
+  unsigned wso = 0;  // uniform: byte offset of the tap being fetched
+#define RTPOSE_BLOAD(fn_, gi_) \
+  bload4(wrs, lane_b + (fn_) * 512u, wso + (unsigned)(gi_) * b_k_bytes)
 
-  float4 s0[GB], s1[GB], s2[GB];
+  float4 bq[RB][GB];
 #pragma unroll
-  for (int fn = 0; fn < NF; ++fn)
+  for (int t = 0; t + 1 < RB; ++t) {
 #pragma unroll
-    for (int gi = 0; gi < G; ++gi) s0[fn * G + gi] = RTPOSE_BLOAD(fn, gi);
-  wb += b_it_bytes;
+    for (int fn = 0; fn < NF; ++fn)
 #pragma unroll
-  for (int fn = 0; fn < NF; ++fn)
+      for (int gi = 0; gi < G; ++gi) bq[t][fn * G + gi] = RTPOSE_BLOAD(fn, gi);
+    wso += b_it_bytes;
+  }
 #pragma unroll
-    for (int gi = 0; gi < G; ++gi) s1[fn * G + gi] = RTPOSE_BLOAD(fn, gi);
-  wb += b_it_bytes;
+  for (int gi = 0; gi < GB; ++gi) bq[RB - 1][gi] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   auto fill_halo = [&](const float4* src) {
     for (int set0 = 0; set0 < nsets; set0 += 4) {
@@ -207,10 +237,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
         if ((set0 + u) * 256 + tid < np_total) smem4[piece_loff(set0 + u)] = t[u];
     }
   };
+#ifndef RTPOSE_EXP_NO_FILL
   if (NBUF == 2) {
     fill_halo(in_base);
     __syncthreads();
   }
+#endif
 
   floatx16 acc[MF][NF];
 #pragma unroll
@@ -227,6 +259,22 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     for (int fm = 0; fm < MF; ++fm) afrag[gi][fm] = (2 * gi + kh) * QS + abase[fm];
   const int rowstep = row_lds;
 
+// developer ablations (tools/exp_variants_bf16.sh): drop one load stream at a time
+#ifdef RTPOSE_EXP_NO_B
+#define RTPOSE_EXP_B(load, keep) (keep)
+#else
+#define RTPOSE_EXP_B(load, keep) (load)
+#endif
+#ifdef RTPOSE_EXP_NO_A
+#define RTPOSE_EXP_A(load, keep) (keep)
+#else
+#define RTPOSE_EXP_A(load, keep) (load)
+#endif
+#ifdef RTPOSE_EXP_NO_STAGE
+#define RTPOSE_EXP_STAGE 0
+#else
+#define RTPOSE_EXP_STAGE 1
+#endif
 #define RTPOSE_PIN()             \
   asm volatile("" ::: "memory"); \
   __builtin_amdgcn_sched_barrier(0)
@@ -244,17 +292,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
         }                                                                                      \
       }                                                                                        \
       RTPOSE_PIN();                                                                            \
-      _Pragma("unroll") for (int fn = 0; fn < NF; ++fn) BLOAD[fn * G + n] = RTPOSE_BLOAD(fn, n); \
-      if (n == G - 1) wb += b_it_bytes;                                                        \
+      _Pragma("unroll") for (int fn = 0; fn < NF; ++fn) BLOAD[fn * G + n] = RTPOSE_EXP_B(RTPOSE_BLOAD(fn, n), BCUR[fn * G + n]); \
+      if (n == G - 1) wso += b_it_bytes;                                                       \
       if (KS > 1) {                                                                            \
         if (n == 0 && (KX) == KS - 1) { /* next tap starts the next stencil row */             \
           _Pragma("unroll") for (int g2 = 0; g2 < G; ++g2)                                     \
             _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) arow[g2][fm] += rowstep;         \
         }                                                                                      \
         _Pragma("unroll") for (int fm = 0; fm < MF; ++fm)                                      \
-          ANXT[n][fm] = smem4[arow[n][fm] + (((KX) + 1 < KS) ? (KX) + 1 : 0)];                 \
+          ANXT[n][fm] = RTPOSE_EXP_A(smem4[arow[n][fm] + (((KX) + 1 < KS) ? (KX) + 1 : 0)], ACUR[n][fm]); \
       }                                                                                        \
-      if ((STAGE) != 0 && n == G - 1) {                                                        \
+      if (((STAGE) & RTPOSE_EXP_STAGE) != 0 && n == G - 1) {                                   \
         smem4[hl[0]] = hv[0];                                                                  \
         _Pragma("unroll") for (int d = 0; d + 1 < kHD; ++d) {                                  \
           hv[d] = hv[d + 1];                                                                   \
@@ -272,40 +320,25 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
       RTPOSE_PIN();                                                                            \
     }                                                                                          \
   }
-#define RTPOSE_CONV_ROW(STAGE)                                                  \
-  {                                                                             \
-    _Pragma("unroll") for (int kx = 0; kx < TAPS; ++kx) {                       \
-      if (kx % 6 == 0) {                                                        \
-        RTPOSE_CONV_STEP(a0, a1, s0, s2, kx, STAGE)                             \
-      } else if (kx % 6 == 1) {                                                 \
-        RTPOSE_CONV_STEP(a1, a0, s1, s0, kx, STAGE)                             \
-      } else if (kx % 6 == 2) {                                                 \
-        RTPOSE_CONV_STEP(a0, a1, s2, s1, kx, STAGE)                             \
-      } else if (kx % 6 == 3) {                                                 \
-        RTPOSE_CONV_STEP(a1, a0, s0, s2, kx, STAGE)                             \
-      } else if (kx % 6 == 4) {                                                 \
-        RTPOSE_CONV_STEP(a0, a1, s1, s0, kx, STAGE)                             \
-      } else {                                                                  \
-        RTPOSE_CONV_STEP(a1, a0, s2, s1, kx, STAGE)                             \
-      }                                                                         \
-    }                                                                           \
-    if (KS > 1 && (TAPS & 1)) {                                                 \
-      _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                          \
-        _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) a0[gi][fm] = a1[gi][fm]; \
-    }                                                                           \
-    _Pragma("unroll") for (int gi = 0; gi < GB; ++gi) {                         \
-      if (TAPS % 3 == 1) {                                                      \
-        const float4 t_ = s0[gi];                                               \
-        s0[gi] = s1[gi];                                                        \
-        s1[gi] = s2[gi];                                                        \
-        s2[gi] = t_;                                                            \
-      } else if (TAPS % 3 == 2) {                                               \
-        const float4 t_ = s2[gi];                                               \
-        s2[gi] = s1[gi];                                                        \
-        s1[gi] = s0[gi];                                                        \
-        s0[gi] = t_;                                                            \
-      }                                                                         \
-    }                                                                           \
+#define RTPOSE_CONV_ROW(STAGE)                                                              \
+  {                                                                                         \
+    _Pragma("unroll") for (int kx = 0; kx < TAPS; ++kx) {                                   \
+      /* A sets alternate; B: multiply ring slot kx % RB, refill the slot freed by the */   \
+      /* previous tap with the tap RB-1 ahead (all indices fold after unrolling)       */   \
+      RTPOSE_CONV_STEP(av[kx & 1], av[(kx & 1) ^ 1], bq[kx % RB], bq[(kx + RB - 1) % RB], kx, STAGE) \
+    }                                                                                       \
+    /* re-normalise the register roles for the next row (a few v_mov per row) */            \
+    if (KS > 1 && (TAPS & 1)) {                                                             \
+      _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                                      \
+        _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) av[0][gi][fm] = av[1][gi][fm];    \
+    }                                                                                       \
+    if (TAPS % RB != 0) {                                                                   \
+      float4 t_[RB][GB];                                                                    \
+      _Pragma("unroll") for (int r = 0; r < RB; ++r)                                        \
+        _Pragma("unroll") for (int gi = 0; gi < GB; ++gi) t_[r][gi] = bq[(r + TAPS) % RB][gi]; \
+      _Pragma("unroll") for (int r = 0; r < RB; ++r)                                        \
+        _Pragma("unroll") for (int gi = 0; gi < GB; ++gi) bq[r][gi] = t_[r][gi];            \
+    }                                                                                       \
   }
 
   // rows of a chunk whose taps carry the staging code: one piece set is fetched per tap;
@@ -332,14 +365,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
       hl[d] = dummy_loff;
     }
     int arow[G][MF];
-    float4 a0[G][MF], a1[G][MF];
+    float4 av[2][G][MF];
 #pragma unroll
     for (int gi = 0; gi < G; ++gi)
 #pragma unroll
       for (int fm = 0; fm < MF; ++fm) {
         arow[gi][fm] = hb_off + afrag[gi][fm];
-        a0[gi][fm] = smem4[arow[gi][fm]];  // tap (0,0)
-        a1[gi][fm] = a0[gi][fm];
+        av[0][gi][fm] = smem4[arow[gi][fm]];  // tap (0,0)
+        av[1][gi][fm] = av[0][gi][fm];
       }
     int ky = 0;
     if (NBUF == 2)
@@ -357,8 +390,90 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
 #undef RTPOSE_BLOAD
 
   // ---- epilogue: bias (+ReLU) (+2x2 max-pool), masked stores, bf16 (RNE) or fp32 ---------
+#ifdef RTPOSE_EXP_NO_STORE
+  if (A.N > 0) {  // keep the accumulators live, skip the whole epilogue
+    float t_ = 0.f;  // every accumulator stays live (else the compiler drops their MFMAs)
+#pragma unroll
+    for (int fm = 0; fm < MF; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < NF; ++fn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t_ += acc[fm][fn][r];
+    if (t_ == 12345.678f) reinterpret_cast<float*>(g.out)[0] = t_;
+    return;
+  }
+#endif
   unsigned short* out_h = reinterpret_cast<unsigned short*>(g.out);
   float* out_f = reinterpret_cast<float*>(g.out);
+  if (A.vec_store) {  // uniform
+    // (the chunk loop ended with a barrier: the halo buffers are dead)
+    constexpr int PITCH2 = (NF * 64 + 16) / 2;  // slab row pitch in bf16 elements
+    unsigned short* sl = reinterpret_cast<unsigned short*>(smem) + wave * (kSlabBytes / 2);
+#pragma unroll
+    for (int fn = 0; fn < NF; ++fn) {
+      const float bias = g.bias[ncol + fn * 32];
+#pragma unroll
+      for (int fm = 0; fm < MF; ++fm) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          if (!A.pool) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              float v = acc[fm][fn][rg * 4 + rr] + bias;
+              if (A.relu) v = fmaxf(v, 0.f);
+              sl[(fm * 32 + rg * 8 + 4 * kh + rr) * PITCH2 + fn * 32 + l31] = to_bf16(v);
+            }
+          } else {
+            float v = fmaxf(fmaxf(acc[fm][fn][rg * 4 + 0], acc[fm][fn][rg * 4 + 1]),
+                            fmaxf(acc[fm][fn][rg * 4 + 2], acc[fm][fn][rg * 4 + 3])) + bias;
+            if (A.relu) v = fmaxf(v, 0.f);
+            sl[(fm * 8 + rg * 2 + kh) * PITCH2 + fn * 32 + l31] = to_bf16(v);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // same-wave LDS traffic is in order
+    constexpr int LPR = NF * 4;     // lanes (16 bytes each) per slab row
+    constexpr int RPI = 64 / LPR;   // rows per wave-instruction
+    const int rows = A.pool ? 8 * MF : 32 * MF;
+    const int lrow = lane / LPR, c16 = lane % LPR;
+    unsigned short* ob = out_h + g.out_choff + ntile * BN + wn * (32 * NF) + c16 * 8;
+    const int Ho = A.H >> 1, Wo = A.W >> 1;
+    for (int it = 0; it * RPI < rows; ++it) {
+      const int row = it * RPI + lrow;
+      const float4 v = *reinterpret_cast<const float4*>(sl + row * PITCH2 + c16 * 8);
+      int n, y, x;
+      bool ok;
+      if (A.pool) {  // MODE 1: slab row = quad index inside the wave
+        const int qi = wm * (8 * MF) + row;
+        const int hw_log2 = A.tw_log2 - 1;
+        n = n_img;
+        y = (y0 >> 1) + (qi >> hw_log2);
+        x = (x0 >> 1) + (qi & ((1 << hw_log2) - 1));
+        ok = y < Ho && x < Wo;
+      } else if (MODE == 0) {
+        const int m = m0 + wm * (32 * MF) + row;
+        ok = m < A.M;
+        const int HW = A.H * A.W;
+        n = m / HW;
+        const int r = m - n * HW;
+        y = r / A.W;
+        x = r - y * A.W;
+      } else {
+        int ty, tx;
+        tile_local_yx(wm * (32 * MF) + row, A.tw_log2, ty, tx);
+        n = n_img;
+        y = y0 + ty;
+        x = x0 + tx;
+        ok = (y < A.H) && (x < A.W);
+      }
+      if (ok && row < rows) {
+        const size_t q = (size_t)g.out_lead + (size_t)(n * g.out_hs + y) * g.out_ws + x;
+        gstore4(ob + q * g.out_cstride, v);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int fn = 0; fn < NF; ++fn) {
     const int ncolf = ncol + fn * 32;
@@ -429,8 +544,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
 
 // 1-D grid, block id -> (group, N tile, M tile); XCD-aware order and half-tile tail exactly
 // as conv_mfma_f32 (conv_mfma.hip).
-template <int KS, int CK, int MODE, int NBUF, int NF>
+template <int KS, int CK, int MODE, int NBUF, int WM, int NF>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs A) {
+  constexpr int MF = 4 / WM;  // block M tile = 128 pixels either way
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int L = blockIdx.x;
   const bool small = MODE == 0 && L >= A.nbig;
@@ -447,12 +563,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs A) {
   if (mt >= A.mtiles) return;
   const int nt = c % A.ntiles, grp = c / A.ntiles;
   if (MODE == 1) {
-    conv_tile<KS, CK, MODE, NBUF, 2, NF>(A, A.g[grp], mt, nt, smem);
+    conv_tile<KS, CK, MODE, NBUF, WM, MF, NF>(A, A.g[grp], mt, nt, smem);
   } else if (!small) {
-    conv_tile<KS, CK, MODE, NBUF, 2, NF>(A, A.g[grp], mt * kBM, nt, smem);
+    conv_tile<KS, CK, MODE, NBUF, WM, MF, NF>(A, A.g[grp], mt * kBM, nt, smem);
   } else {
     const int m0 = mt * kBM + ((L - A.nbig) & 1) * (kBM / 2);
-    if (m0 < A.M) conv_tile<KS, CK, MODE, NBUF, 1, NF>(A, A.g[grp], m0, nt, smem);
+    if (m0 < A.M) conv_tile<KS, CK, MODE, NBUF, WM, MF / 2, NF>(A, A.g[grp], m0, nt, smem);
   }
 }
 
@@ -492,7 +608,7 @@ static int conv_ck(int cin, int k) {
 }
 
 struct ConvPlan {
-  int mode, ck, qs, hw_lds, tw_log2, tiles_x, tiles_y, grid_x, nbuf, nf;
+  int mode, ck, qs, hw_lds, tw_log2, tiles_x, tiles_y, grid_x, nbuf, nf, wm;
   size_t lds_bytes;
 };
 
@@ -563,10 +679,10 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* p
   return 0;
 }
 
-template <int KS, int CK, int MODE, int NBUF, int NF>
+template <int KS, int CK, int MODE, int NBUF, int WM, int NF>
 static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = conv_mfma_bf16<KS, CK, MODE, NBUF, NF>;
+  auto kern = conv_mfma_bf16<KS, CK, MODE, NBUF, WM, NF>;
   if (!attr_set) {
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -634,6 +750,12 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
   a.relu = d0.relu;
   a.pool = d0.pool;
   a.out_f32 = out_f32 ? 1 : 0;
+  a.vec_store = !out_f32;
+  for (int i = 0; i < ngroups; ++i)
+    if (d[i].out_cmap || (d[i].cout % kConvBN) || (d[i].lout.cstride % 8) || (d[i].lout.choff % 8)) a.vec_store = 0;
+#ifdef RTPOSE_EXP_SCALAR_STORE
+  a.vec_store = 0;
+#endif
   a.qs = pl.qs;
   a.hw_lds = pl.hw_lds;
   a.tw_log2 = pl.tw_log2;
@@ -649,8 +771,17 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
   }
   a.mtiles = pl.grid_x;
   const int coutp = cout_pad(d0.cout);
-  pl.nf = (d0.k != 1 && coutp % 128 == 0) ? 2 : 1;
-  a.ntiles = coutp / (kConvBN * pl.nf);
+  // 128-channel N tiles for the k x k layers whose cout allows it: 1 x 4 waves of 128 x 32
+  // (default) or 2 x 2 waves of 64 x 64 (RTPOSE_BF16_WAVES=22, kept for A/B); else 128 x 64
+  static int waves_env = 0;
+  if (!waves_env) {
+    const char* e = getenv("RTPOSE_BF16_WAVES");
+    waves_env = e ? atoi(e) : 14;
+  }
+  const bool wide = d0.k != 1 && coutp % 128 == 0;
+  pl.wm = (wide && waves_env != 22) ? 1 : 2;
+  pl.nf = (wide && pl.wm == 2) ? 2 : 1;
+  a.ntiles = coutp / (32 * pl.nf * (4 / pl.wm));
   a.ncombo = a.ntiles * ngroups;
   a.xcd_remap = (a.ncombo > 1 && a.mtiles >= 64) ? 1 : 0;
   const long ids = a.xcd_remap ? (long)8 * a.ncombo * ceil_div(a.mtiles, 8) : (long)a.mtiles * a.ncombo;
@@ -664,10 +795,12 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
     if (total <= n_cu) a.nbig = 0;
   }
   dim3 grid((unsigned)(a.nbig + 2 * (ids - a.nbig)), 1, 1);
+  if (a.vec_store && pl.lds_bytes < (size_t)4 * kSlabBytes) pl.lds_bytes = (size_t)4 * kSlabBytes;
 #define RTPOSE_CONV_CASE(KS_, CK_, MODE_, NBUF_)                                                  \
   if (d0.k == KS_ && pl.ck == CK_ && pl.mode == MODE_) {                                          \
-    if (pl.nf == 2) return launch_inst<KS_, CK_, MODE_, NBUF_, (KS_ != 1) ? 2 : 1>(a, grid, pl.lds_bytes, s); \
-    return launch_inst<KS_, CK_, MODE_, NBUF_, 1>(a, grid, pl.lds_bytes, s);                       \
+    if (pl.wm == 1) return launch_inst<KS_, CK_, MODE_, NBUF_, (KS_ != 1) ? 1 : 2, 1>(a, grid, pl.lds_bytes, s); \
+    if (pl.nf == 2) return launch_inst<KS_, CK_, MODE_, NBUF_, 2, (KS_ != 1) ? 2 : 1>(a, grid, pl.lds_bytes, s); \
+    return launch_inst<KS_, CK_, MODE_, NBUF_, 2, 1>(a, grid, pl.lds_bytes, s);                    \
   }
   RTPOSE_CONV_CASE(3, 16, 0, 2)
   RTPOSE_CONV_CASE(3, 16, 1, 2)
