@@ -80,10 +80,26 @@ struct ConvArgs {
   int tw_log2;  // MODE 1: log2(tile width); tile height = 128 >> tw_log2
   int tiles_x, tiles_y;
   int mtiles, ntiles, nbig, ncombo, xcd_remap;
+  int dephase_cycles, n_cu;  // second-slot blocks of the first dispatch wave start this much later
+  unsigned long long* dbg;  // RTPOSE_EXP_TIMELINE builds only: 8 x u64 per block
 };
+#ifdef RTPOSE_EXP_TIMELINE
+#define RTPOSE_TSTAMP(slot)                                                              \
+  if (A.dbg && threadIdx.x == 0) A.dbg[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime()
+#else
+#define RTPOSE_TSTAMP(slot)
+#endif
 
 constexpr int kBM = 128;
-constexpr int kHD = 3;  // depth of the halo staging ring (taps between fetch and park)
+#ifndef RTPOSE_EXP_HD
+#define RTPOSE_EXP_HD 3
+#endif
+// depth of the halo staging ring (taps between fetch and park).  The counter behind s_waitcnt
+// is in order, so every wait for a weight piece also waits for all older staging loads: a
+// staging load must be able to take a full HBM/MALL miss (1-3k cycles under load) without
+// being the oldest thing a wave waits for - measured per-CU timelines showed a block that has
+// the CU to itself (its partner in prologue/epilogue, or the tail) at 55 % MFMA rate with 3.
+constexpr int kHD = RTPOSE_EXP_HD;
 // Epilogue slab: each wave transposes its (up to) 64 x 64 bf16 tile through LDS so that a lane
 // stores 16 bytes (8 output channels of one pixel) instead of 64 scattered 2-byte values -
 // measured, the scalar epilogue cost 25-30 % of a 7x7 layer at bf16 MFMA speed.
@@ -115,7 +131,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   // B register ring: the tap being multiplied + RB-1 taps in flight from L2.  Two taps of
   // lead (RB = 3) left the waves waiting on vmcnt once two blocks share a CU; the narrow-N
   // arrangement (NF = 1) has the registers for four.
-  constexpr int RB = (NF == 1 && CK <= 32) ? 5 : 3;
+#ifndef RTPOSE_EXP_RB2
+#define RTPOSE_EXP_RB2 4
+#endif
+  constexpr int RB = (NF == 1 && CK <= 32) ? 5 : (CK <= 32 ? RTPOSE_EXP_RB2 : 3);
   constexpr int TAPS = KS, ROWS = KS;
 
   const int tid = threadIdx.x;
@@ -226,15 +245,18 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
 #pragma unroll
   for (int gi = 0; gi < GB; ++gi) bq[RB - 1][gi] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  // up to kFillDepth pieces per thread in flight: the prologue pays ONE memory round trip for
+  // a 7x7 halo (it was three; measured 13k cycles of prologue on a 96k-cycle main loop)
+  constexpr int kFillDepth = 10;
   auto fill_halo = [&](const float4* src) {
-    for (int set0 = 0; set0 < nsets; set0 += 4) {
-      float4 t[4];
+    for (int set0 = 0; set0 < nsets; set0 += kFillDepth) {
+      float4 t[kFillDepth];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if ((set0 + u) * 256 + tid < np_total) t[u] = gload4(src + piece_goff(set0 + u));
+      for (int u = 0; u < kFillDepth; ++u)
+        if (set0 + u < nsets && (set0 + u) * 256 + tid < np_total) t[u] = gload4(src + piece_goff(set0 + u));
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if ((set0 + u) * 256 + tid < np_total) smem4[piece_loff(set0 + u)] = t[u];
+      for (int u = 0; u < kFillDepth; ++u)
+        if (set0 + u < nsets && (set0 + u) * 256 + tid < np_total) smem4[piece_loff(set0 + u)] = t[u];
     }
   };
 #ifndef RTPOSE_EXP_NO_FILL
@@ -243,7 +265,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     __syncthreads();
   }
 #endif
+  RTPOSE_TSTAMP(1);
 
+  float bias_r[NF];  // fetched now: at the epilogue this load's latency would be fully exposed
+#pragma unroll
+  for (int fn = 0; fn < NF; ++fn) bias_r[fn] = g.bias[ncol + fn * 32];
   floatx16 acc[MF][NF];
 #pragma unroll
   for (int fm = 0; fm < MF; ++fm)
@@ -384,6 +410,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     }
     __syncthreads();
   }
+  RTPOSE_TSTAMP(2);
 #undef RTPOSE_CONV_ROW
 #undef RTPOSE_CONV_STEP
 #undef RTPOSE_PIN
@@ -411,7 +438,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     unsigned short* sl = reinterpret_cast<unsigned short*>(smem) + wave * (kSlabBytes / 2);
 #pragma unroll
     for (int fn = 0; fn < NF; ++fn) {
-      const float bias = g.bias[ncol + fn * 32];
+      const float bias = bias_r[fn];
 #pragma unroll
       for (int fm = 0; fm < MF; ++fm) {
 #pragma unroll
@@ -472,13 +499,19 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
         gstore4(ob + q * g.out_cstride, v);
       }
     }
+    RTPOSE_TSTAMP(3);
+#ifdef RTPOSE_EXP_TIMELINE
+    __builtin_amdgcn_s_waitcnt(0);  // stores retired (vmcnt) - how long does the ack take?
+    RTPOSE_TSTAMP(4);
+    if (A.dbg && threadIdx.x == 0) A.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+#endif
     return;
   }
 #pragma unroll
   for (int fn = 0; fn < NF; ++fn) {
     const int ncolf = ncol + fn * 32;
     const bool col_ok = ncolf < g.cout;
-    const float bias = g.bias[ncolf];  // bias is padded to cout_pad
+    const float bias = bias_r[fn];
     const int och = (g.out_cmap && col_ok) ? g.out_cmap[ncolf] : g.out_choff + ncolf;
     if (!A.pool) {
 #pragma unroll
@@ -549,6 +582,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs A) {
   constexpr int MF = 4 / WM;  // block M tile = 128 pixels either way
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int L = blockIdx.x;
+  RTPOSE_TSTAMP(0);
+  // The two blocks sharing a CU start together and, having equal work, stay in lock step: their
+  // prologues (halo fill) and epilogues coincide and the matrix pipe idles through both (measured:
+  // 13k + 9k cycles on a 96k-cycle main loop).  Blocks [n_cu, 2 n_cu) are the second slot of every
+  // CU in dispatch order; holding them back half a tile keeps the pairs out of phase for the
+  // whole launch, so one block's main loop covers the other's ends.
+  if (A.dephase_cycles > 0 && L >= A.n_cu && L < 2 * A.n_cu) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)A.dephase_cycles) __builtin_amdgcn_s_sleep(32);
+  }
   const bool small = MODE == 0 && L >= A.nbig;
   const int bi = small ? A.nbig + ((L - A.nbig) >> 1) : L;
   int mt, c;
@@ -632,6 +675,14 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* p
   pl->nbuf = d.k == 1 ? 1 : 2;
   const size_t tail = pl->nbuf == 2 ? 256 * 16 : 0;  // dummy park slots
   bool strip = (W <= 64) && !d.pool;
+  {
+    static int force_tile = -1;  // developer A/B: RTPOSE_BF16_FORCE_TILE=k forces 2-D tiles for k x k convs
+    if (force_tile < 0) {
+      const char* e = getenv("RTPOSE_BF16_FORCE_TILE");
+      force_tile = e ? atoi(e) : 0;
+    }
+    if (force_tile == d.k) strip = false;
+  }
   if (strip) {
     const rtpose_layout& l = d.lin;
     const int lb = (kBM - 1) + ((kBM - 1) / W + 1) * (l.ws - W) +
@@ -776,10 +827,11 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
   static int waves_env = 0;
   if (!waves_env) {
     const char* e = getenv("RTPOSE_BF16_WAVES");
-    waves_env = e ? atoi(e) : 14;
+    waves_env = e ? atoi(e) : 14;  // 14: per-kernel-size default, 41: 1 x 4 everywhere, 22: 2 x 2 everywhere
   }
   const bool wide = d0.k != 1 && coutp % 128 == 0;
-  pl.wm = (wide && waves_env != 22) ? 1 : 2;
+  // measured (32 x 368 x 368): 7x7 layers 1237 (1 x 4) vs 1166 (2 x 2) TFLOP/s, 3x3 layers 786 vs 812
+  pl.wm = (wide && (waves_env == 14 ? d0.k == 7 : waves_env != 22)) ? 1 : 2;
   pl.nf = (wide && pl.wm == 2) ? 2 : 1;
   a.ntiles = coutp / (32 * pl.nf * (4 / pl.wm));
   a.ncombo = a.ntiles * ngroups;
@@ -795,6 +847,29 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
     if (total <= n_cu) a.nbig = 0;
   }
   dim3 grid((unsigned)(a.nbig + 2 * (ids - a.nbig)), 1, 1);
+  {
+    static int dephase_env = -1;  // percent of one block's MFMA time; 0 = off
+    if (dephase_env < 0) {
+      const char* e = getenv("RTPOSE_BF16_DEPHASE");
+      dephase_env = e ? atoi(e) : 0;
+    }
+    a.n_cu = n_cu;
+    // one block's matrix time with the SIMD to itself: chunks x taps x MFMAs x 32 cycles
+    const long mfma_cycles = (long)(d0.cin / pl.ck) * d0.k * d0.k * (pl.ck / 16) * 4 * 32;
+    a.dephase_cycles = (pl.nbuf == 2 && (long)grid.x > 2L * n_cu) ? (int)(mfma_cycles * dephase_env / 100) : 0;
+  }
+#ifdef RTPOSE_EXP_TIMELINE
+  {  // developer build: time stamps of the LAST 7x7 launch, dumped by rtpose_debug_timeline_dump
+    extern unsigned long long* g_dbg_buf;
+    extern unsigned g_dbg_blocks;
+    if (!g_dbg_buf) (void)hipMalloc(&g_dbg_buf, (size_t)8192 * 8 * 8);
+    if (d0.k == 7 && grid.x <= 8192) {
+      (void)hipMemsetAsync(g_dbg_buf, 0, (size_t)grid.x * 64, s);
+      a.dbg = g_dbg_buf;
+      g_dbg_blocks = grid.x;
+    }
+  }
+#endif
   if (a.vec_store && pl.lds_bytes < (size_t)4 * kSlabBytes) pl.lds_bytes = (size_t)4 * kSlabBytes;
 #define RTPOSE_CONV_CASE(KS_, CK_, MODE_, NBUF_)                                                  \
   if (d0.k == KS_ && pl.ck == CK_ && pl.mode == MODE_) {                                          \
@@ -819,6 +894,11 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
 #undef RTPOSE_CONV_CASE
   return fail(RTPOSE_E_INVAL, "conv2d_bf16: no kernel instance for k=%d ck=%d mode=%d", d0.k, pl.ck, pl.mode);
 }
+
+#ifdef RTPOSE_EXP_TIMELINE
+unsigned long long* g_dbg_buf = nullptr;
+unsigned g_dbg_blocks = 0;
+#endif
 
 int pack_weights_bf16_launch(const float* w, const float* bias, int cout, int cin_src, int k,
                              const int32_t* cin_map, int cin_packed, void* wp, float* bp, hipStream_t s) {
@@ -859,3 +939,14 @@ int rtpose_conv2d_bf16(const rtpose_conv_desc* d, int ngroups, int N, int H, int
 }
 
 }  // extern "C"
+
+#ifdef RTPOSE_EXP_TIMELINE
+extern "C" int rtpose_debug_timeline_dump(unsigned long long* host, unsigned cap_blocks) {
+  using namespace rtpose;
+  if (!g_dbg_buf) return 0;
+  (void)hipDeviceSynchronize();
+  const unsigned n = g_dbg_blocks < cap_blocks ? g_dbg_blocks : cap_blocks;
+  (void)hipMemcpy(host, g_dbg_buf, (size_t)n * 64, hipMemcpyDeviceToHost);
+  return (int)n;
+}
+#endif

@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+python -m pytest tests/test_bf16_gpu.py -x -q 2>&1 | tail -3
+for d in 0 30 50 70 100; do
+  echo "=== RTPOSE_BF16_DEPHASE=$d"
+  RTPOSE_BF16_DEPHASE=$d python tools/profile_layers.py 32 368 368 3 bf16 2>&1 | grep -E "model0.2 |model0.21 |model2_1.2\+|sum of|^k=[37]"
+done

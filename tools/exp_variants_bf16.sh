@@ -18,6 +18,9 @@ for v in "$@"; do
     bnoa) build bnoa -DRTPOSE_EXP_NO_A & ;;
     bnostage) build bnostage -DRTPOSE_EXP_NO_STAGE & ;;
     bnoab) build bnoab -DRTPOSE_EXP_NO_A -DRTPOSE_EXP_NO_B & ;;
+    bhd3) build bhd3 -DRTPOSE_EXP_HD=3 & ;;
+    bhd9) build bhd9 -DRTPOSE_EXP_HD=9 & ;;
+    btime) build btime -DRTPOSE_EXP_TIMELINE & ;;
     bnofill) build bnofill -DRTPOSE_EXP_NO_FILL & ;;
     bnostore) build bnostore -DRTPOSE_EXP_NO_STORE & ;;
     bnone) build bnone -DRTPOSE_EXP_NO_A -DRTPOSE_EXP_NO_B -DRTPOSE_EXP_NO_STAGE -DRTPOSE_EXP_NO_FILL -DRTPOSE_EXP_NO_STORE & ;;
