@@ -256,3 +256,32 @@ def test_keypoints_agree_bf16_vs_fp32(pkg, model_and_sd, cuda):
                     same += 1
     assert tot > 0
     assert same / tot >= 0.98, "only %d of %d keypoints agree within 1 px" % (same, tot)
+
+
+def test_bf16_full_size_properties_batch32(model_and_sd, cuda):
+    """The bf16 plan at BASELINE size (32 x 3 x 368 x 368): batch-position independence and
+    determinism bit for bit; one image against the emulation oracle at full size."""
+    from oracle import net_oracle
+    m, sd = model_and_sd
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(32, 3, 368, 368, generator=g) - 0.5
+    perm = torch.randperm(32, generator=g)
+    keep = m.keep_intermediates
+    m.keep_intermediates = False
+    m.set_compute_dtype('bf16')
+    try:
+        with torch.no_grad():
+            (paf, heat), _ = m(x.to(cuda))
+            (paf2, heat2), _ = m(x.to(cuda))
+            (paf_p, heat_p), _ = m(x[perm].to(cuda))
+            (paf_1, heat_1), _ = m(x[7:8].to(cuda))
+    finally:
+        m.set_compute_dtype('fp32')
+        m.keep_intermediates = keep
+    assert torch.equal(paf, paf2) and torch.equal(heat, heat2)
+    assert torch.equal(paf_p, paf[perm.to(cuda)]) and torch.equal(heat_p, heat[perm.to(cuda)])
+    assert torch.equal(paf_1[0], paf[7]) and torch.equal(heat_1[0], heat[7])
+    (paf_e, heat_e), _ = net_oracle.forward_bf16_emulated(sd, x[7:8])
+    for a, b in ((paf[7].cpu(), paf_e[0]), (heat[7].cpu(), heat_e[0])):
+        scale = max(1.0, b.abs().max().item())
+        assert (a - b).abs().max().item() <= 2e-2 * scale

@@ -71,3 +71,34 @@ def test_state_dict_roundtrip_repacks(model_and_sd, cuda):
         (p2, _), _ = m(x)
     assert not torch.allclose(p0, p1)
     assert torch.equal(p0, p2)
+
+
+def test_full_size_properties_batch32(model_and_sd, cuda):
+    """BASELINE.json configs[1] at full size (32 x 3 x 368 x 368), through size-independent
+    properties: (a) image i's maps do not depend on its position / neighbours in the batch
+    (bit-exact under a permutation of the batch: strips of the flattened pixel space span image
+    boundaries, the shared-gap layout must not leak between images), (b) the run is
+    deterministic, (c) one image of the batch equals the same image run alone, and equals the
+    oracle at full size within the 1e-3 contract."""
+    from oracle import net_oracle
+    m, sd = model_and_sd
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(32, 3, 368, 368, generator=g) - 0.5
+    perm = torch.randperm(32, generator=g)
+    keep = m.keep_intermediates
+    m.keep_intermediates = False
+    try:
+        with torch.no_grad():
+            (paf, heat), _ = m(x.to(cuda))
+            (paf2, heat2), _ = m(x.to(cuda))
+            (paf_p, heat_p), _ = m(x[perm].to(cuda))
+            (paf_1, heat_1), _ = m(x[5:6].to(cuda))
+    finally:
+        m.keep_intermediates = keep
+    assert paf.shape == (32, 38, 46, 46) and heat.shape == (32, 19, 46, 46)
+    assert torch.equal(paf, paf2) and torch.equal(heat, heat2)
+    assert torch.equal(paf_p, paf[perm.to(cuda)]) and torch.equal(heat_p, heat[perm.to(cuda)])
+    assert torch.equal(paf_1[0], paf[5]) and torch.equal(heat_1[0], heat[5])
+    (paf_r, heat_r), _ = net_oracle.forward(sd, x[5:6])
+    assert (paf[5].cpu() - paf_r[0]).abs().max().item() <= ABS_TOL
+    assert (heat[5].cpu() - heat_r[0]).abs().max().item() <= ABS_TOL
