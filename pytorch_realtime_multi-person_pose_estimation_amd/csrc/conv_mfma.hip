@@ -72,6 +72,11 @@ struct ConvArgs {
 };
 
 constexpr int kBM = 128;
+// 1x1 convs: CK-channel sub-chunks per LDS buffer (see conv_tile); developer knob
+#ifndef RTPOSE_EXP_TB1X1
+#define RTPOSE_EXP_TB1X1 1
+#endif
+constexpr int kTB1x1 = RTPOSE_EXP_TB1X1;
 
 template <int KS>
 struct PiecesPerTap {
@@ -116,7 +121,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   // are short (K = 24..512), so per-block prologue/epilogue latency dominates and is hidden
   // better by occupancy than by in-block pipelining.  TB stays a knob for a future
   // multi-tile (persistent) 1x1 kernel.
-  constexpr int TB = 1;
+  constexpr int TB = (KS == 1) ? kTB1x1 : 1;
   constexpr int CGB = CG * TB;              // channel-group planes per LDS buffer
   constexpr int TAPS = (KS == 1) ? TB : KS; // taps per "row" of the tap loop
   constexpr int ROWS = (KS == 1) ? 1 : KS;
@@ -238,14 +243,15 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   // ---- halo fill used by the prologue (NBUF 2) / before every chunk (NBUF 1) ------
   auto fill_halo = [&](const float* src, int ntaps) {  // ntaps: sub-chunks that exist in this buffer
     const bool ch_ok = pj < ntaps * CG;
-    for (int set0 = 0; set0 < nsets; set0 += 4) {
-      float4 t[4];
+    constexpr int FD = (KS == 1 && kTB1x1 > 1) ? 8 : 4;  // loads in flight per thread
+    for (int set0 = 0; set0 < nsets; set0 += FD) {
+      float4 t[FD];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)  // 4 loads in flight per thread
-        if (ch_ok && (set0 + u) * 256 + tid < np_total) t[u] = gload4(src + piece_goff(set0 + u));
+      for (int u = 0; u < FD; ++u)
+        if (ch_ok && set0 + u < nsets && (set0 + u) * 256 + tid < np_total) t[u] = gload4(src + piece_goff(set0 + u));
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (ch_ok && (set0 + u) * 256 + tid < np_total) smem4[piece_loff(set0 + u)] = t[u];
+      for (int u = 0; u < FD; ++u)
+        if (ch_ok && set0 + u < nsets && (set0 + u) * 256 + tid < np_total) smem4[piece_loff(set0 + u)] = t[u];
     }
   };
   const int nbig = (nchunks + TB - 1) / TB;  // LDS buffer fills per block
@@ -620,7 +626,7 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* p
   const int M = N * H * W;
   // piece sets per thread that fit the staging schedule (set s fetched at tap s, parked at s+1)
   const int max_pieces = (d.k == 1) ? PiecesPerTap<1>::value : d.k * d.k - 1;
-  const int cg = pl->ck / 4;  // channel-group planes per LDS buffer (x TB for 1x1, TB = 1 today)
+  const int cg = (pl->ck / 4) * (d.k == 1 ? kTB1x1 : 1);  // channel-group planes per LDS buffer
   if (!g_force_nbuf) {
     const char* e = getenv("RTPOSE_CONV_NBUF");
     g_force_nbuf = e ? atoi(e) : -1;

@@ -176,24 +176,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   }
   const int np_total = np_pix * CG;  // 16-byte pieces per LDS buffer
 
-  // ---- per-lane A fragment bases (LDS pixel index of this lane's row) ----------------
-  int abase[MF];
-#pragma unroll
-  for (int fm = 0; fm < MF; ++fm) {
-    const int ml = wm * (32 * MF) + fm * 32 + l31;
-    if (MODE == 0) {
-      const int m = min(m0 + ml, A.M - 1);
-      const int HW = A.H * A.W;
-      const int n = m / HW, r = m - n * HW;
-      const int y = r / A.W, x = r - y * A.W;
-      abase[fm] = g.in_lead + (n * g.in_hs + y) * g.in_ws + x - qc0;
-    } else {
-      int ty, tx;
-      tile_local_yx(ml, A.tw_log2, ty, tx);
-      abase[fm] = ty * A.hw_lds + tx;
-    }
-  }
-
   // ---- halo staging helpers: piece idx = (pixel idx / CG, piece idx % CG) ------------
   const int in_cs4 = g.in_cstride >> 3, in_ws = g.in_ws;  // 16-byte pieces per pixel
   const float4* in_base = reinterpret_cast<const float4*>(g.in + g.in_choff);
@@ -216,7 +198,54 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   const int buf4 = CG * QS;
   auto piece_loff = [&](int set) -> int { return pj * QS + set * PIXSET + ppix0; };
   const int dummy_loff = NBUF * buf4 + tid;
+
+  // ---- prologue: the first halo's loads go out before anything that does not feed their
+  //      addresses (measured: the fill is ~11k cycles of pure memory latency per block)
+  constexpr int kFillDepth = 10;
   const int nsets = (np_total + 255) / 256;
+  float4 pf[kFillDepth];
+  const bool pro_fast = NBUF == 2 && nsets <= kFillDepth;
+#ifndef RTPOSE_EXP_NO_FILL
+  if (pro_fast) {
+#pragma unroll
+    for (int u = 0; u < kFillDepth; ++u)
+      if (u < nsets && u * 256 + tid < np_total) pf[u] = gload4(in_base + piece_goff(u));
+  }
+#endif
+
+  // ---- per-lane A fragment bases (LDS pixel index of this lane's row) ----------------
+  int abase[MF];
+  int an = 0, ay = 0, ax = 0;  // strip mode: coordinates of fragment 0's row, stepped by 32 pixels
+  if (MODE == 0) {
+    const int m = m0 + wm * (32 * MF) + l31;
+    const int HW = A.H * A.W;
+    an = m / HW;
+    const int r = m - an * HW;
+    ay = r / A.W;
+    ax = r - ay * A.W;
+  }
+#pragma unroll
+  for (int fm = 0; fm < MF; ++fm) {
+    const int ml = wm * (32 * MF) + fm * 32 + l31;
+    if (MODE == 0) {
+      // rows past the end of the tensor (last strip) read the last real pixel's halo
+      const bool past = m0 + ml > A.M - 1;
+      const int n = past ? A.N - 1 : an, y = past ? A.H - 1 : ay, x = past ? A.W - 1 : ax;
+      abase[fm] = g.in_lead + (n * g.in_hs + y) * g.in_ws + x - qc0;
+      ax += 32;
+      while (ax >= A.W) {
+        ax -= A.W;
+        if (++ay >= A.H) {
+          ay = 0;
+          ++an;
+        }
+      }
+    } else {
+      int ty, tx;
+      tile_local_yx(ml, A.tw_log2, ty, tx);
+      abase[fm] = ty * A.hw_lds + tx;
+    }
+  }
 
   // ---- B operand: buffer loads = SGPR resource + SGPR tap/k-step offset + per-lane VGPR
   //      offset, so the tap loop spends no VALU and no address registers on them; reads past
@@ -245,9 +274,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
 #pragma unroll
   for (int gi = 0; gi < GB; ++gi) bq[RB - 1][gi] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // up to kFillDepth pieces per thread in flight: the prologue pays ONE memory round trip for
-  // a 7x7 halo (it was three; measured 13k cycles of prologue on a 96k-cycle main loop)
-  constexpr int kFillDepth = 10;
+  // up to kFillDepth pieces per thread in flight: ONE memory round trip for a 7x7 halo
   auto fill_halo = [&](const float4* src) {
     for (int set0 = 0; set0 < nsets; set0 += kFillDepth) {
       float4 t[kFillDepth];
@@ -259,9 +286,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
         if (set0 + u < nsets && (set0 + u) * 256 + tid < np_total) smem4[piece_loff(set0 + u)] = t[u];
     }
   };
+  RTPOSE_TSTAMP(6);
 #ifndef RTPOSE_EXP_NO_FILL
   if (NBUF == 2) {
-    fill_halo(in_base);
+    if (pro_fast) {
+#pragma unroll
+      for (int u = 0; u < kFillDepth; ++u)
+        if (u < nsets && u * 256 + tid < np_total) smem4[piece_loff(u)] = pf[u];
+    } else {
+      fill_halo(in_base);
+    }
+    RTPOSE_TSTAMP(7);
     __syncthreads();
   }
 #endif
@@ -276,7 +311,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
 #pragma unroll
     for (int fn = 0; fn < NF; ++fn)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[fm][fn][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[fm][fn][r] = bias_r[fn];  // bias rides in the accumulator
 
   int afrag[G][MF];
 #pragma unroll
@@ -432,32 +467,33 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
 #endif
   unsigned short* out_h = reinterpret_cast<unsigned short*>(g.out);
   float* out_f = reinterpret_cast<float*>(g.out);
+  const float relu_lo = A.relu ? 0.f : -3.0e38f;  // uniform: v = max(v, relu_lo), no select
   if (A.vec_store) {  // uniform
     // (the chunk loop ended with a barrier: the halo buffers are dead)
     constexpr int PITCH2 = (NF * 64 + 16) / 2;  // slab row pitch in bf16 elements
     unsigned short* sl = reinterpret_cast<unsigned short*>(smem) + wave * (kSlabBytes / 2);
+    if (!A.pool) {
 #pragma unroll
-    for (int fn = 0; fn < NF; ++fn) {
-      const float bias = bias_r[fn];
+      for (int fn = 0; fn < NF; ++fn)
 #pragma unroll
-      for (int fm = 0; fm < MF; ++fm) {
+        for (int fm = 0; fm < MF; ++fm)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          if (!A.pool) {
+          for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              float v = acc[fm][fn][rg * 4 + rr] + bias;
-              if (A.relu) v = fmaxf(v, 0.f);
-              sl[(fm * 32 + rg * 8 + 4 * kh + rr) * PITCH2 + fn * 32 + l31] = to_bf16(v);
-            }
-          } else {
-            float v = fmaxf(fmaxf(acc[fm][fn][rg * 4 + 0], acc[fm][fn][rg * 4 + 1]),
-                            fmaxf(acc[fm][fn][rg * 4 + 2], acc[fm][fn][rg * 4 + 3])) + bias;
-            if (A.relu) v = fmaxf(v, 0.f);
-            sl[(fm * 8 + rg * 2 + kh) * PITCH2 + fn * 32 + l31] = to_bf16(v);
+            for (int rr = 0; rr < 4; ++rr)
+              sl[(fm * 32 + rg * 8 + 4 * kh + rr) * PITCH2 + fn * 32 + l31] =
+                  to_bf16(fmaxf(acc[fm][fn][rg * 4 + rr], relu_lo));
+    } else {
+#pragma unroll
+      for (int fn = 0; fn < NF; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < MF; ++fm)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const float v = fmaxf(fmaxf(acc[fm][fn][rg * 4 + 0], acc[fm][fn][rg * 4 + 1]),
+                                  fmaxf(acc[fm][fn][rg * 4 + 2], acc[fm][fn][rg * 4 + 3]));
+            sl[(fm * 8 + rg * 2 + kh) * PITCH2 + fn * 32 + l31] = to_bf16(fmaxf(v, relu_lo));
           }
-        }
-      }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // same-wave LDS traffic is in order
     constexpr int LPR = NF * 4;     // lanes (16 bytes each) per slab row
@@ -466,6 +502,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     const int lrow = lane / LPR, c16 = lane % LPR;
     unsigned short* ob = out_h + g.out_choff + ntile * BN + wn * (32 * NF) + c16 * 8;
     const int Ho = A.H >> 1, Wo = A.W >> 1;
+    // strip mode: (n, y, x) of this lane's first row by division once, then stepped by RPI pixels
+    // (integer division is ~40 VALU instructions; 8 row steps of it were a third of the epilogue)
+    int sn = 0, sy = 0, sx = 0;
+    if (MODE == 0) {
+      const int m = m0 + wm * (32 * MF) + lrow;
+      const int HW = A.H * A.W;
+      sn = m / HW;
+      const int r = m - sn * HW;
+      sy = r / A.W;
+      sx = r - sy * A.W;
+    }
     for (int it = 0; it * RPI < rows; ++it) {
       const int row = it * RPI + lrow;
       const float4 v = *reinterpret_cast<const float4*>(sl + row * PITCH2 + c16 * 8);
@@ -479,13 +526,18 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
         x = (x0 >> 1) + (qi & ((1 << hw_log2) - 1));
         ok = y < Ho && x < Wo;
       } else if (MODE == 0) {
-        const int m = m0 + wm * (32 * MF) + row;
-        ok = m < A.M;
-        const int HW = A.H * A.W;
-        n = m / HW;
-        const int r = m - n * HW;
-        y = r / A.W;
-        x = r - y * A.W;
+        ok = m0 + wm * (32 * MF) + row < A.M;
+        n = sn;
+        y = sy;
+        x = sx;
+        sx += RPI;  // next iteration's row
+        while (sx >= A.W) {
+          sx -= A.W;
+          if (++sy >= A.H) {
+            sy = 0;
+            ++sn;
+          }
+        }
       } else {
         int ty, tx;
         tile_local_yx(wm * (32 * MF) + row, A.tw_log2, ty, tx);
@@ -511,7 +563,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   for (int fn = 0; fn < NF; ++fn) {
     const int ncolf = ncol + fn * 32;
     const bool col_ok = ncolf < g.cout;
-    const float bias = bias_r[fn];
     const int och = (g.out_cmap && col_ok) ? g.out_cmap[ncolf] : g.out_choff + ncolf;
     if (!A.pool) {
 #pragma unroll
@@ -540,8 +591,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
               x = x0 + tx;
               ok = (y < A.H) && (x < A.W);
             }
-            float v = acc[fm][fn][rg * 4 + rr] + bias;
-            if (A.relu) v = fmaxf(v, 0.f);
+            const float v = fmaxf(acc[fm][fn][rg * 4 + rr], relu_lo);
             if (ok && col_ok) {
               const size_t q = (size_t)g.out_lead + (size_t)(n * g.out_hs + y) * g.out_ws + x;
               if (A.out_f32) out_f[q * g.out_cstride + och] = v;
@@ -561,9 +611,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
           const int qi = ml0 >> 2;
           const int py = (y0 >> 1) + (qi >> hw_log2);
           const int px = (x0 >> 1) + (qi & ((1 << hw_log2) - 1));
-          float v = fmaxf(fmaxf(acc[fm][fn][rg * 4 + 0], acc[fm][fn][rg * 4 + 1]),
-                          fmaxf(acc[fm][fn][rg * 4 + 2], acc[fm][fn][rg * 4 + 3])) + bias;
-          if (A.relu) v = fmaxf(v, 0.f);
+          const float v = fmaxf(fmaxf(fmaxf(acc[fm][fn][rg * 4 + 0], acc[fm][fn][rg * 4 + 1]),
+                                      fmaxf(acc[fm][fn][rg * 4 + 2], acc[fm][fn][rg * 4 + 3])), relu_lo);
           if (py < Ho && px < Wo && col_ok) {
             const size_t q = (size_t)g.out_lead + (size_t)(n_img * g.out_hs + py) * g.out_ws + px;
             if (A.out_f32) out_f[q * g.out_cstride + och] = v;

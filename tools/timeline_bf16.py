@@ -32,7 +32,9 @@ def main(n=32, hw=368):
     start, pro, loop, epi, ack = (t[:, 0] - t0, t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4] - t[:, 3])
     hw_id = t[:, 5]
     print("blocks", nb, "span (ticks)", (t[:, 4].max() - t0))
-    for name, v in (("prologue", pro), ("main loop", loop), ("epilogue", epi), ("store ack", ack)):
+    setup, fill, bar = t[:, 6] - t[:, 0], t[:, 7] - t[:, 6], t[:, 1] - t[:, 7]
+    for name, v in (("pro:setup", setup), ("pro:fill", fill), ("pro:barrier", bar), ("prologue", pro), ("main loop", loop),
+                    ("epilogue", epi), ("store ack", ack)):
         v = v[t[:, 4] > 0]
         print("%-10s mean %8.0f  p10 %8.0f  p50 %8.0f  p90 %8.0f  max %8.0f" % (
             name, v.mean(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), v.max()))
