@@ -144,6 +144,30 @@ int rtpose_layout_bf16_to_f32(const void* src, const rtpose_layout* lsrc, float*
                               const rtpose_layout* ldst, int C, int N, int H, int W,
                               void* stream);
 
+/* ---- bf16x3 variant: fp32-grade results from the bf16 matrix pipe ---------------------
+ * Every fp32 operand v travels as two bf16s, hi = bf16(v) and lo = bf16(v - hi) (16 significant
+ * bits), and a product is accumulated as hi*lo + lo*hi + hi*hi in fp32 (the lo*lo term, 2^-18
+ * relative, is dropped): 3 MFMAs of the 16x faster bf16 pipe instead of fp32 MFMAs.  Activations
+ * are stored per 8 channels as [hi x 8 | lo x 8] (32 B: the fp32 footprint); layouts of such
+ * buffers count ELEMENTS (2 per channel, slices on 8-channel boundaries), `cin`/`cout` still
+ * count channels.  Contract: oracle/net_oracle.py:forward_bf16x3_emulated; measured against the
+ * fp32 oracle it stays inside the 1e-3 bound of the fp32 path (tests/test_bf16x3_gpu.py). */
+size_t rtpose_packed_weight_bytes_bf16x3(int cout, int cin, int k);
+int rtpose_pack_conv_weights_bf16x3(const float* w_oihw, const float* bias, int cout,
+                                    int cin_src, int k, const int32_t* cin_map,
+                                    int cin_packed, void* w_packed, float* bias_packed,
+                                    void* stream);
+int rtpose_conv2d_bf16x3(const rtpose_conv_desc* d, int ngroups, int N, int H, int W,
+                         int out_f32, void* stream);
+int rtpose_nchw_to_layout_split(const float* src_nchw, void* dst, const rtpose_layout* ldst,
+                                int C, int cpad, int N, int H, int W, void* stream);
+int rtpose_layout_f32_to_split(const float* src, const rtpose_layout* lsrc, void* dst,
+                               const rtpose_layout* ldst, int C, int cpad, int N, int H,
+                               int W, void* stream);
+int rtpose_layout_split_to_f32(const void* src, const rtpose_layout* lsrc, float* dst,
+                               const rtpose_layout* ldst, int C, int N, int H, int W,
+                               void* stream);
+
 /* MaxPool2d(kernel 2, stride 2, pad 0) between two layouts
  * (rtpose_vgg.py:49-50; floor semantics of nn.MaxPool2d). */
 int rtpose_maxpool2x2(const float* in, const rtpose_layout* lin, float* out,
@@ -217,6 +241,7 @@ int rtpose_net_create(int N, int H, int W, rtpose_net** out);
  * heat-map stay fp32 at the API.  Weight arenas of the two dtypes are NOT interchangeable. */
 #define RTPOSE_DTYPE_F32 0
 #define RTPOSE_DTYPE_BF16 1
+#define RTPOSE_DTYPE_BF16X3 2 /* split bf16 operands, 3 MFMAs per product: fp32-grade results */
 int rtpose_net_create_ex(int N, int H, int W, int dtype, rtpose_net** out);
 int rtpose_net_dtype(const rtpose_net* net);
 void rtpose_net_destroy(rtpose_net* net);

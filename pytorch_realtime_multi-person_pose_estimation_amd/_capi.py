@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("RTPOSE_LIB_PATH") or os.path.join(_HERE, "lib", "libr
 
 NUM_PART = 18
 NUM_LIMB = 19
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_BF16X3 = 0, 1, 2
 
 
 class RtposeError(RuntimeError):
@@ -90,6 +90,12 @@ _SIGS = {
     "rtpose_nchw_to_layout_bf16": (_i, [_vp, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
     "rtpose_layout_f32_to_bf16": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
     "rtpose_layout_bf16_to_f32": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, _i, _vp]),
+    "rtpose_packed_weight_bytes_bf16x3": (_sz, [_i, _i, _i]),
+    "rtpose_pack_conv_weights_bf16x3": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "rtpose_conv2d_bf16x3": (_i, [C.POINTER(ConvDesc), _i, _i, _i, _i, _i, _vp]),
+    "rtpose_nchw_to_layout_split": (_i, [_vp, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
+    "rtpose_layout_f32_to_split": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
+    "rtpose_layout_split_to_f32": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, _i, _vp]),
     "rtpose_net_destroy": (None, [_vp]),
     "rtpose_net_workspace_bytes": (_sz, [_vp]),
     "rtpose_net_weight_bytes": (_sz, [_vp]),

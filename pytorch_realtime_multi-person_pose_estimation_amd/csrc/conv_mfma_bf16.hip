@@ -103,7 +103,7 @@ constexpr int kHD = RTPOSE_EXP_HD;
 // Epilogue slab: each wave transposes its (up to) 64 x 64 bf16 tile through LDS so that a lane
 // stores 16 bytes (8 output channels of one pixel) instead of 64 scattered 2-byte values -
 // measured, the scalar epilogue cost 25-30 % of a 7x7 layer at bf16 MFMA speed.
-constexpr int kSlabBytes = 128 * 80;  // per wave: max over (rows 32*MF) x (pitch 64*NF + 16)
+constexpr int slab_bytes(int mf, int nf, int sp) { return 32 * mf * (nf * 64 * sp + 16); }  // per wave
 
 __device__ __forceinline__ void tile_local_yx(int ml, int tw_log2, int& ty, int& tx) {
   const int qi = ml >> 2;
@@ -119,15 +119,20 @@ __device__ __forceinline__ void tile_local_yx(int ml, int tw_log2, int& ty, int&
 // in two arrangements: 2 x 2 waves of 64 x 64 (MF = NF = 2) and 1 x 4 waves of 128 x 32
 // (MF = 4, NF = 1).  The second halves the B (weight) bytes a CU pulls through its L1 per MFMA
 // - every wave reads all A fragments from LDS instead, which has 4x the L1's bandwidth.
-template <int KS, int CK, int MODE, int NBUF, int WM, int MF, int NF>
+// SP = 2: "split" operands (compute dtype bf16x3).  Every fp32 value v travels as two bf16s,
+// hi = bf16(v) and lo = bf16(v - hi) (16 significant bits), stored as interleaved 16-byte pieces
+// [hi x 8 channels | lo x 8 channels]; a K-step issues hi*lo + lo*hi + hi*hi (the lo*lo term,
+// 2^-18 relative, is dropped) - fp32-grade results from the bf16 pipe at 3/16 of the fp32
+// MFMA time.
+template <int KS, int CK, int MODE, int NBUF, int WM, int MF, int NF, int SP>
 __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g, const int m0_arg,
                                           const int ntile, float* smem) {
   constexpr int P = KS / 2;
   constexpr int BMT = 32 * MF * WM;
   constexpr int BN = 32 * NF * (4 / WM);  // output channels per block
-  constexpr int CG = CK / 8;   // 16-byte pieces (8 channels) per pixel per chunk
+  constexpr int CG = CK / 8 * SP;  // 16-byte pieces (8 channels; hi and lo when split) per pixel per chunk
   constexpr int G = CK / 16;   // K=16 MFMA steps per tap
-  constexpr int GB = G * NF;   // B registers (float4) per tap: [n-fragment][k-step]
+  constexpr int GB = G * NF;   // B fragments per tap: [n-fragment][k-step] (x SP registers)
   // B register ring: the tap being multiplied + RB-1 taps in flight from L2.  Two taps of
   // lead (RB = 3) left the waves waiting on vmcnt once two blocks share a CU; the narrow-N
   // arrangement (NF = 1) has the registers for four.
@@ -252,27 +257,33 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   //      the packed filter (the prefetch runs RB-1 taps ahead) return zero by the bounds check
   const int nchunks = A.cin / CK;
   const int ncol = ntile * BN + wn * (32 * NF) + l31;
-  const unsigned lane_b = (unsigned)(kh * g.cout_pad + ncol) * 16u;
-  const unsigned b_it_bytes = (unsigned)(CG * g.cout_pad) * 16u;  // bytes per (chunk, tap)
-  const unsigned b_k_bytes = (unsigned)(2 * g.cout_pad) * 16u;    // bytes per k-step
+  // piece plane of (k-step gi, lane half kh, hi/lo s) = (2 gi + kh) * SP + s
+  const unsigned lane_b = (unsigned)(kh * SP * g.cout_pad + ncol) * 16u;
+  const unsigned b_it_bytes = (unsigned)(CG * g.cout_pad) * 16u;       // bytes per (chunk, tap)
+  const unsigned b_k_bytes = (unsigned)(2 * SP * g.cout_pad) * 16u;    // bytes per k-step
+  const unsigned b_s_bytes = (unsigned)g.cout_pad * 16u;               // hi -> lo plane
   const unsigned w_bytes = (unsigned)nchunks * (KS * KS) * b_it_bytes;
   const __amdgpu_buffer_rsrc_t wrs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(g.w), 0, (int)w_bytes, 0x00020000);
   unsigned wso = 0;  // uniform: byte offset of the tap being fetched
-#define RTPOSE_BLOAD(fn_, gi_) \
-  bload4(wrs, lane_b + (fn_) * 512u, wso + (unsigned)(gi_) * b_k_bytes)
+#define RTPOSE_BLOAD(fn_, gi_, s_) \
+  bload4(wrs, lane_b + (fn_) * 512u, wso + (unsigned)(gi_) * b_k_bytes + (unsigned)(s_) * b_s_bytes)
 
-  float4 bq[RB][GB];
+  float4 bq[RB][GB][SP];
 #pragma unroll
   for (int t = 0; t + 1 < RB; ++t) {
 #pragma unroll
     for (int fn = 0; fn < NF; ++fn)
 #pragma unroll
-      for (int gi = 0; gi < G; ++gi) bq[t][fn * G + gi] = RTPOSE_BLOAD(fn, gi);
+      for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+        for (int sp = 0; sp < SP; ++sp) bq[t][fn * G + gi][sp] = RTPOSE_BLOAD(fn, gi, sp);
     wso += b_it_bytes;
   }
 #pragma unroll
-  for (int gi = 0; gi < GB; ++gi) bq[RB - 1][gi] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int gi = 0; gi < GB; ++gi)
+#pragma unroll
+    for (int sp = 0; sp < SP; ++sp) bq[RB - 1][gi][sp] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // up to kFillDepth pieces per thread in flight: ONE memory round trip for a 7x7 halo
   auto fill_halo = [&](const float4* src) {
@@ -317,7 +328,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
 #pragma unroll
   for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-    for (int fm = 0; fm < MF; ++fm) afrag[gi][fm] = (2 * gi + kh) * QS + abase[fm];
+    for (int fm = 0; fm < MF; ++fm) afrag[gi][fm] = (2 * gi + kh) * SP * QS + abase[fm];  // hi plane; lo = + QS
   const int rowstep = row_lds;
 
 // developer ablations (tools/exp_variants_bf16.sh): drop one load stream at a time
@@ -347,13 +358,20 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     _Pragma("unroll") for (int n = 0; n < G; ++n) {                                            \
       _Pragma("unroll") for (int fn = 0; fn < NF; ++fn) {                                      \
         _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) {                                    \
-          acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(ACUR[n][fm]),           \
-                                                                as_bf8(BCUR[fn * G + n]),      \
-                                                                acc[fm][fn], 0, 0, 0);         \
+          if (SP == 2) { /* small terms first: hi*lo, lo*hi, then hi*hi */                     \
+            acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                             \
+                as_bf8(ACUR[n][fm][0]), as_bf8(BCUR[fn * G + n][SP - 1]), acc[fm][fn], 0, 0, 0); \
+            acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                             \
+                as_bf8(ACUR[n][fm][SP - 1]), as_bf8(BCUR[fn * G + n][0]), acc[fm][fn], 0, 0, 0); \
+          }                                                                                    \
+          acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                               \
+              as_bf8(ACUR[n][fm][0]), as_bf8(BCUR[fn * G + n][0]), acc[fm][fn], 0, 0, 0);      \
         }                                                                                      \
       }                                                                                        \
       RTPOSE_PIN();                                                                            \
-      _Pragma("unroll") for (int fn = 0; fn < NF; ++fn) BLOAD[fn * G + n] = RTPOSE_EXP_B(RTPOSE_BLOAD(fn, n), BCUR[fn * G + n]); \
+      _Pragma("unroll") for (int fn = 0; fn < NF; ++fn)                                        \
+        _Pragma("unroll") for (int sp = 0; sp < SP; ++sp)                                      \
+          BLOAD[fn * G + n][sp] = RTPOSE_EXP_B(RTPOSE_BLOAD(fn, n, sp), BCUR[fn * G + n][sp]); \
       if (n == G - 1) wso += b_it_bytes;                                                       \
       if (KS > 1) {                                                                            \
         if (n == 0 && (KX) == KS - 1) { /* next tap starts the next stencil row */             \
@@ -361,7 +379,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
             _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) arow[g2][fm] += rowstep;         \
         }                                                                                      \
         _Pragma("unroll") for (int fm = 0; fm < MF; ++fm)                                      \
-          ANXT[n][fm] = RTPOSE_EXP_A(smem4[arow[n][fm] + (((KX) + 1 < KS) ? (KX) + 1 : 0)], ACUR[n][fm]); \
+          _Pragma("unroll") for (int sp = 0; sp < SP; ++sp)                                    \
+            ANXT[n][fm][sp] = RTPOSE_EXP_A(smem4[arow[n][fm] + sp * QS + (((KX) + 1 < KS) ? (KX) + 1 : 0)], \
+                                           ACUR[n][fm][sp]);                                   \
       }                                                                                        \
       if (((STAGE) & RTPOSE_EXP_STAGE) != 0 && n == G - 1) {                                   \
         smem4[hl[0]] = hv[0];                                                                  \
@@ -391,14 +411,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     /* re-normalise the register roles for the next row (a few v_mov per row) */            \
     if (KS > 1 && (TAPS & 1)) {                                                             \
       _Pragma("unroll") for (int gi = 0; gi < G; ++gi)                                      \
-        _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) av[0][gi][fm] = av[1][gi][fm];    \
+        _Pragma("unroll") for (int fm = 0; fm < MF; ++fm)                                   \
+          _Pragma("unroll") for (int sp = 0; sp < SP; ++sp) av[0][gi][fm][sp] = av[1][gi][fm][sp]; \
     }                                                                                       \
     if (TAPS % RB != 0) {                                                                   \
-      float4 t_[RB][GB];                                                                    \
+      float4 t_[RB][GB][SP];                                                                \
       _Pragma("unroll") for (int r = 0; r < RB; ++r)                                        \
-        _Pragma("unroll") for (int gi = 0; gi < GB; ++gi) t_[r][gi] = bq[(r + TAPS) % RB][gi]; \
+        _Pragma("unroll") for (int gi = 0; gi < GB; ++gi)                                   \
+          _Pragma("unroll") for (int sp = 0; sp < SP; ++sp) t_[r][gi][sp] = bq[(r + TAPS) % RB][gi][sp]; \
       _Pragma("unroll") for (int r = 0; r < RB; ++r)                                        \
-        _Pragma("unroll") for (int gi = 0; gi < GB; ++gi) bq[r][gi] = t_[r][gi];            \
+        _Pragma("unroll") for (int gi = 0; gi < GB; ++gi)                                   \
+          _Pragma("unroll") for (int sp = 0; sp < SP; ++sp) bq[r][gi][sp] = t_[r][gi][sp];  \
     }                                                                                       \
   }
 
@@ -426,14 +449,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
       hl[d] = dummy_loff;
     }
     int arow[G][MF];
-    float4 av[2][G][MF];
+    float4 av[2][G][MF][SP];
 #pragma unroll
     for (int gi = 0; gi < G; ++gi)
 #pragma unroll
       for (int fm = 0; fm < MF; ++fm) {
         arow[gi][fm] = hb_off + afrag[gi][fm];
-        av[0][gi][fm] = smem4[arow[gi][fm]];  // tap (0,0)
-        av[1][gi][fm] = av[0][gi][fm];
+#pragma unroll
+        for (int sp = 0; sp < SP; ++sp) {
+          av[0][gi][fm][sp] = smem4[arow[gi][fm] + sp * QS];  // tap (0,0)
+          av[1][gi][fm][sp] = av[0][gi][fm][sp];
+        }
       }
     int ky = 0;
     if (NBUF == 2)
@@ -470,8 +496,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   const float relu_lo = A.relu ? 0.f : -3.0e38f;  // uniform: v = max(v, relu_lo), no select
   if (A.vec_store) {  // uniform
     // (the chunk loop ended with a barrier: the halo buffers are dead)
-    constexpr int PITCH2 = (NF * 64 + 16) / 2;  // slab row pitch in bf16 elements
-    unsigned short* sl = reinterpret_cast<unsigned short*>(smem) + wave * (kSlabBytes / 2);
+    constexpr int PITCH2 = (NF * 64 * SP + 16) / 2;  // slab row pitch in bf16 elements
+    unsigned short* sl = reinterpret_cast<unsigned short*>(smem) + wave * (slab_bytes(MF, NF, SP) / 2);
+    // element of output channel c inside a slab row: c, or (split) its 8-channel group's hi piece
+    const int ce = SP == 1 ? l31 : ((l31 >> 3) * 16 + (l31 & 7));
+    auto put = [&](int row, int fn, float v) {
+      v = fmaxf(v, relu_lo);
+      unsigned short* d = sl + row * PITCH2 + fn * 32 * SP + ce;
+      const unsigned short hi = to_bf16(v);
+      d[0] = hi;
+      if (SP == 2) d[8] = to_bf16(v - __uint_as_float((unsigned)hi << 16));
+    };
     if (!A.pool) {
 #pragma unroll
       for (int fn = 0; fn < NF; ++fn)
@@ -480,27 +515,24 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-              sl[(fm * 32 + rg * 8 + 4 * kh + rr) * PITCH2 + fn * 32 + l31] =
-                  to_bf16(fmaxf(acc[fm][fn][rg * 4 + rr], relu_lo));
+            for (int rr = 0; rr < 4; ++rr) put(fm * 32 + rg * 8 + 4 * kh + rr, fn, acc[fm][fn][rg * 4 + rr]);
     } else {
 #pragma unroll
       for (int fn = 0; fn < NF; ++fn)
 #pragma unroll
         for (int fm = 0; fm < MF; ++fm)
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            const float v = fmaxf(fmaxf(acc[fm][fn][rg * 4 + 0], acc[fm][fn][rg * 4 + 1]),
-                                  fmaxf(acc[fm][fn][rg * 4 + 2], acc[fm][fn][rg * 4 + 3]));
-            sl[(fm * 8 + rg * 2 + kh) * PITCH2 + fn * 32 + l31] = to_bf16(fmaxf(v, relu_lo));
-          }
+          for (int rg = 0; rg < 4; ++rg)
+            put(fm * 8 + rg * 2 + kh, fn,
+                fmaxf(fmaxf(acc[fm][fn][rg * 4 + 0], acc[fm][fn][rg * 4 + 1]),
+                      fmaxf(acc[fm][fn][rg * 4 + 2], acc[fm][fn][rg * 4 + 3])));
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // same-wave LDS traffic is in order
-    constexpr int LPR = NF * 4;     // lanes (16 bytes each) per slab row
+    constexpr int LPR = NF * 4 * SP;  // lanes (16 bytes each) per slab row
     constexpr int RPI = 64 / LPR;   // rows per wave-instruction
     const int rows = A.pool ? 8 * MF : 32 * MF;
     const int lrow = lane / LPR, c16 = lane % LPR;
-    unsigned short* ob = out_h + g.out_choff + ntile * BN + wn * (32 * NF) + c16 * 8;
+    unsigned short* ob = out_h + g.out_choff + (ntile * BN + wn * (32 * NF)) * SP + c16 * 8;
     const int Ho = A.H >> 1, Wo = A.W >> 1;
     // strip mode: (n, y, x) of this lane's first row by division once, then stepped by RPI pixels
     // (integer division is ~40 VALU instructions; 8 row steps of it were a third of the epilogue)
@@ -563,7 +595,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   for (int fn = 0; fn < NF; ++fn) {
     const int ncolf = ncol + fn * 32;
     const bool col_ok = ncolf < g.cout;
-    const int och = (g.out_cmap && col_ok) ? g.out_cmap[ncolf] : g.out_choff + ncolf;
+    // (split layouts: out_choff counts elements = 2 x channels; out_cmap is not combined with them)
+    const int och = (g.out_cmap && col_ok) ? g.out_cmap[ncolf] : (SP == 1 || A.out_f32 ? g.out_choff + ncolf : 0);
+    // split: out_choff counts elements (2 per channel) and may sit inside an 8-channel group (the
+    // heat-map slice of the concat buffer starts at channel 166): address by absolute channel
+    const int ca = (g.out_choff >> 1) + ncolf;
+    const int ochs = (ca >> 3) * 16 + (ca & 7);  // hi element, lo at +8
     if (!A.pool) {
 #pragma unroll
       for (int fm = 0; fm < MF; ++fm) {
@@ -594,8 +631,15 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
             const float v = fmaxf(acc[fm][fn][rg * 4 + rr], relu_lo);
             if (ok && col_ok) {
               const size_t q = (size_t)g.out_lead + (size_t)(n * g.out_hs + y) * g.out_ws + x;
-              if (A.out_f32) out_f[q * g.out_cstride + och] = v;
-              else out_h[q * g.out_cstride + och] = to_bf16(v);
+              if (A.out_f32) {
+                out_f[q * g.out_cstride + och] = v;
+              } else if (SP == 1) {
+                out_h[q * g.out_cstride + och] = to_bf16(v);
+              } else {
+                const unsigned short hi = to_bf16(v);
+                out_h[q * g.out_cstride + ochs] = hi;
+                out_h[q * g.out_cstride + ochs + 8] = to_bf16(v - __uint_as_float((unsigned)hi << 16));
+              }
             }
           }
         }
@@ -615,8 +659,15 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
                                       fmaxf(acc[fm][fn][rg * 4 + 2], acc[fm][fn][rg * 4 + 3])), relu_lo);
           if (py < Ho && px < Wo && col_ok) {
             const size_t q = (size_t)g.out_lead + (size_t)(n_img * g.out_hs + py) * g.out_ws + px;
-            if (A.out_f32) out_f[q * g.out_cstride + och] = v;
-            else out_h[q * g.out_cstride + och] = to_bf16(v);
+            if (A.out_f32) {
+              out_f[q * g.out_cstride + och] = v;
+            } else if (SP == 1) {
+              out_h[q * g.out_cstride + och] = to_bf16(v);
+            } else {
+              const unsigned short hi = to_bf16(v);
+              out_h[q * g.out_cstride + ochs] = hi;
+              out_h[q * g.out_cstride + ochs + 8] = to_bf16(v - __uint_as_float((unsigned)hi << 16));
+            }
           }
         }
       }
@@ -626,7 +677,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
 
 // 1-D grid, block id -> (group, N tile, M tile); XCD-aware order and half-tile tail exactly
 // as conv_mfma_f32 (conv_mfma.hip).
-template <int KS, int CK, int MODE, int NBUF, int WM, int NF>
+template <int KS, int CK, int MODE, int NBUF, int WM, int NF, int SP>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs A) {
   constexpr int MF = 4 / WM;  // block M tile = 128 pixels either way
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -655,22 +706,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs A) {
   if (mt >= A.mtiles) return;
   const int nt = c % A.ntiles, grp = c / A.ntiles;
   if (MODE == 1) {
-    conv_tile<KS, CK, MODE, NBUF, WM, MF, NF>(A, A.g[grp], mt, nt, smem);
+    conv_tile<KS, CK, MODE, NBUF, WM, MF, NF, SP>(A, A.g[grp], mt, nt, smem);
   } else if (!small) {
-    conv_tile<KS, CK, MODE, NBUF, WM, MF, NF>(A, A.g[grp], mt * kBM, nt, smem);
+    conv_tile<KS, CK, MODE, NBUF, WM, MF, NF, SP>(A, A.g[grp], mt * kBM, nt, smem);
   } else {
     const int m0 = mt * kBM + ((L - A.nbig) & 1) * (kBM / 2);
-    if (m0 < A.M) conv_tile<KS, CK, MODE, NBUF, WM, MF / 2, NF>(A, A.g[grp], m0, nt, smem);
+    if (m0 < A.M) conv_tile<KS, CK, MODE, NBUF, WM, MF / 2, NF, SP>(A, A.g[grp], m0, nt, smem);
   }
 }
 
 // ---- weight packing: packed[chunk][tap][piece][cout_pad][8 bf16] <- w[cout][cin_src][k][k] ----
 __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, const float* __restrict__ bias,
                                          int cout, int cin_src, int k, const int32_t* __restrict__ cin_map,
-                                         int cin_packed, int ck, int coutp, unsigned short* __restrict__ wp,
-                                         float* __restrict__ bp) {
+                                         int cin_packed, int ck, int sp, int coutp,
+                                         unsigned short* __restrict__ wp, float* __restrict__ bp) {
   const int T = k * k;
-  const size_t total = (size_t)T * cin_packed * coutp;
+  const size_t total = (size_t)T * cin_packed * sp * coutp;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (size_t)coutp) bp[i] = (i < (size_t)cout && bias) ? bias[i] : 0.f;
   if (i >= total) return;
@@ -678,10 +729,11 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, const floa
   size_t r = i >> 3;
   const int n = r % coutp;
   r /= coutp;
-  const int cg = r % (ck / 8);
-  r /= (ck / 8);
+  const int plane = r % (ck / 8 * sp);  // piece plane inside the chunk: 8-channel group x (hi, lo)
+  r /= (ck / 8 * sp);
   const int tap = r % T;
   const int chunk = r / T;
+  const int cg = plane / sp, lo = plane % sp;
   const int c = chunk * ck + cg * 8 + e;
   const int src = cin_map ? cin_map[c] : (c < cin_src ? c : -1);
   float v = 0.f;
@@ -689,13 +741,14 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, const floa
     const int ky = tap / k, kx = tap - ky * k;
     v = w[(((size_t)n * cin_src + src) * k + ky) * k + kx];
   }
-  wp[i] = to_bf16(v);
+  const unsigned short hi = to_bf16(v);
+  wp[i] = lo ? to_bf16(v - __uint_as_float((unsigned)hi << 16)) : hi;
 }
 
 // ---- host side ----------------------------------------------------------------------------
 // channels per LDS chunk; the packed weight order depends on it, so pack and launch share it
-static int conv_ck(int cin, int k) {
-  if (cin % 32) return 16;
+static int conv_ck(int cin, int k, int sp) {
+  if (sp == 2 || cin % 32) return 16;  // split operands: 16 channels = 64 B per pixel per chunk
   return (k == 1 && cin % 64 == 0) ? 64 : 32;
 }
 
@@ -715,12 +768,12 @@ static int halo_row_lds(int tw, int p) {
   return w;
 }
 
-static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* pl) {
+static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, int sp, ConvPlan* pl) {
   const int P = d.k / 2;
-  pl->ck = conv_ck(d.cin, d.k);
+  pl->ck = conv_ck(d.cin, d.k, sp);
   const int M = N * H * W;
   const int max_sets = d.k * d.k;  // one piece set per tap, the ring is flushed at the chunk end
-  const int cg = pl->ck / 8;
+  const int cg = pl->ck / 8 * sp;
   pl->nbuf = d.k == 1 ? 1 : 2;
   const size_t tail = pl->nbuf == 2 ? 256 * 16 : 0;  // dummy park slots
   bool strip = (W <= 64) && !d.pool;
@@ -779,10 +832,10 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* p
   return 0;
 }
 
-template <int KS, int CK, int MODE, int NBUF, int WM, int NF>
+template <int KS, int CK, int MODE, int NBUF, int WM, int NF, int SP>
 static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = conv_mfma_bf16<KS, CK, MODE, NBUF, WM, NF>;
+  auto kern = conv_mfma_bf16<KS, CK, MODE, NBUF, WM, NF, SP>;
   if (!attr_set) {
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -796,10 +849,12 @@ static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) 
 }  // namespace bf
 
 // d[i].in / w_packed / out point at bf16 data (out: fp32 when out_f32); layouts count bf16
-// ELEMENTS per pixel.
-int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, int out_f32,
+// ELEMENTS per pixel (split = 1: two elements per channel, [hi x 8 | lo x 8] pieces; `cin` and
+// `cout` still count channels).
+int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, int out_f32, int split,
                        hipStream_t s) {
   using namespace bf;
+  const int sp = split ? 2 : 1;
   if (!d || ngroups < 1 || ngroups > 2) return fail(RTPOSE_E_INVAL, "conv2d_bf16: ngroups must be 1 or 2");
   const rtpose_conv_desc& d0 = d[0];
   if (d0.k != 1 && d0.k != 3 && d0.k != 7) return fail(RTPOSE_E_INVAL, "conv2d_bf16: k must be 1, 3 or 7");
@@ -815,10 +870,11 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
       return fail(RTPOSE_E_INVAL, "conv2d_bf16: grouped convs must share geometry");
     if (di.lin.ws < W + P || di.lin.hs < H + P || di.lin.lead < P * di.lin.ws + P)
       return fail(RTPOSE_E_INVAL, "conv2d_bf16: input layout gap smaller than the conv padding");
-    if ((di.lin.cstride % 8) || (di.lin.choff % 8))
+    if ((di.lin.cstride % (8 * sp)) || (di.lin.choff % (8 * sp)))
       return fail(RTPOSE_E_INVAL, "conv2d_bf16: input slice must be 16-byte aligned");
-    if (di.lin.choff + di.cin > di.lin.cstride)
+    if (di.lin.choff + di.cin * sp > di.lin.cstride)
       return fail(RTPOSE_E_INVAL, "conv2d_bf16: input slice exceeds cstride");
+    if (split && di.out_cmap) return fail(RTPOSE_E_INVAL, "conv2d_bf16x3: out_cmap is not supported");
     ConvGroup& g = a.g[i];
     g.in = reinterpret_cast<const unsigned short*>(di.in);
     g.w = reinterpret_cast<const float4*>(di.w_packed);
@@ -840,7 +896,7 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
   }
   if (d0.pool && ((H | W) & 1)) return fail(RTPOSE_E_INVAL, "conv2d_bf16: fused pool needs even H and W");
   ConvPlan pl;
-  int rc = plan_conv(d0, N, H, W, &pl);
+  int rc = plan_conv(d0, N, H, W, sp, &pl);
   if (rc) return rc;
   a.N = N;
   a.H = H;
@@ -852,7 +908,8 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
   a.out_f32 = out_f32 ? 1 : 0;
   a.vec_store = !out_f32;
   for (int i = 0; i < ngroups; ++i)
-    if (d[i].out_cmap || (d[i].cout % kConvBN) || (d[i].lout.cstride % 8) || (d[i].lout.choff % 8)) a.vec_store = 0;
+    if (d[i].out_cmap || (d[i].cout % kConvBN) || (d[i].lout.cstride % (8 * sp)) || (d[i].lout.choff % (8 * sp)))
+      a.vec_store = 0;
 #ifdef RTPOSE_EXP_SCALAR_STORE
   a.vec_store = 0;
 #endif
@@ -880,7 +937,7 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
   }
   const bool wide = d0.k != 1 && coutp % 128 == 0;
   // measured (32 x 368 x 368): 7x7 layers 1237 (1 x 4) vs 1166 (2 x 2) TFLOP/s, 3x3 layers 786 vs 812
-  pl.wm = (wide && (waves_env == 14 ? d0.k == 7 : waves_env != 22)) ? 1 : 2;
+  pl.wm = (wide && !split && (waves_env == 14 ? d0.k == 7 : waves_env != 22)) ? 1 : 2;
   pl.nf = (wide && pl.wm == 2) ? 2 : 1;
   a.ntiles = coutp / (32 * pl.nf * (4 / pl.wm));
   a.ncombo = a.ntiles * ngroups;
@@ -904,7 +961,7 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
     }
     a.n_cu = n_cu;
     // one block's matrix time with the SIMD to itself: chunks x taps x MFMAs x 32 cycles
-    const long mfma_cycles = (long)(d0.cin / pl.ck) * d0.k * d0.k * (pl.ck / 16) * 4 * 32;
+    const long mfma_cycles = (long)(d0.cin / pl.ck) * d0.k * d0.k * (pl.ck / 16) * 4 * 32 * (split ? 3 : 1);
     a.dephase_cycles = (pl.nbuf == 2 && (long)grid.x > 2L * n_cu) ? (int)(mfma_cycles * dephase_env / 100) : 0;
   }
 #ifdef RTPOSE_EXP_TIMELINE
@@ -919,12 +976,30 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
     }
   }
 #endif
-  if (a.vec_store && pl.lds_bytes < (size_t)4 * kSlabBytes) pl.lds_bytes = (size_t)4 * kSlabBytes;
+  {
+    const size_t slab = (size_t)4 * slab_bytes(pl.wm == 1 ? 4 : 2, pl.nf, sp);
+    if (a.vec_store && pl.lds_bytes < slab) pl.lds_bytes = slab;
+  }
+  if (split) {
+#define RTPOSE_CONV_CASE_X3(KS_, MODE_, NBUF_)                                                    \
+  if (d0.k == KS_ && pl.mode == MODE_) {                                                          \
+    if (pl.nf == 2) return launch_inst<KS_, 16, MODE_, NBUF_, 2, (KS_ != 1) ? 2 : 1, 2>(a, grid, pl.lds_bytes, s); \
+    return launch_inst<KS_, 16, MODE_, NBUF_, 2, 1, 2>(a, grid, pl.lds_bytes, s);                  \
+  }
+    RTPOSE_CONV_CASE_X3(3, 0, 2)
+    RTPOSE_CONV_CASE_X3(3, 1, 2)
+    RTPOSE_CONV_CASE_X3(7, 0, 2)
+    RTPOSE_CONV_CASE_X3(7, 1, 2)
+    RTPOSE_CONV_CASE_X3(1, 0, 1)
+    RTPOSE_CONV_CASE_X3(1, 1, 1)
+#undef RTPOSE_CONV_CASE_X3
+    return fail(RTPOSE_E_INVAL, "conv2d_bf16x3: no kernel instance for k=%d mode=%d", d0.k, pl.mode);
+  }
 #define RTPOSE_CONV_CASE(KS_, CK_, MODE_, NBUF_)                                                  \
   if (d0.k == KS_ && pl.ck == CK_ && pl.mode == MODE_) {                                          \
-    if (pl.wm == 1) return launch_inst<KS_, CK_, MODE_, NBUF_, (KS_ != 1) ? 1 : 2, 1>(a, grid, pl.lds_bytes, s); \
-    if (pl.nf == 2) return launch_inst<KS_, CK_, MODE_, NBUF_, 2, (KS_ != 1) ? 2 : 1>(a, grid, pl.lds_bytes, s); \
-    return launch_inst<KS_, CK_, MODE_, NBUF_, 2, 1>(a, grid, pl.lds_bytes, s);                    \
+    if (pl.wm == 1) return launch_inst<KS_, CK_, MODE_, NBUF_, (KS_ != 1) ? 1 : 2, 1, 1>(a, grid, pl.lds_bytes, s); \
+    if (pl.nf == 2) return launch_inst<KS_, CK_, MODE_, NBUF_, 2, (KS_ != 1) ? 2 : 1, 1>(a, grid, pl.lds_bytes, s); \
+    return launch_inst<KS_, CK_, MODE_, NBUF_, 2, 1, 1>(a, grid, pl.lds_bytes, s);                 \
   }
   RTPOSE_CONV_CASE(3, 16, 0, 2)
   RTPOSE_CONV_CASE(3, 16, 1, 2)
@@ -950,16 +1025,18 @@ unsigned g_dbg_blocks = 0;
 #endif
 
 int pack_weights_bf16_launch(const float* w, const float* bias, int cout, int cin_src, int k,
-                             const int32_t* cin_map, int cin_packed, void* wp, float* bp, hipStream_t s) {
+                             const int32_t* cin_map, int cin_packed, void* wp, float* bp, int split,
+                             hipStream_t s) {
+  const int sp = split ? 2 : 1;
   if (cin_packed % 16 || (cin_packed < cin_src && !cin_map))
     return fail(RTPOSE_E_INVAL, "pack_bf16: cin_packed must be a multiple of 16 and >= cin_src");
   if (k != 1 && k != 3 && k != 7) return fail(RTPOSE_E_INVAL, "pack_bf16: k must be 1, 3 or 7");
   const int coutp = cout_pad(cout);
-  const size_t total = (size_t)k * k * cin_packed * coutp;
+  const size_t total = (size_t)k * k * cin_packed * sp * coutp;
   const int threads = 256;
   const unsigned blocks = (unsigned)((total + threads - 1) / threads);
   hipLaunchKernelGGL(bf::pack_weights_bf16_kernel, dim3(blocks), dim3(threads), 0, s, w, bias, cout, cin_src,
-                     k, cin_map, cin_packed, bf::conv_ck(cin_packed, k), coutp,
+                     k, cin_map, cin_packed, bf::conv_ck(cin_packed, k, sp), sp, coutp,
                      reinterpret_cast<unsigned short*>(wp), bp);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
@@ -979,12 +1056,28 @@ int rtpose_pack_conv_weights_bf16(const float* w_oihw, const float* bias, int co
                                   const int32_t* cin_map, int cin_packed, void* w_packed,
                                   float* bias_packed, void* stream) {
   return rtpose::pack_weights_bf16_launch(w_oihw, bias, cout, cin_src, k, cin_map, cin_packed, w_packed,
-                                          bias_packed, rtpose::as_stream(stream));
+                                          bias_packed, 0, rtpose::as_stream(stream));
+}
+
+size_t rtpose_packed_weight_bytes_bf16x3(int cout, int cin, int k) {
+  return 2 * rtpose_packed_weight_bytes_bf16(cout, cin, k);
+}
+
+int rtpose_pack_conv_weights_bf16x3(const float* w_oihw, const float* bias, int cout, int cin_src, int k,
+                                    const int32_t* cin_map, int cin_packed, void* w_packed,
+                                    float* bias_packed, void* stream) {
+  return rtpose::pack_weights_bf16_launch(w_oihw, bias, cout, cin_src, k, cin_map, cin_packed, w_packed,
+                                          bias_packed, 1, rtpose::as_stream(stream));
+}
+
+int rtpose_conv2d_bf16x3(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, int out_f32,
+                         void* stream) {
+  return rtpose::conv2d_bf16_launch(d, ngroups, N, H, W, out_f32, 1, rtpose::as_stream(stream));
 }
 
 int rtpose_conv2d_bf16(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, int out_f32,
                        void* stream) {
-  return rtpose::conv2d_bf16_launch(d, ngroups, N, H, W, out_f32, rtpose::as_stream(stream));
+  return rtpose::conv2d_bf16_launch(d, ngroups, N, H, W, out_f32, 0, rtpose::as_stream(stream));
 }
 
 }  // extern "C"

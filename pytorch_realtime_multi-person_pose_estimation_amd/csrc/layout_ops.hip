@@ -549,6 +549,71 @@ __global__ void layout_bf16_to_f32_kernel(const unsigned short* __restrict__ src
   dst[lay_off(ld, n, y, x) + c] = bf16_to_f32(src[lay_off(ls, n, y, x) + c]);
 }
 
+
+// ---- "split" activations of the bf16x3 plans: value v = hi + lo, hi = bf16(v), lo = bf16(v - hi),
+//      stored per 8 channels as [hi x 8 | lo x 8] (32 bytes); layouts count elements (2 per channel)
+template <bool SRC_NCHW>
+__global__ void to_split_layout_kernel(const float* __restrict__ src, Lay ls, unsigned short* __restrict__ dst,
+                                       Lay ld, int C, int cpad, int N, int H, int W) {
+  const int groups = cpad >> 3;
+  const size_t total = (size_t)N * H * W * groups;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  size_t p;
+  int gc;
+  if (SRC_NCHW) {
+    p = i % ((size_t)N * H * W);
+    gc = (int)(i / ((size_t)N * H * W));
+  } else {
+    gc = (int)(i % groups);
+    p = i / groups;
+  }
+  const int x = p % W;
+  size_t r = p / W;
+  const int y = r % H;
+  const int n = (int)(r / H);
+  unsigned short hi[8], lo[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = gc * 8 + e;
+    float f = 0.f;
+    if (c < C) f = SRC_NCHW ? src[(((size_t)n * C + c) * H + y) * W + x] : src[lay_off(ls, n, y, x) + c];
+    hi[e] = f32_to_bf16_rne(f);
+    lo[e] = f32_to_bf16_rne(f - bf16_to_f32(hi[e]));
+  }
+  uint4 a, b;
+  a.x = hi[0] | ((unsigned)hi[1] << 16);
+  a.y = hi[2] | ((unsigned)hi[3] << 16);
+  a.z = hi[4] | ((unsigned)hi[5] << 16);
+  a.w = hi[6] | ((unsigned)hi[7] << 16);
+  b.x = lo[0] | ((unsigned)lo[1] << 16);
+  b.y = lo[2] | ((unsigned)lo[3] << 16);
+  b.z = lo[4] | ((unsigned)lo[5] << 16);
+  b.w = lo[6] | ((unsigned)lo[7] << 16);
+  uint4* d = reinterpret_cast<uint4*>(dst + lay_off(ld, n, y, x) + gc * 16);
+  d[0] = a;
+  d[1] = b;
+}
+
+__global__ void layout_split_to_f32_kernel(const unsigned short* __restrict__ src, Lay ls,
+                                           float* __restrict__ dst, Lay ld, int C, int N, int H, int W) {
+  const size_t total = (size_t)N * H * W * C;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = i % C;
+  size_t p = i / C;
+  const int x = p % W;
+  p /= W;
+  const int y = p % H;
+  const int n = p / H;
+  // ls.choff counts elements and may sit inside an 8-channel group (the 19 heat-map channels
+  // start at channel 166 of the concat buffer): address by absolute channel
+  const int ca = (ls.choff >> 1) + c;
+  const unsigned short* s = src + ((size_t)ls.lead + (size_t)(n * ls.hs + y) * ls.ws + x) * ls.cstride +
+                            (ca >> 3) * 16 + (ca & 7);
+  dst[lay_off(ld, n, y, x) + c] = bf16_to_f32(s[0]) + bf16_to_f32(s[8]);
+}
+
 }  // namespace rtpose
 
 using namespace rtpose;
@@ -791,6 +856,42 @@ int rtpose_layout_bf16_to_f32(const void* src, const rtpose_layout* lsrc, float*
   const size_t total = (size_t)N * H * W * C;
   if (!total) return 0;
   hipLaunchKernelGGL(layout_bf16_to_f32_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
+                     static_cast<const unsigned short*>(src), to_lay(lsrc), dst, to_lay(ldst), C, N, H, W);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+
+int rtpose_nchw_to_layout_split(const float* src_nchw, void* dst, const rtpose_layout* ldst, int C, int cpad,
+                                int N, int H, int W, void* stream) {
+  if ((cpad % 8) || (ldst->cstride % 16) || (ldst->choff % 16) || cpad < C)
+    return fail(RTPOSE_E_INVAL, "nchw_to_layout_split: slice must be 32-byte aligned, cpad >= C");
+  const size_t total = (size_t)N * H * W * (cpad / 8);
+  if (!total) return 0;
+  hipLaunchKernelGGL(to_split_layout_kernel<true>, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
+                     src_nchw, Lay{}, static_cast<unsigned short*>(dst), to_lay(ldst), C, cpad, N, H, W);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_layout_f32_to_split(const float* src, const rtpose_layout* lsrc, void* dst,
+                               const rtpose_layout* ldst, int C, int cpad, int N, int H, int W, void* stream) {
+  if ((cpad % 8) || (ldst->cstride % 16) || (ldst->choff % 16) || cpad < C)
+    return fail(RTPOSE_E_INVAL, "layout_f32_to_split: slice must be 32-byte aligned, cpad >= C");
+  const size_t total = (size_t)N * H * W * (cpad / 8);
+  if (!total) return 0;
+  hipLaunchKernelGGL(to_split_layout_kernel<false>, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
+                     src, to_lay(lsrc), static_cast<unsigned short*>(dst), to_lay(ldst), C, cpad, N, H, W);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_layout_split_to_f32(const void* src, const rtpose_layout* lsrc, float* dst, const rtpose_layout* ldst,
+                               int C, int N, int H, int W, void* stream) {
+  if (lsrc->choff & 1) return fail(RTPOSE_E_INVAL, "layout_split_to_f32: choff counts elements (2 per channel)");
+  const size_t total = (size_t)N * H * W * C;
+  if (!total) return 0;
+  hipLaunchKernelGGL(layout_split_to_f32_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
                      static_cast<const unsigned short*>(src), to_lay(lsrc), dst, to_lay(ldst), C, N, H, W);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;

@@ -27,10 +27,11 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
 int pack_weights_launch(const float* w, const float* bias, int cout, int cin_src, int k,
                         const int32_t* cin_map, int cin_packed, float* wp, float* bp, hipStream_t s);
 // bf16 path (conv_mfma_bf16.hip)
-int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, int out_f32,
+int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, int out_f32, int split,
                        hipStream_t s);
 int pack_weights_bf16_launch(const float* w, const float* bias, int cout, int cin_src, int k,
-                             const int32_t* cin_map, int cin_packed, void* wp, float* bp, hipStream_t s);
+                             const int32_t* cin_map, int cin_packed, void* wp, float* bp, int split,
+                             hipStream_t s);
 }  // namespace rtpose
 
 using namespace rtpose;
@@ -75,6 +76,7 @@ struct Op {
 struct rtpose_net {
   int N = 0, H = 0, W = 0;       // input
   int bf16 = 0;                  // 1: bf16 activations/weights, fp32 accumulate (BASELINE config 3)
+  int split = 0;                 // bf16 plans only: 1 = "bf16x3" split operands (hi + lo bf16 per value)
   int x0f_buf = -1;              // bf16 plans: fp32 NHWC8 staging buffer for rtpose_preprocess_u8
   int H3 = 0, W3 = 0;            // stride-8 map
   std::vector<Buf> bufs;
@@ -111,7 +113,8 @@ int add_buf(rtpose_net* n, int C, int P, int H, int W, bool f32 = false) {
   b.lay.hs = H + P;
   b.lay.lead = P * (W + P) + P;
   // bf16 plans keep activations as 2-byte elements (C is even for every such buffer)
-  const size_t per_px = (n->bf16 && !f32) ? (size_t)C / 2 : (size_t)C;
+  // (split plans: two 2-byte elements per channel = the fp32 footprint)
+  const size_t per_px = (n->bf16 && !n->split && !f32) ? (size_t)C / 2 : (size_t)C;
   b.floats = round_up(rtpose_layout_pixels(&b.lay, n->N, H, W) * per_px, 64);
   b.off_floats = n->ws_floats;
   n->ws_floats += b.floats;
@@ -128,7 +131,8 @@ int add_conv_w(rtpose_net* n, const std::string& name, int cout, int cin, int k,
   c.k = k;
   c.cat_perm = cat_perm;
   c.w_off = n->wt_floats;
-  n->wt_floats += round_up(n->bf16 ? rtpose_packed_weight_bytes_bf16(cout, c.cin_packed, k) / 4
+  n->wt_floats += round_up(n->split ? rtpose_packed_weight_bytes_bf16x3(cout, c.cin_packed, k) / 4
+                           : n->bf16 ? rtpose_packed_weight_bytes_bf16(cout, c.cin_packed, k) / 4
                                    : rtpose_packed_weight_floats(cout, c.cin_packed, k), 64);
   c.b_off = n->wt_floats;
   n->wt_floats += round_up(rtpose_packed_bias_floats(cout), 64);
@@ -348,16 +352,17 @@ extern "C" {
 int rtpose_net_create_ex(int N, int H, int W, int dtype, rtpose_net** out) {
   if (!out) return fail(RTPOSE_E_INVAL, "net_create: out is NULL");
   if (N <= 0 || H < 8 || W < 8) return fail(RTPOSE_E_INVAL, "net_create: need N>=1 and H,W>=8");
-  if (dtype != RTPOSE_DTYPE_F32 && dtype != RTPOSE_DTYPE_BF16)
-    return fail(RTPOSE_E_INVAL, "net_create: dtype must be RTPOSE_DTYPE_F32 or RTPOSE_DTYPE_BF16");
-  if (dtype == RTPOSE_DTYPE_BF16 && ((H | W) & 7))
+  if (dtype != RTPOSE_DTYPE_F32 && dtype != RTPOSE_DTYPE_BF16 && dtype != RTPOSE_DTYPE_BF16X3)
+    return fail(RTPOSE_E_INVAL, "net_create: dtype must be RTPOSE_DTYPE_F32, _BF16 or _BF16X3");
+  if (dtype != RTPOSE_DTYPE_F32 && ((H | W) & 7))
     return fail(RTPOSE_E_INVAL, "net_create: the bf16 plan needs H and W to be multiples of 8 "
                                 "(crop_with_factor pads to that, im_transform.py:128-132)");
   rtpose_net* n = new rtpose_net();
   n->N = N;
   n->H = H;
   n->W = W;
-  n->bf16 = dtype == RTPOSE_DTYPE_BF16;
+  n->bf16 = dtype != RTPOSE_DTYPE_F32;
+  n->split = dtype == RTPOSE_DTYPE_BF16X3;
   build_plan(n);
   *out = n;
   return 0;
@@ -367,7 +372,9 @@ int rtpose_net_create(int N, int H, int W, rtpose_net** out) {
   return rtpose_net_create_ex(N, H, W, RTPOSE_DTYPE_F32, out);
 }
 
-int rtpose_net_dtype(const rtpose_net* net) { return net && net->bf16 ? RTPOSE_DTYPE_BF16 : RTPOSE_DTYPE_F32; }
+int rtpose_net_dtype(const rtpose_net* net) {
+  return !net || !net->bf16 ? RTPOSE_DTYPE_F32 : (net->split ? RTPOSE_DTYPE_BF16X3 : RTPOSE_DTYPE_BF16);
+}
 
 void rtpose_net_destroy(rtpose_net* net) {
   if (!net) return;
@@ -423,7 +430,7 @@ int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw, const fl
   const int32_t* map = c.cat_perm ? reinterpret_cast<const int32_t*>(net->wt + net->catmap_off) : nullptr;
   if (net->bf16)
     return pack_weights_bf16_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed,
-                                    net->wt + c.w_off, net->wt + c.b_off, as_stream(stream));
+                                    net->wt + c.w_off, net->wt + c.b_off, net->split, as_stream(stream));
   return pack_weights_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed, net->wt + c.w_off,
                              net->wt + c.b_off, as_stream(stream));
 }
@@ -496,13 +503,19 @@ static int net_forward_impl(rtpose_net* net, const float* x_nchw, void* stream) 
       case OP_INPUT: {
         const Buf& b = net->bufs[o.out_buf[0]];
         if (net->bf16) {
-          if (x_nchw) {
-            rc = rtpose_nchw_to_layout_bf16(x_nchw, net->ws + b.off_floats, &b.lay, 3, 16, N, o.H, o.W, stream);
-          } else {
-            const Buf& bs = net->bufs[net->x0f_buf];
-            rc = rtpose_layout_f32_to_bf16(net->ws + bs.off_floats, &bs.lay, net->ws + b.off_floats, &b.lay, 3,
-                                           16, N, o.H, o.W, stream);
-          }
+          rtpose_layout lb = b.lay;
+          if (net->split) lb.cstride *= 2;  // elements
+          const Buf& bs = net->bufs[net->x0f_buf];
+          if (x_nchw && net->split)
+            rc = rtpose_nchw_to_layout_split(x_nchw, net->ws + b.off_floats, &lb, 3, 16, N, o.H, o.W, stream);
+          else if (x_nchw)
+            rc = rtpose_nchw_to_layout_bf16(x_nchw, net->ws + b.off_floats, &lb, 3, 16, N, o.H, o.W, stream);
+          else if (net->split)
+            rc = rtpose_layout_f32_to_split(net->ws + bs.off_floats, &bs.lay, net->ws + b.off_floats, &lb, 3, 16,
+                                            N, o.H, o.W, stream);
+          else
+            rc = rtpose_layout_f32_to_bf16(net->ws + bs.off_floats, &bs.lay, net->ws + b.off_floats, &lb, 3, 16,
+                                           N, o.H, o.W, stream);
           break;
         }
         if (!x_nchw) break;  // forward_prepared: the input buffer was written by the caller
@@ -521,6 +534,14 @@ static int net_forward_impl(rtpose_net* net, const float* x_nchw, void* stream) 
           d[g].bias_packed = net->wt + c.b_off;
           d[g].lin = slice(bi, o.in_choff[g]);
           d[g].lout = slice(bo, o.out_choff[g]);
+          if (net->split) {  // split buffers: layouts count elements, 2 per channel
+            d[g].lin.cstride *= 2;
+            d[g].lin.choff *= 2;
+            if (!o.out_f32) {
+              d[g].lout.cstride *= 2;
+              d[g].lout.choff *= 2;
+            }
+          }
           d[g].cin = c.cin_packed;
           d[g].cout = c.cout;
           d[g].k = c.k;
@@ -528,7 +549,7 @@ static int net_forward_impl(rtpose_net* net, const float* x_nchw, void* stream) 
           d[g].pool = o.pool;
           d[g].out_cmap = nullptr;
         }
-        rc = net->bf16 ? conv2d_bf16_launch(d, o.ngroups, N, o.H, o.W, o.out_f32, s)
+        rc = net->bf16 ? conv2d_bf16_launch(d, o.ngroups, N, o.H, o.W, o.out_f32, net->split, s)
                        : conv2d_launch(d, o.ngroups, N, o.H, o.W, s);
         break;
       }
@@ -545,12 +566,19 @@ static int net_forward_impl(rtpose_net* net, const float* x_nchw, void* stream) 
         const Buf& bi = net->bufs[o.in_buf[0]];
         const Buf& bo = net->bufs[o.out_buf[0]];
         rtpose_layout li = slice(bi, o.in_choff[0]), lo = slice(bo, o.out_choff[0]);
+        if (net->split && is_save) {
+          li.cstride *= 2;
+          li.choff *= 2;
+          rc = rtpose_layout_split_to_f32(net->ws + bi.off_floats, &li, net->ws + bo.off_floats, &lo, o.C, N,
+                                          o.H, o.W, stream);
+          break;
+        }
         if (net->bf16 && is_save) {  // bf16 concat slice -> fp32 record of the stage outputs
           rc = rtpose_layout_bf16_to_f32(net->ws + bi.off_floats, &li, net->ws + bo.off_floats, &lo, o.C, N,
                                          o.H, o.W, stream);
           break;
         }
-        if (net->bf16) {  // bf16 -> bf16: move channel pairs as 4-byte words
+        if (net->bf16 && !net->split) {  // bf16 -> bf16: move channel pairs as 4-byte words
           li.cstride /= 2; li.choff /= 2; lo.cstride /= 2; lo.choff /= 2;
           rc = rtpose_layout_copy(net->ws + bi.off_floats, &li, net->ws + bo.off_floats, &lo, o.C / 2, N, o.H,
                                   o.W, stream);
