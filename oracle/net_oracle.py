@@ -123,3 +123,58 @@ def forward_bf16_emulated(sd, x):
             saved += outs
             inp = torch.cat([outs[0], outs[1], out1], 1)
     return (saved[-2], saved[-1]), saved
+
+
+# ---- bf16x3 restatement ("split" operands: fp32-grade results from the bf16 matrix pipe) -------
+# Every operand v is carried as hi + lo with hi = bf16(v), lo = bf16(v - hi); a product is
+# hi*hi + hi*lo + lo*hi (lo*lo dropped); accumulation, bias, ReLU, max-pool in fp32; activations
+# are re-split between layers (i.e. rounded to hi + lo), the stage-6 maps stay fp32.
+# "parity unpinned" w.r.t. the reference (which has no such path): the product's own claim is
+# the fp32 contract, checked against forward() above.
+def _split(t):
+    hi = _rb(t)
+    lo = _rb(t - hi)
+    return hi, lo
+
+
+def _conv_x3(sd, prefix, x, relu, round_out=True):
+    w = sd[prefix + '.weight']
+    b = sd[prefix + '.bias'].double()
+    pad = w.shape[-1] // 2
+    xh, xl = (t.double() for t in _split(x))
+    wh, wl = (t.double() for t in _split(w))
+    y = (F.conv2d(xh, wh, b, padding=pad) + F.conv2d(xh, wl, None, padding=pad)
+         + F.conv2d(xl, wh, None, padding=pad)).float()
+    if relu:
+        y = F.relu(y)
+    if round_out:
+        hi, lo = _split(y)
+        y = hi + lo
+    return y
+
+
+def forward_bf16x3_emulated(sd, x):
+    sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+    x = x.detach().float().cpu()
+    with torch.no_grad():
+        h = x
+        for idx in VGG_CONV_IDX:
+            h = _conv_x3(sd, 'model0.%d' % idx, h, True)
+            if idx in VGG_POOL_AFTER:
+                h = F.max_pool2d(h, kernel_size=2, stride=2, padding=0)
+        out1 = h
+        saved = []
+        inp = out1
+        for s in range(1, 7):
+            n = 5 if s == 1 else 7
+            outs = []
+            for br in (1, 2):
+                t = inp
+                for i in range(n):
+                    last = i + 1 == n
+                    t = _conv_x3(sd, 'model%d_%d.%d' % (s, br, 2 * i), t, relu=not last,
+                                 round_out=not (last and s == 6))
+                outs.append(t)
+            saved += outs
+            inp = torch.cat([outs[0], outs[1], out1], 1)
+    return (saved[-2], saved[-1]), saved

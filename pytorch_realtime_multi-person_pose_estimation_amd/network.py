@@ -71,6 +71,9 @@ class _Plan(object):
             pass
 
 
+_DTYPES = {'fp32': _capi.DTYPE_F32, 'bf16': _capi.DTYPE_BF16, 'bf16x3': _capi.DTYPE_BF16X3}
+
+
 class _ShapeOnly(object):
     def __init__(self, device):
         self.device = torch.device(device)
@@ -99,11 +102,12 @@ class RtposeVGG(nn.Module):
         self.compute_dtype = 'fp32'
 
     def set_compute_dtype(self, dtype):
-        """'fp32' (reference arithmetic, v_mfma_f32_32x32x2_f32) or 'bf16' (BASELINE config 3:
-        bf16 operands, fp32 accumulate, v_mfma_f32_32x32x16_bf16).  Parameters, inputs and
-        outputs stay fp32 tensors either way."""
-        if dtype not in ('fp32', 'bf16'):
-            raise ValueError("compute dtype must be 'fp32' or 'bf16'")
+        """'fp32' (reference arithmetic, v_mfma_f32_32x32x2_f32), 'bf16' (BASELINE config 3:
+        bf16 operands, fp32 accumulate, v_mfma_f32_32x32x16_bf16) or 'bf16x3' (every fp32
+        operand split into two bf16s, three bf16 MFMAs per product: fp32-grade maps from the
+        16x faster pipe).  Parameters, inputs and outputs stay fp32 tensors either way."""
+        if dtype not in _DTYPES:
+            raise ValueError("compute dtype must be one of %s" % (sorted(_DTYPES),))
         self.compute_dtype = dtype
         return self
 
@@ -165,7 +169,7 @@ class RtposeVGG(nn.Module):
         """The executor instance for N x 3 x H x W inputs on `device` (created on first use);
         for callers that fill the plan's input buffer themselves (rtpose_preprocess_u8)."""
         x = _ShapeOnly(device)
-        dtype = _capi.DTYPE_BF16 if self.compute_dtype == 'bf16' else _capi.DTYPE_F32
+        dtype = _DTYPES[self.compute_dtype]
         key = (n, h, w, x.device.index, dtype)
         plan = self._plans.get(key)
         if plan is None:
