@@ -135,7 +135,8 @@ def measure_traffic(timeout_s=150, dtype="fp32"):
             cur = sqlite3.connect(db).cursor()
             row = cur.execute("select sum(value), count(distinct dispatch_id) from counters_collection "
                               "where counter_name = ? and kernel_name like ?",
-                              (counter, "%conv_mfma_bf16<7, 32, 0%" if dtype == "bf16" else "%conv_mfma_f32<7, 16, 0%")).fetchone()
+                              (counter, "%conv_mfma_bf16<7, 16, 0%" if dtype == "bf16x3" else
+                               "%conv_mfma_bf16<7, 32, 0%" if dtype == "bf16" else "%conv_mfma_f32<7, 16, 0%")).fetchone()
             if not row or not row[1]:
                 return None
             out[counter] = float(row[0]) / float(row[1]) * 1024.0      # KiB per launch -> bytes
@@ -154,9 +155,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes")
-    ap.add_argument("--dtype", choices=("fp32", "bf16"), default="fp32",
+    ap.add_argument("--dtype", choices=("fp32", "bf16", "bf16x3"), default="fp32",
                     help="fp32 = BASELINE.json configs[1] (the contract, default); bf16 = the configs[2] "
-                         "arithmetic (bf16 operands, fp32 accumulate) on the same workload, for reference")
+                         "arithmetic (bf16 operands, fp32 accumulate); bf16x3 = split bf16 operands, 3 MFMAs per "
+                         "product (fp32-grade maps from the bf16 pipe) - both on the same workload, for reference")
     args = ap.parse_args()
 
     pkg = importlib.import_module(PKG)
@@ -179,8 +181,10 @@ def main():
     model.load_state_dict(net_oracle.he_init_state_dict(model, seed=0))
     model = model.cuda().float().eval()
     model.set_compute_dtype(args.dtype)
-    bf16 = args.dtype == "bf16"
-    peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+    bf16 = args.dtype != "fp32"
+    x3 = args.dtype == "bf16x3"
+    # bf16x3 spends three bf16 MFMAs per algorithmic multiply-add
+    peak = (BF16_MFMA_PEAK_TFLOPS / 3.0 if x3 else BF16_MFMA_PEAK_TFLOPS) if bf16 else FP32_MFMA_PEAK_TFLOPS
     est = pipeline.PoseEstimator(model)
 
     g = torch.Generator().manual_seed(rank)
@@ -244,8 +248,10 @@ def main():
             "value": round(fps, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": ("rtpose VGG19 368x368 batch=32 synthetic images, single MI355X, bf16 operands / "
-                                    "fp32 accumulate (NOT the contract config: BASELINE.json configs[1] is fp32)"
+            "config": {"workload": ("rtpose VGG19 368x368 batch=32 synthetic images, single MI355X, %s "
+                                    "(NOT the contract config: BASELINE.json configs[1] is fp32)" % (
+                                        "split bf16 operands hi+lo, 3 bf16 MFMAs per product, fp32 accumulate"
+                                        if x3 else "bf16 operands / fp32 accumulate")
                                     if bf16 else
                                     "rtpose VGG19 368x368 batch=32 synthetic images, single MI355X, fp32 "
                                     "(BASELINE.json configs[1]); per-GPU batch 32, one process per GPU"),
@@ -257,7 +263,8 @@ def main():
             "net_tflops_end_to_end": round(fps / world * GFLOP_PER_IMAGE / 1e3, 2),
             "net_ms_per_step_events": round(net_ms / args.steps, 3),
             "roofline": {"bound": "mfma",
-                         "kernel": ("conv_mfma_bf16<7,32,0>" if bf16 else "conv_mfma_f32<7,16,0>") +
+                         "kernel": ("conv_mfma_bf16<7,16,0,..,SP=2>" if x3 else
+                                    "conv_mfma_bf16<7,32,0>" if bf16 else "conv_mfma_f32<7,16,0>") +
                                    " (7x7 stage convs, 68% of the FLOPs)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None,
@@ -271,7 +278,7 @@ def main():
             if tr:
                 out["roofline"]["traffic"] = round(tr["fetch_bytes"] + tr["write_bytes"])
                 out["roofline"]["traffic_detail"] = tr
-                out["roofline"]["algorithmic_bytes_per_launch"] = 38_000_000 if bf16 else 76_000_000
+                out["roofline"]["algorithmic_bytes_per_launch"] = 38_000_000 if (bf16 and not x3) else 76_000_000
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline((heat_np, paf_np))
         else:
