@@ -28,7 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=5000)
     ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--dtype", choices=("fp32", "bf16"), default="fp32")
+    ap.add_argument("--dtype", choices=("fp32", "bf16", "bf16x3"), default="fp32")
     args = ap.parse_args()
     pkg = importlib.import_module(PKG)
     par = importlib.import_module(PKG + ".parallel")

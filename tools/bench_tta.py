@@ -28,7 +28,7 @@ def main(B=8, iters=5, h0=368, w0=368):
     rng = np.random.default_rng(0)
     imgs = [rng.integers(0, 256, (h0, w0, 3), dtype=np.uint8) for _ in range(B)]
     out = {}
-    for dt in ('fp32', 'bf16'):
+    for dt in ('fp32', 'bf16x3', 'bf16'):
         m.set_compute_dtype(dt)
 
         def step():
@@ -55,9 +55,10 @@ def main(B=8, iters=5, h0=368, w0=368):
         torch.cuda.synchronize()
         print("%s per-image host-prepared path: %.2f ms per image" % (dt, (time.time() - t0) / 3 * 1e3))
     pa, ha = out['fp32']
-    pb, hb = out['bf16']
-    print("merged maps bf16 vs fp32: paf max|d| %.4g (max|ref| %.3g), heat max|d| %.4g (max|ref| %.3g)" % (
-        np.abs(pa - pb).max(), np.abs(pa).max(), np.abs(ha - hb).max(), np.abs(ha).max()))
+    for dt in ('bf16x3', 'bf16'):
+        pb, hb = out[dt]
+        print("merged maps %s vs fp32: paf max|d| %.4g (max|ref| %.3g), heat max|d| %.4g (max|ref| %.3g)" % (
+            dt, np.abs(pa - pb).max(), np.abs(pa).max(), np.abs(ha - hb).max(), np.abs(ha).max()))
 
 
 if __name__ == "__main__":
