@@ -169,3 +169,24 @@ def test_bf16x3_keypoints_identical_to_fp32(pkg, model_and_sd, cuda):
     for a, b in zip(res['fp32'], res['bf16x3']):
         assert np.array_equal(a["parts"], b["parts"]), "person/part assignment differs"
         assert np.array_equal(a["peaks"][:, :2], b["peaks"][:, :2]), "peak coordinates differ"
+
+
+def test_bf16x3_full_size_batch_properties(model_and_sd, cuda):
+    """32 x 3 x 368 x 368: batch-position independence and determinism, bit for bit."""
+    m, _ = model_and_sd
+    g = torch.Generator().manual_seed(13)
+    x = torch.rand(32, 3, 368, 368, generator=g) - 0.5
+    perm = torch.randperm(32, generator=g)
+    keep = m.keep_intermediates
+    m.keep_intermediates = False
+    m.set_compute_dtype('bf16x3')
+    try:
+        with torch.no_grad():
+            (paf, heat), _ = m(x.to(cuda))
+            (paf2, heat2), _ = m(x.to(cuda))
+            (paf_p, heat_p), _ = m(x[perm].to(cuda))
+    finally:
+        m.set_compute_dtype('fp32')
+        m.keep_intermediates = keep
+    assert torch.equal(paf, paf2) and torch.equal(heat, heat2)
+    assert torch.equal(paf_p, paf[perm.to(cuda)]) and torch.equal(heat_p, heat[perm.to(cuda)])

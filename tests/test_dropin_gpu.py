@@ -171,7 +171,7 @@ def test_multiscale_batch_matches_per_image(compat, cuda):
     rng = np.random.default_rng(7)
     imgs = [rng.integers(0, 256, (131, 150, 3), dtype=np.uint8) for _ in range(3)]
     scales = (0.5, 1.0, 1.5)
-    for dt, tol in (('fp32', 2e-6), ('bf16', 2e-6)):
+    for dt, tol in (('fp32', 2e-6), ('bf16', 2e-6), ('bf16x3', 2e-6)):
         model.set_compute_dtype(dt)
         try:
             with torch.no_grad():
