@@ -937,7 +937,7 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
   }
   const bool wide = d0.k != 1 && coutp % 128 == 0;
   // measured (32 x 368 x 368): 7x7 layers 1237 (1 x 4) vs 1166 (2 x 2) TFLOP/s, 3x3 layers 786 vs 812
-  pl.wm = (wide && !split && (waves_env == 14 ? d0.k == 7 : waves_env != 22)) ? 1 : 2;
+  pl.wm = (wide && (waves_env == 14 ? d0.k == 7 : waves_env != 22)) ? 1 : 2;
   pl.nf = (wide && pl.wm == 2) ? 2 : 1;
   a.ntiles = coutp / (32 * pl.nf * (4 / pl.wm));
   a.ncombo = a.ntiles * ngroups;
@@ -983,6 +983,7 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
   if (split) {
 #define RTPOSE_CONV_CASE_X3(KS_, MODE_, NBUF_)                                                    \
   if (d0.k == KS_ && pl.mode == MODE_) {                                                          \
+    if (pl.wm == 1) return launch_inst<KS_, 16, MODE_, NBUF_, (KS_ != 1) ? 1 : 2, 1, 2>(a, grid, pl.lds_bytes, s); \
     if (pl.nf == 2) return launch_inst<KS_, 16, MODE_, NBUF_, 2, (KS_ != 1) ? 2 : 1, 2>(a, grid, pl.lds_bytes, s); \
     return launch_inst<KS_, 16, MODE_, NBUF_, 2, 1, 2>(a, grid, pl.lds_bytes, s);                  \
   }
