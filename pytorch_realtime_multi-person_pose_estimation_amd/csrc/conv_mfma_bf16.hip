@@ -749,6 +749,14 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, const floa
 // channels per LDS chunk; the packed weight order depends on it, so pack and launch share it
 static int conv_ck(int cin, int k, int sp) {
   if (sp == 2 || cin % 32) return 16;  // split operands: 16 channels = 64 B per pixel per chunk
+  // 3x3 layers with deep inputs: 64-channel chunks halve the chunk barriers (conv4_2 1089 -> 1128
+  // TFLOP/s); the wide shallow ones (conv1_2, 64 channels at 368x368) lose with them (645 -> 599)
+  static int ck3 = 0;  // developer A/B: RTPOSE_BF16_CK3=32|64 forces one size for all 3x3 layers
+  if (!ck3) {
+    const char* e = getenv("RTPOSE_BF16_CK3");
+    ck3 = e ? atoi(e) : -1;
+  }
+  if (k == 3 && cin % 64 == 0 && (ck3 == 64 || (ck3 < 0 && cin >= 256))) return 64;
   return (k == 1 && cin % 64 == 0) ? 64 : 32;
 }
 
@@ -810,12 +818,16 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, int sp, Con
     if (th < 2) continue;
     const long cost = (long)ceil_div(W, tw) * ceil_div(H, th);
     const long halo = (long)(th + 2 * P) * halo_row_lds(tw, P);
+    // the halo must fit the staging schedule (one piece set per tap) and the LDS budget
+    if (pl->nbuf == 2 && ceil_div(round_qs((int)halo) * cg, 256) > max_sets) continue;
+    if ((size_t)pl->nbuf * cg * round_qs((int)halo) * 16 + tail > 80 * 1024) continue;
     const long key = cost * 100000 + halo;
     if (best_cost < 0 || key < best_cost) {
       best_cost = key;
       best_tw = twl;
     }
   }
+  if (best_cost < 0) return fail(RTPOSE_E_INVAL, "conv bf16: no 2-D tile fits the staging schedule");
   const int tw = 1 << best_tw, th = kBM >> best_tw;
   pl->mode = 1;
   pl->tw_log2 = best_tw;
@@ -1006,6 +1018,8 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
   RTPOSE_CONV_CASE(3, 16, 1, 2)
   RTPOSE_CONV_CASE(3, 32, 0, 2)
   RTPOSE_CONV_CASE(3, 32, 1, 2)
+  RTPOSE_CONV_CASE(3, 64, 0, 2)
+  RTPOSE_CONV_CASE(3, 64, 1, 2)
   RTPOSE_CONV_CASE(7, 32, 0, 2)
   RTPOSE_CONV_CASE(7, 32, 1, 2)
   RTPOSE_CONV_CASE(7, 16, 0, 2)
