@@ -200,6 +200,13 @@ int rtpose_nchw_to_layout_affine(const float* src_nchw, float* dst, const rtpose
 int rtpose_stem_conv3x3_s2(const float* in, const rtpose_layout* lin, const float* w,
                            const float* bias, float* out, const rtpose_layout* lout,
                            int cin_pad, int cout, int N, int H, int W, int relu, void* stream);
+/* The same conv fused with what precedes it (:96-97): dense NCHW fp32 image -> per-channel
+ * affine (the input BatchNorm2d(3); scale/shift device float[3] or NULL) -> conv 3x3 s2 p1
+ * (zero padding applied after the affine, as in the reference graph) -> ReLU -> NHWC. */
+int rtpose_stem_conv3x3_s2_nchw(const float* x_nchw, const float* scale, const float* shift,
+                                const float* w, const float* bias, float* out,
+                                const rtpose_layout* lout, int cout, int N, int H, int W,
+                                int relu, void* stream);
 /* MaxPool2d(3, 2, 0, ceil_mode=True) (:98) */
 int rtpose_maxpool3x3s2_ceil(const float* in, const rtpose_layout* lin, float* out,
                              const rtpose_layout* lout, int C, int N, int H, int W, void* stream);

@@ -337,6 +337,64 @@ __global__ void nchw_to_layout_affine_kernel(const float* __restrict__ src, floa
 // taps are two float4 loads each, and the weight index depends on loop counters only, so
 // the weights arrive through the scalar cache (s_load), not the vector path.
 // w[ky][kx][8][COUT].  The input layout's zero gaps are the padding: no bounds tests.
+// Same conv fused with the two steps in front of it (rtpose_shufflenetV2.py:96-97): reads the dense
+// NCHW fp32 image directly (3 planes, x fastest = coalesced), applies the input BatchNorm2d(3) as a
+// per-channel affine (the conv's zero padding is applied AFTER it, as in the reference graph) and
+// writes NHWC.  Removes the NHWC8 staging tensor (555 MB at batch 128) and 5/8 of the FMAs.
+template <int COUT>
+__global__ void stem_conv3x3_s2_nchw_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                            const float* __restrict__ shift, const float* __restrict__ w,
+                                            const float* __restrict__ bias, float* __restrict__ out, Lay lo,
+                                            int N, int H, int W, int Ho, int Wo, int relu) {
+  constexpr int C4 = COUT / 4;
+  const size_t total = (size_t)N * Ho * Wo;
+  size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= total) return;
+  const int ox = p % Wo;
+  p /= Wo;
+  const int oy = p % Ho;
+  const int n = p / Ho;
+  float4 acc[C4];
+#pragma unroll
+  for (int j = 0; j < C4; ++j) acc[j] = *reinterpret_cast<const float4*>(bias + 4 * j);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    const float* plane = x + ((size_t)n * 3 + c) * H * W;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy + ky - 1;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox + kx - 1;
+        const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const float v = in ? plane[(size_t)iy * W + ix] * sc + sh : 0.f;
+        const float* wp = w + (size_t)((ky * 3 + kx) * 8 + c) * COUT;  // packed [ky][kx][8][COUT]
+#pragma unroll
+        for (int j = 0; j < C4; ++j) {
+          const float4 ww = *reinterpret_cast<const float4*>(wp + 4 * j);
+          acc[j].x += v * ww.x;
+          acc[j].y += v * ww.y;
+          acc[j].z += v * ww.z;
+          acc[j].w += v * ww.w;
+        }
+      }
+    }
+  }
+  float* op = out + lay_off(lo, n, oy, ox);
+#pragma unroll
+  for (int j = 0; j < C4; ++j) {
+    float4 a = acc[j];
+    if (relu) {
+      a.x = fmaxf(a.x, 0.f);
+      a.y = fmaxf(a.y, 0.f);
+      a.z = fmaxf(a.z, 0.f);
+      a.w = fmaxf(a.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(op + 4 * j) = a;
+  }
+}
+
 template <int COUT>
 __global__ void stem_conv3x3_s2_kernel(const float* __restrict__ in, Lay li, const float* __restrict__ w,
                                        const float* __restrict__ bias, float* __restrict__ out, Lay lo,
@@ -711,6 +769,20 @@ int rtpose_stem_conv3x3_s2(const float* in, const rtpose_layout* lin, const floa
   if (!total) return 0;
   hipLaunchKernelGGL(stem_conv3x3_s2_kernel<24>, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), in,
                      to_lay(lin), w, bias, out, to_lay(lout), N, Ho, Wo, relu);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_stem_conv3x3_s2_nchw(const float* x_nchw, const float* scale, const float* shift, const float* w,
+                                const float* bias, float* out, const rtpose_layout* lout, int cout, int N, int H,
+                                int W, int relu, void* stream) {
+  if (cout != 24 || (lout->cstride % 4) || (lout->choff % 4))
+    return fail(RTPOSE_E_INVAL, "stem_conv3x3_s2_nchw: only cout=24 (ShuffleNetV2 x1.0) is instantiated");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const size_t total = (size_t)N * Ho * Wo;
+  if (!total) return 0;
+  hipLaunchKernelGGL(stem_conv3x3_s2_nchw_kernel<24>, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
+                     x_nchw, scale, shift, w, bias, out, to_lay(lout), N, H, W, Ho, Wo, relu);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -218,13 +218,13 @@ void build(rtpose_shufflenet* n) {
   // ---- stem -----------------------------------------------------------------------
   const int L_aff = add_layer(n, L_AFFINE, "network.0", 3, 3, 8, -1);
   const int L_stem = add_layer(n, L_STEM, "network.1", 24, 3, 8, -1);
-  const int X0 = add_buf(n, 8, 1, H0, W0);
+  const int X0 = -1;  // (no NHWC staging of the image: the stem conv reads the NCHW input itself)
   const int S1 = add_buf(n, 24, 0, H1, W1);
   const int X1 = add_buf(n, 24, 1, H2, W2);
   {
     SOp o;
     o.kind = O_INPUT;
-    o.name = "nchw->nhwc8 + data/bn";
+    o.name = "(data/bn: fused into stage1/conv)";
     o.H = H0;
     o.W = W0;
     o.layer[0] = L_aff;
@@ -493,19 +493,15 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
     if (prof) RTPOSE_HIP_CHECK(hipEventRecord(n->ev[i], s));
     int rc = 0;
     switch (o.kind) {
-      case O_INPUT: {
-        const SBuf& b = n->bufs[o.out_buf[0]];
-        const SLayer& l = n->layers[o.layer[0]];
-        rc = rtpose_nchw_to_layout_affine(x_nchw, n->ws + b.off, &b.lay, 3, 8, n->N, o.H, o.W, n->wt + l.w_off,
-                                          n->wt + l.b_off, stream);
+      case O_INPUT:  // fused into the stem conv, which reads the NCHW image itself
         break;
-      }
       case O_STEM: {
-        const SBuf& bi = n->bufs[o.in_buf[0]];
         const SBuf& bo = n->bufs[o.out_buf[0]];
         const SLayer& l = n->layers[o.layer[0]];
-        rc = rtpose_stem_conv3x3_s2(n->ws + bi.off, &bi.lay, n->wt + l.w_off, n->wt + l.b_off, n->ws + bo.off,
-                                    &bo.lay, 8, l.cout, n->N, o.H, o.W, o.relu, stream);
+        const SLayer& la = n->layers[n->ops[0].layer[0]];  // the input BatchNorm2d(3) as scale / shift
+        rc = rtpose_stem_conv3x3_s2_nchw(x_nchw, n->wt + la.w_off, n->wt + la.b_off, n->wt + l.w_off,
+                                         n->wt + l.b_off, n->ws + bo.off, &bo.lay, l.cout, n->N, o.H, o.W, o.relu,
+                                         stream);
         break;
       }
       case O_POOL3: {
