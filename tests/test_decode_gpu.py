@@ -191,3 +191,40 @@ def test_flip_merge(capi, cuda):
                                           capi.ptr(oh), capi.ptr(op), capi.current_stream()))
     assert np.array_equal(oh.cpu().numpy(), np.stack(exp_h).astype(np.float32))
     assert np.array_equal(op.cpu().numpy(), np.stack(exp_p).astype(np.float32))
+
+
+@pytest.mark.parametrize("hw,thr,up,seed", [
+    ((368, 392), 0.1, 8, 21),    # ski.jpg geometry: 46 x 49 maps
+    ((184, 320), 0.1, 8, 22),    # wide, small
+    ((368, 368), 0.05, 8, 23),   # lower threshold: more (noise) peaks
+    ((368, 368), 0.2, 8, 24),    # higher threshold
+    ((256, 256), 0.1, 4, 25),    # another cfg.MODEL.DOWNSAMPLE (x4 bicubic refine, x4 nearest PAF indexing)
+    ((552, 368), 0.1, 8, 26),    # tall
+])
+def test_randomised_differential_sweep(dec, synth, cuda, hw, thr, up, seed):
+    """Randomised differential test against the oracle over map shapes, thresholds and up-sampling
+    factors the fixed-size tests do not visit."""
+    import types
+    from oracle import post_oracle as po
+    H, W = hw
+    n = 12
+    heats, pafs = [], []
+    rng = np.random.default_rng(seed)
+    for _ in range(n):
+        people = synth.random_people(rng, int(rng.integers(1, 7)), H, W)
+        hm, pf = synth.render(people, H, W, rng=rng)
+        heats.append(hm)
+        pafs.append(pf)
+    heat, paf = np.stack(heats), np.stack(pafs)
+    cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_KEYPOINTS=18, DOWNSAMPLE=up),
+                                DATASET=types.SimpleNamespace(IMAGE_SIZE=368),
+                                TEST=types.SimpleNamespace(THRESH_HEATMAP=thr))
+    recs = dec.decode_maps(torch.from_numpy(heat).to(cuda), torch.from_numpy(paf).to(cuda), config=cfg)
+    nh = 0
+    for i in range(n):
+        # (tie scenes included: the oracle's default mode implements the product's documented tie
+        # contract - lower (idx1, idx2) first; only the compiled reference's unstable sort differs)
+        jl, r = po.paf_to_pose(heat[i], paf[i], 18, thr, up)
+        _check_against(recs[i], jl, r["parts"], r["score"])
+        nh += len(r["parts"])
+    assert nh >= 20
