@@ -1,27 +1,34 @@
 // bf16 implicit-GEMM convolution for gfx950 (MI355X): bf16 activations and weights,
 // fp32 accumulate (v_mfma_f32_32x32x16_bf16), fused bias (+ReLU) (+2x2 max-pool), output
-// rounded to bf16 (round-to-nearest-even) or kept fp32 (network heads).
+// rounded to bf16 (round-to-nearest-even) or kept fp32 (network heads).  Two compute dtypes:
+//   bf16   (SP = 1): BASELINE config 3 arithmetic - operands rounded to bf16, exact products;
+//   bf16x3 (SP = 2): every fp32 operand carried as hi + lo bf16 pieces, three MFMAs per product -
+//                    fp32-grade results (see conv_tile) at 3/16 of the fp32 MFMA time.
 //
-// BASELINE config 3 ("bf16, multi-scale x4 + flip") path of the same nn.Conv2d / nn.ReLU /
-// nn.MaxPool2d modules the fp32 kernel (conv_mfma.hip) stands in for
-// (lib/network/rtpose_vgg.py:23-35, :49-55).  The reference has no reduced-precision path;
-// the contract here is "bf16 operands, exact products, fp32 accumulation", checked against
-// oracle/net_oracle.py:forward_bf16_emulated.
+// Stands in for the same nn.Conv2d / nn.ReLU / nn.MaxPool2d modules as the fp32 kernel
+// (conv_mfma.hip; lib/network/rtpose_vgg.py:23-35, :49-55).  The reference has no reduced-
+// precision path; the contracts are oracle/net_oracle.py:forward_bf16_emulated /
+// forward_bf16x3_emulated.
 //
-// Same design as the fp32 kernel - shared-gap padded NHWC (now 2 bytes per channel), one LDS
-// halo per channel chunk re-used by all k*k taps, weights straight from L2 with a two-tap
-// register prefetch, one barrier per chunk - re-balanced for a matrix pipe that is 16x
-// faster per byte:
-//  * a 16-byte piece is 8 channels = exactly one lane's share of a K=16 MFMA step, so the
-//    A fragment is still ONE ds_read_b128 and the B fragment ONE 16-byte global load, but
-//    they now feed a single 32-cycle MFMA instead of four 64-cycle ones;
-//  * therefore the wave tile is 64 x 64 (block 128 x 128, 4 waves 2 x 2): each A piece is
-//    used by 2 and each B piece by 2 MFMAs, which keeps LDS reads (256 B/clk/CU) at 25 % and
-//    the L1 -> register path (64 B/clk/CU) just within budget;
-//  * B addresses are a uniform (SGPR) base plus a per-lane 32-bit offset: no VALU in the
-//    tap loop for them;
-//  * the next chunk's halo pieces travel through a 3-deep register ring (fetched at tap t,
-//    parked in LDS at tap t+3): a tap is only 256 cycles, shorter than an HBM/MALL miss.
+// Same skeleton as the fp32 kernel - shared-gap padded NHWC (2 bytes per element), one LDS halo
+// per channel chunk re-used by all k*k taps, weights straight from L2, one barrier per chunk -
+// re-balanced for a matrix pipe that is 16x faster per byte:
+//  * a 16-byte piece is 8 channels = exactly one lane's share of a K=16 MFMA step, so the A
+//    fragment is ONE ds_read_b128 and the B fragment ONE 16-byte load feeding a single 32-cycle
+//    MFMA (fp32: four 64-cycle ones);
+//  * block tile 128 x 128 in two wave arrangements (template WM): 2 x 2 waves of 64 x 64, or
+//    1 x 4 waves of 128 x 32 which halves the weight bytes pulled through the L1 and reads all A
+//    fragments from LDS instead (4x the L1's bandwidth); chosen per kernel size by measurement;
+//  * B through buffer loads: SGPR resource + SGPR tap offset + one per-lane VGPR, so the tap loop
+//    spends no VALU and no address registers on weights; the freed registers pay for a prefetch
+//    ring of up to 4 taps;
+//  * the next chunk's halo pieces travel through a register ring (fetched at tap t, parked in LDS
+//    kHD taps later); the first halo's loads are issued before the block's setup math;
+//  * epilogue: the bias rides in the accumulator from the start; each wave transposes its tile
+//    through LDS and stores 16 bytes per lane.
+// Per-CU timelines (tools/timeline_bf16.py): two co-resident blocks keep the matrix pipe ~96 %
+// busy while both are in their tap loops; what is lost is the per-block prologue (~11k cycles,
+// memory latency) and epilogue (~7k) on a 50k-cycle tile, and the tail of the last round.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
