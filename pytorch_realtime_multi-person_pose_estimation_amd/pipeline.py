@@ -10,7 +10,6 @@ conv wrote), and only the fixed-capacity result records cross PCIe.
 import ctypes as C
 
 import numpy as np
-import torch
 
 from . import _capi, decode as dec
 from ._capi import lib, check, ptr, current_stream

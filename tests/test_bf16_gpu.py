@@ -13,7 +13,6 @@ fp32.  Tolerances are written next to each check:
 """
 import ctypes as C
 
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
