@@ -79,3 +79,91 @@ class PoseEstimator(object):
         for r in recs:
             out.append(dec.humans_from_record(r, w * up, h * up, int(self.config.MODEL.NUM_KEYPOINTS)))
         return out
+
+
+class StreamingPoseEstimator(object):
+    """Host images in, host records out, with the PCIe legs overlapped with compute.
+
+    The reference moves one fp32 image per call (`get_outputs`, evaluate/coco_eval.py:96-110: H2D of
+    1.6 MB, D2H of 0.48 MB of maps).  Here a batch of uint8 BGR images (3 B/pixel) is uploaded on a
+    separate copy stream while the previous batch is still in the network; the compute stream does
+    resize + pad + normalise (rtpose_preprocess_u8) straight into the plan's input buffer, the
+    forward and the decode; only the fixed-size result records come back.  Two pinned host / device
+    staging pairs ping-pong; events order the two streams (no host synchronisation inside a batch).
+    """
+
+    def __init__(self, model, batch, h0, w0, preprocess='rtpose', config=None, max_peaks_per_part=32,
+                 max_humans=64):
+        import torch
+        from . import preprocess as pre
+        self.model = model
+        self.config = config or dec.default_config()
+        self.B, self.h0, self.w0 = batch, h0, w0
+        self.mode = {'rtpose': 0, 'vgg': 1}[preprocess]
+        size, factor = int(self.config.DATASET.IMAGE_SIZE), int(self.config.MODEL.DOWNSAMPLE)
+        self.im_scale = float(size) / min(h0, w0)
+        self.hr, self.wr = pre._cv_round(h0 * self.im_scale), pre._cv_round(w0 * self.im_scale)
+        self.hn, self.wn = pre._factor_closest(self.hr, factor), pre._factor_closest(self.wr, factor)
+        self.dev = torch.device('cuda', torch.cuda.current_device())
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
+        self.host = [torch.empty((batch, h0, w0, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.devbuf = [torch.empty((batch, h0, w0, 3), dtype=torch.uint8, device=self.dev) for _ in range(2)]
+        self.uploaded = [torch.cuda.Event() for _ in range(2)]
+        self.consumed = [torch.cuda.Event() for _ in range(2)]
+        for e in self.consumed:
+            e.record(torch.cuda.current_stream())
+        cfg = dec.make_cfg(self.config, max_peaks_per_part, max_humans)
+        self.bufs = dec.DecodeBuffers(cfg, batch, self.dev)
+        self._torch = torch
+
+    def _upload(self, slot, images):
+        torch = self._torch
+        self.host[slot].copy_(torch.from_numpy(images))       # host -> pinned (the caller's array may be pageable)
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(self.consumed[slot])   # the kernels that read this slot are done
+            self.devbuf[slot].copy_(self.host[slot], non_blocking=True)
+            self.uploaded[slot].record(self.copy_stream)
+
+    def _compute(self, slot):
+        torch = self._torch
+        m = self.model
+        main = torch.cuda.current_stream()
+        main.wait_event(self.uploaded[slot])
+        plan = m.plan_for_shape(self.B, self.hn, self.wn, self.dev)
+        ibase, ilay = C.c_void_p(), _capi.Layout()
+        check(lib.rtpose_net_input_view(plan.handle, C.byref(ibase), C.byref(ilay)), "rtpose_net_input_view")
+        s = current_stream()
+        img_bytes = self.h0 * self.w0 * 3
+        for b in range(self.B):
+            check(lib.rtpose_preprocess_u8(C.c_void_p(self.devbuf[slot].data_ptr() + b * img_bytes), self.h0, self.w0,
+                                           self.im_scale, self.mode, ibase, C.byref(ilay), b, self.hn, self.wn,
+                                           self.hr, self.wr, s), "rtpose_preprocess_u8")
+        self.consumed[slot].record(main)
+        check(lib.rtpose_net_set_keep_intermediates(plan.handle, 0))
+        check(lib.rtpose_net_forward_prepared(plan.handle, s), "rtpose_net_forward_prepared")
+        pbase, lpaf, _, h, w = m.output_view(plan, 0)
+        hbase, lheat, _, _, _ = m.output_view(plan, 1)
+        dec.decode_enqueue(hbase, lheat, pbase, lpaf, self.B, h, w, self.bufs)
+        return dec.fetch(self.bufs).copy()                     # D2H of the records + stream sync
+
+    def run(self, batches):
+        """batches: iterable of uint8 arrays [B, h0, w0, 3] (BGR).  Yields one int32 record block
+        [B, words] per batch (decode.parse_image / humans_from_record turn them into Humans)."""
+        it = iter(batches)
+        try:
+            cur = next(it)
+        except StopIteration:
+            return
+        slot = 0
+        self._upload(slot, cur)
+        while True:
+            try:
+                nxt = next(it)
+            except StopIteration:
+                nxt = None
+            if nxt is not None:
+                self._upload(slot ^ 1, nxt)     # next batch's H2D runs under this batch's kernels
+            yield self._compute(slot)
+            if nxt is None:
+                return
+            slot ^= 1

@@ -191,3 +191,30 @@ def test_multiscale_batch_matches_per_image(compat, cuda):
             model.set_compute_dtype('fp32')
     recs = dec.decode_maps(heat_b, paf_b)
     assert len(recs) == 3 and all(r["flags"] == 0 or r["n_peaks"] > 0 for r in recs)
+
+
+def test_streaming_estimator_matches_direct_path(compat, cuda):
+    """StreamingPoseEstimator (uint8 upload on a copy stream, GPU image prep, forward, decode) returns
+    the records the direct path computes for the same images, batch after batch."""
+    from lib.network.rtpose_vgg import get_model
+    from oracle import net_oracle
+    pipeline = importlib.import_module(PKG_NAME + ".pipeline")
+    pre = importlib.import_module(PKG_NAME + ".preprocess")
+    dec = importlib.import_module(PKG_NAME + ".decode")
+    model = get_model('vgg19')
+    model.load_state_dict(net_oracle.he_init_state_dict(model, seed=0))
+    model = model.cuda().eval()
+    rng = np.random.default_rng(4)
+    B, h0, w0 = 3, 120, 150
+    batches = [np.clip(rng.normal(128, 6, (B, h0, w0, 3)), 0, 255).astype(np.uint8) for _ in range(4)]
+    est = pipeline.StreamingPoseEstimator(model, B, h0, w0, max_peaks_per_part=512, max_humans=512)
+    got = list(est.run(batches))
+    assert len(got) == 4
+    for rec_block, imgs in zip(got, batches):
+        for b in range(B):
+            paf, heat, _ = pre.get_outputs_gpu(imgs[b], model, 'rtpose')
+            ref = dec.decode_maps(torch.from_numpy(heat).to(cuda)[None], torch.from_numpy(paf).to(cuda)[None],
+                                  max_peaks_per_part=512, max_humans=512)[0]
+            r = dec.parse_image(rec_block[b], est.bufs.cfg)
+            assert r["flags"] == 0
+            assert np.array_equal(r["peaks"], ref["peaks"]) and np.array_equal(r["parts"], ref["parts"])
