@@ -774,6 +774,16 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
     nf_env = e ? atoi(e) : 1;
   }
   pl.nf = (nf_env == 2 && d0.k != 1 && pl.ck == 16 && pl.nbuf == 2 && cout_pad(d0.cout) % 128 == 0) ? 2 : 1;
+  {
+    // 1x1 layers with >= 128 padded output channels: 128-wide N tiles halve the number of blocks
+    // that each re-stage the same input tile (developer A/B: RTPOSE_CONV_NF1X1=1|2)
+    static int nf1 = 0;
+    if (!nf1) {
+      const char* e = getenv("RTPOSE_CONV_NF1X1");
+      nf1 = e ? atoi(e) : 1;
+    }
+    if (nf1 == 2 && d0.k == 1 && pl.ck == 16 && pl.nbuf == 1 && cout_pad(d0.cout) % 128 == 0) pl.nf = 2;
+  }
   a.ntiles = cout_pad(d0.cout) / (kConvBN * pl.nf);
   a.ncombo = a.ntiles * ngroups;
   a.xcd_remap = (xcd_remap_env != 0 && a.ncombo > 1 && a.mtiles >= 64) ? 1 : 0;
@@ -810,6 +820,8 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
   }
 #define RTPOSE_CONV_CASE(KS_, CK_, MODE_)                                  \
   if (d0.k == KS_ && pl.ck == CK_ && pl.mode == MODE_) {                   \
+    if (pl.nbuf == 1 && pl.nf == 2 && KS_ == 1 && CK_ == 16)                \
+      return launch_inst<KS_, CK_, MODE_, 1, (KS_ == 1 && CK_ == 16) ? 2 : 1>(a, grid, pl.lds_bytes, s); \
     if (pl.nbuf == 1) return launch_inst<KS_, CK_, MODE_, 1, 1>(a, grid, pl.lds_bytes, s); \
     if (pl.nf == 2 && KS_ != 1 && CK_ == 16)                               \
       return launch_inst<KS_, CK_, MODE_, 2, (KS_ != 1 && CK_ == 16) ? 2 : 1>(a, grid, pl.lds_bytes, s); \
