@@ -259,6 +259,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     fill_halo(in_base, min(TB, nchunks));
     __syncthreads();
   }
+  // (NBUF 1, measured and rejected: issuing chunk c+1's loads before chunk c is multiplied and
+  //  parking them afterwards - "load early / write late" - made the ShuffleNetV2 pointwise layers
+  //  5-15 % SLOWER than the plain refill below with 4 blocks per CU hiding each other's latency.)
 
   floatx16 acc[MF][NF];
 #pragma unroll
@@ -464,6 +467,30 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   const float bias = g.bias[ncolf];  // bias is padded to cout_pad
   float* out_base = g.out + ((g.out_cmap && col_ok) ? g.out_cmap[ncolf] : g.out_choff + ncolf);
   if (!A.pool) {
+    // strip mode: the lane's rows are m0 + wm*32*MF + 4*kh + {0,1,2,3, 8,9,10,11, 16,...}: pixel
+    // coordinates by ONE division pair, then stepped (+1,+1,+1,+5 repeating).  An integer division
+    // is ~40 VALU instructions; 32 of them per lane were longer than the whole tap loop of a
+    // short-K 1x1 conv (ShuffleNetV2 pointwise: 8k MFMA cycles per block).
+    int sn = 0, sy = 0, sx = 0;
+    if (MODE == 0) {
+      const int m = m0 + wm * (32 * MF) + 4 * kh;
+      const int HW = A.H * A.W;
+      sn = m / HW;
+      const int r = m - sn * HW;
+      sy = r / A.W;
+      sx = r - sy * A.W;
+    }
+    auto step = [&](int d) {
+      sx += d;
+      while (sx >= A.W) {
+        sx -= A.W;
+        if (++sy >= A.H) {
+          sy = 0;
+          ++sn;
+        }
+      }
+    };
+    (void)step;
 #pragma unroll
     for (int fm = 0; fm < MF; ++fm) {
 #pragma unroll
@@ -476,13 +503,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
           int n, y, x;
           bool ok;
           if (MODE == 0) {
-            const int m = m0 + ml;
-            ok = m < A.M;
-            const int HW = A.H * A.W;
-            n = m / HW;
-            const int r = m - n * HW;
-            y = r / A.W;
-            x = r - y * A.W;
+            ok = m0 + ml < A.M;
+            n = sn;
+            y = sy;
+            x = sx;
+            step(rr == 3 ? 5 : 1);  // (the walk restarts with every n-fragment)
           } else {
             int ty, tx;
             tile_local_yx(ml, A.tw_log2, ty, tx);
@@ -640,7 +665,7 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* p
     const int lb = (kBM - 1) + ((kBM - 1) / W + 1) * (l.ws - W) +
                    ((kBM - 1) / (H * W) + 1) * (l.hs - H) * l.ws + 2 * P * l.ws + 2 * P + 1;
     const int qs = round_qs(lb);
-    const size_t lds = (size_t)pl->nbuf * cg * qs * 16 + (pl->nbuf == 2 ? 256 * 16 : 0);
+    const size_t lds = (size_t)pl->nbuf * cg * qs * 16 + 256 * 16;  // + one dummy park slot per thread
     if ((pl->nbuf == 2 && ceil_div(qs * cg, 256) > max_pieces) || lds > 80 * 1024) strip = false;
     if (strip) {
       pl->mode = 0;
@@ -677,7 +702,7 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* p
   pl->tiles_x = ceil_div(W, tw);
   pl->tiles_y = ceil_div(H, th);
   pl->grid_x = N * pl->tiles_x * pl->tiles_y;
-  pl->lds_bytes = (size_t)pl->nbuf * cg * pl->qs * 16 + (pl->nbuf == 2 ? 256 * 16 : 0);
+  pl->lds_bytes = (size_t)pl->nbuf * cg * pl->qs * 16 + 256 * 16;
   if (pl->nbuf == 2 && ceil_div(pl->qs * cg, 256) > max_pieces)
     return fail(RTPOSE_E_INVAL, "conv halo too large for the staging schedule");
   return 0;
