@@ -168,15 +168,31 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
 
   // ---- per-lane A fragment bases (LDS pixel index of this lane's row) ------
   int abase[MF];
+  int an = 0, ay = 0, ax = 0;  // strip mode: coordinates of fragment 0's row, stepped by 32 pixels
+  if (MODE == 0) {
+    const int m = m0 + wm * (32 * MF) + l31;
+    const int HW = A.H * A.W;
+    an = m / HW;
+    const int r = m - an * HW;
+    ay = r / A.W;
+    ax = r - ay * A.W;
+  }
 #pragma unroll
   for (int fm = 0; fm < MF; ++fm) {
     const int ml = wm * (32 * MF) + fm * 32 + l31;
     if (MODE == 0) {
-      const int m = min(m0 + ml, A.M - 1);
-      const int HW = A.H * A.W;
-      const int n = m / HW, r = m - n * HW;
-      const int y = r / A.W, x = r - y * A.W;
+      // rows past the end of the tensor (last strip) read the last real pixel's halo
+      const bool past = m0 + ml > A.M - 1;
+      const int n = past ? A.N - 1 : an, y = past ? A.H - 1 : ay, x = past ? A.W - 1 : ax;
       abase[fm] = g.in_lead + (n * g.in_hs + y) * g.in_ws + x - qc0;
+      ax += 32;
+      while (ax >= A.W) {
+        ax -= A.W;
+        if (++ay >= A.H) {
+          ay = 0;
+          ++an;
+        }
+      }
     } else {
       int ty, tx;
       tile_local_yx(ml, A.tw_log2, ty, tx);
@@ -263,13 +279,17 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   //  parking them afterwards - "load early / write late" - made the ShuffleNetV2 pointwise layers
   //  5-15 % SLOWER than the plain refill below with 4 blocks per CU hiding each other's latency.)
 
+  // the bias is fetched now (at the epilogue its latency would be fully exposed) and rides in
+  // the accumulator: every register of a lane belongs to the lane's output channel
   floatx16 acc[MF][NF];
 #pragma unroll
-  for (int fm = 0; fm < MF; ++fm)
+  for (int fn = 0; fn < NF; ++fn) {
+    const float b0 = g.bias[ncol + fn * 32];  // bias is padded to cout_pad
 #pragma unroll
-    for (int fn = 0; fn < NF; ++fn)
+    for (int fm = 0; fm < MF; ++fm)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[fm][fn][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[fm][fn][r] = b0;
+  }
 
   // LDS float4 offsets of this lane's A fragments inside a halo buffer: [k-group][m-frag]
   int afrag[G][MF];
@@ -464,7 +484,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   for (int fn = 0; fn < NF; ++fn) {
   const int ncolf = ncol + fn * 32;
   const bool col_ok = ncolf < g.cout;
-  const float bias = g.bias[ncolf];  // bias is padded to cout_pad
   float* out_base = g.out + ((g.out_cmap && col_ok) ? g.out_cmap[ncolf] : g.out_choff + ncolf);
   if (!A.pool) {
     // strip mode: the lane's rows are m0 + wm*32*MF + 4*kh + {0,1,2,3, 8,9,10,11, 16,...}: pixel
@@ -516,7 +535,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
             x = x0 + tx;
             ok = (y < A.H) && (x < A.W);
           }
-          float v = acc[fm][fn][rg * 4 + rr] + bias;
+          float v = acc[fm][fn][rg * 4 + rr];
           if (A.relu) v = fmaxf(v, 0.f);
           if (ok && col_ok) {
             const size_t q = (size_t)g.out_lead + (size_t)(n * g.out_hs + y) * g.out_ws + x;
@@ -538,7 +557,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
         const int py = (y0 >> 1) + (qi >> hw_log2);
         const int px = (x0 >> 1) + (qi & ((1 << hw_log2) - 1));
         float v = fmaxf(fmaxf(acc[fm][fn][rg * 4 + 0], acc[fm][fn][rg * 4 + 1]),
-                        fmaxf(acc[fm][fn][rg * 4 + 2], acc[fm][fn][rg * 4 + 3])) + bias;
+                        fmaxf(acc[fm][fn][rg * 4 + 2], acc[fm][fn][rg * 4 + 3]));
         if (A.relu) v = fmaxf(v, 0.f);
         if (py < Ho && px < Wo && col_ok) {
           const size_t q = (size_t)g.out_lead + (size_t)(n_img * g.out_hs + py) * g.out_ws + px;
