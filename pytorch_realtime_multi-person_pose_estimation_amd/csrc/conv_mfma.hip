@@ -69,7 +69,14 @@ struct ConvArgs {
   int ncombo, xcd_remap;
   int dephase_mode;          // 0 off, 1: ids [n_cu, 2 n_cu), 2: odd ids (first wave of blocks only)
   int dephase_cycles, n_cu;  // start-up delay that puts the 2 blocks of a CU half a tile apart
+  unsigned long long* dbg;   // RTPOSE_EXP_TIMELINE builds only: 8 x u64 per block
 };
+#ifdef RTPOSE_EXP_TIMELINE
+#define RTPOSE_TSTAMP(slot) \
+  if (A.dbg && threadIdx.x == 0) A.dbg[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime()
+#else
+#define RTPOSE_TSTAMP(slot)
+#endif
 
 constexpr int kBM = 128;
 // 1x1 convs: CK-channel sub-chunks per LDS buffer (see conv_tile); developer knob
@@ -279,6 +286,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   //  parking them afterwards - "load early / write late" - made the ShuffleNetV2 pointwise layers
   //  5-15 % SLOWER than the plain refill below with 4 blocks per CU hiding each other's latency.)
 
+  RTPOSE_TSTAMP(1);
   // the bias is fetched now (at the epilogue its latency would be fully exposed) and rides in
   // the accumulator: every register of a lane belongs to the lane's output channel
   floatx16 acc[MF][NF];
@@ -478,6 +486,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
 #undef RTPOSE_CONV_ROW
 #undef RTPOSE_CONV_STEP
 #undef RTPOSE_PIN
+  RTPOSE_TSTAMP(2);
 
   // ---- epilogue: bias (+ReLU) (+2x2 max-pool), masked stores -----------------
 #pragma unroll
@@ -567,6 +576,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     }
   }
   }  // fn
+  RTPOSE_TSTAMP(3);
+#ifdef RTPOSE_EXP_TIMELINE
+  __builtin_amdgcn_s_waitcnt(0);
+  RTPOSE_TSTAMP(4);
+#endif
 }
 
 // Kernel: 1-D grid, block id -> (group, N tile, M tile).
@@ -581,6 +595,7 @@ template <int KS, int CK, int MODE, int NBUF, int NF>
 __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void conv_mfma_f32(const ConvArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int L = blockIdx.x;
+  RTPOSE_TSTAMP(0);
   // Equal tiles keep the two co-resident blocks of a CU in lock step, so their prologues
   // (first halo fill, ~2 us of exposed latency) and epilogues coincide instead of hiding
   // under each other's MFMAs.  Half of the first wave of blocks starts half a tile late.
@@ -850,6 +865,23 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
     if (total <= n_cu && !(e && e[0] == '1')) a.nbig = 0;
   }
   dim3 grid((unsigned)(a.nbig + 2 * (ids - a.nbig)), 1, 1);
+#ifdef RTPOSE_EXP_TIMELINE
+  {  // developer build: stamps of the LAST launch with kernel size RTPOSE_TIMELINE_K (default 1)
+    extern unsigned long long* g_dbg32_buf;
+    extern unsigned g_dbg32_blocks;
+    static int kk = 0;
+    if (!kk) {
+      const char* e = getenv("RTPOSE_TIMELINE_K");
+      kk = e ? atoi(e) : 1;
+    }
+    if (!g_dbg32_buf) (void)hipMalloc(&g_dbg32_buf, (size_t)32768 * 8 * 8);
+    if (d0.k == kk && grid.x <= 32768) {
+      (void)hipMemsetAsync(g_dbg32_buf, 0, (size_t)grid.x * 64, s);
+      a.dbg = g_dbg32_buf;
+      g_dbg32_blocks = grid.x;
+    }
+  }
+#endif
   {
     static int dephase_env = -1;
     if (dephase_env < 0) {
@@ -886,6 +918,11 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
 #undef RTPOSE_CONV_CASE
   return fail(RTPOSE_E_INVAL, "conv2d: no kernel instance for k=%d ck=%d mode=%d", d0.k, pl.ck, pl.mode);
 }
+
+#ifdef RTPOSE_EXP_TIMELINE
+unsigned long long* g_dbg32_buf = nullptr;
+unsigned g_dbg32_blocks = 0;
+#endif
 
 int pack_weights_launch(const float* w, const float* bias, int cout, int cin_src, int k,
                         const int32_t* cin_map, int cin_packed, float* wp, float* bp, hipStream_t s) {
@@ -925,3 +962,14 @@ int rtpose_conv2d(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, v
 }
 
 }  // extern "C"
+
+#ifdef RTPOSE_EXP_TIMELINE
+extern "C" int rtpose_debug_timeline32_dump(unsigned long long* host, unsigned cap_blocks) {
+  using namespace rtpose;
+  if (!g_dbg32_buf) return 0;
+  (void)hipDeviceSynchronize();
+  const unsigned n = g_dbg32_blocks < cap_blocks ? g_dbg32_blocks : cap_blocks;
+  (void)hipMemcpy(host, g_dbg32_buf, (size_t)n * 64, hipMemcpyDeviceToHost);
+  return (int)n;
+}
+#endif
