@@ -207,6 +207,19 @@ int rtpose_stem_conv3x3_s2_nchw(const float* x_nchw, const float* scale, const f
                                 const float* w, const float* bias, float* out,
                                 const rtpose_layout* lout, int cout, int N, int H, int W,
                                 int relu, void* stream);
+int rtpose_stem_conv3x3_s2_nchw_ex(const float* x_nchw, const float* scale, const float* shift,
+                                   const float* w, const float* bias, void* out,
+                                   const rtpose_layout* lout, int cout, int N, int H, int W,
+                                   int relu, int out_bf16, void* stream);
+/* bf16 forms (bf16 plans: 2-byte activations, fp32 arithmetic, fp32 weights; C % 8 == 0) */
+int rtpose_maxpool3x3s2_ceil_bf16(const void* in, const rtpose_layout* lin, void* out,
+                                  const rtpose_layout* lout, int C, int N, int H, int W, void* stream);
+int rtpose_dwconv3x3_bf16(const void* in, const rtpose_layout* lin, const float* w, const float* bias,
+                          void* out, const rtpose_layout* lout, int C, int N, int H, int W, int stride,
+                          void* stream);
+int rtpose_layout_copy_cmap_bf16(const void* src, const rtpose_layout* lsrc, void* dst,
+                                 const rtpose_layout* ldst, int C, const int32_t* cmap, int N, int H,
+                                 int W, void* stream);
 /* MaxPool2d(3, 2, 0, ceil_mode=True) (:98) */
 int rtpose_maxpool3x3s2_ceil(const float* in, const rtpose_layout* lin, float* out,
                              const rtpose_layout* lout, int C, int N, int H, int W, void* stream);
@@ -299,6 +312,9 @@ int rtpose_net_launch_info(rtpose_net* net, int i, float* ms, int* k,
  * ---------------------------------------------------------------------- */
 typedef struct rtpose_shufflenet rtpose_shufflenet;
 int rtpose_shufflenet_create(int N, int H, int W, rtpose_shufflenet** out);
+/* dtype: RTPOSE_DTYPE_F32 or RTPOSE_DTYPE_BF16 (bf16 activations + pointwise weights, fp32
+ * accumulate; depthwise / stem weights and all biases stay fp32; outputs fp32) */
+int rtpose_shufflenet_create_ex(int N, int H, int W, int dtype, rtpose_shufflenet** out);
 void rtpose_shufflenet_destroy(rtpose_shufflenet* net);
 size_t rtpose_shufflenet_workspace_bytes(const rtpose_shufflenet* net);
 size_t rtpose_shufflenet_weight_bytes(const rtpose_shufflenet* net);

@@ -140,3 +140,57 @@ def forward(sd, x):
         paf = F.conv2d(x, sd["paf.weight"], sd["paf.bias"])
         heat = F.conv2d(x, sd["heatmap.weight"], sd["heatmap.bias"])
     return paf, heat
+
+
+# ---- bf16 restatement (BASELINE config 4 "fp32 and bf16") ------------------------------------
+# The product's bf16 plan: BatchNorm folded into the conv (fp32), pointwise weights rounded to
+# bf16, depthwise / stem weights and all biases fp32, fp32 accumulation, every stored activation
+# rounded to bf16 (the passthrough half is a bit copy), heads written fp32.  "parity unpinned"
+# like the fp32 restatement (the slim stub defines the reference); checked against forward() by
+# tolerance.
+def _rb(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _fold(sd, p):
+    s = sd[p + ".1.weight"] / torch.sqrt(sd[p + ".1.running_var"] + BN_EPS)
+    return sd[p + ".0.weight"] * s.view(-1, 1, 1, 1), sd[p + ".1.bias"] - sd[p + ".1.running_mean"] * s
+
+
+def _cbr_bf16(sd, p, x, relu, stride=1, padding=0, groups=1, round_w=True):
+    w, b = _fold(sd, p)
+    if round_w:
+        w = _rb(w)
+    y = F.conv2d(x.double(), w.double(), b.double(), stride, padding, 1, groups).float()
+    return _rb(F.relu(y) if relu else y)
+
+
+def _block_bf16(sd, p, x, stride, two_branch):
+    def conv(z):
+        z = _cbr_bf16(sd, p + ".conv.0", z, True)
+        z = _cbr_bf16(sd, p + ".conv.1", z, False, stride, 1, z.shape[1], round_w=False)   # depthwise: fp32 weights
+        return _cbr_bf16(sd, p + ".conv.2", z, True)
+    if not two_branch:
+        half = x.shape[1] // 2
+        x = torch.cat((x[:, :half], conv(x[:, half:])), 1)
+    else:
+        z = _cbr_bf16(sd, p + ".conv0.0", x, False, stride, 1, x.shape[1], round_w=False)
+        z = _cbr_bf16(sd, p + ".conv0.1", z, True)
+        x = torch.cat((z, conv(x)), 1)
+    return _shuffle(x)
+
+
+def forward_bf16_emulated(sd, x):
+    sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+    x = x.detach().float().cpu()
+    with torch.no_grad():
+        x = _bn(sd, "network.0", x)                                   # fp32 affine on the fp32 image
+        x = _cbr_bf16(sd, "network.1", x, True, 2, 1, round_w=False)  # stem: fp32 weights, bf16 output
+        x = F.max_pool2d(x, 3, 2, 0, ceil_mode=True)
+        for si, (nblocks, stride) in enumerate(((4, 2), (8, 1), (4, 1))):
+            for b in range(nblocks):
+                x = _block_bf16(sd, "network.%d.%d" % (3 + si, b), x, stride if b == 0 else 1, b == 0)
+        x = _cbr_bf16(sd, "network.6", x, True)
+        paf = F.conv2d(x.double(), _rb(sd["paf.weight"]).double(), sd["paf.bias"].double()).float()
+        heat = F.conv2d(x.double(), _rb(sd["heatmap.weight"]).double(), sd["heatmap.bias"].double()).float()
+    return paf, heat

@@ -31,6 +31,13 @@ __device__ __forceinline__ size_t lay_off(const Lay& l, int n, int y, int x) {
   return ((size_t)l.lead + (size_t)(n * l.hs + y) * l.ws + x) * l.cstride + l.choff;
 }
 
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float v) {
+  return __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) {
+  return __uint_as_float((unsigned)h << 16);
+}
+
 // One thread per (pixel, channel) with channel fastest on the NHWC side; the
 // NCHW side is strided by H*W, served from L2 (tensors here are small or read
 // once).  Used for the 3-channel input image and the 38/19-channel outputs.
@@ -345,7 +352,7 @@ template <int COUT>
 __global__ void stem_conv3x3_s2_nchw_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                             const float* __restrict__ shift, const float* __restrict__ w,
                                             const float* __restrict__ bias, float* __restrict__ out, Lay lo,
-                                            int N, int H, int W, int Ho, int Wo, int relu) {
+                                            int N, int H, int W, int Ho, int Wo, int relu, int out_bf16) {
   constexpr int C4 = COUT / 4;
   const size_t total = (size_t)N * Ho * Wo;
   size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -381,18 +388,31 @@ __global__ void stem_conv3x3_s2_nchw_kernel(const float* __restrict__ x, const f
       }
     }
   }
-  float* op = out + lay_off(lo, n, oy, ox);
 #pragma unroll
   for (int j = 0; j < C4; ++j) {
-    float4 a = acc[j];
     if (relu) {
-      a.x = fmaxf(a.x, 0.f);
-      a.y = fmaxf(a.y, 0.f);
-      a.z = fmaxf(a.z, 0.f);
-      a.w = fmaxf(a.w, 0.f);
+      acc[j].x = fmaxf(acc[j].x, 0.f);
+      acc[j].y = fmaxf(acc[j].y, 0.f);
+      acc[j].z = fmaxf(acc[j].z, 0.f);
+      acc[j].w = fmaxf(acc[j].w, 0.f);
     }
-    *reinterpret_cast<float4*>(op + 4 * j) = a;
   }
+  if (out_bf16) {  // uniform: bf16 plans keep the stem output as 2-byte elements
+    unsigned short* oh = reinterpret_cast<unsigned short*>(out) + lay_off(lo, n, oy, ox);
+#pragma unroll
+    for (int j = 0; j < C4; j += 2) {
+      uint4 u;
+      u.x = f32_to_bf16_rne(acc[j].x) | ((unsigned)f32_to_bf16_rne(acc[j].y) << 16);
+      u.y = f32_to_bf16_rne(acc[j].z) | ((unsigned)f32_to_bf16_rne(acc[j].w) << 16);
+      u.z = f32_to_bf16_rne(acc[j + 1].x) | ((unsigned)f32_to_bf16_rne(acc[j + 1].y) << 16);
+      u.w = f32_to_bf16_rne(acc[j + 1].z) | ((unsigned)f32_to_bf16_rne(acc[j + 1].w) << 16);
+      *reinterpret_cast<uint4*>(oh + 4 * j) = u;
+    }
+    return;
+  }
+  float* op = out + lay_off(lo, n, oy, ox);
+#pragma unroll
+  for (int j = 0; j < C4; ++j) *reinterpret_cast<float4*>(op + 4 * j) = acc[j];
 }
 
 template <int COUT>
@@ -548,12 +568,6 @@ static inline unsigned nblocks(size_t total, int threads) {
 
 
 // ---- bf16 activation buffers (conv_mfma_bf16.hip): conversions at the edges of the net ----
-__device__ __forceinline__ unsigned short f32_to_bf16_rne(float v) {
-  return __builtin_bit_cast(unsigned short, (__bf16)v);
-}
-__device__ __forceinline__ float bf16_to_f32(unsigned short h) {
-  return __uint_as_float((unsigned)h << 16);
-}
 
 // One thread per (pixel, 8-channel piece): 16-byte stores.  src is dense NCHW fp32 (SRC_NCHW)
 // or a layout slice; channels [C, cpad) are written as zero.
@@ -672,6 +686,117 @@ __global__ void layout_split_to_f32_kernel(const unsigned short* __restrict__ sr
   dst[lay_off(ld, n, y, x) + c] = bf16_to_f32(s[0]) + bf16_to_f32(s[8]);
 }
 
+
+// ---- bf16 forms of the ShuffleNetV2 building blocks (bf16 plans, BASELINE config 4 "fp32 and
+//      bf16"): bf16 activations in HBM, fp32 arithmetic, 8 channels (16 bytes) per thread ----
+struct bf8 {
+  float v[8];
+};
+__device__ __forceinline__ bf8 load_bf8(const unsigned short* p) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  bf8 r;
+  r.v[0] = __uint_as_float(u.x << 16);
+  r.v[1] = __uint_as_float(u.x & 0xffff0000u);
+  r.v[2] = __uint_as_float(u.y << 16);
+  r.v[3] = __uint_as_float(u.y & 0xffff0000u);
+  r.v[4] = __uint_as_float(u.z << 16);
+  r.v[5] = __uint_as_float(u.z & 0xffff0000u);
+  r.v[6] = __uint_as_float(u.w << 16);
+  r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ void store_bf8(unsigned short* p, const bf8& r) {
+  uint4 u;
+  u.x = f32_to_bf16_rne(r.v[0]) | ((unsigned)f32_to_bf16_rne(r.v[1]) << 16);
+  u.y = f32_to_bf16_rne(r.v[2]) | ((unsigned)f32_to_bf16_rne(r.v[3]) << 16);
+  u.z = f32_to_bf16_rne(r.v[4]) | ((unsigned)f32_to_bf16_rne(r.v[5]) << 16);
+  u.w = f32_to_bf16_rne(r.v[6]) | ((unsigned)f32_to_bf16_rne(r.v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+
+__global__ void maxpool3x3s2_ceil_bf16_kernel(const unsigned short* __restrict__ src, Lay ls,
+                                              unsigned short* __restrict__ dst, Lay ld, int C, int N, int H,
+                                              int W, int Ho, int Wo) {
+  const int c8 = C >> 3;
+  const size_t total = (size_t)N * Ho * Wo * c8;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (i % c8) * 8;
+  size_t p = i / c8;
+  const int x = p % Wo;
+  p /= Wo;
+  const int y = p % Ho;
+  const int n = p / Ho;
+  bf8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r.v[e] = -INFINITY;
+  for (int dy = 0; dy < 3; ++dy)
+    for (int dx = 0; dx < 3; ++dx) {
+      const int yy = 2 * y + dy, xx = 2 * x + dx;
+      if (yy < H && xx < W) {
+        const bf8 v = load_bf8(src + lay_off(ls, n, yy, xx) + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r.v[e] = fmaxf(r.v[e], v.v[e]);
+      }
+    }
+  store_bf8(dst + lay_off(ld, n, y, x) + c, r);
+}
+
+__global__ void dwconv3x3_bf16_kernel(const unsigned short* __restrict__ in, Lay li, const float* __restrict__ w,
+                                      const float* __restrict__ bias, unsigned short* __restrict__ out, Lay lo,
+                                      int C, int N, int Ho, int Wo, int stride) {
+  const int c8 = C >> 3;
+  const size_t total = (size_t)N * Ho * Wo * c8;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (i % c8) * 8;
+  size_t p = i / c8;
+  const int x = p % Wo;
+  p /= Wo;
+  const int y = p % Ho;
+  const int n = p / Ho;
+  bf8 acc;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc.v[e] = bias[c + e];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const unsigned short* ip = in + (long long)lay_off(li, n, stride * y + ky, stride * x + kx) -
+                                 (long long)(li.ws + 1) * li.cstride + c;
+      const bf8 v = load_bf8(ip);
+      const float* wp = w + (size_t)(ky * 3 + kx) * C + c;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc.v[e] += v.v[e] * wp[e];
+    }
+  store_bf8(out + lay_off(lo, n, y, x) + c, acc);
+}
+
+// 8 consecutive source channels per thread (one 16-byte load), up to 8 mapped 2-byte stores
+__global__ void layout_copy_cmap_bf16_kernel(const unsigned short* __restrict__ src, Lay ls,
+                                             unsigned short* __restrict__ dst, Lay ld, int C,
+                                             const int32_t* __restrict__ cmap, int N, int H, int W) {
+  const int c8 = (C + 7) >> 3;
+  const size_t total = (size_t)N * H * W * c8;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (i % c8) * 8;
+  size_t p = i / c8;
+  const int x = p % W;
+  p /= W;
+  const int y = p % H;
+  const int n = p / H;
+  const uint4 u = *reinterpret_cast<const uint4*>(src + lay_off(ls, n, y, x) + c);
+  const unsigned short e[8] = {(unsigned short)(u.x & 0xffff), (unsigned short)(u.x >> 16),
+                               (unsigned short)(u.y & 0xffff), (unsigned short)(u.y >> 16),
+                               (unsigned short)(u.z & 0xffff), (unsigned short)(u.z >> 16),
+                               (unsigned short)(u.w & 0xffff), (unsigned short)(u.w >> 16)};
+  unsigned short* d = dst + lay_off(ld, n, y, x) - ld.choff;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (c + j < C) d[cmap[c + j]] = e[j];
+}
+
 }  // namespace rtpose
 
 using namespace rtpose;
@@ -776,13 +901,21 @@ int rtpose_stem_conv3x3_s2(const float* in, const rtpose_layout* lin, const floa
 int rtpose_stem_conv3x3_s2_nchw(const float* x_nchw, const float* scale, const float* shift, const float* w,
                                 const float* bias, float* out, const rtpose_layout* lout, int cout, int N, int H,
                                 int W, int relu, void* stream) {
-  if (cout != 24 || (lout->cstride % 4) || (lout->choff % 4))
+  return rtpose_stem_conv3x3_s2_nchw_ex(x_nchw, scale, shift, w, bias, out, lout, cout, N, H, W, relu, 0, stream);
+}
+
+int rtpose_stem_conv3x3_s2_nchw_ex(const float* x_nchw, const float* scale, const float* shift, const float* w,
+                                   const float* bias, void* out_v, const rtpose_layout* lout, int cout, int N,
+                                   int H, int W, int relu, int out_bf16, void* stream) {
+  float* out = static_cast<float*>(out_v);
+  const int al = out_bf16 ? 8 : 4;
+  if (cout != 24 || (lout->cstride % al) || (lout->choff % al))
     return fail(RTPOSE_E_INVAL, "stem_conv3x3_s2_nchw: only cout=24 (ShuffleNetV2 x1.0) is instantiated");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const size_t total = (size_t)N * Ho * Wo;
   if (!total) return 0;
   hipLaunchKernelGGL(stem_conv3x3_s2_nchw_kernel<24>, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
-                     x_nchw, scale, shift, w, bias, out, to_lay(lout), N, H, W, Ho, Wo, relu);
+                     x_nchw, scale, shift, w, bias, out, to_lay(lout), N, H, W, Ho, Wo, relu, out_bf16 ? 1 : 0);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -965,6 +1098,48 @@ int rtpose_layout_split_to_f32(const void* src, const rtpose_layout* lsrc, float
   if (!total) return 0;
   hipLaunchKernelGGL(layout_split_to_f32_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
                      static_cast<const unsigned short*>(src), to_lay(lsrc), dst, to_lay(ldst), C, N, H, W);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+
+int rtpose_maxpool3x3s2_ceil_bf16(const void* in, const rtpose_layout* lin, void* out, const rtpose_layout* lout,
+                                  int C, int N, int H, int W, void* stream) {
+  if ((C % 8) || (lin->cstride % 8) || (lin->choff % 8) || (lout->cstride % 8) || (lout->choff % 8) || H < 3 || W < 3)
+    return fail(RTPOSE_E_INVAL, "maxpool3x3s2_bf16: channel slices must be 16-byte aligned, H,W >= 3");
+  const int Ho = (H - 3 + 1) / 2 + 1, Wo = (W - 3 + 1) / 2 + 1;
+  const size_t total = (size_t)N * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(maxpool3x3s2_ceil_bf16_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
+                     static_cast<const unsigned short*>(in), to_lay(lin), static_cast<unsigned short*>(out),
+                     to_lay(lout), C, N, H, W, Ho, Wo);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_dwconv3x3_bf16(const void* in, const rtpose_layout* lin, const float* w, const float* bias, void* out,
+                          const rtpose_layout* lout, int C, int N, int H, int W, int stride, void* stream) {
+  if ((C % 8) || (lin->cstride % 8) || (lin->choff % 8) || (lout->cstride % 8) || (lout->choff % 8) ||
+      (stride != 1 && stride != 2) || lin->ws < W + 1 || lin->hs < H + 1 || lin->lead < lin->ws + 1)
+    return fail(RTPOSE_E_INVAL, "dwconv3x3_bf16: unsupported layout / stride");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const size_t total = (size_t)N * Ho * Wo * (C / 8);
+  if (!total) return 0;
+  hipLaunchKernelGGL(dwconv3x3_bf16_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
+                     static_cast<const unsigned short*>(in), to_lay(lin), w, bias, static_cast<unsigned short*>(out),
+                     to_lay(lout), C, N, Ho, Wo, stride);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int rtpose_layout_copy_cmap_bf16(const void* src, const rtpose_layout* lsrc, void* dst, const rtpose_layout* ldst,
+                                 int C, const int32_t* cmap, int N, int H, int W, void* stream) {
+  if (!cmap || (lsrc->cstride % 8) || (lsrc->choff % 8))
+    return fail(RTPOSE_E_INVAL, "layout_copy_cmap_bf16: cmap is NULL or the source slice is not 16-byte aligned");
+  const size_t total = (size_t)N * H * W * ((C + 7) / 8);
+  if (!total) return 0;
+  hipLaunchKernelGGL(layout_copy_cmap_bf16_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
+                     static_cast<const unsigned short*>(src), to_lay(lsrc), static_cast<unsigned short*>(dst),
+                     to_lay(ldst), C, cmap, N, H, W);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -28,6 +28,12 @@ namespace rtpose {
 int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
 int pack_weights_launch(const float* w, const float* bias, int cout, int cin_src, int k,
                         const int32_t* cin_map, int cin_packed, float* wp, float* bp, hipStream_t s);
+// bf16 plans (conv_mfma_bf16.hip)
+int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, int out_f32, int split,
+                       hipStream_t s);
+int pack_weights_bf16_launch(const float* w, const float* bias, int cout, int cin_src, int k,
+                             const int32_t* cin_map, int cin_packed, void* wp, float* bp, int split,
+                             hipStream_t s);
 
 // w[C][1][3][3] (+bias[C]) -> wp[9][cphys], bp[cphys]; phys channel p reads logical pmap[p] (-1: zero)
 __global__ void pack_dw_kernel(const float* __restrict__ w, const float* __restrict__ b, int C,
@@ -101,6 +107,7 @@ struct Map {
 
 struct rtpose_shufflenet {
   int N = 0, H = 0, W = 0, Hm = 0, Wm = 0;  // Hm x Wm: stride-8 maps
+  int bf16 = 0;  // 1: 2-byte activations + bf16 pointwise weights (fp32 accumulate); outputs stay fp32
   std::vector<SBuf> bufs;
   std::vector<SLayer> layers;
   std::vector<SOp> ops;
@@ -117,7 +124,7 @@ struct rtpose_shufflenet {
 
 namespace {
 
-int add_buf(rtpose_shufflenet* n, int C, int P, int H, int W) {
+int add_buf(rtpose_shufflenet* n, int C, int P, int H, int W, bool f32 = false) {
   SBuf b;
   b.C = C;
   b.H = H;
@@ -128,7 +135,8 @@ int add_buf(rtpose_shufflenet* n, int C, int P, int H, int W) {
   b.lay.hs = H + P;
   b.lay.lead = P * (W + P) + P;
   b.off = n->ws_floats;
-  n->ws_floats += round_up(rtpose_layout_pixels(&b.lay, n->N, H, W) * (size_t)C, 64);
+  const size_t per_px = (n->bf16 && !f32) ? (size_t)C / 2 : (size_t)C;  // bf16 plans: 2-byte elements
+  n->ws_floats += round_up(rtpose_layout_pixels(&b.lay, n->N, H, W) * per_px, 64);
   n->bufs.push_back(b);
   return (int)n->bufs.size() - 1;
 }
@@ -157,7 +165,11 @@ int add_layer(rtpose_shufflenet* n, LKind kind, const std::string& name, int cou
     case L_AFFINE: wf = 64; bf = 64; break;
     case L_STEM: wf = (size_t)9 * 8 * cout; bf = cout; break;
     case L_DW: wf = (size_t)9 * cin_packed; bf = cin_packed; break;
-    case L_PW: wf = rtpose_packed_weight_floats(cout, cin_packed, 1); bf = rtpose_packed_bias_floats(cout); break;
+    case L_PW:
+      wf = n->bf16 ? rtpose_packed_weight_bytes_bf16(cout, cin_packed, 1) / 4
+                   : rtpose_packed_weight_floats(cout, cin_packed, 1);
+      bf = rtpose_packed_bias_floats(cout);
+      break;
   }
   n->wt_floats += round_up(wf, 64);
   l.b_off = n->wt_floats;
@@ -166,7 +178,10 @@ int add_layer(rtpose_shufflenet* n, LKind kind, const std::string& name, int cou
   return (int)n->layers.size() - 1;
 }
 
-int up8(int v) { return (v + 7) / 8 * 8; }
+// channel alignment of slices that feed a pointwise conv: 8 floats (fp32 kernel: cin % 8 == 0),
+// 16 elements for bf16 plans (one K = 16 MFMA step); set by build()
+int g_al = 8;
+int up8(int v) { return (v + g_al - 1) / g_al * g_al; }
 
 // logical -> physical channel of a stage buffer with halves of h channels padded to hp
 int fphys(int j, int h, int hp) { return j < h ? j : hp + (j - h); }
@@ -208,6 +223,7 @@ void add_dw(rtpose_shufflenet* n, const std::string& name, int H, int W, int lay
 }
 
 void build(rtpose_shufflenet* n) {
+  g_al = n->bf16 ? 16 : 8;
   const int H0 = n->H, W0 = n->W;
   const int H1 = (H0 - 1) / 2 + 1, W1 = (W0 - 1) / 2 + 1;          // stem 3x3 s2 p1
   const int H2 = (H1 - 3 + 1) / 2 + 1, W2 = (W1 - 3 + 1) / 2 + 1;  // maxpool 3/2 ceil
@@ -220,7 +236,7 @@ void build(rtpose_shufflenet* n) {
   const int L_stem = add_layer(n, L_STEM, "network.1", 24, 3, 8, -1);
   const int X0 = -1;  // (no NHWC staging of the image: the stem conv reads the NCHW input itself)
   const int S1 = add_buf(n, 24, 0, H1, W1);
-  const int X1 = add_buf(n, 24, 1, H2, W2);
+  const int X1 = add_buf(n, up8(24), 1, H2, W2);  // (channels past 24 stay zero: a 1x1 conv reads them)
   {
     SOp o;
     o.kind = O_INPUT;
@@ -273,7 +289,7 @@ void build(rtpose_shufflenet* n) {
     const int M_even = add_map(n, even), M_odd = add_map(n, odd);
     // temporaries
     const int in_phys = in_is_stage ? 2 * in_hp : in_c;
-    const int T0 = add_buf(n, in_phys, 0, Ho, Wo);      // conv0 branch after dw
+    const int T0 = add_buf(n, up8(in_phys), 0, Ho, Wo);  // conv0 branch after dw
     const int T1a = add_buf(n, hp, 1, Hc, Wc);          // first block: 1x1 at the INPUT resolution
     const int T1 = add_buf(n, hp, 1, Ho, Wo);
     const int T2 = add_buf(n, hp, 0, Ho, Wo);
@@ -339,7 +355,7 @@ void build(rtpose_shufflenet* n) {
     const int lp = add_layer(n, L_PW, "paf", 38, 1024, 1024, -1);
     const int lh = add_layer(n, L_PW, "heatmap", 19, 1024, 1024, -1);
     const int F = add_buf(n, 1024, 0, Hc, Wc);
-    const int OUT = add_buf(n, 64, 0, Hc, Wc);  // [PAF 0..37 | 2 pad | heat 40..58 | pad]
+    const int OUT = add_buf(n, 64, 0, Hc, Wc, true);  // fp32 [PAF 0..37 | 2 pad | heat 40..58 | pad]
     n->out_buf = OUT;
     add_pw(n, "conv5", Hc, Wc, l5, in_buf, 0, F, 0, -1, 1);
     SOp o;
@@ -370,15 +386,22 @@ rtpose_layout slice(const SBuf& b, int choff) {
 
 extern "C" {
 
-int rtpose_shufflenet_create(int N, int H, int W, rtpose_shufflenet** out) {
+int rtpose_shufflenet_create_ex(int N, int H, int W, int dtype, rtpose_shufflenet** out) {
   if (!out || N <= 0 || H < 32 || W < 32) return fail(RTPOSE_E_INVAL, "shufflenet_create: need N>=1, H,W>=32");
+  if (dtype != RTPOSE_DTYPE_F32 && dtype != RTPOSE_DTYPE_BF16)
+    return fail(RTPOSE_E_INVAL, "shufflenet_create: dtype must be RTPOSE_DTYPE_F32 or RTPOSE_DTYPE_BF16");
   rtpose_shufflenet* n = new rtpose_shufflenet();
   n->N = N;
   n->H = H;
   n->W = W;
+  n->bf16 = dtype == RTPOSE_DTYPE_BF16;
   build(n);
   *out = n;
   return 0;
+}
+
+int rtpose_shufflenet_create(int N, int H, int W, rtpose_shufflenet** out) {
+  return rtpose_shufflenet_create_ex(N, H, W, RTPOSE_DTYPE_F32, out);
 }
 
 void rtpose_shufflenet_destroy(rtpose_shufflenet* n) {
@@ -448,6 +471,9 @@ int rtpose_shufflenet_load(rtpose_shufflenet* n, int idx, const float* w, const 
       return 0;
     }
     case L_PW:
+      if (n->bf16)
+        return pack_weights_bf16_launch(w, b, l.cout, l.cin, 1, map, l.cin_packed, n->wt + l.w_off,
+                                        n->wt + l.b_off, 0, s);
       return pack_weights_launch(w, b, l.cout, l.cin, 1, map, l.cin_packed, n->wt + l.w_off, n->wt + l.b_off, s);
   }
   return 0;
@@ -499,30 +525,37 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
         const SBuf& bo = n->bufs[o.out_buf[0]];
         const SLayer& l = n->layers[o.layer[0]];
         const SLayer& la = n->layers[n->ops[0].layer[0]];  // the input BatchNorm2d(3) as scale / shift
-        rc = rtpose_stem_conv3x3_s2_nchw(x_nchw, n->wt + la.w_off, n->wt + la.b_off, n->wt + l.w_off,
-                                         n->wt + l.b_off, n->ws + bo.off, &bo.lay, l.cout, n->N, o.H, o.W, o.relu,
-                                         stream);
+        rc = rtpose_stem_conv3x3_s2_nchw_ex(x_nchw, n->wt + la.w_off, n->wt + la.b_off, n->wt + l.w_off,
+                                            n->wt + l.b_off, n->ws + bo.off, &bo.lay, l.cout, n->N, o.H, o.W,
+                                            o.relu, n->bf16, stream);
         break;
       }
       case O_POOL3: {
         const SBuf& bi = n->bufs[o.in_buf[0]];
         const SBuf& bo = n->bufs[o.out_buf[0]];
-        rc = rtpose_maxpool3x3s2_ceil(n->ws + bi.off, &bi.lay, n->ws + bo.off, &bo.lay, o.C, n->N, o.H, o.W, stream);
+        rc = n->bf16 ? rtpose_maxpool3x3s2_ceil_bf16(n->ws + bi.off, &bi.lay, n->ws + bo.off, &bo.lay, o.C, n->N,
+                                                     o.H, o.W, stream)
+                     : rtpose_maxpool3x3s2_ceil(n->ws + bi.off, &bi.lay, n->ws + bo.off, &bo.lay, o.C, n->N, o.H,
+                                                o.W, stream);
         break;
       }
       case O_DW: {
         const SBuf& bi = n->bufs[o.in_buf[0]];
         const SBuf& bo = n->bufs[o.out_buf[0]];
         const SLayer& l = n->layers[o.layer[0]];
-        rc = rtpose_dwconv3x3(n->ws + bi.off, &bi.lay, n->wt + l.w_off, n->wt + l.b_off, n->ws + bo.off, &bo.lay,
-                              o.C, n->N, o.H, o.W, o.stride, stream);
+        rc = n->bf16 ? rtpose_dwconv3x3_bf16(n->ws + bi.off, &bi.lay, n->wt + l.w_off, n->wt + l.b_off,
+                                             n->ws + bo.off, &bo.lay, o.C, n->N, o.H, o.W, o.stride, stream)
+                     : rtpose_dwconv3x3(n->ws + bi.off, &bi.lay, n->wt + l.w_off, n->wt + l.b_off, n->ws + bo.off,
+                                        &bo.lay, o.C, n->N, o.H, o.W, o.stride, stream);
         break;
       }
       case O_COPYMAP: {
         const SBuf& bi = n->bufs[o.in_buf[0]];
         const SBuf& bo = n->bufs[o.out_buf[0]];
-        rc = rtpose_layout_copy_cmap(n->ws + bi.off, &bi.lay, n->ws + bo.off, &bo.lay, o.C, imap(o.cmap[0]), n->N,
-                                     o.H, o.W, stream);
+        rc = n->bf16 ? rtpose_layout_copy_cmap_bf16(n->ws + bi.off, &bi.lay, n->ws + bo.off, &bo.lay, o.C,
+                                                    imap(o.cmap[0]), n->N, o.H, o.W, stream)
+                     : rtpose_layout_copy_cmap(n->ws + bi.off, &bi.lay, n->ws + bo.off, &bo.lay, o.C,
+                                               imap(o.cmap[0]), n->N, o.H, o.W, stream);
         break;
       }
       case O_PW: {
@@ -544,7 +577,9 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
           d[g].pool = 0;
           d[g].out_cmap = imap(o.cmap[g]);
         }
-        rc = conv2d_launch(d, o.ngroups, n->N, o.H, o.W, s);
+        // bf16 plans: the two heads write the fp32 output record, everything else 2-byte activations
+        rc = n->bf16 ? conv2d_bf16_launch(d, o.ngroups, n->N, o.H, o.W, o.out_buf[0] == n->out_buf, 0, s)
+                     : conv2d_launch(d, o.ngroups, n->N, o.H, o.W, s);
         break;
       }
     }

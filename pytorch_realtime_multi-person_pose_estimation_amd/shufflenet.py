@@ -43,11 +43,12 @@ class BasicBlock(nn.Module):
 
 
 class _Plan(object):
-    def __init__(self, n, h, w, weights, device):
+    def __init__(self, n, h, w, weights, device, dtype=_capi.DTYPE_F32):
         handle = C.c_void_p()
-        check(lib.rtpose_shufflenet_create(n, h, w, C.byref(handle)), "rtpose_shufflenet_create")
+        check(lib.rtpose_shufflenet_create_ex(n, h, w, dtype, C.byref(handle)), "rtpose_shufflenet_create_ex")
         self.handle = handle
         self.shape = (n, h, w)
+        self.dtype = dtype
         ws = lib.rtpose_shufflenet_workspace_bytes(handle)
         self.workspace = torch.empty(ws // 4 + 64, dtype=torch.float32, device=device)
         check(lib.rtpose_shufflenet_bind(handle, ptr(self.workspace), ws, ptr(weights), weights.numel() * 4, 1,
@@ -83,8 +84,17 @@ class Network(nn.Module):
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
         self._plans = {}
-        self._weights = None
-        self._key = None
+        self._weights = {}     # compute dtype -> weight arena
+        self._key = {}         # compute dtype -> parameter versions the arena was packed from
+        self.compute_dtype = 'fp32'
+
+    def set_compute_dtype(self, dtype):
+        """'fp32' or 'bf16' (BASELINE config 4 "fp32 and bf16": 2-byte activations and pointwise
+        weights, fp32 accumulation; depthwise / stem weights, biases and outputs stay fp32)."""
+        if dtype not in ('fp32', 'bf16'):
+            raise ValueError("compute dtype must be 'fp32' or 'bf16'")
+        self.compute_dtype = dtype
+        return self
 
     # ---- native side -------------------------------------------------------
     def _module_by_prefix(self, prefix):
@@ -104,7 +114,7 @@ class Network(nn.Module):
     def _sync_weights(self, plan, device):
         tensors = list(self.parameters()) + list(self.buffers())
         key = tuple((t._version, t.data_ptr()) for t in tensors)
-        if key == self._key:
+        if key == self._key.get(plan.dtype):
             return
         name = C.create_string_buffer(96)
         kind, co, ci = C.c_int(), C.c_int(), C.c_int()
@@ -127,7 +137,7 @@ class Network(nn.Module):
             keep += [w, b]
             check(lib.rtpose_shufflenet_load(plan.handle, i, ptr(w), ptr(b), stream), "rtpose_shufflenet_load")
         torch.cuda.current_stream().synchronize()
-        self._key = key
+        self._key[plan.dtype] = key
 
     def plan_for(self, x):
         if not x.is_cuda:
@@ -135,22 +145,25 @@ class Network(nn.Module):
         if self.training:
             raise _capi.RtposeError("native path implements eval-mode BatchNorm only: call .eval()")
         n, c, h, w = x.shape
-        key = (n, h, w, x.device.index)
+        dtype = _capi.DTYPE_BF16 if self.compute_dtype == 'bf16' else _capi.DTYPE_F32
+        key = (n, h, w, x.device.index, dtype)
         plan = self._plans.get(key)
         if plan is None:
-            if self._weights is None or self._weights.device != x.device:
+            weights = self._weights.get(dtype)
+            if weights is None or weights.device != x.device:
                 probe = C.c_void_p()
-                check(lib.rtpose_shufflenet_create(1, 64, 64, C.byref(probe)))
+                check(lib.rtpose_shufflenet_create_ex(1, 64, 64, dtype, C.byref(probe)))
                 wb = lib.rtpose_shufflenet_weight_bytes(probe)
                 lib.rtpose_shufflenet_destroy(probe)
-                self._weights = torch.zeros(wb // 4 + 64, dtype=torch.float32, device=x.device)
-                self._key = None
-                self._plans.clear()
-            plan = _Plan(n, h, w, self._weights, x.device)
+                weights = torch.zeros(wb // 4 + 64, dtype=torch.float32, device=x.device)
+                self._weights[dtype] = weights
+                for k in [k for k in self._plans if k[4] == dtype]:
+                    del self._plans[k]
+            plan = _Plan(n, h, w, weights, x.device, dtype)
             if len(self._plans) >= 8:
                 self._plans.pop(next(iter(self._plans)))
             self._plans[key] = plan
-            self._key = None   # a new plan re-binds the maps; weights are shared but reload is cheap
+            self._key.pop(dtype, None)   # a new plan re-binds the maps; weights are shared but reload is cheap
         self._sync_weights(plan, x.device)
         return plan
 

@@ -141,3 +141,30 @@ def test_decoder_reads_shufflenet_output_in_place(net_sd, capi, cuda):
         jl, r = po.paf_to_pose(hm, pf)
         out = dec.parse_image(recs[i], cfg)
         assert np.array_equal(out["peaks"], jl) and np.array_equal(out["parts"], r["parts"])
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 128, 160), (1, 3, 368, 368)])
+def test_bf16_plan_matches_emulation_and_fp32(net_sd, cuda, shape):
+    """BASELINE config 4 "fp32 and bf16": the bf16 plan against its emulation oracle (2e-2 of the map
+    scale: 1-ulp rounding flips propagate through 56 layers) and against the fp32 oracle (6e-2)."""
+    from oracle import shufflenet_oracle as so
+    m, sd = net_sd
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(shape, generator=g) - 0.5
+    paf_e, heat_e = so.forward_bf16_emulated(sd, x)
+    paf_r, heat_r = so.forward(sd, x)
+    m.set_compute_dtype('bf16')
+    try:
+        with torch.no_grad():
+            (paf, heat), _ = m(x.to(cuda))
+            (paf2, heat2), _ = m(x.to(cuda))
+    finally:
+        m.set_compute_dtype('fp32')
+    assert torch.equal(paf, paf2) and torch.equal(heat, heat2)
+    for a, e, r in ((paf, paf_e, paf_r), (heat, heat_e, heat_r)):
+        scale = max(1.0, r.abs().max().item())
+        assert (a.cpu() - e).abs().max().item() <= 2e-2 * scale, "vs bf16 emulation"
+        assert (a.cpu() - r).abs().max().item() <= 6e-2 * scale, "vs fp32 oracle"
+    with torch.no_grad():
+        (paf3, _), _ = m(x.to(cuda))         # back on the fp32 plan
+    assert (paf3.cpu() - paf_r).abs().max().item() <= 1e-3 * max(1.0, paf_r.abs().max().item())
