@@ -19,12 +19,13 @@ GFLOP_PER_IMG = 5.543
 MIN_BYTES_PER_IMG = 1.63e6 + 0.48e6   # read input + write outputs (weights 5.2 MB once per batch)
 
 
-def main(n=128, iters=10):
+def main(n=128, iters=10, dtype='fp32'):
     from oracle import shufflenet_oracle as so
     dev = torch.device("cuda:0")
     m = sn.Network(1.0)
     m.load_state_dict(so.seeded_state_dict(m, 0))
     m = m.cuda().eval()
+    m.set_compute_dtype(dtype)
     x = (torch.rand(n, 3, 368, 368, generator=torch.Generator().manual_seed(0)) - 0.5).to(dev)
     plan = m.forward_native(x)
     torch.cuda.synchronize()
@@ -57,5 +58,7 @@ def main(n=128, iters=10):
           % (nl, tot, wall * 1e3, n / wall, n / wall * GFLOP_PER_IMG / 1e3, n / wall * MIN_BYTES_PER_IMG / 1e9))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) > 3:
+    main(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3])
+elif __name__ == "__main__":
     main(*[int(v) for v in sys.argv[1:]])
