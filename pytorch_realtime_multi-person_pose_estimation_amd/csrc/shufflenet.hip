@@ -275,7 +275,9 @@ void build(rtpose_shufflenet* n) {
   bool in_is_stage = false;
   int Hc = H2, Wc = W2;
   for (int si = 0; si < 3; ++si) {
-    const int C = widths[si], h = C / 2, hp = up8(h);
+    // bf16 plans: halves padded to 64 channels (58 -> 64, 116 -> 128, 232 -> 256) so that every
+    // pointwise conv runs with 64-channel LDS chunks (232 padded to 240 would fall back to 16)
+    const int C = widths[si], h = C / 2, hp = n->bf16 ? (h + 63) / 64 * 64 : up8(h);
     const int stride = si == 0 ? 2 : 1;
     const int Ho = si == 0 ? H3 : Hc, Wo = si == 0 ? W3 : Wc;
     const std::string sp = "network." + std::to_string(3 + si) + ".";
