@@ -9,7 +9,13 @@ timeout 900 python bench.py --steps 10 --warmup 3 > $O/final_bench.json 2> $O/fi
 timeout 600 python bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline > $O/final_bench_bf16.json 2> $O/final_bench_bf16.err; cat $O/final_bench_bf16.json
 timeout 600 python tools/bench_config5.py > $O/final_config5.json 2> $O/final_config5.err; cat $O/final_config5.json
 timeout 600 python tools/bench_config5.py --dtype bf16 >> $O/final_config5.json 2>> $O/final_config5.err; tail -1 $O/final_config5.json
-timeout 300 python tools/bench_tta.py 8 5 > $O/final_tta.log 2>&1; tail -6 $O/final_tta.log
+timeout 600 python bench.py --dtype bf16x3 --steps 10 --warmup 3 --no-cpu-baseline > $O/final_bench_bf16x3.json 2> $O/final_bench_bf16x3.err; cut -c1-160 $O/final_bench_bf16x3.json
+timeout 600 python tools/bench_config5.py --dtype bf16x3 >> $O/final_config5.json 2>> $O/final_config5.err
+timeout 300 python tools/bench_tta.py 32 3 > $O/final_tta.log 2>&1; tail -8 $O/final_tta.log
+(timeout 300 python tools/bench_shufflenet.py 128 5 fp32; timeout 300 python tools/bench_shufflenet.py 128 5 bf16) > $O/final_shufflenet.log 2>&1; grep "^launches" $O/final_shufflenet.log
+timeout 300 python tools/latency_b1.py > $O/final_latency.log 2>&1; tail -3 $O/final_latency.log
+timeout 300 python tools/bench_streaming.py > $O/final_streaming.log 2>&1; tail -3 $O/final_streaming.log
+timeout 300 python tools/profile_layers.py 32 368 368 3 bf16x3 > $O/final_bf16x3_layers.log 2>&1
 timeout 300 python tools/profile_layers.py 32 368 368 3 bf16 > $O/final_bf16_layers.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/final_trace -o r1 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic > $O/final_trace_bench.json 2> $O/final_trace.err
