@@ -81,3 +81,37 @@ def test_bad_arguments_are_rejected_on_the_host(capi):
     assert lib.rtpose_decode_workspace_bytes(C.byref(cfg), 4) >= 4 * 19 * (1 + 3 * 32) * 4
     # legacy getters on an empty state: bounds-checked, never UB
     assert lib.get_part_cid(3, 3) == -1 and lib.get_part_x(0) == -1
+
+
+def test_compute_dtype_plans_on_the_host(capi, pkg):
+    """Plan construction is host-only: the reduced-precision plans exist, report their dtype, keep
+    the same 92 convs / launch list, size their arenas sensibly and reject what they cannot run."""
+    lib = capi.lib
+    sizes = {}
+    for dt in (capi.DTYPE_F32, capi.DTYPE_BF16, capi.DTYPE_BF16X3):
+        h = C.c_void_p()
+        capi.check(lib.rtpose_net_create_ex(2, 368, 368, dt, C.byref(h)))
+        try:
+            assert lib.rtpose_net_dtype(h) == dt
+            assert lib.rtpose_net_num_convs(h) == 92
+            sizes[dt] = (lib.rtpose_net_workspace_bytes(h), lib.rtpose_net_weight_bytes(h), lib.rtpose_net_num_launches(h))
+        finally:
+            lib.rtpose_net_destroy(h)
+    f32, bf16, x3 = sizes[capi.DTYPE_F32], sizes[capi.DTYPE_BF16], sizes[capi.DTYPE_BF16X3]
+    assert 0.4 * f32[0] < bf16[0] < 0.7 * f32[0]        # 2-byte activations (+ fp32 staging / records)
+    assert 0.9 * f32[0] < x3[0] < 1.2 * f32[0]          # hi + lo = the fp32 footprint
+    assert 0.4 * f32[1] < bf16[1] < 0.7 * f32[1] and 0.9 * f32[1] < x3[1] < 1.2 * f32[1]
+    assert bf16[2] == x3[2] == f32[2] - 1               # stage 6 writes its fp32 record directly (no save copy)
+    h = C.c_void_p()
+    assert lib.rtpose_net_create_ex(1, 364, 368, capi.DTYPE_BF16, C.byref(h)) != 0   # not a multiple of 8
+    assert "multiples of 8" in capi.last_error()
+    assert lib.rtpose_net_create_ex(1, 368, 368, 7, C.byref(h)) != 0
+    assert lib.rtpose_shufflenet_create_ex(1, 368, 368, capi.DTYPE_BF16X3, C.byref(h)) != 0
+    # packed-weight sizes: bf16 = 2 bytes per element of the padded filter, bf16x3 twice that
+    assert lib.rtpose_packed_weight_bytes_bf16(128, 128, 7) == (49 * 128 + 128) * 128 * 2
+    assert lib.rtpose_packed_weight_bytes_bf16x3(128, 128, 7) == 2 * lib.rtpose_packed_weight_bytes_bf16(128, 128, 7)
+    m = pkg.get_model('vgg19')
+    import pytest as _pt
+    with _pt.raises(ValueError):
+        m.set_compute_dtype('fp16')
+    assert m.set_compute_dtype('bf16x3').compute_dtype == 'bf16x3'
