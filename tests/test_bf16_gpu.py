@@ -7,7 +7,7 @@ fp32 accumulation, fp32 bias/ReLU/pool, activations re-rounded between layers, f
 fp32.  Tolerances are written next to each check:
   * one conv, fp32 output : 2e-5 of max|ref|  (fp32 accumulation order only)
   * one conv, bf16 output : 1 bf16 ulp (2^-7 relative) around the rounded reference
-  * whole net vs emulation: 2e-2 of max|ref|  (rounding flips of 1 ulp propagate)
+  * whole net vs emulation: 3e-2 of max|ref| (observed 1.4e-2), rms 6e-3  (rounding flips of 1 ulp propagate)
   * whole net vs fp32     : 6e-2 of max|ref|  (what bf16 operands cost; the north_star 1e-3
                             bound applies to the fp32 path only)
 """
@@ -188,7 +188,10 @@ def test_net_bf16_matches_emulation_and_fp32(model_and_sd, cuda, shape):
     for i, (a, b) in enumerate(zip(saved, saved_e)):
         scale = max(1.0, b.abs().max().item())
         err = (a.cpu() - b).abs().max().item()
-        assert err <= 2e-2 * scale, "stage output %d vs bf16 emulation: %g (scale %g)" % (i, err, scale)
+        # max over the map of a chaotic quantity (1-ulp rounding flips propagate; which ones flip depends
+        # on the accumulation order): observed 1.0-1.4e-2, rms ~2e-3
+        assert err <= 3e-2 * scale, "stage output %d vs bf16 emulation: %g (scale %g)" % (i, err, scale)
+        assert ((a.cpu() - b) ** 2).mean().sqrt().item() <= 6e-3 * scale
     for a, b in ((paf, paf_r), (heat, heat_r)):
         scale = max(1.0, b.abs().max().item())
         err = (a.cpu() - b).abs().max().item()
