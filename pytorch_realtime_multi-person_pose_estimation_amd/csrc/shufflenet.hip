@@ -178,10 +178,6 @@ int add_layer(rtpose_shufflenet* n, LKind kind, const std::string& name, int cou
   return (int)n->layers.size() - 1;
 }
 
-// channel alignment of slices that feed a pointwise conv: 8 floats (fp32 kernel: cin % 8 == 0),
-// 16 elements for bf16 plans (one K = 16 MFMA step); set by build()
-int g_al = 8;
-int up8(int v) { return (v + g_al - 1) / g_al * g_al; }
 
 // logical -> physical channel of a stage buffer with halves of h channels padded to hp
 int fphys(int j, int h, int hp) { return j < h ? j : hp + (j - h); }
@@ -223,7 +219,10 @@ void add_dw(rtpose_shufflenet* n, const std::string& name, int H, int W, int lay
 }
 
 void build(rtpose_shufflenet* n) {
-  g_al = n->bf16 ? 16 : 8;
+  // channel alignment of slices that feed a pointwise conv: 8 floats (fp32 kernel: cin % 8 == 0),
+  // 16 elements for bf16 plans (one K = 16 MFMA step)
+  const int al = n->bf16 ? 16 : 8;
+  auto up8 = [al](int v) { return (v + al - 1) / al * al; };
   const int H0 = n->H, W0 = n->W;
   const int H1 = (H0 - 1) / 2 + 1, W1 = (W0 - 1) / 2 + 1;          // stem 3x3 s2 p1
   const int H2 = (H1 - 3 + 1) / 2 + 1, W2 = (W1 - 3 + 1) / 2 + 1;  // maxpool 3/2 ceil
