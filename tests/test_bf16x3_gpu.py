@@ -190,3 +190,36 @@ def test_bf16x3_full_size_batch_properties(model_and_sd, cuda):
         m.keep_intermediates = keep
     assert torch.equal(paf, paf2) and torch.equal(heat, heat2)
     assert torch.equal(paf_p, paf[perm.to(cuda)]) and torch.equal(heat_p, heat[perm.to(cuda)])
+
+
+def test_conv_bf16x3_error_bound_wide_dynamic_range(capi, cuda):
+    """Element-wise error bound with operands spanning six decades: the split keeps 16 significant
+    bits of every operand whatever its magnitude (bf16 has the fp32 exponent range), so
+    |error| <= ~2^-15 * sum |a||b| per output - checked as 6e-5 * conv(|x|, |w|)."""
+    lib, Layout = capi.lib, capi.Layout
+    n, h, w, cin, cout, k = 2, 46, 46, 64, 64, 3
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(n, cin, h, w, generator=g) * 10.0 ** (torch.rand(n, cin, h, w, generator=g) * 6 - 3)
+    wt = torch.randn(cout, cin, k, k, generator=g) * 10.0 ** (torch.rand(cout, cin, k, k, generator=g) * 4 - 3)
+    ref = F.conv2d(x.double(), wt.double(), None, padding=1)
+    bound = F.conv2d(x.abs().double(), wt.abs().double(), None, padding=1) * 6e-5 + 1e-30
+    stream = capi.current_stream()
+    lin = Layout.padded(2 * cin, h, w, 1)
+    xin = torch.zeros(lib.rtpose_layout_pixels(C.byref(lin), n, h, w) * 2 * cin, device=cuda, dtype=torch.bfloat16)
+    xd, wd, bd = x.to(cuda), wt.to(cuda), torch.zeros(cout, device=cuda)
+    capi.check(lib.rtpose_nchw_to_layout_split(capi.ptr(xd), capi.ptr(xin), C.byref(lin), cin, cin, n, h, w, stream))
+    wp = torch.zeros(lib.rtpose_packed_weight_bytes_bf16x3(cout, cin, k) // 2, device=cuda, dtype=torch.bfloat16)
+    bp = torch.zeros(lib.rtpose_packed_bias_floats(cout), device=cuda)
+    capi.check(lib.rtpose_pack_conv_weights_bf16x3(capi.ptr(wd), capi.ptr(bd), cout, cin, k, None, cin, capi.ptr(wp),
+                                                   capi.ptr(bp), stream))
+    lo = Layout.dense(cout, h, w)
+    out = torch.zeros(n * h * w * cout, device=cuda)
+    d = (capi.ConvDesc * 1)()
+    d[0].inp, d[0].w_packed, d[0].bias_packed, d[0].out = xin.data_ptr(), wp.data_ptr(), bp.data_ptr(), out.data_ptr()
+    d[0].lin, d[0].lout = lin, lo
+    d[0].cin, d[0].cout, d[0].k, d[0].relu, d[0].pool = cin, cout, k, 0, 0
+    capi.check(lib.rtpose_conv2d_bf16x3(d, 1, n, h, w, 1, stream))     # fp32 output: no re-split error on top
+    got = out.view(n, h, w, cout).permute(0, 3, 1, 2).cpu().double()
+    viol = ((got - ref).abs() > bound).sum().item()
+    assert viol == 0, "%d outputs outside the 6e-5 * sum|a||b| bound (worst ratio %.3g)" % (
+        viol, ((got - ref).abs() / bound).max().item() * 6e-5)
