@@ -772,6 +772,82 @@ __global__ void dwconv3x3_bf16_kernel(const unsigned short* __restrict__ in, Lay
   store_bf8(out + lay_off(lo, n, y, x) + c, acc);
 }
 
+
+// depthwise 3x3, stride 1: FOUR consecutive output pixels of a row per thread.  The plain kernel
+// issues 9 activation + 9 weight loads per output (it is load-instruction bound, ~2 TB/s); here
+// the 3x6 input window and the 9 weight vectors are loaded once for four outputs (28 vs 76
+// loads).  BF = 0: fp32 activations, 4 channels per thread; BF = 1: bf16 activations, 8 channels.
+template <int BF>
+__global__ void dwconv3x3_s1x4_kernel(const void* __restrict__ in_v, Lay li, const float* __restrict__ w,
+                                      const float* __restrict__ bias, void* __restrict__ out_v, Lay lo, int C,
+                                      int N, int H, int W) {
+  constexpr int CV = BF ? 8 : 4;  // channels per thread
+  const int cg = C / CV, xg = (W + 3) >> 2;
+  const size_t total = (size_t)N * H * xg * cg;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % cg) * CV;
+  size_t p = i / cg;
+  const int x0 = (int)(p % xg) * 4;
+  p /= xg;
+  const int y = (int)(p % H);
+  const int n = (int)(p / H);
+  float acc[4][CV];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int e = 0; e < CV; ++e) acc[o][e] = bias[c + e];
+  const float* in_f = static_cast<const float*>(in_v);
+  const unsigned short* in_h = static_cast<const unsigned short*>(in_v);
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    float wv[3][CV];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int e = 0; e < CV; ++e) wv[kx][e] = w[(size_t)(ky * 3 + kx) * C + c + e];
+    // input row y + ky - 1, columns x0 - 1 .. x0 + 4 (offsets of -1 land in the layout gaps; columns
+    // past the row end read the gap / the next row and only feed outputs that are not stored)
+    const long long row = (long long)lay_off(li, n, y + ky, x0) - (long long)(li.ws + 1) * li.cstride + c;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float v[CV];
+      if (BF) {
+        const bf8 t = load_bf8(in_h + row + (long long)j * li.cstride);
+#pragma unroll
+        for (int e = 0; e < CV; ++e) v[e] = t.v[e & 7];
+      } else {
+        const float4 t = *reinterpret_cast<const float4*>(in_f + row + (long long)j * li.cstride);
+        v[0] = t.x;
+        v[1] = t.y;
+        v[2] = t.z;
+        v[3] = t.w;
+      }
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int kx = j - o;  // input column j feeds output o through tap kx = j - o
+        if (kx >= 0 && kx < 3) {
+#pragma unroll
+          for (int e = 0; e < CV; ++e) acc[o][e] += v[e] * wv[kx][e];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    if (x0 + o >= W) break;
+    if (BF) {
+      bf8 r;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r.v[e] = acc[o][e & (CV - 1)];
+      store_bf8(static_cast<unsigned short*>(out_v) + lay_off(lo, n, y, x0 + o) + c, r);
+    } else {
+      *reinterpret_cast<float4*>(static_cast<float*>(out_v) + lay_off(lo, n, y, x0 + o) + c) =
+          make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]);
+    }
+  }
+}
+
 // 8 consecutive source channels per thread (one 16-byte load), up to 8 mapped 2-byte stores
 __global__ void layout_copy_cmap_bf16_kernel(const unsigned short* __restrict__ src, Lay ls,
                                              unsigned short* __restrict__ dst, Lay ld, int C,
@@ -941,6 +1017,13 @@ int rtpose_dwconv3x3(const float* in, const rtpose_layout* lin, const float* w, 
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const size_t total = (size_t)N * Ho * Wo * (C / 4);
   if (!total) return 0;
+  if (stride == 1) {  // 4 output pixels per thread
+    const size_t t4 = (size_t)N * H * ((W + 3) / 4) * (C / 4);
+    hipLaunchKernelGGL(dwconv3x3_s1x4_kernel<0>, dim3(nblocks(t4, 256)), dim3(256), 0, as_stream(stream), in,
+                       to_lay(lin), w, bias, out, to_lay(lout), C, N, H, W);
+    RTPOSE_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(dwconv3x3_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), in,
                      to_lay(lin), w, bias, out, to_lay(lout), C, N, Ho, Wo, stride);
   RTPOSE_HIP_CHECK(hipGetLastError());
@@ -1124,6 +1207,8 @@ int rtpose_dwconv3x3_bf16(const void* in, const rtpose_layout* lin, const float*
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const size_t total = (size_t)N * Ho * Wo * (C / 8);
   if (!total) return 0;
+  // (the 4-pixels-per-thread form measured 2.6x SLOWER here - 32 accumulators x 8 channels per
+  //  thread - so the bf16 plans keep one pixel per thread: 1.57 ms vs 4.03 ms over the 19 layers)
   hipLaunchKernelGGL(dwconv3x3_bf16_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream),
                      static_cast<const unsigned short*>(in), to_lay(lin), w, bias, static_cast<unsigned short*>(out),
                      to_lay(lout), C, N, Ho, Wo, stride);
