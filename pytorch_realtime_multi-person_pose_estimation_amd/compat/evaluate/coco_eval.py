@@ -25,3 +25,8 @@ def get_outputs(img, model, preprocess):
 
 def append_result(image_id, humans, upsample_keypoints, outputs):
     return _pre.append_result(image_id, humans, upsample_keypoints, outputs, cfg.MODEL.NUM_KEYPOINTS)
+
+
+def run_eval(image_dir, anno_file, vis_dir, model, preprocess):
+    """coco_eval.py:245-290 - what evaluate/evaluation.py calls."""
+    return _pre.run_eval(image_dir, anno_file, vis_dir, model, preprocess, cfg)

@@ -281,3 +281,65 @@ def get_multiscale_outputs_batch(imgs, model, preprocess='rtpose', scales=(0.5, 
                                         ptr(acc_paf), hd, wd, hd * ratio, wd * ratio, 1.0 / len(scales),
                                         0.0 if si == 0 else 1.0, 1 if flip else 0, stream), "rtpose_tta_accumulate")
     return acc_paf, acc_heat, s1
+
+
+def imread_bgr(path):
+    """cv2.imread stand-in for run_eval: OpenCV if present, else PIL, else a `.npy` file holding
+    the BGR uint8 array (this image has neither cv2 nor PIL).  Returns None if unreadable."""
+    import os
+    try:
+        import cv2  # noqa: F401
+        return cv2.imread(path)
+    except ImportError:
+        pass
+    try:
+        from PIL import Image
+        return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+    except ImportError:
+        pass
+    for cand in (path, os.path.splitext(path)[0] + ".npy"):
+        if cand.endswith(".npy") and os.path.exists(cand):
+            return np.load(cand)
+    return None
+
+
+def run_eval(image_dir, anno_file, vis_dir, model, preprocess, config=None, imread=None, max_images=None):
+    """evaluate/coco_eval.py:245-290 (the entry evaluate/evaluation.py calls): loop over the person
+    images of a COCO annotation file - get_outputs (GPU image prep + forward), paf_to_pose_cpp,
+    draw_humans into vis_dir, append_result - then the OKS AP of the collected results.
+    pycocotools / cv2 are not needed: the annotation json is read directly, images through
+    `imread` (default imread_bgr), the overlay is written as .npy when cv2 is absent."""
+    import json
+    import os
+    from . import common, oks_eval
+    config = config or dec.default_config()
+    imread = imread or imread_bgr
+    with open(anno_file) as f:
+        ann = json.load(f)
+    person_cat = [c["id"] for c in ann.get("categories", []) if c.get("name") == "person"] or [1]
+    img_ids = sorted({a["image_id"] for a in ann["annotations"] if a.get("category_id", 1) in person_cat})
+    files = {im["id"]: im["file_name"] for im in ann["images"]}
+    if max_images:
+        img_ids = img_ids[:max_images]
+    print("Total number of validation images {}".format(len(img_ids)))
+    outputs = []
+    for i, iid in enumerate(img_ids):
+        if i % 10 == 0 and i != 0:
+            print("Processed {} images".format(i))
+        ori = imread(os.path.join(image_dir, files[iid]))
+        if ori is None:
+            raise IOError("cannot read %s (no cv2 / PIL here: provide imread= or .npy images)" % files[iid])
+        paf, heatmap, scale_img = get_outputs_gpu(ori, model, preprocess, config)
+        humans = dec.paf_to_pose_cpp(heatmap, paf, config)
+        if vis_dir:
+            out = common.draw_humans(ori, humans)
+            os.makedirs(vis_dir, exist_ok=True)
+            try:
+                import cv2
+                cv2.imwrite(os.path.join(vis_dir, files[iid]), out)
+            except ImportError:
+                np.save(os.path.join(vis_dir, os.path.splitext(files[iid])[0] + ".npy"), out)
+        up = int(config.MODEL.DOWNSAMPLE)
+        upsample_keypoints = (heatmap.shape[0] * up / scale_img, heatmap.shape[1] * up / scale_img)
+        append_result(iid, humans, upsample_keypoints, outputs, int(config.MODEL.NUM_KEYPOINTS))
+    return oks_eval.eval_coco(outputs, anno_file, img_ids)

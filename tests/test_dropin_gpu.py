@@ -218,3 +218,45 @@ def test_streaming_estimator_matches_direct_path(compat, cuda):
             r = dec.parse_image(rec_block[b], est.bufs.cfg)
             assert r["flags"] == 0
             assert np.array_equal(r["peaks"], ref["peaks"]) and np.array_equal(r["parts"], ref["parts"])
+
+
+def test_run_eval_flow_on_a_synthetic_coco_set(compat, cuda, tmp_path):
+    """evaluate/evaluation.py's call - `from evaluate.coco_eval import run_eval` - end to end on a tiny
+    synthetic COCO-format set (images as .npy: no cv2 / PIL here): annotation json read, image prep +
+    forward on the GPU, paf_to_pose_cpp, overlays written, results scored by the OKS evaluator.  With
+    random weights the AP itself is meaningless (and ~0); the flow, the result format and the bookkeeping
+    are what is checked.  Also: evaluation.py's imports resolve against compat/."""
+    import json
+    from evaluate.coco_eval import run_eval, append_result, eval_coco  # noqa: F401
+    from lib.network.rtpose_vgg import get_model, use_vgg               # noqa: F401
+    from lib.network.openpose import OpenPose_Model                     # noqa: F401  (evaluation.py:6)
+    from oracle import net_oracle
+    model = get_model(trunk='vgg19')
+    model.load_state_dict(net_oracle.he_init_state_dict(model, seed=0))
+    model.eval()
+    model.float()
+    model = model.cuda()
+    rng = np.random.default_rng(8)
+    img_dir, vis_dir = tmp_path / "images", tmp_path / "vis"
+    img_dir.mkdir()
+    images, annotations = [], []
+    for i in range(3):
+        h0, w0 = 120 + 10 * i, 160
+        np.save(img_dir / ("%06d.npy" % i), np.clip(rng.normal(128, 5, (h0, w0, 3)), 0, 255).astype(np.uint8))
+        images.append({"id": 100 + i, "file_name": "%06d.jpg" % i, "height": h0, "width": w0})
+        kp = []
+        for k in range(17):
+            kp += [20.0 + 5 * k, 30.0 + 3 * k, 2]
+        annotations.append({"id": i + 1, "image_id": 100 + i, "category_id": 1, "iscrowd": 0, "num_keypoints": 17,
+                            "keypoints": kp, "bbox": [10, 20, 100, 80], "area": 8000.0})
+    ann_file = tmp_path / "person_keypoints.json"
+    ann_file.write_text(json.dumps({"images": images, "annotations": annotations,
+                                    "categories": [{"id": 1, "name": "person"}]}))
+    with torch.no_grad():
+        ap = run_eval(image_dir=str(img_dir), anno_file=str(ann_file), vis_dir=str(vis_dir), model=model,
+                      preprocess='rtpose')
+    assert 0.0 <= ap <= 1.0
+    assert sorted(p.name for p in vis_dir.iterdir()) == ["000000.npy", "000001.npy", "000002.npy"]
+    assert np.load(vis_dir / "000001.npy").shape == (130, 160, 3)
+    with pytest.raises(NotImplementedError):
+        OpenPose_Model(l2_stages=4, l1_stages=2, paf_out_channels=38, heat_out_channels=19)
