@@ -284,11 +284,16 @@ def get_multiscale_outputs_batch(imgs, model, preprocess='rtpose', scales=(0.5, 
 
 
 def imread_bgr(path):
-    """cv2.imread stand-in for run_eval: OpenCV if present, else PIL, else a `.npy` file holding
-    the BGR uint8 array (this image has neither cv2 nor PIL).  Returns None if unreadable."""
+    """cv2.imread stand-in for run_eval: a `.npy` side-car holding the BGR uint8 array if the image
+    file itself is absent, else OpenCV if present, else PIL.  Returns None if unreadable."""
     import os
+    if not os.path.exists(path):
+        side = os.path.splitext(path)[0] + ".npy"
+        return np.load(side) if os.path.exists(side) else None
+    if path.endswith(".npy"):
+        return np.load(path)
     try:
-        import cv2  # noqa: F401
+        import cv2
         return cv2.imread(path)
     except ImportError:
         pass
@@ -296,11 +301,7 @@ def imread_bgr(path):
         from PIL import Image
         return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
     except ImportError:
-        pass
-    for cand in (path, os.path.splitext(path)[0] + ".npy"):
-        if cand.endswith(".npy") and os.path.exists(cand):
-            return np.load(cand)
-    return None
+        return None
 
 
 def run_eval(image_dir, anno_file, vis_dir, model, preprocess, config=None, imread=None, max_images=None):
