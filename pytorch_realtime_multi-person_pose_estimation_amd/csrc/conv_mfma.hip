@@ -693,7 +693,14 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* p
   // 1x1 layers: single halo buffer, 4 blocks per CU (occupancy hides the refill latency of
   // these short-K GEMMs better than a second buffer: 42.7 vs 32.6 TF/s); k x k: double buffer
   pl->nbuf = (g_force_nbuf == 1 || g_force_nbuf == 2) ? g_force_nbuf : (d.k == 1 ? 1 : 2);
-  bool strip = (W <= 64) && !d.pool;
+  // strips waste no MFMA work on tile edges but stage a longer halo than 2-D tiles on wide maps
+  // (3x3 at W = 92: 2.4x the tile vs 1.4x, against 8.9 % edge waste); widest map that still strips:
+  static int strip_maxw = 0;
+  if (!strip_maxw) {
+    const char* e = getenv("RTPOSE_CONV_STRIP_MAXW");
+    strip_maxw = e ? atoi(e) : 128;  // measured: conv3_1..3 (92 x 92) 6.70 -> 6.33 ms as strips; 184 x 184: no change
+  }
+  bool strip = (W <= strip_maxw) && !d.pool;
   if (strip) {
     const rtpose_layout& l = d.lin;
     const int lb = (kBM - 1) + ((kBM - 1) / W + 1) * (l.ws - W) +

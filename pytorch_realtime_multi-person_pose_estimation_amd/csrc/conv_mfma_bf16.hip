@@ -791,7 +791,15 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, int sp, Con
   const int cg = pl->ck / 8 * sp;
   pl->nbuf = d.k == 1 ? 1 : 2;
   const size_t tail = pl->nbuf == 2 ? 256 * 16 : 0;  // dummy park slots
-  bool strip = (W <= 64) && !d.pool;
+  // widest map that still uses strips (see conv_mfma.hip); measured on the 92 x 92 layers: bf16
+  // 841 (tiles) vs 835 TFLOP/s (strips), bf16x3 350 vs 356 - the longer tap loop of the split form
+  // amortises the strips' longer halo
+  static int strip_maxw = -1;
+  if (strip_maxw < 0) {
+    const char* e = getenv("RTPOSE_BF16_STRIP_MAXW");
+    strip_maxw = e ? atoi(e) : 0;
+  }
+  bool strip = (W <= (strip_maxw > 0 ? strip_maxw : (sp == 2 ? 128 : 64))) && !d.pool;
   {
     static int force_tile = -1;  // developer A/B: RTPOSE_BF16_FORCE_TILE=k forces 2-D tiles for k x k convs
     if (force_tile < 0) {
