@@ -68,3 +68,18 @@ def barrier(device=None):
             dist.barrier(device_ids=[device.index])
         else:
             dist.barrier()
+
+
+def batch_schedule(n_items, rank, world, batch):
+    """Batches of a rank's contiguous shard for a run in which EVERY rank issues the same number of
+    collectives (the gather is one all_gather per batch): list of (first_item, n_valid) of length
+    ceil(ceil(n_items / world) / batch); trailing entries of a short shard have n_valid == 0 (the
+    rank still computes a padded batch and takes part in the gather)."""
+    lo, hi = shard_range(n_items, rank, world)
+    per_rank = -(-n_items // world)
+    n_batches = -(-per_rank // batch)
+    out = []
+    for b in range(n_batches):
+        i0 = lo + b * batch
+        out.append((i0, max(0, min(batch, hi - i0))))
+    return out

@@ -138,6 +138,23 @@ dist.destroy_process_group()
 '''
 
 
+def test_batch_schedule_covers_every_item_once_with_equal_collective_counts(pkg):
+    par = importlib.import_module(PKG_NAME + ".parallel")
+    for n_items, world, batch in ((5000, 8, 32), (5000, 1, 32), (7, 4, 2), (64, 2, 32), (1, 3, 4)):
+        seen = []
+        lens = set()
+        for r in range(world):
+            sched = par.batch_schedule(n_items, r, world, batch)
+            lens.add(len(sched))
+            lo, hi = par.shard_range(n_items, r, world)
+            for i0, nv in sched:
+                assert 0 <= nv <= batch
+                seen += list(range(i0, i0 + nv))
+                assert nv == 0 or (lo <= i0 and i0 + nv <= hi)
+        assert len(lens) == 1                      # same number of all_gathers on every rank
+        assert sorted(seen) == list(range(n_items))
+
+
 def test_two_rank_shard_and_gather_gloo(tmp_path):
     """world_size 2 on CPU (gloo): shard, decode shard (oracle stand-in), all_gather, parse."""
     import subprocess

@@ -55,14 +55,14 @@ def main():
         heat, paf, _ = synth.make_batch(B, 368, 368, seed=2000 + s)
         pool.append((x, (torch.from_numpy(heat).to(dev), torch.from_numpy(paf).to(dev))))
     est(pool[0][0], pool[0][1])       # capacity growth + plan/weights warm-up (untimed)
-    nb_max = -(-(-(-args.images // world)) // B)   # every rank runs the same number of collectives
+    sched = par.batch_schedule(args.images, rank, world, B)   # every rank runs the same number of collectives
+    nb_max = len(sched)
     humans = 0
     torch.cuda.synchronize()
     par.barrier(dev)
     t0 = time.perf_counter()
     for b in range(nb_max):
-        i0 = lo + b * B
-        n_valid = max(0, min(B, hi - i0))
+        i0, n_valid = sched[b]
         x, scene = pool[((i0 // B) if n_valid else 0) % len(pool)]
         bufs = est.enqueue(x, scene)
         rec = bufs.result.view(bufs.n, bufs.words)
