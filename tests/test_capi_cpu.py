@@ -115,3 +115,20 @@ def test_compute_dtype_plans_on_the_host(capi, pkg):
     with _pt.raises(ValueError):
         m.set_compute_dtype('fp16')
     assert m.set_compute_dtype('bf16x3').compute_dtype == 'bf16x3'
+
+
+def test_header_is_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/rtpose_mi355x.h must compile as C99 on its own
+    (no C++, no HIP, no torch types in the signatures)."""
+    import os
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        import pytest as _pt
+        _pt.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "rtpose_mi355x.h"\nint main(void) { return rtpose_version() == 0; }\n')
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
+                    "-c", str(src), "-o", str(tmp_path / "hdr.o")], check=True)
