@@ -101,14 +101,58 @@ static void resize_cubic(const float* patch, int ph, int pw, int up, float* dst)
   free(hbuf);
 }
 
+/* cv2.resize(src, None, fx=up, fy=up, interpolation=INTER_CUBIC) on one float32 plane
+ * (exported for oracle/cv2_restate.py, the cv2 stand-in the reference modules are imported with) */
+void oracle_resize_cubic(const float* src, int h, int w, int up, float* dst) { resize_cubic(src, h, w, up, dst); }
+
+/*
+ * scipy.ndimage.gaussian_filter(img, sigma) on a float32 plane, mode='reflect', as
+ * paf_to_pose.py:121-122 calls it.  Restated from scipy's published algorithm
+ * (ndimage/_filters.py gaussian_filter -> gaussian_filter1d -> correlate1d,
+ * src/ni_filters.c NI_Correlate1D; scipy unpinned by requirements.txt:6, 1.15.3 here):
+ * one 1-D pass per axis, axis 0 (columns, i.e. along y) first, then axis 1; each pass
+ * accumulates in double, symmetric-kernel form  out = w[0]*c + sum_{j=-r..-1} (x[j] + x[-j]) * w[j],
+ * and is stored to the float32 output before the next pass reads it.  `weights` holds
+ * the 2r+1 normalised kernel values exp(-0.5 x^2 / sigma^2) / sum (computed by the caller
+ * with numpy exactly like _gaussian_kernel1d); reflect = (d c b a | a b c d | d c b a).
+ */
+static int reflect_idx(int i, int n) {
+  while (i < 0 || i >= n) {
+    if (i < 0) i = -i - 1;
+    if (i >= n) i = 2 * n - 1 - i;
+  }
+  return i;
+}
+void oracle_gaussian_filter_f32(float* img, int h, int w, const double* weights, int radius) {
+  float* tmp = (float*)malloc(sizeof(float) * (size_t)h * w);
+  const double* wc = weights + radius;
+  for (int x = 0; x < w; ++x)
+    for (int y = 0; y < h; ++y) {
+      double acc = (double)img[y * w + x] * wc[0];
+      for (int j = -radius; j < 0; ++j)
+        acc += ((double)img[reflect_idx(y + j, h) * w + x] + (double)img[reflect_idx(y - j, h) * w + x]) * wc[j];
+      tmp[y * w + x] = (float)acc;
+    }
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      double acc = (double)tmp[y * w + x] * wc[0];
+      for (int j = -radius; j < 0; ++j)
+        acc += ((double)tmp[y * w + reflect_idx(x + j, w)] + (double)tmp[y * w + reflect_idx(x - j, w)]) * wc[j];
+      img[y * w + x] = (float)acc;
+    }
+  free(tmp);
+}
+
 /*
  * NMS.  heat: dense HWC float32 [h][w][C].  Writes rows (x, y, score, id, part)
  * — the float32 joint_list of paf_to_pose_cpp (paf_to_pose.py:376-378) — in
  * part order, peaks of one part in row-major order.  Returns the number of peaks,
  * or -1 if more than `cap`.
+ * refine = bool_refine_center (:105, default 1), gaussian = bool_gaussian_filt (:121, default 0;
+ * gw/gr = normalised Gaussian weights [2*gr+1] and radius, see oracle_gaussian_filter_f32).
  */
-int oracle_nms(const float* heat, int h, int w, int C, int num_keypoints, float thr, int up, int cap,
-               float* joint_list) {
+int oracle_nms_ex(const float* heat, int h, int w, int C, int num_keypoints, float thr, int up, int cap,
+                  float* joint_list, int refine, int gaussian, const double* gw, int gr) {
   int total = 0;
   const int win = 2; /* paf_to_pose.py:100 */
   float* ups = (float*)malloc(sizeof(float) * (5 * up) * (5 * up));
@@ -127,6 +171,17 @@ int oracle_nms(const float* heat, int h, int w, int C, int num_keypoints, float 
           free(ups);
           return -1;
         }
+        float* o = joint_list + (size_t)total * 5;
+        const double cx = ((double)x + 0.5) * up - 0.5, cy = ((double)y + 0.5) * up - 0.5;
+        if (!refine) { /* :135-139: refined_center = [0, 0], score = map_orig[y, x] */
+          o[0] = (float)cx;
+          o[1] = (float)cy;
+          o[2] = v;
+          o[3] = (float)total;
+          o[4] = (float)part;
+          ++total;
+          continue;
+        }
         /* :108-113 clipped 5x5 window */
         const int x_min = x - win < 0 ? 0 : x - win, y_min = y - win < 0 ? 0 : y - win;
         const int x_max = x + win > w - 1 ? w - 1 : x + win, y_max = y + win > h - 1 ? h - 1 : y + win;
@@ -136,15 +191,14 @@ int oracle_nms(const float* heat, int h, int w, int C, int num_keypoints, float 
           for (int c = 0; c < pw; ++c)
             patch[r * pw + c] = heat[((size_t)(y_min + r) * w + x_min + c) * C + part];
         resize_cubic(patch, ph, pw, up, ups); /* :114-115 */
+        if (gaussian) oracle_gaussian_filter_f32(ups, ph * up, pw * up, gw, gr); /* :121-122 */
         /* :125-126 first arg-max in row-major order */
         int best = 0;
         for (int i = 1; i < ph * up * pw * up; ++i)
           if (ups[i] > ups[best]) best = i;
         const int row = best / (pw * up), col = best % (pw * up);
         /* :129-141 in float64: (c+0.5)*up-0.5 + (loc - ((c-cmin+0.5)*up-0.5)) */
-        const double cx = ((double)x + 0.5) * up - 0.5, cy = ((double)y + 0.5) * up - 0.5;
         const double pcx = ((double)(x - x_min) + 0.5) * up - 0.5, pcy = ((double)(y - y_min) + 0.5) * up - 0.5;
-        float* o = joint_list + (size_t)total * 5;
         o[0] = (float)(cx + ((double)col - pcx));
         o[1] = (float)(cy + ((double)row - pcy));
         o[2] = ups[best];
@@ -155,6 +209,11 @@ int oracle_nms(const float* heat, int h, int w, int C, int num_keypoints, float 
   }
   free(ups);
   return total;
+}
+
+int oracle_nms(const float* heat, int h, int w, int C, int num_keypoints, float thr, int up, int cap,
+               float* joint_list) {
+  return oracle_nms_ex(heat, h, w, C, num_keypoints, thr, up, cap, joint_list, 1, 0, 0, 0);
 }
 
 /* ---- process_paf ------------------------------------------------------------ */

@@ -28,6 +28,11 @@ def _post():
     lib = C.CDLL(_POST)
     lib.oracle_nms.restype = C.c_int
     lib.oracle_nms.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _fp]
+    lib.oracle_nms_ex.restype = C.c_int
+    lib.oracle_nms_ex.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _fp,
+                                  C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
+    lib.oracle_gaussian_filter_f32.restype = None
+    lib.oracle_gaussian_filter_f32.argtypes = [_fp, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
     lib.oracle_process_paf.restype = C.c_int
     lib.oracle_process_paf.argtypes = [_fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip,
                                        _fp, _ip, _ip, _fp, _ip, C.c_int]
@@ -65,13 +70,34 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def nms(heat, num_keypoints=18, thr=0.1, up=8, cap=4096):
-    """heat HWC float32 -> joint_list float32 [P,5] = (x, y, score, id, part)."""
+def gaussian_kernel1d(sigma=3.0, truncate=4.0):
+    """scipy.ndimage._filters._gaussian_kernel1d(sigma, 0, radius) with gaussian_filter1d's radius
+    (int(truncate * sigma + 0.5)): the normalised float64 weights scipy correlates with."""
+    radius = int(truncate * float(sigma) + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (float(sigma) * float(sigma)) * x ** 2)
+    return np.ascontiguousarray(phi / phi.sum(), dtype=np.float64), radius
+
+
+def gaussian_filter_f32(img, sigma=3.0):
+    """C restatement of scipy.ndimage.gaussian_filter(img float32, sigma) (mode='reflect')."""
+    a = _f32(img).copy()
+    wts, r = gaussian_kernel1d(sigma)
+    _post().oracle_gaussian_filter_f32(a.ctypes.data_as(_fp), a.shape[0], a.shape[1],
+                                       wts.ctypes.data_as(C.POINTER(C.c_double)), r)
+    return a
+
+
+def nms(heat, num_keypoints=18, thr=0.1, up=8, cap=4096, refine=True, gaussian=False):
+    """heat HWC float32 -> joint_list float32 [P,5] = (x, y, score, id, part).
+    refine / gaussian = NMS's bool_refine_center / bool_gaussian_filt (paf_to_pose.py:67)."""
     heat = _f32(heat)
     h, w, c = heat.shape
     out = np.zeros((cap, 5), np.float32)
-    n = _post().oracle_nms(heat.ctypes.data_as(_fp), h, w, c, num_keypoints, np.float32(thr), up, cap,
-                           out.ctypes.data_as(_fp))
+    wts, r = gaussian_kernel1d(3.0)
+    n = _post().oracle_nms_ex(heat.ctypes.data_as(_fp), h, w, c, num_keypoints, np.float32(thr), up, cap,
+                              out.ctypes.data_as(_fp), 1 if refine else 0, 1 if gaussian else 0,
+                              wts.ctypes.data_as(C.POINTER(C.c_double)), r)
     if n < 0:
         raise RuntimeError("oracle_nms: more than %d peaks" % cap)
     return out[:n].copy()

@@ -168,20 +168,29 @@ __global__ void flip_merge_kernel(const float* __restrict__ heat, const float* _
 // uint8 BGR HWC image -> cv2.resize(fx=fy=scale, INTER_LINEAR) in OpenCV's 11-bit fixed point
 // -> zero pad to the network size -> normalise -> the net's NHWC8 input buffer.  Integer
 // arithmetic identical to preprocess.resize_linear_u8 (the numpy restatement): bit-exact.
+// Columns (resize.cpp's dx loop): taps that fall outside clamp BOTH the offset and the weight
+// (f = 0).  Rows (the dy loop) keep their weight and resizeGeneric_Invoker clips the two source
+// rows instead - same value in real arithmetic, not always the same 11-bit fixed-point sum.
+template <bool ROWS>
 __device__ __forceinline__ void lin_coeff(int d, int sn, double scale, int& s0, int& s1, int& a0, int& a1) {
   float f = (float)(((double)d + 0.5) * scale - 0.5);
   int s = (int)floorf(f);
   f -= (float)s;
-  if (s < 0) {
-    f = 0.f;
-    s = 0;
+  if (ROWS) {
+    s0 = min(max(s, 0), sn - 1);
+    s1 = min(max(s + 1, 0), sn - 1);
+  } else {
+    if (s < 0) {
+      f = 0.f;
+      s = 0;
+    }
+    if (s >= sn - 1) {
+      f = 0.f;
+      s = sn - 1;
+    }
+    s0 = s;
+    s1 = min(s + 1, sn - 1);
   }
-  if (s >= sn - 1) {
-    f = 0.f;
-    s = sn - 1;
-  }
-  s0 = s;
-  s1 = min(s + 1, sn - 1);
   a1 = (int)rintf(f * 2048.f);
   a0 = (int)rintf((1.f - f) * 2048.f);
 }
@@ -197,8 +206,8 @@ __global__ void preprocess_u8_kernel(const unsigned char* __restrict__ img, int 
   if (y < hr && x < wr) {
     int x0, x1, ax0, ax1, y0, y1, ay0, ay1;
     // flip: this destination column shows the x-mirrored RESIZED image (valid region only)
-    lin_coeff(flip ? wr - 1 - x : x, w0, inv_scale, x0, x1, ax0, ax1);
-    lin_coeff(y, h0, inv_scale, y0, y1, ay0, ay1);
+    lin_coeff<false>(flip ? wr - 1 - x : x, w0, inv_scale, x0, x1, ax0, ax1);
+    lin_coeff<true>(y, h0, inv_scale, y0, y1, ay0, ay1);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const int s00 = img[((size_t)y0 * w0 + x0) * 3 + c], s01 = img[((size_t)y0 * w0 + x1) * 3 + c];

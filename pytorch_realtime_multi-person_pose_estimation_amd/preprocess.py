@@ -35,21 +35,25 @@ def resize_linear_u8(im, fx, fy):
     dw, dh = _cv_round(w * fx), _cv_round(h * fy)
     sx_scale, sy_scale = 1.0 / fx, 1.0 / fy
 
-    def coeffs(dn, sn, scale):
+    def coeffs(dn, sn, scale, rows):
         d = np.arange(dn, dtype=np.float64)
         f = ((d + 0.5) * scale - 0.5).astype(np.float32)
         s = np.floor(f).astype(np.int64)
         f = (f - s.astype(np.float32)).astype(np.float32)
-        lo = s < 0
-        f[lo], s[lo] = 0.0, 0
-        hi = s >= sn - 1
-        f[hi], s[hi] = 0.0, sn - 1
+        if rows:   # resize.cpp's dy loop keeps the weight; resizeGeneric_Invoker clips the two source rows
+            s0, s1 = np.clip(s, 0, sn - 1), np.clip(s + 1, 0, sn - 1)
+        else:      # the dx loop clamps offset AND weight (f = 0) for taps outside the image
+            lo = s < 0
+            f[lo], s[lo] = 0.0, 0
+            hi = s >= sn - 1
+            f[hi], s[hi] = 0.0, sn - 1
+            s0, s1 = s, np.minimum(s + 1, sn - 1)
         a1 = np.rint(f * np.float32(2048)).astype(np.int64)
         a0 = np.rint((np.float32(1.0) - f) * np.float32(2048)).astype(np.int64)
-        return s, np.minimum(s + 1, sn - 1), a0, a1
+        return s0, s1, a0, a1
 
-    x0, x1, ax0, ax1 = coeffs(dw, w, sx_scale)
-    y0, y1, ay0, ay1 = coeffs(dh, h, sy_scale)
+    x0, x1, ax0, ax1 = coeffs(dw, w, sx_scale, False)
+    y0, y1, ay0, ay1 = coeffs(dh, h, sy_scale, True)
     src = im.astype(np.int64)
     if src.ndim == 2:
         src = src[:, :, None]

@@ -117,3 +117,46 @@ def make_batch(n_images, height=368, width=368, seed=1, max_people=8, noise=0.02
         pafs.append(pf)
         gt.append(people)
     return np.stack(heats), np.stack(pafs), gt
+
+
+def he_init_state_dict(model, seed=0):
+    """Seeded stand-in weights for `pose_model.pth` (not available offline): Kaiming-normal conv
+    weights + N(0, 0.05) biases, drawn key by key in state_dict order from one torch generator.
+    The reference's own init (lib/network/rtpose_vgg.py:200-222: N(0, 0.01), zero bias) drives the
+    stage outputs to ~5e-11, useless as a workload or for parity.  bench.py, the tools and the
+    tests all use this; oracle/net_oracle.py carries the same recipe for the build-container
+    golden generators (tests/test_host_golden_cpu.py checks that the two agree)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, v in model.state_dict().items():
+        if k.endswith('.weight'):
+            fan_in = v.shape[1] * v.shape[2] * v.shape[3]
+            sd[k] = torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5
+        else:
+            sd[k] = torch.randn(v.shape, generator=g) * 0.05
+    return sd
+
+
+def seeded_shufflenet_state_dict(model, seed=0):
+    """Seeded stand-in weights for the ShuffleNetV2 pose net (BASELINE configs[3]): Kaiming convs,
+    BN gamma in [0.35, 0.75) so activations stay O(1), running statistics away from (0, 1).
+    Same recipe as oracle/shufflenet_oracle.py:seeded_state_dict."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, v in model.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = v.clone()
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(v.shape, generator=g) + 0.5
+        elif k.endswith("running_mean"):
+            sd[k] = torch.randn(v.shape, generator=g) * 0.1
+        elif v.dim() == 4:
+            fan_in = v.shape[1] * v.shape[2] * v.shape[3]
+            sd[k] = torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5
+        elif k.endswith(".weight"):
+            sd[k] = torch.rand(v.shape, generator=g) * 0.4 + 0.35
+        else:
+            sd[k] = torch.randn(v.shape, generator=g) * 0.1
+    return sd

@@ -38,9 +38,8 @@ def main():
     rank, local_rank, world = par.init_from_env("nccl")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    from oracle import net_oracle
     model = pkg.get_model('vgg19')
-    model.load_state_dict(net_oracle.he_init_state_dict(model, seed=0))
+    model.load_state_dict(synth.he_init_state_dict(model, seed=0))
     model = model.cuda().float().eval()
     model.set_compute_dtype(args.dtype)
     est = pipeline.PoseEstimator(model)

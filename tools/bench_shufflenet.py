@@ -11,6 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PKG = "pytorch_realtime_multi-person_pose_estimation_amd"
 pkg = importlib.import_module(PKG)
+synth = importlib.import_module(pkg.__name__ + ".synth")
 sn = importlib.import_module(PKG + ".shufflenet")
 capi = pkg._capi
 lib = capi.lib
@@ -20,10 +21,9 @@ MIN_BYTES_PER_IMG = 1.63e6 + 0.48e6   # read input + write outputs (weights 5.2 
 
 
 def main(n=128, iters=10, dtype='fp32'):
-    from oracle import shufflenet_oracle as so
     dev = torch.device("cuda:0")
     m = sn.Network(1.0)
-    m.load_state_dict(so.seeded_state_dict(m, 0))
+    m.load_state_dict(synth.seeded_shufflenet_state_dict(m, 0))
     m = m.cuda().eval()
     m.set_compute_dtype(dtype)
     x = (torch.rand(n, 3, 368, 368, generator=torch.Generator().manual_seed(0)) - 0.5).to(dev)

@@ -10,13 +10,13 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("pytorch_realtime_multi-person_pose_estimation_amd")
+synth = importlib.import_module(pkg.__name__ + ".synth")
 pipeline = importlib.import_module(pkg.__name__ + ".pipeline")
 
 
 def main(nb=12, B=32):
-    from oracle import net_oracle
     m = pkg.get_model('vgg19')
-    m.load_state_dict(net_oracle.he_init_state_dict(m, 0))
+    m.load_state_dict(synth.he_init_state_dict(m, 0))
     m = m.cuda().eval()
     rng = np.random.default_rng(0)
     # smooth images: junk-map peaks stay within the default table capacities

@@ -17,9 +17,8 @@ pipeline = importlib.import_module(pkg.__name__ + ".pipeline")
 
 
 def main(iters=50):
-    from oracle import net_oracle
     m = pkg.get_model('vgg19')
-    m.load_state_dict(net_oracle.he_init_state_dict(m, 0))
+    m.load_state_dict(synth.he_init_state_dict(m, 0))
     m = m.cuda().eval()
     x = (torch.rand(1, 3, 368, 368) - 0.5).cuda()
     est = pipeline.PoseEstimator(m)

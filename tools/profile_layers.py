@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("pytorch_realtime_multi-person_pose_estimation_amd")
+synth = importlib.import_module(pkg.__name__ + ".synth")
 capi = pkg._capi
 lib = capi.lib
 
@@ -15,8 +16,7 @@ lib = capi.lib
 def main(n=32, h=368, w=368, iters=5, dtype='fp32'):
     dev = torch.device("cuda:0")
     m = pkg.get_model('vgg19')
-    from oracle import net_oracle
-    m.load_state_dict(net_oracle.he_init_state_dict(m, 0))
+    m.load_state_dict(synth.he_init_state_dict(m, 0))
     m = m.cuda().eval()
     m.set_compute_dtype(dtype)
     x = (torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(0)) - 0.5).to(dev)

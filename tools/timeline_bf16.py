@@ -10,13 +10,13 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("pytorch_realtime_multi-person_pose_estimation_amd")
+synth = importlib.import_module(pkg.__name__ + ".synth")
 lib = pkg._capi.lib
 
 
 def main(n=32, hw=368):
-    from oracle import net_oracle
     m = pkg.get_model('vgg19')
-    m.load_state_dict(net_oracle.he_init_state_dict(m, 0))
+    m.load_state_dict(synth.he_init_state_dict(m, 0))
     m = m.cuda().eval()
     m.set_compute_dtype('bf16')
     x = (torch.rand(n, 3, hw, hw) - 0.5).cuda()
