@@ -49,24 +49,42 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sample_scenes):
-    """The oracle restatement (torch-CPU fp32 functional net = the ATen ops the reference
-    module runs, + the plain-C post) timed on the host cores of this box: bounded sample."""
+    """the reference's arithmetic on the host cores of THIS box, bounded sample.
+      net  = the oracle port (oracle/net_oracle.py: the ATen CPU conv2d / max_pool2d / cat calls the
+             reference module makes, fp32), bs=1 (the reference's own usage, coco_eval.py:105) and bs=32;
+      post = restated NMS (C) + the reference's pafprocess.cpp compiled UNMODIFIED
+             (oracle/_ref/libpafprocess_ref.so, fed x8 INTER_NEAREST maps exactly like
+             paf_to_pose.py:381-386) when that binary travelled with the snapshot, else the C restatement.
+    `value` = 1 / (net bs=1 s/img + post s/img): the reference's serial per-image flow."""
     from oracle import net_oracle, post_oracle
     pkg = importlib.import_module(PKG)
-    # host threads: os.cpu_count() can exceed what this process may use (cgroup quota /
-    # affinity), and oversubscribing torch's pool is catastrophic, so probe a few pool
-    # sizes on a quarter-size input and keep the fastest
+    synth = importlib.import_module(PKG + ".synth")
+    logical = os.cpu_count() or 1
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        avail = os.cpu_count() or 1
+        avail = logical
     m = pkg.get_model('vgg19')
-    sd = net_oracle.he_init_state_dict(m, seed=0)
+    sd = synth.he_init_state_dict(m, seed=0)
     g = torch.Generator().manual_seed(0)
+    # torch's intra-op pool: os.cpu_count() can exceed what this process may use (cgroup quota /
+    # affinity) and oversubscription is catastrophic, so probe a few pool sizes on a quarter-size
+    # input and keep the fastest; all candidates and their times are reported
     probe = torch.rand(1, 3, 184, 184, generator=g) - 0.5
-    best = None
-    for t in sorted({avail, 64, 32, 16, 8}):
+    best, tried = None, {}
+    for t in sorted({avail, 128, 64, 32, 16, 8}):
         if t > avail:
             continue
         torch.set_num_threads(t)
@@ -74,29 +92,68 @@ def cpu_baseline(sample_scenes):
         t0 = time.perf_counter()
         net_oracle.forward(sd, probe)
         dt = time.perf_counter() - t0
+        tried[t] = round(dt, 4)
         if best is None or dt < best[0]:
             best = (dt, t)
         elif dt > 1.5 * best[0]:
             break                                  # more threads only make it worse from here
-    cores = best[1]
-    torch.set_num_threads(cores)
+    threads = best[1]
+    torch.set_num_threads(threads)
     t_net, n_net = 0.0, 0
-    while n_net < 8 and t_net < 12.0:
+    while n_net < 8 and t_net < 8.0:
         x = torch.rand(1, 3, SIZE, SIZE, generator=g) - 0.5               # bs=1 like coco_eval.py:105
         t0 = time.perf_counter()
         net_oracle.forward(sd, x)
         t_net += time.perf_counter() - t0
         n_net += 1
-    heat, paf = sample_scenes
+    xb = torch.rand(BATCH, 3, SIZE, SIZE, generator=g) - 0.5              # one bs=32 pass
     t0 = time.perf_counter()
+    net_oracle.forward(sd, xb)
+    t_b32 = (time.perf_counter() - t0) / BATCH
+    heat, paf = sample_scenes
+    use_ref = post_oracle.have_ref()
+    t_nms = t_pp = 0.0
     for i in range(heat.shape[0]):
-        post_oracle.paf_to_pose(heat[i], paf[i])
-    t_post = (time.perf_counter() - t0) / heat.shape[0]
+        t0 = time.perf_counter()
+        jl = post_oracle.nms(heat[i])
+        t1 = time.perf_counter()
+        if use_ref:                      # paf_to_pose.py:382-386: x8 nearest maps, then process_paf
+            post_oracle.ref_process_paf(jl, post_oracle.upsample_nearest(heat[i], 8),
+                                        post_oracle.upsample_nearest(paf[i], 8))
+        else:
+            post_oracle.process_paf(jl, paf[i], 8)
+        t2 = time.perf_counter()
+        t_nms += t1 - t0
+        t_pp += t2 - t1
+    n_post = heat.shape[0]
+    t_post = (t_nms + t_pp) / n_post
     per_img = t_net / n_net + t_post
-    return {"value": round(1.0 / per_img, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d images 368x368 bs=1 through the torch-CPU fp32 oracle net (%.3f s/img, %d threads) + "
-                      "%d synthetic scenes through the C oracle NMS+process_paf (%.2f ms/img, 1 thread)"
-                      % (n_net, t_net / n_net, cores, heat.shape[0], t_post * 1e3)}
+    return {"value": round(1.0 / per_img, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "post_kind": "reference" if use_ref else "port",
+            "cpu_model": _cpu_model(), "os_cpu_count": logical, "sched_affinity": avail,
+            "torch_threads": threads, "thread_probe_s": tried,
+            "net_bs1_img_s": round(n_net / t_net, 3), "net_bs32_img_s": round(1.0 / t_b32, 3),
+            "post_img_s": round(1.0 / t_post, 1),
+            "end_to_end_bs32_img_s": round(1.0 / (t_b32 + t_post), 3),
+            "sample": "net: %d images 368x368 at bs=1 (%.3f s/img) + one bs=32 pass (%.3f s/img) through the torch-CPU "
+                      "fp32 oracle port, %d threads; post: %d synthetic scenes, restated C NMS (%.2f ms/img) + %s "
+                      "(%.2f ms/img), 1 thread"
+                      % (n_net, t_net / n_net, t_b32, threads, n_post, t_nms / n_post * 1e3,
+                         "the reference's pafprocess.cpp compiled unmodified (oracle/_ref) on x8 nearest maps"
+                         if use_ref else "the C restatement of process_paf (oracle/_ref absent)",
+                         t_pp / n_post * 1e3)}
+
+
+def algorithmic_bytes_7x7(two_byte):
+    """HBM bytes one grouped (PAF + heat-map branch) 7x7 launch must move at least: its input read
+    once, both branches' weights and biases, both outputs - averaged over the 25 such launches of a
+    forward (5 stages x [one 185 -> 128 layer whose 185-channel input the two branches share + four
+    128 -> 128 layers with one input per branch]); rtpose_vgg.py:108-127."""
+    e = 2 if two_byte else 4
+    npix = BATCH * (SIZE // 8) * (SIZE // 8)
+    first = npix * 185 * e + 2 * (185 * 49 * 128 * e + 128 * 4) + 2 * npix * 128 * e
+    other = 2 * npix * 128 * e + 2 * (128 * 49 * 128 * e + 128 * 4) + 2 * npix * 128 * e
+    return int(round((5 * first + 20 * other) / 25.0))
 
 
 def measure_traffic(timeout_s=150, dtype="fp32"):
@@ -176,9 +233,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from oracle import net_oracle  # weight initialiser only (seeded He init shared with the tests)
     model = pkg.get_model('vgg19')
-    model.load_state_dict(net_oracle.he_init_state_dict(model, seed=0))
+    model.load_state_dict(synth.he_init_state_dict(model, seed=0))   # no checkpoint exists offline
     model = model.cuda().float().eval()
     model.set_compute_dtype(args.dtype)
     bf16 = args.dtype != "fp32"
@@ -278,7 +334,7 @@ def main():
             if tr:
                 out["roofline"]["traffic"] = round(tr["fetch_bytes"] + tr["write_bytes"])
                 out["roofline"]["traffic_detail"] = tr
-                out["roofline"]["algorithmic_bytes_per_launch"] = 38_000_000 if (bf16 and not x3) else 76_000_000
+                out["roofline"]["algorithmic_bytes_per_launch"] = algorithmic_bytes_7x7(bf16 and not x3)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline((heat_np, paf_np))
         else:

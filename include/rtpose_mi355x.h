@@ -422,6 +422,27 @@ int rtpose_nms_batch(const float* heat, const rtpose_layout* lheat, int N,
                      int h, int w, const rtpose_decode_cfg* cfg, void* result,
                      void* stream);
 
+/* The two optional branches of NMS (lib/utils/paf_to_pose.py:67; neither is enabled by
+ * the reference's own callers): RTPOSE_NMS_GAUSSIAN = bool_gaussian_filt=True — the x8
+ * patch is smoothed with scipy.ndimage.gaussian_filter(sigma=3) before the arg-max
+ * (:121-122); RTPOSE_NMS_NO_REFINE = bool_refine_center=False — no patch, the peak is
+ * the cell centre (c + 0.5) * up - 0.5 with the low-resolution map value as score
+ * (:135-139); rtpose_peak.x / .y then hold that coordinate truncated to int, which is
+ * what process_paf makes of the joint_list column (pafprocess.cpp:28-29). */
+#define RTPOSE_NMS_NO_REFINE 1
+#define RTPOSE_NMS_GAUSSIAN 2
+int rtpose_nms_batch_ex(const float* heat, const rtpose_layout* lheat, int N,
+                        int h, int w, const rtpose_decode_cfg* cfg, int nms_flags,
+                        void* result, void* stream);
+int rtpose_decode_batch_ex(const float* heat, const rtpose_layout* lheat,
+                           const float* paf, const rtpose_layout* lpaf, int N,
+                           int h, int w, const rtpose_decode_cfg* cfg,
+                           int nms_flags, void* workspace,
+                           size_t workspace_bytes, void* result, void* stream);
+/* The 25 normalised float64 weights RTPOSE_NMS_GAUSSIAN correlates with
+ * (scipy _gaussian_kernel1d(sigma=3, radius=12)); returns 25, or < 0. */
+int rtpose_gaussian_kernel1d(double* weights, int cap);
+
 /* ------------------------------------------------------------------------
  * 5. Flip test-time-augmentation merge
  *    stands in for evaluate/coco_eval.py:197-242 (handle_paf_and_heat).

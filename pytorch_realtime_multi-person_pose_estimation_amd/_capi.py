@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("RTPOSE_LIB_PATH") or os.path.join(_HERE, "lib", "libr
 NUM_PART = 18
 NUM_LIMB = 19
 DTYPE_F32, DTYPE_BF16, DTYPE_BF16X3 = 0, 1, 2
+NMS_NO_REFINE, NMS_GAUSSIAN = 1, 2
 
 
 class RtposeError(RuntimeError):
@@ -134,6 +135,9 @@ _SIGS = {
     "rtpose_decode_result_bytes": (_sz, [C.POINTER(DecodeCfg), _i]),
     "rtpose_decode_batch": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, C.POINTER(DecodeCfg), _vp, _sz, _vp, _vp]),
     "rtpose_nms_batch": (_i, [_vp, _LP, _i, _i, _i, C.POINTER(DecodeCfg), _vp, _vp]),
+    "rtpose_nms_batch_ex": (_i, [_vp, _LP, _i, _i, _i, C.POINTER(DecodeCfg), _i, _vp, _vp]),
+    "rtpose_decode_batch_ex": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, C.POINTER(DecodeCfg), _i, _vp, _sz, _vp, _vp]),
+    "rtpose_gaussian_kernel1d": (_i, [C.POINTER(C.c_double), _i]),
     "rtpose_preprocess_u8": (_i, [_vp, _i, _i, C.c_double, _i, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
     "rtpose_preprocess_u8_flip": (_i, [_vp, _i, _i, C.c_double, _i, _vp, _LP, _i, _i, _i, _i, _i, _i, _vp]),
     "rtpose_tta_accumulate": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, _vp, _vp, _i, _i, C.c_float, C.c_float,

@@ -1,0 +1,54 @@
+"""Book-keeping shared by the two nn.Module front-ends (network.RtposeVGG, shufflenet.Network):
+native plans, packed-weight arenas and the keys that say what an arena was packed from.
+
+* Everything is keyed by (device index, compute dtype): a forward on a second GPU - e.g. a replica
+  made by ``nn.DataParallel`` (demo/picture_demo.py:47), which shares these dicts by reference
+  because ``replicate`` shallow-copies ``__dict__`` - gets its own arena and plans and never evicts
+  or re-packs another device's.  One lock serialises plan creation and weight packing.
+* An arena is re-packed when a parameter / buffer changed.  ``Tensor._version`` and ``data_ptr()``
+  catch ``load_state_dict``, optimiser steps, ``.to()`` / ``.cuda()``; they do NOT see writes made
+  through ``.data`` (``p.data.copy_()``, ``p.data.fill_()`` never bump ``_version``).  So
+  ``load_state_dict`` and ``_apply`` also bump an explicit epoch, ``invalidate_weights()`` is public
+  for code that mutates ``.data``, and ``always_resync = True`` re-packs on every forward.
+"""
+import threading
+
+MAX_PLANS_PER_DEVICE = 8    # bounds the workspaces kept alive per GPU
+
+
+class NativeStateMixin(object):
+    def _init_native_state(self):
+        self._plans = {}         # (n, h, w, device index, dtype) -> plan
+        self._weights = {}       # (device index, dtype) -> packed weight arena (torch tensor)
+        self._weights_key = {}   # (device index, dtype) -> what the arena was packed from
+        self._weights_epoch = [0]   # boxed: shared with DataParallel replicas like the dicts above
+        self._native_lock = threading.RLock()
+        self.always_resync = False
+
+    def invalidate_weights(self):
+        """Force a re-pack of the native weight arenas on the next forward.  Needed after in-place
+        edits through ``.data`` (they leave ``Tensor._version`` untouched); harmless otherwise."""
+        with self._native_lock:
+            self._weights_epoch[0] += 1
+        return self
+
+    def load_state_dict(self, *args, **kwargs):
+        r = super(NativeStateMixin, self).load_state_dict(*args, **kwargs)
+        self.invalidate_weights()
+        return r
+
+    def _apply(self, fn, *args, **kwargs):
+        r = super(NativeStateMixin, self)._apply(fn, *args, **kwargs)
+        if hasattr(self, "_native_lock"):
+            self.invalidate_weights()
+        return r
+
+    def _params_key(self, tensors):
+        return (self._weights_epoch[0],) + tuple((t._version, t.data_ptr()) for t in tensors)
+
+    def _remember_plan(self, key, plan):
+        dev = key[3]
+        mine = [k for k in self._plans if k[3] == dev]
+        if len(mine) >= MAX_PLANS_PER_DEVICE:
+            self._plans.pop(mine[0])        # oldest plan of THIS device only
+        self._plans[key] = plan

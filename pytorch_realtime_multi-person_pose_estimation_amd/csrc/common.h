@@ -28,6 +28,39 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
+// ---- per-device host state ---------------------------------------------------------------
+// One process may drive several GPUs (the reference wraps its model in nn.DataParallel,
+// demo/picture_demo.py:47), so nothing learnt about "the" device is cached per process:
+// kernel attributes and CU counts are kept per HIP device ordinal.
+constexpr int kMaxDevices = 64;
+
+inline int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+  return d;
+}
+
+// "done once per device" flag set (e.g. hipFuncSetAttribute of one kernel instantiation);
+// benign if two threads race: the attribute is simply set twice.
+struct PerDeviceOnce {
+  volatile bool done[kMaxDevices];
+  bool is_set(int dev) const { return done[dev]; }
+  void set(int dev) { done[dev] = true; }
+};
+
+inline int device_cu_count() {
+  static volatile int n_cu[kMaxDevices];
+  const int dev = current_device();
+  int n = n_cu[dev];
+  if (!n) {
+    hipDeviceProp_t prop;
+    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+    if (n <= 0) n = 256;
+    n_cu[dev] = n;
+  }
+  return n;
+}
+
 // Output channels are padded to the conv kernel's N tile.
 constexpr int kConvBN = 64;
 inline int cout_pad(int cout) { return ceil_div(cout, kConvBN) * kConvBN; }

@@ -1,0 +1,78 @@
+// Developer ablation switches of the two conv kernels (conv_mfma.hip, conv_mfma_bf16.hip), all in
+// one place.  PRODUCTION builds (csrc/Makefile) do not define RTPOSE_DEV_BUILD: every macro below
+// collapses to the measured-best setting, no environment variable is read, and a stray
+// -DRTPOSE_EXP_* is a compile error.  Developer builds (tools/exp_variants*.sh, tools/ab_env*.sh:
+// -DRTPOSE_DEV_BUILD [-DRTPOSE_EXP_...]) switch single load streams / pipeline stages off to
+// measure what each costs (verdicts are recorded next to the code they concern and in DESIGN.md §8).
+#pragma once
+#include <cstdlib>
+
+#ifndef RTPOSE_DEV_BUILD
+#if defined(RTPOSE_EXP_TIMELINE) || defined(RTPOSE_EXP_NO_A) || defined(RTPOSE_EXP_NO_B) ||             \
+    defined(RTPOSE_EXP_NO_STAGE) || defined(RTPOSE_EXP_NO_FILL) || defined(RTPOSE_EXP_NO_STORE) ||      \
+    defined(RTPOSE_EXP_SCALAR_STORE) || defined(RTPOSE_EXP_BSPREAD) || defined(RTPOSE_EXP_HALF_B_ON) || \
+    defined(RTPOSE_EXP_STAGGER) || defined(RTPOSE_EXP_TB1X1) || defined(RTPOSE_EXP_HD) ||               \
+    defined(RTPOSE_EXP_RB2)
+#error "RTPOSE_EXP_* ablation switches need -DRTPOSE_DEV_BUILD (they are not part of production builds)"
+#endif
+#endif
+
+namespace rtpose {
+// Environment knobs (RTPOSE_CONV_*, RTPOSE_BF16_*) exist in developer builds only.
+inline const char* dev_env(const char* name) {
+#ifdef RTPOSE_DEV_BUILD
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+}  // namespace rtpose
+
+// per-block s_memtime stamps (tools/timeline_*.py)
+#ifdef RTPOSE_EXP_TIMELINE
+#define RTPOSE_TSTAMP(slot) \
+  if (A.dbg && threadIdx.x == 0) A.dbg[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime()
+#else
+#define RTPOSE_TSTAMP(slot)
+#endif
+
+// fp32 1x1 convs: CK-channel sub-chunks per LDS buffer (4: -20 % on the 1x1 layers)
+#ifndef RTPOSE_EXP_TB1X1
+#define RTPOSE_EXP_TB1X1 1
+#endif
+// bf16: depth of the halo staging ring / of the weight prefetch ring of the 2 x 2 wave form
+#ifndef RTPOSE_EXP_HD
+#define RTPOSE_EXP_HD 3
+#endif
+#ifndef RTPOSE_EXP_RB2
+#define RTPOSE_EXP_RB2 4
+#endif
+
+// fp32: which B register (k-group) is fetched after MFMA pair n (-1 = none); GB is the kernel's
+#ifdef RTPOSE_EXP_BSPREAD
+#define RTPOSE_EXP_BSLOT(n) (((n) % 2 == 0 && (n) / 2 < GB) ? (n) / 2 : -1)
+#else
+#define RTPOSE_EXP_BSLOT(n) (((n) < GB) ? (n) : -1)
+#endif
+#ifdef RTPOSE_EXP_HALF_B_ON
+#define RTPOSE_EXP_HALF_B 1
+#else
+#define RTPOSE_EXP_HALF_B 0
+#endif
+// drop one load stream at a time: weights (B), LDS fragment reads (A), next-chunk halo staging
+#ifdef RTPOSE_EXP_NO_B
+#define RTPOSE_EXP_B(load, keep) (keep)
+#else
+#define RTPOSE_EXP_B(load, keep) (load)
+#endif
+#ifdef RTPOSE_EXP_NO_A
+#define RTPOSE_EXP_A(load, keep) (keep)
+#else
+#define RTPOSE_EXP_A(load, keep) (load)
+#endif
+#ifdef RTPOSE_EXP_NO_STAGE
+#define RTPOSE_EXP_STAGE 0
+#else
+#define RTPOSE_EXP_STAGE 1
+#endif

@@ -31,6 +31,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "conv_exp.h"
 
 namespace rtpose {
 
@@ -71,18 +72,9 @@ struct ConvArgs {
   int dephase_cycles, n_cu;  // start-up delay that puts the 2 blocks of a CU half a tile apart
   unsigned long long* dbg;   // RTPOSE_EXP_TIMELINE builds only: 8 x u64 per block
 };
-#ifdef RTPOSE_EXP_TIMELINE
-#define RTPOSE_TSTAMP(slot) \
-  if (A.dbg && threadIdx.x == 0) A.dbg[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime()
-#else
-#define RTPOSE_TSTAMP(slot)
-#endif
 
 constexpr int kBM = 128;
-// 1x1 convs: CK-channel sub-chunks per LDS buffer (see conv_tile); developer knob
-#ifndef RTPOSE_EXP_TB1X1
-#define RTPOSE_EXP_TB1X1 1
-#endif
+// 1x1 convs: CK-channel sub-chunks per LDS buffer (see conv_tile); developer knob (conv_exp.h)
 constexpr int kTB1x1 = RTPOSE_EXP_TB1X1;
 
 template <int KS>
@@ -316,31 +308,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   // measured, every VALU instruction in this loop costs MFMA issue slots once two
   // waves share a SIMD (tools/exp_variants.sh drops one load stream at a time).
   // which B register (k-group) is fetched after MFMA pair n (-1 = none)
-#ifdef RTPOSE_EXP_BSPREAD
-#define RTPOSE_EXP_BSLOT(n) (((n) % 2 == 0 && (n) / 2 < GB) ? (n) / 2 : -1)
-#else
-#define RTPOSE_EXP_BSLOT(n) (((n) < GB) ? (n) : -1)
-#endif
-#ifdef RTPOSE_EXP_HALF_B_ON
-#define RTPOSE_EXP_HALF_B 1
-#else
-#define RTPOSE_EXP_HALF_B 0
-#endif
-#ifdef RTPOSE_EXP_NO_B
-#define RTPOSE_EXP_B(load, keep) (keep)
-#else
-#define RTPOSE_EXP_B(load, keep) (load)
-#endif
-#ifdef RTPOSE_EXP_NO_A
-#define RTPOSE_EXP_A(load, keep) (keep)
-#else
-#define RTPOSE_EXP_A(load, keep) (load)
-#endif
-#ifdef RTPOSE_EXP_NO_STAGE
-#define RTPOSE_EXP_STAGE 0
-#else
-#define RTPOSE_EXP_STAGE 1
-#endif
+  // (RTPOSE_EXP_BSLOT / _B / _A / _STAGE: identity in production builds, see conv_exp.h)
   // memory clobber: loads/stores may not cross (IR + DAG); sched_barrier: nothing may
   // cross in the machine scheduler
 #define RTPOSE_PIN()                 \
@@ -687,7 +655,7 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* p
   const int max_pieces = (d.k == 1) ? PiecesPerTap<1>::value : d.k * d.k - 1;
   const int cg = (pl->ck / 4) * (d.k == 1 ? kTB1x1 : 1);  // channel-group planes per LDS buffer
   if (!g_force_nbuf) {
-    const char* e = getenv("RTPOSE_CONV_NBUF");
+    const char* e = dev_env("RTPOSE_CONV_NBUF");
     g_force_nbuf = e ? atoi(e) : -1;
   }
   // 1x1 layers: single halo buffer, 4 blocks per CU (occupancy hides the refill latency of
@@ -697,7 +665,7 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* p
   // (3x3 at W = 92: 2.4x the tile vs 1.4x, against 8.9 % edge waste); widest map that still strips:
   static int strip_maxw = 0;
   if (!strip_maxw) {
-    const char* e = getenv("RTPOSE_CONV_STRIP_MAXW");
+    const char* e = dev_env("RTPOSE_CONV_STRIP_MAXW");
     strip_maxw = e ? atoi(e) : 128;  // measured: conv3_1..3 (92 x 92) 6.70 -> 6.33 ms as strips; 184 x 184: no change
   }
   bool strip = (W <= strip_maxw) && !d.pool;
@@ -751,12 +719,13 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, ConvPlan* p
 
 template <int KS, int CK, int MODE, int NBUF, int NF>
 static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  static bool attr_set = false;
+  static PerDeviceOnce attr_set;  // zero-initialised; the attribute is per device
+  const int dev = current_device();
   auto kern = conv_mfma_f32<KS, CK, MODE, NBUF, NF>;
-  if (!attr_set) {
+  if (!attr_set.is_set(dev)) {
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_set = true;
+    attr_set.set(dev);
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   RTPOSE_HIP_CHECK(hipGetLastError());
@@ -819,14 +788,10 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
   a.tiles_x = pl.tiles_x;
   a.tiles_y = pl.tiles_y;
   // ---- 1-D grid: id order, XCD-aware remap, half-tile tail ------------------------------
-  static int n_cu = 0, xcd_remap_env = -1;
-  if (!n_cu) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-    const char* e = getenv("RTPOSE_CONV_XCD_REMAP");
+  const int n_cu = device_cu_count();  // of the device this launch goes to
+  static int xcd_remap_env = -1;
+  if (xcd_remap_env < 0) {
+    const char* e = dev_env("RTPOSE_CONV_XCD_REMAP");
     xcd_remap_env = e ? atoi(e) : 1;
   }
   a.mtiles = pl.grid_x;
@@ -836,7 +801,7 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
   // worse tail, and 32 MFMAs between filler slots) - 427 vs 464 img/s overall.
   static int nf_env = 0;
   if (!nf_env) {
-    const char* e = getenv("RTPOSE_CONV_NF");
+    const char* e = dev_env("RTPOSE_CONV_NF");
     nf_env = e ? atoi(e) : 1;
   }
   pl.nf = (nf_env == 2 && d0.k != 1 && pl.ck == 16 && pl.nbuf == 2 && cout_pad(d0.cout) % 128 == 0) ? 2 : 1;
@@ -845,7 +810,7 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
     // that each re-stage the same input tile (developer A/B: RTPOSE_CONV_NF1X1=1|2)
     static int nf1 = 0;
     if (!nf1) {
-      const char* e = getenv("RTPOSE_CONV_NF1X1");
+      const char* e = dev_env("RTPOSE_CONV_NF1X1");
       nf1 = e ? atoi(e) : 1;
     }
     if (nf1 == 2 && d0.k == 1 && pl.ck == 16 && pl.nbuf == 1 && cout_pad(d0.cout) % 128 == 0) pl.nf = 2;
@@ -865,7 +830,7 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
     const int slots = n_cu * (pl.nbuf == 1 ? 4 : 2);
     const int total = (int)ids;
     const int rem = total % slots;
-    const char* e = getenv("RTPOSE_CONV_NO_HALF_TILES");
+    const char* e = dev_env("RTPOSE_CONV_NO_HALF_TILES");
     if (total > slots && rem > 0 && 2 * rem <= n_cu && !(e && e[0] == '1')) a.nbig = total - rem;
     // small batches (e.g. the reference's own one-image-at-a-time flow): fewer tiles than
     // CUs -> every tile is split, doubling the number of busy CUs
@@ -878,7 +843,7 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
     extern unsigned g_dbg32_blocks;
     static int kk = 0;
     if (!kk) {
-      const char* e = getenv("RTPOSE_TIMELINE_K");
+      const char* e = dev_env("RTPOSE_TIMELINE_K");
       kk = e ? atoi(e) : 1;
     }
     if (!g_dbg32_buf) (void)hipMalloc(&g_dbg32_buf, (size_t)32768 * 8 * 8);
@@ -892,7 +857,7 @@ int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, h
   {
     static int dephase_env = -1;
     if (dephase_env < 0) {
-      const char* e = getenv("RTPOSE_CONV_DEPHASE");
+      const char* e = dev_env("RTPOSE_CONV_DEPHASE");
       dephase_env = e ? atoi(e) : 0;
     }
     a.dephase_mode = (pl.nbuf == 2 && (long)grid.x > 4L * n_cu) ? dephase_env : 0;

@@ -34,6 +34,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "conv_exp.h"
 
 namespace rtpose {
 namespace bf {
@@ -98,9 +99,6 @@ struct ConvArgs {
 #endif
 
 constexpr int kBM = 128;
-#ifndef RTPOSE_EXP_HD
-#define RTPOSE_EXP_HD 3
-#endif
 // depth of the halo staging ring (taps between fetch and park).  The counter behind s_waitcnt
 // is in order, so every wait for a weight piece also waits for all older staging loads: a
 // staging load must be able to take a full HBM/MALL miss (1-3k cycles under load) without
@@ -143,9 +141,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   // B register ring: the tap being multiplied + RB-1 taps in flight from L2.  Two taps of
   // lead (RB = 3) left the waves waiting on vmcnt once two blocks share a CU; the narrow-N
   // arrangement (NF = 1) has the registers for four.
-#ifndef RTPOSE_EXP_RB2
-#define RTPOSE_EXP_RB2 4
-#endif
   constexpr int RB = (NF == 1 && CK <= 32) ? 5 : (CK <= 32 ? RTPOSE_EXP_RB2 : 3);
   constexpr int TAPS = KS, ROWS = KS;
 
@@ -338,22 +333,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     for (int fm = 0; fm < MF; ++fm) afrag[gi][fm] = (2 * gi + kh) * SP * QS + abase[fm];  // hi plane; lo = + QS
   const int rowstep = row_lds;
 
-// developer ablations (tools/exp_variants_bf16.sh): drop one load stream at a time
-#ifdef RTPOSE_EXP_NO_B
-#define RTPOSE_EXP_B(load, keep) (keep)
-#else
-#define RTPOSE_EXP_B(load, keep) (load)
-#endif
-#ifdef RTPOSE_EXP_NO_A
-#define RTPOSE_EXP_A(load, keep) (keep)
-#else
-#define RTPOSE_EXP_A(load, keep) (load)
-#endif
-#ifdef RTPOSE_EXP_NO_STAGE
-#define RTPOSE_EXP_STAGE 0
-#else
-#define RTPOSE_EXP_STAGE 1
-#endif
+// (RTPOSE_EXP_B / _A / _STAGE: identity in production builds, see conv_exp.h)
 #define RTPOSE_PIN()             \
   asm volatile("" ::: "memory"); \
   __builtin_amdgcn_sched_barrier(0)
@@ -760,7 +740,7 @@ static int conv_ck(int cin, int k, int sp) {
   // TFLOP/s); the wide shallow ones (conv1_2, 64 channels at 368x368) lose with them (645 -> 599)
   static int ck3 = 0;  // developer A/B: RTPOSE_BF16_CK3=32|64 forces one size for all 3x3 layers
   if (!ck3) {
-    const char* e = getenv("RTPOSE_BF16_CK3");
+    const char* e = dev_env("RTPOSE_BF16_CK3");
     ck3 = e ? atoi(e) : -1;
   }
   if (k == 3 && cin % 64 == 0 && (ck3 == 64 || (ck3 < 0 && cin >= 256))) return 64;
@@ -796,14 +776,14 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, int sp, Con
   // amortises the strips' longer halo
   static int strip_maxw = -1;
   if (strip_maxw < 0) {
-    const char* e = getenv("RTPOSE_BF16_STRIP_MAXW");
+    const char* e = dev_env("RTPOSE_BF16_STRIP_MAXW");
     strip_maxw = e ? atoi(e) : 0;
   }
   bool strip = (W <= (strip_maxw > 0 ? strip_maxw : (sp == 2 ? 128 : 64))) && !d.pool;
   {
     static int force_tile = -1;  // developer A/B: RTPOSE_BF16_FORCE_TILE=k forces 2-D tiles for k x k convs
     if (force_tile < 0) {
-      const char* e = getenv("RTPOSE_BF16_FORCE_TILE");
+      const char* e = dev_env("RTPOSE_BF16_FORCE_TILE");
       force_tile = e ? atoi(e) : 0;
     }
     if (force_tile == d.k) strip = false;
@@ -861,12 +841,13 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, int sp, Con
 
 template <int KS, int CK, int MODE, int NBUF, int WM, int NF, int SP>
 static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  static bool attr_set = false;
+  static PerDeviceOnce attr_set;  // zero-initialised; the attribute is per device
+  const int dev = current_device();
   auto kern = conv_mfma_bf16<KS, CK, MODE, NBUF, WM, NF, SP>;
-  if (!attr_set) {
+  if (!attr_set.is_set(dev)) {
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_set = true;
+    attr_set.set(dev);
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   RTPOSE_HIP_CHECK(hipGetLastError());
@@ -945,21 +926,14 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
   a.tw_log2 = pl.tw_log2;
   a.tiles_x = pl.tiles_x;
   a.tiles_y = pl.tiles_y;
-  static int n_cu = 0;
-  if (!n_cu) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
+  const int n_cu = device_cu_count();  // of the device this launch goes to
   a.mtiles = pl.grid_x;
   const int coutp = cout_pad(d0.cout);
   // 128-channel N tiles for the k x k layers whose cout allows it: 1 x 4 waves of 128 x 32
   // (default) or 2 x 2 waves of 64 x 64 (RTPOSE_BF16_WAVES=22, kept for A/B); else 128 x 64
   static int waves_env = 0;
   if (!waves_env) {
-    const char* e = getenv("RTPOSE_BF16_WAVES");
+    const char* e = dev_env("RTPOSE_BF16_WAVES");
     waves_env = e ? atoi(e) : 14;  // 14: per-kernel-size default, 41: 1 x 4 everywhere, 22: 2 x 2 everywhere
   }
   const bool wide = d0.k != 1 && coutp % 128 == 0;
@@ -983,7 +957,7 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
   {
     static int dephase_env = -1;  // percent of one block's MFMA time; 0 = off
     if (dephase_env < 0) {
-      const char* e = getenv("RTPOSE_BF16_DEPHASE");
+      const char* e = dev_env("RTPOSE_BF16_DEPHASE");
       dephase_env = e ? atoi(e) : 0;
     }
     a.n_cu = n_cu;

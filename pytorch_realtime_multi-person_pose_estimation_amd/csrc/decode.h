@@ -50,7 +50,7 @@ inline size_t decode_workspace_bytes(const rtpose_decode_cfg* c, int N) {
 }
 
 int nms_launch(const float* heat, const rtpose_layout* lheat, int N, int h, int w,
-               const rtpose_decode_cfg* cfg, void* result, hipStream_t s);
+               const rtpose_decode_cfg* cfg, void* result, hipStream_t s, int flags = 0);
 int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int h, int w, double inv_up,
                         int h1, const rtpose_decode_cfg* cfg, void* workspace, size_t workspace_bytes,
                         void* result, hipStream_t s);

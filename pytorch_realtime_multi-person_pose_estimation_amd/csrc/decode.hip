@@ -54,37 +54,11 @@ __device__ __forceinline__ void cubic_coeffs(float x, float* c) {
   c[3] = 1.f - c[0] - c[1] - c[2];
 }
 
-__global__ __launch_bounds__(256) void nms_refine_kernel(MapView heat, int h, int w, int up,
-                                                         double inv_up, float thr, int pcap,
-                                                         int32_t* __restrict__ result,
-                                                         int result_words) {
-  const int part = blockIdx.x, n = blockIdx.y;
+// find_peaks (paf_to_pose.py:25-38) for one (image, part): 4-neighbour maximum, > thr, peaks
+// compacted in row-major order into s_px / s_py (the order defines the peak ids).  Whole block.
+__device__ __forceinline__ int find_peaks_block(const MapView& heat, int n, int part, int h, int w, float thr,
+                                                int pcap, int* s_wcount, int* s_px, int* s_py, int32_t* res) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int32_t* res = result + (size_t)n * result_words;
-
-  __shared__ int s_sx[kMaxDst];
-  __shared__ float s_alpha[kMaxDst][4];
-  __shared__ int s_wcount[4];
-  __shared__ int s_px[kDecodeMaxPeaks], s_py[kDecodeMaxPeaks];
-  __shared__ float s_patch[4][25];
-  __shared__ float s_hbuf[4][5 * kMaxDst];
-
-  // per-destination-index source offset and cubic weights (cv2.resize INTER_CUBIC:
-  // fx = (float)((dx+0.5)*scale - 0.5); sx = floor(fx); fx -= sx)
-  if (tid < 5 * up) {
-    float fx = (float)(((double)tid + 0.5) * inv_up - 0.5);
-    const int sx = (int)floorf(fx);
-    fx -= (float)sx;
-    float c[4];
-    cubic_coeffs(fx, c);
-    s_sx[tid] = sx;
-    s_alpha[tid][0] = c[0];
-    s_alpha[tid][1] = c[1];
-    s_alpha[tid][2] = c[2];
-    s_alpha[tid][3] = c[3];
-  }
-
-  // ---- find_peaks (paf_to_pose.py:25-38): 4-neighbour maximum, > thr, row-major order
   int base = 0;
   const int npix = h * w;
   for (int start = 0; start < npix; start += 256) {
@@ -121,6 +95,40 @@ __global__ __launch_bounds__(256) void nms_refine_kernel(MapView heat, int h, in
     res[kResPartCount + part] = count;
     if (base > pcap) atomicOr(&res[kResHeader + 2], kOverflowPeaks);
   }
+  return count;
+}
+
+__global__ __launch_bounds__(256) void nms_refine_kernel(MapView heat, int h, int w, int up,
+                                                         double inv_up, float thr, int pcap,
+                                                         int32_t* __restrict__ result,
+                                                         int result_words) {
+  const int part = blockIdx.x, n = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int32_t* res = result + (size_t)n * result_words;
+
+  __shared__ int s_sx[kMaxDst];
+  __shared__ float s_alpha[kMaxDst][4];
+  __shared__ int s_wcount[4];
+  __shared__ int s_px[kDecodeMaxPeaks], s_py[kDecodeMaxPeaks];
+  __shared__ float s_patch[4][25];
+  __shared__ float s_hbuf[4][5 * kMaxDst];
+
+  // per-destination-index source offset and cubic weights (cv2.resize INTER_CUBIC:
+  // fx = (float)((dx+0.5)*scale - 0.5); sx = floor(fx); fx -= sx)
+  if (tid < 5 * up) {
+    float fx = (float)(((double)tid + 0.5) * inv_up - 0.5);
+    const int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    float c[4];
+    cubic_coeffs(fx, c);
+    s_sx[tid] = sx;
+    s_alpha[tid][0] = c[0];
+    s_alpha[tid][1] = c[1];
+    s_alpha[tid][2] = c[2];
+    s_alpha[tid][3] = c[3];
+  }
+
+  const int count = find_peaks_block(heat, n, part, h, w, thr, pcap, s_wcount, s_px, s_py, res);
 
   // ---- refine (paf_to_pose.py:106-142): one wave per peak
   rtpose_peak* peaks = reinterpret_cast<rtpose_peak*>(res + kResPeaks) + (size_t)part * pcap;
@@ -188,6 +196,170 @@ __global__ __launch_bounds__(256) void nms_refine_kernel(MapView heat, int h, in
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// The two optional branches of NMS (paf_to_pose.py:67): bool_gaussian_filt=True smooths the
+// up-sampled patch with scipy.ndimage.gaussian_filter(sigma=3) before the arg-max (:121-122);
+// bool_refine_center=False skips the patch altogether (:135-139).  Neither is used by the
+// reference's callers, so this kernel favours clarity: the whole block works on one peak at a time.
+// gaussian_filter = correlate1d along axis 0 (rows), then axis 1, mode 'reflect', each pass
+// accumulated in double in scipy's symmetric-kernel order and stored as float32
+// (ndimage/src/ni_filters.c NI_Correlate1D).
+constexpr int kGaussR = 12;  // int(truncate 4.0 * sigma 3 + 0.5)
+struct GaussW {
+  double w[2 * kGaussR + 1];
+};
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  while (i < 0 || i >= n) {
+    if (i < 0) i = -i - 1;
+    if (i >= n) i = 2 * n - 1 - i;
+  }
+  return i;
+}
+
+__global__ __launch_bounds__(256) void nms_refine_opt_kernel(MapView heat, int h, int w, int up, double inv_up,
+                                                             float thr, int pcap, int32_t* __restrict__ result,
+                                                             int result_words, int flags, GaussW gw) {
+  const int part = blockIdx.x, n = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int32_t* res = result + (size_t)n * result_words;
+  extern __shared__ float s_dyn[];  // [2][(5 up)^2]: the up-sampled patch and the first Gaussian pass
+  __shared__ int s_sx[kMaxDst];
+  __shared__ float s_alpha[kMaxDst][4];
+  __shared__ int s_wcount[4];
+  __shared__ int s_px[kDecodeMaxPeaks], s_py[kDecodeMaxPeaks];
+  __shared__ float s_patch[25];
+  __shared__ float s_hbuf[5 * kMaxDst];
+  __shared__ float s_best[4];
+  __shared__ int s_besti[4];
+  float* s_up = s_dyn;
+  float* s_tmp = s_dyn + 25 * up * up;
+
+  if (tid < 5 * up) {
+    float fx = (float)(((double)tid + 0.5) * inv_up - 0.5);
+    const int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    float c[4];
+    cubic_coeffs(fx, c);
+    s_sx[tid] = sx;
+    s_alpha[tid][0] = c[0];
+    s_alpha[tid][1] = c[1];
+    s_alpha[tid][2] = c[2];
+    s_alpha[tid][3] = c[3];
+  }
+  const int count = find_peaks_block(heat, n, part, h, w, thr, pcap, s_wcount, s_px, s_py, res);
+  rtpose_peak* peaks = reinterpret_cast<rtpose_peak*>(res + kResPeaks) + (size_t)part * pcap;
+
+  if (flags & RTPOSE_NMS_NO_REFINE) {
+    // :135-139 + compute_resized_coords (:41-64): the peak's cell centre (c + 0.5) * up - 0.5 in
+    // float64, score = the low-res map value.  Stored truncated (what process_paf's (int) cast of
+    // the joint_list column makes of it, pafprocess.cpp:28-29); NMS() on the host re-derives the float.
+    for (int i = tid; i < count; i += 256) {
+      rtpose_peak p;
+      p.x = (int)(((double)s_px[i] + 0.5) * (double)up - 0.5);
+      p.y = (int)(((double)s_py[i] + 0.5) * (double)up - 0.5);
+      p.score = map_at(heat, n, s_py[i], s_px[i], part);
+      p.id = i;
+      peaks[i] = p;
+    }
+    return;
+  }
+
+  for (int i = 0; i < count; ++i) {
+    const int px = s_px[i], py = s_py[i];
+    const int x_min = max(0, px - 2), y_min = max(0, py - 2);
+    const int x_max = min(w - 1, px + 2), y_max = min(h - 1, py + 2);
+    const int pw = x_max - x_min + 1, ph = y_max - y_min + 1;
+    const int dw = pw * up, dh = ph * up;
+    if (tid < pw * ph) {
+      const int r = tid / pw, c = tid - r * pw;
+      s_patch[tid] = map_at(heat, n, y_min + r, x_min + c, part);
+    }
+    __syncthreads();
+    for (int e = tid; e < ph * dw; e += 256) {  // cv2.resize INTER_CUBIC, horizontal pass
+      const int r = e / dw, dx = e - r * dw;
+      const int sx = s_sx[dx];
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int sxj = min(max(sx - 1 + j, 0), pw - 1);
+        v = v + s_patch[r * pw + sxj] * s_alpha[dx][j];
+      }
+      s_hbuf[r * dw + dx] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < dh * dw; e += 256) {  // vertical pass (same expression order as nms_refine_kernel)
+      const int dy = e / dw, dx = e - dy * dw;
+      const int sy = s_sx[dy];
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int syj = min(max(sy - 1 + j, 0), ph - 1);
+        const float t = s_hbuf[syj * dw + dx] * s_alpha[dy][j];
+        v = (j == 0) ? t : v + t;
+      }
+      s_up[e] = v;
+    }
+    __syncthreads();
+    if (flags & RTPOSE_NMS_GAUSSIAN) {
+      const double* wc = gw.w + kGaussR;
+      for (int e = tid; e < dh * dw; e += 256) {  // axis 0
+        const int y = e / dw, x = e - y * dw;
+        double acc = (double)s_up[e] * wc[0];
+        for (int j = -kGaussR; j < 0; ++j)
+          acc += ((double)s_up[reflect_idx(y + j, dh) * dw + x] + (double)s_up[reflect_idx(y - j, dh) * dw + x]) * wc[j];
+        s_tmp[e] = (float)acc;
+      }
+      __syncthreads();
+      for (int e = tid; e < dh * dw; e += 256) {  // axis 1
+        const int y = e / dw, x = e - y * dw;
+        double acc = (double)s_tmp[e] * wc[0];
+        for (int j = -kGaussR; j < 0; ++j)
+          acc += ((double)s_tmp[y * dw + reflect_idx(x + j, dw)] + (double)s_tmp[y * dw + reflect_idx(x - j, dw)]) * wc[j];
+        s_up[e] = (float)acc;
+      }
+      __syncthreads();
+    }
+    float best = -INFINITY;  // first maximum in row-major order (:125-126)
+    int best_idx = 0x7fffffff;
+    for (int e = tid; e < dh * dw; e += 256) {
+      const float v = s_up[e];
+      if (v > best) {
+        best = v;
+        best_idx = e;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float ob = __shfl_xor(best, o);
+      const int oi = __shfl_xor(best_idx, o);
+      if (ob > best || (ob == best && oi < best_idx)) {
+        best = ob;
+        best_idx = oi;
+      }
+    }
+    if (lane == 0) {
+      s_best[wave] = best;
+      s_besti[wave] = best_idx;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int k = 1; k < 4; ++k)
+        if (s_best[k] > best || (s_best[k] == best && s_besti[k] < best_idx)) {
+          best = s_best[k];
+          best_idx = s_besti[k];
+        }
+      const int dy = best_idx / dw, dx = best_idx - dy * dw;
+      rtpose_peak p;
+      p.x = x_min * up + dx;
+      p.y = y_min * up + dy;
+      p.score = best;
+      p.id = i;
+      peaks[i] = p;
+    }
+    __syncthreads();
   }
 }
 
@@ -501,17 +673,43 @@ static int check_cfg(const rtpose_decode_cfg* cfg) {
   return 0;
 }
 
+// scipy.ndimage._filters._gaussian_kernel1d(sigma = 3, order 0, radius 12) in float64, the sum
+// taken in numpy's pairwise order (8 running partial sums, then the tail) so that the weights are
+// the ones scipy correlates with, bit for bit, wherever libm's exp agrees with numpy's.
+static GaussW gauss_weights() {
+  GaussW g;
+  const int n = 2 * kGaussR + 1;
+  for (int i = -kGaussR; i <= kGaussR; ++i) g.w[i + kGaussR] = exp(-0.5 / 9.0 * (double)(i * i));
+  double r[8];
+  for (int j = 0; j < 8; ++j) r[j] = g.w[j];
+  int i = 8;
+  for (; i < n - n % 8; i += 8)
+    for (int j = 0; j < 8; ++j) r[j] += g.w[i + j];
+  double sum = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) sum += g.w[i];
+  for (int k = 0; k < n; ++k) g.w[k] /= sum;
+  return g;
+}
+
 int nms_launch(const float* heat, const rtpose_layout* lheat, int N, int h, int w,
-               const rtpose_decode_cfg* cfg, void* result, hipStream_t s) {
+               const rtpose_decode_cfg* cfg, void* result, hipStream_t s, int flags) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (N <= 0 || h <= 0 || w <= 0) return fail(RTPOSE_E_INVAL, "decode: empty batch");
   const int words = decode_result_words(cfg);
   int32_t* res = static_cast<int32_t*>(result);
   hipLaunchKernelGGL(clear_header_kernel, dim3(ceil_div(N * kResPeaks, 256)), dim3(256), 0, s, res, words, N);
-  hipLaunchKernelGGL(nms_refine_kernel, dim3(cfg->num_keypoints, N), dim3(256), 0, s, to_view(heat, lheat),
-                     h, w, cfg->upsample, 1.0 / (double)cfg->upsample, cfg->thresh_heatmap,
-                     cfg->max_peaks_per_part, res, words);
+  if (flags & ~(RTPOSE_NMS_NO_REFINE | RTPOSE_NMS_GAUSSIAN)) return fail(RTPOSE_E_INVAL, "nms: unknown flag");
+  if (flags) {
+    const size_t dyn = (size_t)2 * 25 * cfg->upsample * cfg->upsample * sizeof(float);
+    hipLaunchKernelGGL(nms_refine_opt_kernel, dim3(cfg->num_keypoints, N), dim3(256), dyn, s,
+                       to_view(heat, lheat), h, w, cfg->upsample, 1.0 / (double)cfg->upsample,
+                       cfg->thresh_heatmap, cfg->max_peaks_per_part, res, words, flags, gauss_weights());
+  } else {
+    hipLaunchKernelGGL(nms_refine_kernel, dim3(cfg->num_keypoints, N), dim3(256), 0, s, to_view(heat, lheat),
+                       h, w, cfg->upsample, 1.0 / (double)cfg->upsample, cfg->thresh_heatmap,
+                       cfg->max_peaks_per_part, res, words);
+  }
   hipLaunchKernelGGL(peak_prefix_kernel, dim3(N), dim3(64), 0, s, cfg->max_peaks_per_part, res, words,
                      cfg->num_keypoints);
   RTPOSE_HIP_CHECK(hipGetLastError());
@@ -533,13 +731,14 @@ int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int 
   float* score_ws = reinterpret_cast<float*>(wsb + decode_ws_conn_bytes(cfg, N));
   float* rows_ws = reinterpret_cast<float*>(wsb + decode_ws_conn_bytes(cfg, N) + decode_ws_score_bytes(cfg, N));
   const size_t lds = pcap * pcap <= kLdsPairs ? (size_t)pcap * pcap * sizeof(float) : 0;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;  // zero-initialised; the attribute is per device
+  const int dev = current_device();
+  if (!attr_set.is_set(dev)) {
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(limb_assign_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    attr_set = true;
+    attr_set.set(dev);
   }
   hipLaunchKernelGGL(limb_assign_kernel, dim3(RTPOSE_NUM_LIMB, N), dim3(256), lds, s, to_view(paf, lpaf), h,
                      w, inv_up, h1, pcap, res, words, conn, conn_words, score_ws);
@@ -567,18 +766,36 @@ size_t rtpose_decode_result_bytes(const rtpose_decode_cfg* cfg, int N) {
   return (size_t)N * decode_result_words(cfg) * sizeof(int32_t);
 }
 
+int rtpose_nms_batch_ex(const float* heat, const rtpose_layout* lheat, int N, int h, int w,
+                        const rtpose_decode_cfg* cfg, int nms_flags, void* result, void* stream) {
+  if (!heat || !lheat || !result) return fail(RTPOSE_E_INVAL, "nms: NULL argument");
+  return nms_launch(heat, lheat, N, h, w, cfg, result, as_stream(stream), nms_flags);
+}
+
 int rtpose_nms_batch(const float* heat, const rtpose_layout* lheat, int N, int h, int w,
                      const rtpose_decode_cfg* cfg, void* result, void* stream) {
-  if (!heat || !lheat || !result) return fail(RTPOSE_E_INVAL, "nms: NULL argument");
-  return nms_launch(heat, lheat, N, h, w, cfg, result, as_stream(stream));
+  return rtpose_nms_batch_ex(heat, lheat, N, h, w, cfg, 0, result, stream);
+}
+
+int rtpose_gaussian_kernel1d(double* weights, int cap) {
+  if (!weights || cap < 2 * kGaussR + 1) return fail(RTPOSE_E_INVAL, "gaussian_kernel1d: need room for 25 doubles");
+  const GaussW g = gauss_weights();
+  for (int i = 0; i < 2 * kGaussR + 1; ++i) weights[i] = g.w[i];
+  return 2 * kGaussR + 1;
 }
 
 int rtpose_decode_batch(const float* heat, const rtpose_layout* lheat, const float* paf,
                         const rtpose_layout* lpaf, int N, int h, int w, const rtpose_decode_cfg* cfg,
                         void* workspace, size_t workspace_bytes, void* result, void* stream) {
+  return rtpose_decode_batch_ex(heat, lheat, paf, lpaf, N, h, w, cfg, 0, workspace, workspace_bytes, result, stream);
+}
+
+int rtpose_decode_batch_ex(const float* heat, const rtpose_layout* lheat, const float* paf,
+                           const rtpose_layout* lpaf, int N, int h, int w, const rtpose_decode_cfg* cfg,
+                           int nms_flags, void* workspace, size_t workspace_bytes, void* result, void* stream) {
   if (!heat || !lheat || !paf || !lpaf || !workspace || !result)
     return fail(RTPOSE_E_INVAL, "decode: NULL argument");
-  int rc = nms_launch(heat, lheat, N, h, w, cfg, result, as_stream(stream));
+  int rc = nms_launch(heat, lheat, N, h, w, cfg, result, as_stream(stream), nms_flags);
   if (rc) return rc;
   return assign_group_launch(paf, lpaf, N, h, w, 1.0 / (double)cfg->upsample, h * cfg->upsample, cfg,
                              workspace, workspace_bytes, result, as_stream(stream));

@@ -52,22 +52,24 @@ class DecodeBuffers(object):
         self.host = torch.empty(rb // 4, dtype=torch.int32).pin_memory() if device.type == 'cuda' else None
 
 
-def decode_enqueue(heat_ptr, lheat, paf_ptr, lpaf, n, h, w, bufs, nms_only=False):
-    """Enqueue the decode kernels on the current stream (device pointers + layouts)."""
+def decode_enqueue(heat_ptr, lheat, paf_ptr, lpaf, n, h, w, bufs, nms_only=False, nms_flags=0):
+    """Enqueue the decode kernels on the current stream (device pointers + layouts).
+    nms_flags: _capi.NMS_NO_REFINE | _capi.NMS_GAUSSIAN (the optional branches of NMS, paf_to_pose.py:67)."""
     cfg = bufs.cfg
     if nms_only:
-        check(lib.rtpose_nms_batch(heat_ptr, C.byref(lheat), n, h, w, C.byref(cfg), ptr(bufs.result),
-                                   current_stream()), "rtpose_nms_batch")
+        check(lib.rtpose_nms_batch_ex(heat_ptr, C.byref(lheat), n, h, w, C.byref(cfg), nms_flags, ptr(bufs.result),
+                                      current_stream()), "rtpose_nms_batch_ex")
     else:
-        check(lib.rtpose_decode_batch(heat_ptr, C.byref(lheat), paf_ptr, C.byref(lpaf), n, h, w, C.byref(cfg),
-                                      ptr(bufs.workspace), bufs.workspace.numel() * 4, ptr(bufs.result),
-                                      current_stream()), "rtpose_decode_batch")
+        check(lib.rtpose_decode_batch_ex(heat_ptr, C.byref(lheat), paf_ptr, C.byref(lpaf), n, h, w, C.byref(cfg),
+                                         nms_flags, ptr(bufs.workspace), bufs.workspace.numel() * 4,
+                                         ptr(bufs.result), current_stream()), "rtpose_decode_batch_ex")
 
 
 def fetch(bufs):
-    """D2H of the result block -> numpy int32 [N, words]."""
-    bufs.host.copy_(bufs.result, non_blocking=True)
-    torch.cuda.current_stream().synchronize()
+    """D2H of the result block -> numpy int32 [N, words] (on the device the buffers live on)."""
+    with torch.cuda.device(bufs.result.device):
+        bufs.host.copy_(bufs.result, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
     return bufs.host.numpy().reshape(bufs.n, bufs.words)
 
 
@@ -93,7 +95,7 @@ def parse_image(rec, cfg):
             "n_peaks": int(rec[RES_HEADER])}
 
 
-def decode_maps(heat, paf, config=None, max_peaks_per_part=32, max_humans=64, nms_only=False):
+def decode_maps(heat, paf, config=None, max_peaks_per_part=32, max_humans=64, nms_only=False, nms_flags=0):
     """heat [N,h,w,C>=num_keypoints], paf [N,h,w,38]: dense NHWC float32 CUDA tensors.
     Returns a list of per-image dicts (see parse_image).  Grows capacities on overflow."""
     if not heat.is_cuda:
@@ -105,9 +107,10 @@ def decode_maps(heat, paf, config=None, max_peaks_per_part=32, max_humans=64, nm
     lpaf = Layout.dense(paf.shape[3], h, w)
     while True:
         cfg = make_cfg(config, max_peaks_per_part, max_humans)
-        bufs = DecodeBuffers(cfg, n, heat.device)
-        decode_enqueue(ptr(heat), lheat, ptr(paf), lpaf, n, h, w, bufs, nms_only=nms_only)
-        recs = fetch(bufs)
+        with torch.cuda.device(heat.device):      # kernels + stream of the maps' device, whatever is current
+            bufs = DecodeBuffers(cfg, n, heat.device)
+            decode_enqueue(ptr(heat), lheat, ptr(paf), lpaf, n, h, w, bufs, nms_only=nms_only, nms_flags=nms_flags)
+            recs = fetch(bufs)
         flags = int(np.bitwise_or.reduce(recs[:, RES_HEADER + 2]))
         if flags & OVERFLOW_PEAKS:
             if max_peaks_per_part >= MAX_PEAKS_LIMIT:
@@ -145,21 +148,32 @@ def humans_from_record(rec, up_w, up_h, num_keypoints=18):
 
 def NMS(heatmaps, upsampFactor=1., bool_refine_center=True, bool_gaussian_filt=False, config=None):
     """Drop-in for lib/utils/paf_to_pose.py:67 — list (per joint type) of [K,4] float64 arrays
-    (x, y, score, id).  Only the reference's default flags are implemented (refine on, Gaussian
-    filter off — the reference never enables it, paf_to_pose.py:67,:121)."""
-    if not bool_refine_center or bool_gaussian_filt:
-        raise NotImplementedError("only bool_refine_center=True, bool_gaussian_filt=False (the reference defaults)")
+    (x, y, score, id), all flag settings: bool_gaussian_filt smooths the up-sampled patch with
+    scipy's gaussian_filter(sigma=3) arithmetic on the GPU (:121-122), bool_refine_center=False
+    returns the grid-snapped cell centres (:135-139)."""
     config = config or default_config()
-    cfgc = types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_KEYPOINTS=config.MODEL.NUM_KEYPOINTS,
-                                                             DOWNSAMPLE=int(upsampFactor)),
+    up = int(upsampFactor)
+    if up != upsampFactor or up < 1:
+        raise ValueError("upsampFactor must be a positive integer (cfg.MODEL.DOWNSAMPLE)")
+    cfgc = types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_KEYPOINTS=config.MODEL.NUM_KEYPOINTS, DOWNSAMPLE=up),
                                  TEST=config.TEST)
     dev = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
     if dev is None:
         raise _capi.RtposeError("NMS needs an MI355X (HIP) device; there is no CPU fallback")
+    flags = 0
+    if not bool_refine_center:
+        flags |= _capi.NMS_NO_REFINE          # (the Gaussian lives inside the refine branch, :106-122)
+    elif bool_gaussian_filt:
+        flags |= _capi.NMS_GAUSSIAN
     heat = torch.as_tensor(np.ascontiguousarray(heatmaps, dtype=np.float32)).to(dev)[None]
-    rec = decode_maps(heat, heat.new_zeros(1, heat.shape[1], heat.shape[2], 38), cfgc, nms_only=True)[0]
-    pk = rec["peaks"]
-    return [pk[pk[:, 4] == j][:, :4].astype(np.float64) for j in range(int(config.MODEL.NUM_KEYPOINTS))]
+    rec = decode_maps(heat, heat.new_zeros(1, heat.shape[1], heat.shape[2], 38), cfgc, nms_only=True,
+                      nms_flags=flags)[0]
+    pk = rec["peaks"].astype(np.float64)
+    if not bool_refine_center:
+        # the device keeps the centre truncated to int (what process_paf reads); the reference's
+        # list carries compute_resized_coords' float64 value (c + 0.5) * up - 0.5  (:41-64)
+        pk[:, 0:2] = (np.floor(pk[:, 0:2] / up) + 0.5) * up - 0.5
+    return [pk[pk[:, 4] == j][:, :4] for j in range(int(config.MODEL.NUM_KEYPOINTS))]
 
 
 def paf_to_pose_cpp(heatmaps, pafs, config):

@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from . import _capi
 from ._capi import lib, check, ptr, current_stream
+from ._native_state import NativeStateMixin
 
 # (cin, cout, k) tables; 'P' = MaxPool2d(2, 2, 0).  reference :69-83, :95-127
 _VGG = [(3, 64, 3), (64, 64, 3), 'P', (64, 128, 3), (128, 128, 3), 'P', (128, 256, 3),
@@ -83,7 +84,7 @@ class _ShapeOnly(object):
             self.device = torch.device('cuda', torch.cuda.current_device())
 
 
-class RtposeVGG(nn.Module):
+class RtposeVGG(NativeStateMixin, nn.Module):
     """Drop-in for the module built by reference ``get_model('vgg19')``."""
 
     def __init__(self):
@@ -95,9 +96,7 @@ class RtposeVGG(nn.Module):
         for s in range(1, 7):
             setattr(self, 'model%d_2' % s, _sequential(_stage1(19) if s == 1 else _stage_t(19), False))
         self._initialize_weights_norm()
-        self._plans = {}
-        self._weights = {}       # compute dtype -> packed weight arena
-        self._weights_key = {}   # compute dtype -> parameter versions the arena was packed from
+        self._init_native_state()   # plans / weight arenas per (device, dtype), see _native_state.py
         self.keep_intermediates = True   # reference forward returns all 12 stage outputs
         self.compute_dtype = 'fp32'
 
@@ -132,8 +131,9 @@ class RtposeVGG(nn.Module):
 
     def _sync_weights(self, plan, device):
         convs = self._convs()
-        key = tuple((m.weight._version, m.bias._version, m.weight.data_ptr()) for _, m in convs)
-        if key == self._weights_key.get(plan.dtype):
+        wkey = (device.index, plan.dtype)
+        key = self._params_key([t for _, m in convs for t in (m.weight, m.bias)])
+        if key == self._weights_key.get(wkey) and not self.always_resync:
             return
         n = lib.rtpose_net_num_convs(plan.handle)
         if n != len(convs):
@@ -153,7 +153,7 @@ class RtposeVGG(nn.Module):
                 b = b.to(device=device, dtype=torch.float32).contiguous()
             check(lib.rtpose_net_load_conv(plan.handle, i, ptr(w), ptr(b), stream), "rtpose_net_load_conv")
         torch.cuda.current_stream().synchronize()  # temporaries above may be freed
-        self._weights_key[plan.dtype] = key
+        self._weights_key[wkey] = key
 
     def plan_for(self, x):
         if not x.is_cuda:
@@ -171,24 +171,22 @@ class RtposeVGG(nn.Module):
         x = _ShapeOnly(device)
         dtype = _DTYPES[self.compute_dtype]
         key = (n, h, w, x.device.index, dtype)
-        plan = self._plans.get(key)
-        if plan is None:
-            weights = self._weights.get(dtype)
-            if weights is None or weights.device != x.device:
-                probe = C.c_void_p()
-                check(lib.rtpose_net_create_ex(1, 8, 8, dtype, C.byref(probe)))
-                wb = lib.rtpose_net_weight_bytes(probe)
-                lib.rtpose_net_destroy(probe)
-                weights = torch.zeros(wb // 4 + 64, dtype=torch.float32, device=x.device)
-                self._weights[dtype] = weights
-                self._weights_key.pop(dtype, None)
-                for k in [k for k in self._plans if k[4] == dtype]:
-                    del self._plans[k]
-            plan = _Plan(n, h, w, weights, x.device, dtype)
-            if len(self._plans) >= 8:   # bound the workspace kept alive
-                self._plans.pop(next(iter(self._plans)))
-            self._plans[key] = plan
-        self._sync_weights(plan, x.device)
+        with self._native_lock, torch.cuda.device(x.device):
+            plan = self._plans.get(key)
+            if plan is None:
+                wkey = (x.device.index, dtype)
+                weights = self._weights.get(wkey)
+                if weights is None:
+                    probe = C.c_void_p()
+                    check(lib.rtpose_net_create_ex(1, 8, 8, dtype, C.byref(probe)))
+                    wb = lib.rtpose_net_weight_bytes(probe)
+                    lib.rtpose_net_destroy(probe)
+                    weights = torch.zeros(wb // 4 + 64, dtype=torch.float32, device=x.device)
+                    self._weights[wkey] = weights
+                    self._weights_key.pop(wkey, None)
+                plan = _Plan(n, h, w, weights, x.device, dtype)
+                self._remember_plan(key, plan)
+            self._sync_weights(plan, x.device)
         return plan
 
     def forward_native(self, x, keep_intermediates=False):

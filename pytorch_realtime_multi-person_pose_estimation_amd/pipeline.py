@@ -39,18 +39,20 @@ class PoseEstimator(object):
         decoder sees are  scene + scene_alpha * net_output  (bench / tests only: there
         are no trained weights offline, so realistic peaks are superimposed on what
         the randomly initialised network wrote; see include/rtpose_mi355x.h)."""
+        import torch
         m = self.model
-        plan = m.forward_native(x, keep_intermediates=False)
-        n = x.shape[0]
-        pbase, lpaf, _, h, w = m.output_view(plan, 0)
-        hbase, lheat, _, _, _ = m.output_view(plan, 1)
-        if scene is not None:
-            sh, sp = scene
-            s = current_stream()
-            check(lib.rtpose_layout_axpby(hbase, C.byref(lheat), ptr(sh), 19, n, h, w, scene_alpha, 1.0, s))
-            check(lib.rtpose_layout_axpby(pbase, C.byref(lpaf), ptr(sp), 38, n, h, w, scene_alpha, 1.0, s))
-        bufs = self._buffers(n, x.device)
-        dec.decode_enqueue(hbase, lheat, pbase, lpaf, n, h, w, bufs)
+        with torch.cuda.device(x.device):       # everything below goes to x's device and its current stream
+            plan = m.forward_native(x, keep_intermediates=False)
+            n = x.shape[0]
+            pbase, lpaf, _, h, w = m.output_view(plan, 0)
+            hbase, lheat, _, _, _ = m.output_view(plan, 1)
+            if scene is not None:
+                sh, sp = scene
+                s = current_stream()
+                check(lib.rtpose_layout_axpby(hbase, C.byref(lheat), ptr(sh), 19, n, h, w, scene_alpha, 1.0, s))
+                check(lib.rtpose_layout_axpby(pbase, C.byref(lpaf), ptr(sp), 38, n, h, w, scene_alpha, 1.0, s))
+            bufs = self._buffers(n, x.device)
+            dec.decode_enqueue(hbase, lheat, pbase, lpaf, n, h, w, bufs)
         bufs.map_hw = (h, w)
         return bufs
 
@@ -112,12 +114,18 @@ class StreamingPoseEstimator(object):
         self.consumed = [torch.cuda.Event() for _ in range(2)]
         for e in self.consumed:
             e.record(torch.cuda.current_stream())
+        self.max_peaks_per_part, self.max_humans = max_peaks_per_part, max_humans
         cfg = dec.make_cfg(self.config, max_peaks_per_part, max_humans)
         self.bufs = dec.DecodeBuffers(cfg, batch, self.dev)
         self._torch = torch
 
     def _upload(self, slot, images):
         torch = self._torch
+        images = np.asarray(images)
+        if images.shape != (self.B, self.h0, self.w0, 3) or images.dtype != np.uint8:
+            raise _capi.RtposeError("StreamingPoseEstimator: every batch must be uint8 [%d, %d, %d, 3], got %s %s "
+                                    "(pad a short final batch with copies and drop their records)"
+                                    % (self.B, self.h0, self.w0, images.dtype, images.shape))
         self.host[slot].copy_(torch.from_numpy(images))       # host -> pinned (the caller's array may be pageable)
         with torch.cuda.stream(self.copy_stream):
             self.copy_stream.wait_event(self.consumed[slot])   # the kernels that read this slot are done
@@ -143,12 +151,28 @@ class StreamingPoseEstimator(object):
         check(lib.rtpose_net_forward_prepared(plan.handle, s), "rtpose_net_forward_prepared")
         pbase, lpaf, _, h, w = m.output_view(plan, 0)
         hbase, lheat, _, _, _ = m.output_view(plan, 1)
-        dec.decode_enqueue(hbase, lheat, pbase, lpaf, self.B, h, w, self.bufs)
-        return dec.fetch(self.bufs).copy()                     # D2H of the records + stream sync
+        while True:
+            dec.decode_enqueue(hbase, lheat, pbase, lpaf, self.B, h, w, self.bufs)
+            recs = dec.fetch(self.bufs).copy()                 # D2H of the records + stream sync
+            flags = int(np.bitwise_or.reduce(recs[:, dec.RES_HEADER + 2]))
+            if not flags:
+                return recs
+            # a crowded image overflowed a device table: grow it and decode the SAME maps again (they are
+            # still in the plan's workspace; the next batch has only been uploaded, not run) - records
+            # are never handed out truncated
+            if flags & dec.OVERFLOW_PEAKS and self.max_peaks_per_part < dec.MAX_PEAKS_LIMIT:
+                self.max_peaks_per_part = min(2 * self.max_peaks_per_part, dec.MAX_PEAKS_LIMIT)
+            elif flags & dec.OVERFLOW_HUMANS and self.max_humans < dec.MAX_HUMANS_LIMIT:
+                self.max_humans = min(2 * self.max_humans, dec.MAX_HUMANS_LIMIT)
+            else:
+                raise _capi.RtposeError("decode tables overflowed at maximum capacity (flags=%d)" % flags)
+            self.bufs = dec.DecodeBuffers(dec.make_cfg(self.config, self.max_peaks_per_part, self.max_humans),
+                                          self.B, self.dev)
 
     def run(self, batches):
         """batches: iterable of uint8 arrays [B, h0, w0, 3] (BGR).  Yields one int32 record block
-        [B, words] per batch (decode.parse_image / humans_from_record turn them into Humans)."""
+        [B, words] per batch (decode.parse_image(rec, self.bufs.cfg) / humans_from_record turn them into
+        Humans; self.bufs.cfg is the capacity the block was written with - it grows on overflow)."""
         it = iter(batches)
         try:
             cur = next(it)

@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from . import _capi
 from ._capi import lib, check, ptr, current_stream
+from ._native_state import NativeStateMixin
 
 _WIDTH = {1.0: (116, 232, 464, 1024)}
 
@@ -61,7 +62,7 @@ class _Plan(object):
             pass
 
 
-class Network(nn.Module):
+class Network(NativeStateMixin, nn.Module):
     def __init__(self, width_multiplier=1.0):
         super(Network, self).__init__()
         if width_multiplier not in _WIDTH:
@@ -83,9 +84,7 @@ class Network(nn.Module):
                 nn.init.kaiming_uniform_(m.weight, mode='fan_in')
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
-        self._plans = {}
-        self._weights = {}     # compute dtype -> weight arena
-        self._key = {}         # compute dtype -> parameter versions the arena was packed from
+        self._init_native_state()   # plans / weight arenas per (device, dtype), see _native_state.py
         self.compute_dtype = 'fp32'
 
     def set_compute_dtype(self, dtype):
@@ -112,9 +111,9 @@ class Network(nn.Module):
         return w.float().contiguous(), b.float().contiguous()
 
     def _sync_weights(self, plan, device):
-        tensors = list(self.parameters()) + list(self.buffers())
-        key = tuple((t._version, t.data_ptr()) for t in tensors)
-        if key == self._key.get(plan.dtype):
+        wkey = (device.index, plan.dtype)
+        key = self._params_key(list(self.parameters()) + list(self.buffers()))
+        if key == self._weights_key.get(wkey) and not self.always_resync:
             return
         name = C.create_string_buffer(96)
         kind, co, ci = C.c_int(), C.c_int(), C.c_int()
@@ -137,7 +136,7 @@ class Network(nn.Module):
             keep += [w, b]
             check(lib.rtpose_shufflenet_load(plan.handle, i, ptr(w), ptr(b), stream), "rtpose_shufflenet_load")
         torch.cuda.current_stream().synchronize()
-        self._key[plan.dtype] = key
+        self._weights_key[wkey] = key
 
     def plan_for(self, x):
         if not x.is_cuda:
@@ -147,24 +146,22 @@ class Network(nn.Module):
         n, c, h, w = x.shape
         dtype = _capi.DTYPE_BF16 if self.compute_dtype == 'bf16' else _capi.DTYPE_F32
         key = (n, h, w, x.device.index, dtype)
-        plan = self._plans.get(key)
-        if plan is None:
-            weights = self._weights.get(dtype)
-            if weights is None or weights.device != x.device:
-                probe = C.c_void_p()
-                check(lib.rtpose_shufflenet_create_ex(1, 64, 64, dtype, C.byref(probe)))
-                wb = lib.rtpose_shufflenet_weight_bytes(probe)
-                lib.rtpose_shufflenet_destroy(probe)
-                weights = torch.zeros(wb // 4 + 64, dtype=torch.float32, device=x.device)
-                self._weights[dtype] = weights
-                for k in [k for k in self._plans if k[4] == dtype]:
-                    del self._plans[k]
-            plan = _Plan(n, h, w, weights, x.device, dtype)
-            if len(self._plans) >= 8:
-                self._plans.pop(next(iter(self._plans)))
-            self._plans[key] = plan
-            self._key.pop(dtype, None)   # a new plan re-binds the maps; weights are shared but reload is cheap
-        self._sync_weights(plan, x.device)
+        with self._native_lock, torch.cuda.device(x.device):
+            plan = self._plans.get(key)
+            if plan is None:
+                wkey = (x.device.index, dtype)
+                weights = self._weights.get(wkey)
+                if weights is None:
+                    probe = C.c_void_p()
+                    check(lib.rtpose_shufflenet_create_ex(1, 64, 64, dtype, C.byref(probe)))
+                    wb = lib.rtpose_shufflenet_weight_bytes(probe)
+                    lib.rtpose_shufflenet_destroy(probe)
+                    weights = torch.zeros(wb // 4 + 64, dtype=torch.float32, device=x.device)
+                    self._weights[wkey] = weights
+                plan = _Plan(n, h, w, weights, x.device, dtype)
+                self._remember_plan(key, plan)
+                self._weights_key.pop(wkey, None)   # a new plan re-binds the maps; the reload is cheap
+            self._sync_weights(plan, x.device)
         return plan
 
     def forward_native(self, x):

@@ -169,28 +169,81 @@ def test_paf_to_pose_cpp_dropin(pkg, dec, cuda):
 
 
 def test_flip_merge(capi, cuda):
-    """handle_paf_and_heat (evaluate/coco_eval.py:197-242) restated in numpy vs the kernel."""
+    """rtpose_flip_merge == the reference's own handle_paf_and_heat (evaluate/coco_eval.py:197-242,
+    executed unmodified -> tests/golden/host_ref.npz), bit for bit; the oracle restatement
+    (oracle/host_oracle.py, pinned to the same golden on the CPU) covers a batch of random maps."""
+    from oracle import host_oracle as ho, make_golden_host as mg
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "host_ref.npz"))
+
+    def run(heat, heat_f, paf, paf_f):
+        t = [torch.from_numpy(np.ascontiguousarray(a)).to(cuda) for a in (heat, heat_f, paf, paf_f)]
+        oh, op = torch.empty_like(t[0]), torch.empty_like(t[2])
+        n, h, w = t[0].shape[:3]
+        capi.check(capi.lib.rtpose_flip_merge(capi.ptr(t[0]), capi.ptr(t[1]), capi.ptr(t[2]), capi.ptr(t[3]), n, h, w,
+                                              capi.ptr(oh), capi.ptr(op), capi.current_stream()))
+        return op.cpu().numpy(), oh.cpu().numpy()
+    for k, (h, w, seed) in enumerate(mg.FM_CASES):
+        heat, heat_f, paf, paf_f = mg.fm_inputs(h, w, seed)
+        avg_paf, avg_heat = run(heat[None], heat_f[None], paf[None], paf_f[None])
+        assert np.array_equal(avg_paf[0], ref["fm%d_paf" % k]) and np.array_equal(avg_heat[0], ref["fm%d_heat" % k])
     rng = np.random.default_rng(1)
-    n, h, w = 2, 9, 11
+    n, h, w = 3, 9, 11
     heat, heat_f = [rng.normal(size=(n, h, w, 19)).astype(np.float32) for _ in range(2)]
     paf, paf_f = [rng.normal(size=(n, h, w, 38)).astype(np.float32) for _ in range(2)]
-    swap_heat = np.array((0, 1, 5, 6, 7, 2, 3, 4, 11, 12, 13, 8, 9, 10, 15, 14, 17, 16, 18))
-    swap_paf = np.array((6, 7, 8, 9, 10, 11, 0, 1, 2, 3, 4, 5, 20, 21, 22, 23, 24, 25, 26, 27, 12, 13, 14, 15,
-                         16, 17, 18, 19, 28, 29, 32, 33, 30, 31, 36, 37, 34, 35))
-    exp_h, exp_p = [], []
+    avg_paf, avg_heat = run(heat, heat_f, paf, paf_f)
     for i in range(n):
-        fp = paf_f[i][:, ::-1, :].copy()
-        fp[:, :, swap_paf[1::2]] = fp[:, :, swap_paf[1::2]]
-        fp[:, :, swap_paf[::2]] = -fp[:, :, swap_paf[::2]]
-        exp_p.append((paf[i] + fp[:, :, swap_paf]) / 2.)
-        exp_h.append((heat[i] + heat_f[i][:, ::-1, :][:, :, swap_heat]) / 2.)
-    t = [torch.from_numpy(a).to(cuda) for a in (heat, heat_f, paf, paf_f)]
-    oh = torch.empty_like(t[0])
-    op = torch.empty_like(t[2])
-    capi.check(capi.lib.rtpose_flip_merge(capi.ptr(t[0]), capi.ptr(t[1]), capi.ptr(t[2]), capi.ptr(t[3]), n, h, w,
-                                          capi.ptr(oh), capi.ptr(op), capi.current_stream()))
-    assert np.array_equal(oh.cpu().numpy(), np.stack(exp_h).astype(np.float32))
-    assert np.array_equal(op.cpu().numpy(), np.stack(exp_p).astype(np.float32))
+        ep, eh = ho.handle_paf_and_heat(heat[i], heat_f[i], paf[i], paf_f[i])
+        assert np.array_equal(avg_paf[i], ep) and np.array_equal(avg_heat[i], eh)
+
+
+def test_nms_optional_branches_match_reference(dec, capi, cuda):
+    """NMS(bool_gaussian_filt=True) and NMS(bool_refine_center=False) on the GPU == the reference's
+    own NMS (lib/utils/paf_to_pose.py:67-145 executed unmodified with the real
+    scipy.ndimage.gaussian_filter -> golden), coordinates, ids and float scores bit for bit; then a
+    batch against the C oracle, and the truncated coordinates process_paf consumes."""
+    import ctypes as C
+    from oracle import make_golden_host as mg, post_oracle as po
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "host_ref.npz"))
+    w25 = (C.c_double * 25)()
+    assert capi.lib.rtpose_gaussian_kernel1d(w25, 25) == 25
+    assert np.array_equal(np.array(w25), po.gaussian_kernel1d(3.0)[0])      # scipy's weights, bit for bit
+    for k, (hh, ww, npeople, seed) in enumerate(mg.NMS_SCENES):
+        heat, _ = mg.scene(hh, ww, npeople, seed)
+        for tag, kw in (("default", {}), ("gauss", {"bool_gaussian_filt": True}),
+                        ("norefine", {"bool_refine_center": False})):
+            per_type = dec.NMS(heat, upsampFactor=8, **kw)
+            want = ref["nms%d_%s" % (k, tag)]
+            assert len(per_type) == 18
+            for j, arr in enumerate(per_type):
+                exp = want[want[:, 4] == j][:, :4]
+                assert arr.dtype == np.float64 and arr.shape == exp.shape
+                assert np.array_equal(arr[:, [0, 1, 3]], exp[:, [0, 1, 3]]), (k, tag, j)
+                assert np.array_equal(arr[:, 2].astype(np.float32), exp[:, 2].astype(np.float32)), (k, tag, j)
+    # batch + other up-sampling factors against the C oracle; full decode with the flags set
+    rng = np.random.default_rng(5)
+    for up, flags, okw in ((4, capi.NMS_GAUSSIAN, {"gaussian": True}), (8, capi.NMS_GAUSSIAN, {"gaussian": True}),
+                           (2, capi.NMS_GAUSSIAN, {"gaussian": True}), (8, capi.NMS_NO_REFINE, {"refine": False}),
+                           (3, capi.NMS_NO_REFINE, {"refine": False})):
+        import types
+        from conftest import PKG_NAME as _P
+        synth = importlib.import_module(_P + ".synth")
+        heats, pafs = [], []
+        for _ in range(4):
+            hm, pf = synth.render(synth.random_people(rng, 3, 368, 416), 368, 416, rng=rng)
+            heats.append(hm)
+            pafs.append(pf)
+        heat, paf = np.stack(heats), np.stack(pafs)
+        cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(NUM_KEYPOINTS=18, DOWNSAMPLE=up),
+                                    DATASET=types.SimpleNamespace(IMAGE_SIZE=368),
+                                    TEST=types.SimpleNamespace(THRESH_HEATMAP=0.1))
+        recs = dec.decode_maps(torch.from_numpy(heat).to(cuda), torch.from_numpy(paf).to(cuda), config=cfg,
+                               nms_flags=flags)
+        for i in range(4):
+            jl = po.nms(heat[i], 18, 0.1, up, **okw)
+            r = po.process_paf(jl, paf[i], up)
+            jl_dev = jl.copy()
+            jl_dev[:, 0:2] = np.trunc(jl[:, 0:2])          # pafprocess.cpp:28-29 (int) cast
+            _check_against(recs[i], jl_dev, r["parts"], r["score"])
 
 
 @pytest.mark.parametrize("hw,thr,up,seed", [

@@ -102,10 +102,15 @@ def test_resize_bilinear_accum_matches_torch(capi, cuda):
 
 
 def test_multiscale_flip_outputs(compat, cuda):
-    """config-3 style TTA runs end to end; with scales=(1.0,) and no flip it equals get_outputs."""
+    """config-3 style TTA: with scales=(1.0,) and no flip it equals get_outputs; the per-image and
+    the batched GPU-resident paths equal the golden composition of the REFERENCE's functions
+    (oracle/tta_oracle.py:make_golden - crop_with_factor, rtpose_preprocess, the reference module,
+    handle_paf_and_heat, all executed unmodified) within the 1e-3 fp32 contract; and the result is
+    flip-equivariant: TTA of the mirrored image == mirrored TTA (L/R channels swapped, PAF x negated)."""
     from lib.network.rtpose_vgg import get_model
-    from oracle import net_oracle
+    from oracle import net_oracle, tta_oracle, host_oracle as ho
     pre = importlib.import_module(PKG_NAME + ".preprocess")
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "host_ref.npz"))
     model = get_model('vgg19')
     model.load_state_dict(net_oracle.he_init_state_dict(model, seed=0))
     model = model.cuda().eval()
@@ -114,39 +119,91 @@ def test_multiscale_flip_outputs(compat, cuda):
     with torch.no_grad():
         paf1, heat1, s = pre.get_outputs(img, model, 'rtpose')
         paf_a, heat_a, s_a = pre.get_multiscale_outputs(img, model, 'rtpose', scales=(1.0,), flip=False)
-        paf_m, heat_m, _ = pre.get_multiscale_outputs(img, model, 'rtpose', scales=(0.5, 1.0, 1.5), flip=True)
-    assert abs(s - s_a) < 1e-12 and paf_a.shape == paf1.shape == paf_m.shape
+    assert abs(s - s_a) < 1e-12 and paf_a.shape == paf1.shape
     assert np.abs(paf_a - paf1).max() <= 1e-5 and np.abs(heat_a - heat1).max() <= 1e-5
-    assert np.isfinite(paf_m).all() and np.isfinite(heat_m).all()
-    # flip-symmetry sanity: TTA of the mirrored image == mirrored TTA (x-PAF channels negated, L/R swapped)
+
+    case = tta_oracle.TTA_CASE
+    timg = tta_oracle.tta_image()
+    for tag, flip in (("flip", True), ("noflip", False)):
+        with torch.no_grad():
+            paf_m, heat_m, s_m = pre.get_multiscale_outputs(timg, model, case["preprocess"], scales=case["scales"],
+                                                            flip=flip)
+            paf_b, heat_b, s_b = pre.get_multiscale_outputs_batch([timg, timg[:, ::-1].copy()], model,
+                                                                  case["preprocess"], scales=case["scales"], flip=flip)
+        assert s_m == s_b == float(ref["tta_s1"])
+        for got_p, got_h in ((paf_m, heat_m), (paf_b[0].cpu().numpy(), heat_b[0].cpu().numpy())):
+            assert got_p.shape == ref["tta_%s_paf" % tag].shape
+            assert np.abs(got_p - ref["tta_%s_paf" % tag]).max() <= 1e-3, tag
+            assert np.abs(got_h - ref["tta_%s_heat" % tag]).max() <= 1e-3, tag
+
+    # flip equivariance needs resize(mirror(img)) == mirror(resize(img)) exactly: power-of-two zoom
+    # (92 x 115 -> x2, x4), so the fixed-point resize taps mirror exactly
+    img2 = rng.integers(0, 256, (92, 115, 3), dtype=np.uint8)
+    with torch.no_grad():
+        paf_n, heat_n, _ = pre.get_multiscale_outputs(img2, model, 'rtpose', scales=(0.5, 1.0), flip=True)
+        paf_f, heat_f, _ = pre.get_multiscale_outputs(img2[:, ::-1].copy(), model, 'rtpose', scales=(0.5, 1.0), flip=True)
+    mir_p = paf_f[:, ::-1][:, :, ho.SWAP_PAF].copy()
+    mir_p[:, :, 0::2] = -mir_p[:, :, 0::2]
+    mir_h = heat_f[:, ::-1][:, :, ho.SWAP_HEAT]
+    scale = max(1.0, np.abs(paf_n).max())
+    assert np.abs(paf_n - mir_p).max() <= 2e-5 * scale and np.abs(heat_n - mir_h).max() <= 2e-5 * scale
+    # ... and it is not trivially symmetric: a single un-flipped pass is not
+    with torch.no_grad():
+        paf_u, _, _ = pre.get_multiscale_outputs(img2, model, 'rtpose', scales=(0.5, 1.0), flip=False)
+        paf_uf, _, _ = pre.get_multiscale_outputs(img2[:, ::-1].copy(), model, 'rtpose', scales=(0.5, 1.0), flip=False)
+    mir_u = paf_uf[:, ::-1][:, :, ho.SWAP_PAF].copy()
+    mir_u[:, :, 0::2] = -mir_u[:, :, 0::2]
+    assert np.abs(paf_u - mir_u).max() > 1e-2
 
 
 def test_gpu_preprocess_bit_exact_and_same_outputs(compat, capi, cuda):
-    """rtpose_preprocess_u8 == crop_with_factor + rtpose/vgg_preprocess (numpy restatement), bit for bit,
-    and get_outputs_gpu == get_outputs."""
+    """rtpose_preprocess_u8 == the reference's OWN crop_with_factor + rtpose_preprocess / vgg_preprocess
+    (lib/network/im_transform.py:119-134, lib/datasets/preprocessing.py:16-43 executed unmodified ->
+    tests/golden/host_ref.npz; cv2.resize = the restated OpenCV algorithm), bit for bit for the resized
+    uint8 pixels and the rtpose normalisation; more sizes against the pinned oracle restatement; and
+    get_outputs_gpu == get_outputs."""
     import ctypes as C
     from lib.network.rtpose_vgg import get_model
-    from oracle import net_oracle
+    from oracle import net_oracle, host_oracle as ho, make_golden_host as mg
     pre = importlib.import_module(PKG_NAME + ".preprocess")
     lib = capi.lib
-    rng = np.random.default_rng(2)
-    for (h0, w0), mode in (((337, 356), 'rtpose'), ((200, 150), 'vgg'), ((368, 368), 'rtpose'), ((97, 233), 'vgg')):
-        img = rng.integers(0, 256, (h0, w0, 3), dtype=np.uint8)
-        crop, scale, real = pre.crop_with_factor(img, 368, factor=8, is_ceil=True)
-        ref = (pre.rtpose_preprocess if mode == 'rtpose' else pre.vgg_preprocess)(crop)      # [3, hn, wn]
-        hn, wn = crop.shape[:2]
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "host_ref.npz"))
+
+    def gpu_prep(img, dest, factor, mode):
+        h0, w0 = img.shape[:2]
+        scale = float(dest) / min(h0, w0)
+        hr, wr = pre._cv_round(h0 * scale), pre._cv_round(w0 * scale)
+        hn, wn = pre._factor_closest(hr, factor), pre._factor_closest(wr, factor)
         lay = capi.Layout.padded(8, hn, wn, 1)
         buf = torch.zeros(lib.rtpose_layout_pixels(C.byref(lay), 1, hn, wn) * 8, device=cuda)
         img_d = torch.from_numpy(img).to(cuda)
         capi.check(lib.rtpose_preprocess_u8(capi.ptr(img_d), h0, w0, scale, 0 if mode == 'rtpose' else 1, capi.ptr(buf),
-                                            C.byref(lay), 0, hn, wn, real[0], real[1], capi.current_stream()))
+                                            C.byref(lay), 0, hn, wn, hr, wr, capi.current_stream()))
         out = torch.empty(1, 3, hn, wn, device=cuda)
         capi.check(lib.rtpose_layout_to_nchw(capi.ptr(buf), C.byref(lay), capi.ptr(out), 3, 1, hn, wn, capi.current_stream()))
-        got = out[0].cpu().numpy()
+        return out[0].cpu().numpy()
+
+    for k, (h0, w0, dest, factor, seed, keep) in enumerate(mg.CW_CASES):
+        img = mg.cw_input(h0, w0, seed)
+        got = gpu_prep(img, dest, factor, 'rtpose')
+        crop = ref["cw%d_crop" % k]
+        # x / 256 - 0.5 is exact in fp32, so the uint8 pixels can be read back exactly
+        assert np.array_equal(np.rint((got + 0.5) * 256).astype(np.uint8).transpose(1, 2, 0), crop), k
+        if keep:
+            assert np.array_equal(got, ref["cw%d_rtpose" % k]), k
+            # vgg: numpy divides the whole array by 255. first, then subtracts / divides per channel
+            assert np.abs(gpu_prep(img, dest, factor, 'vgg') - ref["cw%d_vgg" % k]).max() <= 2e-7, k
+    rng = np.random.default_rng(2)
+    for (h0, w0), mode in (((337, 356), 'rtpose'), ((200, 150), 'vgg'), ((368, 368), 'rtpose'), ((97, 233), 'vgg'),
+                           ((50, 41), 'rtpose')):
+        img = rng.integers(0, 256, (h0, w0, 3), dtype=np.uint8)
+        crop, scale, real = ho.crop_with_factor(img, 368, factor=8, is_ceil=True)
+        want = (ho.rtpose_preprocess if mode == 'rtpose' else ho.vgg_preprocess)(crop)
+        got = gpu_prep(img, 368, 8, mode)
         if mode == 'rtpose':
-            assert np.array_equal(got, ref)
-        else:   # float division order: numpy divides the whole array by 255. then subtracts / divides
-            assert np.abs(got - ref).max() <= 2e-7
+            assert np.array_equal(got, want)
+        else:
+            assert np.abs(got - want).max() <= 2e-7
     model = get_model('vgg19')
     model.load_state_dict(net_oracle.he_init_state_dict(model, seed=0))
     model = model.cuda().eval()
@@ -155,6 +212,51 @@ def test_gpu_preprocess_bit_exact_and_same_outputs(compat, capi, cuda):
         paf_a, heat_a, s_a = pre.get_outputs(img, model, 'rtpose')
         paf_b, heat_b, s_b = pre.get_outputs_gpu(img, model, 'rtpose')
     assert s_a == s_b and np.array_equal(paf_a, paf_b) and np.array_equal(heat_a, heat_b)
+
+
+def test_picture_demo_on_ski_jpg_config1(compat, cuda):
+    """BASELINE configs[0]: the demo/picture_demo.py:45-61 call sequence on readme/ski.jpg (674 x 712 ->
+    1 x 3 x 368 x 392, maps 46 x 49) through the drop-in import tree on the GPU, against what the
+    reference's picture_demo.py itself (run unmodified on the CPU by oracle/make_golden_host.py)
+    computed for the same pixels and the same seeded weights."""
+    from lib.network.rtpose_vgg import get_model
+    from evaluate.coco_eval import get_outputs
+    from lib.utils.paf_to_pose import paf_to_pose_cpp
+    from lib.config import cfg
+    from oracle import net_oracle, post_oracle as po
+    pre = importlib.import_module(PKG_NAME + ".preprocess")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ski_demo.npz"))
+    model = get_model('vgg19')
+    model.load_state_dict(net_oracle.he_init_state_dict(model, seed=0))
+    model = torch.nn.DataParallel(model).cuda()
+    model.float()
+    model.eval()
+    oriImg = z["ski_bgr"]
+    with torch.no_grad():
+        paf, heatmap, im_scale = get_outputs(oriImg, model, 'rtpose')
+        paf_g, heat_g, im_scale_g = pre.get_outputs_gpu(oriImg, model, 'rtpose')
+    assert im_scale == im_scale_g == float(z["im_scale"])
+    assert paf.shape == (46, 49, 38) and heatmap.shape == (46, 49, 19)
+    assert np.abs(paf - z["paf"]).max() <= 1e-3 and np.abs(heatmap - z["heatmap"]).max() <= 1e-3
+    assert np.array_equal(paf, paf_g) and np.array_equal(heatmap, heat_g)      # GPU image prep: same pixels
+    # post-processing on the REFERENCE's maps (identical input tensors -> bit-exact tier, SURVEY §7):
+    humans = paf_to_pose_cpp(z["heatmap"], z["paf"], cfg)
+    jl = po.nms(z["heatmap"])
+    assert len(jl) > 1000                      # a random network's maps: junk peaks, exact score ties
+    r = po.process_paf(jl, z["paf"], 8)        # the product's documented tie contract
+    assert len(humans) == len(r["parts"])
+    for hid, hm in enumerate(humans):
+        assert sorted(hm.body_parts) == [p for p in range(18) if r["parts"][hid, p] >= 0]
+        assert np.float32(hm.score) == r["score"][hid]
+        for p, bp in hm.body_parts.items():
+            cid = r["parts"][hid, p]
+            assert (bp.x, bp.y, bp.score) == (float(int(jl[cid, 0])) / 392, float(int(jl[cid, 1])) / 368, float(jl[cid, 2]))
+    # against the reference's own Humans: every person whose limbs were decided without an exact tie
+    # is identical; tie scenes are outside the bit-exact contract (DESIGN §3.3) - compare as sets
+    want = z["parts"]
+    ref_people = {tuple((p, tuple(want[h, p])) for p in range(18) if not np.isnan(want[h, p, 0])) for h in range(len(want))}
+    got_people = {tuple((p, (bp.x, bp.y, bp.score)) for p, bp in sorted(hm.body_parts.items())) for hm in humans}
+    assert len(ref_people & got_people) >= len(ref_people) - 2, (len(ref_people & got_people), len(ref_people))
 
 
 def test_multiscale_batch_matches_per_image(compat, cuda):

@@ -168,3 +168,28 @@ def test_bf16_plan_matches_emulation_and_fp32(net_sd, cuda, shape):
     with torch.no_grad():
         (paf3, _), _ = m(x.to(cuda))         # back on the fp32 plan
     assert (paf3.cpu() - paf_r).abs().max().item() <= 1e-3 * max(1.0, paf_r.abs().max().item())
+
+
+def test_full_size_batch128_config4(net_sd, cuda):
+    """BASELINE.json configs[3] at its full shape (128 x 3 x 368 x 368): deterministic, every image
+    independent of its position / neighbours in the batch (bit-exact under a permutation, and equal
+    to the same image run in a batch of 2), and images spread over the batch equal the CPU oracle."""
+    from oracle import shufflenet_oracle as so
+    m, sd = net_sd
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(128, 3, 368, 368, generator=g) - 0.5
+    perm = torch.randperm(128, generator=g)
+    with torch.no_grad():
+        (paf, heat), _ = m(x.to(cuda))
+        (paf2, heat2), _ = m(x.to(cuda))
+        (paf_p, heat_p), _ = m(x[perm].to(cuda))
+        (paf_s, heat_s), _ = m(x[[7, 100]].to(cuda))
+    assert paf.shape == (128, 38, 46, 46) and heat.shape == (128, 19, 46, 46)
+    assert torch.equal(paf, paf2) and torch.equal(heat, heat2)
+    assert torch.equal(paf_p, paf[perm.to(cuda)]) and torch.equal(heat_p, heat[perm.to(cuda)])
+    assert torch.equal(paf_s, paf[[7, 100]]) and torch.equal(heat_s, heat[[7, 100]])
+    idx = [0, 31, 64, 77, 127, 5]
+    paf_r, heat_r = so.forward(sd, x[idx])
+    scale = max(1.0, paf_r.abs().max().item(), heat_r.abs().max().item())
+    assert (paf[idx].cpu() - paf_r).abs().max().item() <= 1e-3 * scale
+    assert (heat[idx].cpu() - heat_r).abs().max().item() <= 1e-3 * scale

@@ -1,5 +1,7 @@
 #!/bin/bash
 # usage: tools/ab_env_f32.sh VAR v1 v2 ...   (fp32 per-launch profile under each value of an env switch)
+[ -f "$(dirname "$0")/exp/lib_dev.so" ] || "$(dirname "$0")/build_dev.sh"
+export RTPOSE_LIB_PATH="$(cd "$(dirname "$0")" && pwd)/exp/lib_dev.so"   # env knobs exist in developer builds only
 cd "$(dirname "$0")/.."
 VAR=$1; shift
 for v in "$@"; do

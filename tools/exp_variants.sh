@@ -8,7 +8,7 @@ build() { # name flags...
   name=$1; shift
   objs=""
   for f in conv_mfma layout_ops net shufflenet decode legacy_pafprocess; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$SRC "$@" -c $SRC/$f.hip -o tools/exp/${name}_$f.o &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DRTPOSE_DEV_BUILD -Iinclude -I$SRC "$@" -c $SRC/$f.hip -o tools/exp/${name}_$f.o &
     objs="$objs tools/exp/${name}_$f.o"
   done
   wait

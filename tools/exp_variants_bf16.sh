@@ -6,7 +6,7 @@ SRC=pytorch_realtime_multi-person_pose_estimation_amd/csrc
 mkdir -p tools/exp
 build() { # name flags...
   name=$1; shift
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$SRC "$@" -c $SRC/conv_mfma_bf16.hip -o tools/exp/${name}_bf.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DRTPOSE_DEV_BUILD -Iinclude -I$SRC "$@" -c $SRC/conv_mfma_bf16.hip -o tools/exp/${name}_bf.o
   objs="tools/exp/${name}_bf.o"
   for f in conv_mfma layout_ops net shufflenet decode legacy_pafprocess; do objs="$objs $SRC/build/$f.o"; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/exp/lib_$name.so $objs
