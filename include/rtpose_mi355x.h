@@ -118,6 +118,45 @@ typedef struct rtpose_conv_desc {
 int rtpose_conv2d(const rtpose_conv_desc* d, int ngroups, int N, int H, int W,
                   void* stream);
 
+/* ---- fused pointwise chain of the ShuffleNetV2 pose network (BASELINE configs[3]) ----
+ * stands in for lib/network/rtpose_shufflenetV2.py BasicBlock (:22-63): conv_bn_relu 1x1, optionally
+ * preceded by the conv_bn depthwise 3x3 (stride 1) that feeds it and followed by
+ * torch.cat((x1, x2), 1) + channel_shuffle(2) - ONE launch: the depthwise result is produced in LDS
+ * and never stored, the pass-through half x1 is copied to its shuffled slots by the same blocks.
+ *   out[p][cmap(n)] = act( bias[n] + sum_c A[p][c] * W[n][c] ),
+ *   A[p][c] = in[p][c]                                            (dw_w == NULL)
+ *           = dw_b[c] + sum_{ky,kx} dw_w[ky*3+kx][c] * in[p + (ky-1, kx-1)][c]   (zero padding = the layout gap)
+ *   out[p][pt_cmap[i]] = pt_src[p][i], i < pt_c                   (pt_src != NULL)
+ * fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32) / fp32 out. */
+typedef struct rtpose_pw_desc {
+  const float* in;          /* activation buffer base (layout `lin`; gap >= 1 when dw_w != NULL)   */
+  const float* dw_w;        /* NULL, or device [9][cin] depthwise taps (BN folded), tap-major          */
+  const float* dw_b;        /* device [cin] depthwise bias                                            */
+  const float* w_packed;    /* from rtpose_pack_pw_weights: [cin/4][coutp][4]                          */
+  const float* bias_packed; /* [coutp]                                                                */
+  float* out;               /* activation buffer base (layout `lout`)                                 */
+  rtpose_layout lin;
+  rtpose_layout lout;
+  int32_t cin;              /* packed input channels (multiple of 8)                                  */
+  int32_t cout;             /* columns that are stored                                                */
+  int32_t coutp;            /* columns of the packed matrix: 64, 128 or a multiple of 256             */
+  int32_t relu;
+  const int32_t* out_cmap;  /* NULL (column n -> channel lout.choff + n) or device int32[coutp]: column
+                               n -> absolute channel of the pixel, < 0 = not stored                   */
+  const float* pt_src;      /* NULL, or the buffer holding the pass-through channels (layout `lpt`)   */
+  rtpose_layout lpt;
+  const int32_t* pt_cmap;   /* device int32[pt_c]: pass-through channel i -> absolute output channel  */
+  int32_t pt_c;
+} rtpose_pw_desc;
+size_t rtpose_packed_pw_floats(int cin_packed, int coutp);
+/* w_oi: device [cout][cin_src] (a 1x1 conv's OIHW weights), written to columns
+ * [col_off, col_off + cout) of the packed matrix - several layers may share one matrix (the PAF and
+ * heat-map heads, rtpose_shufflenetV2.py:107-108, run as one 128-column GEMM). */
+int rtpose_pack_pw_weights(const float* w_oi, const float* bias, int cout, int cin_src,
+                           const int32_t* cin_map, int cin_packed, int coutp, int col_off,
+                           float* w_packed, float* bias_packed, void* stream);
+int rtpose_pw_fused(const rtpose_pw_desc* d, int N, int H, int W, void* stream);
+
 /* ---- bf16 variant (BASELINE config 3: "bf16, multi-scale x4 + flip") ----------------
  * Same modules, bf16 activations and weights, fp32 accumulate
  * (v_mfma_f32_32x32x16_bf16), bias/ReLU/pool in fp32, output rounded to bf16
@@ -350,6 +389,21 @@ int rtpose_shufflenet_launch_info(rtpose_shufflenet* net, int i, float* ms, doub
 int rtpose_preprocess_u8(const unsigned char* img_bgr, int h0, int w0, double im_scale, int mode,
                          float* dst, const rtpose_layout* ldst, int n_index, int Hn, int Wn, int hr,
                          int wr, void* stream);
+
+/* A whole bucket of images in ONE launch: `images` is a HOST array of `count` descriptors (they
+ * travel as kernel arguments, 64 per launch; nothing is allocated or copied), every image has its
+ * own source size, scale, valid size and destination slot; all share the padded size Hn x Wn of
+ * the destination (the evaluation driver buckets images by it, evaluate/coco_eval.py:258-272). */
+typedef struct rtpose_prep_image {
+  const void* img_bgr; /* device, uint8 [h0][w0][3]                               */
+  double im_scale;     /* crop_with_factor's im_scale (im_transform.py:124)       */
+  int32_t h0, w0;      /* source size                                             */
+  int32_t hr, wr;      /* cvRound(h0 * im_scale), cvRound(w0 * im_scale)          */
+  int32_t flip;        /* != 0: x-mirrored inside the valid width (flip TTA pass) */
+  int32_t n_index;     /* image slot of the destination layout                    */
+} rtpose_prep_image;
+int rtpose_preprocess_u8_batch(const rtpose_prep_image* images, int count, int mode, float* dst,
+                               const rtpose_layout* ldst, int Hn, int Wn, void* stream);
 
 /* Same, with flip != 0 writing the x-mirrored RESIZED image (columns [0, wr) mirrored, the
  * zero padding stays on the right): the second pass of flip test-time augmentation. */

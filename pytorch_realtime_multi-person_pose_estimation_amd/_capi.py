@@ -44,6 +44,21 @@ class ConvDesc(C.Structure):
                 ("out_cmap", C.c_void_p)]
 
 
+class PwDesc(C.Structure):
+    """rtpose_pw_desc: one fused pointwise chain (csrc/pw_fused.hip)."""
+    _fields_ = [("inp", C.c_void_p), ("dw_w", C.c_void_p), ("dw_b", C.c_void_p), ("w_packed", C.c_void_p),
+                ("bias_packed", C.c_void_p), ("out", C.c_void_p), ("lin", Layout), ("lout", Layout),
+                ("cin", C.c_int32), ("cout", C.c_int32), ("coutp", C.c_int32), ("relu", C.c_int32),
+                ("out_cmap", C.c_void_p), ("pt_src", C.c_void_p), ("lpt", Layout), ("pt_cmap", C.c_void_p),
+                ("pt_c", C.c_int32)]
+
+
+class PrepImage(C.Structure):
+    """rtpose_prep_image: one image of a rtpose_preprocess_u8_batch launch."""
+    _fields_ = [("img_bgr", C.c_void_p), ("im_scale", C.c_double), ("h0", C.c_int32), ("w0", C.c_int32),
+                ("hr", C.c_int32), ("wr", C.c_int32), ("flip", C.c_int32), ("n_index", C.c_int32)]
+
+
 class DecodeCfg(C.Structure):
     _fields_ = [("num_keypoints", C.c_int32), ("upsample", C.c_int32),
                 ("thresh_heatmap", C.c_float), ("max_peaks_per_part", C.c_int32),
@@ -72,6 +87,9 @@ _SIGS = {
     "rtpose_packed_bias_floats": (_sz, [_i]),
     "rtpose_pack_conv_weights": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "rtpose_conv2d": (_i, [C.POINTER(ConvDesc), _i, _i, _i, _i, _vp]),
+    "rtpose_packed_pw_floats": (_sz, [_i, _i]),
+    "rtpose_pack_pw_weights": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "rtpose_pw_fused": (_i, [C.POINTER(PwDesc), _i, _i, _i, _vp]),
     "rtpose_maxpool2x2": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, _i, _vp]),
     "rtpose_nchw_to_layout": (_i, [_vp, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
     "rtpose_layout_to_nchw": (_i, [_vp, _LP, _vp, _i, _i, _i, _i, _vp]),
@@ -138,6 +156,7 @@ _SIGS = {
     "rtpose_nms_batch_ex": (_i, [_vp, _LP, _i, _i, _i, C.POINTER(DecodeCfg), _i, _vp, _vp]),
     "rtpose_decode_batch_ex": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, C.POINTER(DecodeCfg), _i, _vp, _sz, _vp, _vp]),
     "rtpose_gaussian_kernel1d": (_i, [C.POINTER(C.c_double), _i]),
+    "rtpose_preprocess_u8_batch": (_i, [C.POINTER(PrepImage), _i, _i, _vp, _LP, _i, _i, _vp]),
     "rtpose_preprocess_u8": (_i, [_vp, _i, _i, C.c_double, _i, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
     "rtpose_preprocess_u8_flip": (_i, [_vp, _i, _i, C.c_double, _i, _vp, _LP, _i, _i, _i, _i, _i, _i, _vp]),
     "rtpose_tta_accumulate": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, _vp, _vp, _i, _i, C.c_float, C.c_float,

@@ -13,7 +13,11 @@ native plans, packed-weight arenas and the keys that say what an arena was packe
 """
 import threading
 
-MAX_PLANS_PER_DEVICE = 8    # bounds the workspaces kept alive per GPU
+# Plans (one per input shape) keep their activation workspace alive: ~0.22 GB per 368 x 368 image for
+# rtpose_vgg in fp32.  An MI355X has 288 GB, and an evaluation run over mixed-size images wants one
+# plan per (batch, padded size) bucket, so the cache is bounded by BYTES per device, not by count.
+MAX_WORKSPACE_BYTES_PER_DEVICE = 128 << 30
+MAX_PLANS_PER_DEVICE = 256
 
 
 class NativeStateMixin(object):
@@ -48,7 +52,9 @@ class NativeStateMixin(object):
 
     def _remember_plan(self, key, plan):
         dev = key[3]
-        mine = [k for k in self._plans if k[3] == dev]
-        if len(mine) >= MAX_PLANS_PER_DEVICE:
-            self._plans.pop(mine[0])        # oldest plan of THIS device only
+        mine = [k for k in self._plans if k[3] == dev]          # insertion order: oldest first
+        size = lambda p: p.workspace.numel() * p.workspace.element_size()   # noqa: E731
+        total = sum(size(self._plans[k]) for k in mine) + size(plan)
+        while mine and (total > MAX_WORKSPACE_BYTES_PER_DEVICE or len(mine) >= MAX_PLANS_PER_DEVICE):
+            total -= size(self._plans.pop(mine.pop(0)))          # evict plans of THIS device only
         self._plans[key] = plan

@@ -195,9 +195,23 @@ __device__ __forceinline__ void lin_coeff(int d, int sn, double scale, int& s0, 
   a0 = (int)rintf((1.f - f) * 2048.f);
 }
 
-__global__ void preprocess_u8_kernel(const unsigned char* __restrict__ img, int h0, int w0, double inv_scale,
-                                     int mode, float* __restrict__ dst, Lay ld, int n, int Hn, int Wn,
-                                     int hr, int wr, int flip) {
+// One image of a batch: where it is, how it is resized, which image slot of the network input it fills.
+struct PrepImg {
+  const unsigned char* img;  // device, BGR uint8 [h0][w0][3]
+  double inv_scale;          // 1 / im_scale
+  int h0, w0, hr, wr;        // source size; resized (valid) size inside the Hn x Wn padded input
+  int flip, n;               // mirror inside the valid width; image index in the destination
+};
+constexpr int kPrepBatch = 64;  // descriptors per launch, passed by value (kernel argument: no device table)
+struct PrepBatch {
+  PrepImg im[kPrepBatch];
+};
+
+// grid (pixels of the padded Hn x Wn input / 256, images): one launch prepares a whole bucket of images
+__global__ void preprocess_u8_kernel(PrepBatch batch, int mode, float* __restrict__ dst, Lay ld, int Hn, int Wn) {
+  const PrepImg& d = batch.im[blockIdx.y];
+  const unsigned char* __restrict__ img = d.img;
+  const int h0 = d.h0, w0 = d.w0, hr = d.hr, wr = d.wr;
   const size_t total = (size_t)Hn * Wn;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -206,8 +220,8 @@ __global__ void preprocess_u8_kernel(const unsigned char* __restrict__ img, int 
   if (y < hr && x < wr) {
     int x0, x1, ax0, ax1, y0, y1, ay0, ay1;
     // flip: this destination column shows the x-mirrored RESIZED image (valid region only)
-    lin_coeff<false>(flip ? wr - 1 - x : x, w0, inv_scale, x0, x1, ax0, ax1);
-    lin_coeff<true>(y, h0, inv_scale, y0, y1, ay0, ay1);
+    lin_coeff<false>(d.flip ? wr - 1 - x : x, w0, d.inv_scale, x0, x1, ax0, ax1);
+    lin_coeff<true>(y, h0, d.inv_scale, y0, y1, ay0, ay1);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const int s00 = img[((size_t)y0 * w0 + x0) * 3 + c], s01 = img[((size_t)y0 * w0 + x1) * 3 + c];
@@ -226,9 +240,9 @@ __global__ void preprocess_u8_kernel(const unsigned char* __restrict__ img, int 
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[c] = ((float)px[2 - c] / 255.f - mean[c]) / sd[c];
   }
-  float* d = dst + lay_off(ld, n, y, x);
-  *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], 0.f);
-  *reinterpret_cast<float4*>(d + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  float* q = dst + lay_off(ld, d.n, y, x);
+  *reinterpret_cast<float4*>(q) = make_float4(o[0], o[1], o[2], 0.f);
+  *reinterpret_cast<float4*>(q + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // Multi-scale test-time augmentation: dst = beta * dst + alpha * bilinear_resize(src), dense
@@ -1068,17 +1082,54 @@ int rtpose_layout_axpby(float* dst, const rtpose_layout* ldst, const float* src_
   return 0;
 }
 
+int rtpose_preprocess_u8_batch(const rtpose_prep_image* images, int count, int mode, float* dst,
+                               const rtpose_layout* ldst, int Hn, int Wn, void* stream) {
+  if (!images || count <= 0 || !dst || !ldst || (mode != 0 && mode != 1) || ldst->cstride < 8 ||
+      (ldst->cstride % 4) || (ldst->choff % 4) || Hn <= 0 || Wn <= 0)
+    return fail(RTPOSE_E_INVAL, "preprocess_u8: bad arguments");
+  for (int i = 0; i < count; ++i) {
+    const rtpose_prep_image& d = images[i];
+    if (!d.img_bgr || d.h0 <= 0 || d.w0 <= 0 || d.im_scale <= 0 || d.hr <= 0 || d.wr <= 0 || Hn < d.hr ||
+        Wn < d.wr || d.n_index < 0)
+      return fail(RTPOSE_E_INVAL, "preprocess_u8: bad image descriptor %d", i);
+  }
+  const size_t total = (size_t)Hn * Wn;
+  for (int first = 0; first < count; first += kPrepBatch) {  // the descriptors travel as kernel arguments
+    PrepBatch b;
+    memset(&b, 0, sizeof(b));
+    const int n = count - first < kPrepBatch ? count - first : kPrepBatch;
+    for (int i = 0; i < n; ++i) {
+      const rtpose_prep_image& d = images[first + i];
+      PrepImg& o = b.im[i];
+      o.img = static_cast<const unsigned char*>(d.img_bgr);
+      o.inv_scale = 1.0 / d.im_scale;
+      o.h0 = d.h0;
+      o.w0 = d.w0;
+      o.hr = d.hr;
+      o.wr = d.wr;
+      o.flip = d.flip ? 1 : 0;
+      o.n = d.n_index;
+    }
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(nblocks(total, 256), n), dim3(256), 0, as_stream(stream), b,
+                       mode, dst, to_lay(ldst), Hn, Wn);
+  }
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int rtpose_preprocess_u8_flip(const unsigned char* img_bgr, int h0, int w0, double im_scale, int mode, float* dst,
                               const rtpose_layout* ldst, int n_index, int Hn, int Wn, int hr, int wr, int flip,
                               void* stream) {
-  if (!img_bgr || !dst || h0 <= 0 || w0 <= 0 || im_scale <= 0 || Hn < hr || Wn < wr || (mode != 0 && mode != 1) ||
-      ldst->cstride < 8 || (ldst->cstride % 4) || (ldst->choff % 4))
-    return fail(RTPOSE_E_INVAL, "preprocess_u8: bad arguments");
-  const size_t total = (size_t)Hn * Wn;
-  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(nblocks(total, 256)), dim3(256), 0, as_stream(stream), img_bgr, h0,
-                     w0, 1.0 / im_scale, mode, dst, to_lay(ldst), n_index, Hn, Wn, hr, wr, flip ? 1 : 0);
-  RTPOSE_HIP_CHECK(hipGetLastError());
-  return 0;
+  rtpose_prep_image d;
+  d.img_bgr = img_bgr;
+  d.h0 = h0;
+  d.w0 = w0;
+  d.im_scale = im_scale;
+  d.hr = hr;
+  d.wr = wr;
+  d.flip = flip;
+  d.n_index = n_index;
+  return rtpose_preprocess_u8_batch(&d, 1, mode, dst, ldst, Hn, Wn, stream);
 }
 
 int rtpose_preprocess_u8(const unsigned char* img_bgr, int h0, int w0, double im_scale, int mode, float* dst,

@@ -35,6 +35,12 @@ int pack_weights_bf16_launch(const float* w, const float* bias, int cout, int ci
                              const int32_t* cin_map, int cin_packed, void* wp, float* bp, int split,
                              hipStream_t s);
 
+// fused pointwise chains of the fp32 plan (pw_fused.hip)
+int pw_fused_launch(const rtpose_pw_desc* d, int N, int H, int W, hipStream_t s);
+int pack_pw_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map, int K,
+                   int coutp, int col_off, float* wp, float* bp, hipStream_t s);
+int pw_halo_stride(const rtpose_layout& l, int H, int W);
+
 // w[C][1][3][3] (+bias[C]) -> wp[9][cphys], bp[cphys]; phys channel p reads logical pmap[p] (-1: zero)
 __global__ void pack_dw_kernel(const float* __restrict__ w, const float* __restrict__ b, int C,
                                const int32_t* __restrict__ pmap, int cphys, float* __restrict__ wp,
@@ -75,6 +81,8 @@ struct SLayer {
   int cin_packed = 0;         // L_PW: packed input channels; L_DW: physical channels
   int map_id = -1;            // index into maps (cin_map for PW, phys->logical for DW), -1 identity
   size_t w_off = 0, b_off = 0;
+  int coutp = 0, col_off = 0; // L_PW of a fused (fp32) plan: columns of the packed matrix this layer's
+                              // cout columns start at (the two heads share one 128-column matrix)
 };
 
 struct SBuf {
@@ -83,7 +91,7 @@ struct SBuf {
   int C = 0, H = 0, W = 0;
 };
 
-enum OKind { O_INPUT, O_STEM, O_POOL3, O_DW, O_PW, O_COPYMAP };
+enum OKind { O_INPUT, O_STEM, O_POOL3, O_DW, O_PW, O_COPYMAP, O_PWF };
 
 struct SOp {
   OKind kind;
@@ -96,6 +104,9 @@ struct SOp {
   int cmap[2] = {-1, -1};      // map ids (out_cmap / copy map)
   int relu = 0, stride = 1, C = 0;
   double flops = 0;
+  // O_PWF (pw_fused.hip): layer[0] = the pointwise layer, dw_layer = the depthwise 3x3 evaluated in front
+  // of it inside the kernel (-1: none), pt_buf / pt_map = pass-through half copied by the same launch
+  int dw_layer = -1, pt_buf = -1, pt_map = -1, pt_c = 0, cout_store = 0;
 };
 
 struct Map {
@@ -108,6 +119,7 @@ struct Map {
 struct rtpose_shufflenet {
   int N = 0, H = 0, W = 0, Hm = 0, Wm = 0;  // Hm x Wm: stride-8 maps
   int bf16 = 0;  // 1: 2-byte activations + bf16 pointwise weights (fp32 accumulate); outputs stay fp32
+  int fused = 0; // fp32 plans: pointwise chains run as fused launches (pw_fused.hip)
   std::vector<SBuf> bufs;
   std::vector<SLayer> layers;
   std::vector<SOp> ops;
@@ -218,6 +230,38 @@ void add_dw(rtpose_shufflenet* n, const std::string& name, int H, int W, int lay
   n->ops.push_back(o);
 }
 
+// one fused launch: [depthwise 3x3 ->] pointwise (+ReLU) [+ pass-through half]
+void add_pwf(rtpose_shufflenet* n, const std::string& name, int H, int W, int layer, int dw_layer, int in_buf,
+             int in_choff, int out_buf, int out_choff, int cmap, int relu, int pt_buf = -1, int pt_map = -1,
+             int pt_c = 0, int cout_store = 0) {
+  SOp o;
+  o.kind = O_PWF;
+  o.name = name;
+  o.H = H;
+  o.W = W;
+  o.layer[0] = layer;
+  o.dw_layer = dw_layer;
+  o.in_buf[0] = in_buf;
+  o.in_choff[0] = in_choff;
+  o.out_buf[0] = out_buf;
+  o.out_choff[0] = out_choff;
+  o.cmap[0] = cmap;
+  o.relu = relu;
+  o.pt_buf = pt_buf;
+  o.pt_map = pt_map;
+  o.pt_c = pt_c;
+  const SLayer& l = n->layers[layer];
+  o.cout_store = cout_store ? cout_store : l.cout;
+  o.flops = 2.0 * n->N * H * W * (double)l.cout * l.cin;
+  if (dw_layer >= 0) o.flops += 2.0 * n->N * H * W * (double)n->layers[dw_layer].cin * 9;
+  n->ops.push_back(o);
+}
+
+// can the depthwise 3x3 that reads `b` be evaluated inside the fused pointwise kernel?
+bool dw_fusable(const rtpose_shufflenet* n, int buf, int H, int W) {
+  return n->fused && pw_halo_stride(n->bufs[buf].lay, H, W) * 8 <= 2048;
+}
+
 void build(rtpose_shufflenet* n) {
   // channel alignment of slices that feed a pointwise conv: 8 floats (fp32 kernel: cin % 8 == 0),
   // 16 elements for bf16 plans (one K = 16 MFMA step)
@@ -310,11 +354,28 @@ void build(rtpose_shufflenet* n) {
       const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, in_c, up8(in_phys), M_in);
       const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, hp, -1);
       const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, hp, -1);
-      add_dw(n, bp + "conv0.0", Hc, Wc, l_c00, in_buf, T0, stride);
-      add_pw(n, bp + "conv0.1", Ho, Wo, l_c01, T0, 0, SA, 0, M_even, 1);
-      add_pw(n, bp + "conv.0", Hc, Wc, l_c0, in_buf, 0, T1a, 0, -1, 1);
-      add_dw(n, bp + "conv.1", Hc, Wc, l_c1, T1a, T2, stride);
-      add_pw(n, bp + "conv.2", Ho, Wo, l_c2, T2, 0, SA, 0, M_odd, 1);
+      if (!n->fused) {
+        add_dw(n, bp + "conv0.0", Hc, Wc, l_c00, in_buf, T0, stride);
+        add_pw(n, bp + "conv0.1", Ho, Wo, l_c01, T0, 0, SA, 0, M_even, 1);
+        add_pw(n, bp + "conv.0", Hc, Wc, l_c0, in_buf, 0, T1a, 0, -1, 1);
+        add_dw(n, bp + "conv.1", Hc, Wc, l_c1, T1a, T2, stride);
+        add_pw(n, bp + "conv.2", Ho, Wo, l_c2, T2, 0, SA, 0, M_odd, 1);
+      } else {
+        // stride-1 depthwise convs are evaluated inside the pointwise launch that consumes them
+        if (stride == 1 && dw_fusable(n, in_buf, Hc, Wc)) {
+          add_pwf(n, bp + "conv0.0+conv0.1", Ho, Wo, l_c01, l_c00, in_buf, 0, SA, 0, M_even, 1);
+        } else {
+          add_dw(n, bp + "conv0.0", Hc, Wc, l_c00, in_buf, T0, stride);
+          add_pwf(n, bp + "conv0.1", Ho, Wo, l_c01, -1, T0, 0, SA, 0, M_even, 1);
+        }
+        add_pwf(n, bp + "conv.0", Hc, Wc, l_c0, -1, in_buf, 0, T1a, 0, -1, 1);
+        if (stride == 1 && dw_fusable(n, T1a, Hc, Wc)) {
+          add_pwf(n, bp + "conv.1+conv.2", Ho, Wo, l_c2, l_c1, T1a, 0, SA, 0, M_odd, 1);
+        } else {
+          add_dw(n, bp + "conv.1", Hc, Wc, l_c1, T1a, T2, stride);
+          add_pwf(n, bp + "conv.2", Ho, Wo, l_c2, -1, T2, 0, SA, 0, M_odd, 1);
+        }
+      }
     }
     int cur = SA, nxt = SB;
     // -- blocks 1..: pass-through half + processed half (reference :31-39, :56-59) --
@@ -323,19 +384,31 @@ void build(rtpose_shufflenet* n) {
       const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, h, hp, -1);
       const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, hp, -1);
       const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, hp, -1);
-      SOp c;
-      c.kind = O_COPYMAP;
-      c.name = bp + "x1->even";
-      c.H = Ho;
-      c.W = Wo;
-      c.in_buf[0] = cur;
-      c.out_buf[0] = nxt;
-      c.cmap[0] = M_even;
-      c.C = h;
-      n->ops.push_back(c);
-      add_pw(n, bp + "conv.0", Ho, Wo, l_c0, cur, hp, T1, 0, -1, 1);
-      add_dw(n, bp + "conv.1", Ho, Wo, l_c1, T1, T2, 1);
-      add_pw(n, bp + "conv.2", Ho, Wo, l_c2, T2, 0, nxt, 0, M_odd, 1);
+      if (n->fused && dw_fusable(n, T1, Ho, Wo)) {
+        // two launches per unit: conv.0, then conv.1 (in LDS) -> conv.2 -> odd slots + x1 -> even slots
+        add_pwf(n, bp + "conv.0", Ho, Wo, l_c0, -1, cur, hp, T1, 0, -1, 1);
+        add_pwf(n, bp + "conv.1+conv.2+x1", Ho, Wo, l_c2, l_c1, T1, 0, nxt, 0, M_odd, 1, cur, M_even, h);
+      } else {
+        SOp c;
+        c.kind = O_COPYMAP;
+        c.name = bp + "x1->even";
+        c.H = Ho;
+        c.W = Wo;
+        c.in_buf[0] = cur;
+        c.out_buf[0] = nxt;
+        c.cmap[0] = M_even;
+        c.C = h;
+        n->ops.push_back(c);
+        if (n->fused) {
+          add_pwf(n, bp + "conv.0", Ho, Wo, l_c0, -1, cur, hp, T1, 0, -1, 1);
+          add_dw(n, bp + "conv.1", Ho, Wo, l_c1, T1, T2, 1);
+          add_pwf(n, bp + "conv.2", Ho, Wo, l_c2, -1, T2, 0, nxt, 0, M_odd, 1);
+        } else {
+          add_pw(n, bp + "conv.0", Ho, Wo, l_c0, cur, hp, T1, 0, -1, 1);
+          add_dw(n, bp + "conv.1", Ho, Wo, l_c1, T1, T2, 1);
+          add_pw(n, bp + "conv.2", Ho, Wo, l_c2, T2, 0, nxt, 0, M_odd, 1);
+        }
+      }
       std::swap(cur, nxt);
     }
     in_buf = cur;
@@ -358,6 +431,26 @@ void build(rtpose_shufflenet* n) {
     const int F = add_buf(n, 1024, 0, Hc, Wc);
     const int OUT = add_buf(n, 64, 0, Hc, Wc, true);  // fp32 [PAF 0..37 | 2 pad | heat 40..58 | pad]
     n->out_buf = OUT;
+    if (n->fused) {
+      // the two heads as ONE 128-column GEMM: PAF in columns 0..37, heat-map in 64..82 of a shared packed
+      // matrix; the column -> channel map drops the padding columns
+      SLayer& P = n->layers[lp];
+      SLayer& Hh = n->layers[lh];
+      P.coutp = Hh.coutp = 128;
+      Hh.col_off = 64;
+      Hh.w_off = P.w_off = n->wt_floats;
+      n->wt_floats += round_up((size_t)1024 * 128, 64);
+      Hh.b_off = P.b_off = n->wt_floats;
+      n->wt_floats += 128;
+      std::vector<int32_t> hm(128, -1);
+      for (int i = 0; i < 38; ++i) hm[i] = i;
+      for (int i = 0; i < 19; ++i) hm[64 + i] = 40 + i;
+      const int M_heads = add_map(n, hm);
+      add_pwf(n, "conv5", Hc, Wc, l5, -1, in_buf, 0, F, 0, -1, 1);
+      add_pwf(n, "paf+heatmap", Hc, Wc, lp, -1, F, 0, OUT, 0, M_heads, 0, -1, -1, 0, 128);
+      n->ops.back().flops = 2.0 * n->N * Hc * Wc * 1024.0 * 57;
+      return;
+    }
     add_pw(n, "conv5", Hc, Wc, l5, in_buf, 0, F, 0, -1, 1);
     SOp o;
     o.kind = O_PW;
@@ -396,6 +489,7 @@ int rtpose_shufflenet_create_ex(int N, int H, int W, int dtype, rtpose_shufflene
   n->H = H;
   n->W = W;
   n->bf16 = dtype == RTPOSE_DTYPE_BF16;
+  n->fused = !n->bf16;  // the fused pointwise chains exist in fp32 (v_mfma_f32_32x32x2_f32) only
   build(n);
   *out = n;
   return 0;
@@ -472,6 +566,9 @@ int rtpose_shufflenet_load(rtpose_shufflenet* n, int idx, const float* w, const 
       return 0;
     }
     case L_PW:
+      if (l.coutp)  // shares a packed matrix with another layer (the heads of a fused plan)
+        return pack_pw_launch(w, b, l.cout, l.cin, map, l.cin_packed, l.coutp, l.col_off, n->wt + l.w_off,
+                              n->wt + l.b_off, s);
       if (n->bf16)
         return pack_weights_bf16_launch(w, b, l.cout, l.cin, 1, map, l.cin_packed, n->wt + l.w_off,
                                         n->wt + l.b_off, 0, s);
@@ -557,6 +654,38 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
                                                     imap(o.cmap[0]), n->N, o.H, o.W, stream)
                      : rtpose_layout_copy_cmap(n->ws + bi.off, &bi.lay, n->ws + bo.off, &bo.lay, o.C,
                                                imap(o.cmap[0]), n->N, o.H, o.W, stream);
+        break;
+      }
+      case O_PWF: {
+        const SLayer& l = n->layers[o.layer[0]];
+        const SBuf& bi = n->bufs[o.in_buf[0]];
+        const SBuf& bo = n->bufs[o.out_buf[0]];
+        rtpose_pw_desc d;
+        memset(&d, 0, sizeof(d));
+        d.in = n->ws + bi.off;
+        d.lin = slice(bi, o.in_choff[0]);
+        if (o.dw_layer >= 0) {
+          const SLayer& ld = n->layers[o.dw_layer];
+          d.dw_w = n->wt + ld.w_off;
+          d.dw_b = n->wt + ld.b_off;
+        }
+        d.w_packed = n->wt + l.w_off;
+        d.bias_packed = n->wt + l.b_off;
+        d.out = n->ws + bo.off;
+        d.lout = slice(bo, o.out_choff[0]);
+        d.cin = l.cin_packed;
+        d.cout = o.cout_store;
+        d.coutp = l.coutp ? l.coutp : cout_pad(l.cout);
+        d.relu = o.relu;
+        d.out_cmap = imap(o.cmap[0]);
+        if (o.pt_buf >= 0) {
+          const SBuf& bp = n->bufs[o.pt_buf];
+          d.pt_src = n->ws + bp.off;
+          d.lpt = slice(bp, 0);
+          d.pt_cmap = imap(o.pt_map);
+          d.pt_c = o.pt_c;
+        }
+        rc = pw_fused_launch(&d, n->N, o.H, o.W, s);
         break;
       }
       case O_PW: {

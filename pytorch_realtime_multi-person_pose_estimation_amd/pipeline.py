@@ -118,6 +118,7 @@ class StreamingPoseEstimator(object):
         cfg = dec.make_cfg(self.config, max_peaks_per_part, max_humans)
         self.bufs = dec.DecodeBuffers(cfg, batch, self.dev)
         self._torch = torch
+        self._pre = pre
 
     def _upload(self, slot, images):
         torch = self._torch
@@ -138,14 +139,12 @@ class StreamingPoseEstimator(object):
         main = torch.cuda.current_stream()
         main.wait_event(self.uploaded[slot])
         plan = m.plan_for_shape(self.B, self.hn, self.wn, self.dev)
-        ibase, ilay = C.c_void_p(), _capi.Layout()
-        check(lib.rtpose_net_input_view(plan.handle, C.byref(ibase), C.byref(ilay)), "rtpose_net_input_view")
         s = current_stream()
         img_bytes = self.h0 * self.w0 * 3
-        for b in range(self.B):
-            check(lib.rtpose_preprocess_u8(C.c_void_p(self.devbuf[slot].data_ptr() + b * img_bytes), self.h0, self.w0,
-                                           self.im_scale, self.mode, ibase, C.byref(ilay), b, self.hn, self.wn,
-                                           self.hr, self.wr, s), "rtpose_preprocess_u8")
+        base = self.devbuf[slot].data_ptr()
+        self._pre.preprocess_into_plan(plan, [base + b * img_bytes for b in range(self.B)],
+                                       [(self.h0, self.w0)] * self.B, int(self.config.DATASET.IMAGE_SIZE),
+                                       self.mode, s)                      # ONE launch for the whole batch
         self.consumed[slot].record(main)
         check(lib.rtpose_net_set_keep_intermediates(plan.handle, 0))
         check(lib.rtpose_net_forward_prepared(plan.handle, s), "rtpose_net_forward_prepared")

@@ -15,6 +15,11 @@ import torch
 from . import _capi, decode as dec
 from ._capi import lib, check, ptr, current_stream
 
+
+def C_byref(x):
+    import ctypes
+    return ctypes.byref(x)
+
 try:  # pragma: no cover - not in this image
     import cv2 as _cv2
 except Exception:  # noqa: BLE001
@@ -119,6 +124,36 @@ def get_outputs(img, model, preprocess, config=None):
     heatmap = output2.cpu().data.numpy().transpose(0, 2, 3, 1)[0]
     paf = output1.cpu().data.numpy().transpose(0, 2, 3, 1)[0]
     return paf, heatmap, im_scale
+
+
+def prep_geometry(h0, w0, dest_size, factor):
+    """crop_with_factor's sizes without touching pixels: (im_scale, (hr, wr) resized, (hn, wn) padded)."""
+    im_scale = float(dest_size) / min(h0, w0)
+    hr, wr = _cv_round(h0 * im_scale), _cv_round(w0 * im_scale)
+    return im_scale, (hr, wr), (_factor_closest(hr, factor), _factor_closest(wr, factor))
+
+
+def preprocess_into_plan(plan, images_dev, sizes, dest_size, mode, stream, flips=None, slots=None):
+    """ONE rtpose_preprocess_u8_batch launch: device uint8 BGR images (tensors, or raw device
+    addresses) of sizes [(h0, w0), ...] -> resized / padded / normalised into the plan's input
+    buffer, image k into slot slots[k] (default k), mirrored inside its valid width if flips[k]."""
+    import ctypes as C
+    ibase, ilay = C.c_void_p(), _capi.Layout()
+    check(lib.rtpose_net_input_view(plan.handle, C.byref(ibase), C.byref(ilay)), "rtpose_net_input_view")
+    n, hn, wn = plan.shape
+    descs = (_capi.PrepImage * len(sizes))()
+    for k, (h0, w0) in enumerate(sizes):
+        im_scale = float(dest_size) / min(h0, w0)
+        d = descs[k]
+        d.img_bgr = images_dev[k].data_ptr() if hasattr(images_dev[k], "data_ptr") else int(images_dev[k])
+        d.im_scale, d.h0, d.w0 = im_scale, h0, w0
+        d.hr, d.wr = _cv_round(h0 * im_scale), _cv_round(w0 * im_scale)
+        d.flip = int(bool(flips[k])) if flips is not None else 0
+        d.n_index = slots[k] if slots is not None else k
+        if d.n_index >= n:
+            raise _capi.RtposeError("image slot %d outside the %d-image plan" % (d.n_index, n))
+    check(lib.rtpose_preprocess_u8_batch(descs, len(sizes), mode, ibase, C.byref(ilay), hn, wn, stream),
+          "rtpose_preprocess_u8_batch")
 
 
 def get_outputs_gpu(img, model, preprocess, config=None):
@@ -266,15 +301,11 @@ def get_multiscale_outputs_batch(imgs, model, preprocess='rtpose', scales=(0.5, 
         hr, wr = _cv_round(h0 * im_scale), _cv_round(w0 * im_scale)
         hn, wn = _factor_closest(hr, stride), _factor_closest(wr, stride)
         plan = m.plan_for_shape(nb, hn, wn, dev)
-        ibase, ilay = C.c_void_p(), _capi.Layout()
-        check(lib.rtpose_net_input_view(plan.handle, C.byref(ibase), C.byref(ilay)), "rtpose_net_input_view")
-        for b in range(B):
-            src = C.c_void_p(img_d.data_ptr() + b * img_bytes)
-            check(lib.rtpose_preprocess_u8_flip(src, h0, w0, im_scale, mode, ibase, C.byref(ilay), b, hn, wn, hr, wr,
-                                                0, stream), "rtpose_preprocess_u8_flip")
-            if flip:
-                check(lib.rtpose_preprocess_u8_flip(src, h0, w0, im_scale, mode, ibase, C.byref(ilay), B + b, hn, wn,
-                                                    hr, wr, 1, stream), "rtpose_preprocess_u8_flip")
+        # all B images and their B mirror images in ONE launch
+        srcs = [img_d.data_ptr() + b * img_bytes for b in range(B)]
+        reps = 2 if flip else 1
+        preprocess_into_plan(plan, srcs * reps, [(h0, w0)] * (B * reps), int(round(base * s)), mode, stream,
+                             flips=[0] * B + [1] * B if flip else None)
         check(lib.rtpose_net_set_keep_intermediates(plan.handle, 0))
         check(lib.rtpose_net_forward_prepared(plan.handle, stream), "rtpose_net_forward_prepared")
         pbase, lpaf, _, hs, ws = m.output_view(plan, 0)
@@ -348,3 +379,169 @@ def run_eval(image_dir, anno_file, vis_dir, model, preprocess, config=None, imre
         upsample_keypoints = (heatmap.shape[0] * up / scale_img, heatmap.shape[1] * up / scale_img)
         append_result(iid, humans, upsample_keypoints, outputs, int(config.MODEL.NUM_KEYPOINTS))
     return oks_eval.eval_coco(outputs, anno_file, img_ids)
+
+
+def _coco_person_images(anno_file, max_images=None):
+    """run_eval's image list (coco_eval.py:248-252: the images that contain the person category)."""
+    import json
+    with open(anno_file) as f:
+        ann = json.load(f)
+    person_cat = [c["id"] for c in ann.get("categories", []) if c.get("name") == "person"] or [1]
+    img_ids = sorted({a["image_id"] for a in ann["annotations"] if a.get("category_id", 1) in person_cat})
+    info = {im["id"]: im for im in ann["images"]}
+    if max_images:
+        img_ids = img_ids[:max_images]
+    return img_ids, info
+
+
+def eval_batches(sizes, dest_size, factor, batch, by_source_size=False):
+    """The batched evaluation schedule: image indices grouped by the padded network input size
+    (hn, wn) crop_with_factor gives them (by the source size itself for TTA, whose scales must agree),
+    each bucket cut into batches of <= `batch`; deterministic order (buckets by first occurrence).
+    -> list of (key, [indices])."""
+    buckets = {}
+    for i, (h0, w0) in enumerate(sizes):
+        key = (h0, w0) if by_source_size else prep_geometry(h0, w0, dest_size, factor)[2]
+        buckets.setdefault(key, []).append(i)
+    out = []
+    for key, idx in buckets.items():
+        for j in range(0, len(idx), batch):
+            out.append((key, idx[j:j + batch]))
+    return out
+
+
+def run_eval_batched(image_dir, anno_file, vis_dir, model, preprocess, config=None, imread=None, max_images=None,
+                     batch=32, tta_scales=None, tta_flip=False, rank=0, world=1, return_outputs=False):
+    """evaluate/coco_eval.py:245-283 restructured for the GPU (BASELINE configs[2] and [4]).
+
+    The reference loops over the person images one at a time: imread -> get_outputs (batch 1, maps
+    to the host) -> paf_to_pose_cpp (maps back through numpy / SWIG) -> append_result.  Here the
+    images are bucketed by their padded input size, a bucket is cut into batches of `batch`, and per
+    batch: the uint8 images are uploaded (3 B/pixel), ONE kernel resizes / pads / normalises them
+    into the plan's input buffer, one forward, the decoder reads the stage-6 maps where the net
+    wrote them, and only the fixed-size result records come back.  Maps never cross PCIe.
+    With tta_scales (+ tta_flip) every batch runs get_multiscale_outputs_batch instead (configs[2]).
+    `world` ranks take the batches round-robin and exchange ONE all_gather of the record block per
+    step (parallel.gather_records); every rank ends up with all results.
+    The results are identical to run_eval's (same pixels, batch-invariant kernels, same decoder) and
+    come out in run_eval's order.  Returns the OKS AP (or (AP, outputs) with return_outputs)."""
+    import os
+    from . import common, oks_eval, parallel as par
+    config = config or dec.default_config()
+    imread = imread or imread_bgr
+    size, factor = int(config.DATASET.IMAGE_SIZE), int(config.MODEL.DOWNSAMPLE)
+    nkp = int(config.MODEL.NUM_KEYPOINTS)
+    img_ids, info = _coco_person_images(anno_file, max_images)
+    print("Total number of validation images {}".format(len(img_ids)))
+    m = _unwrap(model)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    mode = {'rtpose': 0, 'vgg': 1}[preprocess]
+
+    def load(i):
+        ori = imread(os.path.join(image_dir, info[img_ids[i]]["file_name"]))
+        if ori is None:
+            raise IOError("cannot read %s (no cv2 / PIL here: provide imread= or .npy images)"
+                          % info[img_ids[i]]["file_name"])
+        return np.ascontiguousarray(ori, dtype=np.uint8)
+
+    cache = {}
+    sizes = []
+    for i, iid in enumerate(img_ids):
+        im = info[iid]
+        if "height" in im and "width" in im:
+            sizes.append((int(im["height"]), int(im["width"])))
+        else:                                   # annotation without sizes: read the image now
+            cache[i] = load(i)
+            sizes.append(cache[i].shape[:2])
+    sched = eval_batches(sizes, size, factor, batch, by_source_size=tta_scales is not None)
+    steps = -(-len(sched) // world)
+    max_peaks, max_humans = 64, 64
+    bufs = None
+    humans_of = {}                              # image index -> list[Human]
+    stream = current_stream()
+    for step in range(steps):
+        mine = step * world + rank
+        key, idx = sched[mine] if mine < len(sched) else (None, [])
+        while True:                             # (repeats only when a device table overflowed)
+            cfg = dec.make_cfg(config, max_peaks, max_humans)
+            if bufs is None or bufs.cfg.max_peaks_per_part != max_peaks or bufs.cfg.max_humans != max_humans:
+                bufs = dec.DecodeBuffers(cfg, batch, dev)
+            if idx:
+                imgs = [cache.pop(i) if i in cache else load(i) for i in idx]
+                for i, im in zip(idx, imgs):
+                    if tuple(im.shape[:2]) != tuple(sizes[i]):
+                        raise _capi.RtposeError("image %s is %s, the annotation file says %s"
+                                                % (info[img_ids[i]]["file_name"], im.shape[:2], sizes[i]))
+                if tta_scales is not None:
+                    paf_d, heat_d, _ = get_multiscale_outputs_batch(imgs, model, preprocess, scales=tta_scales,
+                                                                    flip=tta_flip, config=config)
+                    hm, wm = heat_d.shape[1], heat_d.shape[2]
+                    lheat, lpaf = _capi.Layout.dense(19, hm, wm), _capi.Layout.dense(38, hm, wm)
+                    hbase, pbase = ptr(heat_d), ptr(paf_d)
+                else:
+                    hn, wn = key
+                    plan = m.plan_for_shape(len(idx), hn, wn, dev)
+                    up = [torch.from_numpy(im).to(dev, non_blocking=True) for im in imgs]
+                    preprocess_into_plan(plan, up, [im.shape[:2] for im in imgs], size, mode, stream)
+                    check(lib.rtpose_net_set_keep_intermediates(plan.handle, 0))
+                    check(lib.rtpose_net_forward_prepared(plan.handle, stream), "rtpose_net_forward_prepared")
+                    pbase, lpaf, _, hm, wm = m.output_view(plan, 0)
+                    hbase, lheat, _, _, _ = m.output_view(plan, 1)
+                # the record block always has `batch` slots (equal shapes for the gather); the decoder
+                # fills the first len(idx)
+                check(lib.rtpose_decode_batch(hbase, C_byref(lheat), pbase, C_byref(lpaf), len(idx), hm, wm,
+                                              C_byref(cfg), ptr(bufs.workspace), bufs.workspace.numel() * 4,
+                                              ptr(bufs.result), stream), "rtpose_decode_batch")
+            rec_dev = bufs.result.view(batch, bufs.words)
+            if world > 1:
+                allrec = par.gather_records(rec_dev, world).cpu().numpy().reshape(world, batch, bufs.words)
+            else:
+                allrec = dec.fetch(bufs).reshape(1, batch, bufs.words)
+            flags = 0
+            for r in range(world):
+                b = step * world + r
+                nvalid = len(sched[b][1]) if b < len(sched) else 0
+                if nvalid:
+                    flags |= int(np.bitwise_or.reduce(allrec[r, :nvalid, dec.RES_HEADER + 2]))
+            if flags & dec.OVERFLOW_PEAKS and max_peaks < dec.MAX_PEAKS_LIMIT:
+                max_peaks = min(2 * max_peaks, dec.MAX_PEAKS_LIMIT)
+                continue                        # every rank sees the same flags: all repeat the step together
+            if flags & dec.OVERFLOW_HUMANS and max_humans < dec.MAX_HUMANS_LIMIT:
+                max_humans = min(2 * max_humans, dec.MAX_HUMANS_LIMIT)
+                continue
+            if flags:
+                raise _capi.RtposeError("decode tables overflowed at maximum capacity (flags=%d)" % flags)
+            break
+        for r in range(world):
+            b = step * world + r
+            if b >= len(sched):
+                continue
+            bkey, bidx = sched[b]
+            for k, i in enumerate(bidx):
+                rec = dec.parse_image(allrec[r, k], cfg)
+                if tta_scales is not None:
+                    s1, (hr1, wr1), _ = prep_geometry(bkey[0], bkey[1], size, factor)
+                    hmap, wmap = -(-hr1 // factor), -(-wr1 // factor)
+                else:
+                    hmap, wmap = bkey[0] // factor, bkey[1] // factor
+                humans_of[i] = (dec.humans_from_record(rec, wmap * factor, hmap * factor, nkp), hmap, wmap)
+        if step % 10 == 0 and step:
+            print("Processed {} images".format(min(step * world * batch, len(img_ids))))
+    outputs = []
+    for i, iid in enumerate(img_ids):           # run_eval's order
+        humans, hmap, wmap = humans_of[i]
+        scale_img = float(size) / min(sizes[i])
+        if vis_dir and rank == 0:
+            ori = load(i)
+            out = common.draw_humans(ori, humans)
+            os.makedirs(vis_dir, exist_ok=True)
+            name = info[iid]["file_name"]
+            try:
+                import cv2
+                cv2.imwrite(os.path.join(vis_dir, name), out)
+            except ImportError:
+                np.save(os.path.join(vis_dir, os.path.splitext(name)[0] + ".npy"), out)
+        upsample_keypoints = (hmap * factor / scale_img, wmap * factor / scale_img)     # coco_eval.py:279
+        append_result(iid, humans, upsample_keypoints, outputs, nkp)
+    ap = oks_eval.eval_coco(outputs, anno_file, img_ids)
+    return (ap, outputs) if return_outputs else ap

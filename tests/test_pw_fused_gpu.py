@@ -1,0 +1,124 @@
+"""GPU parity of the fused pointwise chain kernel (csrc/pw_fused.hip, rtpose_pw_fused) against
+plain torch-CPU fp32 ops: F.conv2d 1x1 (+ReLU), the depthwise 3x3 F.conv2d(groups=C, padding=1) in
+front of it, and the cat + channel_shuffle store pattern (lib/network/rtpose_shufflenetV2.py:22-63).
+Every wave arrangement (64 / 128 / 256+ columns), K that is and is not a multiple of the 32-channel
+chunk, ragged pixel counts (last strip partly empty), strips that span image boundaries."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-4   # fp32 MFMA vs ATen fp32: different summation order only
+
+
+def _to_layout(capi, x_nchw, lay, cpad, cuda):
+    n, c, h, w = x_nchw.shape
+    buf = torch.zeros(capi.lib.rtpose_layout_pixels(C.byref(lay), n, h, w) * lay.cstride, device=cuda)
+    capi.check(capi.lib.rtpose_nchw_to_layout(capi.ptr(x_nchw.to(cuda).contiguous()), capi.ptr(buf), C.byref(lay), c,
+                                              cpad, n, h, w, capi.current_stream()))
+    return buf
+
+
+def _from_layout(capi, buf, lay, c, n, h, w, cuda):
+    out = torch.empty(n, c, h, w, device=cuda)
+    capi.check(capi.lib.rtpose_layout_to_nchw(capi.ptr(buf), C.byref(lay), capi.ptr(out), c, n, h, w,
+                                              capi.current_stream()))
+    return out.cpu()
+
+
+def _run(capi, cuda, n, h, w, cin, cout, coutp, dw, relu, pt_c=0, pad_in=1, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    K = (cin + 7) // 8 * 8
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, generator=g) / cin ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    lin = capi.Layout.padded(K, h, w, pad_in) if pad_in else capi.Layout.dense(K, h, w)
+    xin = _to_layout(capi, x, lin, K, cuda)
+    ref_in = x
+    d = capi.PwDesc()
+    keep = [xin]
+    if dw:
+        dw_w = torch.randn(cin, 1, 3, 3, generator=g) * 0.3
+        dw_b = torch.randn(cin, generator=g) * 0.1
+        ref_in = F.conv2d(x, dw_w, dw_b, padding=1, groups=cin)
+        wp = torch.zeros(9, K)
+        wp[:, :cin] = dw_w.reshape(cin, 9).t()
+        bp = torch.zeros(K)
+        bp[:cin] = dw_b
+        wp_d, bp_d = wp.to(cuda), bp.to(cuda)
+        keep += [wp_d, bp_d]
+        d.dw_w, d.dw_b = wp_d.data_ptr(), bp_d.data_ptr()
+    ref = F.conv2d(ref_in, wt[:, :, None, None], b)
+    if relu:
+        ref = F.relu(ref)
+    wpk = torch.zeros(capi.lib.rtpose_packed_pw_floats(K, coutp) + 64 * coutp, device=cuda)
+    bpk = torch.zeros(coutp, device=cuda)
+    wt_d, b_d = wt.contiguous().to(cuda), b.to(cuda)
+    capi.check(capi.lib.rtpose_pack_pw_weights(capi.ptr(wt_d), capi.ptr(b_d), cout, cin, None, K, coutp, 0,
+                                               capi.ptr(wpk), capi.ptr(bpk), capi.current_stream()))
+    # output: [pt | gemm] interleaved like channel_shuffle(2) when pt_c, else plain
+    ctot = (2 * cout if pt_c else cout)
+    cs = (ctot + 7) // 8 * 8
+    lout = capi.Layout.padded(cs, h, w, 1)
+    out = torch.zeros(capi.lib.rtpose_layout_pixels(C.byref(lout), n, h, w) * cs, device=cuda)
+    keep += [wpk, bpk, wt_d, b_d, out]
+    d.inp, d.w_packed, d.bias_packed, d.out = xin.data_ptr(), wpk.data_ptr(), bpk.data_ptr(), out.data_ptr()
+    d.lin, d.lout = lin, lout
+    d.cin, d.cout, d.coutp, d.relu = K, cout, coutp, 1 if relu else 0
+    if pt_c:
+        assert pt_c == cout
+        xpt = torch.randn(n, pt_c, h, w, generator=g)
+        lpt = capi.Layout.padded((pt_c + 7) // 8 * 8, h, w, 1)
+        ptb = _to_layout(capi, xpt, lpt, lpt.cstride, cuda)
+        odd = torch.arange(cout, dtype=torch.int32) * 2 + 1
+        even = torch.arange(pt_c, dtype=torch.int32) * 2
+        odd_d, even_d = odd.to(cuda), even.to(cuda)
+        keep += [ptb, odd_d, even_d]
+        d.out_cmap, d.pt_src, d.lpt, d.pt_cmap, d.pt_c = odd_d.data_ptr(), ptb.data_ptr(), lpt, even_d.data_ptr(), pt_c
+        ref = torch.stack([xpt, ref], 2).reshape(n, 2 * cout, h, w)      # cat + channel_shuffle(2)
+    capi.check(capi.lib.rtpose_pw_fused(C.byref(d), n, h, w, capi.current_stream()), "rtpose_pw_fused")
+    got = _from_layout(capi, out, lout, ctot, n, h, w, cuda)
+    # the layout gaps must stay untouched (zero): everything outside the real pixels
+    total = out.abs().sum().item()
+    inside = got.abs().sum().item()
+    assert abs(total - inside) <= 1e-3 * max(1.0, inside), "kernel wrote outside the real pixels"
+    scale = max(1.0, ref.abs().max().item())
+    err = (got - ref).abs().max().item()
+    assert err <= TOL * scale, (err, scale)
+
+
+@pytest.mark.parametrize("cin,cout,coutp", [(24, 58, 64), (64, 58, 64), (120, 116, 128), (232, 232, 256),
+                                            (464, 1024, 1024), (1024, 100, 128), (32, 19, 64)])
+def test_pointwise_only(capi, cuda, cin, cout, coutp):
+    _run(capi, cuda, 3, 13, 17, cin, cout, coutp, dw=False, relu=True, pad_in=1, seed=cin)
+    _run(capi, cuda, 2, 46, 46, cin, cout, coutp, dw=False, relu=False, pad_in=0, seed=cin + 1)
+
+
+@pytest.mark.parametrize("cin,cout,coutp", [(58, 58, 64), (116, 116, 128), (232, 232, 256), (128, 116, 128),
+                                            (240, 232, 256)])
+def test_depthwise_then_pointwise(capi, cuda, cin, cout, coutp):
+    _run(capi, cuda, 3, 13, 17, cin, cout, coutp, dw=True, relu=True, seed=cin)
+    _run(capi, cuda, 2, 46, 46, cin, cout, coutp, dw=True, relu=True, seed=cin + 1)
+    _run(capi, cuda, 1, 5, 60, cin, cout, coutp, dw=True, relu=False, seed=cin + 2)       # widest map that still fuses
+
+
+@pytest.mark.parametrize("c", [58, 116, 232])
+def test_unit_with_pass_through_and_shuffle(capi, cuda, c):
+    _run(capi, cuda, 2, 23, 25, c, c, (c + 63) // 64 * 64, dw=True, relu=True, pt_c=c, seed=c)
+    _run(capi, cuda, 4, 46, 46, c, c, (c + 63) // 64 * 64, dw=True, relu=True, pt_c=c, seed=c + 1)
+
+
+def test_bad_arguments_fail_loudly(capi, cuda):
+    d = capi.PwDesc()
+    assert capi.lib.rtpose_pw_fused(C.byref(d), 1, 8, 8, None) != 0
+    t = torch.zeros(4096, device=cuda)
+    d.inp = d.w_packed = d.bias_packed = d.out = t.data_ptr()
+    d.lin = d.lout = capi.Layout.dense(8, 8, 8)
+    d.cin, d.cout, d.coutp = 8, 8, 96          # coutp must be 64, 128 or k * 256
+    assert capi.lib.rtpose_pw_fused(C.byref(d), 1, 8, 8, None) != 0
+    d.coutp, d.dw_w, d.dw_b = 64, t.data_ptr(), t.data_ptr()   # depthwise input without a layout gap
+    assert capi.lib.rtpose_pw_fused(C.byref(d), 1, 8, 8, None) != 0

@@ -43,7 +43,8 @@ def main(n=128, iters=10, dtype='fp32'):
         name = C.create_string_buffer(96)
         lib.rtpose_shufflenet_launch_info(plan.handle, i, C.byref(ms), C.byref(fl), name, 96)
         nm = name.value.decode()
-        kind = "pw" if ("conv.0" in nm or "conv.2" in nm or "conv0.1" in nm or nm in ("conv5", "paf+heatmap")) else \
+        kind = "fused dw+pw(+x1)" if "+conv" in nm else \
+            "pw" if ("conv.0" in nm or "conv.2" in nm or "conv0.1" in nm or nm in ("conv5", "paf+heatmap")) else \
             ("dw" if ("conv.1" in nm or "conv0.0" in nm) else ("copy" if "x1->even" in nm else nm))
         if os.environ.get("VERBOSE"):
             print("  %-34s %7.3f ms %7.2f TF/s" % (nm, ms.value, fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0))
