@@ -30,3 +30,9 @@ def append_result(image_id, humans, upsample_keypoints, outputs):
 def run_eval(image_dir, anno_file, vis_dir, model, preprocess):
     """coco_eval.py:245-290 - what evaluate/evaluation.py calls."""
     return _pre.run_eval(image_dir, anno_file, vis_dir, model, preprocess, cfg)
+
+
+def run_eval_batched(image_dir, anno_file, vis_dir, model, preprocess, **kw):
+    """run_eval restructured for the GPU: images bucketed by padded size, batched, maps never leave HBM
+    (same results, same order; see preprocess.run_eval_batched for batch= / tta_scales= / rank= / world=)."""
+    return _pre.run_eval_batched(image_dir, anno_file, vis_dir, model, preprocess, cfg, **kw)

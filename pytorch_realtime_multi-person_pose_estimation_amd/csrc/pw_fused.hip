@@ -23,7 +23,7 @@
 //   * PT: the block also copies the pass-through half x1 of its pixels to the even channel slots of the
 //     output buffer while its GEMM result goes to the odd slots through out_cmap - cat + channel_shuffle
 //     cost no launch and no extra pass.
-//   * 2 blocks per CU (<= 72 KB LDS, <= 256 VGPRs): one block's staging / depthwise / epilogue phases
+//   * 2 blocks per CU (<= 63 KB LDS, <= 256 VGPRs): one block's staging / depthwise / epilogue phases
 //     run under the other's MFMAs.
 #include <hip/hip_runtime.h>
 
@@ -70,88 +70,135 @@ constexpr int kPwMaxStage = 8;  // DW: staged 16-byte pieces per thread per chun
   asm volatile("" ::: "memory"); \
   __builtin_amdgcn_sched_barrier(0)
 
+__device__ __forceinline__ int pw_pix_q(int m, int HW, int W, int lead, int hs, int ws) {
+  const int n = m / HW, r = m - n * HW;
+  const int y = r / W, x = r - y * W;
+  return lead + (n * hs + y) * ws + x;
+}
+
 // WM x WN waves (WM * WN = 4), wave tile (32 MF) x (32 NFW), WM * MF = 2.
+// PERSISTENT: the grid is 2 blocks per CU; a block walks work items (64-pixel strip, BN-column pass)
+// blockIdx.x, + gridDim.x, ...  The first K chunk of the NEXT item is requested while the last chunk of
+// the current one is multiplied, so an item's prologue (one exposed memory round trip) and its
+// epilogue stores run under MFMAs instead of in front of / behind them.
 template <int WM, int MF, int NFW, bool DW>
 __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
   constexpr int WN = 4 / WM;
   constexpr int BN = WN * NFW * 32;
   static_assert(WM * MF * 32 == kPwBM, "block tile is 64 pixels");
   extern __shared__ __attribute__((aligned(16))) float4 smem4[];
-  __shared__ int s_qin[kPwBM], s_qout[kPwBM], s_qpt[kPwBM];
+  __shared__ int s_qout[2][kPwBM], s_qpt[2][kPwBM];  // per work item (parity): output / pass-through pixel of row r
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WM, wn = wave / WM;
   const int l31 = lane & 31, kh = lane >> 5;
-  const int m0 = blockIdx.x * kPwBM;
   const int HW = A.H * A.W;
-
-  // ---- pixel tables: pixel index of tile row r in the input / output / pass-through layouts ----
-  if (tid < kPwBM) {
-    const int m = min(m0 + tid, A.M - 1);  // rows past the end replay the last pixel (never stored)
-    const int n = m / HW, r = m - n * HW;
-    const int y = r / A.W, x = r - y * A.W;
-    s_qin[tid] = A.in.lead + (n * A.in.hs + y) * A.in.ws + x;
-    s_qout[tid] = (m0 + tid < A.M) ? A.out_lead + (n * A.out_hs + y) * A.out_ws + x : -1;
-    s_qpt[tid] = A.pt.base ? A.pt.lead + (n * A.pt.hs + y) * A.pt.ws + x : 0;
-  }
-  __syncthreads();
+  const int pl = tid & 7, px = tid >> 3;  // staging role: channel-group plane, first pixel
 
   // ---- LDS carve-up (float4 units) ---------------------------------------------------------
   constexpr int ASUB = kPwPL * kPwQS;  // one A chunk buffer
   float4* a_lds = smem4;               // [2][ASUB]
-  float4* st_lds = smem4 + 2 * ASUB;   // DW: [2][kPwPL * nps]
+  float4* st = smem4 + 2 * ASUB;       // DW: [kPwPL][nps] staged halo (single buffer: parked after the
+                                       //     previous chunk's depthwise phase, which a barrier closes)
   const int nps = A.nps;
-
-  // ---- pass-through half: x1 -> even slots (cat + channel_shuffle folded into the store) ------
-  if (A.pt.base) {
-    const int g4 = (A.pt_c + 3) >> 2;
-    for (int it = tid; it < kPwBM * g4; it += 256) {
-      const int p = it / g4, g = it - p * g4;
-      const int qo = s_qout[p];
-      if (qo < 0) continue;
-      const float4 v = pw_gload4(A.pt.base + (size_t)s_qpt[p] * A.pt.cstride + A.pt.choff + 4 * g);
-      const float vv[4] = {v.x, v.y, v.z, v.w};
-      float* o = A.out + (size_t)qo * A.out_cstride;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (4 * g + e < A.pt_c) o[A.pt_cmap[4 * g + e]] = vv[e];
-    }
-  }
-
-  // ---- A staging geometry ----------------------------------------------------------------------
-  // DW = 0: piece u of thread t = (pixel t/8 + 32 u, plane t%8) of the chunk, u < 2
-  // DW = 1: the chunk's halo: pixels [q_org, q_org + np) x 8 planes, piece i = t + 256 u -> (i / 8, i % 8)
-  const int pl = tid & 7;
-  const float* in_base = A.in.base + A.in.choff + 4 * pl;
-  int q_org = 0, np = 0;
-  size_t goff[DW ? kPwMaxStage : 2];
-  int n_st = 2;
-  if (DW) {
-    q_org = s_qin[0] - A.in.ws - 1;
-    np = s_qin[kPwBM - 1] + A.in.ws + 1 - q_org + 1;
-    n_st = (np * kPwPL + 255) >> 8;
-#pragma unroll
-    for (int u = 0; u < kPwMaxStage; ++u) goff[u] = (size_t)(q_org + min((tid >> 3) + 32 * u, np - 1)) * A.in.cstride;
-  } else {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) goff[u] = (size_t)s_qin[(tid >> 3) + 32 * u] * A.in.cstride;
-  }
-  // DW compute items of this thread: (pixel tid/8 + 32 u, plane tid%8): halo-relative pixel index
-  int sp[2] = {0, 0};
-  if (DW) {
-    sp[0] = s_qin[tid >> 3] - q_org;
-    sp[1] = s_qin[(tid >> 3) + 32] - q_org;
-  }
+  float4* dwl = st + kPwPL * nps;      // DW: [10][K/4] depthwise taps + bias, loaded once per block
 
   const int nch = (A.K + 31) >> 5;
+  const int gtot = A.K >> 3;  // 8-channel k-groups in all
   const int npass = A.coutp / BN;
+  const int nwork = ((A.M + kPwBM - 1) / kPwBM) * npass;
   const float4* w4 = reinterpret_cast<const float4*>(A.w);
+  // Addresses are a uniform (scalar) base + a 32-bit per-lane element offset: the loads take the
+  // SGPR-base form and no 64-bit address pairs are kept per piece (the host checks that every tensor
+  // is below 2^31 floats).
+  const float* in_base = A.in.base + A.in.choff;
 
-  for (int pass = 0; pass < npass; ++pass) {
-    const int ncol = pass * BN + wn * (32 * NFW) + l31;  // column of n-fragment 0 of this lane
+  // Per work item, per thread: where its staged pieces come from.
+  //   DW = 0: piece u = (pixel px + 32 u, plane pl) of the strip, u < 2          -> q[u] = pixel index
+  //   DW = 1: the strip's halo = pixels [q_org, q_org + np) x 8 planes, piece u = (px + 32 u, pl), u < n_st;
+  //           sp[u] = halo-relative index of the thread's two depthwise output pixels
+  struct Item {
+    int m0, pass;
+    int q0, q1;      // DW = 0: q[0], q[1];  DW = 1: q_org, np
+    int sp0, sp1;    // DW = 1
+  };
+  auto setup = [&](int wi) -> Item {
+    Item it;
+    const int tile = wi / npass;
+    it.pass = wi - tile * npass;
+    it.m0 = tile * kPwBM;
+    const int ma = min(it.m0 + px, A.M - 1), mb = min(it.m0 + px + 32, A.M - 1);  // rows past the end replay the last pixel
+    const int qa = pw_pix_q(ma, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
+    const int qb = pw_pix_q(mb, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
+    if (DW) {
+      const int qf = pw_pix_q(it.m0, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
+      const int ql = pw_pix_q(min(it.m0 + kPwBM - 1, A.M - 1), HW, A.W, A.in.lead, A.in.hs, A.in.ws);
+      it.q0 = qf - A.in.ws - 1;
+      it.q1 = ql + A.in.ws + 1 - it.q0 + 1;
+      it.sp0 = qa - it.q0;
+      it.sp1 = qb - it.q0;
+    } else {
+      it.q0 = qa;
+      it.q1 = qb;
+      it.sp0 = it.sp1 = 0;
+    }
+    return it;
+  };
+  auto write_tables = [&](const Item& it, int par) {  // threads 0..63
+    const int m = it.m0 + tid;
+    const int mc = min(m, A.M - 1);
+    s_qout[par][tid] = m < A.M ? pw_pix_q(mc, HW, A.W, A.out_lead, A.out_hs, A.out_ws) : -1;
+    s_qpt[par][tid] = A.pt.base ? pw_pix_q(mc, HW, A.W, A.pt.lead, A.pt.hs, A.pt.ws) : 0;
+  };
+  // staged pieces of channel chunk c0 of item `it` -> registers.  Branch-free: every thread always issues
+  // all its loads, pixels past the halo / channel groups past K are clamped to valid addresses (their LDS
+  // slots exist and are never multiplied) - per-piece predicates put every load in its own basic block,
+  // which cost ~90 VGPRs and the load/MFMA interleaving.
+  float4 sr[DW ? kPwMaxStage : 2];
+  auto load_pieces = [&](const Item& it, int c0) {
+    const unsigned cofs = (unsigned)(min(c0 + 4 * pl, A.K - 4));
+    if (DW) {
+#pragma unroll
+      for (int u = 0; u < kPwMaxStage; ++u)
+        sr[u] = pw_gload4(in_base + ((unsigned)(it.q0 + min(px + 32 * u, it.q1 - 1)) * (unsigned)A.in.cstride + cofs));
+    } else {
+      sr[0] = pw_gload4(in_base + ((unsigned)it.q0 * (unsigned)A.in.cstride + cofs));
+      sr[1] = pw_gload4(in_base + ((unsigned)it.q1 * (unsigned)A.in.cstride + cofs));
+    }
+  };
 
+  int wi = blockIdx.x;
+  if (wi >= nwork) return;
+  Item cur = setup(wi);
+#pragma unroll
+  for (int u = 0; u < (DW ? kPwMaxStage : 2); ++u) sr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < kPwBM) write_tables(cur, 0);
+  load_pieces(cur, 0);
+  if (DW) {  // (visible after the first chunk's barrier)
+    const int k4 = A.K >> 2;
+    for (int i = tid; i < 10 * k4; i += 256)
+      dwl[i] = i < 9 * k4 ? pw_gload4(A.dw_w + 4 * (size_t)i) : pw_gload4(A.dw_b + 4 * (size_t)(i - 9 * k4));
+  }
+  int par = 0;   // work-item parity (tables)
+  int lbuf = 0;  // LDS chunk-buffer parity, runs on across work items
+
+  while (true) {
+    const int wnext = wi + gridDim.x;
+    const bool has_next = wnext < nwork;
+    Item nxt = cur;
+    if (has_next) nxt = setup(wnext);
+    const int ncol = cur.pass * BN + wn * (32 * NFW) + l31;  // column of n-fragment 0 of this lane
+    const unsigned w_lane = (unsigned)(kh * A.coutp + ncol);  // float4 index of this lane in a k-group's two planes
+
+    // B fragments of k-group 0 (their latency hides behind the first chunk's staging + barrier)
+    float4 bcur[NFW], bnxt[NFW];
+#pragma unroll
+    for (int fn = 0; fn < NFW; ++fn) {
+      bcur[fn] = pw_gload4(w4 + (w_lane + fn * 32));
+      bnxt[fn] = bcur[fn];
+    }
     floatx16 acc[MF][NFW];
 #pragma unroll
     for (int fn = 0; fn < NFW; ++fn) {
@@ -162,71 +209,51 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
         for (int r = 0; r < 16; ++r) acc[fm][fn][r] = b0;
     }
 
-    // pieces of chunk 0 into registers
-    float4 sr[DW ? kPwMaxStage : 2];
-#pragma unroll
-    for (int u = 0; u < (DW ? kPwMaxStage : 2); ++u) {
-      sr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (u < n_st && 4 * pl < A.K) sr[u] = pw_gload4(in_base + goff[u]);
-    }
-    // B fragments of k-group 0
-    float4 bcur[NFW], bnxt[NFW];
-#pragma unroll
-    for (int fn = 0; fn < NFW; ++fn) bnxt[fn] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int fn = 0; fn < NFW; ++fn) bcur[fn] = pw_gload4(w4 + (size_t)kh * A.coutp + ncol + fn * 32);
-
-    const int gtot = A.K >> 3;  // 8-channel k-groups in all
     for (int c = 0; c < nch; ++c) {
-      const int buf = c & 1;
       const int c0 = c << 5;
-      float4* a_buf = a_lds + buf * ASUB;
-      float4 dww[9], dwb;
+      float4* a_buf = a_lds + lbuf * ASUB;
+      const bool last = c + 1 == nch;
       if (DW) {
-        // the depthwise taps of this thread's channel group (same for both of its pixels)
-        const bool ok = c0 + 4 * pl < A.K;
+        // park the staged halo pieces, request the next chunk's (of this item, or chunk 0 of the next)
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-          dww[t] = ok ? pw_gload4(A.dw_w + (size_t)t * A.K + c0 + 4 * pl) : make_float4(0.f, 0.f, 0.f, 0.f);
-        dwb = ok ? pw_gload4(A.dw_b + c0 + 4 * pl) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4* st = st_lds + buf * (kPwPL * nps);
-        // park the staged halo pieces, fetch the next chunk's
-#pragma unroll
-        for (int u = 0; u < kPwMaxStage; ++u)
-          if (u < n_st && (tid >> 3) + 32 * u < np) st[pl * nps + (tid >> 3) + 32 * u] = sr[u];
-        const bool nxt_ok = c + 1 < nch && c0 + 32 + 4 * pl < A.K;
-#pragma unroll
-        for (int u = 0; u < kPwMaxStage; ++u)
-          if (u < n_st && nxt_ok) sr[u] = pw_gload4(in_base + goff[u] + c0 + 32);
-        __syncthreads();  // halo of chunk c visible
+        for (int u = 0; u < kPwMaxStage; ++u) st[pl * nps + px + 32 * u] = sr[u];  // (nps >= 256 pixels)
+        load_pieces(last ? nxt : cur, last ? 0 : c0 + 32);  // (no next item: nxt == cur, a harmless re-read)
+        __syncthreads();  // halo of chunk c visible; every wave is past the previous item's epilogue
+        if (c == 0 && has_next && tid < kPwBM) write_tables(nxt, par ^ 1);
         // depthwise 3x3 (+bias) -> A tile.  Tap (ky, kx) of pixel q is pixel q + (ky-1) ws + (kx-1).
+        const int k4 = A.K >> 2;
+        const float4* wl = dwl + min((c0 >> 2) + pl, k4 - 1);  // (groups past K: their A planes are not read)
+        float4 v0 = wl[9 * k4], v1 = v0;                       // bias
+        const float4* s0 = st + pl * nps + cur.sp0 - A.in.ws - 1;
+        const float4* s1 = st + pl * nps + cur.sp1 - A.in.ws - 1;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          float4 v = dwb;
-          const float4* s0 = st + pl * nps + sp[u] - A.in.ws - 1;
+        for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
-          for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-              const float4 x = s0[ky * A.in.ws + kx];
-              const float4 ww = dww[ky * 3 + kx];
-              v.x += x.x * ww.x;
-              v.y += x.y * ww.y;
-              v.z += x.z * ww.z;
-              v.w += x.w * ww.w;
-            }
-          a_buf[pl * kPwQS + (tid >> 3) + 32 * u] = v;
+          for (int kx = 0; kx < 3; ++kx) {
+            const float4 ww = wl[(ky * 3 + kx) * k4];
+            const float4 x0 = s0[ky * A.in.ws + kx], x1 = s1[ky * A.in.ws + kx];
+            v0.x += x0.x * ww.x;
+            v0.y += x0.y * ww.y;
+            v0.z += x0.z * ww.z;
+            v0.w += x0.w * ww.w;
+            v1.x += x1.x * ww.x;
+            v1.y += x1.y * ww.y;
+            v1.z += x1.z * ww.z;
+            v1.w += x1.w * ww.w;
+          }
+          RTPOSE_PW_PIN();  // one stencil row (9 LDS reads) at a time: all 27 at once cost 108 VGPRs
         }
-        __syncthreads();  // A tile of chunk c visible
+        a_buf[pl * kPwQS + px] = v0;
+        a_buf[pl * kPwQS + px + 32] = v1;
+        __syncthreads();  // A tile of chunk c visible; the staged halo may be overwritten
       } else {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) a_buf[pl * kPwQS + (tid >> 3) + 32 * u] = sr[u];
-        const bool nxt_ok = c + 1 < nch && c0 + 32 + 4 * pl < A.K;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-          if (nxt_ok) sr[u] = pw_gload4(in_base + goff[u] + c0 + 32);
+        a_buf[pl * kPwQS + px] = sr[0];
+        a_buf[pl * kPwQS + px + 32] = sr[1];
+        load_pieces(last ? nxt : cur, last ? 0 : c0 + 32);  // (no next item: nxt == cur, a harmless re-read)
         __syncthreads();  // A tile of chunk c visible (the other buffer was last read before the previous barrier)
+        if (c == 0 && has_next && tid < kPwBM) write_tables(nxt, par ^ 1);
       }
+      lbuf ^= 1;
 
       // ---- multiply chunk c: ng k-groups of 8 channels, 4 MFMAs per (m, n) fragment pair each ----
       // Operands of the NEXT k-group are requested before the current group's MFMAs are issued (B from
@@ -236,9 +263,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
       // requests in flight (in a rolled loop with guards it drained vmcnt to 0 at every group).
       const int ng = min(4, gtot - 4 * c);
       const float4* a_rd = a_buf + kh * kPwQS + wm * (32 * MF) + l31;
-      const float4* w_rd = w4 + (size_t)kh * A.coutp + ncol;  // + 2 * group * coutp
 #define RTPOSE_PW_BLOAD(DST, GG)                                                              \
-  _Pragma("unroll") for (int fn = 0; fn < NFW; ++fn) DST[fn] = pw_gload4(w_rd + (size_t)2 * (GG) * A.coutp + fn * 32)
+  _Pragma("unroll") for (int fn = 0; fn < NFW; ++fn)                                          \
+      DST[fn] = pw_gload4(w4 + (size_t)(2 * (GG) * A.coutp) + (w_lane + fn * 32))
 #define RTPOSE_PW_ALOAD(DST, GI) \
   _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) DST[fm] = a_rd[2 * (GI) * kPwQS + fm * 32]
 #define RTPOSE_PW_MUL(AV, BV)                                                                           \
@@ -251,43 +278,36 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
       }                                                                                                 \
     }                                                                                                   \
   }
+      // (no rolled loop for the short last chunk of K = 24, 120, 232, 464: a second code region made the
+      //  compiler keep the 64 accumulator registers twice - guarded straight-line groups instead; loads
+      //  of groups past K are clamped to valid memory and never multiplied)
+      const int gg = 4 * c, gl = gtot - 1;
       float4 a0[MF], a1[MF];
       RTPOSE_PW_ALOAD(a0, 0);
-      if (ng == 4) {
-        const int gg = 4 * c;
-        RTPOSE_PW_BLOAD(bnxt, gg + 1);
-        RTPOSE_PW_ALOAD(a1, 1);
-        RTPOSE_PW_PIN();
-        RTPOSE_PW_MUL(a0, bcur);
-        RTPOSE_PW_PIN();
-        RTPOSE_PW_BLOAD(bcur, gg + 2);
+      RTPOSE_PW_BLOAD(bnxt, min(gg + 1, gl));
+      RTPOSE_PW_ALOAD(a1, 1);
+      RTPOSE_PW_PIN();
+      RTPOSE_PW_MUL(a0, bcur);
+      RTPOSE_PW_PIN();
+      if (ng > 1) {
+        RTPOSE_PW_BLOAD(bcur, min(gg + 2, gl));
         RTPOSE_PW_ALOAD(a0, 2);
         RTPOSE_PW_PIN();
         RTPOSE_PW_MUL(a1, bnxt);
         RTPOSE_PW_PIN();
-        RTPOSE_PW_BLOAD(bnxt, gg + 3);
+      }
+      if (ng > 2) {
+        RTPOSE_PW_BLOAD(bnxt, min(gg + 3, gl));
         RTPOSE_PW_ALOAD(a1, 3);
         RTPOSE_PW_PIN();
         RTPOSE_PW_MUL(a0, bcur);
         RTPOSE_PW_PIN();
-        RTPOSE_PW_BLOAD(bcur, min(gg + 4, gtot - 1));  // first group of the next chunk (clamped: valid memory)
+      }
+      if (ng > 3) {
+        RTPOSE_PW_BLOAD(bcur, min(gg + 4, gl));  // first group of the next chunk
         RTPOSE_PW_PIN();
         RTPOSE_PW_MUL(a1, bnxt);
         RTPOSE_PW_PIN();
-      } else {  // the short last chunk of a K that is not a multiple of 32 (K = 24, 120, 232, 464)
-        for (int gi = 0; gi < ng; ++gi) {
-          if (gi + 1 < ng) {
-            RTPOSE_PW_BLOAD(bnxt, 4 * c + gi + 1);
-            RTPOSE_PW_ALOAD(a1, gi + 1);
-          }
-          RTPOSE_PW_PIN();
-          RTPOSE_PW_MUL(a0, bcur);
-          RTPOSE_PW_PIN();
-#pragma unroll
-          for (int fn = 0; fn < NFW; ++fn) bcur[fn] = bnxt[fn];
-#pragma unroll
-          for (int fm = 0; fm < MF; ++fm) a0[fm] = a1[fm];
-        }
       }
 #undef RTPOSE_PW_MUL
 #undef RTPOSE_PW_ALOAD
@@ -296,30 +316,64 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
 
     // ---- epilogue: (ReLU), scatter through out_cmap.  A lane holds column ncol of rows
     //      rg*8 + 4*kh + rr of its 32-row fragment (v_mfma_f32_32x32x2_f32 C layout). ----
-    int qrow[MF][16];  // output pixel of every row this lane holds (batched LDS reads)
-#pragma unroll
-    for (int fm = 0; fm < MF; ++fm)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) qrow[fm][rg * 4 + rr] = s_qout[wm * (32 * MF) + fm * 32 + rg * 8 + 4 * kh + rr];
+    int chn[NFW];
 #pragma unroll
     for (int fn = 0; fn < NFW; ++fn) {
       const int n = ncol + fn * 32;
-      int ch = -1;
-      if (n < A.cout) ch = A.out_cmap ? A.out_cmap[n] : A.out_choff + n;
-      float* ocol = A.out + (ch >= 0 ? ch : 0);
+      chn[fn] = -1;
+      if (n < A.cout) chn[fn] = A.out_cmap ? A.out_cmap[n] : A.out_choff + n;
+    }
 #pragma unroll
-      for (int fm = 0; fm < MF; ++fm)
+    for (int fm = 0; fm < MF; ++fm) {
+      int qrow[16];  // output pixel of every row of this fragment the lane holds (batched LDS reads)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) qrow[rg * 4 + rr] = s_qout[par][wm * (32 * MF) + fm * 32 + rg * 8 + 4 * kh + rr];
+#pragma unroll
+      for (int fn = 0; fn < NFW; ++fn) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int qo = qrow[fm][r];
           float v = acc[fm][fn][r];
           if (A.relu) v = fmaxf(v, 0.f);
-          if (qo >= 0 && ch >= 0) ocol[(size_t)qo * A.out_cstride] = v;
+          if (qrow[r] >= 0 && chn[fn] >= 0) A.out[(unsigned)qrow[r] * (unsigned)A.out_cstride + (unsigned)chn[fn]] = v;
         }
+      }
     }
-    __syncthreads();  // the LDS buffers are re-filled by the next pass
+
+    // ---- pass-through half: x1 -> even slots (cat + channel_shuffle folded into the store) ------
+    if (A.pt.base && cur.pass == 0) {
+      const int g4 = (A.pt_c + 3) >> 2;
+      const int nit = kPwBM * g4;
+      constexpr int PB = 4;  // loads in flight per thread (a load -> 4 stores chain per item exposed a full
+                             // memory round trip per item: 0.25 ms per launch at 232 channels)
+      for (int it0 = tid; it0 < nit; it0 += 256 * PB) {
+        float4 v[PB];
+        int qo[PB], gg[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+          const int it = it0 + 256 * u;
+          const int p = min(it, nit - 1) / g4;
+          gg[u] = min(it, nit - 1) - p * g4;
+          qo[u] = it < nit ? s_qout[par][p] : -1;
+          v[u] = pw_gload4(A.pt.base + ((unsigned)s_qpt[par][p] * (unsigned)A.pt.cstride + (unsigned)(A.pt.choff + 4 * gg[u])));
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+          if (qo[u] < 0) continue;
+          const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+          const unsigned o = (unsigned)qo[u] * (unsigned)A.out_cstride;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (4 * gg[u] + e < A.pt_c) A.out[o + (unsigned)A.pt_cmap[4 * gg[u] + e]] = vv[e];
+        }
+      }
+    }
+
+    if (!has_next) break;
+    cur = nxt;
+    wi = wnext;
+    par ^= 1;
   }
 }
 #undef RTPOSE_PW_PIN
@@ -386,6 +440,9 @@ int pw_fused_launch(const rtpose_pw_desc* d, int N, int H, int W, hipStream_t s)
     return fail(RTPOSE_E_INVAL, "pw_fused: the depthwise input needs a layout gap of 1 and a bias");
   if (d->pt_src && (!d->pt_cmap || d->pt_c <= 0 || (d->lpt.cstride % 4) || (d->lpt.choff % 4)))
     return fail(RTPOSE_E_INVAL, "pw_fused: bad pass-through description");
+  if (rtpose_layout_pixels(&d->lin, N, H, W) * (size_t)d->lin.cstride >= ((size_t)1 << 31) ||
+      rtpose_layout_pixels(&d->lout, N, H, W) * (size_t)d->lout.cstride >= ((size_t)1 << 31))
+    return fail(RTPOSE_E_INVAL, "pw_fused: tensors must be below 2^31 floats (32-bit element offsets)");
   PwArgs a;
   memset(&a, 0, sizeof(a));
   a.in = PwView{d->in, d->lin.cstride, d->lin.choff, d->lin.ws, d->lin.hs, d->lin.lead};
@@ -415,12 +472,14 @@ int pw_fused_launch(const rtpose_pw_desc* d, int N, int H, int W, hipStream_t s)
   a.relu = d->relu;
   size_t lds = (size_t)2 * kPwPL * kPwQS * 16;
   if (dw) {
-    a.nps = pw_halo_stride(d->lin, H, W);
-    if (a.nps * kPwPL > 256 * kPwMaxStage)
+    if (pw_halo_stride(d->lin, H, W) > 32 * kPwMaxStage)
       return fail(RTPOSE_E_INVAL, "pw_fused: map too wide for the fused depthwise halo (W <= ~60)");
-    lds += (size_t)2 * kPwPL * a.nps * 16;
+    a.nps = 32 * kPwMaxStage + 2;  // every staged piece has a slot (unconditional parking); planes 8 banks apart
+    lds += (size_t)kPwPL * a.nps * 16 + (size_t)10 * d->cin * 4;
   }
-  const int grid = ceil_div(a.M, kPwBM);
+  const int npass_h = d->coutp == 64 ? 1 : (d->coutp == 128 ? 1 : d->coutp / 256);
+  const int nwork = ceil_div(a.M, kPwBM) * npass_h;
+  const int grid = nwork < 2 * device_cu_count() ? nwork : 2 * device_cu_count();  // persistent: 2 blocks per CU
   if (d->coutp == 64) return dw ? pw_launch_inst<2, 1, 1, true>(a, grid, lds, s) : pw_launch_inst<2, 1, 1, false>(a, grid, lds, s);
   if (d->coutp == 128) return dw ? pw_launch_inst<1, 2, 1, true>(a, grid, lds, s) : pw_launch_inst<1, 2, 1, false>(a, grid, lds, s);
   return dw ? pw_launch_inst<1, 2, 2, true>(a, grid, lds, s) : pw_launch_inst<1, 2, 2, false>(a, grid, lds, s);

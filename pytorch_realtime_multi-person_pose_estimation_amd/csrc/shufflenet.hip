@@ -259,7 +259,7 @@ void add_pwf(rtpose_shufflenet* n, const std::string& name, int H, int W, int la
 
 // can the depthwise 3x3 that reads `b` be evaluated inside the fused pointwise kernel?
 bool dw_fusable(const rtpose_shufflenet* n, int buf, int H, int W) {
-  return n->fused && pw_halo_stride(n->bufs[buf].lay, H, W) * 8 <= 2048;
+  return n->fused && pw_halo_stride(n->bufs[buf].lay, H, W) <= 256;
 }
 
 void build(rtpose_shufflenet* n) {
@@ -432,22 +432,22 @@ void build(rtpose_shufflenet* n) {
     const int OUT = add_buf(n, 64, 0, Hc, Wc, true);  // fp32 [PAF 0..37 | 2 pad | heat 40..58 | pad]
     n->out_buf = OUT;
     if (n->fused) {
-      // the two heads as ONE 128-column GEMM: PAF in columns 0..37, heat-map in 64..82 of a shared packed
-      // matrix; the column -> channel map drops the padding columns
+      // the two heads as ONE 64-column GEMM: PAF in columns 0..37, heat-map in 38..56 of a shared packed
+      // matrix (38 + 19 = 57 <= 64); the column -> channel map puts them at [0, 38) and [40, 59)
       SLayer& P = n->layers[lp];
       SLayer& Hh = n->layers[lh];
-      P.coutp = Hh.coutp = 128;
-      Hh.col_off = 64;
+      P.coutp = Hh.coutp = 64;
+      Hh.col_off = 38;
       Hh.w_off = P.w_off = n->wt_floats;
-      n->wt_floats += round_up((size_t)1024 * 128, 64);
+      n->wt_floats += round_up((size_t)(1024 + 32) * 64, 64);
       Hh.b_off = P.b_off = n->wt_floats;
-      n->wt_floats += 128;
-      std::vector<int32_t> hm(128, -1);
+      n->wt_floats += 64;
+      std::vector<int32_t> hm(64, -1);
       for (int i = 0; i < 38; ++i) hm[i] = i;
-      for (int i = 0; i < 19; ++i) hm[64 + i] = 40 + i;
+      for (int i = 0; i < 19; ++i) hm[38 + i] = 40 + i;
       const int M_heads = add_map(n, hm);
       add_pwf(n, "conv5", Hc, Wc, l5, -1, in_buf, 0, F, 0, -1, 1);
-      add_pwf(n, "paf+heatmap", Hc, Wc, lp, -1, F, 0, OUT, 0, M_heads, 0, -1, -1, 0, 128);
+      add_pwf(n, "paf+heatmap", Hc, Wc, lp, -1, F, 0, OUT, 0, M_heads, 0, -1, -1, 0, 64);
       n->ops.back().flops = 2.0 * n->N * Hc * Wc * 1024.0 * 57;
       return;
     }

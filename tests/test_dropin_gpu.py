@@ -362,3 +362,78 @@ def test_run_eval_flow_on_a_synthetic_coco_set(compat, cuda, tmp_path):
     assert np.load(vis_dir / "000001.npy").shape == (130, 160, 3)
     with pytest.raises(NotImplementedError):
         OpenPose_Model(l2_stages=4, l1_stages=2, paf_out_channels=38, heat_out_channels=19)
+
+
+def _synthetic_coco_set(tmp_path, n_images, rng, sizes):
+    import json
+    img_dir = tmp_path / "images"
+    img_dir.mkdir()
+    images, annotations = [], []
+    for i in range(n_images):
+        h0, w0 = sizes[int(rng.integers(len(sizes)))]
+        np.save(img_dir / ("%06d.npy" % i), np.clip(rng.normal(128, 4, (h0, w0, 3)), 0, 255).astype(np.uint8))
+        images.append({"id": 1000 + i, "file_name": "%06d.jpg" % i, "height": h0, "width": w0})
+        kp = []
+        for k in range(17):
+            kp += [10.0 + 3 * k, 12.0 + 2 * k, 2]
+        annotations.append({"id": i + 1, "image_id": 1000 + i, "category_id": 1, "iscrowd": 0, "num_keypoints": 17,
+                            "keypoints": kp, "bbox": [5, 5, 60, 50], "area": 3000.0})
+    ann_file = tmp_path / "person_keypoints.json"
+    ann_file.write_text(json.dumps({"images": images, "annotations": annotations,
+                                    "categories": [{"id": 1, "name": "person"}]}))
+    return str(img_dir), str(ann_file)
+
+
+def test_batched_eval_driver_equals_serial_run_eval(compat, cuda, tmp_path):
+    """evaluate/coco_eval.py:245-283 as a batched GPU pipeline (images bucketed by padded size, one image-prep
+    launch + one forward + one decode per batch, maps never leave HBM) produces EXACTLY the COCO results of
+    the serial batch-1 loop, in the same order, on a synthetic COCO-format set of 520 mixed-size images; and
+    the TTA variant (configs[2]) decodes from the device accumulators."""
+    from evaluate.coco_eval import run_eval_batched
+    from lib.network.rtpose_vgg import get_model
+    from oracle import net_oracle
+    pre = importlib.import_module(PKG_NAME + ".preprocess")
+    model = get_model(trunk='vgg19')
+    model.load_state_dict(net_oracle.he_init_state_dict(model, seed=0))
+    model = model.cuda().float().eval()
+    rng = np.random.default_rng(12)
+    sizes = [(64, 80), (64, 81), (72, 64), (64, 64), (70, 96), (96, 70), (64, 100)]
+    img_dir, ann_file = _synthetic_coco_set(tmp_path, 520, rng, sizes)
+    with torch.no_grad():
+        ap_b, out_b = run_eval_batched(img_dir, ann_file, None, model, 'rtpose', batch=32, return_outputs=True)
+        # the reference-shaped serial loop (batch 1, maps through the host) on the same set
+        outputs = []
+        import json
+        ann = json.load(open(ann_file))
+        ids = sorted(im["id"] for im in ann["images"])
+        files = {im["id"]: im["file_name"] for im in ann["images"]}
+        dec = importlib.import_module(PKG_NAME + ".decode")
+        cfg = dec.default_config()
+        for iid in ids:
+            ori = pre.imread_bgr(os.path.join(img_dir, files[iid]))
+            paf, heatmap, scale_img = pre.get_outputs(ori, model, 'rtpose', cfg)       # host prep, maps to host
+            humans = dec.paf_to_pose_cpp(heatmap, paf, cfg)
+            pre.append_result(iid, humans, (heatmap.shape[0] * 8 / scale_img, heatmap.shape[1] * 8 / scale_img),
+                              outputs, 18)
+    assert len(out_b) == len(outputs) > 0
+    for a, b in zip(out_b, outputs):
+        assert a["image_id"] == b["image_id"] and a["keypoints"] == b["keypoints"] and a["score"] == b["score"]
+    assert 0.0 <= ap_b <= 1.0
+    # every bucket really was batched: 7 sizes -> few padded shapes, 520 images -> far fewer steps than images
+    sched = pre.eval_batches([(im["height"], im["width"]) for im in sorted(ann["images"], key=lambda d: d["id"])],
+                             368, 8, 32)
+    assert len(sched) <= 520 // 32 + len(sizes) + 1
+    # TTA (scales x flip) through the same driver: runs from the device accumulators, same image count
+    with torch.no_grad():
+        ap_t, out_t = run_eval_batched(img_dir, ann_file, None, model, 'rtpose', batch=8, max_images=24,
+                                       tta_scales=(0.5, 1.0), tta_flip=True, return_outputs=True)
+        # ... and equals the per-image TTA path + the decoder on the host-side maps
+        for iid in ids[:3]:
+            ori = pre.imread_bgr(os.path.join(img_dir, files[iid]))
+            paf, heatmap, s1 = pre.get_multiscale_outputs(ori, model, 'rtpose', scales=(0.5, 1.0), flip=True)
+            humans = dec.paf_to_pose_cpp(heatmap, paf, cfg)
+            exp = []
+            pre.append_result(iid, humans, (heatmap.shape[0] * 8 / s1, heatmap.shape[1] * 8 / s1), exp, 18)
+            got = [o for o in out_t if o["image_id"] == iid]
+            assert len(got) == len(exp)
+    assert 0.0 <= ap_t <= 1.0

@@ -256,3 +256,99 @@ def test_oks_evaluator_properties(pkg):
     assert tuple(kp[0]) == (0.5 * 600 + 0.5, 0.25 * 400 + 0.5, 1)          # nose -> COCO 0
     assert tuple(kp[4]) == (0.1 * 600 + 0.5, 0.2 * 400 + 0.5, 1)           # our 16 (REar) -> COCO index 4
     assert kp[:, 2].sum() == 2
+
+
+def test_eval_schedule_buckets_and_covers_every_image_once(pkg):
+    """preprocess.eval_batches: images grouped by crop_with_factor's padded size, batches <= B, every image
+    exactly once; the round-robin rank assignment of run_eval_batched covers every batch exactly once."""
+    import importlib
+    import numpy as np
+    pre = importlib.import_module(PKG_NAME + ".preprocess")
+    rng = np.random.default_rng(0)
+    sizes = [(int(rng.integers(200, 640)), int(rng.integers(200, 640))) for _ in range(500)]
+    sched = pre.eval_batches(sizes, 368, 8, 32)
+    seen = sorted(i for _, idx in sched for i in idx)
+    assert seen == list(range(500))
+    for key, idx in sched:
+        assert 1 <= len(idx) <= 32
+        for i in idx:
+            assert pre.prep_geometry(sizes[i][0], sizes[i][1], 368, 8)[2] == key
+    for world in (1, 2, 3, 8):
+        steps = -(-len(sched) // world)
+        taken = sorted(step * world + r for step in range(steps) for r in range(world) if step * world + r < len(sched))
+        assert taken == list(range(len(sched)))
+    # TTA buckets by the source size itself (all scales of a batch must agree)
+    for key, idx in pre.eval_batches(sizes[:50], 368, 8, 4, by_source_size=True):
+        assert all(sizes[i] == key for i in idx)
+    # geometry == crop_with_factor's
+    img = rng.integers(0, 256, (123, 211, 3), dtype=np.uint8)
+    crop, scale, real = pre.crop_with_factor(img, 368, factor=8, is_ceil=True)
+    s, (hr, wr), (hn, wn) = pre.prep_geometry(123, 211, 368, 8)
+    assert (s, (hr, wr), (hn, wn)) == (scale, tuple(real[:2]), crop.shape[:2])
+
+
+def test_native_state_is_per_device_and_invalidates(pkg, monkeypatch):
+    """Plans / weight arenas are keyed by (device, dtype): a forward on a second device neither evicts nor
+    re-packs the first one's (nn.DataParallel replicas share these dicts); load_state_dict, _apply and
+    invalidate_weights() force a re-pack, `.data` edits are caught by invalidate_weights()."""
+    import contextlib
+    import importlib
+    import torch
+    net = importlib.import_module(PKG_NAME + ".network")
+    ns = importlib.import_module(PKG_NAME + "._native_state")
+    packs = []
+
+    class FakePlan(object):
+        def __init__(self, n, h, w, weights, device, dtype=0):
+            self.shape, self.dtype, self.weights = (n, h, w), dtype, weights
+            self.workspace = torch.empty(1 << 20, dtype=torch.float32)
+            self.handle = None
+
+    class Dev(object):
+        def __init__(self, index):
+            self.type, self.index = 'cuda', index
+
+        def __eq__(self, o):
+            return isinstance(o, Dev) and o.index == self.index
+
+        def __hash__(self):
+            return self.index
+    monkeypatch.setattr(net, "_Plan", FakePlan)
+    monkeypatch.setattr(net, "_ShapeOnly", lambda d: type("S", (), {"device": d})())
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    monkeypatch.setattr(net.lib, "rtpose_net_create_ex", lambda *a: 0)
+    monkeypatch.setattr(net.lib, "rtpose_net_weight_bytes", lambda p: 1024)
+    monkeypatch.setattr(net.lib, "rtpose_net_destroy", lambda p: None)
+    real_zeros = torch.zeros
+    monkeypatch.setattr(torch, "zeros", lambda *a, **k: real_zeros(*a, **{kk: v for kk, v in k.items() if kk != "device"}))
+    m = net.get_model('vgg19')
+    monkeypatch.setattr(type(m), "_sync_weights", lambda self, plan, device: (
+        packs.append(device.index) if self._params_key([p for p in self.parameters()]) != self._weights_key.get(
+            (device.index, plan.dtype)) or self.always_resync else None,
+        self._weights_key.__setitem__((device.index, plan.dtype), self._params_key([p for p in self.parameters()]))))
+    d0, d1 = Dev(0), Dev(1)
+    p0 = m.plan_for_shape(2, 64, 64, d0)
+    p1 = m.plan_for_shape(2, 64, 64, d1)
+    assert p0 is not p1 and p0.weights is not p1.weights            # separate arenas
+    assert m.plan_for_shape(2, 64, 64, d0) is p0                     # device 1 evicted nothing of device 0
+    assert packs == [0, 1]                                           # one pack per device, none repeated
+    m.plan_for_shape(2, 64, 64, d0)
+    assert packs == [0, 1]
+    next(m.parameters()).data.fill_(0.5)                             # `.data` edit: invisible to _version ...
+    m.plan_for_shape(2, 64, 64, d0)
+    assert packs == [0, 1]
+    m.invalidate_weights()                                           # ... so the caller says so
+    m.plan_for_shape(2, 64, 64, d0)
+    m.plan_for_shape(2, 64, 64, d1)
+    assert packs == [0, 1, 0, 1]
+    m.load_state_dict(m.state_dict())
+    m.plan_for_shape(2, 64, 64, d0)
+    assert packs[-1] == 0 and len(packs) == 5
+    m.always_resync = True
+    m.plan_for_shape(2, 64, 64, d0)
+    assert len(packs) == 6
+    # byte-bounded plan cache, per device
+    monkeypatch.setattr(ns, "MAX_WORKSPACE_BYTES_PER_DEVICE", 3 * (4 << 20) + 1)
+    for k in range(5):
+        m.plan_for_shape(1, 64 + 8 * k, 64, d1)
+    assert sum(1 for key in m._plans if key[3] == 1) <= 3 and any(key[3] == 0 for key in m._plans)
