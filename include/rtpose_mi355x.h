@@ -147,6 +147,14 @@ typedef struct rtpose_pw_desc {
   rtpose_layout lpt;
   const int32_t* pt_cmap;   /* device int32[pt_c]: pass-through channel i -> absolute output channel  */
   int32_t pt_c;
+  /* pass-through, interleave form (pt_pairs > 0; pt_cmap / pt_c unused): output channel j < 2 pt_pairs is
+   * source channel pt_a + j/2 (j even) or pt_b + j/2 (j odd) of `pt_src`, stored at channel
+   * (j < pt_split ? pt_d0 + j : pt_d1 + j - pt_split): the next unit's x1 when both buffers keep their
+   * channels as four runs [even-low | even-high | odd-low | odd-high] (contiguous loads and stores).     */
+  int32_t pt_pairs, pt_a, pt_b, pt_split, pt_d0, pt_d1;
+  const int32_t* in_planes; /* NULL (the input is the contiguous slice lin.choff .. + cin) or device
+                               int32[cin / 4]: channel offset, relative to lin.choff, of every 4-channel
+                               group of the GEMM's K axis (a 16-byte granular gather: x2 of a unit is two runs) */
 } rtpose_pw_desc;
 size_t rtpose_packed_pw_floats(int cin_packed, int coutp);
 /* w_oi: device [cout][cin_src] (a 1x1 conv's OIHW weights), written to columns

@@ -50,7 +50,8 @@ class PwDesc(C.Structure):
                 ("bias_packed", C.c_void_p), ("out", C.c_void_p), ("lin", Layout), ("lout", Layout),
                 ("cin", C.c_int32), ("cout", C.c_int32), ("coutp", C.c_int32), ("relu", C.c_int32),
                 ("out_cmap", C.c_void_p), ("pt_src", C.c_void_p), ("lpt", Layout), ("pt_cmap", C.c_void_p),
-                ("pt_c", C.c_int32)]
+                ("pt_c", C.c_int32), ("pt_pairs", C.c_int32), ("pt_a", C.c_int32), ("pt_b", C.c_int32),
+                ("pt_split", C.c_int32), ("pt_d0", C.c_int32), ("pt_d1", C.c_int32), ("in_planes", C.c_void_p)]
 
 
 class PrepImage(C.Structure):

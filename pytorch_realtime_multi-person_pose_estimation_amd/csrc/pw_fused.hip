@@ -56,6 +56,10 @@ struct PwArgs {
   PwView pt;                // PT: source of the pass-through channels (same N, H, W)
   const int32_t* pt_cmap;   // PT: [pt_c] source channel i -> absolute output channel
   int pt_c;
+  // PT, interleave form (pt_pairs > 0, pt_cmap unused): output channel j < 2 pt_pairs takes source channel
+  // pt_a + j/2 (j even) or pt_b + j/2 (j odd) and lands at (j < pt_split ? pt_d0 + j : pt_d1 + j - pt_split)
+  int pt_pairs, pt_a, pt_b, pt_split, pt_d0, pt_d1;
+  const int32_t* in_planes;  // optional [K/4]: channel offset (inside the pixel) of every 4-channel plane of K
   int N, H, W, M;
   int K, coutp, cout, relu;
   int nps;  // DW: LDS plane stride (pixels) of the staged halo
@@ -64,6 +68,7 @@ struct PwArgs {
 constexpr int kPwBM = 64;   // pixels per block
 constexpr int kPwQS = 66;   // LDS plane stride of the A tile (pixels): planes 8 banks apart
 constexpr int kPwPL = 8;    // 16-byte channel-group planes per K chunk (32 channels)
+constexpr int kPwMaxK = 1024; // largest K (s_plane table)
 constexpr int kPwMaxStage = 8;  // DW: staged 16-byte pieces per thread per chunk (<= 256 halo pixels)
 
 #define RTPOSE_PW_PIN()          \
@@ -88,6 +93,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
   static_assert(WM * MF * 32 == kPwBM, "block tile is 64 pixels");
   extern __shared__ __attribute__((aligned(16))) float4 smem4[];
   __shared__ int s_qout[2][kPwBM], s_qpt[2][kPwBM];  // per work item (parity): output / pass-through pixel of row r
+  __shared__ int s_plane[kPwMaxK / 4];               // channel offset of every 4-channel plane of K
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
   // which cost ~90 VGPRs and the load/MFMA interleaving.
   float4 sr[DW ? kPwMaxStage : 2];
   auto load_pieces = [&](const Item& it, int c0) {
-    const unsigned cofs = (unsigned)(min(c0 + 4 * pl, A.K - 4));
+    const unsigned cofs = (unsigned)s_plane[min((c0 >> 2) + pl, (A.K >> 2) - 1)];
     if (DW) {
 #pragma unroll
       for (int u = 0; u < kPwMaxStage; ++u)
@@ -171,6 +177,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
 
   int wi = blockIdx.x;
   if (wi >= nwork) return;
+  for (int j = tid; j < (A.K >> 2); j += 256) s_plane[j] = A.in_planes ? A.in_planes[j] : 4 * j;
+  __syncthreads();
   Item cur = setup(wi);
 #pragma unroll
   for (int u = 0; u < (DW ? kPwMaxStage : 2); ++u) sr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -341,8 +349,52 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
       }
     }
 
-    // ---- pass-through half: x1 -> even slots (cat + channel_shuffle folded into the store) ------
-    if (A.pt.base && cur.pass == 0) {
+    // ---- pass-through half, interleave form: the next unit's x1 = this buffer's logical channels [0, h)
+    //      = (even run, odd run) interleaved, written as contiguous runs: 16-byte loads, 8-byte stores,
+    //      every line written once (the scatter form below wrote every line of the buffer twice) ------
+    if (A.pt.base && A.pt_pairs > 0 && cur.pass == 0) {
+      const int g4 = (A.pt_pairs + 3) >> 2;
+      const int nit = kPwBM * g4;
+      const bool vec2 = !(A.pt_split & 1) && !((A.pt_d1 - A.pt_split) & 1) && !(A.pt_d0 & 1);
+      for (int it0 = tid; it0 < nit; it0 += 512) {
+        float4 va[2], vb[2];
+        int qo[2], k0[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int it = min(it0 + 256 * u, nit - 1);
+          const int p = it / g4;
+          k0[u] = 4 * (it - p * g4);
+          qo[u] = it0 + 256 * u < nit ? s_qout[par][p] : -1;
+          const unsigned so = (unsigned)s_qpt[par][p] * (unsigned)A.pt.cstride + (unsigned)(A.pt.choff + k0[u]);
+          va[u] = pw_gload4(A.pt.base + (so + (unsigned)A.pt_a));
+          vb[u] = pw_gload4(A.pt.base + (so + (unsigned)A.pt_b));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (qo[u] < 0) continue;
+          const float a4[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, b4[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+          const unsigned o = (unsigned)qo[u] * (unsigned)A.out_cstride;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int k = k0[u] + e;  // pair index: outputs j = 2k, 2k + 1
+            if (k >= A.pt_pairs) continue;
+            const int j = 2 * k;
+            if (vec2) {
+              const int dj = j < A.pt_split ? A.pt_d0 + j : A.pt_d1 + j - A.pt_split;
+              *reinterpret_cast<float2*>(A.out + (o + (unsigned)dj)) = make_float2(a4[e], b4[e]);
+            } else {
+              const int da = j < A.pt_split ? A.pt_d0 + j : A.pt_d1 + j - A.pt_split;
+              const int db = j + 1 < A.pt_split ? A.pt_d0 + j + 1 : A.pt_d1 + j + 1 - A.pt_split;
+              A.out[o + (unsigned)da] = a4[e];
+              A.out[o + (unsigned)db] = b4[e];
+            }
+          }
+        }
+      }
+    }
+
+    // ---- pass-through half, scatter form: x1 -> pt_cmap slots (cat + channel_shuffle folded into the store) ------
+    if (A.pt.base && A.pt_pairs == 0 && cur.pass == 0) {
       const int g4 = (A.pt_c + 3) >> 2;
       const int nit = kPwBM * g4;
       constexpr int PB = 4;  // loads in flight per thread (a load -> 4 stores chain per item exposed a full
@@ -433,13 +485,17 @@ int pw_fused_launch(const rtpose_pw_desc* d, int N, int H, int W, hipStream_t s)
   if (d->cin <= 0 || (d->cin % 8)) return fail(RTPOSE_E_INVAL, "pw_fused: cin must be a multiple of 8");
   if (d->coutp != 64 && d->coutp != 128 && (d->coutp % 256)) return fail(RTPOSE_E_INVAL, "pw_fused: coutp must be 64, 128 or a multiple of 256");
   if (d->cout <= 0 || d->cout > d->coutp) return fail(RTPOSE_E_INVAL, "pw_fused: cout exceeds coutp");
-  if ((d->lin.cstride % 4) || (d->lin.choff % 4) || d->lin.choff + d->cin > d->lin.cstride)
+  if ((d->lin.cstride % 4) || (d->lin.choff % 4) || (!d->in_planes && d->lin.choff + d->cin > d->lin.cstride))
     return fail(RTPOSE_E_INVAL, "pw_fused: input slice must be 16-byte aligned and inside the pixel");
   const bool dw = d->dw_w != nullptr;
   if (dw && (!d->dw_b || d->lin.ws < W + 1 || d->lin.hs < H + 1 || d->lin.lead < d->lin.ws + 1))
     return fail(RTPOSE_E_INVAL, "pw_fused: the depthwise input needs a layout gap of 1 and a bias");
-  if (d->pt_src && (!d->pt_cmap || d->pt_c <= 0 || (d->lpt.cstride % 4) || (d->lpt.choff % 4)))
+  if (d->pt_src && d->pt_pairs == 0 && (!d->pt_cmap || d->pt_c <= 0 || (d->lpt.cstride % 4) || (d->lpt.choff % 4)))
     return fail(RTPOSE_E_INVAL, "pw_fused: bad pass-through description");
+  if (d->pt_src && d->pt_pairs > 0 &&
+      ((d->lpt.cstride % 4) || ((d->lpt.choff + d->pt_a) % 4) || ((d->lpt.choff + d->pt_b) % 4) || d->pt_pairs < 0))
+    return fail(RTPOSE_E_INVAL, "pw_fused: interleave pass-through runs must be 16-byte aligned");
+  if (d->cin > kPwMaxK) return fail(RTPOSE_E_INVAL, "pw_fused: cin > 1024");
   if (rtpose_layout_pixels(&d->lin, N, H, W) * (size_t)d->lin.cstride >= ((size_t)1 << 31) ||
       rtpose_layout_pixels(&d->lout, N, H, W) * (size_t)d->lout.cstride >= ((size_t)1 << 31))
     return fail(RTPOSE_E_INVAL, "pw_fused: tensors must be below 2^31 floats (32-bit element offsets)");
@@ -461,7 +517,14 @@ int pw_fused_launch(const rtpose_pw_desc* d, int N, int H, int W, hipStream_t s)
     a.pt = PwView{d->pt_src, d->lpt.cstride, d->lpt.choff, d->lpt.ws, d->lpt.hs, d->lpt.lead};
     a.pt_cmap = d->pt_cmap;
     a.pt_c = d->pt_c;
+    a.pt_pairs = d->pt_pairs;
+    a.pt_a = d->pt_a;
+    a.pt_b = d->pt_b;
+    a.pt_split = d->pt_split;
+    a.pt_d0 = d->pt_d0;
+    a.pt_d1 = d->pt_d1;
   }
+  a.in_planes = d->in_planes;
   a.N = N;
   a.H = H;
   a.W = W;

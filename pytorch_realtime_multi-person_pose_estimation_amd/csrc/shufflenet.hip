@@ -107,6 +107,8 @@ struct SOp {
   // O_PWF (pw_fused.hip): layer[0] = the pointwise layer, dw_layer = the depthwise 3x3 evaluated in front
   // of it inside the kernel (-1: none), pt_buf / pt_map = pass-through half copied by the same launch
   int dw_layer = -1, pt_buf = -1, pt_map = -1, pt_c = 0, cout_store = 0;
+  int planes_map = -1;          // input plane gather table (map id), -1: contiguous slice
+  int pt_pairs = 0, pt_a = 0, pt_b = 0, pt_split = 0, pt_d0 = 0, pt_d1 = 0;  // interleave pass-through
 };
 
 struct Map {
@@ -191,8 +193,19 @@ int add_layer(rtpose_shufflenet* n, LKind kind, const std::string& name, int cou
 }
 
 
-// logical -> physical channel of a stage buffer with halves of h channels padded to hp
-int fphys(int j, int h, int hp) { return j < h ? j : hp + (j - h); }
+// logical -> physical channel of a stage buffer (logical = the order after torch.cat + channel_shuffle(2)).
+//  * unfused (bf16) plans: two halves of h channels padded to hp: [0, h) | pad | [h, 2h) | pad - the
+//    next unit's x2 is the contiguous slice at hp; the shuffle is a strided scatter on the store side.
+//  * fused (fp32) plans: four runs of h/2 channels padded to q = hp / 2:
+//        [even-low | even-high | odd-low | odd-high],  logical 2i -> even, 2i+1 -> odd, i < h/2 -> low.
+//    Producers write CONTIGUOUS runs (the pass-through half = the evens, the GEMM = the odds), and the
+//    next unit reads x1 = (even-low, odd-low) interleaved, x2 = even-high + odd-high as two runs through
+//    the kernel's 16-byte plane gather: no strided 4-byte stores, every line written once.
+int fphys(int j, int h, int hp, bool quarter = false) {
+  if (!quarter) return j < h ? j : hp + (j - h);
+  const int q = hp / 2, hh = h / 2, i = j >> 1;
+  return (2 * (j & 1) + (i >= hh ? 1 : 0)) * q + (i >= hh ? i - hh : i);
+}
 
 void add_pw(rtpose_shufflenet* n, const std::string& name, int H, int W, int layer, int in_buf, int in_choff,
             int out_buf, int out_choff, int cmap, int relu) {
@@ -320,7 +333,9 @@ void build(rtpose_shufflenet* n) {
   for (int si = 0; si < 3; ++si) {
     // bf16 plans: halves padded to 64 channels (58 -> 64, 116 -> 128, 232 -> 256) so that every
     // pointwise conv runs with 64-channel LDS chunks (232 padded to 240 would fall back to 16)
-    const int C = widths[si], h = C / 2, hp = n->bf16 ? (h + 63) / 64 * 64 : up8(h);
+    const bool qt = n->fused != 0;  // four-run channel layout (see fphys)
+    const int C = widths[si], h = C / 2,
+              hp = n->bf16 ? (h + 63) / 64 * 64 : (qt ? 2 * ((h / 2 + 3) / 4 * 4) : up8(h));
     const int stride = si == 0 ? 2 : 1;
     const int Ho = si == 0 ? H3 : Hc, Wo = si == 0 ? W3 : Wc;
     const std::string sp = "network." + std::to_string(3 + si) + ".";
@@ -328,10 +343,24 @@ void build(rtpose_shufflenet* n) {
     const int SA = add_buf(n, 2 * hp, 1, Ho, Wo), SB = add_buf(n, 2 * hp, 1, Ho, Wo);
     std::vector<int32_t> even(h), odd(h);
     for (int i = 0; i < h; ++i) {
-      even[i] = fphys(2 * i, h, hp);
-      odd[i] = fphys(2 * i + 1, h, hp);
+      even[i] = fphys(2 * i, h, hp, qt);
+      odd[i] = fphys(2 * i + 1, h, hp, qt);
     }
     const int M_even = add_map(n, even), M_odd = add_map(n, odd);
+    // fused plans: x2 of a unit = logical [h, 2h) = the even-high run then the odd-high run.  Packed K position
+    // k reads x2 channel M_x2[k] (weights are permuted at pack time), plane j of K sits at channel M_pl[j].
+    int M_x2 = -1, M_pl = -1;
+    if (qt) {
+      const int q = hp / 2, hh = h / 2;
+      std::vector<int32_t> x2(hp, -1), pln(hp / 4);
+      for (int k = 0; k < hp; ++k) {
+        const int p = k < q ? k : k - q;
+        if (p < hh) x2[k] = 2 * p + (k < q ? 0 : 1);  // logical (h + 2p [+1]) - h
+      }
+      for (int j = 0; j < hp / 4; ++j) pln[j] = 4 * j < q ? q + 4 * j : 3 * q + (4 * j - q);
+      M_x2 = add_map(n, x2);
+      M_pl = add_map(n, pln);
+    }
     // temporaries
     const int in_phys = in_is_stage ? 2 * in_hp : in_c;
     const int T0 = add_buf(n, up8(in_phys), 0, Ho, Wo);  // conv0 branch after dw
@@ -345,7 +374,7 @@ void build(rtpose_shufflenet* n) {
       int M_in = -1, M_inphys = -1;
       if (in_is_stage) {  // input buffer holds [h' | pad | h' | pad]
         std::vector<int32_t> m(in_phys, -1);
-        for (int j = 0; j < in_c; ++j) m[fphys(j, in_h, in_hp)] = j;
+        for (int j = 0; j < in_c; ++j) m[fphys(j, in_h, in_hp, qt)] = j;
         M_in = add_map(n, m);
         M_inphys = M_in;
       }
@@ -381,13 +410,36 @@ void build(rtpose_shufflenet* n) {
     // -- blocks 1..: pass-through half + processed half (reference :31-39, :56-59) --
     for (int b = 1; b < nblocks[si]; ++b) {
       const std::string bp = sp + std::to_string(b) + ".";
-      const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, h, hp, -1);
+      const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, h, hp, qt ? M_x2 : -1);
       const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, hp, -1);
       const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, hp, -1);
       if (n->fused && dw_fusable(n, T1, Ho, Wo)) {
-        // two launches per unit: conv.0, then conv.1 (in LDS) -> conv.2 -> odd slots + x1 -> even slots
-        add_pwf(n, bp + "conv.0", Ho, Wo, l_c0, -1, cur, hp, T1, 0, -1, 1);
-        add_pwf(n, bp + "conv.1+conv.2+x1", Ho, Wo, l_c2, l_c1, T1, 0, nxt, 0, M_odd, 1, cur, M_even, h);
+        // two launches per unit: conv.0 (x2 gathered as two runs), then conv.1 (in LDS) -> conv.2 -> the odd
+        // runs + the next x1 = (even-low, odd-low) interleaved -> the even runs
+        add_pwf(n, bp + "conv.0", Ho, Wo, l_c0, -1, cur, 0, T1, 0, -1, 1);
+        n->ops.back().planes_map = M_pl;
+        add_pwf(n, bp + "conv.1+conv.2+x1", Ho, Wo, l_c2, l_c1, T1, 0, nxt, 0, M_odd, 1, cur, -1, 0);
+        SOp& o = n->ops.back();
+        o.pt_pairs = h / 2;
+        o.pt_a = 0;
+        o.pt_b = hp;          // odd-low run = run 2 at 2 q
+        o.pt_split = h / 2;
+        o.pt_d0 = 0;
+        o.pt_d1 = hp / 2;     // even-high run at q
+      } else if (n->fused) {
+        // map too wide for the in-kernel depthwise halo: the depthwise conv runs as its own launch, the
+        // pointwise launches (plane gather, interleaved pass-through) stay the same
+        add_pwf(n, bp + "conv.0", Ho, Wo, l_c0, -1, cur, 0, T1, 0, -1, 1);
+        n->ops.back().planes_map = M_pl;
+        add_dw(n, bp + "conv.1", Ho, Wo, l_c1, T1, T2, 1);
+        add_pwf(n, bp + "conv.2+x1", Ho, Wo, l_c2, -1, T2, 0, nxt, 0, M_odd, 1, cur, -1, 0);
+        SOp& o = n->ops.back();
+        o.pt_pairs = h / 2;
+        o.pt_a = 0;
+        o.pt_b = hp;
+        o.pt_split = h / 2;
+        o.pt_d0 = 0;
+        o.pt_d1 = hp / 2;
       } else {
         SOp c;
         c.kind = O_COPYMAP;
@@ -399,15 +451,9 @@ void build(rtpose_shufflenet* n) {
         c.cmap[0] = M_even;
         c.C = h;
         n->ops.push_back(c);
-        if (n->fused) {
-          add_pwf(n, bp + "conv.0", Ho, Wo, l_c0, -1, cur, hp, T1, 0, -1, 1);
-          add_dw(n, bp + "conv.1", Ho, Wo, l_c1, T1, T2, 1);
-          add_pwf(n, bp + "conv.2", Ho, Wo, l_c2, -1, T2, 0, nxt, 0, M_odd, 1);
-        } else {
-          add_pw(n, bp + "conv.0", Ho, Wo, l_c0, cur, hp, T1, 0, -1, 1);
-          add_dw(n, bp + "conv.1", Ho, Wo, l_c1, T1, T2, 1);
-          add_pw(n, bp + "conv.2", Ho, Wo, l_c2, T2, 0, nxt, 0, M_odd, 1);
-        }
+        add_pw(n, bp + "conv.0", Ho, Wo, l_c0, cur, hp, T1, 0, -1, 1);
+        add_dw(n, bp + "conv.1", Ho, Wo, l_c1, T1, T2, 1);
+        add_pw(n, bp + "conv.2", Ho, Wo, l_c2, T2, 0, nxt, 0, M_odd, 1);
       }
       std::swap(cur, nxt);
     }
@@ -423,7 +469,7 @@ void build(rtpose_shufflenet* n) {
   // ---- conv5 + heads -------------------------------------------------------------------
   {
     std::vector<int32_t> m(2 * in_hp, -1);
-    for (int j = 0; j < in_c; ++j) m[fphys(j, in_h, in_hp)] = j;
+    for (int j = 0; j < in_c; ++j) m[fphys(j, in_h, in_hp, n->fused != 0)] = j;
     const int M_in = add_map(n, m);
     const int l5 = add_layer(n, L_PW, "network.6", 1024, in_c, up8(2 * in_hp), M_in);
     const int lp = add_layer(n, L_PW, "paf", 38, 1024, 1024, -1);
@@ -678,12 +724,19 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
         d.coutp = l.coutp ? l.coutp : cout_pad(l.cout);
         d.relu = o.relu;
         d.out_cmap = imap(o.cmap[0]);
+        d.in_planes = imap(o.planes_map);
         if (o.pt_buf >= 0) {
           const SBuf& bp = n->bufs[o.pt_buf];
           d.pt_src = n->ws + bp.off;
           d.lpt = slice(bp, 0);
           d.pt_cmap = imap(o.pt_map);
           d.pt_c = o.pt_c;
+          d.pt_pairs = o.pt_pairs;
+          d.pt_a = o.pt_a;
+          d.pt_b = o.pt_b;
+          d.pt_split = o.pt_split;
+          d.pt_d0 = o.pt_d0;
+          d.pt_d1 = o.pt_d1;
         }
         rc = pw_fused_launch(&d, n->N, o.H, o.W, s);
         break;

@@ -112,6 +112,93 @@ def test_unit_with_pass_through_and_shuffle(capi, cuda, c):
     _run(capi, cuda, 4, 46, 46, c, c, (c + 63) // 64 * 64, dw=True, relu=True, pt_c=c, seed=c + 1)
 
 
+@pytest.mark.parametrize("h,w_map", [(58, 46), (116, 46), (232, 46), (116, 70)])
+def test_unit_in_the_four_run_layout(capi, cuda, h, w_map):
+    """One ShuffleNetV2 unit (rtpose_shufflenetV2.py:31-39, :56-62) the way the fused fp32 plan runs it: the
+    stage buffer keeps its 2h logical channels as four runs [even-low | even-high | odd-low | odd-high];
+    launch 1 = conv.0 on x2 gathered as two runs (in_planes), launch 2 = conv.1 (depthwise, in LDS) -> conv.2 ->
+    the odd runs + the next x1 = (even-low, odd-low) interleaved -> the even runs.  Checked against
+    torch: chunk -> conv/bn-folded convs -> cat -> channel_shuffle(2)."""
+    g = torch.Generator().manual_seed(h)
+    n, hh_, q = 2, h // 2, (h // 2 + 3) // 4 * 4
+    H = 9
+    C4 = 4 * q
+    x = torch.randn(n, 2 * h, H, w_map, generator=g)                      # logical channel order
+    w0 = torch.randn(h, h, generator=g) / h ** 0.5
+    b0 = torch.randn(h, generator=g) * 0.1
+    wd = torch.randn(h, 1, 3, 3, generator=g) * 0.3
+    bd = torch.randn(h, generator=g) * 0.1
+    w2 = torch.randn(h, h, generator=g) / h ** 0.5
+    b2 = torch.randn(h, generator=g) * 0.1
+    x1, x2 = x[:, :h], x[:, h:]
+    y = F.relu(F.conv2d(F.conv2d(F.relu(F.conv2d(x2, w0[:, :, None, None], b0)), wd, bd, padding=1, groups=h),
+                        w2[:, :, None, None], b2))
+    ref = torch.stack([x1, y], 2).reshape(n, 2 * h, H, w_map)            # cat + channel_shuffle(2)
+
+    def phys(j):
+        i = j >> 1
+        return (2 * (j & 1) + (1 if i >= hh_ else 0)) * q + (i - hh_ if i >= hh_ else i)
+    perm = torch.tensor([phys(j) for j in range(2 * h)])
+    xp = torch.zeros(n, C4, H, w_map)
+    xp[:, perm] = x
+    lay = capi.Layout.padded(C4, H, w_map, 1)
+    cur = _to_layout(capi, xp, lay, C4, cuda)
+    nxt = torch.zeros_like(cur)
+    K = 2 * q
+    lt1 = capi.Layout.padded(K, H, w_map, 1)
+    t1 = torch.zeros(capi.lib.rtpose_layout_pixels(C.byref(lt1), n, H, w_map) * K, device=cuda)
+    coutp = (h + 63) // 64 * 64
+    # conv.0: packed K position k reads x2 channel x2map[k]; plane j sits at channel pln[j]
+    x2map = torch.full((K,), -1, dtype=torch.int32)
+    for k in range(K):
+        p = k if k < q else k - q
+        if p < hh_:
+            x2map[k] = 2 * p + (0 if k < q else 1)
+    pln = torch.tensor([q + 4 * j if 4 * j < q else 3 * q + (4 * j - q) for j in range(K // 4)], dtype=torch.int32)
+    keep = []
+
+    def pack(wt, b, cmap):
+        wpk = torch.zeros(capi.lib.rtpose_packed_pw_floats(K, coutp) + 64 * coutp, device=cuda)
+        bpk = torch.zeros(coutp, device=cuda)
+        wt_d, b_d = wt.contiguous().to(cuda), b.to(cuda)
+        cm = cmap.to(cuda) if cmap is not None else None
+        capi.check(capi.lib.rtpose_pack_pw_weights(capi.ptr(wt_d), capi.ptr(b_d), h, h, capi.ptr(cm) if cm is not None else None,
+                                                   K, coutp, 0, capi.ptr(wpk), capi.ptr(bpk), capi.current_stream()))
+        keep.extend([wpk, bpk, wt_d, b_d, cm])
+        return wpk, bpk
+    wp0, bp0 = pack(w0, b0, x2map)
+    wp2, bp2 = pack(w2, b2, None)
+    pln_d = pln.to(cuda)
+    d = capi.PwDesc()
+    d.inp, d.w_packed, d.bias_packed, d.out = cur.data_ptr(), wp0.data_ptr(), bp0.data_ptr(), t1.data_ptr()
+    d.lin, d.lout, d.cin, d.cout, d.coutp, d.relu = lay, lt1, K, h, coutp, 1
+    d.in_planes = pln_d.data_ptr()
+    capi.check(capi.lib.rtpose_pw_fused(C.byref(d), n, H, w_map, capi.current_stream()), "conv.0")
+    wdp = torch.zeros(9, K)
+    wdp[:, :h] = wd.reshape(h, 9).t()
+    bdp = torch.zeros(K)
+    bdp[:h] = bd
+    wdp_d, bdp_d = wdp.to(cuda), bdp.to(cuda)
+    odd = torch.tensor([phys(2 * i + 1) for i in range(h)], dtype=torch.int32).to(cuda)
+    d2 = capi.PwDesc()
+    d2.inp, d2.w_packed, d2.bias_packed, d2.out = t1.data_ptr(), wp2.data_ptr(), bp2.data_ptr(), nxt.data_ptr()
+    d2.dw_w, d2.dw_b = wdp_d.data_ptr(), bdp_d.data_ptr()
+    d2.lin, d2.lout, d2.cin, d2.cout, d2.coutp, d2.relu = lt1, lay, K, h, coutp, 1
+    d2.out_cmap = odd.data_ptr()
+    d2.pt_src, d2.lpt = cur.data_ptr(), lay
+    d2.pt_pairs, d2.pt_a, d2.pt_b, d2.pt_split, d2.pt_d0, d2.pt_d1 = hh_, 0, 2 * q, hh_, 0, q
+    if w_map > 60:      # too wide for the in-kernel depthwise halo: must be refused, not mis-computed
+        assert capi.lib.rtpose_pw_fused(C.byref(d2), n, H, w_map, capi.current_stream()) != 0
+        return
+    capi.check(capi.lib.rtpose_pw_fused(C.byref(d2), n, H, w_map, capi.current_stream()), "conv.1+conv.2+x1")
+    got = _from_layout(capi, nxt, lay, C4, n, H, w_map, cuda)[:, perm]
+    scale = max(1.0, ref.abs().max().item())
+    assert (got[:, 0::2] - ref[:, 0::2]).abs().max().item() == 0.0          # the pass-through half is a copy
+    assert (got - ref).abs().max().item() <= TOL * scale
+    total, inside = nxt.abs().sum().item(), got.abs().sum().item()
+    assert abs(total - inside) <= 1e-3 * max(1.0, inside), "kernel wrote outside the real channels / pixels"
+
+
 def test_bad_arguments_fail_loudly(capi, cuda):
     d = capi.PwDesc()
     assert capi.lib.rtpose_pw_fused(C.byref(d), 1, 8, 8, None) != 0

@@ -1,14 +1,18 @@
-"""BASELINE config 5 (developer tool; bench.py keeps the weak-scaling contract): a fixed set of
-5000 synthetic 368x368 images (COCO val2017 is not available offline) sharded contiguously
-across the ranks (parallel.shard_range), processed in batches of 32 per rank, ONE RCCL
-all_gather of the result records per batch.  STRONG scaling: total work is fixed.
+"""BASELINE configs[4] (developer tool; bench.py keeps the weak-scaling contract): the evaluation flow of
+evaluate/coco_eval.py:245-283 over a 5000-entry image index (COCO val2017 is not available offline, so
+the entries are synthetic 368x368 uint8 BGR images), sharded contiguously across the ranks
+(parallel.shard_range), in batches of 32 per rank, ONE RCCL all_gather of the result records per batch.
+STRONG scaling: total work is fixed.
 
   python tools/bench_config5.py                      # 1 GPU
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
          --master-port 29511 tools/bench_config5.py
 
-Images are regenerated per batch from the image index (seeded), so every rank sees exactly the
-shard it owns whatever the world size; rank 0 prints one JSON line."""
+Every index entry is a distinct image: entry i's pixels are a hash of (i, pixel) evaluated on the device
+(generating 5000 images with numpy would time numpy), so every rank sees exactly the shard it owns
+whatever the world size.  Per batch, like preprocess.run_eval_batched: uint8 images -> ONE
+rtpose_preprocess_u8_batch launch (resize / pad / normalise into the plan's input) -> forward ->
+scene blend (random weights give junk maps, see bench.py) -> decode -> gather.  Rank 0 prints one JSON line."""
 import argparse
 import importlib
 import json
@@ -24,6 +28,14 @@ sys.path.insert(0, ROOT)
 PKG = "pytorch_realtime_multi-person_pose_estimation_amd"
 
 
+def synth_images(index, hw, dev):
+    """uint8 [len(index), hw, hw, 3]: entry i = low bits of a multiplicative hash of (i, pixel), on the device."""
+    p = torch.arange(hw * hw * 3, device=dev, dtype=torch.int64)[None, :]
+    i = torch.as_tensor(index, device=dev, dtype=torch.int64)[:, None]
+    v = ((p * 2654435761 + (i + 1) * 40503 * 65537) >> 11) & 255
+    return v.to(torch.uint8).reshape(len(index), hw, hw, 3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=5000)
@@ -34,7 +46,10 @@ def main():
     par = importlib.import_module(PKG + ".parallel")
     synth = importlib.import_module(PKG + ".synth")
     dec = importlib.import_module(PKG + ".decode")
-    pipeline = importlib.import_module(PKG + ".pipeline")
+    pre = importlib.import_module(PKG + ".preprocess")
+    capi = pkg._capi
+    lib = capi.lib
+    import ctypes as C
     rank, local_rank, world = par.init_from_env("nccl")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -42,45 +57,59 @@ def main():
     model.load_state_dict(synth.he_init_state_dict(model, seed=0))
     model = model.cuda().float().eval()
     model.set_compute_dtype(args.dtype)
-    est = pipeline.PoseEstimator(model)
-    lo, hi = par.shard_range(args.images, rank, world)
-    B = args.batch
-    # a small pool of distinct device batches, cycled (generating 5000 scenes on the host would
-    # time numpy, not the path); the image index -> pool slot mapping is rank independent
+    B, HW = args.batch, 368
+    index = list(range(args.images))                       # the evaluation set: 5000 entries
+    sched = par.batch_schedule(len(index), rank, world, B)   # every rank runs the same number of collectives
+    # scenes blended over the net output (decoder input = scene + 1e-3 * maps): a pool of 16 batches, entry i
+    # uses scene (i % pool size) - rank independent
     pool = []
-    for s in range(4):
-        g = torch.Generator().manual_seed(1000 + s)
-        x = (torch.rand(B, 3, 368, 368, generator=g) - 0.5).to(dev)
-        heat, paf, _ = synth.make_batch(B, 368, 368, seed=2000 + s)
-        pool.append((x, (torch.from_numpy(heat).to(dev), torch.from_numpy(paf).to(dev))))
-    est(pool[0][0], pool[0][1])       # capacity growth + plan/weights warm-up (untimed)
-    sched = par.batch_schedule(args.images, rank, world, B)   # every rank runs the same number of collectives
-    nb_max = len(sched)
-    humans = 0
+    for s in range(16):
+        heat, paf, _ = synth.make_batch(B, HW, HW, seed=2000 + s)
+        pool.append((torch.from_numpy(heat).to(dev), torch.from_numpy(paf).to(dev)))
+    plan = model.plan_for_shape(B, HW, HW, dev)
+    cfg = dec.make_cfg(None, 64, 64)
+    bufs = dec.DecodeBuffers(cfg, B, dev)
+    stream = capi.current_stream()
+
+    def run_batch(i0, n_valid):
+        idx = [index[min(i0 + k, len(index) - 1)] for k in range(B)] if n_valid else [index[0]] * B
+        imgs = synth_images(idx, HW, dev)
+        pre.preprocess_into_plan(plan, [imgs.data_ptr() + k * HW * HW * 3 for k in range(B)], [(HW, HW)] * B, HW, 0, stream)
+        capi.check(lib.rtpose_net_set_keep_intermediates(plan.handle, 0))
+        capi.check(lib.rtpose_net_forward_prepared(plan.handle, stream), "rtpose_net_forward_prepared")
+        pbase, lpaf, _, h, w = model.output_view(plan, 0)
+        hbase, lheat, _, _, _ = model.output_view(plan, 1)
+        sh, sp = pool[(i0 // B) % len(pool)]
+        capi.check(lib.rtpose_layout_axpby(hbase, C.byref(lheat), capi.ptr(sh), 19, B, h, w, 1e-3, 1.0, stream))
+        capi.check(lib.rtpose_layout_axpby(pbase, C.byref(lpaf), capi.ptr(sp), 38, B, h, w, 1e-3, 1.0, stream))
+        dec.decode_enqueue(hbase, lheat, pbase, lpaf, B, h, w, bufs)
+        rec = bufs.result.view(B, bufs.words)
+        host = par.gather_records(rec, world).cpu() if world > 1 else dec.fetch(bufs)
+        return np.asarray(host).reshape(-1, bufs.words), imgs
+
+    run_batch(0, B)                     # plan / weights / RCCL warm-up (untimed)
+    humans = flags = 0
     torch.cuda.synchronize()
     par.barrier(dev)
     t0 = time.perf_counter()
-    for b in range(nb_max):
-        i0, n_valid = sched[b]
-        x, scene = pool[((i0 // B) if n_valid else 0) % len(pool)]
-        bufs = est.enqueue(x, scene)
-        rec = bufs.result.view(bufs.n, bufs.words)
-        if world > 1:
-            host = par.gather_records(rec, world).cpu()
-        else:
-            host = dec.fetch(bufs)
+    for i0, n_valid in sched:
+        host, _ = run_batch(i0, n_valid)
         if rank == 0:
-            humans += int(np.asarray(host).reshape(-1, bufs.words)[:, dec.RES_HEADER + 1].sum())
+            humans += int(host[:, dec.RES_HEADER + 1].sum())
+            flags |= int(np.bitwise_or.reduce(host[:, dec.RES_HEADER + 2]))
     torch.cuda.synchronize()
     par.barrier(dev)
     elapsed = par.max_over_ranks(time.perf_counter() - t0, dev)
     if rank == 0:
         print(json.dumps({"metric": "config 5: fixed 5000-image set, images/s (strong scaling)",
                           "value": round(args.images / elapsed, 2), "unit": "images/s", "n_gpus": world,
-                          "images": args.images, "batch_per_rank": B, "batches_per_rank": nb_max,
+                          "images": args.images, "batch_per_rank": B, "batches_per_rank": len(sched),
                           "seconds": round(elapsed, 3), "dtype": args.dtype, "scaling": "strong",
+                          "index": "%d distinct synthetic uint8 images (device hash of (entry, pixel)), contiguous "
+                                   "shards; image prep by one rtpose_preprocess_u8_batch launch per batch" % args.images,
                           "note": "the last batch of a shard is padded to the batch size (the padded images are "
-                                  "computed and gathered, not counted)", "humans_seen_rank0_gather": humans}))
+                                  "computed and gathered, not counted)", "humans_seen_rank0_gather": humans,
+                          "overflow_flags": flags}))
     if world > 1:
         torch.distributed.destroy_process_group()
 
