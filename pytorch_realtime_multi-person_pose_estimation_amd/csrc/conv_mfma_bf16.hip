@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "conv_exp.h"
@@ -88,15 +89,11 @@ struct ConvArgs {
   int tw_log2;  // MODE 1: log2(tile width); tile height = 128 >> tw_log2
   int tiles_x, tiles_y;
   int mtiles, ntiles, nbig, ncombo, xcd_remap;
+  int npersist;  // strip mode: blocks [0, npersist) walk the full-tile ids L, L + npersist, ... < nbig; blocks
+                 // past them are the half tiles of the tail.  == nbig: one tile per block (not persistent)
   int dephase_cycles, n_cu;  // second-slot blocks of the first dispatch wave start this much later
   unsigned long long* dbg;  // RTPOSE_EXP_TIMELINE builds only: 8 x u64 per block
 };
-#ifdef RTPOSE_EXP_TIMELINE
-#define RTPOSE_TSTAMP(slot)                                                              \
-  if (A.dbg && threadIdx.x == 0) A.dbg[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime()
-#else
-#define RTPOSE_TSTAMP(slot)
-#endif
 
 constexpr int kBM = 128;
 // depth of the halo staging ring (taps between fetch and park).  The counter behind s_waitcnt
@@ -129,9 +126,14 @@ __device__ __forceinline__ void tile_local_yx(int ml, int tw_log2, int& ty, int&
 // [hi x 8 channels | lo x 8 channels]; a K-step issues hi*lo + lo*hi + hi*hi (the lo*lo term,
 // 2^-18 relative, is dropped) - fp32-grade results from the bf16 pipe at 3/16 of the fp32
 // MFMA time.
+// PERSISTENT form (bi_stride > 0; strip mode, NBUF 2 only): the block walks the full-tile ids bi,
+// bi + bi_stride, ... < A.nbig.  During the LAST chunk of a tile the staging ring fetches chunk 0 of the
+// NEXT tile's halo into the idle LDS buffer instead of re-staging itself, so the next tile starts
+// its tap loop at once: the ~11k-cycle prologue (one exposed memory round trip per block) is paid
+// once per block instead of once per tile, and the epilogue's stores drain under the next tile's MFMAs.
 template <int KS, int CK, int MODE, int NBUF, int WM, int MF, int NF, int SP>
-__device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g, const int m0_arg,
-                                          const int ntile, float* smem) {
+__device__ __forceinline__ void conv_tile(const ConvArgs& A, const int grp_first, const int m0_first,
+                                          const int ntile_first, float* smem, int bi = 0, const int bi_stride = 0) {
   constexpr int P = KS / 2;
   constexpr int BMT = 32 * MF * WM;
   constexpr int BN = 32 * NF * (4 / WM);  // output channels per block
@@ -150,6 +152,34 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   const int wm = wave % WM, wn = wave / WM;
   const int l31 = lane & 31, kh = lane >> 5;
   const int QS = A.qs;
+  const bool persist = MODE == 0 && NBUF == 2 && bi_stride > 0;
+  // (the group is carried as an index and its descriptor copied by value per tile: a pointer into the
+  //  kernel argument that changes inside the loop made the compiler spill the whole ConvArgs to scratch)
+  int grp = grp_first;
+  int m0_arg = m0_first, ntile = ntile_first;
+  int lpar = 0;  // LDS buffer holding chunk 0 of the current tile
+  // the next full tile of this block (persistent form), found while the current one is set up
+  bool has_next = false;
+  int nx_bi = bi, nx_m0 = 0, nx_nt = 0, nx_q_origin = 0, nx_np_total = 0, nx_grp = grp_first;
+  // strip-mode staging geometry of a tile: first halo pixel, 16-byte pieces of one chunk's halo
+  auto strip_geom = [&](const ConvGroup& gg, int m0s, int& q_org, int& np_tot) {
+    const int HW = A.H * A.W;
+    const int n = m0s / HW, r = m0s - n * HW;
+    const int y = r / A.W, x = r - y * A.W;
+    const int qf = gg.in_lead + (n * gg.in_hs + y) * gg.in_ws + x;
+    const int ml = min(m0s + 32 * MF * WM, A.M) - 1;
+    const int n2 = ml / HW, r2 = ml - n2 * HW;
+    const int y2 = r2 / A.W, x2 = r2 - y2 * A.W;
+    const int ql = gg.in_lead + (n2 * gg.in_hs + y2) * gg.in_ws + x2;
+    q_org = qf - (KS / 2) * gg.in_ws - (KS / 2);
+    np_tot = (ql + (KS / 2) * gg.in_ws + (KS / 2) - q_org + 1) * (CK / 8 * SP);
+  };
+  // One tile.  Instantiated twice: FIRST (the block's first tile fills its own halo - the prologue) and the
+  // persistent continuation, whose chunk 0 was staged by the previous tile.  Keeping the prologue out of the
+  // looped copy matters: as loop-invariant code its addresses stayed live through the tap loop (+80 VGPRs).
+  auto tile = [&](auto first_tag) __attribute__((always_inline)) {
+  constexpr bool FIRST = decltype(first_tag)::value;
+  const ConvGroup g = grp ? A.g[1] : A.g[0];
 
   // ---- block -> tile ---------------------------------------------------------------
   int m0 = 0, n_img = 0, y0 = 0, x0 = 0;
@@ -189,18 +219,23 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   constexpr int PIXSET = 256 / CG;
   const int pj = tid % CG, ppix0 = tid / CG;
   const unsigned hw_inv = MODE == 1 ? (65536u + A.hw_lds - 1) / A.hw_lds : 0u;
-  auto piece_goff = [&](int set) -> size_t {  // float4 offset from the chunk's first piece
+  // float4 offset of piece (set, tid) from the halo's first pixel.  It does not depend on WHICH halo is
+  // staged (this tile's next chunk or the next tile's first): the halo origin goes into the uniform base
+  // pointer, so the per-thread offsets are computed once (with the origin inside, the compiler kept both
+  // variants of every 64-bit address live through the tap loop).
+  auto piece_rel = [&](int set) -> unsigned {
     int pix = set * PIXSET + ppix0;
-    int q;
+    int qr;
     if (MODE == 0) {
-      q = q_origin + pix;
+      qr = pix;
     } else {
       pix = min(pix, np_pix - 1);
       const int hy = (int)(((unsigned)pix * hw_inv) >> 16), hx = pix - hy * A.hw_lds;
-      q = q_origin + hy * in_ws + hx;
+      qr = hy * in_ws + hx;
     }
-    return (size_t)q * in_cs4 + pj;
+    return (unsigned)qr * (unsigned)in_cs4 + (unsigned)pj;
   };
+  const float4* halo_base = in_base + (size_t)q_origin * in_cs4;  // chunk 0 of this tile's halo
   float4* smem4 = reinterpret_cast<float4*>(smem);
   const int buf4 = CG * QS;
   auto piece_loff = [&](int set) -> int { return pj * QS + set * PIXSET + ppix0; };
@@ -210,13 +245,42 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   //      addresses (measured: the fill is ~11k cycles of pure memory latency per block)
   constexpr int kFillDepth = 10;
   const int nsets = (np_total + 255) / 256;
+  // persistent: the next full tile of this block (ids past the remapped order's padding are skipped)
+  has_next = false;
+  nx_q_origin = q_origin;
+  nx_np_total = np_total;
+  nx_grp = grp;
+  if (persist) {
+    for (nx_bi = bi + bi_stride; nx_bi < A.nbig; nx_bi += bi_stride) {
+      int mt, c;
+      if (A.xcd_remap) {
+        const int xcd = nx_bi & 7, j = nx_bi >> 3;
+        c = j % A.ncombo;
+        mt = (j / A.ncombo) * 8 + xcd;
+      } else {
+        mt = nx_bi % A.mtiles;
+        c = nx_bi / A.mtiles;
+      }
+      if (mt < A.mtiles) {
+        has_next = true;
+        nx_m0 = mt * kBM;
+        nx_nt = c % A.ntiles;
+        nx_grp = c / A.ntiles;
+        strip_geom(nx_grp ? A.g[1] : A.g[0], nx_m0, nx_q_origin, nx_np_total);
+        break;
+      }
+    }
+  }
+  const float4* nx_in_base = reinterpret_cast<const float4*>(
+      nx_grp ? A.g[1].in + A.g[1].in_choff : A.g[0].in + A.g[0].in_choff);
+  const int nx_nsets = (nx_np_total + 255) / 256;
   float4 pf[kFillDepth];
-  const bool pro_fast = NBUF == 2 && nsets <= kFillDepth;
+  const bool pro_fast = FIRST && NBUF == 2 && nsets <= kFillDepth;
 #ifndef RTPOSE_EXP_NO_FILL
-  if (pro_fast) {
+  if (FIRST && pro_fast) {
 #pragma unroll
     for (int u = 0; u < kFillDepth; ++u)
-      if (u < nsets && u * 256 + tid < np_total) pf[u] = gload4(in_base + piece_goff(u));
+      if (u < nsets && u * 256 + tid < np_total) pf[u] = gload4(halo_base + piece_rel(u));
   }
 #endif
 
@@ -293,7 +357,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
       float4 t[kFillDepth];
 #pragma unroll
       for (int u = 0; u < kFillDepth; ++u)
-        if (set0 + u < nsets && (set0 + u) * 256 + tid < np_total) t[u] = gload4(src + piece_goff(set0 + u));
+        if (set0 + u < nsets && (set0 + u) * 256 + tid < np_total) t[u] = gload4(src + piece_rel(set0 + u));
 #pragma unroll
       for (int u = 0; u < kFillDepth; ++u)
         if (set0 + u < nsets && (set0 + u) * 256 + tid < np_total) smem4[piece_loff(set0 + u)] = t[u];
@@ -301,13 +365,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
   };
   RTPOSE_TSTAMP(6);
 #ifndef RTPOSE_EXP_NO_FILL
-  if (NBUF == 2) {
+  if (FIRST && NBUF == 2) {  // (persistent: only the block's first tile fills its own halo; lpar == 0)
     if (pro_fast) {
 #pragma unroll
       for (int u = 0; u < kFillDepth; ++u)
         if (u < nsets && u * 256 + tid < np_total) smem4[piece_loff(u)] = pf[u];
     } else {
-      fill_halo(in_base);
+      fill_halo(halo_base);
     }
     RTPOSE_TSTAMP(7);
     __syncthreads();
@@ -376,9 +440,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
           hv[d] = hv[d + 1];                                                                   \
           hl[d] = hl[d + 1];                                                                   \
         }                                                                                      \
-        if (ps < nsets) { /* uniform */                                                        \
-          hv[kHD - 1] = gload4(next_base + piece_goff(ps));                                    \
-          hl[kHD - 1] = (tid < np_total - ps * 256) ? hn_off + piece_loff(ps) : dummy_loff;    \
+        if (ps < st_nsets) { /* uniform */                                                     \
+          hv[kHD - 1] = gload4(next_base + piece_rel(ps));                                     \
+          hl[kHD - 1] = (tid < st_np_total - ps * 256) ? hn_off + piece_loff(ps) : dummy_loff; \
         } else {                                                                               \
           hv[kHD - 1] = make_float4(0.f, 0.f, 0.f, 0.f);                                       \
           hl[kHD - 1] = dummy_loff;                                                            \
@@ -412,23 +476,29 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     }                                                                                       \
   }
 
-  // rows of a chunk whose taps carry the staging code: one piece set is fetched per tap;
-  // whatever is still in the ring at the end of the chunk is parked before the barrier
-  const int stage_rows = min(ROWS, (nsets + TAPS - 1) / TAPS);
   float4 hv[kHD];
   int hl[kHD];
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     if (NBUF == 1) {  // every wave is past the previous chunk (barrier at the loop end)
-      fill_halo(in_base + (size_t)chunk * CG);
+      fill_halo(halo_base + (size_t)chunk * CG);
       __syncthreads();
     }
-    const int hb_off = NBUF == 2 ? (chunk & 1) * buf4 : 0;
-    const int hn_off = NBUF == 2 ? ((chunk + 1) & 1) * buf4 : 0;
-    // the last chunk re-stages itself into the idle buffer (never read): no branch
+    const int hb_off = NBUF == 2 ? ((chunk + lpar) & 1) * buf4 : 0;
+    const int hn_off = NBUF == 2 ? ((chunk + lpar + 1) & 1) * buf4 : 0;
+    // the last chunk stages chunk 0 of the block's NEXT tile into the idle buffer (persistent), or
+    // re-stages itself there (never read): no branch either way
+    const bool to_next = chunk + 1 == nchunks && has_next;
     const int chunk_next = min(chunk + 1, nchunks - 1);
-    const float4* next_base = in_base + (size_t)chunk_next * CG;
+    const float4* next_base = to_next ? nx_in_base + (size_t)nx_q_origin * in_cs4
+                                      : halo_base + (size_t)chunk_next * CG;  // (uniform: halo origin included)
+    const int st_np_total = to_next ? nx_np_total : np_total;
+    const int st_nsets = to_next ? nx_nsets : nsets;
+    // rows of a chunk whose taps carry the staging code: one piece set is fetched per tap;
+    // whatever is still in the ring at the end of the chunk is parked before the barrier
+    const int stage_rows = min(ROWS, (st_nsets + TAPS - 1) / TAPS);
     (void)next_base;
     (void)hn_off;
+    (void)st_np_total;
     int ps = 0;
 #pragma unroll
     for (int d = 0; d < kHD; ++d) {
@@ -475,16 +545,25 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
 #pragma unroll
         for (int r = 0; r < 16; ++r) t_ += acc[fm][fn][r];
     if (t_ == 12345.678f) reinterpret_cast<float*>(g.out)[0] = t_;
-    return;
+    if (!has_next) return;
   }
+  if (false) {
+#else
+  {
 #endif
   unsigned short* out_h = reinterpret_cast<unsigned short*>(g.out);
   float* out_f = reinterpret_cast<float*>(g.out);
   const float relu_lo = A.relu ? 0.f : -3.0e38f;  // uniform: v = max(v, relu_lo), no select
+  const bool pool = MODE == 1 && A.pool;          // (the fused 2x2 max-pool exists for 2-D tiles only)
   if (A.vec_store) {  // uniform
-    // (the chunk loop ended with a barrier: the halo buffers are dead)
+    // The chunk loop ended with a barrier: the halo buffer multiplied last is dead.  Persistent blocks
+    // keep the slabs inside that one buffer (the other one already holds the next tile's halo), which is
+    // why a wave transposes its tile in two halves of MF/2 fragments (20 KB for the four waves).
+    constexpr int HALVES = MF >= 2 ? 2 : 1;
+    constexpr int MFH = MF / HALVES;
     constexpr int PITCH2 = (NF * 64 * SP + 16) / 2;  // slab row pitch in bf16 elements
-    unsigned short* sl = reinterpret_cast<unsigned short*>(smem) + wave * (slab_bytes(MF, NF, SP) / 2);
+    const int dead4 = (persist ? ((nchunks - 1 + lpar) & 1) * buf4 : 0);  // float4 offset of the dead buffer
+    unsigned short* sl = reinterpret_cast<unsigned short*>(smem) + dead4 * 8 + wave * (slab_bytes(MFH, NF, SP) / 2);
     // element of output channel c inside a slab row: c, or (split) its 8-channel group's hi piece
     const int ce = SP == 1 ? l31 : ((l31 >> 3) * 16 + (l31 & 7));
     auto put = [&](int row, int fn, float v) {
@@ -494,30 +573,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
       d[0] = hi;
       if (SP == 2) d[8] = to_bf16(v - __uint_as_float((unsigned)hi << 16));
     };
-    if (!A.pool) {
-#pragma unroll
-      for (int fn = 0; fn < NF; ++fn)
-#pragma unroll
-        for (int fm = 0; fm < MF; ++fm)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) put(fm * 32 + rg * 8 + 4 * kh + rr, fn, acc[fm][fn][rg * 4 + rr]);
-    } else {
-#pragma unroll
-      for (int fn = 0; fn < NF; ++fn)
-#pragma unroll
-        for (int fm = 0; fm < MF; ++fm)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg)
-            put(fm * 8 + rg * 2 + kh, fn,
-                fmaxf(fmaxf(acc[fm][fn][rg * 4 + 0], acc[fm][fn][rg * 4 + 1]),
-                      fmaxf(acc[fm][fn][rg * 4 + 2], acc[fm][fn][rg * 4 + 3])));
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // same-wave LDS traffic is in order
     constexpr int LPR = NF * 4 * SP;  // lanes (16 bytes each) per slab row
     constexpr int RPI = 64 / LPR;   // rows per wave-instruction
-    const int rows = A.pool ? 8 * MF : 32 * MF;
+    const int rows_h = pool ? 8 * MFH : 32 * MFH;  // slab rows per half
     const int lrow = lane / LPR, c16 = lane % LPR;
     unsigned short* ob = out_h + g.out_choff + (ntile * BN + wn * (32 * NF)) * SP + c16 * 8;
     const int Ho = A.H >> 1, Wo = A.W >> 1;
@@ -532,43 +590,70 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
       sy = r / A.W;
       sx = r - sy * A.W;
     }
-    for (int it = 0; it * RPI < rows; ++it) {
-      const int row = it * RPI + lrow;
-      const float4 v = *reinterpret_cast<const float4*>(sl + row * PITCH2 + c16 * 8);
-      int n, y, x;
-      bool ok;
-      if (A.pool) {  // MODE 1: slab row = quad index inside the wave
-        const int qi = wm * (8 * MF) + row;
-        const int hw_log2 = A.tw_log2 - 1;
-        n = n_img;
-        y = (y0 >> 1) + (qi >> hw_log2);
-        x = (x0 >> 1) + (qi & ((1 << hw_log2) - 1));
-        ok = y < Ho && x < Wo;
-      } else if (MODE == 0) {
-        ok = m0 + wm * (32 * MF) + row < A.M;
-        n = sn;
-        y = sy;
-        x = sx;
-        sx += RPI;  // next iteration's row
-        while (sx >= A.W) {
-          sx -= A.W;
-          if (++sy >= A.H) {
-            sy = 0;
-            ++sn;
-          }
-        }
+#pragma unroll
+    for (int hf = 0; hf < HALVES; ++hf) {
+      if (!pool) {
+#pragma unroll
+        for (int fn = 0; fn < NF; ++fn)
+#pragma unroll
+          for (int fmh = 0; fmh < MFH; ++fmh)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr)
+                put(fmh * 32 + rg * 8 + 4 * kh + rr, fn, acc[hf * MFH + fmh][fn][rg * 4 + rr]);
       } else {
-        int ty, tx;
-        tile_local_yx(wm * (32 * MF) + row, A.tw_log2, ty, tx);
-        n = n_img;
-        y = y0 + ty;
-        x = x0 + tx;
-        ok = (y < A.H) && (x < A.W);
+#pragma unroll
+        for (int fn = 0; fn < NF; ++fn)
+#pragma unroll
+          for (int fmh = 0; fmh < MFH; ++fmh)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+              put(fmh * 8 + rg * 2 + kh, fn,
+                  fmaxf(fmaxf(acc[hf * MFH + fmh][fn][rg * 4 + 0], acc[hf * MFH + fmh][fn][rg * 4 + 1]),
+                        fmaxf(acc[hf * MFH + fmh][fn][rg * 4 + 2], acc[hf * MFH + fmh][fn][rg * 4 + 3])));
       }
-      if (ok && row < rows) {
-        const size_t q = (size_t)g.out_lead + (size_t)(n * g.out_hs + y) * g.out_ws + x;
-        gstore4(ob + q * g.out_cstride, v);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // same-wave LDS traffic is in order
+      for (int it = 0; it * RPI < rows_h; ++it) {
+        const int row = it * RPI + lrow;       // slab row
+        const int grow = hf * rows_h + row;    // row (quad, when pooling) inside the wave's tile
+        const float4 v = *reinterpret_cast<const float4*>(sl + row * PITCH2 + c16 * 8);
+        int n, y, x;
+        bool ok;
+        if (pool) {  // MODE 1: slab row = quad index inside the wave
+          const int qi = wm * (8 * MF) + grow;
+          const int hw_log2 = A.tw_log2 - 1;
+          n = n_img;
+          y = (y0 >> 1) + (qi >> hw_log2);
+          x = (x0 >> 1) + (qi & ((1 << hw_log2) - 1));
+          ok = y < Ho && x < Wo;
+        } else if (MODE == 0) {
+          ok = m0 + wm * (32 * MF) + grow < A.M;
+          n = sn;
+          y = sy;
+          x = sx;
+          sx += RPI;  // next iteration's row (the walk runs on into the second half)
+          while (sx >= A.W) {
+            sx -= A.W;
+            if (++sy >= A.H) {
+              sy = 0;
+              ++sn;
+            }
+          }
+        } else {
+          int ty, tx;
+          tile_local_yx(wm * (32 * MF) + grow, A.tw_log2, ty, tx);
+          n = n_img;
+          y = y0 + ty;
+          x = x0 + tx;
+          ok = (y < A.H) && (x < A.W);
+        }
+        if (ok && row < rows_h) {
+          const size_t q = (size_t)g.out_lead + (size_t)(n * g.out_hs + y) * g.out_ws + x;
+          gstore4(ob + q * g.out_cstride, v);
+        }
       }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // slab reads precede the next half's writes
     }
     RTPOSE_TSTAMP(3);
 #ifdef RTPOSE_EXP_TIMELINE
@@ -576,8 +661,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     RTPOSE_TSTAMP(4);
     if (A.dbg && threadIdx.x == 0) A.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
 #endif
-    return;
-  }
+  } else {
 #pragma unroll
   for (int fn = 0; fn < NF; ++fn) {
     const int ncolf = ncol + fn * 32;
@@ -588,7 +672,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
     // heat-map slice of the concat buffer starts at channel 166): address by absolute channel
     const int ca = (g.out_choff >> 1) + ncolf;
     const int ochs = (ca >> 3) * 16 + (ca & 7);  // hi element, lo at +8
-    if (!A.pool) {
+    if (!pool) {
 #pragma unroll
       for (int fm = 0; fm < MF; ++fm) {
 #pragma unroll
@@ -660,6 +744,19 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const ConvGroup& g,
       }
     }
   }
+  }  // scalar epilogue
+  }  // epilogue
+  if (has_next) {
+    __syncthreads();  // every wave is done with its slab before the next tile's staging ring writes that buffer
+    grp = nx_grp;
+    m0_arg = nx_m0;
+    ntile = nx_nt;
+    bi = nx_bi;
+    lpar = (nchunks + lpar) & 1;  // the buffer the last chunk staged the next tile's chunk 0 into
+  }
+  };  // tile
+  tile(std::true_type{});
+  while (has_next) tile(std::false_type{});
 }
 
 // 1-D grid, block id -> (group, N tile, M tile); XCD-aware order and half-tile tail exactly
@@ -679,26 +776,32 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs A) {
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)A.dephase_cycles) __builtin_amdgcn_s_sleep(32);
   }
-  const bool small = MODE == 0 && L >= A.nbig;
-  const int bi = small ? A.nbig + ((L - A.nbig) >> 1) : L;
-  int mt, c;
-  if (A.xcd_remap) {
-    const int xcd = bi & 7, j = bi >> 3;
-    c = j % A.ncombo;
-    mt = (j / A.ncombo) * 8 + xcd;
-  } else {
-    mt = bi % A.mtiles;
-    c = bi / A.mtiles;
+  const bool small = MODE == 0 && L >= A.npersist;
+  const int stride = (MODE == 0 && NBUF == 2 && A.npersist < A.nbig) ? A.npersist : 0;
+  int bi = small ? A.nbig + ((L - A.npersist) >> 1) : L;
+  int mt = 0, c = 0;
+  for (;;) {  // (persistent blocks skip the padding ids of the remapped order)
+    if (A.xcd_remap) {
+      const int xcd = bi & 7, j = bi >> 3;
+      c = j % A.ncombo;
+      mt = (j / A.ncombo) * 8 + xcd;
+    } else {
+      mt = bi % A.mtiles;
+      c = bi / A.mtiles;
+    }
+    if (mt < A.mtiles) break;
+    if (small || stride == 0) return;
+    bi += stride;
+    if (bi >= A.nbig) return;
   }
-  if (mt >= A.mtiles) return;
   const int nt = c % A.ntiles, grp = c / A.ntiles;
   if (MODE == 1) {
-    conv_tile<KS, CK, MODE, NBUF, WM, MF, NF, SP>(A, A.g[grp], mt, nt, smem);
+    conv_tile<KS, CK, MODE, NBUF, WM, MF, NF, SP>(A, grp, mt, nt, smem);
   } else if (!small) {
-    conv_tile<KS, CK, MODE, NBUF, WM, MF, NF, SP>(A, A.g[grp], mt * kBM, nt, smem);
+    conv_tile<KS, CK, MODE, NBUF, WM, MF, NF, SP>(A, grp, mt * kBM, nt, smem, bi, stride);
   } else {
-    const int m0 = mt * kBM + ((L - A.nbig) & 1) * (kBM / 2);
-    if (m0 < A.M) conv_tile<KS, CK, MODE, NBUF, WM, MF / 2, NF, SP>(A, A.g[grp], m0, nt, smem);
+    const int m0 = mt * kBM + ((L - A.npersist) & 1) * (kBM / 2);
+    if (m0 < A.M) conv_tile<KS, CK, MODE, NBUF, WM, MF / 2, NF, SP>(A, grp, m0, nt, smem);
   }
 }
 
@@ -953,7 +1056,28 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
     if (total > slots && rem > 0 && 2 * rem <= n_cu) a.nbig = total - rem;
     if (total <= n_cu) a.nbig = 0;
   }
-  dim3 grid((unsigned)(a.nbig + 2 * (ids - a.nbig)), 1, 1);
+  // persistent strips: 2 blocks per CU walk the full tiles (k x k layers; the grouped convs share the
+  // input pixel pitch, which the cross-tile staging relies on); RTPOSE_BF16_PERSIST=0 (developer builds)
+  // restores one tile per block
+  a.npersist = a.nbig;
+  {
+    static int persist_env = -1;
+    if (persist_env < 0) {
+      const char* e = dev_env("RTPOSE_BF16_PERSIST");
+      persist_env = e ? atoi(e) : 1;
+    }
+    const int slots = (n_cu * 2) & ~7;  // multiple of 8: a block stays on its XCD's ids
+    bool same_pitch = true;
+    for (int i = 1; i < ngroups; ++i) same_pitch = same_pitch && d[i].lin.cstride == d0.lin.cstride && d[i].lin.lead == d0.lin.lead;
+    // the epilogue's half-size slabs must fit inside ONE halo buffer (the other holds the next tile's halo)
+    const int mf = pl.wm == 1 ? 4 : 2;
+    const size_t half_slabs = (size_t)4 * slab_bytes(mf / 2, pl.nf, sp);
+    const size_t buf_bytes = (size_t)(pl.ck / 8 * sp) * pl.qs * 16;
+    if (persist_env && pl.mode == 0 && pl.nbuf == 2 && d0.k != 1 && same_pitch && slots >= 8 && a.nbig > slots &&
+        (!a.vec_store || half_slabs <= buf_bytes))
+      a.npersist = slots;
+  }
+  dim3 grid((unsigned)(a.npersist + 2 * (ids - a.nbig)), 1, 1);
   {
     static int dephase_env = -1;  // percent of one block's MFMA time; 0 = off
     if (dephase_env < 0) {
