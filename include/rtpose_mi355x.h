@@ -165,6 +165,22 @@ int rtpose_pack_pw_weights(const float* w_oi, const float* bias, int cout, int c
                            float* w_packed, float* bias_packed, void* stream);
 int rtpose_pw_fused(const rtpose_pw_desc* d, int N, int H, int W, void* stream);
 
+/* bf16 form (the bf16 plan of BASELINE configs[3]): bf16 activations and pointwise weights, fp32 accumulate
+ * (v_mfma_f32_32x32x16_bf16), depthwise taps / biases fp32, outputs rounded to bf16 (round-to-nearest-even)
+ * or written fp32 (out_f32 != 0: the two heads).  In the desc `in`, `out`, `pt_src` point at 2-byte elements
+ * (out: 4-byte when out_f32), the layouts count ELEMENTS, slices are multiples of 8 elements, cin a
+ * multiple of 16.  The bf16 epilogue stores the GEMM's columns [0, cout) as the CONTIGUOUS channels
+ * lout.choff .. (16 bytes per lane), so a layer that writes runs of the four-run layout is packed with a
+ * column map (`col_map[i]` = output channel of packed column col_off + i, < 0 = a zero column); out_cmap is
+ * honoured by the fp32 epilogue only; the pass-through half exists in its interleave form only.
+ * Contract: oracle/shufflenet_oracle.py:forward_bf16_emulated (the reference has no bf16 path). */
+size_t rtpose_packed_pw_bytes_bf16(int cin_packed, int coutp);
+int rtpose_pack_pw_weights_bf16(const float* w_oi, const float* bias, int cout, int cin_src,
+                                const int32_t* cin_map, int cin_packed, int ncols,
+                                const int32_t* col_map, int coutp, int col_off, void* w_packed,
+                                float* bias_packed, void* stream);
+int rtpose_pw_fused_bf16(const rtpose_pw_desc* d, int out_f32, int N, int H, int W, void* stream);
+
 /* ---- bf16 variant (BASELINE config 3: "bf16, multi-scale x4 + flip") ----------------
  * Same modules, bf16 activations and weights, fp32 accumulate
  * (v_mfma_f32_32x32x16_bf16), bias/ReLU/pool in fp32, output rounded to bf16

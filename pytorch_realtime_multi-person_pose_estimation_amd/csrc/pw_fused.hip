@@ -225,7 +225,6 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
         // park the staged halo pieces, request the next chunk's (of this item, or chunk 0 of the next)
 #pragma unroll
         for (int u = 0; u < kPwMaxStage; ++u) st[pl * nps + px + 32 * u] = sr[u];  // (nps >= 256 pixels)
-        load_pieces(last ? nxt : cur, last ? 0 : c0 + 32);  // (no next item: nxt == cur, a harmless re-read)
         __syncthreads();  // halo of chunk c visible; every wave is past the previous item's epilogue
         if (c == 0 && has_next && tid < kPwBM) write_tables(nxt, par ^ 1);
         // depthwise 3x3 (+bias) -> A tile.  Tap (ky, kx) of pixel q is pixel q + (ky-1) ws + (kx-1).
@@ -253,6 +252,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
         }
         a_buf[pl * kPwQS + px] = v0;
         a_buf[pl * kPwQS + px + 32] = v1;
+        // the next chunk's halo (of this item, or chunk 0 of the next; no next item: nxt == cur, a harmless
+        // re-read) is requested only now: the depthwise phase above is the register peak of the kernel, and
+        // the MFMAs below still cover the latency
+        load_pieces(last ? nxt : cur, last ? 0 : c0 + 32);
         __syncthreads();  // A tile of chunk c visible; the staged halo may be overwritten
       } else {
         a_buf[pl * kPwQS + px] = sr[0];

@@ -40,6 +40,11 @@ int pw_fused_launch(const rtpose_pw_desc* d, int N, int H, int W, hipStream_t s)
 int pack_pw_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map, int K,
                    int coutp, int col_off, float* wp, float* bp, hipStream_t s);
 int pw_halo_stride(const rtpose_layout& l, int H, int W);
+// ... and of the bf16 plan (pw_fused_bf16.hip)
+int pw_fused_bf16_launch(const rtpose_pw_desc* d, int out_f32, int N, int H, int W, hipStream_t s);
+int pack_pw_bf16_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map, int K,
+                        int ncols, const int32_t* col_map, int coutp, int col_off, void* wp, float* bp,
+                        hipStream_t s);
 
 // w[C][1][3][3] (+bias[C]) -> wp[9][cphys], bp[cphys]; phys channel p reads logical pmap[p] (-1: zero)
 __global__ void pack_dw_kernel(const float* __restrict__ w, const float* __restrict__ b, int C,
@@ -81,8 +86,10 @@ struct SLayer {
   int cin_packed = 0;         // L_PW: packed input channels; L_DW: physical channels
   int map_id = -1;            // index into maps (cin_map for PW, phys->logical for DW), -1 identity
   size_t w_off = 0, b_off = 0;
-  int coutp = 0, col_off = 0; // L_PW of a fused (fp32) plan: columns of the packed matrix this layer's
-                              // cout columns start at (the two heads share one 128-column matrix)
+  int coutp = 0, col_off = 0; // L_PW of a fused plan: columns of the packed matrix this layer's cout columns
+                              // start at (the two heads share one 64-column matrix)
+  int colmap_id = -1, ncols = 0;  // fused bf16 plans: packed column i is output channel maps[colmap_id][i]
+                              // (-1: identity), ncols columns are packed / stored
 };
 
 struct SBuf {
@@ -180,7 +187,8 @@ int add_layer(rtpose_shufflenet* n, LKind kind, const std::string& name, int cou
     case L_STEM: wf = (size_t)9 * 8 * cout; bf = cout; break;
     case L_DW: wf = (size_t)9 * cin_packed; bf = cin_packed; break;
     case L_PW:
-      wf = n->bf16 ? rtpose_packed_weight_bytes_bf16(cout, cin_packed, 1) / 4
+      wf = n->bf16 ? (n->fused ? (size_t)(cin_packed + 64) * cout_pad(cout > 0 ? cout : 1) / 2
+                               : rtpose_packed_weight_bytes_bf16(cout, cin_packed, 1) / 4)
                    : rtpose_packed_weight_floats(cout, cin_packed, 1);
       bf = rtpose_packed_bias_floats(cout);
       break;
@@ -272,7 +280,7 @@ void add_pwf(rtpose_shufflenet* n, const std::string& name, int H, int W, int la
 
 // can the depthwise 3x3 that reads `b` be evaluated inside the fused pointwise kernel?
 bool dw_fusable(const rtpose_shufflenet* n, int buf, int H, int W) {
-  return n->fused && pw_halo_stride(n->bufs[buf].lay, H, W) <= 256;
+  return n->fused && pw_halo_stride(n->bufs[buf].lay, H, W) <= 256;  // (same bound in both dtypes)
 }
 
 void build(rtpose_shufflenet* n) {
@@ -335,7 +343,8 @@ void build(rtpose_shufflenet* n) {
     // pointwise conv runs with 64-channel LDS chunks (232 padded to 240 would fall back to 16)
     const bool qt = n->fused != 0;  // four-run channel layout (see fphys)
     const int C = widths[si], h = C / 2,
-              hp = n->bf16 ? (h + 63) / 64 * 64 : (qt ? 2 * ((h / 2 + 3) / 4 * 4) : up8(h));
+              hp = qt ? 2 * ((h / 2 + (n->bf16 ? 7 : 3)) / (n->bf16 ? 8 : 4) * (n->bf16 ? 8 : 4))  // 2 q, q = run pitch
+                      : (n->bf16 ? (h + 63) / 64 * 64 : up8(h));
     const int stride = si == 0 ? 2 : 1;
     const int Ho = si == 0 ? H3 : Hc, Wo = si == 0 ? W3 : Wc;
     const std::string sp = "network." + std::to_string(3 + si) + ".";
@@ -352,15 +361,39 @@ void build(rtpose_shufflenet* n) {
     int M_x2 = -1, M_pl = -1;
     if (qt) {
       const int q = hp / 2, hh = h / 2;
-      std::vector<int32_t> x2(hp, -1), pln(hp / 4);
+      const int pg = n->bf16 ? 8 : 4;  // channels per 16-byte plane
+      std::vector<int32_t> x2(hp, -1), pln(hp / pg);
       for (int k = 0; k < hp; ++k) {
         const int p = k < q ? k : k - q;
         if (p < hh) x2[k] = 2 * p + (k < q ? 0 : 1);  // logical (h + 2p [+1]) - h
       }
-      for (int j = 0; j < hp / 4; ++j) pln[j] = 4 * j < q ? q + 4 * j : 3 * q + (4 * j - q);
+      for (int j = 0; j < hp / pg; ++j) pln[j] = pg * j < q ? q + pg * j : 3 * q + (pg * j - q);
       M_x2 = add_map(n, x2);
       M_pl = add_map(n, pln);
     }
+    // bf16 fused plans: the epilogue stores the GEMM's columns as contiguous channels, so a layer that writes
+    // the even or the odd runs has its columns packed in run order: column c' = (low run | pad | high run | pad)
+    int M_cols = -1;
+    if (qt && n->bf16) {
+      const int q = hp / 2, hh = h / 2;
+      std::vector<int32_t> cm(hp, -1);
+      for (int c = 0; c < hp; ++c) {
+        const int p = c < q ? c : c - q;
+        if (p < hh) cm[c] = c < q ? p : hh + p;
+      }
+      M_cols = add_map(n, cm);
+    }
+    auto runs_out = [&](int layer) {  // the layer writes both runs of a parity: hp packed / stored columns
+      if (M_cols < 0) return;
+      n->layers[layer].colmap_id = M_cols;
+      n->layers[layer].ncols = hp;
+      n->layers[layer].coutp = cout_pad(hp);
+    };
+    auto plain_out = [&](int layer, int cout) {  // contiguous output channels, whole 8-channel groups stored
+      if (!(qt && n->bf16)) return;
+      n->layers[layer].ncols = (cout + 7) / 8 * 8;
+      n->layers[layer].coutp = cout_pad(cout);
+    };
     // temporaries
     const int in_phys = in_is_stage ? 2 * in_hp : in_c;
     const int T0 = add_buf(n, up8(in_phys), 0, Ho, Wo);  // conv0 branch after dw
@@ -383,6 +416,9 @@ void build(rtpose_shufflenet* n) {
       const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, in_c, up8(in_phys), M_in);
       const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, hp, -1);
       const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, hp, -1);
+      runs_out(l_c01);
+      runs_out(l_c2);
+      plain_out(l_c0, h);
       if (!n->fused) {
         add_dw(n, bp + "conv0.0", Hc, Wc, l_c00, in_buf, T0, stride);
         add_pw(n, bp + "conv0.1", Ho, Wo, l_c01, T0, 0, SA, 0, M_even, 1);
@@ -400,9 +436,11 @@ void build(rtpose_shufflenet* n) {
         add_pwf(n, bp + "conv.0", Hc, Wc, l_c0, -1, in_buf, 0, T1a, 0, -1, 1);
         if (stride == 1 && dw_fusable(n, T1a, Hc, Wc)) {
           add_pwf(n, bp + "conv.1+conv.2", Ho, Wo, l_c2, l_c1, T1a, 0, SA, 0, M_odd, 1);
+        if (n->bf16) n->ops.back().out_choff[0] = hp;  // bf16: the odd runs as contiguous columns
         } else {
           add_dw(n, bp + "conv.1", Hc, Wc, l_c1, T1a, T2, stride);
           add_pwf(n, bp + "conv.2", Ho, Wo, l_c2, -1, T2, 0, SA, 0, M_odd, 1);
+        if (n->bf16) n->ops.back().out_choff[0] = hp;  // bf16: the odd runs as contiguous columns
         }
       }
     }
@@ -413,12 +451,15 @@ void build(rtpose_shufflenet* n) {
       const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, h, hp, qt ? M_x2 : -1);
       const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, hp, -1);
       const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, hp, -1);
+      runs_out(l_c2);
+      plain_out(l_c0, h);
       if (n->fused && dw_fusable(n, T1, Ho, Wo)) {
         // two launches per unit: conv.0 (x2 gathered as two runs), then conv.1 (in LDS) -> conv.2 -> the odd
         // runs + the next x1 = (even-low, odd-low) interleaved -> the even runs
         add_pwf(n, bp + "conv.0", Ho, Wo, l_c0, -1, cur, 0, T1, 0, -1, 1);
         n->ops.back().planes_map = M_pl;
         add_pwf(n, bp + "conv.1+conv.2+x1", Ho, Wo, l_c2, l_c1, T1, 0, nxt, 0, M_odd, 1, cur, -1, 0);
+        if (n->bf16) n->ops.back().out_choff[0] = hp;  // bf16: the odd runs as contiguous columns
         SOp& o = n->ops.back();
         o.pt_pairs = h / 2;
         o.pt_a = 0;
@@ -433,6 +474,7 @@ void build(rtpose_shufflenet* n) {
         n->ops.back().planes_map = M_pl;
         add_dw(n, bp + "conv.1", Ho, Wo, l_c1, T1, T2, 1);
         add_pwf(n, bp + "conv.2+x1", Ho, Wo, l_c2, -1, T2, 0, nxt, 0, M_odd, 1, cur, -1, 0);
+        if (n->bf16) n->ops.back().out_choff[0] = hp;  // bf16: the odd runs as contiguous columns
         SOp& o = n->ops.back();
         o.pt_pairs = h / 2;
         o.pt_a = 0;
@@ -484,6 +526,12 @@ void build(rtpose_shufflenet* n) {
       SLayer& Hh = n->layers[lh];
       P.coutp = Hh.coutp = 64;
       Hh.col_off = 38;
+      P.ncols = 38;
+      Hh.ncols = 19;
+      if (n->bf16) {
+        n->layers[l5].ncols = 1024;
+        n->layers[l5].coutp = 1024;
+      }
       Hh.w_off = P.w_off = n->wt_floats;
       n->wt_floats += round_up((size_t)(1024 + 32) * 64, 64);
       Hh.b_off = P.b_off = n->wt_floats;
@@ -535,7 +583,7 @@ int rtpose_shufflenet_create_ex(int N, int H, int W, int dtype, rtpose_shufflene
   n->H = H;
   n->W = W;
   n->bf16 = dtype == RTPOSE_DTYPE_BF16;
-  n->fused = !n->bf16;  // the fused pointwise chains exist in fp32 (v_mfma_f32_32x32x2_f32) only
+  n->fused = 1;  // pointwise chains run as fused launches (pw_fused.hip, pw_fused_bf16.hip)
   build(n);
   *out = n;
   return 0;
@@ -612,6 +660,11 @@ int rtpose_shufflenet_load(rtpose_shufflenet* n, int idx, const float* w, const 
       return 0;
     }
     case L_PW:
+      if (n->fused && n->bf16) {  // column-mapped bf16 packing (see pw_fused_bf16.hip)
+        const int32_t* cmap = l.colmap_id >= 0 ? reinterpret_cast<const int32_t*>(n->wt + n->maps[l.colmap_id].off) : nullptr;
+        return pack_pw_bf16_launch(w, b, l.cout, l.cin, map, l.cin_packed, l.ncols, cmap, l.coutp, l.col_off,
+                                   n->wt + l.w_off, n->wt + l.b_off, s);
+      }
       if (l.coutp)  // shares a packed matrix with another layer (the heads of a fused plan)
         return pack_pw_launch(w, b, l.cout, l.cin, map, l.cin_packed, l.coutp, l.col_off, n->wt + l.w_off,
                               n->wt + l.b_off, s);
@@ -738,7 +791,16 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
           d.pt_d0 = o.pt_d0;
           d.pt_d1 = o.pt_d1;
         }
-        rc = pw_fused_launch(&d, n->N, o.H, o.W, s);
+        if (n->bf16) {
+          const bool f32out = o.out_buf[0] == n->out_buf;  // the two heads write the fp32 output record
+          if (!f32out) {  // columns [0, ncols) -> contiguous channels from out_choff (no scatter in bf16)
+            d.cout = l.ncols;
+            d.out_cmap = nullptr;
+          }
+          rc = pw_fused_bf16_launch(&d, f32out ? 1 : 0, n->N, o.H, o.W, s);
+        } else {
+          rc = pw_fused_launch(&d, n->N, o.H, o.W, s);
+        }
         break;
       }
       case O_PW: {

@@ -199,6 +199,108 @@ def test_unit_in_the_four_run_layout(capi, cuda, h, w_map):
     assert abs(total - inside) <= 1e-3 * max(1.0, inside), "kernel wrote outside the real channels / pixels"
 
 
+def _rb(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("h", [58, 116, 232])
+def test_unit_bf16_four_run_layout(capi, cuda, h):
+    """The bf16 form (rtpose_pw_fused_bf16) of the same unit: bf16 activations / pointwise weights, fp32
+    accumulate, depthwise taps and biases fp32, every stored activation rounded to bf16 - against the same
+    arithmetic emulated in torch (oracle/shufflenet_oracle.py:_block_bf16 semantics).  Runs are 8-channel
+    aligned (q = up8(h/2)); conv.2's columns are packed in run order (col_map) because the bf16 epilogue
+    stores contiguous channels."""
+    g = torch.Generator().manual_seed(h + 1)
+    n, H, W = 2, 9, 46
+    hh_, q = h // 2, (h // 2 + 7) // 8 * 8
+    C4, K = 4 * q, 2 * q
+    x = _rb(torch.randn(n, 2 * h, H, W, generator=g))
+    w0 = torch.randn(h, h, generator=g) / h ** 0.5
+    b0 = torch.randn(h, generator=g) * 0.1
+    wd = torch.randn(h, 1, 3, 3, generator=g) * 0.3
+    bd = torch.randn(h, generator=g) * 0.1
+    w2 = torch.randn(h, h, generator=g) / h ** 0.5
+    b2 = torch.randn(h, generator=g) * 0.1
+    x1, x2 = x[:, :h], x[:, h:]
+    t1 = _rb(F.relu(F.conv2d(x2.double(), _rb(w0)[:, :, None, None].double(), b0.double()).float()))
+    t2 = _rb(F.conv2d(t1.double(), wd.double(), bd.double(), padding=1, groups=h).float())
+    y = _rb(F.relu(F.conv2d(t2.double(), _rb(w2)[:, :, None, None].double(), b2.double()).float()))
+    ref = torch.stack([x1, y], 2).reshape(n, 2 * h, H, W)
+
+    def phys(j):
+        i = j >> 1
+        return (2 * (j & 1) + (1 if i >= hh_ else 0)) * q + (i - hh_ if i >= hh_ else i)
+    perm = torch.tensor([phys(j) for j in range(2 * h)])
+    xp = torch.zeros(n, C4, H, W)
+    xp[:, perm] = x
+    lay = capi.Layout.padded(C4, H, W, 1)
+    npix = capi.lib.rtpose_layout_pixels(C.byref(lay), n, H, W)
+    cur = torch.zeros(npix * C4, dtype=torch.int16, device=cuda)
+    nxt = torch.zeros_like(cur)
+    xs = xp.to(cuda).contiguous()
+    capi.check(capi.lib.rtpose_nchw_to_layout_bf16(capi.ptr(xs), capi.ptr(cur), C.byref(lay), C4, C4, n, H, W,
+                                                   capi.current_stream()))
+    lt1 = capi.Layout.padded(K, H, W, 1)
+    t1b = torch.zeros(capi.lib.rtpose_layout_pixels(C.byref(lt1), n, H, W) * K, dtype=torch.int16, device=cuda)
+    coutp = (K + 63) // 64 * 64
+    x2map = torch.full((K,), -1, dtype=torch.int32)
+    colmap = torch.full((K,), -1, dtype=torch.int32)
+    for k in range(K):
+        p = k if k < q else k - q
+        if p < hh_:
+            x2map[k] = 2 * p + (0 if k < q else 1)
+            colmap[k] = p if k < q else hh_ + p
+    pln = torch.tensor([q + 8 * j if 8 * j < q else 3 * q + (8 * j - q) for j in range(K // 8)], dtype=torch.int32)
+    keep = []
+
+    def pack(wt, b, cin_map, ncols, col_map):
+        wpk = torch.zeros(capi.lib.rtpose_packed_pw_bytes_bf16(K, coutp) // 2, dtype=torch.int16, device=cuda)
+        bpk = torch.zeros(coutp, device=cuda)
+        wt_d, b_d = wt.contiguous().to(cuda), b.to(cuda)
+        cm = cin_map.to(cuda) if cin_map is not None else None
+        cl = col_map.to(cuda) if col_map is not None else None
+        capi.check(capi.lib.rtpose_pack_pw_weights_bf16(capi.ptr(wt_d), capi.ptr(b_d), h, h, capi.ptr(cm) if cm is not None else None,
+                                                        K, ncols, capi.ptr(cl) if cl is not None else None, coutp, 0,
+                                                        capi.ptr(wpk), capi.ptr(bpk), capi.current_stream()))
+        keep.extend([wpk, bpk, wt_d, b_d, cm, cl])
+        return wpk, bpk
+    n0 = (h + 7) // 8 * 8
+    wp0, bp0 = pack(w0, b0, x2map, n0, None)
+    wp2, bp2 = pack(w2, b2, None, K, colmap)
+    pln_d = pln.to(cuda)
+    d = capi.PwDesc()
+    d.inp, d.w_packed, d.bias_packed, d.out = cur.data_ptr(), wp0.data_ptr(), bp0.data_ptr(), t1b.data_ptr()
+    d.lin, d.lout, d.cin, d.cout, d.coutp, d.relu = lay, lt1, K, n0, coutp, 1
+    d.in_planes = pln_d.data_ptr()
+    capi.check(capi.lib.rtpose_pw_fused_bf16(C.byref(d), 0, n, H, W, capi.current_stream()), "conv.0 bf16")
+    wdp = torch.zeros(9, K)
+    wdp[:, :h] = wd.reshape(h, 9).t()
+    bdp = torch.zeros(K)
+    bdp[:h] = bd
+    wdp_d, bdp_d = wdp.to(cuda), bdp.to(cuda)
+    d2 = capi.PwDesc()
+    d2.inp, d2.w_packed, d2.bias_packed, d2.out = t1b.data_ptr(), wp2.data_ptr(), bp2.data_ptr(), nxt.data_ptr()
+    d2.dw_w, d2.dw_b = wdp_d.data_ptr(), bdp_d.data_ptr()
+    lodd = capi.Layout.padded(C4, H, W, 1, choff=2 * q)
+    d2.lin, d2.lout, d2.cin, d2.cout, d2.coutp, d2.relu = lt1, lodd, K, K, coutp, 1
+    d2.pt_src, d2.lpt = cur.data_ptr(), lay
+    d2.pt_pairs, d2.pt_a, d2.pt_b, d2.pt_split, d2.pt_d0, d2.pt_d1 = hh_, 0, 2 * q, hh_, 0, q
+    capi.check(capi.lib.rtpose_pw_fused_bf16(C.byref(d2), 0, n, H, W, capi.current_stream()), "conv.1+conv.2+x1 bf16")
+    # read back: bf16 layout -> fp32 layout -> NCHW
+    f32buf = torch.zeros(npix * C4, device=cuda)
+    capi.check(capi.lib.rtpose_layout_bf16_to_f32(capi.ptr(nxt), C.byref(lay), capi.ptr(f32buf), C.byref(lay), C4, n, H, W,
+                                                  capi.current_stream()))
+    got = _from_layout(capi, f32buf, lay, C4, n, H, W, cuda)
+    pads = [c for c in range(C4) if c not in set(perm.tolist())]
+    assert got[:, pads].abs().max().item() == 0.0                      # the run padding stays zero
+    got = got[:, perm]
+    assert (got[:, 0::2] - ref[:, 0::2]).abs().max().item() == 0.0     # the pass-through half is a copy
+    scale = max(1.0, ref.abs().max().item())
+    # one bf16 ulp (2^-8 relative) where the fp32 dw accumulation order flips a rounding, two stages deep
+    assert (got - ref).abs().max().item() <= 2e-2 * scale
+    assert ((got - ref).abs() > 1e-6).float().mean().item() < 0.05    # ... and almost everywhere identical
+
+
 def test_bad_arguments_fail_loudly(capi, cuda):
     d = capi.PwDesc()
     assert capi.lib.rtpose_pw_fused(C.byref(d), 1, 8, 8, None) != 0
