@@ -270,6 +270,12 @@ int rtpose_stem_conv3x3_s2_nchw(const float* x_nchw, const float* scale, const f
                                 const float* w, const float* bias, float* out,
                                 const rtpose_layout* lout, int cout, int N, int H, int W,
                                 int relu, void* stream);
+/* The stem conv AND the max-pool that follows it (:96-99) in one launch: the 184 x 184 x 24 conv tensor is
+ * never stored.  out: fp32 or (out_bf16) bf16 NHWC layout of the pooled map; scale/shift = the input
+ * BatchNorm2d(3) or NULL; w packed [ky][kx][8][24] as for rtpose_stem_conv3x3_s2. */
+int rtpose_stem_pool_nchw(const float* x_nchw, const float* scale, const float* shift, const float* w,
+                          const float* bias, void* out, const rtpose_layout* lout, int cout, int N,
+                          int H, int W, int out_bf16, void* stream);
 int rtpose_stem_conv3x3_s2_nchw_ex(const float* x_nchw, const float* scale, const float* shift,
                                    const float* w, const float* bias, void* out,
                                    const rtpose_layout* lout, int cout, int N, int H, int W,

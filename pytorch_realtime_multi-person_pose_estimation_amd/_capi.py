@@ -102,6 +102,7 @@ _SIGS = {
     "rtpose_stem_conv3x3_s2": (_i, [_vp, _LP, _vp, _vp, _vp, _LP, _i, _i, _i, _i, _i, _i, _vp]),
     "rtpose_stem_conv3x3_s2_nchw": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
     "rtpose_stem_conv3x3_s2_nchw_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _LP, _i, _i, _i, _i, _i, _i, _vp]),
+    "rtpose_stem_pool_nchw": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
     "rtpose_maxpool3x3s2_ceil_bf16": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, _i, _vp]),
     "rtpose_dwconv3x3_bf16": (_i, [_vp, _LP, _vp, _vp, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
     "rtpose_layout_copy_cmap_bf16": (_i, [_vp, _LP, _vp, _LP, _i, _vp, _i, _i, _i, _vp]),

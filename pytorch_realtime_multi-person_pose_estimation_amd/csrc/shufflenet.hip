@@ -98,7 +98,7 @@ struct SBuf {
   int C = 0, H = 0, W = 0;
 };
 
-enum OKind { O_INPUT, O_STEM, O_POOL3, O_DW, O_PW, O_COPYMAP, O_PWF };
+enum OKind { O_INPUT, O_STEM, O_POOL3, O_DW, O_PW, O_COPYMAP, O_PWF, O_STEMPOOL };
 
 struct SOp {
   OKind kind;
@@ -299,7 +299,7 @@ void build(rtpose_shufflenet* n) {
   const int L_aff = add_layer(n, L_AFFINE, "network.0", 3, 3, 8, -1);
   const int L_stem = add_layer(n, L_STEM, "network.1", 24, 3, 8, -1);
   const int X0 = -1;  // (no NHWC staging of the image: the stem conv reads the NCHW input itself)
-  const int S1 = add_buf(n, 24, 0, H1, W1);
+  // (the stem conv's own 184 x 184 x 24 output does not exist: conv + max-pool are one launch)
   const int X1 = add_buf(n, up8(24), 1, H2, W2);  // (channels past 24 stay zero: a 1x1 conv reads them)
   {
     SOp o;
@@ -311,25 +311,16 @@ void build(rtpose_shufflenet* n) {
     o.out_buf[0] = X0;
     n->ops.push_back(o);
     SOp s;
-    s.kind = O_STEM;
-    s.name = "stage1/conv";
+    s.kind = O_STEMPOOL;
+    s.name = "stage1/conv+pool";
     s.H = H0;
     s.W = W0;
     s.layer[0] = L_stem;
     s.in_buf[0] = X0;
-    s.out_buf[0] = S1;
+    s.out_buf[0] = X1;
     s.relu = 1;
     s.flops = 2.0 * n->N * H1 * W1 * 24.0 * 27;
     n->ops.push_back(s);
-    SOp p;
-    p.kind = O_POOL3;
-    p.name = "stage1/pool";
-    p.H = H1;
-    p.W = W1;
-    p.in_buf[0] = S1;
-    p.out_buf[0] = X1;
-    p.C = 24;
-    n->ops.push_back(p);
   }
 
   // ---- stages ------------------------------------------------------------------------
@@ -725,6 +716,14 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
         rc = rtpose_stem_conv3x3_s2_nchw_ex(x_nchw, n->wt + la.w_off, n->wt + la.b_off, n->wt + l.w_off,
                                             n->wt + l.b_off, n->ws + bo.off, &bo.lay, l.cout, n->N, o.H, o.W,
                                             o.relu, n->bf16, stream);
+        break;
+      }
+      case O_STEMPOOL: {
+        const SBuf& bo = n->bufs[o.out_buf[0]];
+        const SLayer& l = n->layers[o.layer[0]];
+        const SLayer& la = n->layers[n->ops[0].layer[0]];  // the input BatchNorm2d(3) as scale / shift
+        rc = rtpose_stem_pool_nchw(x_nchw, n->wt + la.w_off, n->wt + la.b_off, n->wt + l.w_off, n->wt + l.b_off,
+                                   n->ws + bo.off, &bo.lay, l.cout, n->N, o.H, o.W, n->bf16, stream);
         break;
       }
       case O_POOL3: {

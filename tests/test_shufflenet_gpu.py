@@ -2,6 +2,7 @@
 kernels in csrc/layout_ops.hip) against the oracle restatement and the golden outputs of the
 reference module (imported unmodified through the slim stub; parity unpinned w.r.t. the real slim)."""
 import ctypes as C
+import ctypes as C_
 import importlib
 import os
 
@@ -193,3 +194,42 @@ def test_full_size_batch128_config4(net_sd, cuda):
     scale = max(1.0, paf_r.abs().max().item(), heat_r.abs().max().item())
     assert (paf[idx].cpu() - paf_r).abs().max().item() <= 1e-3 * scale
     assert (heat[idx].cpu() - heat_r).abs().max().item() <= 1e-3 * scale
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 368, 368), (3, 3, 97, 131), (1, 3, 64, 40)])
+def test_stem_and_pool_in_one_launch(capi, cuda, shape):
+    """rtpose_stem_pool_nchw == BatchNorm2d(3) (as scale / shift) -> conv 3x3 s2 p1 (+bias, BN folded) -> ReLU ->
+    MaxPool2d(3, 2, 0, ceil_mode=True) of plain torch (rtpose_shufflenetV2.py:96-99), fp32 and bf16 output;
+    odd sizes exercise the ceil-mode windows that hang over the conv map and partial tiles."""
+    g = torch.Generator().manual_seed(shape[2])
+    n, _, H, W = shape
+    x = torch.rand(shape, generator=g) - 0.5
+    scale, shift = torch.rand(3, generator=g) + 0.5, torch.randn(3, generator=g) * 0.1
+    w = torch.randn(24, 3, 3, 3, generator=g) * 0.3
+    b = torch.randn(24, generator=g) * 0.1
+    xa = x * scale.view(1, 3, 1, 1) + shift.view(1, 3, 1, 1)
+    ref = F.max_pool2d(F.relu(F.conv2d(xa, w, b, stride=2, padding=1)), 3, 2, 0, ceil_mode=True)
+    H2, W2 = ref.shape[2], ref.shape[3]
+    wp = torch.zeros(3, 3, 8, 24)
+    wp[:, :, :3, :] = w.permute(2, 3, 1, 0)                 # packed [ky][kx][cin_pad 8][cout]
+    d = [t.contiguous().to(cuda) for t in (x, scale, shift, wp, b)]
+    for bf16, C in ((0, 24), (1, 32)):
+        lay = capi.Layout.padded(C, H2, W2, 1)
+        npix = capi.lib.rtpose_layout_pixels(C_.byref(lay), n, H2, W2)
+        out = torch.zeros(npix * C, dtype=torch.int16 if bf16 else torch.float32, device=cuda)
+        capi.check(capi.lib.rtpose_stem_pool_nchw(capi.ptr(d[0]), capi.ptr(d[1]), capi.ptr(d[2]), capi.ptr(d[3]),
+                                                  capi.ptr(d[4]), capi.ptr(out), C_.byref(lay), 24, n, H, W, bf16,
+                                                  capi.current_stream()), "rtpose_stem_pool_nchw")
+        if bf16:
+            f = torch.zeros(npix * C, device=cuda)
+            capi.check(capi.lib.rtpose_layout_bf16_to_f32(capi.ptr(out), C_.byref(lay), capi.ptr(f), C_.byref(lay), C, n,
+                                                          H2, W2, capi.current_stream()))
+            out = f
+        got = torch.empty(n, C, H2, W2, device=cuda)
+        capi.check(capi.lib.rtpose_layout_to_nchw(capi.ptr(out), C_.byref(lay), capi.ptr(got), C, n, H2, W2,
+                                                  capi.current_stream()))
+        got = got.cpu()
+        assert got[:, 24:].abs().max().item() == 0.0 if C > 24 else True
+        tol = 1e-2 if bf16 else 1e-5
+        assert (got[:, :24] - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (bf16, shape)
+        assert abs(out.abs().sum().item() - got.abs().sum().item()) <= 1e-3 * got.abs().sum().item()   # gaps untouched
