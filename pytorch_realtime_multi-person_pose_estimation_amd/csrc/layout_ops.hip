@@ -441,7 +441,7 @@ __global__ void stem_conv3x3_s2_nchw_kernel(const float* __restrict__ x, const f
 // Stem conv + max-pool in ONE launch (rtpose_shufflenetV2.py:96-99: BatchNorm2d(3) -> conv 3x3 s2 p1 + BN +
 // ReLU -> MaxPool2d(3, 2, 0, ceil_mode=True)).  A block owns an 8 x 8 tile of pool outputs: it stages the
 // 35 x 35 x 3 input patch (affine applied, zero outside the image: the conv's padding comes after the
-// BatchNorm) and the 27 x 24 filter in LDS, evaluates the 17 x 17 x 24 conv outputs the tile's windows
+// BatchNorm) in LDS, evaluates the 17 x 17 x 24 conv outputs the tile's windows
 // touch (13 % recomputed at tile borders) into LDS, and writes the window maxima.  The 184 x 184 x 24
 // stem tensor (416 MB fp32 / 208 MB bf16 at batch 128) is never stored: the two launches it replaces
 // cost 0.60 (fp32) / 0.52 ms (bf16) of a 10.5 / 4.7 ms forward.
@@ -457,55 +457,70 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
                                                         const float* __restrict__ bias, void* __restrict__ out_v,
                                                         Lay lo, int H, int W, int H1, int W1, int H2, int W2) {
   __shared__ float s_in[3][kSpI][kSpIP];
-  __shared__ float s_w[27][kSpC];
-  __shared__ float s_b[kSpC];
   __shared__ float s_st[kSpS * kSpS][kSpCP];
   const int tid = threadIdx.x;
   const int n = blockIdx.z;
   const int py0 = blockIdx.y * kSpT, px0 = blockIdx.x * kSpT;
   const int sy0 = 2 * py0, sx0 = 2 * px0;        // first conv output of the tile
   const int iy0 = 2 * sy0 - 1, ix0 = 2 * sx0 - 1;  // first input pixel of the tile (may be -1: padding)
-  for (int i = tid; i < 27 * kSpC; i += 256) {
-    const int ch = i % kSpC, t = i / kSpC;          // t = (ky*3 + kx)*3 + c  <-  packed [ky][kx][8][24]
-    const int c = t % 3, tap = t / 3;
-    s_w[t][ch] = w[(size_t)(tap * 8 + c) * kSpC + ch];
-  }
-  if (tid < kSpC) s_b[tid] = bias[tid];
-  for (int i = tid; i < 3 * kSpI * kSpI; i += 256) {
-    const int xx = i % kSpI;
-    int r = i / kSpI;
-    const int yy = r % kSpI, c = r / kSpI;
-    const int iy = iy0 + yy, ix = ix0 + xx;
-    float v = 0.f;
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-      v = x[((size_t)n * 3 + c) * H * W + (size_t)iy * W + ix];
-      if (scale) v = v * scale[c] + shift[c];
+  {  // the input patch: all of a thread's loads are issued before the first is used (one memory round trip
+     // per block instead of fifteen)
+    constexpr int NL = (3 * kSpI * kSpI + 255) / 256;
+    float v[NL];
+    const float sc[3] = {scale ? scale[0] : 1.f, scale ? scale[1] : 1.f, scale ? scale[2] : 1.f};
+    const float sh[3] = {scale ? shift[0] : 0.f, scale ? shift[1] : 0.f, scale ? shift[2] : 0.f};
+    const float* xn = x + (size_t)n * 3 * H * W;
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {  // branch-free: clamped addresses, masked afterwards
+      const int i = min(tid + 256 * u, 3 * kSpI * kSpI - 1);
+      const int xx = i % kSpI;
+      const int r = i / kSpI;
+      const int yy = r % kSpI, c = r / kSpI;
+      const int iy = iy0 + yy, ix = ix0 + xx;
+      const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const float t = xn[(unsigned)(c * H + min(max(iy, 0), H - 1)) * (unsigned)W + (unsigned)min(max(ix, 0), W - 1)];
+      const float a = c == 0 ? sc[0] : (c == 1 ? sc[1] : sc[2]), b = c == 0 ? sh[0] : (c == 1 ? sh[1] : sh[2]);
+      v[u] = in ? t * a + b : 0.f;
     }
-    s_in[c][yy][xx] = v;
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int i = tid + 256 * u;
+      if (i < 3 * kSpI * kSpI) {
+        const int xx = i % kSpI;
+        const int r = i / kSpI;
+        s_in[r / kSpI][r % kSpI][xx] = v[u];
+      }
+    }
   }
   __syncthreads();
-  // conv outputs: item = (position, 12-channel half)
-  for (int it = tid; it < 2 * kSpS * kSpS; it += 256) {
-    const int half = it / (kSpS * kSpS), p = it - half * (kSpS * kSpS);
-    const int sy = p / kSpS, sx = p - sy * kSpS;
-    float acc[12];
+  // conv outputs: a wave owns one 12-channel half (wave & 1) of the positions (wave >> 1) * 64 + lane + 128 k.
+  // The half is uniform per wave, so the 27 x 12 filter taps are SCALAR loads (SGPR operands of the FMAs):
+  // with the taps in LDS the kernel was LDS-instruction bound (4 LDS reads per 12 FMAs, 0.50 ms).
+  {
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wv & 1;
+    const float* wh = w + half * 12;
+    for (int p = (wv >> 1) * 64 + (tid & 63); p < kSpS * kSpS; p += 128) {
+      const int sy = p / kSpS, sx = p - sy * kSpS;
+      float acc[12];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) acc[j] = s_b[half * 12 + j];
+      for (int j = 0; j < 12; ++j) acc[j] = bias[half * 12 + j];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+      for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx)
+        for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float v = s_in[c][2 * sy + ky][2 * sx + kx];
-          const float* wr = &s_w[(ky * 3 + kx) * 3 + c][half * 12];
+          for (int c = 0; c < 3; ++c) {
+            const float v = s_in[c][2 * sy + ky][2 * sx + kx];
+            const float* wr = wh + ((ky * 3 + kx) * 8 + c) * kSpC;  // packed [ky][kx][8][24]: uniform address
 #pragma unroll
-          for (int j = 0; j < 12; ++j) acc[j] += v * wr[j];
-        }
-    // conv outputs outside the 184 x 184 map do not exist: -inf so that the (ceil-mode) windows ignore them
-    const bool ok = sy0 + sy < H1 && sx0 + sx < W1;
+            for (int j = 0; j < 12; ++j) acc[j] += v * wr[j];
+          }
+      // conv outputs outside the 184 x 184 map do not exist: -inf so that the (ceil-mode) windows ignore them
+      const bool ok = sy0 + sy < H1 && sx0 + sx < W1;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) s_st[p][half * 12 + j] = ok ? fmaxf(acc[j], 0.f) : -INFINITY;
+      for (int j = 0; j < 12; ++j) s_st[p][half * 12 + j] = ok ? fmaxf(acc[j], 0.f) : -INFINITY;
+    }
   }
   __syncthreads();
   // window maxima: item = (pool output, 8-channel group)
