@@ -69,7 +69,10 @@ constexpr int kPwBM = 64;   // pixels per block
 constexpr int kPwQS = 66;   // LDS plane stride of the A tile (pixels): planes 8 banks apart
 constexpr int kPwPL = 8;    // 16-byte channel-group planes per K chunk (32 channels)
 constexpr int kPwMaxK = 1024; // largest K (s_plane table)
-constexpr int kPwMaxStage = 8;  // DW: staged 16-byte pieces per thread per chunk (<= 256 halo pixels)
+constexpr int kPwMaxStage = 4;  // DW: staged 16-byte pieces per thread per chunk (the 10 x 10 halo of an 8 x 8 tile)
+constexpr int kPwTile = 8;      // DW: the block's 64 pixels are an 8 x 8 tile (halo 100 pixels = 1.56x; a 64-pixel strip of
+                                // a 46-wide map needed 209 = 3.3x)
+constexpr int kPwHalo = kPwTile + 2;
 
 #define RTPOSE_PW_PIN()          \
   asm volatile("" ::: "memory"); \
@@ -114,7 +117,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
   const int nch = (A.K + 31) >> 5;
   const int gtot = A.K >> 3;  // 8-channel k-groups in all
   const int npass = A.coutp / BN;
-  const int nwork = ((A.M + kPwBM - 1) / kPwBM) * npass;
+  const int tiles_x = (A.W + kPwTile - 1) / kPwTile, tiles_y = (A.H + kPwTile - 1) / kPwTile;  // DW: 8 x 8 tiles of one image
+  const int nwork = (DW ? A.N * tiles_y * tiles_x : (A.M + kPwBM - 1) / kPwBM) * npass;
   const float4* w4 = reinterpret_cast<const float4*>(A.w);
   // Addresses are a uniform (scalar) base + a 32-bit per-lane element offset: the loads take the
   // SGPR-base form and no 64-bit address pairs are kept per piece (the host checks that every tensor
@@ -126,38 +130,57 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
   //   DW = 1: the strip's halo = pixels [q_org, q_org + np) x 8 planes, piece u = (px + 32 u, pl), u < n_st;
   //           sp[u] = halo-relative index of the thread's two depthwise output pixels
   struct Item {
-    int m0, pass;
-    int q0, q1;      // DW = 0: q[0], q[1];  DW = 1: q_org, np
-    int sp0, sp1;    // DW = 1
+    int m0, pass;    // DW = 0: first pixel of the strip
+    int n, y0, x0;   // DW = 1: image and first pixel of the 8 x 8 tile
+    int q0, q1;      // DW = 0: the thread's two pixels;  DW = 1: q0 = pixel index of the halo's corner (y0-1, x0-1)
   };
   auto setup = [&](int wi) -> Item {
     Item it;
     const int tile = wi / npass;
     it.pass = wi - tile * npass;
     it.m0 = tile * kPwBM;
-    const int ma = min(it.m0 + px, A.M - 1), mb = min(it.m0 + px + 32, A.M - 1);  // rows past the end replay the last pixel
-    const int qa = pw_pix_q(ma, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
-    const int qb = pw_pix_q(mb, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
+    it.n = it.y0 = it.x0 = 0;
     if (DW) {
-      const int qf = pw_pix_q(it.m0, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
-      const int ql = pw_pix_q(min(it.m0 + kPwBM - 1, A.M - 1), HW, A.W, A.in.lead, A.in.hs, A.in.ws);
-      it.q0 = qf - A.in.ws - 1;
-      it.q1 = ql + A.in.ws + 1 - it.q0 + 1;
-      it.sp0 = qa - it.q0;
-      it.sp1 = qb - it.q0;
+      const int tx = tile % tiles_x, r = tile / tiles_x;
+      const int ty = r % tiles_y;
+      it.n = r / tiles_y;
+      it.y0 = ty * kPwTile;
+      it.x0 = tx * kPwTile;
+      it.q0 = A.in.lead + (it.n * A.in.hs + it.y0 - 1) * A.in.ws + it.x0 - 1;  // >= 0: lead = ws + 1
+      it.q1 = 0;
     } else {
-      it.q0 = qa;
-      it.q1 = qb;
-      it.sp0 = it.sp1 = 0;
+      const int ma = min(it.m0 + px, A.M - 1), mb = min(it.m0 + px + 32, A.M - 1);  // rows past the end replay the last pixel
+      it.q0 = pw_pix_q(ma, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
+      it.q1 = pw_pix_q(mb, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
     }
     return it;
   };
-  auto write_tables = [&](const Item& it, int par) {  // threads 0..63
-    const int m = it.m0 + tid;
-    const int mc = min(m, A.M - 1);
-    s_qout[par][tid] = m < A.M ? pw_pix_q(mc, HW, A.W, A.out_lead, A.out_hs, A.out_ws) : -1;
-    s_qpt[par][tid] = A.pt.base ? pw_pix_q(mc, HW, A.W, A.pt.lead, A.pt.hs, A.pt.ws) : 0;
+  auto write_tables = [&](const Item& it, int par) {  // threads 0..63: output / pass-through pixel of tile row tid
+    if (DW) {
+      const int y = it.y0 + (tid >> 3), x = it.x0 + (tid & 7);
+      const bool ok = y < A.H && x < A.W;
+      const int yc = min(y, A.H - 1), xc = min(x, A.W - 1);
+      s_qout[par][tid] = ok ? A.out_lead + (it.n * A.out_hs + yc) * A.out_ws + xc : -1;
+      s_qpt[par][tid] = A.pt.base ? A.pt.lead + (it.n * A.pt.hs + yc) * A.pt.ws + xc : 0;
+    } else {
+      const int m = it.m0 + tid;
+      const int mc = min(m, A.M - 1);
+      s_qout[par][tid] = m < A.M ? pw_pix_q(mc, HW, A.W, A.out_lead, A.out_hs, A.out_ws) : -1;
+      s_qpt[par][tid] = A.pt.base ? pw_pix_q(mc, HW, A.W, A.pt.lead, A.pt.hs, A.pt.ws) : 0;
+    }
   };
+  // DW: halo pixel (hy, hx) of the tile, hp = 10 hy + hx, sits hy * ws + hx pixels after the corner: the
+  // thread's staged pieces are hp = px + 32 u (clamped to 99) - the same offsets for every tile
+  int hoff[DW ? kPwMaxStage : 1];
+  if (DW) {
+#pragma unroll
+    for (int u = 0; u < kPwMaxStage; ++u) {
+      const int hp = min(px + 32 * u, kPwHalo * kPwHalo - 1);
+      hoff[u] = (hp / kPwHalo) * A.in.ws + hp % kPwHalo;
+    }
+  }
+  // the thread's two depthwise output pixels are tile rows px and px + 32: halo index of their tap (0, 0)
+  const int sp0 = (px >> 3) * kPwHalo + (px & 7), sp1 = sp0 + 4 * kPwHalo;
   // staged pieces of channel chunk c0 of item `it` -> registers.  Branch-free: every thread always issues
   // all its loads, pixels past the halo / channel groups past K are clamped to valid addresses (their LDS
   // slots exist and are never multiplied) - per-piece predicates put every load in its own basic block,
@@ -168,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
     if (DW) {
 #pragma unroll
       for (int u = 0; u < kPwMaxStage; ++u)
-        sr[u] = pw_gload4(in_base + ((unsigned)(it.q0 + min(px + 32 * u, it.q1 - 1)) * (unsigned)A.in.cstride + cofs));
+        sr[u] = pw_gload4(in_base + ((unsigned)(it.q0 + hoff[u]) * (unsigned)A.in.cstride + cofs));
     } else {
       sr[0] = pw_gload4(in_base + ((unsigned)it.q0 * (unsigned)A.in.cstride + cofs));
       sr[1] = pw_gload4(in_base + ((unsigned)it.q1 * (unsigned)A.in.cstride + cofs));
@@ -224,21 +247,21 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
       if (DW) {
         // park the staged halo pieces, request the next chunk's (of this item, or chunk 0 of the next)
 #pragma unroll
-        for (int u = 0; u < kPwMaxStage; ++u) st[pl * nps + px + 32 * u] = sr[u];  // (nps >= 256 pixels)
+        for (int u = 0; u < kPwMaxStage; ++u) st[pl * nps + px + 32 * u] = sr[u];  // (nps >= 128 slots)
         __syncthreads();  // halo of chunk c visible; every wave is past the previous item's epilogue
         if (c == 0 && has_next && tid < kPwBM) write_tables(nxt, par ^ 1);
         // depthwise 3x3 (+bias) -> A tile.  Tap (ky, kx) of pixel q is pixel q + (ky-1) ws + (kx-1).
         const int k4 = A.K >> 2;
         const float4* wl = dwl + min((c0 >> 2) + pl, k4 - 1);  // (groups past K: their A planes are not read)
         float4 v0 = wl[9 * k4], v1 = v0;                       // bias
-        const float4* s0 = st + pl * nps + cur.sp0 - A.in.ws - 1;
-        const float4* s1 = st + pl * nps + cur.sp1 - A.in.ws - 1;
+        const float4* s0 = st + pl * nps + sp0;
+        const float4* s1 = st + pl * nps + sp1;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
             const float4 ww = wl[(ky * 3 + kx) * k4];
-            const float4 x0 = s0[ky * A.in.ws + kx], x1 = s1[ky * A.in.ws + kx];
+            const float4 x0 = s0[ky * kPwHalo + kx], x1 = s1[ky * kPwHalo + kx];
             v0.x += x0.x * ww.x;
             v0.y += x0.y * ww.y;
             v0.z += x0.z * ww.z;
@@ -538,13 +561,11 @@ int pw_fused_launch(const rtpose_pw_desc* d, int N, int H, int W, hipStream_t s)
   a.relu = d->relu;
   size_t lds = (size_t)2 * kPwPL * kPwQS * 16;
   if (dw) {
-    if (pw_halo_stride(d->lin, H, W) > 32 * kPwMaxStage)
-      return fail(RTPOSE_E_INVAL, "pw_fused: map too wide for the fused depthwise halo (W <= ~60)");
     a.nps = 32 * kPwMaxStage + 2;  // every staged piece has a slot (unconditional parking); planes 8 banks apart
     lds += (size_t)kPwPL * a.nps * 16 + (size_t)10 * d->cin * 4;
   }
   const int npass_h = d->coutp == 64 ? 1 : (d->coutp == 128 ? 1 : d->coutp / 256);
-  const int nwork = ceil_div(a.M, kPwBM) * npass_h;
+  const int nwork = (dw ? N * ceil_div(H, kPwTile) * ceil_div(W, kPwTile) : ceil_div(a.M, kPwBM)) * npass_h;
   const int grid = nwork < 2 * device_cu_count() ? nwork : 2 * device_cu_count();  // persistent: 2 blocks per CU
   if (d->coutp == 64) return dw ? pw_launch_inst<2, 1, 1, true>(a, grid, lds, s) : pw_launch_inst<2, 1, 1, false>(a, grid, lds, s);
   if (d->coutp == 128) return dw ? pw_launch_inst<1, 2, 1, true>(a, grid, lds, s) : pw_launch_inst<1, 2, 1, false>(a, grid, lds, s);

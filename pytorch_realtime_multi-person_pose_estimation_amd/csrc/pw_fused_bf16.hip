@@ -81,7 +81,9 @@ constexpr int kBM = 64;
 constexpr int kQS = 66;
 constexpr int kPL = 8;          // 16-byte planes per K chunk (64 channels)
 constexpr int kMaxK = 1024;
-constexpr int kMaxStage = 8;
+constexpr int kMaxStage = 4;   // DW: staged pieces per thread per chunk (10 x 10 halo of an 8 x 8 tile)
+constexpr int kTile = 8;       // DW: the block's 64 pixels are an 8 x 8 tile (see pw_fused.hip)
+constexpr int kHalo = kTile + 2;
 
 #define RTPOSE_PWB_PIN()         \
   asm volatile("" ::: "memory"); \
@@ -123,43 +125,63 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16(const Args A) {
   const int nch = (A.K + 63) >> 6;
   const int kst = A.K >> 4;  // 16-channel K-steps in all
   const int npass = A.coutp / BN;
-  const int nwork = ((A.M + kBM - 1) / kBM) * npass;
+  const int tiles_x = (A.W + kTile - 1) / kTile, tiles_y = (A.H + kTile - 1) / kTile;  // DW: 8 x 8 tiles of one image
+  const int nwork = (DW ? A.N * tiles_y * tiles_x : (A.M + kBM - 1) / kBM) * npass;
   const float4* in4 = reinterpret_cast<const float4*>(A.in.base);
   const unsigned in_cs4 = (unsigned)A.in.cstride >> 3, in_co4 = (unsigned)A.in.choff >> 3;
 
   struct Item {
-    int m0, pass;
-    int q0, q1;    // DW = 0: the thread's two pixels;  DW = 1: halo origin, halo pixels
-    int sp0, sp1;  // DW = 1: halo-relative index of the thread's two depthwise output pixels
+    int m0, pass;    // DW = 0: first pixel of the strip
+    int n, y0, x0;   // DW = 1: image and first pixel of the 8 x 8 tile
+    int q0, q1;      // DW = 0: the thread's two pixels;  DW = 1: q0 = pixel index of the halo's corner (y0-1, x0-1)
   };
   auto setup = [&](int wi) -> Item {
     Item it;
     const int tile = wi / npass;
     it.pass = wi - tile * npass;
     it.m0 = tile * kBM;
-    const int ma = min(it.m0 + px, A.M - 1), mb = min(it.m0 + px + 32, A.M - 1);
-    const int qa = pix_q(ma, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
-    const int qb = pix_q(mb, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
+    it.n = it.y0 = it.x0 = 0;
     if (DW) {
-      const int qf = pix_q(it.m0, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
-      const int ql = pix_q(min(it.m0 + kBM - 1, A.M - 1), HW, A.W, A.in.lead, A.in.hs, A.in.ws);
-      it.q0 = qf - A.in.ws - 1;
-      it.q1 = ql + A.in.ws + 1 - it.q0 + 1;
-      it.sp0 = qa - it.q0;
-      it.sp1 = qb - it.q0;
+      const int tx = tile % tiles_x, r = tile / tiles_x;
+      const int ty = r % tiles_y;
+      it.n = r / tiles_y;
+      it.y0 = ty * kTile;
+      it.x0 = tx * kTile;
+      it.q0 = A.in.lead + (it.n * A.in.hs + it.y0 - 1) * A.in.ws + it.x0 - 1;  // >= 0: lead = ws + 1
+      it.q1 = 0;
     } else {
-      it.q0 = qa;
-      it.q1 = qb;
-      it.sp0 = it.sp1 = 0;
+      const int ma = min(it.m0 + px, A.M - 1), mb = min(it.m0 + px + 32, A.M - 1);  // rows past the end replay the last pixel
+      it.q0 = pix_q(ma, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
+      it.q1 = pix_q(mb, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
     }
     return it;
   };
-  auto write_tables = [&](const Item& it, int par) {  // threads 0..63
-    const int m = it.m0 + tid;
-    const int mc = min(m, A.M - 1);
-    s_qout[par][tid] = m < A.M ? pix_q(mc, HW, A.W, A.out_lead, A.out_hs, A.out_ws) : -1;
-    s_qpt[par][tid] = A.pt.base ? pix_q(mc, HW, A.W, A.pt.lead, A.pt.hs, A.pt.ws) : 0;
+  auto write_tables = [&](const Item& it, int par) {  // threads 0..63: output / pass-through pixel of tile row tid
+    if (DW) {
+      const int y = it.y0 + (tid >> 3), x = it.x0 + (tid & 7);
+      const bool ok = y < A.H && x < A.W;
+      const int yc = min(y, A.H - 1), xc = min(x, A.W - 1);
+      s_qout[par][tid] = ok ? A.out_lead + (it.n * A.out_hs + yc) * A.out_ws + xc : -1;
+      s_qpt[par][tid] = A.pt.base ? A.pt.lead + (it.n * A.pt.hs + yc) * A.pt.ws + xc : 0;
+    } else {
+      const int m = it.m0 + tid;
+      const int mc = min(m, A.M - 1);
+      s_qout[par][tid] = m < A.M ? pix_q(mc, HW, A.W, A.out_lead, A.out_hs, A.out_ws) : -1;
+      s_qpt[par][tid] = A.pt.base ? pix_q(mc, HW, A.W, A.pt.lead, A.pt.hs, A.pt.ws) : 0;
+    }
   };
+  // DW: halo pixel (hy, hx) of the tile, hp = 10 hy + hx, sits hy * ws + hx pixels after the corner: the
+  // thread's staged pieces are hp = px + 32 u (clamped to 99) - the same offsets for every tile
+  int hoff[DW ? kMaxStage : 1];
+  if (DW) {
+#pragma unroll
+    for (int u = 0; u < kMaxStage; ++u) {
+      const int hp = min(px + 32 * u, kHalo * kHalo - 1);
+      hoff[u] = (hp / kHalo) * A.in.ws + hp % kHalo;
+    }
+  }
+  // the thread's two depthwise output pixels are tile rows px and px + 32: halo index of their tap (0, 0)
+  const int sp0 = (px >> 3) * kHalo + (px & 7), sp1 = sp0 + 4 * kHalo;
   // staged pieces of channel chunk c0 (a multiple of 64) of item `it` -> registers; branch-free, clamped
   float4 sr[DW ? kMaxStage : 2];
   auto load_pieces = [&](const Item& it, int c0) {
@@ -167,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16(const Args A) {
     if (DW) {
 #pragma unroll
       for (int u = 0; u < kMaxStage; ++u)
-        sr[u] = gload4(in4 + ((unsigned)(it.q0 + min(px + 32 * u, it.q1 - 1)) * in_cs4 + cofs));
+        sr[u] = gload4(in4 + ((unsigned)(it.q0 + hoff[u]) * in_cs4 + cofs));
     } else {
       sr[0] = gload4(in4 + ((unsigned)it.q0 * in_cs4 + cofs));
       sr[1] = gload4(in4 + ((unsigned)it.q1 * in_cs4 + cofs));
@@ -219,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16(const Args A) {
       const bool last = c + 1 == nch;
       if (DW) {
 #pragma unroll
-        for (int u = 0; u < kMaxStage; ++u) st[pl * nps + px + 32 * u] = sr[u];  // (nps >= 256 pixels)
+        for (int u = 0; u < kMaxStage; ++u) st[pl * nps + px + 32 * u] = sr[u];  // (nps >= 128 slots)
         __syncthreads();  // halo of chunk c visible; every wave is past the previous item's epilogue slabs
         if (c == 0 && has_next && tid < kBM) write_tables(nxt, par ^ 1);
         // depthwise 3x3 (+bias) in fp32 on the 8 channels of this thread's plane, two pixels; rounded to bf16
@@ -234,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16(const Args A) {
             const float4 b1 = *reinterpret_cast<const float4*>(dwl + 9 * A.K + ch + 4);
             v[0] = b0.x, v[1] = b0.y, v[2] = b0.z, v[3] = b0.w, v[4] = b1.x, v[5] = b1.y, v[6] = b1.z, v[7] = b1.w;
           }
-          const float4* s0 = st + pl * nps + (u ? cur.sp1 : cur.sp0) - A.in.ws - 1;
+          const float4* s0 = st + pl * nps + (u ? sp1 : sp0);
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
@@ -243,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16(const Args A) {
               const float4 w1 = *reinterpret_cast<const float4*>(dwl + (ky * 3 + kx) * A.K + ch + 4);
               const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
               float x[8];
-              unpack8(s0[ky * A.in.ws + kx], x);
+              unpack8(s0[ky * kHalo + kx], x);
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] += x[e] * ww[e];
             }
@@ -543,14 +565,12 @@ int pw_fused_bf16_launch(const rtpose_pw_desc* d, int out_f32, int N, int H, int
   const size_t slab4 = (size_t)4 * 32 * mf * ((32 * nfw + 8) / 8);
   size_t st4 = slab4;
   if (dw) {
-    if (halo_stride(d->lin, H, W) > 32 * kMaxStage)
-      return fail(RTPOSE_E_INVAL, "pw_fused_bf16: map too wide for the fused depthwise halo (W <= ~60)");
     a.nps = 32 * kMaxStage + 2;
     if ((size_t)kPL * a.nps > st4) st4 = (size_t)kPL * a.nps;
   }
   const size_t lds = ((size_t)2 * kPL * kQS + st4) * 16 + (dw ? (size_t)10 * d->cin * 4 : 0);
   const int npass_h = d->coutp <= 128 ? 1 : d->coutp / 256;
-  const int nwork = ceil_div(a.M, kBM) * npass_h;
+  const int nwork = (dw ? N * ceil_div(H, kTile) * ceil_div(W, kTile) : ceil_div(a.M, kBM)) * npass_h;
   const int grid = nwork < 2 * device_cu_count() ? nwork : 2 * device_cu_count();
   if (d->coutp == 64) return dw ? launch_inst<2, 1, 1, true>(a, grid, lds, s) : launch_inst<2, 1, 1, false>(a, grid, lds, s);
   if (d->coutp == 128) return dw ? launch_inst<1, 2, 1, true>(a, grid, lds, s) : launch_inst<1, 2, 1, false>(a, grid, lds, s);

@@ -103,7 +103,8 @@ def test_pointwise_only(capi, cuda, cin, cout, coutp):
 def test_depthwise_then_pointwise(capi, cuda, cin, cout, coutp):
     _run(capi, cuda, 3, 13, 17, cin, cout, coutp, dw=True, relu=True, seed=cin)
     _run(capi, cuda, 2, 46, 46, cin, cout, coutp, dw=True, relu=True, seed=cin + 1)
-    _run(capi, cuda, 1, 5, 60, cin, cout, coutp, dw=True, relu=False, seed=cin + 2)       # widest map that still fuses
+    _run(capi, cuda, 1, 5, 60, cin, cout, coutp, dw=True, relu=False, seed=cin + 2)       # H < one 8 x 8 tile
+    _run(capi, cuda, 2, 19, 133, cin, cout, coutp, dw=True, relu=True, seed=cin + 3)      # wide map, ragged tiles
 
 
 @pytest.mark.parametrize("c", [58, 116, 232])
@@ -187,9 +188,6 @@ def test_unit_in_the_four_run_layout(capi, cuda, h, w_map):
     d2.out_cmap = odd.data_ptr()
     d2.pt_src, d2.lpt = cur.data_ptr(), lay
     d2.pt_pairs, d2.pt_a, d2.pt_b, d2.pt_split, d2.pt_d0, d2.pt_d1 = hh_, 0, 2 * q, hh_, 0, q
-    if w_map > 60:      # too wide for the in-kernel depthwise halo: must be refused, not mis-computed
-        assert capi.lib.rtpose_pw_fused(C.byref(d2), n, H, w_map, capi.current_stream()) != 0
-        return
     capi.check(capi.lib.rtpose_pw_fused(C.byref(d2), n, H, w_map, capi.current_stream()), "conv.1+conv.2+x1")
     got = _from_layout(capi, nxt, lay, C4, n, H, w_map, cuda)[:, perm]
     scale = max(1.0, ref.abs().max().item())
