@@ -214,6 +214,24 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
   }
   int par = 0;   // work-item parity (tables)
   int lbuf = 0;  // LDS chunk-buffer parity, runs on across work items
+  // Plain pointwise variants with <= 128 columns (BAHEAD) fetch B a whole CHUNK ahead (4 k-groups, 16 VGPRs more):
+  // the counter behind s_waitcnt is in order, so with B only one k-group ahead every wait for a weight
+  // fragment also waited for the chunk's staging loads (activations from HBM, issued just before it) - the
+  // waves stalled on memory in the middle of every chunk.  Now everything a chunk's MFMAs read was requested
+  // before the previous chunk was multiplied (stage-3 conv.0 0.115 -> 0.100 ms, heads 0.46 -> 0.37 ms).  The
+  // 256-column variant does not have the registers: with 32 more it spilled inside the tap loop (0.31 -> 0.44 ms).
+  constexpr bool BAHEAD = !DW && NFW == 1;
+  float4 bw_cur[BAHEAD ? 4 : 1][NFW], bw_nxt[BAHEAD ? 4 : 1][NFW];
+  if (BAHEAD) {
+    const unsigned wl0 = (unsigned)(kh * A.coutp + cur.pass * BN + wn * (32 * NFW) + l31);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int fn = 0; fn < NFW; ++fn) {
+        bw_cur[g][fn] = pw_gload4(w4 + (size_t)(2 * min(g, gtot - 1) * A.coutp) + (wl0 + fn * 32));
+        bw_nxt[g][fn] = bw_cur[g][fn];
+      }
+  }
 
   while (true) {
     const int wnext = wi + gridDim.x;
@@ -283,6 +301,15 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
       } else {
         a_buf[pl * kPwQS + px] = sr[0];
         a_buf[pl * kPwQS + px + 32] = sr[1];
+        if (BAHEAD) {  // B of the next chunk (of this item, or chunk 0 of the next item's columns), BEFORE the staging loads
+          const int gnext = last ? 0 : 4 * (c + 1);
+          const unsigned wl = (unsigned)(kh * A.coutp + (last ? nxt.pass : cur.pass) * BN + wn * (32 * NFW) + l31);
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int fn = 0; fn < NFW; ++fn)
+              bw_nxt[g][fn] = pw_gload4(w4 + (size_t)(2 * min(gnext + g, gtot - 1) * A.coutp) + (wl + fn * 32));
+        }
         load_pieces(last ? nxt : cur, last ? 0 : c0 + 32);  // (no next item: nxt == cur, a harmless re-read)
         __syncthreads();  // A tile of chunk c visible (the other buffer was last read before the previous barrier)
         if (c == 0 && has_next && tid < kPwBM) write_tables(nxt, par ^ 1);
@@ -318,6 +345,32 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
       const int gg = 4 * c, gl = gtot - 1;
       float4 a0[MF], a1[MF];
       RTPOSE_PW_ALOAD(a0, 0);
+      if (BAHEAD) {
+        RTPOSE_PW_ALOAD(a1, 1);
+        RTPOSE_PW_PIN();
+        RTPOSE_PW_MUL(a0, bw_cur[0]);
+        RTPOSE_PW_PIN();
+        if (ng > 1) {
+          RTPOSE_PW_ALOAD(a0, 2);
+          RTPOSE_PW_PIN();
+          RTPOSE_PW_MUL(a1, bw_cur[1]);
+          RTPOSE_PW_PIN();
+        }
+        if (ng > 2) {
+          RTPOSE_PW_ALOAD(a1, 3);
+          RTPOSE_PW_PIN();
+          RTPOSE_PW_MUL(a0, bw_cur[2]);
+          RTPOSE_PW_PIN();
+        }
+        if (ng > 3) {
+          RTPOSE_PW_MUL(a1, bw_cur[3]);
+          RTPOSE_PW_PIN();
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int fn = 0; fn < NFW; ++fn) bw_cur[g][fn] = bw_nxt[g][fn];
+      } else {
       RTPOSE_PW_BLOAD(bnxt, min(gg + 1, gl));
       RTPOSE_PW_ALOAD(a1, 1);
       RTPOSE_PW_PIN();
@@ -343,6 +396,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
         RTPOSE_PW_MUL(a1, bnxt);
         RTPOSE_PW_PIN();
       }
+      }  // BAHEAD
 #undef RTPOSE_PW_MUL
 #undef RTPOSE_PW_ALOAD
 #undef RTPOSE_PW_BLOAD
