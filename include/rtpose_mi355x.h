@@ -118,6 +118,22 @@ typedef struct rtpose_conv_desc {
 int rtpose_conv2d(const rtpose_conv_desc* d, int ngroups, int N, int H, int W,
                   void* stream);
 
+/* ---- fp32 Winograd F(2x2, 3x3) form of the 3x3 convs (csrc/conv_wino.hip) ------------------
+ * Same module boundary as rtpose_conv2d (nn.Conv2d 3x3 + nn.ReLU + nn.MaxPool2d of
+ * lib/network/rtpose_vgg.py:23-35, :49-55): 16 instead of 36 multiplies per 2 x 2 output tile and
+ * input channel, fp32 MFMA, results within a few ulp of the direct sum (contract: 1e-3).  The
+ * descriptor is rtpose_conv_desc with k = 3, `w_packed` from rtpose_pack_conv_weights_winograd
+ * (transformed filters U = G g G^T, 16/9 the size) and out_cmap = NULL.
+ * rtpose_conv2d_winograd_ok: 1 when (cin, cout, k) has a Winograd instance (k = 3 and cin a multiple
+ * of 16, or of 8 when cout <= 64 modulo 128), else 0 - callers fall back to rtpose_conv2d. */
+int rtpose_conv2d_winograd_ok(int cin, int cout, int k);
+size_t rtpose_packed_weight_floats_winograd(int cout, int cin);
+int rtpose_pack_conv_weights_winograd(const float* w_oihw, const float* bias, int cout,
+                                      int cin_src, const int32_t* cin_map, int cin_packed,
+                                      float* w_packed, float* bias_packed, void* stream);
+int rtpose_conv2d_winograd(const rtpose_conv_desc* d, int ngroups, int N, int H, int W,
+                           void* stream);
+
 /* ---- fused pointwise chain of the ShuffleNetV2 pose network (BASELINE configs[3]) ----
  * stands in for lib/network/rtpose_shufflenetV2.py BasicBlock (:22-63): conv_bn_relu 1x1, optionally
  * preceded by the conv_bn depthwise 3x3 (stride 1) that feeds it and followed by

@@ -1,0 +1,469 @@
+// fp32 Winograd F(2x2, 3x3) convolution for gfx950 (MI355X): stride 1, "same" padding, fused bias
+// (+ReLU) (+2x2 max-pool).
+//
+// Stands in for the 3x3 nn.Conv2d / nn.ReLU / nn.MaxPool2d modules of the VGG-19 front end and the
+// stage-1 branches (lib/network/rtpose_vgg.py:23-35, :49-55, :108-127) wherever the direct
+// implicit-GEMM kernel (conv_mfma.hip) is MFMA-bound: 16 multiplies per 2 x 2 output tile and input
+// channel instead of 36, i.e. 2.25x fewer matrix-core flops for results that differ from the direct
+// sum by a few ulp (Lavin & Gray's minimal filtering F(2x2, 3x3); the north-star bound is 1e-3).
+//
+//   Y = A^T [ (G g G^T) o (B^T d B) ] A        per 4 x 4 input patch d, 3 x 3 filter g, summed over cin
+//
+// MI355X shape (not a translation of any CUDA kernel):
+//  * "wtile" = one 2 x 2 output tile.  The 16 frequencies are 16 independent GEMMs
+//    [wtiles x cin] . [cin x cout]; a wave owns ALL 16 frequencies of a 32-wtile x 32-column tile
+//    = 16 v_mfma_f32_32x32x2_f32 accumulators = 256 registers (the AGPR half of the 512 a wave gets at
+//    one wave per SIMD), so the output transform A^T M A is lane-local: no cross-wave exchange, and
+//    the fused 2 x 2 max-pool is a max over the 4 outputs a lane just produced.  The bias rides in
+//    the accumulator of frequency (1,1) (A^T e11 A = all-ones).
+//  * A block = 4 waves = (32 WM) consecutive wtiles of the flattened (n, ty, tx) order x (32 WN) output
+//    columns; no 2-D tile waste on the 46 x 46 maps (23 x 23 wtiles).
+//  * Input transform: every thread loads HALF a 4 x 4 patch of 4 channels (3 rows x 4 pixels, 16-byte
+//    loads straight from the shared-gap NHWC layout: the zero gap is the conv padding), forms 8
+//    frequencies with 16 float4 adds and writes them to LDS as V[f][c/4][wtile][4] - the layout the A
+//    operand is read from with one conflict-free ds_read_b128 per 4 MFMAs.  Double-buffered per
+//    channel chunk: the patch of chunk c+2 is in flight and chunk c+1 is transformed while chunk c is
+//    multiplied; one barrier per chunk.
+//  * B operand = transformed weights U[chunk][f][c/4][cout][4], packed once
+//    (rtpose_pack_conv_weights_winograd), straight from L2 to registers two frequencies ahead.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "common.h"
+
+namespace rtpose {
+
+namespace wino {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef const floatx4 __attribute__((address_space(1)))* gcf4_t;
+__device__ __forceinline__ float4 gload4(const void* p) {
+  const floatx4 v = *(gcf4_t)(unsigned long long)(p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) {
+  return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+}
+
+struct Group {
+  const float* in;
+  const float* w;
+  const float* bias;
+  float* out;
+  int in_cstride, in_choff, in_ws, in_hs, in_lead;
+  int out_cstride, out_choff, out_ws, out_hs, out_lead;
+  int cout, cout_pad;
+};
+
+struct Args {
+  Group g[2];
+  int N, H, W;
+  int TY, TX, T;  // wtiles per column / row of an image, and in the whole batch
+  int cin;
+  int relu, pool;
+  int mtiles, ntiles, ncombo, xcd_remap;
+};
+
+template <int WM, int WN, int CK>
+__global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
+  constexpr int NT = 32 * WM;  // wtiles per block
+  constexpr int CG = CK / 4;   // 16-byte channel groups per chunk
+  constexpr int G = CK / 8;    // 8-deep k groups per chunk (4 MFMAs each)
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(NT * CG * 2 == 256, "one half patch per thread and chunk");
+  constexpr int VBUF = 16 * CG * NT;  // float4 per V buffer
+  extern __shared__ __attribute__((aligned(16))) float4 V4[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  // ---- block -> (m tile, n tile, group); XCD-aware order as in conv_mfma.hip ----------------
+  const int bi = blockIdx.x;
+  int mt, c;
+  if (A.xcd_remap) {
+    const int xcd = bi & 7, j = bi >> 3;
+    c = j % A.ncombo;
+    mt = (j / A.ncombo) * 8 + xcd;
+  } else {
+    mt = bi % A.mtiles;
+    c = bi / A.mtiles;
+  }
+  if (mt >= A.mtiles) return;
+  const int nt = c % A.ntiles, grp = c / A.ntiles;
+  const Group g = grp ? A.g[1] : A.g[0];
+  const int TT = A.TY * A.TX;
+
+  // ---- input transform role: (channel group, wtile, upper / lower half of the patch) ---------
+  // B^T over the patch rows d0..d3:  fy 0: d0 - d2,  1: d1 + d2,  2: d2 - d1,  3: d1 - d3.
+  // A thread loads three rows (R0, R1, R2) and forms  ta = R0 - R2,  tb = R2 + sgn R1:
+  //   upper half (waves 0,1): (d0, d1, d2), sgn +1 -> fy 0, 1;   lower half (waves 2,3): (d2, d3, d1), sgn -1 -> fy 2, 3
+  // - the same instruction stream for both halves, no branch inside the pinned MFMA loop.
+  const int cg = tid % CG, tl = (tid / CG) % NT;
+  const int half = __builtin_amdgcn_readfirstlane(tid / (CG * NT));
+  const float sgn = half ? -1.f : 1.f;
+  const float* pbase;
+  {
+    const int t = min(mt * NT + tl, A.T - 1);  // wtiles past the end re-read the last one
+    const int n = t / TT, r = t - n * TT;
+    const int ty = r / A.TX, tx = r - ty * A.TX;
+    const size_t q = (size_t)g.in_lead + (size_t)(n * g.in_hs + 2 * ty - 1) * g.in_ws + (2 * tx - 1);
+    pbase = g.in + q * g.in_cstride + g.in_choff + cg * 4;
+  }
+  int poff[3][4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int row = half ? (r == 0 ? 2 : r == 1 ? 3 : 1) : r;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) poff[r][x] = (row * g.in_ws + x) * g.in_cstride;
+  }
+  float4 p[3][4], ta[4], tb[4];
+  auto load_piece = [&](int chunk, int i) { p[i >> 2][i & 3] = gload4(pbase + chunk * CK + poff[i >> 2][i & 3]); };
+  auto form_ta = [&](int x) { ta[x] = p[0][x] - p[2][x]; };
+  auto form_tb = [&](int x) {
+    tb[x] = make_float4(__builtin_fmaf(sgn, p[1][x].x, p[2][x].x), __builtin_fmaf(sgn, p[1][x].y, p[2][x].y),
+                        __builtin_fmaf(sgn, p[1][x].z, p[2][x].z), __builtin_fmaf(sgn, p[1][x].w, p[2][x].w));
+  };
+  // V[f][cg][wtile], f = fy * 4 + fx; this thread writes fy in {2 half, 2 half + 1}; B^T over x as above
+  const int vst = (half * 8 * CG + cg) * NT + tl;
+  auto store_v = [&](int buf, int o) {
+    const float4* t = (o & 4) ? tb : ta;
+    const int fx = o & 3;
+    const float4 v = fx == 0 ? t[0] - t[2] : fx == 1 ? t[1] + t[2] : fx == 2 ? t[2] - t[1] : t[1] - t[3];
+    V4[buf * VBUF + vst + o * CG * NT] = v;
+  };
+
+  // ---- MFMA roles -----------------------------------------------------------------------------
+  const int ncol = nt * (32 * WN) + wn * 32 + l31;
+  const int arow = wm * 32 + l31;
+  floatx16 acc[16];
+#pragma unroll
+  for (int f = 0; f < 16; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+  {
+    const float b0 = g.bias[ncol];  // padded to cout_pad
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[5][r] = b0;
+  }
+  // B: uniform base that advances one step (2 frequencies) at a time + per-lane byte offsets
+  const char* wq = reinterpret_cast<const char*>(g.w);
+  unsigned boff[2][G];
+#pragma unroll
+  for (int fs = 0; fs < 2; ++fs)
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) boff[fs][gi] = (unsigned)(((fs * CG + 2 * gi + kh) * g.cout_pad + ncol) * 16);
+  const size_t bstep = (size_t)2 * CG * g.cout_pad * 16;  // bytes per step
+  float4 bs[4][2][G];  // [step % 4][frequency of the pair][k group]
+#pragma unroll
+  for (int fs = 0; fs < 2; ++fs)
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+      bs[0][fs][gi] = gload4(wq + boff[fs][gi]);
+      bs[1][fs][gi] = gload4(wq + bstep + boff[fs][gi]);
+    }
+  wq += 2 * bstep;
+
+  const int nchunks = A.cin / CK;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) load_piece(0, i);
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    form_ta(x);
+    form_tb(x);
+  }
+#pragma unroll
+  for (int o = 0; o < 8; ++o) store_v(0, o);
+  {
+    const int c1 = min(1, nchunks - 1);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) load_piece(c1, i);
+  }
+  __syncthreads();
+
+  // One step = the two frequencies 2s, 2s+1 = 8 G MFMAs on two alternating accumulators.  Between MFMA
+  // pairs, in a fixed (pinned) order: the A fragments of the next step (LDS), the B fragments two steps
+  // ahead (L2), and one micro-op of the input transform of the NEXT chunk: 8 adds that consume the
+  // patch registers, the 12 patch loads of the chunk after that, 8 row transforms + LDS writes.
+#define RTPOSE_PIN()             \
+  asm volatile("" ::: "memory"); \
+  __builtin_amdgcn_sched_barrier(0)
+  constexpr int SLOTS = 4 * G;  // MFMA pairs (= filler slots) per step
+  float4 a[2][2][G];            // [step % 2][frequency of the pair][k group]
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const float4* va = V4 + (chunk & 1) * VBUF + kh * NT + arow;
+    const int nbuf = (chunk + 1) & 1;
+    const int c2 = min(chunk + 2, nchunks - 1);  // the last chunks re-stage themselves (never read)
+#pragma unroll
+    for (int fs = 0; fs < 2; ++fs)
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi) a[0][fs][gi] = va[(fs * CG + 2 * gi) * NT];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+      for (int slot = 0; slot < SLOTS; ++slot) {
+        const int gi = slot >> 2, j = slot & 3;
+        {
+          const float4 a0 = a[s & 1][0][gi], a1 = a[s & 1][1][gi];
+          const float4 b0 = bs[s & 3][0][gi], b1 = bs[s & 3][1][gi];
+          const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+          const float b0v[4] = {b0.x, b0.y, b0.z, b0.w}, b1v[4] = {b1.x, b1.y, b1.z, b1.w};
+          acc[2 * s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[j], b0v[j], acc[2 * s], 0, 0, 0);
+          acc[2 * s + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[j], b1v[j], acc[2 * s + 1], 0, 0, 0);
+        }
+        RTPOSE_PIN();
+        if (slot < 2 * G) {  // A of the next step (the first step of a chunk is read after the barrier)
+          if (s < 7) a[(s + 1) & 1][slot / G][slot % G] = va[((2 * (s + 1) + slot / G) * CG + 2 * (slot % G)) * NT];
+        } else {             // B two steps ahead
+          const int i = slot - 2 * G;
+          bs[(s + 2) & 3][i / G][i % G] = gload4(wq + boff[i / G][i % G]);
+          if (slot == SLOTS - 1) wq += bstep;
+        }
+        {  // input transform micro-op
+          const int kk = s * SLOTS + slot;
+          const int op = G == 2 ? ((kk & 1) ? -1 : kk >> 1) : kk;
+          if (op >= 0 && op < 4) form_ta(op);
+          else if (op >= 4 && op < 8) form_tb(op - 4);
+          else if (op >= 8 && op < 20) load_piece(c2, op - 8);
+          else if (op >= 20 && op < 28) store_v(nbuf, op - 20);
+        }
+        RTPOSE_PIN();
+      }
+    }
+    __syncthreads();
+  }
+#undef RTPOSE_PIN
+
+  // ---- epilogue: output transform A^T M A, (+ReLU) (+2x2 max-pool), masked stores -----------------
+  // accumulator register r of a lane = wtile row (r / 4) * 8 + 4 kh + r % 4 of the wave tile, column l31
+  const bool col_ok = ncol < g.cout;
+  float* out_base = g.out + g.out_choff + ncol;
+  int sn, sy, sx;
+  {
+    const int t = mt * NT + wm * 32 + 4 * kh;
+    sn = t / TT;
+    const int r = t - sn * TT;
+    sy = r / A.TX;
+    sx = r - sy * A.TX;
+  }
+  int tcur = mt * NT + wm * 32 + 4 * kh;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float s[4][2];
+#pragma unroll
+    for (int fy = 0; fy < 4; ++fy) {
+      s[fy][0] = acc[fy * 4 + 0][r] + acc[fy * 4 + 1][r] + acc[fy * 4 + 2][r];
+      s[fy][1] = acc[fy * 4 + 1][r] - acc[fy * 4 + 2][r] - acc[fy * 4 + 3][r];
+    }
+    float y[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      y[0][x] = s[0][x] + s[1][x] + s[2][x];
+      y[1][x] = s[1][x] - s[2][x] - s[3][x];
+    }
+    if (A.relu) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[i >> 1][i & 1] = fmaxf(y[i >> 1][i & 1], 0.f);
+    }
+    const bool ok = col_ok && tcur < A.T;
+    if (A.pool) {  // H and W even: every wtile is one pooled pixel
+      const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+      if (ok) {
+        const size_t q = (size_t)g.out_lead + (size_t)(sn * g.out_hs + sy) * g.out_ws + sx;
+        out_base[q * g.out_cstride] = v;
+      }
+    } else {
+      const size_t q = (size_t)g.out_lead + (size_t)(sn * g.out_hs + 2 * sy) * g.out_ws + 2 * sx;
+      const bool x1 = 2 * sx + 1 < A.W, y1 = 2 * sy + 1 < A.H;
+      if (ok) {
+        out_base[q * g.out_cstride] = y[0][0];
+        if (x1) out_base[(q + 1) * g.out_cstride] = y[0][1];
+        if (y1) {
+          out_base[(q + g.out_ws) * g.out_cstride] = y[1][0];
+          if (x1) out_base[(q + g.out_ws + 1) * g.out_cstride] = y[1][1];
+        }
+      }
+    }
+    // next row: +1, +1, +1, +5 wtiles
+    const int d = (r & 3) == 3 ? 5 : 1;
+    tcur += d;
+    sx += d;
+    while (sx >= A.TX) {
+      sx -= A.TX;
+      if (++sy >= A.TY) {
+        sy = 0;
+        ++sn;
+      }
+    }
+  }
+}
+
+// ---- weight packing: U = G g G^T, packed[chunk][f][cg][cout_pad][4]  <-  w[cout][cin_src][3][3] -----------
+__global__ void pack_wino_kernel(const float* __restrict__ w, const float* __restrict__ bias, int cout,
+                                 int cin_src, const int32_t* __restrict__ cin_map, int cin_packed, int ck,
+                                 int coutp, float* __restrict__ wp, float* __restrict__ bp) {
+  const size_t total = (size_t)16 * cin_packed * coutp;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)coutp) bp[i] = (i < (size_t)cout && bias) ? bias[i] : 0.f;
+  if (i >= total) return;
+  const int e = i & 3;
+  size_t r = i >> 2;
+  const int n = r % coutp;
+  r /= coutp;
+  const int cg = r % (ck / 4);
+  r /= (ck / 4);
+  const int f = r % 16;
+  const int chunk = r / 16;
+  const int c = chunk * ck + cg * 4 + e;
+  const int src = cin_map ? cin_map[c] : (c < cin_src ? c : -1);
+  float v = 0.f;
+  if (n < cout && src >= 0 && src < cin_src) {
+    const float* gw = w + ((size_t)n * cin_src + src) * 9;
+    const int fy = f >> 2, fx = f & 3;
+    // rows of G: (1,0,0), (.5,.5,.5), (.5,-.5,.5), (0,0,1)
+    float col[3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      const float g0 = gw[x], g1 = gw[3 + x], g2 = gw[6 + x];
+      col[x] = fy == 0 ? g0 : fy == 1 ? 0.5f * (g0 + g1 + g2) : fy == 2 ? 0.5f * (g0 - g1 + g2) : g2;
+    }
+    v = fx == 0 ? col[0]
+        : fx == 1 ? 0.5f * (col[0] + col[1] + col[2])
+        : fx == 2 ? 0.5f * (col[0] - col[1] + col[2])
+                  : col[2];
+  }
+  wp[i] = v;
+}
+
+template <int WM, int WN, int CK>
+static int launch_inst(const Args& a, dim3 grid, hipStream_t s) {
+  static PerDeviceOnce attr_set;
+  const int dev = current_device();
+  auto kern = wino_f32<WM, WN, CK>;
+  constexpr size_t lds = (size_t)2 * 16 * (CK / 4) * (32 * WM) * 16;
+  if (!attr_set.is_set(dev)) {
+    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_set.set(dev);
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace wino
+
+// channel chunk the packed Winograd weights of a conv are laid out for (the kernel instance is chosen by
+// the padded output width: >= 128 columns -> 32 wtiles x 128 columns, 16-channel chunks; 64 -> 64 x 64, 8)
+static int wino_ck(int cout) { return cout_pad(cout) % 128 == 0 ? 16 : 8; }
+
+int conv2d_wino_ok(int cin, int cout, int k) { return k == 3 && cin > 0 && cin % wino_ck(cout) == 0; }
+
+int conv2d_wino_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s) {
+  using namespace wino;
+  if (!d || ngroups < 1 || ngroups > 2) return fail(RTPOSE_E_INVAL, "conv2d_winograd: ngroups must be 1 or 2");
+  const rtpose_conv_desc& d0 = d[0];
+  if (!conv2d_wino_ok(d0.cin, d0.cout, d0.k))
+    return fail(RTPOSE_E_INVAL, "conv2d_winograd: k must be 3 and cin a multiple of %d", wino_ck(d0.cout));
+  if (N <= 0 || H <= 0 || W <= 0) return fail(RTPOSE_E_INVAL, "conv2d_winograd: empty tensor");
+  if (d0.pool && ((H | W) & 1)) return fail(RTPOSE_E_INVAL, "conv2d_winograd: fused pool needs even H and W");
+  Args a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < ngroups; ++i) {
+    const rtpose_conv_desc& di = d[i];
+    if (di.k != 3 || di.cin != d0.cin || di.relu != d0.relu || di.pool != d0.pool ||
+        cout_pad(di.cout) != cout_pad(d0.cout) || di.lin.ws != d0.lin.ws || di.lin.hs != d0.lin.hs)
+      return fail(RTPOSE_E_INVAL, "conv2d_winograd: grouped convs must share geometry");
+    if (di.lin.ws < W + 1 || di.lin.hs < H + 1 || di.lin.lead < di.lin.ws + 1)
+      return fail(RTPOSE_E_INVAL, "conv2d_winograd: input layout gap smaller than the conv padding");
+    if ((di.lin.cstride % 4) || (di.lin.choff % 4))
+      return fail(RTPOSE_E_INVAL, "conv2d_winograd: input slice must be 16-byte aligned");
+    if (di.lin.choff + di.cin > di.lin.cstride)
+      return fail(RTPOSE_E_INVAL, "conv2d_winograd: input slice exceeds cstride");
+    if (di.out_cmap) return fail(RTPOSE_E_INVAL, "conv2d_winograd: out_cmap is not supported");
+    Group& g = a.g[i];
+    g.in = di.in;
+    g.w = di.w_packed;
+    g.bias = di.bias_packed;
+    g.out = di.out;
+    g.in_cstride = di.lin.cstride;
+    g.in_choff = di.lin.choff;
+    g.in_ws = di.lin.ws;
+    g.in_hs = di.lin.hs;
+    g.in_lead = di.lin.lead;
+    g.out_cstride = di.lout.cstride;
+    g.out_choff = di.lout.choff;
+    g.out_ws = di.lout.ws;
+    g.out_hs = di.lout.hs;
+    g.out_lead = di.lout.lead;
+    g.cout = di.cout;
+    g.cout_pad = cout_pad(di.cout);
+  }
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.TY = ceil_div(H, 2);
+  a.TX = ceil_div(W, 2);
+  const long T = (long)N * a.TY * a.TX;
+  if (T > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv2d_winograd: tensor too large");
+  a.T = (int)T;
+  a.cin = d0.cin;
+  a.relu = d0.relu;
+  a.pool = d0.pool;
+  const int ck = wino_ck(d0.cout);
+  const int wm = ck == 16 ? 1 : 2, wn = 4 / wm;
+  a.mtiles = ceil_div(a.T, 32 * wm);
+  a.ntiles = cout_pad(d0.cout) / (32 * wn);
+  a.ncombo = a.ntiles * ngroups;
+  a.xcd_remap = (a.ncombo > 1 && a.mtiles >= 64) ? 1 : 0;
+  const long ids = a.xcd_remap ? (long)8 * a.ncombo * ceil_div(a.mtiles, 8) : (long)a.mtiles * a.ncombo;
+  if (ids > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv2d_winograd: grid too large");
+  const dim3 grid((unsigned)ids, 1, 1);
+  if (ck == 16) return launch_inst<1, 4, 16>(a, grid, s);
+  return launch_inst<2, 2, 8>(a, grid, s);
+}
+
+int pack_weights_wino_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map,
+                             int cin_packed, float* wp, float* bp, hipStream_t s) {
+  if (!conv2d_wino_ok(cin_packed, cout, 3) || (cin_packed < cin_src && !cin_map))
+    return fail(RTPOSE_E_INVAL, "pack_winograd: cin_packed must be a multiple of %d and >= cin_src", wino_ck(cout));
+  const int coutp = cout_pad(cout);
+  const size_t total = (size_t)16 * cin_packed * coutp;
+  const int threads = 256;
+  const unsigned blocks = (unsigned)((total + threads - 1) / threads);
+  hipLaunchKernelGGL(wino::pack_wino_kernel, dim3(blocks), dim3(threads), 0, s, w, bias, cout, cin_src, cin_map,
+                     cin_packed, wino_ck(cout), coutp, wp, bp);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace rtpose
+
+extern "C" {
+
+int rtpose_conv2d_winograd_ok(int cin, int cout, int k) { return rtpose::conv2d_wino_ok(cin, cout, k); }
+
+size_t rtpose_packed_weight_floats_winograd(int cout, int cin) {
+  // + two (chunk, frequency) steps of slack: the kernel's B prefetch runs two steps ahead
+  return (size_t)(16 * cin + 64) * rtpose::cout_pad(cout);  // + 4 (chunk, frequency) blocks: the B prefetch runs two steps ahead
+}
+
+int rtpose_pack_conv_weights_winograd(const float* w_oihw, const float* bias, int cout, int cin_src,
+                                      const int32_t* cin_map, int cin_packed, float* w_packed,
+                                      float* bias_packed, void* stream) {
+  return rtpose::pack_weights_wino_launch(w_oihw, bias, cout, cin_src, cin_map, cin_packed, w_packed,
+                                          bias_packed, rtpose::as_stream(stream));
+}
+
+int rtpose_conv2d_winograd(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, void* stream) {
+  return rtpose::conv2d_wino_launch(d, ngroups, N, H, W, rtpose::as_stream(stream));
+}
+
+}  // extern "C"

@@ -24,6 +24,10 @@
 
 namespace rtpose {
 int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
+int conv2d_wino_ok(int cin, int cout, int k);
+int conv2d_wino_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
+int pack_weights_wino_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map,
+                             int cin_packed, float* wp, float* bp, hipStream_t s);
 int pack_weights_launch(const float* w, const float* bias, int cout, int cin_src, int k,
                         const int32_t* cin_map, int cin_packed, float* wp, float* bp, hipStream_t s);
 // bf16 path (conv_mfma_bf16.hip)
@@ -49,6 +53,7 @@ struct ConvW {
   std::string name;
   int cout = 0, cin_src = 0, cin_packed = 0, k = 0;
   bool cat_perm = false;   // input channels follow the cat([L1,L2,out1]) order
+  bool wino = false;       // fp32 plans: 3x3 conv in Winograd F(2x2, 3x3) form (csrc/conv_wino.hip)
   size_t w_off = 0, b_off = 0;  // float offsets in the weight arena
 };
 
@@ -77,6 +82,7 @@ struct rtpose_net {
   int N = 0, H = 0, W = 0;       // input
   int bf16 = 0;                  // 1: bf16 activations/weights, fp32 accumulate (BASELINE config 3)
   int split = 0;                 // bf16 plans only: 1 = "bf16x3" split operands (hi + lo bf16 per value)
+  int wino = 1;                  // fp32 plans: Winograd for the eligible 3x3 convs (RTPOSE_WINOGRAD=0 turns it off)
   int x0f_buf = -1;              // bf16 plans: fp32 NHWC8 staging buffer for rtpose_preprocess_u8
   int H3 = 0, W3 = 0;            // stride-8 map
   std::vector<Buf> bufs;
@@ -138,8 +144,9 @@ int add_conv_w(rtpose_net* n, const std::string& name, int cout, int cin, int k,
   c.cin_packed = cat_perm ? kCatC : (n->bf16 ? ceil_div(cin, 16) * 16 : ceil_div(cin, 8) * 8);
   c.k = k;
   c.cat_perm = cat_perm;
+  c.wino = !n->bf16 && n->wino && conv2d_wino_ok(c.cin_packed, cout, k);
   c.w_off = n->wt_floats;
-  n->wt_floats += round_up(n->split ? rtpose_packed_weight_bytes_bf16x3(cout, c.cin_packed, k) / 4
+  n->wt_floats += round_up(c.wino ? rtpose_packed_weight_floats_winograd(cout, c.cin_packed) : n->split ? rtpose_packed_weight_bytes_bf16x3(cout, c.cin_packed, k) / 4
                            : n->bf16 ? rtpose_packed_weight_bytes_bf16(cout, c.cin_packed, k) / 4
                                    : rtpose_packed_weight_floats(cout, c.cin_packed, k), 64);
   c.b_off = n->wt_floats;
@@ -371,6 +378,11 @@ int rtpose_net_create_ex(int N, int H, int W, int dtype, rtpose_net** out) {
   n->W = W;
   n->bf16 = dtype != RTPOSE_DTYPE_F32;
   n->split = dtype == RTPOSE_DTYPE_BF16X3;
+  {
+    // production knob (numerics: Winograd results differ from the direct sum by a few ulp)
+    const char* e = getenv("RTPOSE_WINOGRAD");
+    n->wino = !(e && e[0] == '0');
+  }
   build_plan(n);
   *out = n;
   return 0;
@@ -449,6 +461,9 @@ int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw, const fl
   if (net->bf16)
     return pack_weights_bf16_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed,
                                     net->wt + c.w_off, net->wt + c.b_off, net->split, as_stream(stream));
+  if (c.wino)
+    return pack_weights_wino_launch(w_oihw, bias, c.cout, c.cin_src, map, c.cin_packed, net->wt + c.w_off,
+                                    net->wt + c.b_off, as_stream(stream));
   return pack_weights_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed, net->wt + c.w_off,
                              net->wt + c.b_off, as_stream(stream));
 }
@@ -628,7 +643,10 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
           d[g].pool = o.pool;
           d[g].out_cmap = nullptr;
         }
+        bool wino = true;  // grouped convs share geometry, hence the form
+        for (int g = 0; g < o.ngroups; ++g) wino = wino && net->convs[o.conv_idx[g]].wino;
         rc = net->bf16 ? conv2d_bf16_launch(d, o.ngroups, N, o.H, o.W, o.out_f32, net->split, s)
+             : wino    ? conv2d_wino_launch(d, o.ngroups, N, o.H, o.W, s)
                        : conv2d_launch(d, o.ngroups, N, o.H, o.W, s);
         break;
       }

@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4  # relative to max|ref|; fp32 fma-chain vs ATen summation order
 
 
-def _run_conv(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, seed, groups=1, cin_pad=None):
+def _run_conv(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, seed, groups=1, cin_pad=None,
+              winograd=False):
     lib, Layout = capi.lib, capi.Layout
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -41,17 +42,26 @@ def _run_conv(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, see
     lout_full = Layout.padded(cstride_out, ho, wo, pad_out)
     obuf = torch.zeros(lib.rtpose_layout_pixels(C.byref(lout_full), n, ho, wo) * cstride_out, device=dev)
     for gi in range(groups):
-        wp = torch.zeros(lib.rtpose_packed_weight_floats(cout, cin_p, k), device=dev)
         bp = torch.zeros(lib.rtpose_packed_bias_floats(cout), device=dev)
-        capi.check(lib.rtpose_pack_conv_weights(capi.ptr(ws[gi]), capi.ptr(bs[gi]), cout, cin, k, None, cin_p,
-                                                capi.ptr(wp), capi.ptr(bp), stream))
+        if winograd:
+            assert lib.rtpose_conv2d_winograd_ok(cin_p, cout, k) == 1
+            wp = torch.zeros(lib.rtpose_packed_weight_floats_winograd(cout, cin_p), device=dev)
+            capi.check(lib.rtpose_pack_conv_weights_winograd(capi.ptr(ws[gi]), capi.ptr(bs[gi]), cout, cin, None,
+                                                             cin_p, capi.ptr(wp), capi.ptr(bp), stream))
+        else:
+            wp = torch.zeros(lib.rtpose_packed_weight_floats(cout, cin_p, k), device=dev)
+            capi.check(lib.rtpose_pack_conv_weights(capi.ptr(ws[gi]), capi.ptr(bs[gi]), cout, cin, k, None, cin_p,
+                                                    capi.ptr(wp), capi.ptr(bp), stream))
         keep += [wp, bp]
         d = descs[gi]
         d.inp, d.w_packed, d.bias_packed, d.out = xin.data_ptr(), wp.data_ptr(), bp.data_ptr(), obuf.data_ptr()
         d.lin = lin
         d.lout = Layout.padded(cstride_out, ho, wo, pad_out, choff=gi * cout + 1)
         d.cin, d.cout, d.k, d.relu, d.pool = cin_p, cout, k, int(relu), int(pool)
-    capi.check(lib.rtpose_conv2d(descs, groups, n, h, w, stream), "rtpose_conv2d")
+    if winograd:
+        capi.check(lib.rtpose_conv2d_winograd(descs, groups, n, h, w, stream), "rtpose_conv2d_winograd")
+    else:
+        capi.check(lib.rtpose_conv2d(descs, groups, n, h, w, stream), "rtpose_conv2d")
     for gi in range(groups):
         o = torch.empty(n, cout, ho, wo, device=dev)
         lo = Layout.padded(cstride_out, ho, wo, pad_out, choff=gi * cout + 1)
@@ -97,6 +107,49 @@ def test_grouped_branches(capi, cuda):
     outs, refs = _run_conv(capi, cuda, 2, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=7, groups=2)
     for o, r in zip(outs, refs):
         assert (o - r).abs().max().item() <= TOL * max(1.0, r.abs().max().item())
+
+
+WINO_CASES = [
+    # n, h, w, cin, cout, relu, pool, pad_in, pad_out       (k = 3; csrc/conv_wino.hip)
+    (2, 46, 46, 256, 512, 1, 0, 1, 1),     # conv4_1: 32 wtiles x 128 columns, 4 N tiles, XCD-ordered grid
+    (1, 46, 46, 128, 128, 1, 0, 3, 1),     # stage-1 conv reading the P = 3 concat layout
+    (1, 96, 80, 64, 64, 1, 1, 1, 1),       # conv1_2: 64 wtiles x 64 columns, 8-channel chunks, fused pool
+    (1, 100, 92, 128, 256, 1, 0, 1, 1),    # conv3_1
+    (2, 23, 17, 64, 128, 0, 0, 1, 0),      # odd H and W: the last wtile row / column is half outside
+    (1, 12, 10, 16, 24, 0, 0, 1, 0),       # tiny: one partial block, ragged cout
+    (5, 6, 6, 32, 40, 1, 1, 1, 3),         # wtile strips spanning several images + pool
+    (3, 7, 5, 8, 64, 1, 0, 2, 1),          # one 8-channel chunk (no double buffering to speak of)
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_winograd_matches_torch_cpu(capi, cuda, case):
+    n, h, w, cin, cout, relu, pool, pin, pout = case
+    outs, refs = _run_conv(capi, cuda, n, h, w, cin, cout, 3, relu, pool, pin, pout, seed=hash(case) % 1000,
+                           winograd=True)
+    ref = refs[0]
+    err = (outs[0] - ref).abs().max().item()
+    assert err <= TOL * max(1.0, ref.abs().max().item()), "max abs err %g" % err
+
+
+def test_winograd_grouped_branches_and_direct_agree(capi, cuda):
+    outs, refs = _run_conv(capi, cuda, 2, 46, 46, 128, 128, 3, 1, 0, 3, 3, seed=9, groups=2, winograd=True)
+    direct, _ = _run_conv(capi, cuda, 2, 46, 46, 128, 128, 3, 1, 0, 3, 3, seed=9, groups=2)
+    for o, r, d in zip(outs, refs, direct):
+        assert (o - r).abs().max().item() <= TOL * max(1.0, r.abs().max().item())
+        assert (o - d).abs().max().item() <= 2e-5 * max(1.0, r.abs().max().item())
+
+
+def test_winograd_rejects_what_it_cannot_do(capi, cuda):
+    lib = capi.lib
+    assert lib.rtpose_conv2d_winograd_ok(128, 128, 7) == 0 and lib.rtpose_conv2d_winograd_ok(8, 128, 3) == 0
+    assert lib.rtpose_conv2d_winograd_ok(8, 64, 3) == 1 and lib.rtpose_conv2d_winograd_ok(512, 512, 3) == 1
+    d = (capi.ConvDesc * 1)()
+    d[0].k = 7
+    d[0].cin = 16
+    d[0].cout = 128
+    assert lib.rtpose_conv2d_winograd(d, 1, 1, 8, 8, None) != 0
+    assert "k must be 3" in capi.last_error()
 
 
 def test_conv_rejects_bad_geometry(capi, cuda):
