@@ -118,19 +118,25 @@ typedef struct rtpose_conv_desc {
 int rtpose_conv2d(const rtpose_conv_desc* d, int ngroups, int N, int H, int W,
                   void* stream);
 
-/* ---- fp32 Winograd F(2x2, 3x3) form of the 3x3 convs (csrc/conv_wino.hip) ------------------
- * Same module boundary as rtpose_conv2d (nn.Conv2d 3x3 + nn.ReLU + nn.MaxPool2d of
- * lib/network/rtpose_vgg.py:23-35, :49-55): 16 instead of 36 multiplies per 2 x 2 output tile and
- * input channel, fp32 MFMA, results within a few ulp of the direct sum (contract: 1e-3).  The
- * descriptor is rtpose_conv_desc with k = 3, `w_packed` from rtpose_pack_conv_weights_winograd
- * (transformed filters U = G g G^T, 16/9 the size) and out_cmap = NULL.
- * rtpose_conv2d_winograd_ok: 1 when (cin, cout, k) has a Winograd instance (k = 3 and cin a multiple
- * of 16, or of 8 when cout <= 64 modulo 128), else 0 - callers fall back to rtpose_conv2d. */
-int rtpose_conv2d_winograd_ok(int cin, int cout, int k);
-size_t rtpose_packed_weight_floats_winograd(int cout, int cin);
+/* ---- fp32 Winograd forms of the 3x3 and 7x7 convs (csrc/conv_wino.hip, csrc/conv_wino7.hip) ------
+ * Same module boundary as rtpose_conv2d (nn.Conv2d + nn.ReLU (+ nn.MaxPool2d) of
+ * lib/network/rtpose_vgg.py:23-35, :49-55, :108-127), fewer matrix-core multiplies:
+ *   k = 3: F(2x2, 3x3), 16 instead of 36 multiplies per 2 x 2 outputs and input channel (2.25x);
+ *   k = 7: F(4, 7) along x, direct along y: 70 instead of 196 per 4 outputs (2.8x), no fused pool.
+ * fp32 MFMA throughout; results differ from the direct sum by rounding only (k = 3: a few ulp,
+ * k = 7: ~2e-5 at magnitude 4; whole network < 1e-5 on the stage outputs; contract 1e-3).
+ * The descriptor is rtpose_conv_desc with `w_packed` from rtpose_pack_conv_weights_winograd
+ * (transformed filters: 16/9 resp. 70/49 the size) and out_cmap = NULL.
+ * rtpose_conv2d_winograd_fits: 1 when the conv described by `d` (k, cin, cout, pool, lin.hs) has a
+ * Winograd instance at N x H x W (k = 3: cin a multiple of 16, or of 8 when cout_pad is 64 modulo
+ * 128; k = 7: cin a multiple of 8, cout_pad a multiple of 128, and the transformed rows of a block
+ * fit the LDS), else 0 - callers then use rtpose_conv2d with the plain packing. */
+int rtpose_conv2d_winograd_fits(const rtpose_conv_desc* d, int N, int H, int W);
+size_t rtpose_packed_weight_floats_winograd(int cout, int cin, int k);
 int rtpose_pack_conv_weights_winograd(const float* w_oihw, const float* bias, int cout,
-                                      int cin_src, const int32_t* cin_map, int cin_packed,
-                                      float* w_packed, float* bias_packed, void* stream);
+                                      int cin_src, int k, const int32_t* cin_map,
+                                      int cin_packed, float* w_packed, float* bias_packed,
+                                      void* stream);
 int rtpose_conv2d_winograd(const rtpose_conv_desc* d, int ngroups, int N, int H, int W,
                            void* stream);
 

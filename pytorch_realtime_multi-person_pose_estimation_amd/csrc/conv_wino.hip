@@ -444,25 +444,46 @@ int pack_weights_wino_launch(const float* w, const float* bias, int cout, int ci
   return 0;
 }
 
+// k = 7: csrc/conv_wino7.hip
+int conv2d_wino7_fits(int cin, int cout, int N, int H, int W, int hs);
+int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
+int pack_weights_wino7_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map,
+                              int cin_packed, float* wp, float* bp, hipStream_t s);
+size_t packed_weight_floats_wino7(int cout, int cin);
+
+int conv2d_winograd_fits(int k, int cin, int cout, int pool, int N, int H, int W, int hs) {
+  if (k == 3) return conv2d_wino_ok(cin, cout, 3);
+  if (k == 7) return !pool && conv2d_wino7_fits(cin, cout, N, H, W, hs);
+  return 0;
+}
+
 }  // namespace rtpose
 
 extern "C" {
 
-int rtpose_conv2d_winograd_ok(int cin, int cout, int k) { return rtpose::conv2d_wino_ok(cin, cout, k); }
-
-size_t rtpose_packed_weight_floats_winograd(int cout, int cin) {
-  // + two (chunk, frequency) steps of slack: the kernel's B prefetch runs two steps ahead
-  return (size_t)(16 * cin + 64) * rtpose::cout_pad(cout);  // + 4 (chunk, frequency) blocks: the B prefetch runs two steps ahead
+int rtpose_conv2d_winograd_fits(const rtpose_conv_desc* d, int N, int H, int W) {
+  return d ? rtpose::conv2d_winograd_fits(d->k, d->cin, d->cout, d->pool, N, H, W, d->lin.hs) : 0;
 }
 
-int rtpose_pack_conv_weights_winograd(const float* w_oihw, const float* bias, int cout, int cin_src,
+size_t rtpose_packed_weight_floats_winograd(int cout, int cin, int k) {
+  if (k == 7) return rtpose::packed_weight_floats_wino7(cout, cin);
+  // + 4 (chunk, frequency) blocks: the B prefetch runs two steps ahead
+  return (size_t)(16 * cin + 64) * rtpose::cout_pad(cout);
+}
+
+int rtpose_pack_conv_weights_winograd(const float* w_oihw, const float* bias, int cout, int cin_src, int k,
                                       const int32_t* cin_map, int cin_packed, float* w_packed,
                                       float* bias_packed, void* stream) {
+  if (k == 7)
+    return rtpose::pack_weights_wino7_launch(w_oihw, bias, cout, cin_src, cin_map, cin_packed, w_packed,
+                                             bias_packed, rtpose::as_stream(stream));
+  if (k != 3) return rtpose::fail(RTPOSE_E_INVAL, "pack_winograd: k must be 3 or 7");
   return rtpose::pack_weights_wino_launch(w_oihw, bias, cout, cin_src, cin_map, cin_packed, w_packed,
                                           bias_packed, rtpose::as_stream(stream));
 }
 
 int rtpose_conv2d_winograd(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, void* stream) {
+  if (d && d[0].k == 7) return rtpose::conv2d_wino7_launch(d, ngroups, N, H, W, rtpose::as_stream(stream));
   return rtpose::conv2d_wino_launch(d, ngroups, N, H, W, rtpose::as_stream(stream));
 }
 

@@ -1,0 +1,517 @@
+// fp32 7x7 convolution in 1-D Winograd form F(4, 7) along x, direct along y, for gfx950 (MI355X):
+// stride 1, "same" padding, fused bias (+ReLU).
+//
+// Stands in for the 7x7 nn.Conv2d + nn.ReLU modules of the refinement stages 2..6
+// (lib/network/rtpose_vgg.py:108-127: Mconv1..5_stageN_L1/L2, cin 185 or 128 -> 128), which are 65 % of
+// the network's flops.  Along x every group of 4 consecutive outputs is computed from 10 "frequencies"
+// (Toom-Cook interpolation points 0, +-1, +-2, +-1/2, +-3/2, inf):
+//
+//   out[y][4 gx + i][o] = sum_f AT[i][f] * sum_ky sum_c  V[y + ky - 3][gx][f][c] * U[ky][f][c][o]
+//   V[r][gx][f][c] = sum_n BT[f][n] * in[r][4 gx - 3 + n][c]         U[ky][f][c][o] = sum_kx G[f][kx] * w[o][c][ky][kx]
+//
+// i.e. 70 multiplies per 4 outputs and input channel instead of 196 (2.8x fewer matrix-core flops).
+// Measured against the fp64 sum the fp32 result is ~2e-5 off where the direct fp32 sum is ~1e-6 off
+// (output magnitude ~4); through the whole network the stage outputs move by < 1e-5 (contract: 1e-3).
+//
+// MI355X shape:
+//  * "position" = one group of 4 output pixels.  A wave owns all 10 frequencies of 32 consecutive
+//    positions (flattened (n, y, gx) order) x 32 output columns = 10 v_mfma_f32_32x32x2_f32
+//    accumulators (160 AGPRs, one wave per SIMD); the output transform AT is lane-local and the bias
+//    rides in the accumulator of the point p = 1 (its AT column is all ones).  A block = 4 waves =
+//    32 positions x 128 columns.
+//  * V lives in LDS per 8-channel chunk as [padded row][f][c/4][gx][4 floats]: one transformed input row
+//    serves the 7 output rows around it, the A fragment of (ky, f) is one ds_read_b128 per lane at
+//    (row(lane) + ky, f, gx(lane)).  Double-buffered: the 10-pixel input segments of chunk c+2 are in
+//    flight and chunk c+1 is transformed (VALU, in the shadow of the MFMAs) while chunk c is multiplied;
+//    one barrier per chunk (280 MFMAs per wave).
+//  * B = transformed filters, packed [chunk][ky][f][c/4][cout][4] by rtpose_pack_conv_weights_winograd,
+//    straight from L2 to registers three frequency pairs ahead.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "common.h"
+
+namespace rtpose {
+
+namespace wino7 {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef const floatx4 __attribute__((address_space(1)))* gcf4_t;
+__device__ __forceinline__ float4 gload4(const void* p) {
+  const floatx4 v = *(gcf4_t)(unsigned long long)(p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ float4 fma4(float s, float4 a, float4 b) {  // s * a + b, one rounding
+  return make_float4(__builtin_fmaf(s, a.x, b.x), __builtin_fmaf(s, a.y, b.y), __builtin_fmaf(s, a.z, b.z),
+                     __builtin_fmaf(s, a.w, b.w));
+}
+__device__ __forceinline__ float4 mul4(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) {
+  return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+}
+
+// Input transform, rows scaled by N_f = prod_{l != f} (p_f - p_l) (the filter transform divides by it):
+// every entry is a multiple of 1/16, exact in fp32.  Rows 2p-1 / 2p (points +-p) share their even- and
+// odd-n halves:  V[2p-1] = E_p + O_p,  V[2p] = E_p - O_p.
+__device__ static constexpr float kBT[10][10] = {
+    {2.25f, 0.f, -12.8125f, 0.f, 17.0625f, 0.f, -7.5f, 0.f, 1.f, 0.f},
+    {0.f, -2.25f, -2.25f, 10.5625f, 10.5625f, -6.5f, -6.5f, 1.f, 1.f, 0.f},
+    {0.f, 2.25f, -2.25f, -10.5625f, 10.5625f, 6.5f, -6.5f, -1.f, 1.f, 0.f},
+    {0.f, -1.125f, -0.5625f, 6.125f, 3.0625f, -7.f, -3.5f, 2.f, 1.f, 0.f},
+    {0.f, 1.125f, -0.5625f, -6.125f, 3.0625f, 7.f, -3.5f, -2.f, 1.f, 0.f},
+    {0.f, -4.5f, -9.f, 7.625f, 15.25f, -3.625f, -7.25f, 0.5f, 1.f, 0.f},
+    {0.f, 4.5f, -9.f, -7.625f, 15.25f, 3.625f, -7.25f, -0.5f, 1.f, 0.f},
+    {0.f, -1.5f, -1.f, 7.875f, 5.25f, -7.875f, -5.25f, 1.5f, 1.f, 0.f},
+    {0.f, 1.5f, -1.f, -7.875f, 5.25f, 7.875f, -5.25f, -1.5f, 1.f, 0.f},
+    {0.f, 2.25f, 0.f, -12.8125f, 0.f, 17.0625f, 0.f, -7.5f, 0.f, 1.f},
+};
+
+struct Group {
+  const float* in;
+  const float* w;
+  const float* bias;
+  float* out;
+  int in_cstride, in_choff, in_ws, in_hs, in_lead;
+  int out_cstride, out_choff, out_ws, out_hs, out_lead;
+  int cout, cout_pad;
+};
+
+struct Args {
+  Group g[2];
+  int N, H, W;
+  int GX, T;    // positions per row, and in the whole batch
+  int cin, relu;
+  int RS;       // float4 per transformed row in LDS (>= 20 GX, chosen against bank conflicts)
+  int VB;       // float4 per V buffer
+  int mtiles, ntiles, ncombo, xcd_remap;
+};
+
+constexpr int CK = 8, CG = 2;   // channels per chunk, 16-byte channel groups per chunk
+constexpr int NPS = 35;         // (ky, frequency pair) steps per chunk
+constexpr int PF = 3;           // B prefetch distance in steps; 5 register sets (35 % 5 == 0)
+
+// NI = (row, gx, channel group) transform items per thread and chunk
+template <int NI>
+__global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
+  extern __shared__ __attribute__((aligned(16))) float4 V4[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  const int bi = blockIdx.x;
+  int mt, c;
+  if (A.xcd_remap) {
+    const int xcd = bi & 7, j = bi >> 3;
+    c = j % A.ncombo;
+    mt = (j / A.ncombo) * 8 + xcd;
+  } else {
+    mt = bi % A.mtiles;
+    c = bi / A.mtiles;
+  }
+  if (mt >= A.mtiles) return;
+  const int nt = c % A.ntiles, grp = c / A.ntiles;
+  const Group g = grp ? A.g[1] : A.g[0];
+  const int GX = A.GX, RS = A.RS;
+  const int PI = A.H * GX;  // positions per image
+
+  // ---- rows of the padded layout this block needs: [R0 - 3, R1 + 3] ----------------------------
+  const int t0 = mt * 32;
+  int R0, nrows;
+  {
+    const int n0 = t0 / PI, y0 = (t0 - n0 * PI) / GX;
+    const int t1 = min(t0 + 31, A.T - 1);
+    const int n1 = t1 / PI, y1 = (t1 - n1 * PI) / GX;
+    R0 = n0 * g.in_hs + y0;
+    nrows = n1 * g.in_hs + y1 - R0 + 7;
+  }
+  const int nitems = nrows * GX * CG;
+
+  // ---- input transform role: NI items (row, gx, channel group) ----------------------------------------
+  // The last group of a row reaches past the row's own 3-pixel gap (x >= W + 3 is the NEXT row's - or the next
+  // image's - data) when W is not a multiple of 4.  Those inputs only meet outputs that are not stored, but
+  // through the transform they would cancel only up to rounding, and an image's result would depend on its
+  // neighbour in the batch: segments n = 7..9 are therefore clamped to the last gap pixel (a zero).
+  const float* src[NI];
+  int vdst[NI], xhi[NI][3];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int i = min(tid + k * 256, nitems - 1);  // surplus threads repeat the last item (same value, same slot)
+    const int r = i / (GX * CG), rem = i - r * (GX * CG);
+    const int gx = rem >> 1, cg = rem & 1;
+    const long q = (long)g.in_lead + (long)(R0 - 3 + r) * g.in_ws + (4 * gx - 3);
+    src[k] = g.in + q * g.in_cstride + g.in_choff + cg * 4;
+    vdst[k] = r * RS + cg * GX + gx;
+#pragma unroll
+    for (int n = 7; n < 10; ++n) xhi[k][n - 7] = min(n, A.W + 5 - 4 * gx) * g.in_cstride;
+  }
+  int xoff[7];
+#pragma unroll
+  for (int n = 0; n < 7; ++n) xoff[n] = n * g.in_cstride;
+  float4 d[NI][10], eo[4][2];
+  auto load_piece = [&](int chunk, int k, int n) {
+    d[k][n] = gload4(src[k] + chunk * CK + (n < 7 ? xoff[n] : xhi[k][n < 7 ? 0 : n - 7]));
+  };
+  // micro-ops of one item: 8 half sums, then the 10 frequencies (each written to LDS as it is formed)
+  auto form_eo = [&](int k, int o) {
+    const int p = o >> 1, odd = o & 1;  // pair p (rows 2p+1, 2p+2), even / odd n
+    const int n0 = odd ? 1 : 2;  // column 0 of these rows is zero
+    float4 s = mul4(kBT[2 * p + 1][n0], d[k][n0]);
+#pragma unroll
+    for (int n = n0 + 2; n < 10; n += 2)
+      if (kBT[2 * p + 1][n] != 0.f) s = fma4(kBT[2 * p + 1][n], d[k][n], s);
+    eo[p][odd] = s;
+  };
+  auto store_f = [&](int buf, int k, int f) {
+    float4 v;
+    if (f == 0 || f == 9) {
+      const int n0 = f == 0 ? 0 : 1;
+      v = mul4(kBT[f][n0], d[k][n0]);
+#pragma unroll
+      for (int n = n0 + 2; n < 10; n += 2) v = fma4(kBT[f][n], d[k][n], v);
+    } else {
+      const int p = (f - 1) >> 1;
+      v = ((f - 1) & 1) ? sub4(eo[p][0], eo[p][1]) : add4(eo[p][0], eo[p][1]);
+    }
+    V4[buf * A.VB + vdst[k] + f * CG * GX] = v;
+  };
+  // op order per item: E/O of the 4 pairs, f = 0, f = 9 (the item's registers are then dead), f = 1..8
+  auto item_op = [&](int buf, int k, int o) {
+    if (o < 8) form_eo(k, o);
+    else if (o == 8) store_f(buf, k, 0);
+    else if (o == 9) store_f(buf, k, 9);
+    else store_f(buf, k, o - 9);
+  };
+
+  // ---- MFMA roles ---------------------------------------------------------------------------------
+  int abase;
+  {
+    const int t = min(t0 + l31, A.T - 1);  // positions past the end repeat the last one (not stored)
+    const int n = t / PI, r = t - n * PI;
+    const int y = r / GX, gx = r - y * GX;
+    abase = (n * g.in_hs + y - R0) * RS + kh * GX + gx;
+  }
+  const int ncol = nt * 128 + wn * 32 + l31;
+  floatx16 acc[10];
+#pragma unroll
+  for (int f = 0; f < 10; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+  {
+    const float b0 = g.bias[ncol];  // padded to cout_pad
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[1][r] = b0;
+  }
+  const char* wq = reinterpret_cast<const char*>(g.w);
+  const unsigned boff = (unsigned)((kh * g.cout_pad + ncol) * 16);
+  const unsigned fstep = (unsigned)(CG * g.cout_pad * 16);  // bytes per frequency block
+  const size_t bstep = (size_t)2 * fstep;                   // bytes per step (frequency pair)
+  float4 bs[5][2];
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    bs[s][0] = gload4(wq + s * bstep + boff);
+    bs[s][1] = gload4(wq + s * bstep + boff + fstep);
+  }
+  wq += PF * bstep;
+
+  const int nchunks = A.cin / CK;
+#pragma unroll
+  for (int k = 0; k < NI; ++k)
+#pragma unroll
+    for (int n = 0; n < 10; ++n) load_piece(0, k, n);
+#pragma unroll
+  for (int k = 0; k < NI; ++k)
+#pragma unroll
+    for (int o = 0; o < 18; ++o) item_op(0, k, o);
+  {
+    const int c1 = min(1, nchunks - 1);
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+#pragma unroll
+      for (int n = 0; n < 10; ++n) load_piece(c1, k, n);
+  }
+  __syncthreads();
+
+#define RTPOSE_PIN()             \
+  asm volatile("" ::: "memory"); \
+  __builtin_amdgcn_sched_barrier(0)
+  constexpr int NOPS = 28 * NI;                    // transform micro-ops per chunk
+  constexpr int STRIDE = (4 * NPS) / NOPS;         // one every STRIDE filler slots
+  static_assert(STRIDE >= 1, "too many transform items per thread");
+  float4 a[2][2];
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const float4* va = V4 + (chunk & 1) * A.VB + abase;
+    const int nbuf = (chunk + 1) & 1;
+    const int c2 = min(chunk + 2, nchunks - 1);  // the last chunks re-stage themselves (never read)
+    a[0][0] = va[0];
+    a[0][1] = va[CG * GX];
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int fp = ps % 5;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        {
+          const float4 a0 = a[ps & 1][0], a1 = a[ps & 1][1], b0 = bs[ps % 5][0], b1 = bs[ps % 5][1];
+          const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+          const float b0v[4] = {b0.x, b0.y, b0.z, b0.w}, b1v[4] = {b1.x, b1.y, b1.z, b1.w};
+          acc[2 * fp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[j], b0v[j], acc[2 * fp], 0, 0, 0);
+          acc[2 * fp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[j], b1v[j], acc[2 * fp + 1], 0, 0, 0);
+        }
+        RTPOSE_PIN();
+        if (j < 2) {  // A of the next step (the first step of a chunk is read after the barrier)
+          if (ps + 1 < NPS) {
+            const int kyn = (ps + 1) / 5, fn = 2 * ((ps + 1) % 5) + j;
+            a[(ps + 1) & 1][j] = va[kyn * RS + fn * CG * GX];
+          }
+        } else {      // B three steps ahead
+          bs[(ps + PF) % 5][j - 2] = gload4(wq + boff + (j - 2) * fstep);
+          if (j == 3) wq += bstep;
+        }
+        {  // input transform micro-op
+          const int kk = ps * 4 + j;
+          const int op = (kk % STRIDE == 0) ? kk / STRIDE : -1;
+          if (op >= 0 && op < 18 * NI) item_op(nbuf, op / 18, op % 18);
+          else if (op >= 18 * NI && op < NOPS) load_piece(c2, (op - 18 * NI) / 10, (op - 18 * NI) % 10);
+        }
+        RTPOSE_PIN();
+      }
+    }
+    __syncthreads();
+  }
+#undef RTPOSE_PIN
+
+  // ---- epilogue: output transform AT (points 0, +-1, +-2, +-1/2, +-3/2, inf), (+ReLU), masked stores ----
+  // accumulator register r of a lane = position (r / 4) * 8 + 4 kh + r % 4 of the block, column l31
+  const bool col_ok = ncol < g.cout;
+  float* out_base = g.out + g.out_choff + ncol;
+  int tcur = t0 + 4 * kh;
+  int sn = tcur / PI, sy, sx;
+  {
+    const int r = tcur - sn * PI;
+    sy = r / GX;
+    sx = r - sy * GX;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float S[4], D[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      S[p] = acc[2 * p + 1][r] + acc[2 * p + 2][r];
+      D[p] = acc[2 * p + 1][r] - acc[2 * p + 2][r];
+    }
+    float y[4];
+    y[0] = acc[0][r] + ((S[0] + S[1]) + (S[2] + S[3]));
+    y[1] = __builtin_fmaf(2.f, D[1], D[0]) + __builtin_fmaf(1.5f, D[3], 0.5f * D[2]);
+    y[2] = __builtin_fmaf(4.f, S[1], S[0]) + __builtin_fmaf(2.25f, S[3], 0.25f * S[2]);
+    y[3] = (__builtin_fmaf(8.f, D[1], D[0]) + __builtin_fmaf(3.375f, D[3], 0.125f * D[2])) + acc[9][r];
+    if (col_ok && tcur < A.T) {
+      const size_t q = (size_t)g.out_lead + (size_t)(sn * g.out_hs + sy) * g.out_ws + 4 * sx;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = A.relu ? fmaxf(y[i], 0.f) : y[i];
+        if (4 * sx + i < A.W) out_base[(q + i) * g.out_cstride] = v;
+      }
+    }
+    const int dstep = (r & 3) == 3 ? 5 : 1;  // next register: +1, +1, +1, +5 positions
+    tcur += dstep;
+    sx += dstep;
+    while (sx >= GX) {
+      sx -= GX;
+      if (++sy >= A.H) {
+        sy = 0;
+        ++sn;
+      }
+    }
+  }
+}
+
+// ---- weight packing: U[ky][f] = sum_kx G[f][kx] w[ky][kx];  packed[chunk][ky][f][cg][cout_pad][4] ------------
+__global__ void pack_wino7_kernel(const float* __restrict__ w, const float* __restrict__ bias, int cout,
+                                  int cin_src, const int32_t* __restrict__ cin_map, int cin_packed, int coutp,
+                                  float* __restrict__ wp, float* __restrict__ bp) {
+  const size_t total = (size_t)70 * cin_packed * coutp;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)coutp) bp[i] = (i < (size_t)cout && bias) ? bias[i] : 0.f;
+  if (i >= total) return;
+  const int e = i & 3;
+  size_t r = i >> 2;
+  const int n = r % coutp;
+  r /= coutp;
+  const int cg = r % CG;
+  r /= CG;
+  const int f = r % 10;
+  r /= 10;
+  const int ky = r % 7;
+  const int chunk = r / 7;
+  const int c = chunk * CK + cg * 4 + e;
+  const int src = cin_map ? cin_map[c] : (c < cin_src ? c : -1);
+  float v = 0.f;
+  if (n < cout && src >= 0 && src < cin_src) {
+    const float* gw = w + (((size_t)n * cin_src + src) * 7 + ky) * 7;
+    if (f == 9) {
+      v = gw[6];
+    } else {
+      // G[f][kx] = p_f^kx / N_f, N_f = prod_{l != f} (p_f - p_l) over the 9 finite points (exact in double)
+      const double pts[9] = {0.0, 1.0, -1.0, 2.0, -2.0, 0.5, -0.5, 1.5, -1.5};
+      double nf = 1.0;
+      for (int l = 0; l < 9; ++l)
+        if (l != f) nf *= pts[f] - pts[l];
+      double s = 0.0, pw = 1.0;
+      for (int kx = 0; kx < 7; ++kx) {
+        s += pw * (double)gw[kx];
+        pw *= pts[f];
+      }
+      v = (float)(s / nf);
+    }
+  }
+  wp[i] = v;
+}
+
+// LDS row stride (float4): >= 20 GX, and = GX modulo 16 so that the 32 positions of a wave tile, which
+// wrap from one transformed row to the next, keep landing in distinct 16-byte bank slots
+static int row_stride(int gx) {
+  int rs = 10 * CG * gx;
+  while ((rs & 15) != (gx & 15)) ++rs;
+  return rs;
+}
+
+struct Plan {
+  int gx, rs, nrows, ni;
+  long T;
+  size_t lds;
+};
+
+static int make_plan(int N, int H, int W, int hs, Plan* p) {
+  p->gx = ceil_div(W, 4);
+  p->rs = row_stride(p->gx);
+  p->T = (long)N * H * p->gx;
+  if (p->T > 0x7fffffffL) return -1;
+  // the most rows a block of 32 consecutive positions touches (+6 halo rows); blocks that run from one
+  // image into the next also carry the gap rows between them
+  const int pi = H * p->gx;
+  int nrows = 0;
+  for (long t0 = 0; t0 < p->T; t0 += 32) {
+    const long t1 = t0 + 31 < p->T - 1 ? t0 + 31 : p->T - 1;
+    const int n0 = (int)(t0 / pi), y0 = (int)((t0 - (long)n0 * pi) / p->gx);
+    const int n1 = (int)(t1 / pi), y1 = (int)((t1 - (long)n1 * pi) / p->gx);
+    const int rows = (n1 * hs + y1) - (n0 * hs + y0) + 7;
+    if (rows > nrows) nrows = rows;
+  }
+  p->nrows = nrows;
+  p->ni = ceil_div(nrows * p->gx * CG, 256);
+  p->lds = (size_t)2 * nrows * p->rs * 16;
+  return 0;
+}
+
+template <int NI>
+static int launch_inst(const Args& a, dim3 grid, size_t lds, hipStream_t s) {
+  static PerDeviceOnce attr_set;
+  const int dev = current_device();
+  auto kern = wino7_f32<NI>;
+  if (!attr_set.is_set(dev)) {
+    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set.set(dev);
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace wino7
+
+// 1 when the 7x7 conv can run in F(4,7) form at this geometry (a kernel instance exists and the
+// transformed rows of a block fit the LDS), else 0: callers then use the direct kernel
+int conv2d_wino7_fits(int cin, int cout, int N, int H, int W, int hs) {
+  if (cin <= 0 || cin % wino7::CK || cout_pad(cout) % 128 || N <= 0 || H <= 0 || W <= 0) return 0;
+  wino7::Plan p;
+  if (wino7::make_plan(N, H, W, hs, &p)) return 0;
+  return p.lds <= 156 * 1024;  // (<= 499 items: at most 2 per thread)
+}
+
+int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s) {
+  using namespace wino7;
+  if (!d || ngroups < 1 || ngroups > 2) return fail(RTPOSE_E_INVAL, "conv2d_winograd: ngroups must be 1 or 2");
+  const rtpose_conv_desc& d0 = d[0];
+  if (d0.k != 7 || d0.pool || !conv2d_wino7_fits(d0.cin, d0.cout, N, H, W, d0.lin.hs))
+    return fail(RTPOSE_E_INVAL, "conv2d_winograd: no F(4,7) instance for cin %d cout %d at %d x %d x %d", d0.cin,
+                d0.cout, N, H, W);
+  Args a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < ngroups; ++i) {
+    const rtpose_conv_desc& di = d[i];
+    if (di.k != 7 || di.cin != d0.cin || di.relu != d0.relu || di.pool ||
+        cout_pad(di.cout) != cout_pad(d0.cout) || di.lin.ws != d0.lin.ws || di.lin.hs != d0.lin.hs)
+      return fail(RTPOSE_E_INVAL, "conv2d_winograd: grouped convs must share geometry");
+    if (di.lin.ws < W + 3 || di.lin.hs < H + 3 || di.lin.lead < 3 * di.lin.ws + 3)
+      return fail(RTPOSE_E_INVAL, "conv2d_winograd: input layout gap smaller than the conv padding");
+    if ((di.lin.cstride % 4) || (di.lin.choff % 4))
+      return fail(RTPOSE_E_INVAL, "conv2d_winograd: input slice must be 16-byte aligned");
+    if (di.lin.choff + di.cin > di.lin.cstride)
+      return fail(RTPOSE_E_INVAL, "conv2d_winograd: input slice exceeds cstride");
+    if (di.out_cmap) return fail(RTPOSE_E_INVAL, "conv2d_winograd: out_cmap is not supported");
+    Group& g = a.g[i];
+    g.in = di.in;
+    g.w = di.w_packed;
+    g.bias = di.bias_packed;
+    g.out = di.out;
+    g.in_cstride = di.lin.cstride;
+    g.in_choff = di.lin.choff;
+    g.in_ws = di.lin.ws;
+    g.in_hs = di.lin.hs;
+    g.in_lead = di.lin.lead;
+    g.out_cstride = di.lout.cstride;
+    g.out_choff = di.lout.choff;
+    g.out_ws = di.lout.ws;
+    g.out_hs = di.lout.hs;
+    g.out_lead = di.lout.lead;
+    g.cout = di.cout;
+    g.cout_pad = cout_pad(di.cout);
+  }
+  Plan p;
+  make_plan(N, H, W, d0.lin.hs, &p);
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.GX = p.gx;
+  a.T = (int)p.T;
+  a.cin = d0.cin;
+  a.relu = d0.relu;
+  a.RS = p.rs;
+  a.VB = p.nrows * p.rs;
+  a.mtiles = ceil_div(a.T, 32);
+  a.ntiles = cout_pad(d0.cout) / 128;
+  a.ncombo = a.ntiles * ngroups;
+  a.xcd_remap = (a.ncombo > 1 && a.mtiles >= 64) ? 1 : 0;
+  const long ids = a.xcd_remap ? (long)8 * a.ncombo * ceil_div(a.mtiles, 8) : (long)a.mtiles * a.ncombo;
+  if (ids > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv2d_winograd: grid too large");
+  const dim3 grid((unsigned)ids, 1, 1);
+  if (p.ni == 1) return launch_inst<1>(a, grid, p.lds, s);
+  return launch_inst<2>(a, grid, p.lds, s);
+}
+
+int pack_weights_wino7_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map,
+                              int cin_packed, float* wp, float* bp, hipStream_t s) {
+  if (cin_packed % wino7::CK || cin_packed <= 0 || (cin_packed < cin_src && !cin_map))
+    return fail(RTPOSE_E_INVAL, "pack_winograd: cin_packed must be a multiple of 8 and >= cin_src");
+  const int coutp = cout_pad(cout);
+  const size_t total = (size_t)70 * cin_packed * coutp;
+  const int threads = 256;
+  const unsigned blocks = (unsigned)((total + threads - 1) / threads);
+  hipLaunchKernelGGL(wino7::pack_wino7_kernel, dim3(blocks), dim3(threads), 0, s, w, bias, cout, cin_src, cin_map,
+                     cin_packed, coutp, wp, bp);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+size_t packed_weight_floats_wino7(int cout, int cin) {
+  // + 3 steps (6 frequency blocks of 8 x cout_pad floats): the B prefetch runs three steps ahead
+  return (size_t)(70 * cin + 64) * cout_pad(cout);
+}
+
+}  // namespace rtpose

@@ -24,10 +24,7 @@
 
 namespace rtpose {
 int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
-int conv2d_wino_ok(int cin, int cout, int k);
-int conv2d_wino_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
-int pack_weights_wino_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map,
-                             int cin_packed, float* wp, float* bp, hipStream_t s);
+int conv2d_winograd_fits(int k, int cin, int cout, int pool, int N, int H, int W, int hs);
 int pack_weights_launch(const float* w, const float* bias, int cout, int cin_src, int k,
                         const int32_t* cin_map, int cin_packed, float* wp, float* bp, hipStream_t s);
 // bf16 path (conv_mfma_bf16.hip)
@@ -53,7 +50,9 @@ struct ConvW {
   std::string name;
   int cout = 0, cin_src = 0, cin_packed = 0, k = 0;
   bool cat_perm = false;   // input channels follow the cat([L1,L2,out1]) order
-  bool wino = false;       // fp32 plans: 3x3 conv in Winograd F(2x2, 3x3) form (csrc/conv_wino.hip)
+  bool wino = false;       // fp32 plans: this plan runs the conv in Winograd form (csrc/conv_wino.hip, conv_wino7.hip)
+  bool dual = false;       // 7x7: the arena holds the Winograd packing at w_off AND the direct one at w_off_direct
+  size_t w_off_direct = 0;
   size_t w_off = 0, b_off = 0;  // float offsets in the weight arena
 };
 
@@ -136,7 +135,7 @@ int add_buf(rtpose_net* n, int C, int P, int H, int W, bool f32 = false) {
   return (int)n->bufs.size() - 1;
 }
 
-int add_conv_w(rtpose_net* n, const std::string& name, int cout, int cin, int k, bool cat_perm) {
+int add_conv_w(rtpose_net* n, const std::string& name, int cout, int cin, int k, bool cat_perm, int H = 0, int W = 0) {
   ConvW c;
   c.name = name;
   c.cout = cout;
@@ -144,11 +143,22 @@ int add_conv_w(rtpose_net* n, const std::string& name, int cout, int cin, int k,
   c.cin_packed = cat_perm ? kCatC : (n->bf16 ? ceil_div(cin, 16) * 16 : ceil_div(cin, 8) * 8);
   c.k = k;
   c.cat_perm = cat_perm;
-  c.wino = !n->bf16 && n->wino && conv2d_wino_ok(c.cin_packed, cout, k);
+  // The weight arena is shared by every plan of a module (any N x H x W), so its layout may not depend on
+  // the geometry.  3x3: the Winograd form always applies, one packing.  7x7: whether F(4,7) fits depends on
+  // the map width (LDS), so such a conv keeps BOTH packings and each plan picks one (c.wino).
+  const bool en = !n->bf16 && n->wino && (n->wino == 1 || n->wino == k);
+  const bool w3 = en && k == 3 && conv2d_winograd_fits(3, c.cin_packed, cout, 0, 1, 8, 8, 9);
+  c.dual = en && k == 7 && c.cin_packed % 8 == 0 && cout_pad(cout) % 128 == 0;
+  c.wino = w3 || (c.dual && conv2d_winograd_fits(7, c.cin_packed, cout, 0, n->N, H, W, H + 3));
   c.w_off = n->wt_floats;
-  n->wt_floats += round_up(c.wino ? rtpose_packed_weight_floats_winograd(cout, c.cin_packed) : n->split ? rtpose_packed_weight_bytes_bf16x3(cout, c.cin_packed, k) / 4
-                           : n->bf16 ? rtpose_packed_weight_bytes_bf16(cout, c.cin_packed, k) / 4
-                                   : rtpose_packed_weight_floats(cout, c.cin_packed, k), 64);
+  n->wt_floats += round_up((w3 || c.dual) ? rtpose_packed_weight_floats_winograd(cout, c.cin_packed, k)
+                           : n->split     ? rtpose_packed_weight_bytes_bf16x3(cout, c.cin_packed, k) / 4
+                           : n->bf16      ? rtpose_packed_weight_bytes_bf16(cout, c.cin_packed, k) / 4
+                                          : rtpose_packed_weight_floats(cout, c.cin_packed, k), 64);
+  if (c.dual) {
+    c.w_off_direct = n->wt_floats;
+    n->wt_floats += round_up(rtpose_packed_weight_floats(cout, c.cin_packed, k), 64);
+  }
   c.b_off = n->wt_floats;
   n->wt_floats += round_up(rtpose_packed_bias_floats(cout), 64);
   n->convs.push_back(c);
@@ -246,7 +256,7 @@ void build_plan(rtpose_net* n) {
         const int cout = i < 6 ? 128 : last;
         const int k = i < 5 ? 7 : 1;
         cws[b][s - 2][i] = add_conv_w(n, "model" + std::to_string(s) + sfx + std::to_string(2 * i),
-                                      cout, cin, k, i == 0);
+                                      cout, cin, k, i == 0, H3, W3);
       }
   }
   n->catmap_off = n->wt_floats;
@@ -381,7 +391,7 @@ int rtpose_net_create_ex(int N, int H, int W, int dtype, rtpose_net** out) {
   {
     // production knob (numerics: Winograd results differ from the direct sum by a few ulp)
     const char* e = getenv("RTPOSE_WINOGRAD");
-    n->wino = !(e && e[0] == '0');
+    n->wino = !e ? 1 : e[0] == '0' ? 0 : e[0] == '3' ? 3 : e[0] == '7' ? 7 : 1;  // "3" / "7": only that kernel size
   }
   build_plan(n);
   *out = n;
@@ -461,9 +471,14 @@ int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw, const fl
   if (net->bf16)
     return pack_weights_bf16_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed,
                                     net->wt + c.w_off, net->wt + c.b_off, net->split, as_stream(stream));
-  if (c.wino)
-    return pack_weights_wino_launch(w_oihw, bias, c.cout, c.cin_src, map, c.cin_packed, net->wt + c.w_off,
-                                    net->wt + c.b_off, as_stream(stream));
+  if (c.dual) {
+    const int rc = pack_weights_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed,
+                                       net->wt + c.w_off_direct, net->wt + c.b_off, as_stream(stream));
+    if (rc) return rc;
+  }
+  if (c.wino || c.dual)
+    return rtpose_pack_conv_weights_winograd(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed,
+                                             net->wt + c.w_off, net->wt + c.b_off, stream);
   return pack_weights_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed, net->wt + c.w_off,
                              net->wt + c.b_off, as_stream(stream));
 }
@@ -624,7 +639,7 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
           const Buf& bo = net->bufs[o.out_buf[g]];
           d[g].in = net->ws + bi.off_floats;
           d[g].out = net->ws + bo.off_floats;
-          d[g].w_packed = net->wt + c.w_off;
+          d[g].w_packed = net->wt + ((c.dual && !c.wino) ? c.w_off_direct : c.w_off);
           d[g].bias_packed = net->wt + c.b_off;
           d[g].lin = slice(bi, o.in_choff[g]);
           d[g].lout = slice(bo, o.out_choff[g]);
@@ -646,7 +661,7 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
         bool wino = true;  // grouped convs share geometry, hence the form
         for (int g = 0; g < o.ngroups; ++g) wino = wino && net->convs[o.conv_idx[g]].wino;
         rc = net->bf16 ? conv2d_bf16_launch(d, o.ngroups, N, o.H, o.W, o.out_f32, net->split, s)
-             : wino    ? conv2d_wino_launch(d, o.ngroups, N, o.H, o.W, s)
+             : wino    ? rtpose_conv2d_winograd(d, o.ngroups, N, o.H, o.W, s)
                        : conv2d_launch(d, o.ngroups, N, o.H, o.W, s);
         break;
       }

@@ -44,9 +44,8 @@ def _run_conv(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, see
     for gi in range(groups):
         bp = torch.zeros(lib.rtpose_packed_bias_floats(cout), device=dev)
         if winograd:
-            assert lib.rtpose_conv2d_winograd_ok(cin_p, cout, k) == 1
-            wp = torch.zeros(lib.rtpose_packed_weight_floats_winograd(cout, cin_p), device=dev)
-            capi.check(lib.rtpose_pack_conv_weights_winograd(capi.ptr(ws[gi]), capi.ptr(bs[gi]), cout, cin, None,
+            wp = torch.zeros(lib.rtpose_packed_weight_floats_winograd(cout, cin_p, k), device=dev)
+            capi.check(lib.rtpose_pack_conv_weights_winograd(capi.ptr(ws[gi]), capi.ptr(bs[gi]), cout, cin, k, None,
                                                              cin_p, capi.ptr(wp), capi.ptr(bp), stream))
         else:
             wp = torch.zeros(lib.rtpose_packed_weight_floats(cout, cin_p, k), device=dev)
@@ -59,6 +58,7 @@ def _run_conv(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, see
         d.lout = Layout.padded(cstride_out, ho, wo, pad_out, choff=gi * cout + 1)
         d.cin, d.cout, d.k, d.relu, d.pool = cin_p, cout, k, int(relu), int(pool)
     if winograd:
+        assert lib.rtpose_conv2d_winograd_fits(descs, n, h, w) == 1
         capi.check(lib.rtpose_conv2d_winograd(descs, groups, n, h, w, stream), "rtpose_conv2d_winograd")
     else:
         capi.check(lib.rtpose_conv2d(descs, groups, n, h, w, stream), "rtpose_conv2d")
@@ -109,6 +109,36 @@ def test_grouped_branches(capi, cuda):
         assert (o - r).abs().max().item() <= TOL * max(1.0, r.abs().max().item())
 
 
+WINO7_CASES = [
+    # n, h, w, cin (packed), cout, relu, pad_in, pad_out      (k = 7; csrc/conv_wino7.hip)
+    (2, 46, 46, 128, 128, 1, 3, 3),      # Mconv2_stageN: 12 position groups per row, blocks crossing images
+    (1, 46, 49, 192, 128, 1, 3, 3),      # ski.jpg geometry (46x49), 185 -> 192 packed input, W % 4 == 1
+    (3, 23, 18, 64, 256, 0, 3, 0),       # W % 4 == 2, two N tiles, no ReLU
+    (5, 6, 7, 16, 128, 1, 3, 3),         # tiny maps: a block spans several images (W % 4 == 3)
+    (1, 70, 66, 128, 128, 1, 3, 0),      # multi-scale map, wider rows
+    (1, 9, 80, 8, 128, 1, 4, 1),         # one chunk; 20 groups per row; gap wider than the padding
+]
+
+
+@pytest.mark.parametrize("case", WINO7_CASES)
+def test_winograd7_matches_torch_cpu(capi, cuda, case):
+    n, h, w, cin, cout, relu, pin, pout = case
+    src_cin = 185 if cin == 192 else cin
+    outs, refs = _run_conv(capi, cuda, n, h, w, src_cin, cout, 7, relu, 0, pin, pout, seed=hash(case) % 1000,
+                           cin_pad=cin, winograd=True)
+    ref = refs[0]
+    err = (outs[0] - ref).abs().max().item()
+    assert err <= TOL * max(1.0, ref.abs().max().item()), "max abs err %g" % err
+
+
+def test_winograd7_grouped_branches_and_direct_agree(capi, cuda):
+    outs, refs = _run_conv(capi, cuda, 2, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=7, groups=2, winograd=True)
+    direct, _ = _run_conv(capi, cuda, 2, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=7, groups=2)
+    for o, r, d in zip(outs, refs, direct):
+        assert (o - r).abs().max().item() <= TOL * max(1.0, r.abs().max().item())
+        assert (o - d).abs().max().item() <= 1e-4 * max(1.0, r.abs().max().item())
+
+
 WINO_CASES = [
     # n, h, w, cin, cout, relu, pool, pad_in, pad_out       (k = 3; csrc/conv_wino.hip)
     (2, 46, 46, 256, 512, 1, 0, 1, 1),     # conv4_1: 32 wtiles x 128 columns, 4 N tiles, XCD-ordered grid
@@ -142,12 +172,18 @@ def test_winograd_grouped_branches_and_direct_agree(capi, cuda):
 
 def test_winograd_rejects_what_it_cannot_do(capi, cuda):
     lib = capi.lib
-    assert lib.rtpose_conv2d_winograd_ok(128, 128, 7) == 0 and lib.rtpose_conv2d_winograd_ok(8, 128, 3) == 0
-    assert lib.rtpose_conv2d_winograd_ok(8, 64, 3) == 1 and lib.rtpose_conv2d_winograd_ok(512, 512, 3) == 1
     d = (capi.ConvDesc * 1)()
-    d[0].k = 7
-    d[0].cin = 16
-    d[0].cout = 128
+
+    def fits(k, cin, cout, n=1, h=46, w=46, pool=0):
+        d[0].k, d[0].cin, d[0].cout, d[0].pool = k, cin, cout, pool
+        d[0].lin = capi.Layout.padded(cin, h, w, k // 2)
+        return lib.rtpose_conv2d_winograd_fits(d, n, h, w)
+
+    assert fits(3, 8, 128) == 0 and fits(3, 8, 64) == 1 and fits(3, 512, 512) == 1 and fits(1, 128, 128) == 0
+    assert fits(7, 128, 128, 32) == 1 and fits(7, 192, 128, 32) == 1
+    assert fits(7, 128, 38) == 0            # 64 padded columns: the stage heads are 1x1 anyway
+    assert fits(7, 128, 128, 2, 184, 184) == 0   # transformed rows of a 184-wide map do not fit the LDS
+    d[0].k, d[0].cin, d[0].cout = 5, 16, 128
     assert lib.rtpose_conv2d_winograd(d, 1, 1, 8, 8, None) != 0
     assert "k must be 3" in capi.last_error()
 
