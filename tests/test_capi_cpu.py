@@ -100,9 +100,10 @@ def test_compute_dtype_plans_on_the_host(capi, pkg):
     f32, bf16, x3 = sizes[capi.DTYPE_F32], sizes[capi.DTYPE_BF16], sizes[capi.DTYPE_BF16X3]
     assert 0.4 * f32[0] < bf16[0] < 0.7 * f32[0]        # 2-byte activations (+ fp32 staging / records)
     assert 0.9 * f32[0] < x3[0] < 1.2 * f32[0]          # hi + lo = the fp32 footprint
-    # weights: bf16 = half of the plain fp32 packing = the bf16x3 one; the fp32 plan keeps its 3x3 / 7x7 filters
-    # in Winograd form (16/9 resp. 70/49 of the taps)
-    assert 0.45 * x3[1] < bf16[1] < 0.6 * x3[1] and 1.3 * x3[1] < f32[1] < 1.6 * x3[1]
+    # weights: bf16 = half of the plain fp32 packing = the bf16x3 one; the fp32 plan keeps its 3x3 filters in
+    # Winograd form (16/9 of the taps) and its 7x7 filters twice (70/49 Winograd + the direct packing: which one
+    # a plan uses depends on its geometry, the arena is shared by all plans)
+    assert 0.45 * x3[1] < bf16[1] < 0.6 * x3[1] and 2.0 * x3[1] < f32[1] < 2.5 * x3[1]
     assert bf16[2] == x3[2] == f32[2] - 1               # stage 6 writes its fp32 record directly (no save copy)
     h = C.c_void_p()
     assert lib.rtpose_net_create_ex(1, 364, 368, capi.DTYPE_BF16, C.byref(h)) != 0   # not a multiple of 8
