@@ -193,7 +193,9 @@ def measure_traffic(timeout_s=150, dtype="fp32"):
             row = cur.execute("select sum(value), count(distinct dispatch_id) from counters_collection "
                               "where counter_name = ? and kernel_name like ?",
                               (counter, "%conv_mfma_bf16<7, 16, 0%" if dtype == "bf16x3" else
-                               "%conv_mfma_bf16<7, 32, 0%" if dtype == "bf16" else "%conv_mfma_f32<7, 16, 0%")).fetchone()
+                               "%conv_mfma_bf16<7, 32, 0%" if dtype == "bf16" else
+                               "%wino7_f32%" if os.environ.get("RTPOSE_WINOGRAD", "1")[:1] in ("1", "7") else
+                               "%conv_mfma_f32<7, 16, 0%")).fetchone()
             if not row or not row[1]:
                 return None
             out[counter] = float(row[0]) / float(row[1]) * 1024.0      # KiB per launch -> bytes
@@ -268,7 +270,7 @@ def main():
     plan = model.plan_for(x)
     lib.rtpose_net_set_profiling(plan.handle, 1)
     nl = lib.rtpose_net_num_launches(plan.handle)
-    k7_ms, k7_flops, k7_n, net_ms = 0.0, 0.0, 0, 0.0
+    k7_ms, k7_flops, k7_exec, k7_n, k7_wino, net_ms = 0.0, 0.0, 0.0, 0, 0, 0.0
 
     torch.cuda.synchronize()
     par.barrier(dev)
@@ -276,14 +278,17 @@ def main():
     for _ in range(args.steps):
         bufs, host = step()
         # per-launch HIP events of this step's forward (recorded on the launch stream)
-        ms, k, fl = C.c_float(), C.c_int(), C.c_double()
+        ms, k, fl, fx, wf = C.c_float(), C.c_int(), C.c_double(), C.c_double(), C.c_int()
         for i in range(nl):
             lib.rtpose_net_launch_info(plan.handle, i, C.byref(ms), C.byref(k), C.byref(fl), None, 0)
             if ms.value > 0:
                 net_ms += ms.value
                 if k.value == 7:
+                    lib.rtpose_net_launch_executed_flops(plan.handle, i, C.byref(fx), C.byref(wf))
                     k7_ms += ms.value
                     k7_flops += fl.value
+                    k7_exec += fx.value
+                    k7_wino += wf.value
                     k7_n += 1
     torch.cuda.synchronize()
     par.barrier(dev)
@@ -299,6 +304,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         fps = BATCH * world * args.steps / elapsed
         achieved = k7_flops / (k7_ms * 1e-3) / 1e12 if k7_ms > 0 else 0.0
+        executed = k7_exec / (k7_ms * 1e-3) / 1e12 if k7_ms > 0 else 0.0
+        wino7 = k7_wino == k7_n and k7_n > 0
         out = {
             "metric": "end-to-end persons-posed FPS at 368x368 (net+pafprocess)",
             "value": round(fps, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -320,10 +327,16 @@ def main():
             "net_ms_per_step_events": round(net_ms / args.steps, 3),
             "roofline": {"bound": "mfma",
                          "kernel": ("conv_mfma_bf16<7,16,0,..,SP=2>" if x3 else
-                                    "conv_mfma_bf16<7,32,0>" if bf16 else "conv_mfma_f32<7,16,0>") +
-                                   " (7x7 stage convs, 68% of the FLOPs)",
+                                    "conv_mfma_bf16<7,32,0>" if bf16 else
+                                    "wino7_f32 (F(4,7) Winograd along x)" if wino7 else "conv_mfma_f32<7,16,0>") +
+                                   " (7x7 stage convs, 68% of the network's direct-convolution FLOPs)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None,
+                         # `achieved` counts the ALGORITHMIC flops of the direct 7x7 sum.  In
+                         # Winograd form the kernel issues 70/196 of them (+ group / channel padding), so
+                         # frac may exceed 1; executed_frac = issued MFMA flops / time / peak is the
+                         # matrix-pipe utilisation and cannot.
+                         "executed": round(executed, 2), "executed_frac": round(executed / peak, 4),
                          "launches_timed": k7_n,
                          "flops_per_launch": round(k7_flops / max(k7_n, 1)),
                          "avg_launch_ms": round(k7_ms / max(k7_n, 1), 4)},

@@ -394,6 +394,11 @@ int rtpose_net_num_launches(const rtpose_net* net);
  * LAST forward, its conv kernel size (0 = not a conv), and algorithmic flops. */
 int rtpose_net_launch_info(rtpose_net* net, int i, float* ms, int* k,
                            double* flops, char* name, int name_cap);
+/* Matrix-core flops launch i actually ISSUES (padded channels / columns included; the Winograd
+ * forms issue 16/36 resp. 70/196 of the direct sum's), and whether it runs in Winograd form:
+ * algorithmic flops / time can exceed the MFMA peak, executed flops / time cannot. */
+int rtpose_net_launch_executed_flops(const rtpose_net* net, int i, double* flops,
+                                     int* winograd);
 
 /* ------------------------------------------------------------------------
  * 3b. The ShuffleNetV2 x1.0 pose network (lib/network/rtpose_shufflenetV2.py:80-148,

@@ -144,6 +144,7 @@ _SIGS = {
     "rtpose_net_set_profiling": (_i, [_vp, _i]),
     "rtpose_net_num_launches": (_i, [_vp]),
     "rtpose_net_launch_info": (_i, [_vp, _i, C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(C.c_double), C.c_char_p, _i]),
+    "rtpose_net_launch_executed_flops": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_i)]),
     "rtpose_shufflenet_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
     "rtpose_shufflenet_destroy": (None, [_vp]),
     "rtpose_shufflenet_workspace_bytes": (_sz, [_vp]),

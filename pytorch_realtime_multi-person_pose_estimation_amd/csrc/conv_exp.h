@@ -12,7 +12,7 @@
     defined(RTPOSE_EXP_NO_STAGE) || defined(RTPOSE_EXP_NO_FILL) || defined(RTPOSE_EXP_NO_STORE) ||      \
     defined(RTPOSE_EXP_SCALAR_STORE) || defined(RTPOSE_EXP_BSPREAD) || defined(RTPOSE_EXP_HALF_B_ON) || \
     defined(RTPOSE_EXP_STAGGER) || defined(RTPOSE_EXP_TB1X1) || defined(RTPOSE_EXP_HD) ||               \
-    defined(RTPOSE_EXP_RB2)
+    defined(RTPOSE_EXP_RB2) || defined(RTPOSE_EXP_W7_PF)
 #error "RTPOSE_EXP_* ablation switches need -DRTPOSE_DEV_BUILD (they are not part of production builds)"
 #endif
 #endif
@@ -47,6 +47,11 @@ inline const char* dev_env(const char* name) {
 #endif
 #ifndef RTPOSE_EXP_RB2
 #define RTPOSE_EXP_RB2 4
+#endif
+
+// F(4,7) kernel: weight prefetch distance in (ky, frequency pair) steps (<= 4: 5 register sets)
+#ifndef RTPOSE_EXP_W7_PF
+#define RTPOSE_EXP_W7_PF 3
 #endif
 
 // fp32: which B register (k-group) is fetched after MFMA pair n (-1 = none); GB is the kernel's

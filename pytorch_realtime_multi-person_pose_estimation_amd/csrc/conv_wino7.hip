@@ -31,33 +31,67 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "conv_exp.h"
 
 namespace rtpose {
 
 namespace wino7 {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-typedef const floatx4 __attribute__((address_space(1)))* gcf4_t;
-__device__ __forceinline__ float4 gload4(const void* p) {
-  const floatx4 v = *(gcf4_t)(unsigned long long)(p);
-  return make_float4(v[0], v[1], v[2], v[3]);
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// 16 bytes as two packed pairs: the transform below is written on float2 so that it compiles to
+// v_pk_fma_f32 / v_pk_add_f32 (fp32 VALU instructions take their cycles from the SAME ALUs the fp32 MFMAs
+// run on - tools/exp/mfma_issue.hip: 64 -> 101 cycles per MFMA with 4 v_fma_f32 after each, at one or two
+// waves per SIMD alike - so every VALU instruction in the multiply loop is paid for in matrix throughput).
+struct F4 {
+  f2 lo, hi;
+};
+__device__ __forceinline__ F4 fma4(float s, F4 a, F4 b) {  // s * a + b, one rounding
+  const f2 ss = {s, s};
+  return F4{__builtin_elementwise_fma(ss, a.lo, b.lo), __builtin_elementwise_fma(ss, a.hi, b.hi)};
 }
-__device__ __forceinline__ float4 fma4(float s, float4 a, float4 b) {  // s * a + b, one rounding
-  return make_float4(__builtin_fmaf(s, a.x, b.x), __builtin_fmaf(s, a.y, b.y), __builtin_fmaf(s, a.z, b.z),
-                     __builtin_fmaf(s, a.w, b.w));
+__device__ __forceinline__ F4 mul4(float s, F4 a) {
+  const f2 ss = {s, s};
+  return F4{ss * a.lo, ss * a.hi};
 }
-__device__ __forceinline__ float4 mul4(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
-__device__ __forceinline__ float4 add4(float4 a, float4 b) {
-  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+__device__ __forceinline__ F4 add4(F4 a, F4 b) { return F4{a.lo + b.lo, a.hi + b.hi}; }
+__device__ __forceinline__ F4 sub4(F4 a, F4 b) { return F4{a.lo - b.lo, a.hi - b.hi}; }
+__device__ __forceinline__ float4 to_float4(F4 a) { return make_float4(a.lo.x, a.lo.y, a.hi.x, a.hi.y); }
+
+// Raw buffer loads: address = base (4 SGPRs) + per-lane byte offset (1 VGPR, fixed for the whole kernel) + uniform
+// byte offset (1 SGPR, advanced by the scalar unit): no vector instruction is spent on address arithmetic.
+// (Bound to the LLVM intrinsic by name: this compiler lowers __builtin_amdgcn_raw_buffer_load_b128 to a
+// ONE-dword load.)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ f32x4 llvm_raw_buffer_load_v4f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ __forceinline__ i32x4 make_rsrc(const void* p) {
+  union {
+    struct {
+      const void* p;
+      unsigned range, cfg;
+    } s;
+    i32x4 v;
+  } u;
+  u.s.p = p;
+  u.s.range = 0x7ffffffe;  // bytes addressable from p
+  u.s.cfg = 0x00020000;    // raw buffer, 32-bit data format
+  return u.v;
 }
-__device__ __forceinline__ float4 sub4(float4 a, float4 b) {
-  return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+__device__ __forceinline__ F4 bload(i32x4 r, unsigned voff, unsigned soff) {
+  const f32x4 v = llvm_raw_buffer_load_v4f32(r, (int)voff, (int)soff, 0);
+  return F4{f2{v.x, v.y}, f2{v.z, v.w}};
+}
+__device__ __forceinline__ float4 bload_f4(i32x4 r, unsigned voff, unsigned soff) {
+  const f32x4 v = llvm_raw_buffer_load_v4f32(r, (int)voff, (int)soff, 0);
+  return make_float4(v.x, v.y, v.z, v.w);
 }
 
 // Input transform, rows scaled by N_f = prod_{l != f} (p_f - p_l) (the filter transform divides by it):
-// every entry is a multiple of 1/16, exact in fp32.  Rows 2p-1 / 2p (points +-p) share their even- and
-// odd-n halves:  V[2p-1] = E_p + O_p,  V[2p] = E_p - O_p.
+// every entry is a multiple of 1/16, exact in fp32.  Rows 2p+1 / 2p+2 (points +-p) share their even- and
+// odd-n halves:  V[2p+1] = E_p + O_p,  V[2p+2] = E_p - O_p.
 __device__ static constexpr float kBT[10][10] = {
     {2.25f, 0.f, -12.8125f, 0.f, 17.0625f, 0.f, -7.5f, 0.f, 1.f, 0.f},
     {0.f, -2.25f, -2.25f, 10.5625f, 10.5625f, -6.5f, -6.5f, 1.f, 1.f, 0.f},
@@ -85,6 +119,7 @@ struct Args {
   Group g[2];
   int N, H, W;
   int GX, T;    // positions per row, and in the whole batch
+  int TPI;      // > 0: position strips restart with every image (TPI blocks per image); 0: one flat strip space
   int cin, relu;
   int RS;       // float4 per transformed row in LDS (>= 20 GX, chosen against bank conflicts)
   int VB;       // float4 per V buffer
@@ -93,10 +128,22 @@ struct Args {
 
 constexpr int CK = 8, CG = 2;   // channels per chunk, 16-byte channel groups per chunk
 constexpr int NPS = 35;         // (ky, frequency pair) steps per chunk
-constexpr int PF = 3;           // B prefetch distance in steps; 5 register sets (35 % 5 == 0)
+constexpr int PF = RTPOSE_EXP_W7_PF;  // B prefetch distance in steps (3); 5 register sets (35 % 5 == 0)
 
-// NI = (row, gx, channel group) transform items per thread and chunk
-template <int NI>
+// LDS row stride (float4): >= 20 GX, and = GX modulo 16 so that the 32 positions of a wave tile, which
+// wrap from one transformed row to the next, keep landing in distinct 16-byte bank slots
+__host__ __device__ constexpr int row_stride(int gx) {
+  int rs = 10 * CG * gx;
+  while ((rs & 15) != (gx & 15)) ++rs;
+  return rs;
+}
+// rows (incl. the 6 halo rows) a strip of 32 positions that stays inside one image can touch
+__host__ __device__ constexpr int strip_rows(int gx) { return (31 + gx - 1) / gx + 1 + 6; }
+
+// NI  = (row, gx, channel group) transform items per thread and chunk
+// GXT = compile-time position groups per row (0: run-time).  With GXT every LDS address of the multiply loop is
+//       one base register + an immediate; the run-time form pays one v_add per access.
+template <int NI, int GXT>
 __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
   extern __shared__ __attribute__((aligned(16))) float4 V4[];
   const int tid = threadIdx.x;
@@ -117,15 +164,26 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
   if (mt >= A.mtiles) return;
   const int nt = c % A.ntiles, grp = c / A.ntiles;
   const Group g = grp ? A.g[1] : A.g[0];
-  const int GX = A.GX, RS = A.RS;
+  const int GX = GXT ? GXT : A.GX;
+  const int RS = GXT ? row_stride(GXT) : A.RS;
+  const int VB = GXT ? strip_rows(GXT) * row_stride(GXT) : A.VB;
   const int PI = A.H * GX;  // positions per image
 
-  // ---- rows of the padded layout this block needs: [R0 - 3, R1 + 3] ----------------------------
-  const int t0 = mt * 32;
+  // ---- this block's 32 positions [t0, t0 + 32) of the flat (n, y, gx) order, valid below tlim ----------
+  int t0, tlim;
+  if (A.TPI) {
+    const int n = mt / A.TPI;
+    t0 = n * PI + (mt - n * A.TPI) * 32;
+    tlim = (n + 1) * PI;
+  } else {
+    t0 = mt * 32;
+    tlim = A.T;
+  }
+  // rows of the padded layout it needs: [R0 - 3, R1 + 3]
   int R0, nrows;
   {
     const int n0 = t0 / PI, y0 = (t0 - n0 * PI) / GX;
-    const int t1 = min(t0 + 31, A.T - 1);
+    const int t1 = min(t0 + 31, tlim - 1);
     const int n1 = t1 / PI, y1 = (t1 - n1 * PI) / GX;
     R0 = n0 * g.in_hs + y0;
     nrows = n1 * g.in_hs + y1 - R0 + 7;
@@ -137,61 +195,56 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
   // image's - data) when W is not a multiple of 4.  Those inputs only meet outputs that are not stored, but
   // through the transform they would cancel only up to rounding, and an image's result would depend on its
   // neighbour in the batch: segments n = 7..9 are therefore clamped to the last gap pixel (a zero).
-  const float* src[NI];
-  int vdst[NI], xhi[NI][3];
+  const i32x4 rin = make_rsrc(g.in), rw = make_rsrc(g.w);
+  unsigned voff[NI], vhi[NI][3];
+  int vdst[NI];
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
     const int i = min(tid + k * 256, nitems - 1);  // surplus threads repeat the last item (same value, same slot)
     const int r = i / (GX * CG), rem = i - r * (GX * CG);
     const int gx = rem >> 1, cg = rem & 1;
     const long q = (long)g.in_lead + (long)(R0 - 3 + r) * g.in_ws + (4 * gx - 3);
-    src[k] = g.in + q * g.in_cstride + g.in_choff + cg * 4;
+    voff[k] = (unsigned)((q * g.in_cstride + g.in_choff + cg * 4) * 4);
     vdst[k] = r * RS + cg * GX + gx;
 #pragma unroll
-    for (int n = 7; n < 10; ++n) xhi[k][n - 7] = min(n, A.W + 5 - 4 * gx) * g.in_cstride;
+    for (int n = 7; n < 10; ++n) vhi[k][n - 7] = voff[k] + (unsigned)(min(n, A.W + 5 - 4 * gx) * g.in_cstride * 4);
   }
-  int xoff[7];
-#pragma unroll
-  for (int n = 0; n < 7; ++n) xoff[n] = n * g.in_cstride;
-  float4 d[NI][10], eo[4][2];
+  const unsigned pxb = (unsigned)g.in_cstride * 4;  // bytes per pixel (uniform)
+  F4 d[NI][10], eo[2];
   auto load_piece = [&](int chunk, int k, int n) {
-    d[k][n] = gload4(src[k] + chunk * CK + (n < 7 ? xoff[n] : xhi[k][n < 7 ? 0 : n - 7]));
+    const unsigned cb = (unsigned)chunk * (CK * 4);
+    d[k][n] = n < 7 ? bload(rin, voff[k], cb + n * pxb) : bload(rin, vhi[k][n < 7 ? 0 : n - 7], cb);
   };
-  // micro-ops of one item: 8 half sums, then the 10 frequencies (each written to LDS as it is formed)
-  auto form_eo = [&](int k, int o) {
-    const int p = o >> 1, odd = o & 1;  // pair p (rows 2p+1, 2p+2), even / odd n
-    const int n0 = odd ? 1 : 2;  // column 0 of these rows is zero
-    float4 s = mul4(kBT[2 * p + 1][n0], d[k][n0]);
+  // The transform of one item in 6 groups of 10..20 packed VALU instructions.  (A lone VALU instruction between
+  // two MFMAs costs ~8 cycles of matrix time, a group of 12..16 costs ~60 in all: few, full groups.)
+  //   group p = 0..3: E_p, O_p (4 terms each), then frequencies 2p+1 = E_p + O_p and 2p+2 = E_p - O_p -> LDS
+  //   group 4: frequency 0;  group 5: frequency 9                      (5 terms each)
+  auto tgroup = [&](float4* vw, int k, int gidx) {
+    if (gidx < 4) {
+      const int row = 2 * gidx + 1;
 #pragma unroll
-    for (int n = n0 + 2; n < 10; n += 2)
-      if (kBT[2 * p + 1][n] != 0.f) s = fma4(kBT[2 * p + 1][n], d[k][n], s);
-    eo[p][odd] = s;
-  };
-  auto store_f = [&](int buf, int k, int f) {
-    float4 v;
-    if (f == 0 || f == 9) {
-      const int n0 = f == 0 ? 0 : 1;
-      v = mul4(kBT[f][n0], d[k][n0]);
+      for (int odd = 0; odd < 2; ++odd) {
+        const int n0 = odd ? 1 : 2;  // column 0 of these rows is zero
+        F4 s = mul4(kBT[row][n0], d[k][n0]);
 #pragma unroll
-      for (int n = n0 + 2; n < 10; n += 2) v = fma4(kBT[f][n], d[k][n], v);
+        for (int t = 1; t < 4; ++t) s = fma4(kBT[row][n0 + 2 * t], d[k][n0 + 2 * t], s);
+        eo[odd] = s;
+      }
+      vw[vdst[k] + row * CG * GX] = to_float4(add4(eo[0], eo[1]));
+      vw[vdst[k] + (row + 1) * CG * GX] = to_float4(sub4(eo[0], eo[1]));
     } else {
-      const int p = (f - 1) >> 1;
-      v = ((f - 1) & 1) ? sub4(eo[p][0], eo[p][1]) : add4(eo[p][0], eo[p][1]);
+      const int f = gidx == 4 ? 0 : 9, n0 = gidx == 4 ? 0 : 1;
+      F4 s = mul4(kBT[f][n0], d[k][n0]);
+#pragma unroll
+      for (int t = 1; t < 5; ++t) s = fma4(kBT[f][n0 + 2 * t], d[k][n0 + 2 * t], s);
+      vw[vdst[k] + f * CG * GX] = to_float4(s);
     }
-    V4[buf * A.VB + vdst[k] + f * CG * GX] = v;
-  };
-  // op order per item: E/O of the 4 pairs, f = 0, f = 9 (the item's registers are then dead), f = 1..8
-  auto item_op = [&](int buf, int k, int o) {
-    if (o < 8) form_eo(k, o);
-    else if (o == 8) store_f(buf, k, 0);
-    else if (o == 9) store_f(buf, k, 9);
-    else store_f(buf, k, o - 9);
   };
 
   // ---- MFMA roles ---------------------------------------------------------------------------------
   int abase;
   {
-    const int t = min(t0 + l31, A.T - 1);  // positions past the end repeat the last one (not stored)
+    const int t = min(t0 + l31, tlim - 1);  // positions past the end repeat the last one (not stored)
     const int n = t / PI, r = t - n * PI;
     const int y = r / GX, gx = r - y * GX;
     abase = (n * g.in_hs + y - R0) * RS + kh * GX + gx;
@@ -207,17 +260,16 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[1][r] = b0;
   }
-  const char* wq = reinterpret_cast<const char*>(g.w);
   const unsigned boff = (unsigned)((kh * g.cout_pad + ncol) * 16);
   const unsigned fstep = (unsigned)(CG * g.cout_pad * 16);  // bytes per frequency block
-  const size_t bstep = (size_t)2 * fstep;                   // bytes per step (frequency pair)
+  unsigned wso = 0;                                         // uniform byte offset of the next B step to fetch
   float4 bs[5][2];
 #pragma unroll
   for (int s = 0; s < PF; ++s) {
-    bs[s][0] = gload4(wq + s * bstep + boff);
-    bs[s][1] = gload4(wq + s * bstep + boff + fstep);
+    bs[s][0] = bload_f4(rw, boff, wso);
+    bs[s][1] = bload_f4(rw, boff, wso + fstep);
+    wso += 2 * fstep;
   }
-  wq += PF * bstep;
 
   const int nchunks = A.cin / CK;
 #pragma unroll
@@ -227,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
 #pragma unroll
   for (int k = 0; k < NI; ++k)
 #pragma unroll
-    for (int o = 0; o < 18; ++o) item_op(0, k, o);
+    for (int gi = 0; gi < 6; ++gi) tgroup(V4, k, gi);
   {
     const int c1 = min(1, nchunks - 1);
 #pragma unroll
@@ -240,13 +292,16 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
 #define RTPOSE_PIN()             \
   asm volatile("" ::: "memory"); \
   __builtin_amdgcn_sched_barrier(0)
-  constexpr int NOPS = 28 * NI;                    // transform micro-ops per chunk
-  constexpr int STRIDE = (4 * NPS) / NOPS;         // one every STRIDE filler slots
-  static_assert(STRIDE >= 1, "too many transform items per thread");
+  // One step = the frequency pair (2 fp, 2 fp + 1) of one ky = 8 MFMAs on two alternating accumulators, with a
+  // filler slot after every second one.  Slot 0 / 1: the A fragments of the next step (LDS); slot 2 / 3: the B
+  // fragments PF steps ahead (L2).  Slot 3 of the first steps also carries transform work of the NEXT chunk: its
+  // 6 NI groups (steps 0..11), then the 10 NI segment loads of the chunk after that, two per step.
+  constexpr int NG = 6 * NI, GSTR = NI == 1 ? 2 : 1;
+  static_assert(12 + 5 * NI <= NPS, "transform work does not fit the steps of a chunk");
   float4 a[2][2];
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const float4* va = V4 + (chunk & 1) * A.VB + abase;
-    const int nbuf = (chunk + 1) & 1;
+    const float4* va = V4 + (chunk & 1) * VB + abase;
+    float4* vw = V4 + ((chunk + 1) & 1) * VB;
     const int c2 = min(chunk + 2, nchunks - 1);  // the last chunks re-stage themselves (never read)
     a[0][0] = va[0];
     a[0][1] = va[CG * GX];
@@ -266,17 +321,20 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
         if (j < 2) {  // A of the next step (the first step of a chunk is read after the barrier)
           if (ps + 1 < NPS) {
             const int kyn = (ps + 1) / 5, fn = 2 * ((ps + 1) % 5) + j;
-            a[(ps + 1) & 1][j] = va[kyn * RS + fn * CG * GX];
+            a[(ps + 1) & 1][j] = RTPOSE_EXP_A(va[kyn * RS + fn * CG * GX], a[ps & 1][j]);
           }
-        } else {      // B three steps ahead
-          bs[(ps + PF) % 5][j - 2] = gload4(wq + boff + (j - 2) * fstep);
-          if (j == 3) wq += bstep;
+        } else {      // B PF steps ahead
+          bs[(ps + PF) % 5][j - 2] = RTPOSE_EXP_B(bload_f4(rw, boff, wso), bs[ps % 5][j - 2]);
+          wso += fstep;
         }
-        {  // input transform micro-op
-          const int kk = ps * 4 + j;
-          const int op = (kk % STRIDE == 0) ? kk / STRIDE : -1;
-          if (op >= 0 && op < 18 * NI) item_op(nbuf, op / 18, op % 18);
-          else if (op >= 18 * NI && op < NOPS) load_piece(c2, (op - 18 * NI) / 10, (op - 18 * NI) % 10);
+        if (RTPOSE_EXP_STAGE && j == 3) {
+          if (ps % GSTR == 0 && ps / GSTR < NG) {
+            tgroup(vw, (ps / GSTR) / 6, (ps / GSTR) % 6);
+          } else if (ps >= 12 && ps < 12 + 5 * NI) {  // two segment loads per step
+            const int l = 2 * (ps - 12);
+            load_piece(c2, l / 10, l % 10);
+            load_piece(c2, (l + 1) / 10, (l + 1) % 10);
+          }
         }
         RTPOSE_PIN();
       }
@@ -309,7 +367,7 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
     y[1] = __builtin_fmaf(2.f, D[1], D[0]) + __builtin_fmaf(1.5f, D[3], 0.5f * D[2]);
     y[2] = __builtin_fmaf(4.f, S[1], S[0]) + __builtin_fmaf(2.25f, S[3], 0.25f * S[2]);
     y[3] = (__builtin_fmaf(8.f, D[1], D[0]) + __builtin_fmaf(3.375f, D[3], 0.125f * D[2])) + acc[9][r];
-    if (col_ok && tcur < A.T) {
+    if (col_ok && tcur < tlim) {
       const size_t q = (size_t)g.out_lead + (size_t)(sn * g.out_hs + sy) * g.out_ws + 4 * sx;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -372,16 +430,8 @@ __global__ void pack_wino7_kernel(const float* __restrict__ w, const float* __re
   wp[i] = v;
 }
 
-// LDS row stride (float4): >= 20 GX, and = GX modulo 16 so that the 32 positions of a wave tile, which
-// wrap from one transformed row to the next, keep landing in distinct 16-byte bank slots
-static int row_stride(int gx) {
-  int rs = 10 * CG * gx;
-  while ((rs & 15) != (gx & 15)) ++rs;
-  return rs;
-}
-
 struct Plan {
-  int gx, rs, nrows, ni;
+  int gx, rs, nrows, ni, tpi, mtiles;
   long T;
   size_t lds;
 };
@@ -391,16 +441,24 @@ static int make_plan(int N, int H, int W, int hs, Plan* p) {
   p->rs = row_stride(p->gx);
   p->T = (long)N * H * p->gx;
   if (p->T > 0x7fffffffL) return -1;
-  // the most rows a block of 32 consecutive positions touches (+6 halo rows); blocks that run from one
-  // image into the next also carry the gap rows between them
   const int pi = H * p->gx;
+  // maps with >= 256 positions: strips of 32 positions restart with every image (<= 6 % of padded positions;
+  // a strip then never carries the gap rows between two images: fewer transformed rows, less transform work);
+  // tiny maps: one flat strip space over the whole batch
+  p->tpi = pi >= 256 ? ceil_div(pi, 32) : 0;
   int nrows = 0;
-  for (long t0 = 0; t0 < p->T; t0 += 32) {
-    const long t1 = t0 + 31 < p->T - 1 ? t0 + 31 : p->T - 1;
-    const int n0 = (int)(t0 / pi), y0 = (int)((t0 - (long)n0 * pi) / p->gx);
-    const int n1 = (int)(t1 / pi), y1 = (int)((t1 - (long)n1 * pi) / p->gx);
-    const int rows = (n1 * hs + y1) - (n0 * hs + y0) + 7;
-    if (rows > nrows) nrows = rows;
+  if (p->tpi) {
+    nrows = strip_rows(p->gx) < H + 6 ? strip_rows(p->gx) : H + 6;
+    p->mtiles = N * p->tpi;
+  } else {
+    for (long t0 = 0; t0 < p->T; t0 += 32) {
+      const long t1 = t0 + 31 < p->T - 1 ? t0 + 31 : p->T - 1;
+      const int n0 = (int)(t0 / pi), y0 = (int)((t0 - (long)n0 * pi) / p->gx);
+      const int n1 = (int)(t1 / pi), y1 = (int)((t1 - (long)n1 * pi) / p->gx);
+      const int rows = (n1 * hs + y1) - (n0 * hs + y0) + 7;
+      if (rows > nrows) nrows = rows;
+    }
+    p->mtiles = (int)((p->T + 31) / 32);
   }
   p->nrows = nrows;
   p->ni = ceil_div(nrows * p->gx * CG, 256);
@@ -408,11 +466,11 @@ static int make_plan(int N, int H, int W, int hs, Plan* p) {
   return 0;
 }
 
-template <int NI>
+template <int NI, int GXT>
 static int launch_inst(const Args& a, dim3 grid, size_t lds, hipStream_t s) {
   static PerDeviceOnce attr_set;
   const int dev = current_device();
-  auto kern = wino7_f32<NI>;
+  auto kern = wino7_f32<NI, GXT>;
   if (!attr_set.is_set(dev)) {
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -431,7 +489,7 @@ int conv2d_wino7_fits(int cin, int cout, int N, int H, int W, int hs) {
   if (cin <= 0 || cin % wino7::CK || cout_pad(cout) % 128 || N <= 0 || H <= 0 || W <= 0) return 0;
   wino7::Plan p;
   if (wino7::make_plan(N, H, W, hs, &p)) return 0;
-  return p.lds <= 156 * 1024;  // (<= 499 items: at most 2 per thread)
+  return p.ni <= 2 && p.lds <= 156 * 1024;
 }
 
 int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s) {
@@ -455,6 +513,8 @@ int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
     if (di.lin.choff + di.cin > di.lin.cstride)
       return fail(RTPOSE_E_INVAL, "conv2d_winograd: input slice exceeds cstride");
     if (di.out_cmap) return fail(RTPOSE_E_INVAL, "conv2d_winograd: out_cmap is not supported");
+    if (rtpose_layout_pixels(&di.lin, N, H, W) * (size_t)di.lin.cstride * 4 >= 0x7ffffffeull)
+      return fail(RTPOSE_E_INVAL, "conv2d_winograd: input buffer beyond the 2 GB a buffer descriptor addresses");
     Group& g = a.g[i];
     g.in = di.in;
     g.w = di.w_packed;
@@ -484,15 +544,19 @@ int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
   a.relu = d0.relu;
   a.RS = p.rs;
   a.VB = p.nrows * p.rs;
-  a.mtiles = ceil_div(a.T, 32);
+  a.TPI = p.tpi;
+  a.mtiles = p.mtiles;
   a.ntiles = cout_pad(d0.cout) / 128;
   a.ncombo = a.ntiles * ngroups;
   a.xcd_remap = (a.ncombo > 1 && a.mtiles >= 64) ? 1 : 0;
   const long ids = a.xcd_remap ? (long)8 * a.ncombo * ceil_div(a.mtiles, 8) : (long)a.mtiles * a.ncombo;
   if (ids > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv2d_winograd: grid too large");
   const dim3 grid((unsigned)ids, 1, 1);
-  if (p.ni == 1) return launch_inst<1>(a, grid, p.lds, s);
-  return launch_inst<2>(a, grid, p.lds, s);
+  // 46-wide maps (368 x 368 inputs, BASELINE configs[1]): every LDS offset of the multiply loop is an immediate
+  if (p.gx == 12 && p.tpi && p.ni == 1 && p.nrows == strip_rows(12))
+    return launch_inst<1, 12>(a, grid, (size_t)2 * strip_rows(12) * row_stride(12) * 16, s);
+  if (p.ni == 1) return launch_inst<1, 0>(a, grid, p.lds, s);
+  return launch_inst<2, 0>(a, grid, p.lds, s);
 }
 
 int pack_weights_wino7_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map,

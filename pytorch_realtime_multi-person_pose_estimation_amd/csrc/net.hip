@@ -502,6 +502,30 @@ int rtpose_net_set_profiling(rtpose_net* net, int enable) {
 
 int rtpose_net_num_launches(const rtpose_net* net) { return (int)net->ops.size(); }
 
+int rtpose_net_launch_executed_flops(const rtpose_net* net, int i, double* flops, int* winograd) {
+  if (!net || i < 0 || i >= (int)net->ops.size()) return fail(RTPOSE_E_INVAL, "launch_executed_flops: bad index");
+  const Op& o = net->ops[i];
+  double fl = 0.0;
+  int wino = 0;
+  if (o.kind == OP_CONV)
+    for (int g = 0; g < o.ngroups; ++g) {
+      const ConvW& c = net->convs[o.conv_idx[g]];
+      const double kc = (double)c.cin_packed * cout_pad(c.cout);
+      if (c.wino && c.k == 3) {         // 16 frequencies per 2 x 2 wtile
+        fl += 2.0 * net->N * ceil_div(o.H, 2) * ceil_div(o.W, 2) * 16.0 * kc;
+        wino = 1;
+      } else if (c.wino && c.k == 7) {  // 10 frequencies x 7 rows per group of 4 pixels
+        fl += 2.0 * net->N * o.H * ceil_div(o.W, 4) * 70.0 * kc;
+        wino = 1;
+      } else {
+        fl += 2.0 * net->N * o.H * o.W * (double)c.k * c.k * kc;
+      }
+    }
+  if (flops) *flops = fl;
+  if (winograd) *winograd = wino;
+  return 0;
+}
+
 int rtpose_net_launch_info(rtpose_net* net, int i, float* ms, int* k, double* flops, char* name,
                            int name_cap) {
   if (!net || i < 0 || i >= (int)net->ops.size()) return fail(RTPOSE_E_INVAL, "launch_info: bad index");

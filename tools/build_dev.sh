@@ -1,17 +1,34 @@
 #!/bin/bash
-# Developer build of the library: tools/exp/lib_dev.so, compiled with -DRTPOSE_DEV_BUILD so that the
-# RTPOSE_CONV_* / RTPOSE_BF16_* environment knobs are read.  The production library
-# (csrc/Makefile) ignores them.  Use:  RTPOSE_LIB_PATH=tools/exp/lib_dev.so tools/ab_env.sh VAR v1 v2
+# Developer build of the library: tools/exp/lib_dev.so (or $OUT), compiled with -DRTPOSE_DEV_BUILD so that the
+# RTPOSE_CONV_* / RTPOSE_BF16_* environment knobs are read and the RTPOSE_EXP_* ablation macros
+# (csrc/conv_exp.h) are accepted.  The production library (csrc/Makefile) ignores / rejects them.
+#   tools/build_dev.sh [-DRTPOSE_EXP_...]            all sources with the flags
+#   ONLY=conv_wino7 OUT=tools/exp/lib_x.so tools/build_dev.sh -DRTPOSE_EXP_NO_B
+#                                                    flags on ONE source, the rest from the cached plain dev objects
+# Use:  RTPOSE_LIB_PATH=tools/exp/lib_dev.so tools/ab_env.sh VAR v1 v2
 set -e
 cd "$(dirname "$0")/.."
 SRC=pytorch_realtime_multi-person_pose_estimation_amd/csrc
-mkdir -p tools/exp
+OUT=${OUT:-tools/exp/lib_dev.so}
+mkdir -p tools/exp/objs
+FILES=$(sed -n 's/^SRCS := //p' $SRC/Makefile | sed 's/\.hip//g')
+CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -pragma-unroll-threshold=200000 -DRTPOSE_DEV_BUILD -Iinclude -I$SRC"
 objs=""
-for f in conv_mfma conv_mfma_bf16 layout_ops net shufflenet decode legacy_pafprocess; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DRTPOSE_DEV_BUILD "$@" -Iinclude -I$SRC -c $SRC/$f.hip -o tools/exp/dev_$f.o &
-  objs="$objs tools/exp/dev_$f.o"
+for f in $FILES; do
+  o=tools/exp/objs/$f.o
+  if [ -n "$ONLY" ]; then
+    if [ "$f" = "$ONLY" ]; then
+      o=tools/exp/objs/$f.variant.o
+      $CC "$@" -c $SRC/$f.hip -o $o &
+    elif [ ! -f $o ] || [ $SRC/$f.hip -nt $o ]; then
+      $CC -c $SRC/$f.hip -o $o &
+    fi
+  else
+    o=tools/exp/objs/$f.all.o
+    $CC "$@" -c $SRC/$f.hip -o $o &
+  fi
+  objs="$objs $o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/exp/lib_dev.so $objs
-rm -f $objs
-ls -la tools/exp/lib_dev.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $objs
+ls -la $OUT
