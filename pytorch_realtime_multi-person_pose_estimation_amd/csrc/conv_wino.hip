@@ -31,24 +31,13 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "wino_common.h"
 
 namespace rtpose {
 
 namespace wino {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-typedef const floatx4 __attribute__((address_space(1)))* gcf4_t;
-__device__ __forceinline__ float4 gload4(const void* p) {
-  const floatx4 v = *(gcf4_t)(unsigned long long)(p);
-  return make_float4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ float4 operator+(float4 a, float4 b) {
-  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-}
-__device__ __forceinline__ float4 operator-(float4 a, float4 b) {
-  return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
-}
+using namespace winoc;
 
 struct Group {
   const float* in;
@@ -109,35 +98,55 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   const int cg = tid % CG, tl = (tid / CG) % NT;
   const int half = __builtin_amdgcn_readfirstlane(tid / (CG * NT));
   const float sgn = half ? -1.f : 1.f;
-  const float* pbase;
+  // every global operand comes through a raw buffer load: per-lane byte offset in ONE register for the whole
+  // kernel, everything that moves (chunk, patch row / column, frequency) in the scalar offset
+  // (the input descriptor is based at the block's first patch, so the 32-bit offsets stay small whatever the
+  // size of the activation buffer)
+  const i32x4 rw = make_rsrc(g.w);
+  i32x4 rin;
+  unsigned pvoff;
   {
-    const int t = min(mt * NT + tl, A.T - 1);  // wtiles past the end re-read the last one
-    const int n = t / TT, r = t - n * TT;
-    const int ty = r / A.TX, tx = r - ty * A.TX;
-    const size_t q = (size_t)g.in_lead + (size_t)(n * g.in_hs + 2 * ty - 1) * g.in_ws + (2 * tx - 1);
-    pbase = g.in + q * g.in_cstride + g.in_choff + cg * 4;
+    auto patch_q = [&](int t) -> size_t {
+      const int n = t / TT, r = t - n * TT;
+      const int ty = r / A.TX, tx = r - ty * A.TX;
+      return (size_t)g.in_lead + (size_t)(n * g.in_hs + 2 * ty - 1) * g.in_ws + (2 * tx - 1);
+    };
+    const size_t q0 = patch_q(min(mt * NT, A.T - 1));                // uniform: lowest address of the block
+    const size_t q = patch_q(min(mt * NT + tl, A.T - 1));            // wtiles past the end re-read the last one
+    rin = make_rsrc(g.in + q0 * g.in_cstride + g.in_choff);
+    pvoff = (unsigned)(((q - q0) * g.in_cstride + cg * 4) * 4);
   }
-  int poff[3][4];
+  unsigned psoff[3];  // uniform byte offsets of this half's three patch rows
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const int row = half ? (r == 0 ? 2 : r == 1 ? 3 : 1) : r;
-#pragma unroll
-    for (int x = 0; x < 4; ++x) poff[r][x] = (row * g.in_ws + x) * g.in_cstride;
+    psoff[r] = (unsigned)(row * g.in_ws * g.in_cstride * 4);
   }
-  float4 p[3][4], ta[4], tb[4];
-  auto load_piece = [&](int chunk, int i) { p[i >> 2][i & 3] = gload4(pbase + chunk * CK + poff[i >> 2][i & 3]); };
-  auto form_ta = [&](int x) { ta[x] = p[0][x] - p[2][x]; };
-  auto form_tb = [&](int x) {
-    tb[x] = make_float4(__builtin_fmaf(sgn, p[1][x].x, p[2][x].x), __builtin_fmaf(sgn, p[1][x].y, p[2][x].y),
-                        __builtin_fmaf(sgn, p[1][x].z, p[2][x].z), __builtin_fmaf(sgn, p[1][x].w, p[2][x].w));
+  const unsigned pxb = (unsigned)g.in_cstride * 4;  // bytes per pixel
+  F4 p[3][4], ta[4], tb[4];
+  auto load_piece = [&](int chunk, int i) {
+    p[i >> 2][i & 3] = bload(rin, pvoff, (unsigned)chunk * (CK * 4) + psoff[i >> 2] + (i & 3) * pxb);
   };
-  // V[f][cg][wtile], f = fy * 4 + fx; this thread writes fy in {2 half, 2 half + 1}; B^T over x as above
+  // V[f][cg][wtile], f = fy * 4 + fx; this thread writes fy in {2 half, 2 half + 1}; B^T over x as over the rows
   const int vst = (half * 8 * CG + cg) * NT + tl;
-  auto store_v = [&](int buf, int o) {
-    const float4* t = (o & 4) ? tb : ta;
-    const int fx = o & 3;
-    const float4 v = fx == 0 ? t[0] - t[2] : fx == 1 ? t[1] + t[2] : fx == 2 ? t[2] - t[1] : t[1] - t[3];
-    V4[buf * VBUF + vst + o * CG * NT] = v;
+  // transform in two groups of 16 packed VALU instructions (few, full groups: see wino_common.h)
+  auto tgroup = [&](int buf, int gidx) {
+    if (gidx == 0) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        ta[x] = sub4(p[0][x], p[2][x]);
+        tb[x] = fma4(sgn, p[1][x], p[2][x]);
+      }
+    } else {
+      float4* v = V4 + buf * VBUF + vst;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        const F4* t = (o & 4) ? tb : ta;
+        const int fx = o & 3;
+        v[o * CG * NT] = to_float4(fx == 0 ? sub4(t[0], t[2]) : fx == 1 ? add4(t[1], t[2]) : fx == 2 ? sub4(t[2], t[1])
+                                                                                          : sub4(t[1], t[3]));
+      }
+    }
   };
 
   // ---- MFMA roles -----------------------------------------------------------------------------
@@ -153,34 +162,26 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[5][r] = b0;
   }
-  // B: uniform base that advances one step (2 frequencies) at a time + per-lane byte offsets
-  const char* wq = reinterpret_cast<const char*>(g.w);
-  unsigned boff[2][G];
-#pragma unroll
-  for (int fs = 0; fs < 2; ++fs)
-#pragma unroll
-    for (int gi = 0; gi < G; ++gi) boff[fs][gi] = (unsigned)(((fs * CG + 2 * gi + kh) * g.cout_pad + ncol) * 16);
-  const size_t bstep = (size_t)2 * CG * g.cout_pad * 16;  // bytes per step
+  // B: lane offset (k half, column) in one register; (frequency of the pair, k group) and the step in the scalar offset
+  const unsigned boff = (unsigned)((kh * g.cout_pad + ncol) * 16);
+  const unsigned cgstep = (unsigned)(g.cout_pad * 16);     // bytes per channel group plane
+  const unsigned bstep = (unsigned)(2 * CG) * cgstep;      // bytes per step (2 frequencies)
+  unsigned wso = 0;                                        // uniform byte offset of the next step to fetch
   float4 bs[4][2][G];  // [step % 4][frequency of the pair][k group]
 #pragma unroll
-  for (int fs = 0; fs < 2; ++fs)
+  for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-    for (int gi = 0; gi < G; ++gi) {
-      bs[0][fs][gi] = gload4(wq + boff[fs][gi]);
-      bs[1][fs][gi] = gload4(wq + bstep + boff[fs][gi]);
-    }
-  wq += 2 * bstep;
+    for (int fs = 0; fs < 2; ++fs)
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi) bs[s2][fs][gi] = bload_f4(rw, boff, wso + (fs * CG + 2 * gi) * cgstep);
+    wso += bstep;
+  }
 
   const int nchunks = A.cin / CK;
 #pragma unroll
   for (int i = 0; i < 12; ++i) load_piece(0, i);
-#pragma unroll
-  for (int x = 0; x < 4; ++x) {
-    form_ta(x);
-    form_tb(x);
-  }
-#pragma unroll
-  for (int o = 0; o < 8; ++o) store_v(0, o);
+  tgroup(0, 0);
+  tgroup(0, 1);
   {
     const int c1 = min(1, nchunks - 1);
 #pragma unroll
@@ -190,8 +191,8 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
 
   // One step = the two frequencies 2s, 2s+1 = 8 G MFMAs on two alternating accumulators.  Between MFMA
   // pairs, in a fixed (pinned) order: the A fragments of the next step (LDS), the B fragments two steps
-  // ahead (L2), and one micro-op of the input transform of the NEXT chunk: 8 adds that consume the
-  // patch registers, the 12 patch loads of the chunk after that, 8 row transforms + LDS writes.
+  // ahead (L2); the last slot of step 0 / 1 also carries the two halves of the input transform of the NEXT
+  // chunk, the last slots of steps 2..7 two patch loads each of the chunk after that.
 #define RTPOSE_PIN()             \
   asm volatile("" ::: "memory"); \
   __builtin_amdgcn_sched_barrier(0)
@@ -223,16 +224,16 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
           if (s < 7) a[(s + 1) & 1][slot / G][slot % G] = va[((2 * (s + 1) + slot / G) * CG + 2 * (slot % G)) * NT];
         } else {             // B two steps ahead
           const int i = slot - 2 * G;
-          bs[(s + 2) & 3][i / G][i % G] = gload4(wq + boff[i / G][i % G]);
-          if (slot == SLOTS - 1) wq += bstep;
+          bs[(s + 2) & 3][i / G][i % G] = bload_f4(rw, boff, wso + ((i / G) * CG + 2 * (i % G)) * cgstep);
+          if (slot == SLOTS - 1) wso += bstep;
         }
-        {  // input transform micro-op
-          const int kk = s * SLOTS + slot;
-          const int op = G == 2 ? ((kk & 1) ? -1 : kk >> 1) : kk;
-          if (op >= 0 && op < 4) form_ta(op);
-          else if (op >= 4 && op < 8) form_tb(op - 4);
-          else if (op >= 8 && op < 20) load_piece(c2, op - 8);
-          else if (op >= 20 && op < 28) store_v(nbuf, op - 20);
+        if (slot == SLOTS - 1) {
+          if (s < 2) {
+            tgroup(nbuf, s);
+          } else {
+            load_piece(c2, 2 * (s - 2));
+            load_piece(c2, 2 * (s - 2) + 1);
+          }
         }
         RTPOSE_PIN();
       }

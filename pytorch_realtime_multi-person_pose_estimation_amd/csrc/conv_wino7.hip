@@ -32,62 +32,13 @@
 
 #include "common.h"
 #include "conv_exp.h"
+#include "wino_common.h"
 
 namespace rtpose {
 
 namespace wino7 {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-// 16 bytes as two packed pairs: the transform below is written on float2 so that it compiles to
-// v_pk_fma_f32 / v_pk_add_f32 (fp32 VALU instructions take their cycles from the SAME ALUs the fp32 MFMAs
-// run on - tools/exp/mfma_issue.hip: 64 -> 101 cycles per MFMA with 4 v_fma_f32 after each, at one or two
-// waves per SIMD alike - so every VALU instruction in the multiply loop is paid for in matrix throughput).
-struct F4 {
-  f2 lo, hi;
-};
-__device__ __forceinline__ F4 fma4(float s, F4 a, F4 b) {  // s * a + b, one rounding
-  const f2 ss = {s, s};
-  return F4{__builtin_elementwise_fma(ss, a.lo, b.lo), __builtin_elementwise_fma(ss, a.hi, b.hi)};
-}
-__device__ __forceinline__ F4 mul4(float s, F4 a) {
-  const f2 ss = {s, s};
-  return F4{ss * a.lo, ss * a.hi};
-}
-__device__ __forceinline__ F4 add4(F4 a, F4 b) { return F4{a.lo + b.lo, a.hi + b.hi}; }
-__device__ __forceinline__ F4 sub4(F4 a, F4 b) { return F4{a.lo - b.lo, a.hi - b.hi}; }
-__device__ __forceinline__ float4 to_float4(F4 a) { return make_float4(a.lo.x, a.lo.y, a.hi.x, a.hi.y); }
-
-// Raw buffer loads: address = base (4 SGPRs) + per-lane byte offset (1 VGPR, fixed for the whole kernel) + uniform
-// byte offset (1 SGPR, advanced by the scalar unit): no vector instruction is spent on address arithmetic.
-// (Bound to the LLVM intrinsic by name: this compiler lowers __builtin_amdgcn_raw_buffer_load_b128 to a
-// ONE-dword load.)
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ f32x4 llvm_raw_buffer_load_v4f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm(
-    "llvm.amdgcn.raw.buffer.load.v4f32");
-__device__ __forceinline__ i32x4 make_rsrc(const void* p) {
-  union {
-    struct {
-      const void* p;
-      unsigned range, cfg;
-    } s;
-    i32x4 v;
-  } u;
-  u.s.p = p;
-  u.s.range = 0x7ffffffe;  // bytes addressable from p
-  u.s.cfg = 0x00020000;    // raw buffer, 32-bit data format
-  return u.v;
-}
-__device__ __forceinline__ F4 bload(i32x4 r, unsigned voff, unsigned soff) {
-  const f32x4 v = llvm_raw_buffer_load_v4f32(r, (int)voff, (int)soff, 0);
-  return F4{f2{v.x, v.y}, f2{v.z, v.w}};
-}
-__device__ __forceinline__ float4 bload_f4(i32x4 r, unsigned voff, unsigned soff) {
-  const f32x4 v = llvm_raw_buffer_load_v4f32(r, (int)voff, (int)soff, 0);
-  return make_float4(v.x, v.y, v.z, v.w);
-}
+using namespace winoc;
 
 // Input transform, rows scaled by N_f = prod_{l != f} (p_f - p_l) (the filter transform divides by it):
 // every entry is a multiple of 1/16, exact in fp32.  Rows 2p+1 / 2p+2 (points +-p) share their even- and
@@ -195,7 +146,10 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
   // image's - data) when W is not a multiple of 4.  Those inputs only meet outputs that are not stored, but
   // through the transform they would cancel only up to rounding, and an image's result would depend on its
   // neighbour in the batch: segments n = 7..9 are therefore clamped to the last gap pixel (a zero).
-  const i32x4 rin = make_rsrc(g.in), rw = make_rsrc(g.w);
+  // (the input descriptor is based at the block's first row, so the 32-bit offsets stay small whatever the size
+  // of the activation buffer)
+  const long qbase = (long)g.in_lead + (long)(R0 - 3) * g.in_ws - 3;
+  const i32x4 rin = make_rsrc(g.in + qbase * g.in_cstride + g.in_choff), rw = make_rsrc(g.w);
   unsigned voff[NI], vhi[NI][3];
   int vdst[NI];
 #pragma unroll
@@ -203,8 +157,7 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
     const int i = min(tid + k * 256, nitems - 1);  // surplus threads repeat the last item (same value, same slot)
     const int r = i / (GX * CG), rem = i - r * (GX * CG);
     const int gx = rem >> 1, cg = rem & 1;
-    const long q = (long)g.in_lead + (long)(R0 - 3 + r) * g.in_ws + (4 * gx - 3);
-    voff[k] = (unsigned)((q * g.in_cstride + g.in_choff + cg * 4) * 4);
+    voff[k] = (unsigned)((((long)r * g.in_ws + 4 * gx) * g.in_cstride + cg * 4) * 4);
     vdst[k] = r * RS + cg * GX + gx;
 #pragma unroll
     for (int n = 7; n < 10; ++n) vhi[k][n - 7] = voff[k] + (unsigned)(min(n, A.W + 5 - 4 * gx) * g.in_cstride * 4);
@@ -513,8 +466,6 @@ int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
     if (di.lin.choff + di.cin > di.lin.cstride)
       return fail(RTPOSE_E_INVAL, "conv2d_winograd: input slice exceeds cstride");
     if (di.out_cmap) return fail(RTPOSE_E_INVAL, "conv2d_winograd: out_cmap is not supported");
-    if (rtpose_layout_pixels(&di.lin, N, H, W) * (size_t)di.lin.cstride * 4 >= 0x7ffffffeull)
-      return fail(RTPOSE_E_INVAL, "conv2d_winograd: input buffer beyond the 2 GB a buffer descriptor addresses");
     Group& g = a.g[i];
     g.in = di.in;
     g.w = di.w_packed;
