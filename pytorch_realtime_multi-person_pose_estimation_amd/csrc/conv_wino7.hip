@@ -29,6 +29,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "common.h"
 #include "conv_exp.h"
@@ -75,6 +78,9 @@ struct Args {
   int RS;       // float4 per transformed row in LDS (>= 20 GX, chosen against bank conflicts)
   int VB;       // float4 per V buffer
   int mtiles, ntiles, ncombo, xcd_remap;
+  int persist;      // 1: gridDim.x blocks share the (tile, chunk) units evenly (see wino7_f32)
+  float* scratch;   // persist: one partial accumulator tile per block (4 waves x 160 registers x 64 lanes)
+  int* flags;       // persist: flags[p] = 1 while block p's partial tile is waiting to be merged
 };
 
 constexpr int CK = 8, CG = 2;   // channels per chunk, 16-byte channel groups per chunk
@@ -94,25 +100,17 @@ __host__ __device__ constexpr int strip_rows(int gx) { return (31 + gx - 1) / gx
 // NI  = (row, gx, channel group) transform items per thread and chunk
 // GXT = compile-time position groups per row (0: run-time).  With GXT every LDS address of the multiply loop is
 //       one base register + an immediate; the run-time form pays one v_add per access.
+// One segment = chunks [cb, ce) of tile (mt, c).  part 0: the whole tile (store it); part 2: the LAST chunks of a
+// tile whose first chunks belong to the previous block: the raw accumulators go to scratch slot `slot`; part 1: the
+// FIRST chunks of a tile whose last chunks the next block has already done (it does them first thing): wait for
+// its slot, add the partial sums, store the tile.
 template <int NI, int GXT>
-__global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
-  extern __shared__ __attribute__((aligned(16))) float4 V4[];
+__device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const int mt, const int c, const int cb,
+                                              const int ce, const int part, const int slot) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, kh = lane >> 5;
-
-  const int bi = blockIdx.x;
-  int mt, c;
-  if (A.xcd_remap) {
-    const int xcd = bi & 7, j = bi >> 3;
-    c = j % A.ncombo;
-    mt = (j / A.ncombo) * 8 + xcd;
-  } else {
-    mt = bi % A.mtiles;
-    c = bi / A.mtiles;
-  }
-  if (mt >= A.mtiles) return;
   const int nt = c % A.ntiles, grp = c / A.ntiles;
   const Group g = grp ? A.g[1] : A.g[0];
   const int GX = GXT ? GXT : A.GX;
@@ -208,14 +206,14 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
   for (int f = 0; f < 10; ++f)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-  {
+  if (cb == 0) {
     const float b0 = g.bias[ncol];  // padded to cout_pad
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[1][r] = b0;
   }
   const unsigned boff = (unsigned)((kh * g.cout_pad + ncol) * 16);
   const unsigned fstep = (unsigned)(CG * g.cout_pad * 16);  // bytes per frequency block
-  unsigned wso = 0;                                         // uniform byte offset of the next B step to fetch
+  unsigned wso = (unsigned)cb * (2 * NPS) * fstep;          // uniform byte offset of the next B step to fetch
   float4 bs[5][2];
 #pragma unroll
   for (int s = 0; s < PF; ++s) {
@@ -224,17 +222,16 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
     wso += 2 * fstep;
   }
 
-  const int nchunks = A.cin / CK;
 #pragma unroll
   for (int k = 0; k < NI; ++k)
 #pragma unroll
-    for (int n = 0; n < 10; ++n) load_piece(0, k, n);
+    for (int n = 0; n < 10; ++n) load_piece(cb, k, n);
 #pragma unroll
   for (int k = 0; k < NI; ++k)
 #pragma unroll
     for (int gi = 0; gi < 6; ++gi) tgroup(V4, k, gi);
   {
-    const int c1 = min(1, nchunks - 1);
+    const int c1 = min(cb + 1, ce - 1);
 #pragma unroll
     for (int k = 0; k < NI; ++k)
 #pragma unroll
@@ -252,10 +249,10 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
   constexpr int NG = 6 * NI, GSTR = NI == 1 ? 2 : 1;
   static_assert(12 + 5 * NI <= NPS, "transform work does not fit the steps of a chunk");
   float4 a[2][2];
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const float4* va = V4 + (chunk & 1) * VB + abase;
-    float4* vw = V4 + ((chunk + 1) & 1) * VB;
-    const int c2 = min(chunk + 2, nchunks - 1);  // the last chunks re-stage themselves (never read)
+  for (int chunk = cb; chunk < ce; ++chunk) {
+    const float4* va = V4 + ((chunk - cb) & 1) * VB + abase;
+    float4* vw = V4 + ((chunk - cb + 1) & 1) * VB;
+    const int c2 = min(chunk + 2, ce - 1);  // the last chunks re-stage themselves (never read)
     a[0][0] = va[0];
     a[0][1] = va[CG * GX];
 #pragma unroll
@@ -295,6 +292,32 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
     __syncthreads();
   }
 #undef RTPOSE_PIN
+
+  // ---- split tiles: hand the partial sums over / take them in ------------------------------------------
+  if (part) {
+    float* sp = A.scratch + ((size_t)(slot * 4 + wn) * 160) * 64 + lane;
+    if (part == 2) {
+#pragma unroll
+      for (int f = 0; f < 10; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sp[(f * 16 + r) * 64] = acc[f][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();  // every wave's partial is out (and released) before the flag goes up
+      if (tid == 0) __hip_atomic_store(A.flags + slot, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid == 0) {
+      while (__hip_atomic_load(A.flags + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+    for (int f = 0; f < 10; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[f][r] += sp[(f * 16 + r) * 64];
+    __syncthreads();  // all reads done before the slot is handed back
+    if (tid == 0) __hip_atomic_store(A.flags + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 
   // ---- epilogue: output transform AT (points 0, +-1, +-2, +-1/2, +-3/2, inf), (+ReLU), masked stores ----
   // accumulator register r of a lane = position (r / 4) * 8 + 4 kh + r % 4 of the block, column l31
@@ -338,6 +361,47 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
         ++sn;
       }
     }
+  }
+}
+
+// Grid: either one block per tile (persist = 0; XCD-aware order as in conv_mfma.hip), or - when there are at
+// least as many tiles as blocks - gridDim.x persistent blocks that share the (tile, chunk) units of the launch
+// EVENLY: block p owns units [p U / P, (p + 1) U / P) of the tile-major order, i.e. the tail of one tile, some whole
+// tiles, the head of another.  32 x 46 x 46 x (2 branches): 1152 tiles on 256 CUs are 4.5 tiles per CU instead of 5
+// rounds of whole tiles.  A tile is split between at most two blocks (units per block >= chunks per tile); the
+// block holding the head stores it (wino7_segment).  Partial sums are added in a different order than in an unsplit
+// tile: bitwise results depend on where a tile falls in the launch (run-to-run deterministic).
+template <int NI, int GXT>
+__global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
+  extern __shared__ __attribute__((aligned(16))) float4 V4[];
+  const int nch = A.cin / CK;
+  long u0, u1;
+  if (A.persist) {
+    const long U = (long)A.mtiles * A.ncombo * nch, P = gridDim.x, p = blockIdx.x;
+    u0 = p * U / P;
+    u1 = (p + 1) * U / P;
+  } else {
+    const int bi = blockIdx.x;
+    int mt, c;
+    if (A.xcd_remap) {
+      const int xcd = bi & 7, j = bi >> 3;
+      c = j % A.ncombo;
+      mt = (j / A.ncombo) * 8 + xcd;
+    } else {
+      mt = bi % A.mtiles;
+      c = bi / A.mtiles;
+    }
+    if (mt >= A.mtiles) return;
+    u0 = ((long)mt * A.ncombo + c) * nch;
+    u1 = u0 + nch;
+  }
+  for (long u = u0; u < u1;) {
+    const int tile = (int)(u / nch), cb = (int)(u - (long)tile * nch);
+    const int ce = min(nch, cb + (int)(u1 - u));
+    const int part = cb > 0 ? 2 : (ce < nch ? 1 : 0);
+    const int mt = tile / A.ncombo, c = tile - mt * A.ncombo;
+    wino7_segment<NI, GXT>(A, V4, mt, c, cb, ce, part, part == 2 ? (int)blockIdx.x : (int)blockIdx.x + 1);
+    u += ce - cb;
   }
 }
 
@@ -416,6 +480,30 @@ static int make_plan(int N, int H, int W, int hs, Plan* p) {
   p->nrows = nrows;
   p->ni = ceil_div(nrows * p->gx * CG, 256);
   p->lds = (size_t)2 * nrows * p->rs * 16;
+  return 0;
+}
+
+// Scratch of the persistent form: one partial tile + one flag per block, per (device, stream) - launches on one
+// stream are serialised, launches on different streams must not share slots.  Never freed (a few per process).
+struct Scratch {
+  float* partial = nullptr;
+  int* flags = nullptr;
+  int blocks = 0;
+};
+static int get_scratch(hipStream_t s, int blocks, Scratch* out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, Scratch> pool;
+  std::lock_guard<std::mutex> lock(mu);
+  Scratch& sc = pool[std::make_pair(current_device(), s)];
+  if (sc.blocks < blocks + 1) {
+    // (a replaced allocation is leaked on purpose: an earlier launch on the stream may still be using it)
+    const size_t n = (size_t)(blocks + 1);
+    RTPOSE_HIP_CHECK(hipMalloc(&sc.partial, n * 4 * 160 * 64 * sizeof(float)));
+    RTPOSE_HIP_CHECK(hipMalloc(&sc.flags, n * sizeof(int)));
+    RTPOSE_HIP_CHECK(hipMemsetAsync(sc.flags, 0, n * sizeof(int), s));
+    sc.blocks = blocks + 1;
+  }
+  *out = sc;
   return 0;
 }
 
@@ -500,8 +588,29 @@ int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
   a.ntiles = cout_pad(d0.cout) / 128;
   a.ncombo = a.ntiles * ngroups;
   a.xcd_remap = (a.ncombo > 1 && a.mtiles >= 64) ? 1 : 0;
-  const long ids = a.xcd_remap ? (long)8 * a.ncombo * ceil_div(a.mtiles, 8) : (long)a.mtiles * a.ncombo;
+  long ids = a.xcd_remap ? (long)8 * a.ncombo * ceil_div(a.mtiles, 8) : (long)a.mtiles * a.ncombo;
   if (ids > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv2d_winograd: grid too large");
+  {
+    // persistent form: as many blocks as CUs share the (tile, chunk) units evenly; worth it (and valid: a tile
+    // may be split between at most two blocks) when there are at least as many tiles as CUs and the tiles do
+    // not already come out as whole rounds
+    const int n_cu = device_cu_count();
+    const long tiles = (long)a.mtiles * a.ncombo;
+    static int persist_env = -1;
+    if (persist_env < 0) {
+      const char* e = dev_env("RTPOSE_W7_PERSIST");
+      persist_env = e ? atoi(e) : 1;
+    }
+    if (persist_env && tiles >= n_cu && tiles % n_cu != 0) {
+      Scratch sc;
+      const int rc = get_scratch(s, n_cu, &sc);
+      if (rc) return rc;
+      a.persist = 1;
+      a.scratch = sc.partial;
+      a.flags = sc.flags;
+      ids = n_cu;
+    }
+  }
   const dim3 grid((unsigned)ids, 1, 1);
   // 46-wide maps (368 x 368 inputs, BASELINE configs[1]): every LDS offset of the multiply loop is an immediate
   if (p.gx == 12 && p.tpi && p.ni == 1 && p.nrows == strip_rows(12))

@@ -139,6 +139,17 @@ def test_winograd7_grouped_branches_and_direct_agree(capi, cuda):
         assert (o - d).abs().max().item() <= 1e-4 * max(1.0, r.abs().max().item())
 
 
+def test_winograd7_persistent_blocks_split_tiles(capi, cuda):
+    """8 x 46 x 46, two branches = 288 tiles >= 256 CUs: the launch runs as persistent blocks that share the
+    (tile, chunk) units evenly, most tiles' sums are split between two blocks (conv_wino7.hip: wino7_f32).
+    Run twice: the hand-over flags are back to zero after a launch, the result is deterministic."""
+    outs, refs = _run_conv(capi, cuda, 8, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=11, groups=2, winograd=True)
+    again, _ = _run_conv(capi, cuda, 8, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=11, groups=2, winograd=True)
+    for o, r, o2 in zip(outs, refs, again):
+        assert (o - r).abs().max().item() <= TOL * max(1.0, r.abs().max().item())
+        assert torch.equal(o, o2)
+
+
 WINO_CASES = [
     # n, h, w, cin, cout, relu, pool, pad_in, pad_out       (k = 3; csrc/conv_wino.hip)
     (2, 46, 46, 256, 512, 1, 0, 1, 1),     # conv4_1: 32 wtiles x 128 columns, 4 N tiles, XCD-ordered grid
