@@ -12,7 +12,7 @@
     defined(RTPOSE_EXP_NO_STAGE) || defined(RTPOSE_EXP_NO_FILL) || defined(RTPOSE_EXP_NO_STORE) ||      \
     defined(RTPOSE_EXP_SCALAR_STORE) || defined(RTPOSE_EXP_BSPREAD) || defined(RTPOSE_EXP_HALF_B_ON) || \
     defined(RTPOSE_EXP_STAGGER) || defined(RTPOSE_EXP_TB1X1) || defined(RTPOSE_EXP_HD) ||               \
-    defined(RTPOSE_EXP_RB2) || defined(RTPOSE_EXP_W7_PF)
+    defined(RTPOSE_EXP_RB2) || defined(RTPOSE_EXP_W7_PF) || defined(RTPOSE_EXP_W7_TMASK) || defined(RTPOSE_EXP_W7_LPS)
 #error "RTPOSE_EXP_* ablation switches need -DRTPOSE_DEV_BUILD (they are not part of production builds)"
 #endif
 #endif
@@ -49,9 +49,20 @@ inline const char* dev_env(const char* name) {
 #define RTPOSE_EXP_RB2 4
 #endif
 
-// F(4,7) kernel: weight prefetch distance in (ky, frequency pair) steps (<= 4: 5 register sets)
+// F(4,7) kernel: weight prefetch distance in (ky, frequency pair) steps (<= 4: 5 register sets; 2: +5 %, 3: +0.7 %)
 #ifndef RTPOSE_EXP_W7_PF
-#define RTPOSE_EXP_W7_PF 3
+#define RTPOSE_EXP_W7_PF 4
+#endif
+
+// F(4,7) kernel: which parts of the next chunk's input transform run in the multiply loop (1: the VALU groups +
+// LDS writes, 2: the segment loads)
+// segment loads per step (1: 0.719 -> 0.695 ms per 128 -> 128 layer against 2; the loads touch 32 cache lines
+// each and all four waves issue them in the same steps, 5 per step 0.718)
+#ifndef RTPOSE_EXP_W7_LPS
+#define RTPOSE_EXP_W7_LPS 1
+#endif
+#ifndef RTPOSE_EXP_W7_TMASK
+#define RTPOSE_EXP_W7_TMASK 3
 #endif
 
 // fp32: which B register (k-group) is fetched after MFMA pair n (-1 = none); GB is the kernel's

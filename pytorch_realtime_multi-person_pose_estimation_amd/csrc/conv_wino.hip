@@ -168,14 +168,6 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   const unsigned bstep = (unsigned)(2 * CG) * cgstep;      // bytes per step (2 frequencies)
   unsigned wso = 0;                                        // uniform byte offset of the next step to fetch
   float4 bs[4][2][G];  // [step % 4][frequency of the pair][k group]
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-    for (int fs = 0; fs < 2; ++fs)
-#pragma unroll
-      for (int gi = 0; gi < G; ++gi) bs[s2][fs][gi] = bload_f4(rw, boff, wso + (fs * CG + 2 * gi) * cgstep);
-    wso += bstep;
-  }
 
   const int nchunks = A.cin / CK;
 #pragma unroll
@@ -186,6 +178,15 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
     const int c1 = min(1, nchunks - 1);
 #pragma unroll
     for (int i = 0; i < 12; ++i) load_piece(c1, i);
+  }
+  // (B after the patch loads, as in the steady state of the loop: see conv_wino7.hip)
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+    for (int fs = 0; fs < 2; ++fs)
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi) bs[s2][fs][gi] = bload_f4(rw, boff, wso + (fs * CG + 2 * gi) * cgstep);
+    wso += bstep;
   }
   __syncthreads();
 

@@ -79,13 +79,13 @@ struct Args {
   int VB;       // float4 per V buffer
   int mtiles, ntiles, ncombo, xcd_remap;
   int persist;      // 1: gridDim.x blocks share the (tile, chunk) units evenly (see wino7_f32)
-  float* scratch;   // persist: one partial accumulator tile per block (4 waves x 160 registers x 64 lanes)
-  int* flags;       // persist: flags[p] = 1 while block p's partial tile is waiting to be merged
+  float* scratch;   // persist: one accumulator tile per block (4 waves x 160 registers x 64 lanes)
+  int* flags;       // persist: flags[p] = 1 while the sums block p saved wait for block p + 1
 };
 
 constexpr int CK = 8, CG = 2;   // channels per chunk, 16-byte channel groups per chunk
 constexpr int NPS = 35;         // (ky, frequency pair) steps per chunk
-constexpr int PF = RTPOSE_EXP_W7_PF;  // B prefetch distance in steps (3); 5 register sets (35 % 5 == 0)
+constexpr int PF = RTPOSE_EXP_W7_PF;  // B prefetch distance in steps (4); 5 register sets (35 % 5 == 0)
 
 // LDS row stride (float4): >= 20 GX, and = GX modulo 16 so that the 32 positions of a wave tile, which
 // wrap from one transformed row to the next, keep landing in distinct 16-byte bank slots
@@ -100,13 +100,13 @@ __host__ __device__ constexpr int strip_rows(int gx) { return (31 + gx - 1) / gx
 // NI  = (row, gx, channel group) transform items per thread and chunk
 // GXT = compile-time position groups per row (0: run-time).  With GXT every LDS address of the multiply loop is
 //       one base register + an immediate; the run-time form pays one v_add per access.
-// One segment = chunks [cb, ce) of tile (mt, c).  part 0: the whole tile (store it); part 2: the LAST chunks of a
-// tile whose first chunks belong to the previous block: the raw accumulators go to scratch slot `slot`; part 1: the
-// FIRST chunks of a tile whose last chunks the next block has already done (it does them first thing): wait for
-// its slot, add the partial sums, store the tile.
+// One segment = chunks [cb, ce) of tile (mt, c).  A tile split between two blocks is summed in the SAME order as an
+// unsplit one: the block with the first chunks (cb == 0, ce < all) saves its raw accumulators to scratch slot
+// `slot` and raises the flag; the block with the last chunks (cb > 0) starts from them instead of from zero and
+// stores the tile.  Results are bit-identical however the launch is cut.
 template <int NI, int GXT>
 __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const int mt, const int c, const int cb,
-                                              const int ce, const int part, const int slot) {
+                                              const int ce, const int nch, const int slot) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -202,25 +202,32 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   }
   const int ncol = nt * 128 + wn * 32 + l31;
   floatx16 acc[10];
-#pragma unroll
-  for (int f = 0; f < 10; ++f)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+  float* sp = A.scratch + ((size_t)(slot * 4 + wn) * 160) * 64 + lane;  // this wave's rows of the scratch slot
   if (cb == 0) {
+#pragma unroll
+    for (int f = 0; f < 10; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
     const float b0 = g.bias[ncol];  // padded to cout_pad
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[1][r] = b0;
+  } else {  // continue the sums the previous block started (it did so first thing: the wait is a formality)
+    if (tid == 0) {
+      while (__hip_atomic_load(A.flags + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+    for (int f = 0; f < 10; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[f][r] = sp[(f * 16 + r) * 64];
+    __syncthreads();  // all reads done before the slot is handed back
+    if (tid == 0) __hip_atomic_store(A.flags + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   const unsigned boff = (unsigned)((kh * g.cout_pad + ncol) * 16);
   const unsigned fstep = (unsigned)(CG * g.cout_pad * 16);  // bytes per frequency block
   unsigned wso = (unsigned)cb * (2 * NPS) * fstep;          // uniform byte offset of the next B step to fetch
   float4 bs[5][2];
-#pragma unroll
-  for (int s = 0; s < PF; ++s) {
-    bs[s][0] = bload_f4(rw, boff, wso);
-    bs[s][1] = bload_f4(rw, boff, wso + fstep);
-    wso += 2 * fstep;
-  }
 
 #pragma unroll
   for (int k = 0; k < NI; ++k)
@@ -237,6 +244,15 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
 #pragma unroll
       for (int n = 0; n < 10; ++n) load_piece(c1, k, n);
   }
+  // (the first B fragments are requested AFTER the segment loads, as in the steady state of the loop below: the
+  //  compiler's in-order vmcnt bookkeeping merges the two entries of the loop, and with the B loads older than the
+  //  segment loads here it made every transform group wait for the B loads in flight - 5 % of the kernel)
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    bs[s][0] = bload_f4(rw, boff, wso);
+    bs[s][1] = bload_f4(rw, boff, wso + fstep);
+    wso += 2 * fstep;
+  }
   __syncthreads();
 
 #define RTPOSE_PIN()             \
@@ -247,7 +263,8 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   // fragments PF steps ahead (L2).  Slot 3 of the first steps also carries transform work of the NEXT chunk: its
   // 6 NI groups (steps 0..11), then the 10 NI segment loads of the chunk after that, two per step.
   constexpr int NG = 6 * NI, GSTR = NI == 1 ? 2 : 1;
-  static_assert(12 + 5 * NI <= NPS, "transform work does not fit the steps of a chunk");
+  constexpr int LPS = RTPOSE_EXP_W7_LPS, LSTEPS = (10 * NI + LPS - 1) / LPS;  // segment loads per step, steps with loads
+  static_assert(12 + LSTEPS <= NPS, "transform work does not fit the steps of a chunk");
   float4 a[2][2];
   for (int chunk = cb; chunk < ce; ++chunk) {
     const float4* va = V4 + ((chunk - cb) & 1) * VB + abase;
@@ -279,11 +296,13 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
         }
         if (RTPOSE_EXP_STAGE && j == 3) {
           if (ps % GSTR == 0 && ps / GSTR < NG) {
-            tgroup(vw, (ps / GSTR) / 6, (ps / GSTR) % 6);
-          } else if (ps >= 12 && ps < 12 + 5 * NI) {  // two segment loads per step
-            const int l = 2 * (ps - 12);
-            load_piece(c2, l / 10, l % 10);
-            load_piece(c2, (l + 1) / 10, (l + 1) % 10);
+            if (RTPOSE_EXP_W7_TMASK & 1) tgroup(vw, (ps / GSTR) / 6, (ps / GSTR) % 6);
+          } else if (ps >= 12 && ps < 12 + LSTEPS && (RTPOSE_EXP_W7_TMASK & 2)) {  // LPS segment loads per step
+#pragma unroll
+            for (int q = 0; q < LPS; ++q) {
+              const int l = LPS * (ps - 12) + q;
+              if (l < 10 * NI) load_piece(c2, l / 10, l % 10);
+            }
           }
         }
         RTPOSE_PIN();
@@ -293,30 +312,16 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   }
 #undef RTPOSE_PIN
 
-  // ---- split tiles: hand the partial sums over / take them in ------------------------------------------
-  if (part) {
-    float* sp = A.scratch + ((size_t)(slot * 4 + wn) * 160) * 64 + lane;
-    if (part == 2) {
-#pragma unroll
-      for (int f = 0; f < 10; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sp[(f * 16 + r) * 64] = acc[f][r];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __syncthreads();  // every wave's partial is out (and released) before the flag goes up
-      if (tid == 0) __hip_atomic_store(A.flags + slot, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-    if (tid == 0) {
-      while (__hip_atomic_load(A.flags + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) __builtin_amdgcn_s_sleep(8);
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // ---- first part of a split tile: hand the sums over ------------------------------------------------
+  if (ce < nch) {
 #pragma unroll
     for (int f = 0; f < 10; ++f)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[f][r] += sp[(f * 16 + r) * 64];
-    __syncthreads();  // all reads done before the slot is handed back
-    if (tid == 0) __hip_atomic_store(A.flags + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int r = 0; r < 16; ++r) sp[(f * 16 + r) * 64] = acc[f][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();  // every wave's sums are out (and released) before the flag goes up
+    if (tid == 0) __hip_atomic_store(A.flags + slot, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
   }
 
   // ---- epilogue: output transform AT (points 0, +-1, +-2, +-1/2, +-3/2, inf), (+ReLU), masked stores ----
@@ -366,11 +371,12 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
 
 // Grid: either one block per tile (persist = 0; XCD-aware order as in conv_mfma.hip), or - when there are at
 // least as many tiles as blocks - gridDim.x persistent blocks that share the (tile, chunk) units of the launch
-// EVENLY: block p owns units [p U / P, (p + 1) U / P) of the tile-major order, i.e. the tail of one tile, some whole
-// tiles, the head of another.  32 x 46 x 46 x (2 branches): 1152 tiles on 256 CUs are 4.5 tiles per CU instead of 5
-// rounds of whole tiles.  A tile is split between at most two blocks (units per block >= chunks per tile); the
-// block holding the head stores it (wino7_segment).  Partial sums are added in a different order than in an unsplit
-// tile: bitwise results depend on where a tile falls in the launch (run-to-run deterministic).
+// EVENLY: block p owns units [p U / P, (p + 1) U / P) of the tile-major order, i.e. the last chunks of one tile,
+// some whole tiles, the first chunks of another.  32 x 46 x 46 x (2 branches): 1152 tiles on 256 CUs are 4.5 tiles
+// per CU instead of 5 rounds of whole tiles.  A tile is split between at most two blocks (units per block >= chunks
+// per tile).  Order inside a block: the FIRST chunks of its last tile first (saved for block p + 1), the whole
+// tiles, and the LAST chunks of its first tile at the very end, continuing the sums block p - 1 saved at its start:
+// nobody waits, and the sums run in the order of an unsplit tile.
 template <int NI, int GXT>
 __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
   extern __shared__ __attribute__((aligned(16))) float4 V4[];
@@ -395,13 +401,27 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
     u0 = ((long)mt * A.ncombo + c) * nch;
     u1 = u0 + nch;
   }
-  for (long u = u0; u < u1;) {
-    const int tile = (int)(u / nch), cb = (int)(u - (long)tile * nch);
-    const int ce = min(nch, cb + (int)(u1 - u));
-    const int part = cb > 0 ? 2 : (ce < nch ? 1 : 0);
+  const int tf = (int)(u0 / nch), cbf = (int)(u0 - (long)tf * nch);          // first tile, its first owned chunk
+  const int tl = (int)((u1 - 1) / nch), cel = (int)(u1 - (long)tl * nch);    // last tile, end of its owned chunks
+  const int nseg = tl - tf + 1;
+  for (int i = 0; i < nseg; ++i) {
+    // segment order: [tl if its end is not owned] , tf + 1 .. , [tf last if its start is not owned]
+    int tile, cb = 0, ce = nch;
+    const bool head_first = cel < nch && nseg > 1, tail_last = cbf > 0;
+    if (head_first && i == 0) {
+      tile = tl;
+      ce = cel;
+    } else if (tail_last && i == nseg - 1) {
+      tile = tf;
+      cb = cbf;
+      if (tf == tl) ce = cel;
+    } else {
+      tile = tf + i - (head_first ? 1 : 0) + (tail_last ? 1 : 0);
+      if (tile == tl) ce = cel;
+    }
     const int mt = tile / A.ncombo, c = tile - mt * A.ncombo;
-    wino7_segment<NI, GXT>(A, V4, mt, c, cb, ce, part, part == 2 ? (int)blockIdx.x : (int)blockIdx.x + 1);
-    u += ce - cb;
+    // slot: a block saves into its own, and continues from its predecessor's
+    wino7_segment<NI, GXT>(A, V4, mt, c, cb, ce, nch, cb > 0 ? (int)blockIdx.x - 1 : (int)blockIdx.x);
   }
 }
 
@@ -634,7 +654,7 @@ int pack_weights_wino7_launch(const float* w, const float* bias, int cout, int c
 }
 
 size_t packed_weight_floats_wino7(int cout, int cin) {
-  // + 3 steps (6 frequency blocks of 8 x cout_pad floats): the B prefetch runs three steps ahead
+  // + 4 steps (8 frequency blocks of 8 x cout_pad floats): the B prefetch runs up to four steps ahead
   return (size_t)(70 * cin + 64) * cout_pad(cout);
 }
 

@@ -13,16 +13,18 @@ TOL = 1e-4  # relative to max|ref|; fp32 fma-chain vs ATen summation order
 
 
 def _run_conv(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, seed, groups=1, cin_pad=None,
-              winograd=False):
+              winograd=False, only_images=None):
     lib, Layout = capi.lib, capi.Layout
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, cin, h, w, generator=g)
+    if only_images:   # the same random stream, but only the first images go through the kernel
+        n = only_images
     cin_p = cin_pad or ((cin + 7) // 8 * 8)
     ws, bs, refs = [], [], []
     for gi in range(groups):
         wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
         b = torch.randn(cout, generator=g) * 0.1
-        y = F.conv2d(x, wt, b, padding=k // 2)
+        y = F.conv2d(x[:n], wt, b, padding=k // 2)
         if relu:
             y = F.relu(y)
         if pool:
@@ -33,7 +35,7 @@ def _run_conv(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, see
     stream = capi.current_stream()
     lin = Layout.padded(cin_p, h, w, pad_in)
     xin = torch.zeros(lib.rtpose_layout_pixels(C.byref(lin), n, h, w) * cin_p, device=dev)
-    xd = x.to(dev)
+    xd = x[:n].contiguous().to(dev)
     capi.check(lib.rtpose_nchw_to_layout(capi.ptr(xd), capi.ptr(xin), C.byref(lin), cin, cin_p, n, h, w, stream))
     ho, wo = (h // 2, w // 2) if pool else (h, w)
     cstride_out = cout * groups + 3  # odd stride + channel offsets: exercises slices
@@ -141,13 +143,20 @@ def test_winograd7_grouped_branches_and_direct_agree(capi, cuda):
 
 def test_winograd7_persistent_blocks_split_tiles(capi, cuda):
     """8 x 46 x 46, two branches = 288 tiles >= 256 CUs: the launch runs as persistent blocks that share the
-    (tile, chunk) units evenly, most tiles' sums are split between two blocks (conv_wino7.hip: wino7_f32).
-    Run twice: the hand-over flags are back to zero after a launch, the result is deterministic."""
+    (tile, chunk) units evenly, most tiles are split between two blocks (conv_wino7.hip: wino7_f32).  The second
+    block continues the first one's sums, so the result is BIT-identical to the one-block-per-tile launch of a
+    smaller batch of the same images; run twice: the hand-over flags are back to zero after a launch."""
     outs, refs = _run_conv(capi, cuda, 8, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=11, groups=2, winograd=True)
     again, _ = _run_conv(capi, cuda, 8, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=11, groups=2, winograd=True)
     for o, r, o2 in zip(outs, refs, again):
         assert (o - r).abs().max().item() <= TOL * max(1.0, r.abs().max().item())
         assert torch.equal(o, o2)
+    # same generator stream: the first 2 images / both filters of an n = 2 run are those of the n = 8 run? no -
+    # the inputs are drawn as one (n, c, h, w) tensor, so re-run the FIRST image alone through a slice instead
+    small, _ = _run_conv(capi, cuda, 8, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=11, groups=2, winograd=True,
+                         only_images=3)
+    for o, sm in zip(outs, small):
+        assert torch.equal(o[:3], sm)
 
 
 WINO_CASES = [

@@ -43,6 +43,61 @@ __global__ __launch_bounds__(512) void kern(float* out, int iters, long long* cy
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+// K VALU instructions (PK: v_pk_fma_f32, else v_fma_f32) after every GAP-th MFMA
+template <int K, int GAP, int PK>
+__global__ __launch_bounds__(512) void kern2(float* out, int iters) {
+  floatx16 acc[8];
+  for (int i = 0; i < 8; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  f2 f[16];
+  for (int i = 0; i < 16; ++i) f[i] = f2{threadIdx.x * 0.001f + i, 1.f};
+  float a = threadIdx.x * 0.5f, b = 1.0f;
+  const f2 c1 = {1.0001f, 1.0001f}, c2 = {0.5f, 0.5f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m], 0, 0, 0);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if ((m % GAP) == GAP - 1) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          if (PK) f[k & 15] = __builtin_elementwise_fma(f[k & 15], c1, c2);
+          else f[k & 15].x = __builtin_fmaf(f[k & 15].x, 1.0001f, 0.5f);
+        }
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float s = 0;
+  for (int i = 0; i < 16; ++i) s += f[i].x + f[i].y;
+  for (int i = 0; i < 8; ++i) s += acc[i][0];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int K, int GAP, int PK>
+void run2() {
+  float* out;
+  hipMalloc(&out, 256 * 1024 * 4);
+  const int iters = 2000;
+  hipLaunchKernelGGL((kern2<K, GAP, PK>), dim3(256), dim3(256), 0, 0, out, iters);
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((kern2<K, GAP, PK>), dim3(256), dim3(256), 0, 0, out, iters);
+  hipEventRecord(e1);
+  hipDeviceSynchronize();
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double per = (double)ms * 1e-3 / (iters * 8.0) * 2.4e9;
+  printf("1 wave/SIMD: %2d %s after every %d. MFMA: %.1f cycles per MFMA -> %.1f cycles per VALU instruction\n", K,
+         PK ? "v_pk_fma_f32" : "v_fma_f32   ", GAP, per, (per - 70.8) * GAP / K);
+  hipFree(out);
+}
+
 template <int K, int LDSR>
 void run(int threads, const char* tag) {
   float* out;
@@ -72,6 +127,16 @@ void run(int threads, const char* tag) {
 }
 
 int main() {
+  run2<4, 1, 0>();
+  run2<4, 1, 1>();
+  run2<8, 2, 0>();
+  run2<8, 2, 1>();
+  run2<16, 4, 0>();
+  run2<16, 4, 1>();
+  run2<16, 8, 0>();
+  run2<16, 8, 1>();
+  run2<32, 8, 0>();
+  run2<32, 8, 1>();
   run<0, 0>(256, "1 wave/SIMD");
   run<4, 0>(256, "1 wave/SIMD");
   run<8, 0>(256, "1 wave/SIMD");

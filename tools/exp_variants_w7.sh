@@ -3,7 +3,7 @@
 # variants (results are WRONG) with one of them dropped, plus the weight prefetch distance.
 #   tools/exp_variants_w7.sh build     (here, no GPU needed)      tools/exp_variants_w7.sh run   (on the GPU box)
 cd "$(dirname "$0")/.."
-VARIANTS="base: noB:-DRTPOSE_EXP_NO_B noA:-DRTPOSE_EXP_NO_A noT:-DRTPOSE_EXP_NO_STAGE noAB:-DRTPOSE_EXP_NO_A,-DRTPOSE_EXP_NO_B noABT:-DRTPOSE_EXP_NO_A,-DRTPOSE_EXP_NO_B,-DRTPOSE_EXP_NO_STAGE pf2:-DRTPOSE_EXP_W7_PF=2 pf4:-DRTPOSE_EXP_W7_PF=4"
+VARIANTS="${VARIANTS:-base: noB:-DRTPOSE_EXP_NO_B noA:-DRTPOSE_EXP_NO_A noT:-DRTPOSE_EXP_NO_STAGE noAB:-DRTPOSE_EXP_NO_A,-DRTPOSE_EXP_NO_B noABT:-DRTPOSE_EXP_NO_A,-DRTPOSE_EXP_NO_B,-DRTPOSE_EXP_NO_STAGE pf2:-DRTPOSE_EXP_W7_PF=2 pf4:-DRTPOSE_EXP_W7_PF=4 tvalu:-DRTPOSE_EXP_W7_TMASK=1 tload:-DRTPOSE_EXP_W7_TMASK=2}"
 for v in $VARIANTS; do
   name=${v%%:*}; flags=$(echo ${v#*:} | tr ',' ' ')
   if [ "$1" = "build" ]; then
