@@ -39,6 +39,8 @@
 
 namespace rtpose {
 
+int wino_scratch(hipStream_t s, int blocks, size_t floats_per_block, float** partial, int** flags);
+
 namespace wino7 {
 
 using namespace winoc;
@@ -503,30 +505,6 @@ static int make_plan(int N, int H, int W, int hs, Plan* p) {
   return 0;
 }
 
-// Scratch of the persistent form: one partial tile + one flag per block, per (device, stream) - launches on one
-// stream are serialised, launches on different streams must not share slots.  Never freed (a few per process).
-struct Scratch {
-  float* partial = nullptr;
-  int* flags = nullptr;
-  int blocks = 0;
-};
-static int get_scratch(hipStream_t s, int blocks, Scratch* out) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, Scratch> pool;
-  std::lock_guard<std::mutex> lock(mu);
-  Scratch& sc = pool[std::make_pair(current_device(), s)];
-  if (sc.blocks < blocks + 1) {
-    // (a replaced allocation is leaked on purpose: an earlier launch on the stream may still be using it)
-    const size_t n = (size_t)(blocks + 1);
-    RTPOSE_HIP_CHECK(hipMalloc(&sc.partial, n * 4 * 160 * 64 * sizeof(float)));
-    RTPOSE_HIP_CHECK(hipMalloc(&sc.flags, n * sizeof(int)));
-    RTPOSE_HIP_CHECK(hipMemsetAsync(sc.flags, 0, n * sizeof(int), s));
-    sc.blocks = blocks + 1;
-  }
-  *out = sc;
-  return 0;
-}
-
 template <int NI, int GXT>
 static int launch_inst(const Args& a, dim3 grid, size_t lds, hipStream_t s) {
   static PerDeviceOnce attr_set;
@@ -543,6 +521,35 @@ static int launch_inst(const Args& a, dim3 grid, size_t lds, hipStream_t s) {
 }
 
 }  // namespace wino7
+
+// Scratch of the persistent kernels (this file and conv_wino.hip): one accumulator tile + one flag per block, per
+// (device, stream) - launches on one stream are serialised, launches on different streams must not share slots.
+// Never freed (a few per process).
+int wino_scratch(hipStream_t s, int blocks, size_t floats_per_block, float** partial, int** flags) {
+  struct Scratch {
+    float* partial = nullptr;
+    int* flags = nullptr;
+    int blocks = 0;
+    size_t floats = 0;
+  };
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, Scratch> pool;
+  std::lock_guard<std::mutex> lock(mu);
+  Scratch& sc = pool[std::make_pair(current_device(), s)];
+  if (sc.blocks < blocks + 1 || sc.floats < floats_per_block) {
+    // (a replaced allocation is leaked on purpose: an earlier launch on the stream may still be using it)
+    const size_t n = (size_t)(blocks + 1 > sc.blocks ? blocks + 1 : sc.blocks);
+    const size_t fl = floats_per_block > sc.floats ? floats_per_block : sc.floats;
+    RTPOSE_HIP_CHECK(hipMalloc(&sc.partial, n * fl * sizeof(float)));
+    RTPOSE_HIP_CHECK(hipMalloc(&sc.flags, n * sizeof(int)));
+    RTPOSE_HIP_CHECK(hipMemsetAsync(sc.flags, 0, n * sizeof(int), s));
+    sc.blocks = (int)n;
+    sc.floats = fl;
+  }
+  *partial = sc.partial;
+  *flags = sc.flags;
+  return 0;
+}
 
 // 1 when the 7x7 conv can run in F(4,7) form at this geometry (a kernel instance exists and the
 // transformed rows of a block fit the LDS), else 0: callers then use the direct kernel
@@ -622,12 +629,9 @@ int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
       persist_env = e ? atoi(e) : 1;
     }
     if (persist_env && tiles >= n_cu && tiles % n_cu != 0) {
-      Scratch sc;
-      const int rc = get_scratch(s, n_cu, &sc);
+      const int rc = wino_scratch(s, n_cu, (size_t)4 * 160 * 64, &a.scratch, &a.flags);
       if (rc) return rc;
       a.persist = 1;
-      a.scratch = sc.partial;
-      a.flags = sc.flags;
       ids = n_cu;
     }
   }
