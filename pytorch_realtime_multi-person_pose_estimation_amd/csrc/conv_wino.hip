@@ -128,7 +128,11 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
     p[i >> 2][i & 3] = bload(rin, pvoff, (unsigned)chunk * (CK * 4) + psoff[i >> 2] + (i & 3) * pxb);
   };
   // V[f][cg][wtile], f = fy * 4 + fx; this thread writes fy in {2 half, 2 half + 1}; B^T over x as over the rows
-  const int vst = (half * 8 * CG + cg) * NT + tl;
+  // (wtile slots are rotated by SW per channel group: the 16 lanes of a write phase - 16 / CG wtiles x CG groups -
+  //  then land in 16 distinct 16-byte bank slots; unrotated, the CG planes of a wtile are 512 B apart = the same
+  //  banks: SQ_LDS_BANK_CONFLICT was 7 % of the kernel's cycles)
+  constexpr int SW = 16 / CG;
+  const int vst = (half * 8 * CG + cg) * NT + ((tl + SW * cg) % NT);
   // transform in two groups of 16 packed VALU instructions (few, full groups: see wino_common.h)
   auto tgroup = [&](int buf, int gidx) {
     if (gidx == 0) {
@@ -200,13 +204,16 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   constexpr int SLOTS = 4 * G;  // MFMA pairs (= filler slots) per step
   float4 a[2][2][G];            // [step % 2][frequency of the pair][k group]
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const float4* va = V4 + (chunk & 1) * VBUF + kh * NT + arow;
+    const float4* vab = V4 + (chunk & 1) * VBUF;
+    const float4* va[G];  // per k group: plane (2 gi + kh), this lane's rotated wtile slot
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) va[gi] = vab + (2 * gi + kh) * NT + ((arow + SW * (2 * gi + kh)) % NT);
     const int nbuf = (chunk + 1) & 1;
     const int c2 = min(chunk + 2, nchunks - 1);  // the last chunks re-stage themselves (never read)
 #pragma unroll
     for (int fs = 0; fs < 2; ++fs)
 #pragma unroll
-      for (int gi = 0; gi < G; ++gi) a[0][fs][gi] = va[(fs * CG + 2 * gi) * NT];
+      for (int gi = 0; gi < G; ++gi) a[0][fs][gi] = va[gi][fs * CG * NT];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
 #pragma unroll
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
         }
         RTPOSE_PIN();
         if (slot < 2 * G) {  // A of the next step (the first step of a chunk is read after the barrier)
-          if (s < 7) a[(s + 1) & 1][slot / G][slot % G] = va[((2 * (s + 1) + slot / G) * CG + 2 * (slot % G)) * NT];
+          if (s < 7) a[(s + 1) & 1][slot / G][slot % G] = va[slot % G][(2 * (s + 1) + slot / G) * CG * NT];
         } else {             // B two steps ahead
           const int i = slot - 2 * G;
           bs[(s + 2) & 3][i / G][i % G] = bload_f4(rw, boff, wso + ((i / G) * CG + 2 * (i % G)) * cgstep);

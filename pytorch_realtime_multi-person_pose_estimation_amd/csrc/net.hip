@@ -147,7 +147,9 @@ int add_conv_w(rtpose_net* n, const std::string& name, int cout, int cin, int k,
   // the geometry.  3x3: the Winograd form always applies, one packing.  7x7: whether F(4,7) fits depends on
   // the map width (LDS), so such a conv keeps BOTH packings and each plan picks one (c.wino).
   const bool en = !n->bf16 && n->wino && (n->wino == 1 || n->wino == k);
-  const bool w3 = en && k == 3 && conv2d_winograd_fits(3, c.cin_packed, cout, 0, 1, 8, 8, 9);
+  // (3x3 with < 32 input channels stays direct: nothing to amortise the transforms over - conv1_1, 3 -> 64 on 8
+  //  padded channels, takes 0.71 ms in Winograd form and 0.50 ms in the direct kernel)
+  const bool w3 = en && k == 3 && c.cin_packed >= 32 && conv2d_winograd_fits(3, c.cin_packed, cout, 0, 1, 8, 8, 9);
   c.dual = en && k == 7 && c.cin_packed % 8 == 0 && cout_pad(cout) % 128 == 0;
   c.wino = w3 || (c.dual && conv2d_winograd_fits(7, c.cin_packed, cout, 0, n->N, H, W, H + 3));
   c.w_off = n->wt_floats;
