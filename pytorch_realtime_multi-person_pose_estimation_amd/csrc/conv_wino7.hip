@@ -560,6 +560,12 @@ int conv2d_wino7_fits(int cin, int cout, int N, int H, int W, int hs) {
   return p.ni <= 2 && p.lds <= 156 * 1024;
 }
 
+// position strips (block rows of the launch grid) of an N x H x W conv, for callers that choose between the forms
+int conv2d_wino7_tiles(int N, int H, int W, int hs) {
+  wino7::Plan p;
+  return wino7::make_plan(N, H, W, hs, &p) ? 0 : p.mtiles;
+}
+
 int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s) {
   using namespace wino7;
   if (!d || ngroups < 1 || ngroups > 2) return fail(RTPOSE_E_INVAL, "conv2d_winograd: ngroups must be 1 or 2");
