@@ -45,20 +45,51 @@ namespace wino7 {
 
 using namespace winoc;
 
-// Input transform, rows scaled by N_f = prod_{l != f} (p_f - p_l) (the filter transform divides by it):
-// every entry is a multiple of 1/16, exact in fp32.  Rows 2p+1 / 2p+2 (points +-p) share their even- and
-// odd-n halves:  V[2p+1] = E_p + O_p,  V[2p+2] = E_p - O_p.
-__device__ static constexpr float kBT[10][10] = {
-    {2.25f, 0.f, -12.8125f, 0.f, 17.0625f, 0.f, -7.5f, 0.f, 1.f, 0.f},
-    {0.f, -2.25f, -2.25f, 10.5625f, 10.5625f, -6.5f, -6.5f, 1.f, 1.f, 0.f},
-    {0.f, 2.25f, -2.25f, -10.5625f, 10.5625f, 6.5f, -6.5f, -1.f, 1.f, 0.f},
-    {0.f, -1.125f, -0.5625f, 6.125f, 3.0625f, -7.f, -3.5f, 2.f, 1.f, 0.f},
-    {0.f, 1.125f, -0.5625f, -6.125f, 3.0625f, 7.f, -3.5f, -2.f, 1.f, 0.f},
-    {0.f, -4.5f, -9.f, 7.625f, 15.25f, -3.625f, -7.25f, 0.5f, 1.f, 0.f},
-    {0.f, 4.5f, -9.f, -7.625f, 15.25f, 3.625f, -7.25f, -0.5f, 1.f, 0.f},
-    {0.f, -1.5f, -1.f, 7.875f, 5.25f, -7.875f, -5.25f, 1.5f, 1.f, 0.f},
-    {0.f, 1.5f, -1.f, -7.875f, 5.25f, 7.875f, -5.25f, -1.5f, 1.f, 0.f},
-    {0.f, 2.25f, 0.f, -12.8125f, 0.f, 17.0625f, 0.f, -7.5f, 0.f, 1.f},
+// F(FM, 7): FM outputs from FM + 6 inputs through NFQ = FM + 6 "frequencies" = Toom-Cook interpolation points
+// 0, +-p_1 .. +-p_NP, inf.  kBT = the input transform, rows scaled by N_f = prod_{l != f} (p_f - p_l) (the filter
+// transform divides by it).  Rows 2p+1 / 2p+2 (points +-p) share their even- and odd-n halves:
+// V[2p+1] = E_p + O_p,  V[2p+2] = E_p - O_p; row 0 has only even, row NFQ-1 (inf) only odd columns.
+//   FM = 4: points 0, +-1, +-2, +-1/2, +-3/2, inf - every entry a multiple of 1/16, exact in fp32; 70 multiplies per
+//           4 outputs instead of 196 (2.8x); whole-network stage outputs move by < 1e-5
+//   FM = 6: + the points +-2/3 - 84 per 6 outputs instead of 294 (3.5x); entries in 18ths / 144ths (rounded to fp32),
+//           whole network 1.5e-5 (points +-3 instead: 6.4e-5, +-1/4: 2.8e-5; contract 1e-3)
+template <int FM>
+struct WT;
+template <>
+struct WT<4> {
+  static constexpr int NFQ = 10, NP = 4, NSETS = 5;
+  __device__ static constexpr float kPts[4] = {1.f, 2.f, 0.5f, 1.5f};
+  __device__ static constexpr float kBT[10][10] = {
+      {2.25f, 0.f, -12.8125f, 0.f, 17.0625f, 0.f, -7.5f, 0.f, 1.f, 0.f},
+      {0.f, -2.25f, -2.25f, 10.5625f, 10.5625f, -6.5f, -6.5f, 1.f, 1.f, 0.f},
+      {0.f, 2.25f, -2.25f, -10.5625f, 10.5625f, 6.5f, -6.5f, -1.f, 1.f, 0.f},
+      {0.f, -1.125f, -0.5625f, 6.125f, 3.0625f, -7.f, -3.5f, 2.f, 1.f, 0.f},
+      {0.f, 1.125f, -0.5625f, -6.125f, 3.0625f, 7.f, -3.5f, -2.f, 1.f, 0.f},
+      {0.f, -4.5f, -9.f, 7.625f, 15.25f, -3.625f, -7.25f, 0.5f, 1.f, 0.f},
+      {0.f, 4.5f, -9.f, -7.625f, 15.25f, 3.625f, -7.25f, -0.5f, 1.f, 0.f},
+      {0.f, -1.5f, -1.f, 7.875f, 5.25f, -7.875f, -5.25f, 1.5f, 1.f, 0.f},
+      {0.f, 1.5f, -1.f, -7.875f, 5.25f, 7.875f, -5.25f, -1.5f, 1.f, 0.f},
+      {0.f, 2.25f, 0.f, -12.8125f, 0.f, 17.0625f, 0.f, -7.5f, 0.f, 1.f},
+  };
+};
+template <>
+struct WT<6> {
+  static constexpr int NFQ = 12, NP = 5, NSETS = 6;
+  __device__ static constexpr float kPts[5] = {1.f, 2.f, 0.5f, 1.5f, 0.666666667f};
+  __device__ static constexpr float kBT[12][12] = {
+      {-1.f, 0.f, 7.94444444f, 0.f, -20.3958333f, 0.f, 20.3958333f, 0.f, -7.94444444f, 0.f, 1.f, 0.f},
+      {0.f, 1.f, 1.f, -6.94444444f, -6.94444444f, 13.4513889f, 13.4513889f, -6.94444444f, -6.94444444f, 1.f, 1.f, 0.f},
+      {0.f, -1.f, 1.f, 6.94444444f, -6.94444444f, -13.4513889f, 13.4513889f, 6.94444444f, -6.94444444f, -1.f, 1.f, 0.f},
+      {0.f, 0.5f, 0.25f, -3.84722222f, -1.92361111f, 9.23611111f, 4.61805556f, -7.88888889f, -3.94444444f, 2.f, 1.f, 0.f},
+      {0.f, -0.5f, 0.25f, 3.84722222f, -1.92361111f, -9.23611111f, 4.61805556f, 7.88888889f, -3.94444444f, -2.f, 1.f, 0.f},
+      {0.f, 2.f, 4.f, -7.88888889f, -15.7777778f, 9.23611111f, 18.4722222f, -3.84722222f, -7.69444444f, 0.5f, 1.f, 0.f},
+      {0.f, -2.f, 4.f, 7.88888889f, -15.7777778f, -9.23611111f, 18.4722222f, 3.84722222f, -7.69444444f, -0.5f, 1.f, 0.f},
+      {0.f, 0.666666667f, 0.444444444f, -5.f, -3.33333333f, 11.375f, 7.58333333f, -8.54166667f, -5.69444444f, 1.5f, 1.f, 0.f},
+      {0.f, -0.666666667f, 0.444444444f, 5.f, -3.33333333f, -11.375f, 7.58333333f, 8.54166667f, -5.69444444f, -1.5f, 1.f, 0.f},
+      {0.f, 1.5f, 2.25f, -8.54166667f, -12.8125f, 11.375f, 17.0625f, -5.f, -7.5f, 0.666666667f, 1.f, 0.f},
+      {0.f, -1.5f, 2.25f, 8.54166667f, -12.8125f, -11.375f, 17.0625f, 5.f, -7.5f, -0.666666667f, 1.f, 0.f},
+      {0.f, -1.f, 0.f, 7.94444444f, 0.f, -20.3958333f, 0.f, 20.3958333f, 0.f, -7.94444444f, 0.f, 1.f},
+  };
 };
 
 struct Group {
@@ -86,13 +117,11 @@ struct Args {
 };
 
 constexpr int CK = 8, CG = 2;   // channels per chunk, 16-byte channel groups per chunk
-constexpr int NPS = 35;         // (ky, frequency pair) steps per chunk
-constexpr int PF = RTPOSE_EXP_W7_PF;  // B prefetch distance in steps (4); 5 register sets (35 % 5 == 0)
 
 // LDS row stride (float4): >= 20 GX, and = GX modulo 16 so that the 32 positions of a wave tile, which
 // wrap from one transformed row to the next, keep landing in distinct 16-byte bank slots
-__host__ __device__ constexpr int row_stride(int gx) {
-  int rs = 10 * CG * gx;
+__host__ __device__ constexpr int row_stride(int gx, int nfq) {
+  int rs = nfq * CG * gx;
   while ((rs & 15) != (gx & 15)) ++rs;
   return rs;
 }
@@ -106,9 +135,15 @@ __host__ __device__ constexpr int strip_rows(int gx) { return (31 + gx - 1) / gx
 // unsplit one: the block with the first chunks (cb == 0, ce < all) saves its raw accumulators to scratch slot
 // `slot` and raises the flag; the block with the last chunks (cb > 0) starts from them instead of from zero and
 // stores the tile.  Results are bit-identical however the launch is cut.
-template <int NI, int GXT>
+template <int NI, int GXT, int FM>
 __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const int mt, const int c, const int cb,
                                               const int ce, const int nch, const int slot) {
+  using T = WT<FM>;
+  constexpr int NFQ = T::NFQ, NP = T::NP, NSETS = T::NSETS;  // frequencies, +-point pairs, B register sets
+  constexpr int NPS = 7 * NFQ / 2;                           // (ky, frequency pair) steps per chunk (NPS % NSETS == 0)
+  constexpr int PF = RTPOSE_EXP_W7_PF < NSETS ? RTPOSE_EXP_W7_PF : NSETS - 1;  // B prefetch distance in steps
+  constexpr int NHI = NFQ - 7;                               // segments that can reach past the row's own gap
+  static_assert(NPS % NSETS == 0, "B register sets must rotate in step with the chunk");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,8 +151,8 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   const int nt = c % A.ntiles, grp = c / A.ntiles;
   const Group g = grp ? A.g[1] : A.g[0];
   const int GX = GXT ? GXT : A.GX;
-  const int RS = GXT ? row_stride(GXT) : A.RS;
-  const int VB = GXT ? strip_rows(GXT) * row_stride(GXT) : A.VB;
+  const int RS = GXT ? row_stride(GXT, NFQ) : A.RS;
+  const int VB = GXT ? strip_rows(GXT) * row_stride(GXT, NFQ) : A.VB;
   const int PI = A.H * GX;  // positions per image
 
   // ---- this block's 32 positions [t0, t0 + 32) of the flat (n, y, gx) order, valid below tlim ----------
@@ -145,51 +180,51 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   // The last group of a row reaches past the row's own 3-pixel gap (x >= W + 3 is the NEXT row's - or the next
   // image's - data) when W is not a multiple of 4.  Those inputs only meet outputs that are not stored, but
   // through the transform they would cancel only up to rounding, and an image's result would depend on its
-  // neighbour in the batch: segments n = 7..9 are therefore clamped to the last gap pixel (a zero).
+  // neighbour in the batch: segments n >= 7 are therefore clamped to the last gap pixel (a zero).
   // (the input descriptor is based at the block's first row, so the 32-bit offsets stay small whatever the size
   // of the activation buffer)
   const long qbase = (long)g.in_lead + (long)(R0 - 3) * g.in_ws - 3;
   const i32x4 rin = make_rsrc(g.in + qbase * g.in_cstride + g.in_choff), rw = make_rsrc(g.w);
-  unsigned voff[NI], vhi[NI][3];
+  unsigned voff[NI], vhi[NI][NHI];
   int vdst[NI];
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
     const int i = min(tid + k * 256, nitems - 1);  // surplus threads repeat the last item (same value, same slot)
     const int r = i / (GX * CG), rem = i - r * (GX * CG);
     const int gx = rem >> 1, cg = rem & 1;
-    voff[k] = (unsigned)((((long)r * g.in_ws + 4 * gx) * g.in_cstride + cg * 4) * 4);
+    voff[k] = (unsigned)((((long)r * g.in_ws + FM * gx) * g.in_cstride + cg * 4) * 4);
     vdst[k] = r * RS + cg * GX + gx;
 #pragma unroll
-    for (int n = 7; n < 10; ++n) vhi[k][n - 7] = voff[k] + (unsigned)(min(n, A.W + 5 - 4 * gx) * g.in_cstride * 4);
+    for (int n = 7; n < NFQ; ++n) vhi[k][n - 7] = voff[k] + (unsigned)(min(n, A.W + 5 - FM * gx) * g.in_cstride * 4);
   }
   const unsigned pxb = (unsigned)g.in_cstride * 4;  // bytes per pixel (uniform)
-  F4 d[NI][10], eo[2];
+  F4 d[NI][NFQ], eo[2];
   auto load_piece = [&](int chunk, int k, int n) {
     const unsigned cb = (unsigned)chunk * (CK * 4);
     d[k][n] = n < 7 ? bload(rin, voff[k], cb + n * pxb) : bload(rin, vhi[k][n < 7 ? 0 : n - 7], cb);
   };
-  // The transform of one item in 6 groups of 10..20 packed VALU instructions.  (A lone VALU instruction between
+  // The transform of one item in NP + 2 groups of 10..20 packed VALU instructions.  (A lone VALU instruction between
   // two MFMAs costs ~8 cycles of matrix time, a group of 12..16 costs ~60 in all: few, full groups.)
-  //   group p = 0..3: E_p, O_p (4 terms each), then frequencies 2p+1 = E_p + O_p and 2p+2 = E_p - O_p -> LDS
-  //   group 4: frequency 0;  group 5: frequency 9                      (5 terms each)
+  //   group p < NP: E_p, O_p (NP terms each), then frequencies 2p+1 = E_p + O_p and 2p+2 = E_p - O_p -> LDS
+  //   group NP: frequency 0;  group NP + 1: frequency NFQ - 1 (inf)                    (NP + 1 terms each)
   auto tgroup = [&](float4* vw, int k, int gidx) {
-    if (gidx < 4) {
+    if (gidx < NP) {
       const int row = 2 * gidx + 1;
 #pragma unroll
       for (int odd = 0; odd < 2; ++odd) {
         const int n0 = odd ? 1 : 2;  // column 0 of these rows is zero
-        F4 s = mul4(kBT[row][n0], d[k][n0]);
+        F4 s = mul4(T::kBT[row][n0], d[k][n0]);
 #pragma unroll
-        for (int t = 1; t < 4; ++t) s = fma4(kBT[row][n0 + 2 * t], d[k][n0 + 2 * t], s);
+        for (int t = 1; t < NP; ++t) s = fma4(T::kBT[row][n0 + 2 * t], d[k][n0 + 2 * t], s);
         eo[odd] = s;
       }
       vw[vdst[k] + row * CG * GX] = to_float4(add4(eo[0], eo[1]));
       vw[vdst[k] + (row + 1) * CG * GX] = to_float4(sub4(eo[0], eo[1]));
     } else {
-      const int f = gidx == 4 ? 0 : 9, n0 = gidx == 4 ? 0 : 1;
-      F4 s = mul4(kBT[f][n0], d[k][n0]);
+      const int f = gidx == NP ? 0 : NFQ - 1, n0 = gidx == NP ? 0 : 1;
+      F4 s = mul4(T::kBT[f][n0], d[k][n0]);
 #pragma unroll
-      for (int t = 1; t < 5; ++t) s = fma4(kBT[f][n0 + 2 * t], d[k][n0 + 2 * t], s);
+      for (int t = 1; t < NP + 1; ++t) s = fma4(T::kBT[f][n0 + 2 * t], d[k][n0 + 2 * t], s);
       vw[vdst[k] + f * CG * GX] = to_float4(s);
     }
   };
@@ -203,11 +238,11 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
     abase = (n * g.in_hs + y - R0) * RS + kh * GX + gx;
   }
   const int ncol = nt * 128 + wn * 32 + l31;
-  floatx16 acc[10];
-  float* sp = A.scratch + ((size_t)(slot * 4 + wn) * 160) * 64 + lane;  // this wave's rows of the scratch slot
+  floatx16 acc[NFQ];
+  float* sp = A.scratch + ((size_t)(slot * 4 + wn) * (NFQ * 16)) * 64 + lane;  // this wave's rows of the scratch slot
   if (cb == 0) {
 #pragma unroll
-    for (int f = 0; f < 10; ++f)
+    for (int f = 0; f < NFQ; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
     const float b0 = g.bias[ncol];  // padded to cout_pad
@@ -220,7 +255,7 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll
-    for (int f = 0; f < 10; ++f)
+    for (int f = 0; f < NFQ; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[f][r] = sp[(f * 16 + r) * 64];
     __syncthreads();  // all reads done before the slot is handed back
@@ -229,22 +264,22 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   const unsigned boff = (unsigned)((kh * g.cout_pad + ncol) * 16);
   const unsigned fstep = (unsigned)(CG * g.cout_pad * 16);  // bytes per frequency block
   unsigned wso = (unsigned)cb * (2 * NPS) * fstep;          // uniform byte offset of the next B step to fetch
-  float4 bs[5][2];
+  float4 bs[NSETS][2];
 
 #pragma unroll
   for (int k = 0; k < NI; ++k)
 #pragma unroll
-    for (int n = 0; n < 10; ++n) load_piece(cb, k, n);
+    for (int n = 0; n < NFQ; ++n) load_piece(cb, k, n);
 #pragma unroll
   for (int k = 0; k < NI; ++k)
 #pragma unroll
-    for (int gi = 0; gi < 6; ++gi) tgroup(V4, k, gi);
+    for (int gi = 0; gi < NP + 2; ++gi) tgroup(V4, k, gi);
   {
     const int c1 = min(cb + 1, ce - 1);
 #pragma unroll
     for (int k = 0; k < NI; ++k)
 #pragma unroll
-      for (int n = 0; n < 10; ++n) load_piece(c1, k, n);
+      for (int n = 0; n < NFQ; ++n) load_piece(c1, k, n);
   }
   // (the first B fragments are requested AFTER the segment loads, as in the steady state of the loop below: the
   //  compiler's in-order vmcnt bookkeeping merges the two entries of the loop, and with the B loads older than the
@@ -264,9 +299,9 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   // filler slot after every second one.  Slot 0 / 1: the A fragments of the next step (LDS); slot 2 / 3: the B
   // fragments PF steps ahead (L2).  Slot 3 of the first steps also carries transform work of the NEXT chunk: its
   // 6 NI groups (steps 0..11), then the 10 NI segment loads of the chunk after that, two per step.
-  constexpr int NG = 6 * NI, GSTR = NI == 1 ? 2 : 1;
-  constexpr int LPS = RTPOSE_EXP_W7_LPS, LSTEPS = (10 * NI + LPS - 1) / LPS;  // segment loads per step, steps with loads
-  static_assert(12 + LSTEPS <= NPS, "transform work does not fit the steps of a chunk");
+  constexpr int NG = (NP + 2) * NI, GSTR = NI == 1 ? 2 : 1, LS = NG * GSTR;  // groups, their step stride, first load step
+  constexpr int LPS = RTPOSE_EXP_W7_LPS, LSTEPS = (NFQ * NI + LPS - 1) / LPS;    // segment loads per step, steps with loads
+  static_assert(LS + LSTEPS <= NPS, "transform work does not fit the steps of a chunk");
   float4 a[2][2];
   for (int chunk = cb; chunk < ce; ++chunk) {
     const float4* va = V4 + ((chunk - cb) & 1) * VB + abase;
@@ -276,11 +311,11 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
     a[0][1] = va[CG * GX];
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
-      const int fp = ps % 5;
+      const int fp = ps % (NFQ / 2);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         {
-          const float4 a0 = a[ps & 1][0], a1 = a[ps & 1][1], b0 = bs[ps % 5][0], b1 = bs[ps % 5][1];
+          const float4 a0 = a[ps & 1][0], a1 = a[ps & 1][1], b0 = bs[ps % NSETS][0], b1 = bs[ps % NSETS][1];
           const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
           const float b0v[4] = {b0.x, b0.y, b0.z, b0.w}, b1v[4] = {b1.x, b1.y, b1.z, b1.w};
           acc[2 * fp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[j], b0v[j], acc[2 * fp], 0, 0, 0);
@@ -289,21 +324,21 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
         RTPOSE_PIN();
         if (j < 2) {  // A of the next step (the first step of a chunk is read after the barrier)
           if (ps + 1 < NPS) {
-            const int kyn = (ps + 1) / 5, fn = 2 * ((ps + 1) % 5) + j;
+            const int kyn = (ps + 1) / (NFQ / 2), fn = 2 * ((ps + 1) % (NFQ / 2)) + j;
             a[(ps + 1) & 1][j] = RTPOSE_EXP_A(va[kyn * RS + fn * CG * GX], a[ps & 1][j]);
           }
         } else {      // B PF steps ahead
-          bs[(ps + PF) % 5][j - 2] = RTPOSE_EXP_B(bload_f4(rw, boff, wso), bs[ps % 5][j - 2]);
+          bs[(ps + PF) % NSETS][j - 2] = RTPOSE_EXP_B(bload_f4(rw, boff, wso), bs[ps % NSETS][j - 2]);
           wso += fstep;
         }
         if (RTPOSE_EXP_STAGE && j == 3) {
           if (ps % GSTR == 0 && ps / GSTR < NG) {
-            if (RTPOSE_EXP_W7_TMASK & 1) tgroup(vw, (ps / GSTR) / 6, (ps / GSTR) % 6);
-          } else if (ps >= 12 && ps < 12 + LSTEPS && (RTPOSE_EXP_W7_TMASK & 2)) {  // LPS segment loads per step
+            if (RTPOSE_EXP_W7_TMASK & 1) tgroup(vw, (ps / GSTR) / (NP + 2), (ps / GSTR) % (NP + 2));
+          } else if (ps >= LS && ps < LS + LSTEPS && (RTPOSE_EXP_W7_TMASK & 2)) {  // LPS segment loads per step
 #pragma unroll
             for (int q = 0; q < LPS; ++q) {
-              const int l = LPS * (ps - 12) + q;
-              if (l < 10 * NI) load_piece(c2, l / 10, l % 10);
+              const int l = LPS * (ps - LS) + q;
+              if (l < NFQ * NI) load_piece(c2, l / NFQ, l % NFQ);
             }
           }
         }
@@ -317,7 +352,7 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   // ---- first part of a split tile: hand the sums over ------------------------------------------------
   if (ce < nch) {
 #pragma unroll
-    for (int f = 0; f < 10; ++f)
+    for (int f = 0; f < NFQ; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sp[(f * 16 + r) * 64] = acc[f][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -339,23 +374,34 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    float S[4], D[4];
+    float S[NP], D[NP];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
       S[p] = acc[2 * p + 1][r] + acc[2 * p + 2][r];
       D[p] = acc[2 * p + 1][r] - acc[2 * p + 2][r];
     }
-    float y[4];
-    y[0] = acc[0][r] + ((S[0] + S[1]) + (S[2] + S[3]));
-    y[1] = __builtin_fmaf(2.f, D[1], D[0]) + __builtin_fmaf(1.5f, D[3], 0.5f * D[2]);
-    y[2] = __builtin_fmaf(4.f, S[1], S[0]) + __builtin_fmaf(2.25f, S[3], 0.25f * S[2]);
-    y[3] = (__builtin_fmaf(8.f, D[1], D[0]) + __builtin_fmaf(3.375f, D[3], 0.125f * D[2])) + acc[9][r];
-    if (col_ok && tcur < tlim) {
-      const size_t q = (size_t)g.out_lead + (size_t)(sn * g.out_hs + sy) * g.out_ws + 4 * sx;
+    // out_i = [i == 0] M_0 + sum_p p^i (S_p for even i, D_p for odd i) + [i == FM - 1] M_inf
+    float y[FM];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < FM; ++i) {
+      float v = (i & 1) ? D[0] : S[0];  // the point 1
+      float pw[NP];
+#pragma unroll
+      for (int p = 1; p < NP; ++p) {
+        pw[p] = 1.f;
+        for (int e = 0; e < i; ++e) pw[p] *= T::kPts[p];  // compile-time constant
+        v = __builtin_fmaf(pw[p], (i & 1) ? D[p] : S[p], v);
+      }
+      if (i == 0) v += acc[0][r];
+      if (i == FM - 1) v += acc[NFQ - 1][r];
+      y[i] = v;
+    }
+    if (col_ok && tcur < tlim) {
+      const size_t q = (size_t)g.out_lead + (size_t)(sn * g.out_hs + sy) * g.out_ws + FM * sx;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
         const float v = A.relu ? fmaxf(y[i], 0.f) : y[i];
-        if (4 * sx + i < A.W) out_base[(q + i) * g.out_cstride] = v;
+        if (FM * sx + i < A.W) out_base[(q + i) * g.out_cstride] = v;
       }
     }
     const int dstep = (r & 3) == 3 ? 5 : 1;  // next register: +1, +1, +1, +5 positions
@@ -379,7 +425,7 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
 // per tile).  Order inside a block: the FIRST chunks of its last tile first (saved for block p + 1), the whole
 // tiles, and the LAST chunks of its first tile at the very end, continuing the sums block p - 1 saved at its start:
 // nobody waits, and the sums run in the order of an unsplit tile.
-template <int NI, int GXT>
+template <int NI, int GXT, int FM>
 __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
   extern __shared__ __attribute__((aligned(16))) float4 V4[];
   const int nch = A.cin / CK;
@@ -423,15 +469,15 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
     }
     const int mt = tile / A.ncombo, c = tile - mt * A.ncombo;
     // slot: a block saves into its own, and continues from its predecessor's
-    wino7_segment<NI, GXT>(A, V4, mt, c, cb, ce, nch, cb > 0 ? (int)blockIdx.x - 1 : (int)blockIdx.x);
+    wino7_segment<NI, GXT, FM>(A, V4, mt, c, cb, ce, nch, cb > 0 ? (int)blockIdx.x - 1 : (int)blockIdx.x);
   }
 }
 
 // ---- weight packing: U[ky][f] = sum_kx G[f][kx] w[ky][kx];  packed[chunk][ky][f][cg][cout_pad][4] ------------
 __global__ void pack_wino7_kernel(const float* __restrict__ w, const float* __restrict__ bias, int cout,
                                   int cin_src, const int32_t* __restrict__ cin_map, int cin_packed, int coutp,
-                                  float* __restrict__ wp, float* __restrict__ bp) {
-  const size_t total = (size_t)70 * cin_packed * coutp;
+                                  int nfq, float* __restrict__ wp, float* __restrict__ bp) {
+  const size_t total = (size_t)7 * nfq * cin_packed * coutp;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (size_t)coutp) bp[i] = (i < (size_t)cout && bias) ? bias[i] : 0.f;
   if (i >= total) return;
@@ -441,8 +487,8 @@ __global__ void pack_wino7_kernel(const float* __restrict__ w, const float* __re
   r /= coutp;
   const int cg = r % CG;
   r /= CG;
-  const int f = r % 10;
-  r /= 10;
+  const int f = r % nfq;
+  r /= nfq;
   const int ky = r % 7;
   const int chunk = r / 7;
   const int c = chunk * CK + cg * 4 + e;
@@ -450,13 +496,13 @@ __global__ void pack_wino7_kernel(const float* __restrict__ w, const float* __re
   float v = 0.f;
   if (n < cout && src >= 0 && src < cin_src) {
     const float* gw = w + (((size_t)n * cin_src + src) * 7 + ky) * 7;
-    if (f == 9) {
+    if (f == nfq - 1) {
       v = gw[6];
     } else {
-      // G[f][kx] = p_f^kx / N_f, N_f = prod_{l != f} (p_f - p_l) over the 9 finite points (exact in double)
-      const double pts[9] = {0.0, 1.0, -1.0, 2.0, -2.0, 0.5, -0.5, 1.5, -1.5};
+      // G[f][kx] = p_f^kx / N_f, N_f = prod_{l != f} (p_f - p_l) over the nfq - 1 finite points (in double)
+      const double pts[11] = {0.0, 1.0, -1.0, 2.0, -2.0, 0.5, -0.5, 1.5, -1.5, 2.0 / 3.0, -2.0 / 3.0};
       double nf = 1.0;
-      for (int l = 0; l < 9; ++l)
+      for (int l = 0; l < nfq - 1; ++l)
         if (l != f) nf *= pts[f] - pts[l];
       double s = 0.0, pw = 1.0;
       for (int kx = 0; kx < 7; ++kx) {
@@ -469,15 +515,28 @@ __global__ void pack_wino7_kernel(const float* __restrict__ w, const float* __re
   wp[i] = v;
 }
 
+// Which F(FM, 7): 6 unless RTPOSE_WINOGRAD7_M=4 (environment, read once per process: the packed filters of every
+// plan of the process must agree).
+static int wino7_fm() {
+  static int fm = 0;
+  if (!fm) {
+    const char* e = getenv("RTPOSE_WINOGRAD7_M");
+    fm = (e && e[0] == '4') ? 4 : 6;
+  }
+  return fm;
+}
+
 struct Plan {
-  int gx, rs, nrows, ni, tpi, mtiles;
+  int fm, nfq, gx, rs, nrows, ni, tpi, mtiles;
   long T;
   size_t lds;
 };
 
 static int make_plan(int N, int H, int W, int hs, Plan* p) {
-  p->gx = ceil_div(W, 4);
-  p->rs = row_stride(p->gx);
+  p->fm = wino7_fm();
+  p->nfq = p->fm + 6;
+  p->gx = ceil_div(W, p->fm);
+  p->rs = row_stride(p->gx, p->nfq);
   p->T = (long)N * H * p->gx;
   if (p->T > 0x7fffffffL) return -1;
   const int pi = H * p->gx;
@@ -505,11 +564,11 @@ static int make_plan(int N, int H, int W, int hs, Plan* p) {
   return 0;
 }
 
-template <int NI, int GXT>
+template <int NI, int GXT, int FM>
 static int launch_inst(const Args& a, dim3 grid, size_t lds, hipStream_t s) {
   static PerDeviceOnce attr_set;
   const int dev = current_device();
-  auto kern = wino7_f32<NI, GXT>;
+  auto kern = wino7_f32<NI, GXT, FM>;
   if (!attr_set.is_set(dev)) {
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -557,7 +616,8 @@ int conv2d_wino7_fits(int cin, int cout, int N, int H, int W, int hs) {
   if (cin <= 0 || cin % wino7::CK || cout_pad(cout) % 128 || N <= 0 || H <= 0 || W <= 0) return 0;
   wino7::Plan p;
   if (wino7::make_plan(N, H, W, hs, &p)) return 0;
-  return p.ni <= 2 && p.lds <= 156 * 1024;
+  // (F(6,7) with two transform items per thread would spill: one item only)
+  return p.ni <= (p.fm == 6 ? 1 : 2) && p.lds <= 156 * 1024;
 }
 
 // position strips (block rows of the launch grid) of an N x H x W conv, for callers that choose between the forms
@@ -635,7 +695,7 @@ int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
       persist_env = e ? atoi(e) : 1;
     }
     if (persist_env && tiles >= n_cu && tiles % n_cu != 0) {
-      const int rc = wino_scratch(s, n_cu, (size_t)4 * 160 * 64, &a.scratch, &a.flags);
+      const int rc = wino_scratch(s, n_cu, (size_t)4 * 12 * 16 * 64, &a.scratch, &a.flags);
       if (rc) return rc;
       a.persist = 1;
       ids = n_cu;
@@ -643,10 +703,15 @@ int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
   }
   const dim3 grid((unsigned)ids, 1, 1);
   // 46-wide maps (368 x 368 inputs, BASELINE configs[1]): every LDS offset of the multiply loop is an immediate
+  if (p.fm == 6) {
+    if (p.gx == 8 && p.tpi && p.ni == 1 && p.nrows == strip_rows(8))
+      return launch_inst<1, 8, 6>(a, grid, (size_t)2 * strip_rows(8) * row_stride(8, 12) * 16, s);
+    return launch_inst<1, 0, 6>(a, grid, p.lds, s);
+  }
   if (p.gx == 12 && p.tpi && p.ni == 1 && p.nrows == strip_rows(12))
-    return launch_inst<1, 12>(a, grid, (size_t)2 * strip_rows(12) * row_stride(12) * 16, s);
-  if (p.ni == 1) return launch_inst<1, 0>(a, grid, p.lds, s);
-  return launch_inst<2, 0>(a, grid, p.lds, s);
+    return launch_inst<1, 12, 4>(a, grid, (size_t)2 * strip_rows(12) * row_stride(12, 10) * 16, s);
+  if (p.ni == 1) return launch_inst<1, 0, 4>(a, grid, p.lds, s);
+  return launch_inst<2, 0, 4>(a, grid, p.lds, s);
 }
 
 int pack_weights_wino7_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map,
@@ -654,18 +719,19 @@ int pack_weights_wino7_launch(const float* w, const float* bias, int cout, int c
   if (cin_packed % wino7::CK || cin_packed <= 0 || (cin_packed < cin_src && !cin_map))
     return fail(RTPOSE_E_INVAL, "pack_winograd: cin_packed must be a multiple of 8 and >= cin_src");
   const int coutp = cout_pad(cout);
-  const size_t total = (size_t)70 * cin_packed * coutp;
+  const int nfq = wino7::wino7_fm() + 6;
+  const size_t total = (size_t)7 * nfq * cin_packed * coutp;
   const int threads = 256;
   const unsigned blocks = (unsigned)((total + threads - 1) / threads);
   hipLaunchKernelGGL(wino7::pack_wino7_kernel, dim3(blocks), dim3(threads), 0, s, w, bias, cout, cin_src, cin_map,
-                     cin_packed, coutp, wp, bp);
+                     cin_packed, coutp, nfq, wp, bp);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 size_t packed_weight_floats_wino7(int cout, int cin) {
-  // + 4 steps (8 frequency blocks of 8 x cout_pad floats): the B prefetch runs up to four steps ahead
-  return (size_t)(70 * cin + 64) * cout_pad(cout);
+  // + 5 steps (10 frequency blocks of 8 x cout_pad floats): the B prefetch runs up to five steps ahead
+  return (size_t)(7 * (wino7::wino7_fm() + 6) * cin + 96) * cout_pad(cout);
 }
 
 }  // namespace rtpose

@@ -112,11 +112,14 @@ def test_grouped_branches(capi, cuda):
 
 
 WINO7_CASES = [
-    # n, h, w, cin (packed), cout, relu, pad_in, pad_out      (k = 7; csrc/conv_wino7.hip)
-    (2, 46, 46, 128, 128, 1, 3, 3),      # Mconv2_stageN: 12 position groups per row, blocks crossing images
-    (1, 46, 49, 192, 128, 1, 3, 3),      # ski.jpg geometry (46x49), 185 -> 192 packed input, W % 4 == 1
-    (3, 23, 18, 64, 256, 0, 3, 0),       # W % 4 == 2, two N tiles, no ReLU
-    (5, 6, 7, 16, 128, 1, 3, 3),         # tiny maps: a block spans several images (W % 4 == 3)
+    # n, h, w, cin (packed), cout, relu, pad_in, pad_out      (k = 7; csrc/conv_wino7.hip, F(6,7): groups of 6 pixels)
+    (2, 46, 46, 128, 128, 1, 3, 3),      # Mconv2_stageN: 8 position groups per row (W % 6 == 4), strips per image
+    (1, 46, 49, 192, 128, 1, 3, 3),      # ski.jpg geometry (46x49), 185 -> 192 packed input, W % 6 == 1
+    (3, 23, 18, 64, 256, 0, 3, 0),       # W % 6 == 0, two N tiles, no ReLU, strips crossing images
+    (5, 6, 7, 16, 128, 1, 3, 3),         # tiny maps: a block spans several images (W % 6 == 1)
+    (2, 20, 27, 32, 128, 1, 3, 3),       # W % 6 == 3
+    (1, 17, 35, 8, 128, 0, 3, 1),        # W % 6 == 5, one chunk
+    (1, 30, 44, 24, 128, 1, 3, 0),       # W % 6 == 2
     (1, 70, 66, 128, 128, 1, 3, 0),      # multi-scale map, wider rows
     (1, 9, 80, 8, 128, 1, 4, 1),         # one chunk; 20 groups per row; gap wider than the padding
 ]
@@ -142,18 +145,18 @@ def test_winograd7_grouped_branches_and_direct_agree(capi, cuda):
 
 
 def test_winograd7_persistent_blocks_split_tiles(capi, cuda):
-    """8 x 46 x 46, two branches = 288 tiles >= 256 CUs: the launch runs as persistent blocks that share the
+    """12 x 46 x 46, two branches = 288 tiles (F(6,7): 12 strips per image) >= 256 CUs: the launch runs as persistent blocks that share the
     (tile, chunk) units evenly, most tiles are split between two blocks (conv_wino7.hip: wino7_f32).  The second
     block continues the first one's sums, so the result is BIT-identical to the one-block-per-tile launch of a
     smaller batch of the same images; run twice: the hand-over flags are back to zero after a launch."""
-    outs, refs = _run_conv(capi, cuda, 8, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=11, groups=2, winograd=True)
-    again, _ = _run_conv(capi, cuda, 8, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=11, groups=2, winograd=True)
+    outs, refs = _run_conv(capi, cuda, 12, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=11, groups=2, winograd=True)
+    again, _ = _run_conv(capi, cuda, 12, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=11, groups=2, winograd=True)
     for o, r, o2 in zip(outs, refs, again):
         assert (o - r).abs().max().item() <= TOL * max(1.0, r.abs().max().item())
         assert torch.equal(o, o2)
     # same generator stream: the first 2 images / both filters of an n = 2 run are those of the n = 8 run? no -
     # the inputs are drawn as one (n, c, h, w) tensor, so re-run the FIRST image alone through a slice instead
-    small, _ = _run_conv(capi, cuda, 8, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=11, groups=2, winograd=True,
+    small, _ = _run_conv(capi, cuda, 12, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=11, groups=2, winograd=True,
                          only_images=3)
     for o, sm in zip(outs, small):
         assert torch.equal(o[:3], sm)
