@@ -25,7 +25,6 @@
 namespace rtpose {
 int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
 int conv2d_winograd_fits(int k, int cin, int cout, int pool, int N, int H, int W, int hs);
-int conv2d_wino7_tiles(int N, int H, int W, int hs);
 int pack_weights_launch(const float* w, const float* bias, int cout, int cin_src, int k,
                         const int32_t* cin_map, int cin_packed, float* wp, float* bp, hipStream_t s);
 // bf16 path (conv_mfma_bf16.hip)
@@ -152,10 +151,11 @@ int add_conv_w(rtpose_net* n, const std::string& name, int cout, int cin, int k,
   //  padded channels, takes 0.71 ms in Winograd form and 0.50 ms in the direct kernel)
   const bool w3 = en && k == 3 && c.cin_packed >= 32 && conv2d_winograd_fits(3, c.cin_packed, cout, 0, 1, 8, 8, 9);
   c.dual = en && k == 7 && c.cin_packed % 8 == 0 && cout_pad(cout) % 128 == 0;
-  // F(4,7) blocks are one wave per SIMD and 32 positions x 128 columns each: with fewer than 64 of them (one
-  // 368 x 368 image: 36) the direct kernel, which splits its tiles to fill the CUs, is faster (3.2 vs 4.2 ms)
-  c.wino = w3 || (c.dual && conv2d_winograd_fits(7, c.cin_packed, cout, 0, n->N, H, W, H + 3) &&
-                  2 * conv2d_wino7_tiles(n->N, H, W, H + 3) >= 64);
+  // (The form is NOT chosen by batch size: at one 368 x 368 image the F(6,7) grid has only 24 blocks and the direct
+  //  kernel, which splits its tiles to fill the CUs, would be faster - 3.2 vs 4.1 ms for the 25 launches - but then
+  //  an image's maps would depend on the batch it is evaluated in.  Bit-identical results for every batch size are
+  //  kept instead; `RTPOSE_WINOGRAD=3` gives the faster single-image plan.)
+  c.wino = w3 || (c.dual && conv2d_winograd_fits(7, c.cin_packed, cout, 0, n->N, H, W, H + 3));
   c.w_off = n->wt_floats;
   n->wt_floats += round_up((w3 || c.dual) ? rtpose_packed_weight_floats_winograd(cout, c.cin_packed, k)
                            : n->split     ? rtpose_packed_weight_bytes_bf16x3(cout, c.cin_packed, k) / 4
