@@ -31,6 +31,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "conv_exp.h"
 #include "wino_common.h"
 
 namespace rtpose {
@@ -229,13 +230,16 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
         }
         RTPOSE_PIN();
         if (slot < 2 * G) {  // A of the next step (the first step of a chunk is read after the barrier)
-          if (s < 7) a[(s + 1) & 1][slot / G][slot % G] = va[slot % G][(2 * (s + 1) + slot / G) * CG * NT];
+          if (s < 7)
+            a[(s + 1) & 1][slot / G][slot % G] =
+                RTPOSE_EXP_A(va[slot % G][(2 * (s + 1) + slot / G) * CG * NT], a[s & 1][slot / G][slot % G]);
         } else {             // B two steps ahead
           const int i = slot - 2 * G;
-          bs[(s + 2) & 3][i / G][i % G] = bload_f4(rw, boff, wso + ((i / G) * CG + 2 * (i % G)) * cgstep);
+          bs[(s + 2) & 3][i / G][i % G] =
+              RTPOSE_EXP_B(bload_f4(rw, boff, wso + ((i / G) * CG + 2 * (i % G)) * cgstep), bs[s & 3][i / G][i % G]);
           if (slot == SLOTS - 1) wso += bstep;
         }
-        if (slot == SLOTS - 1) {
+        if (RTPOSE_EXP_STAGE && slot == SLOTS - 1) {
           if (s < 2) {
             tgroup(nbuf, s);
           } else {

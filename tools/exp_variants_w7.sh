@@ -7,9 +7,9 @@ VARIANTS="${VARIANTS:-base: noB:-DRTPOSE_EXP_NO_B noA:-DRTPOSE_EXP_NO_A noT:-DRT
 for v in $VARIANTS; do
   name=${v%%:*}; flags=$(echo ${v#*:} | tr ',' ' ')
   if [ "$1" = "build" ]; then
-    ONLY=conv_wino7 OUT=tools/exp/lib_w7_$name.so tools/build_dev.sh $flags > /dev/null || echo "build of $name failed"
+    ONLY=${ONLY:-conv_wino7} OUT=tools/exp/lib_w7_$name.so tools/build_dev.sh $flags > /dev/null || echo "build of $name failed"
   else
     echo "=== $name"
-    RTPOSE_LIB_PATH=$PWD/tools/exp/lib_w7_$name.so python tools/profile_layers.py 32 368 368 3 fp32 2>&1 | grep -E "model2_1.0|model2_1.2|^k=7|sum of"
+    RTPOSE_LIB_PATH=$PWD/tools/exp/lib_w7_$name.so python tools/profile_layers.py 32 368 368 3 fp32 2>&1 | grep -E "${SHOW:-model2_1.0|model2_1.2|^k=7|sum of}"
   fi
 done
