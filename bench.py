@@ -328,12 +328,12 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": ("conv_mfma_bf16<7,16,0,..,SP=2>" if x3 else
                                     "conv_mfma_bf16<7,32,0>" if bf16 else
-                                    "wino7_f32 (F(4,7) Winograd along x)" if wino7 else "conv_mfma_f32<7,16,0>") +
+                                    "wino7_f32 (F(%s,7) Winograd along x)" % os.environ.get("RTPOSE_WINOGRAD7_M", "6") if wino7 else "conv_mfma_f32<7,16,0>") +
                                    " (7x7 stage convs, 68% of the network's direct-convolution FLOPs)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None,
                          # `achieved` counts the ALGORITHMIC flops of the direct 7x7 sum.  In
-                         # Winograd form the kernel issues 70/196 of them (+ group / channel padding), so
+                         # Winograd form the kernel issues 84/294 of them (F(6,7); + group / channel padding), so
                          # frac may exceed 1; executed_frac = issued MFMA flops / time / peak is the
                          # matrix-pipe utilisation and cannot.
                          "executed": round(executed, 2), "executed_frac": round(executed / peak, 4),

@@ -620,7 +620,10 @@ int conv2d_wino7_fits(int cin, int cout, int N, int H, int W, int hs) {
   return p.ni <= (p.fm == 6 ? 1 : 2) && p.lds <= 156 * 1024;
 }
 
-// position strips (block rows of the launch grid) of an N x H x W conv, for callers that choose between the forms
+// FM of the F(FM, 7) form this process uses (for flop accounting)
+int conv2d_wino7_fm() { return wino7::wino7_fm(); }
+
+// position strips (block rows of the launch grid) of an N x H x W conv
 int conv2d_wino7_tiles(int N, int H, int W, int hs) {
   wino7::Plan p;
   return wino7::make_plan(N, H, W, hs, &p) ? 0 : p.mtiles;

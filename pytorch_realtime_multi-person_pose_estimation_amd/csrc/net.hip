@@ -25,6 +25,7 @@
 namespace rtpose {
 int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
 int conv2d_winograd_fits(int k, int cin, int cout, int pool, int N, int H, int W, int hs);
+int conv2d_wino7_fm();
 int pack_weights_launch(const float* w, const float* bias, int cout, int cin_src, int k,
                         const int32_t* cin_map, int cin_packed, float* wp, float* bp, hipStream_t s);
 // bf16 path (conv_mfma_bf16.hip)
@@ -520,8 +521,9 @@ int rtpose_net_launch_executed_flops(const rtpose_net* net, int i, double* flops
       if (c.wino && c.k == 3) {         // 16 frequencies per 2 x 2 wtile
         fl += 2.0 * net->N * ceil_div(o.H, 2) * ceil_div(o.W, 2) * 16.0 * kc;
         wino = 1;
-      } else if (c.wino && c.k == 7) {  // 10 frequencies x 7 rows per group of 4 pixels
-        fl += 2.0 * net->N * o.H * ceil_div(o.W, 4) * 70.0 * kc;
+      } else if (c.wino && c.k == 7) {  // FM + 6 frequencies x 7 rows per group of FM pixels
+        const int fm = conv2d_wino7_fm();
+        fl += 2.0 * net->N * o.H * ceil_div(o.W, fm) * 7.0 * (fm + 6) * kc;
         wino = 1;
       } else {
         fl += 2.0 * net->N * o.H * o.W * (double)c.k * c.k * kc;
