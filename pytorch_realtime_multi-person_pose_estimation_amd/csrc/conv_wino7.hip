@@ -139,7 +139,9 @@ template <int NI, int GXT, int FM>
 __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const int mt, const int c, const int cb,
                                               const int ce, const int nch, const int slot) {
   using T = WT<FM>;
-  constexpr int NFQ = T::NFQ, NP = T::NP, NSETS = T::NSETS;  // frequencies, +-point pairs, B register sets
+  // frequencies, +-point pairs, B register sets (F(6,7) with two transform items per thread: 3 sets, weights only 2
+  // steps ahead - the registers go to the second item's 12 segments)
+  constexpr int NFQ = T::NFQ, NP = T::NP, NSETS = (FM == 6 && NI == 2) ? 3 : T::NSETS;
   constexpr int NPS = 7 * NFQ / 2;                           // (ky, frequency pair) steps per chunk (NPS % NSETS == 0)
   constexpr int PF = RTPOSE_EXP_W7_PF < NSETS ? RTPOSE_EXP_W7_PF : NSETS - 1;  // B prefetch distance in steps
   constexpr int NHI = NFQ - 7;                               // segments that can reach past the row's own gap
@@ -616,8 +618,7 @@ int conv2d_wino7_fits(int cin, int cout, int N, int H, int W, int hs) {
   if (cin <= 0 || cin % wino7::CK || cout_pad(cout) % 128 || N <= 0 || H <= 0 || W <= 0) return 0;
   wino7::Plan p;
   if (wino7::make_plan(N, H, W, hs, &p)) return 0;
-  // (F(6,7) with two transform items per thread would spill: one item only)
-  return p.ni <= (p.fm == 6 ? 1 : 2) && p.lds <= 156 * 1024;
+  return p.ni <= 2 && p.lds <= 156 * 1024;
 }
 
 // FM of the F(FM, 7) form this process uses (for flop accounting)
@@ -709,7 +710,8 @@ int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
   if (p.fm == 6) {
     if (p.gx == 8 && p.tpi && p.ni == 1 && p.nrows == strip_rows(8))
       return launch_inst<1, 8, 6>(a, grid, (size_t)2 * strip_rows(8) * row_stride(8, 12) * 16, s);
-    return launch_inst<1, 0, 6>(a, grid, p.lds, s);
+    if (p.ni == 1) return launch_inst<1, 0, 6>(a, grid, p.lds, s);
+    return launch_inst<2, 0, 6>(a, grid, p.lds, s);
   }
   if (p.gx == 12 && p.tpi && p.ni == 1 && p.nrows == strip_rows(12))
     return launch_inst<1, 12, 4>(a, grid, (size_t)2 * strip_rows(12) * row_stride(12, 10) * 16, s);
