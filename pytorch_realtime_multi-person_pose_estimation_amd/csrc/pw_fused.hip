@@ -31,6 +31,8 @@
 
 namespace rtpose {
 
+typedef float pw_f2 __attribute__((ext_vector_type(2)));
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef const floatx4 __attribute__((address_space(1)))* gcf4_t;
@@ -271,7 +273,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
         // depthwise 3x3 (+bias) -> A tile.  Tap (ky, kx) of pixel q is pixel q + (ky-1) ws + (kx-1).
         const int k4 = A.K >> 2;
         const float4* wl = dwl + min((c0 >> 2) + pl, k4 - 1);  // (groups past K: their A planes are not read)
-        float4 v0 = wl[9 * k4], v1 = v0;                       // bias
+        const float4 vb = wl[9 * k4];                          // bias
+        pw_f2 v0lo = {vb.x, vb.y}, v0hi = {vb.z, vb.w}, v1lo = v0lo, v1hi = v0hi;
         const float4* s0 = st + pl * nps + sp0;
         const float4* s1 = st + pl * nps + sp1;
 #pragma unroll
@@ -280,19 +283,18 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
           for (int kx = 0; kx < 3; ++kx) {
             const float4 ww = wl[(ky * 3 + kx) * k4];
             const float4 x0 = s0[ky * kPwHalo + kx], x1 = s1[ky * kPwHalo + kx];
-            v0.x += x0.x * ww.x;
-            v0.y += x0.y * ww.y;
-            v0.z += x0.z * ww.z;
-            v0.w += x0.w * ww.w;
-            v1.x += x1.x * ww.x;
-            v1.y += x1.y * ww.y;
-            v1.z += x1.z * ww.z;
-            v1.w += x1.w * ww.w;
+            // packed fused multiply-adds (v_pk_fma_f32): fp32 VALU instructions take their cycles from the ALUs the
+            // fp32 MFMAs run on - 4 instead of 16 per tap
+            const pw_f2 wlo = {ww.x, ww.y}, whi = {ww.z, ww.w};
+            v0lo = __builtin_elementwise_fma(pw_f2{x0.x, x0.y}, wlo, v0lo);
+            v0hi = __builtin_elementwise_fma(pw_f2{x0.z, x0.w}, whi, v0hi);
+            v1lo = __builtin_elementwise_fma(pw_f2{x1.x, x1.y}, wlo, v1lo);
+            v1hi = __builtin_elementwise_fma(pw_f2{x1.z, x1.w}, whi, v1hi);
           }
           RTPOSE_PW_PIN();  // one stencil row (9 LDS reads) at a time: all 27 at once cost 108 VGPRs
         }
-        a_buf[pl * kPwQS + px] = v0;
-        a_buf[pl * kPwQS + px + 32] = v1;
+        a_buf[pl * kPwQS + px] = make_float4(v0lo.x, v0lo.y, v0hi.x, v0hi.y);
+        a_buf[pl * kPwQS + px + 32] = make_float4(v1lo.x, v1lo.y, v1hi.x, v1hi.y);
         // the next chunk's halo (of this item, or chunk 0 of the next; no next item: nxt == cur, a harmless
         // re-read) is requested only now: the depthwise phase above is the register peak of the kernel, and
         // the MFMAs below still cover the latency
