@@ -131,6 +131,71 @@ __host__ __device__ constexpr int strip_rows(int gx) { return (31 + gx - 1) / gx
 // NI  = (row, gx, channel group) transform items per thread and chunk
 // GXT = compile-time position groups per row (0: run-time).  With GXT every LDS address of the multiply loop is
 //       one base register + an immediate; the run-time form pays one v_add per access.
+// The input-transform role of a thread: NI items (row, gx, channel group) of the block's transformed rows.
+// The last group of a row reaches past the row's own 3-pixel gap (x >= W + 3 is the NEXT row's - or the next
+// image's - data) when W is not a multiple of FM.  Those inputs only meet outputs that are not stored, but
+// through the transform they would cancel only up to rounding, and an image's result would depend on its
+// neighbour in the batch: segments n >= 7 are therefore clamped to the last gap pixel (a zero).
+// (the input descriptor is based at the block's first row, so the 32-bit offsets stay small whatever the size
+// of the activation buffer)
+template <int NI, int FM>
+struct Xform {
+  using T = WT<FM>;
+  static constexpr int NFQ = T::NFQ, NP = T::NP, NHI = NFQ - 7;
+  i32x4 rin;
+  unsigned voff[NI], vhi[NI][NHI], pxb;
+  int vdst[NI], fstride;  // LDS slot of frequency 0 of an item; float4 between frequencies
+  F4 d[NI][NFQ], eo[2];
+
+  __device__ __forceinline__ void setup(const Group& g, int W, int GX, int RS, int R0, int nrows) {
+    const int tid = threadIdx.x;
+    const int nitems = nrows * GX * CG;
+    const long qbase = (long)g.in_lead + (long)(R0 - 3) * g.in_ws - 3;
+    rin = make_rsrc(g.in + qbase * g.in_cstride + g.in_choff);
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int i = min(tid + k * 256, nitems - 1);  // surplus threads repeat the last item (same value, same slot)
+      const int r = i / (GX * CG), rem = i - r * (GX * CG);
+      const int gx = rem >> 1, cg = rem & 1;
+      voff[k] = (unsigned)((((long)r * g.in_ws + FM * gx) * g.in_cstride + cg * 4) * 4);
+      vdst[k] = r * RS + cg * GX + gx;
+#pragma unroll
+      for (int n = 7; n < NFQ; ++n) vhi[k][n - 7] = voff[k] + (unsigned)(min(n, W + 5 - FM * gx) * g.in_cstride * 4);
+    }
+    pxb = (unsigned)g.in_cstride * 4;  // bytes per pixel (uniform)
+    fstride = CG * GX;
+  }
+  __device__ __forceinline__ void load_piece(int chunk, int k, int n) {
+    const unsigned cb = (unsigned)chunk * (CK * 4);
+    d[k][n] = n < 7 ? bload(rin, voff[k], cb + n * pxb) : bload(rin, vhi[k][n < 7 ? 0 : n - 7], cb);
+  }
+  // The transform of one item in NP + 2 groups of 10..20 packed VALU instructions.  (A lone VALU instruction between
+  // two MFMAs costs ~8 cycles of matrix time, a group of 12..16 costs ~60 in all: few, full groups.)
+  //   group p < NP: E_p, O_p (NP terms each), then frequencies 2p+1 = E_p + O_p and 2p+2 = E_p - O_p -> LDS
+  //   group NP: frequency 0;  group NP + 1: frequency NFQ - 1 (inf)                    (NP + 1 terms each)
+  __device__ __forceinline__ void tgroup(float4* vw, int k, int gidx) {
+    if (gidx < NP) {
+      const int row = 2 * gidx + 1;
+#pragma unroll
+      for (int odd = 0; odd < 2; ++odd) {
+        const int n0 = odd ? 1 : 2;  // column 0 of these rows is zero
+        F4 s = mul4(T::kBT[row][n0], d[k][n0]);
+#pragma unroll
+        for (int t = 1; t < NP; ++t) s = fma4(T::kBT[row][n0 + 2 * t], d[k][n0 + 2 * t], s);
+        eo[odd] = s;
+      }
+      vw[vdst[k] + row * fstride] = to_float4(add4(eo[0], eo[1]));
+      vw[vdst[k] + (row + 1) * fstride] = to_float4(sub4(eo[0], eo[1]));
+    } else {
+      const int f = gidx == NP ? 0 : NFQ - 1, n0 = gidx == NP ? 0 : 1;
+      F4 s = mul4(T::kBT[f][n0], d[k][n0]);
+#pragma unroll
+      for (int t = 1; t < NP + 1; ++t) s = fma4(T::kBT[f][n0 + 2 * t], d[k][n0 + 2 * t], s);
+      vw[vdst[k] + f * fstride] = to_float4(s);
+    }
+  }
+};
+
 // One segment = chunks [cb, ce) of tile (mt, c).  A tile split between two blocks is summed in the SAME order as an
 // unsplit one: the block with the first chunks (cb == 0, ce < all) saves its raw accumulators to scratch slot
 // `slot` and raises the flag; the block with the last chunks (cb > 0) starts from them instead of from zero and
@@ -144,7 +209,6 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   constexpr int NFQ = T::NFQ, NP = T::NP, NSETS = (FM == 6 && NI == 2) ? 3 : T::NSETS;
   constexpr int NPS = 7 * NFQ / 2;                           // (ky, frequency pair) steps per chunk (NPS % NSETS == 0)
   constexpr int PF = RTPOSE_EXP_W7_PF < NSETS ? RTPOSE_EXP_W7_PF : NSETS - 1;  // B prefetch distance in steps
-  constexpr int NHI = NFQ - 7;                               // segments that can reach past the row's own gap
   static_assert(NPS % NSETS == 0, "B register sets must rotate in step with the chunk");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -176,60 +240,12 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
     R0 = n0 * g.in_hs + y0;
     nrows = n1 * g.in_hs + y1 - R0 + 7;
   }
-  const int nitems = nrows * GX * CG;
-
-  // ---- input transform role: NI items (row, gx, channel group) ----------------------------------------
-  // The last group of a row reaches past the row's own 3-pixel gap (x >= W + 3 is the NEXT row's - or the next
-  // image's - data) when W is not a multiple of 4.  Those inputs only meet outputs that are not stored, but
-  // through the transform they would cancel only up to rounding, and an image's result would depend on its
-  // neighbour in the batch: segments n >= 7 are therefore clamped to the last gap pixel (a zero).
-  // (the input descriptor is based at the block's first row, so the 32-bit offsets stay small whatever the size
-  // of the activation buffer)
-  const long qbase = (long)g.in_lead + (long)(R0 - 3) * g.in_ws - 3;
-  const i32x4 rin = make_rsrc(g.in + qbase * g.in_cstride + g.in_choff), rw = make_rsrc(g.w);
-  unsigned voff[NI], vhi[NI][NHI];
-  int vdst[NI];
-#pragma unroll
-  for (int k = 0; k < NI; ++k) {
-    const int i = min(tid + k * 256, nitems - 1);  // surplus threads repeat the last item (same value, same slot)
-    const int r = i / (GX * CG), rem = i - r * (GX * CG);
-    const int gx = rem >> 1, cg = rem & 1;
-    voff[k] = (unsigned)((((long)r * g.in_ws + FM * gx) * g.in_cstride + cg * 4) * 4);
-    vdst[k] = r * RS + cg * GX + gx;
-#pragma unroll
-    for (int n = 7; n < NFQ; ++n) vhi[k][n - 7] = voff[k] + (unsigned)(min(n, A.W + 5 - FM * gx) * g.in_cstride * 4);
-  }
-  const unsigned pxb = (unsigned)g.in_cstride * 4;  // bytes per pixel (uniform)
-  F4 d[NI][NFQ], eo[2];
-  auto load_piece = [&](int chunk, int k, int n) {
-    const unsigned cb = (unsigned)chunk * (CK * 4);
-    d[k][n] = n < 7 ? bload(rin, voff[k], cb + n * pxb) : bload(rin, vhi[k][n < 7 ? 0 : n - 7], cb);
-  };
-  // The transform of one item in NP + 2 groups of 10..20 packed VALU instructions.  (A lone VALU instruction between
-  // two MFMAs costs ~8 cycles of matrix time, a group of 12..16 costs ~60 in all: few, full groups.)
-  //   group p < NP: E_p, O_p (NP terms each), then frequencies 2p+1 = E_p + O_p and 2p+2 = E_p - O_p -> LDS
-  //   group NP: frequency 0;  group NP + 1: frequency NFQ - 1 (inf)                    (NP + 1 terms each)
-  auto tgroup = [&](float4* vw, int k, int gidx) {
-    if (gidx < NP) {
-      const int row = 2 * gidx + 1;
-#pragma unroll
-      for (int odd = 0; odd < 2; ++odd) {
-        const int n0 = odd ? 1 : 2;  // column 0 of these rows is zero
-        F4 s = mul4(T::kBT[row][n0], d[k][n0]);
-#pragma unroll
-        for (int t = 1; t < NP; ++t) s = fma4(T::kBT[row][n0 + 2 * t], d[k][n0 + 2 * t], s);
-        eo[odd] = s;
-      }
-      vw[vdst[k] + row * CG * GX] = to_float4(add4(eo[0], eo[1]));
-      vw[vdst[k] + (row + 1) * CG * GX] = to_float4(sub4(eo[0], eo[1]));
-    } else {
-      const int f = gidx == NP ? 0 : NFQ - 1, n0 = gidx == NP ? 0 : 1;
-      F4 s = mul4(T::kBT[f][n0], d[k][n0]);
-#pragma unroll
-      for (int t = 1; t < NP + 1; ++t) s = fma4(T::kBT[f][n0 + 2 * t], d[k][n0 + 2 * t], s);
-      vw[vdst[k] + f * CG * GX] = to_float4(s);
-    }
-  };
+  // ---- input transform role: NI items (row, gx, channel group), see Xform ----------------------------
+  Xform<NI, FM> X;
+  X.setup(g, A.W, GX, RS, R0, nrows);
+  const i32x4 rw = make_rsrc(g.w);
+  auto load_piece = [&](int chunk, int k, int n) { X.load_piece(chunk, k, n); };
+  auto tgroup = [&](float4* vw, int k, int gidx) { X.tgroup(vw, k, gidx); };
 
   // ---- MFMA roles ---------------------------------------------------------------------------------
   int abase;
@@ -475,6 +491,219 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
   }
 }
 
+// Small grids (few images): the same arithmetic on 4x as many blocks.  A block = 32 positions x 32 columns, its four
+// waves split the FREQUENCIES (3 of the 12 each) instead of the columns; every wave still runs over all chunks and ky
+// in the same order, so each frequency sum - and after the exchange through LDS the output transform - is
+// bit-identical to wino7_f32's.  One 368 x 368 image: 24 tiles x 4 column tiles = 96 blocks instead of 24, each with a
+// quarter of the MFMAs per chunk (the input transform is repeated by the 4 column tiles, on otherwise idle CUs).
+template <int NI>
+__global__ __launch_bounds__(256, 1) void wino7s_f32(const Args A) {
+  constexpr int FM = 6;
+  using T = WT<FM>;
+  constexpr int NFQ = T::NFQ, NP = T::NP, FW = NFQ / 4;  // frequencies per wave
+  constexpr int NSETS = 7, PF = 3;                        // B register sets (one per ky step of a chunk), prefetch distance
+  extern __shared__ __attribute__((aligned(16))) float4 V4[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int bi = blockIdx.x;
+  const int c = bi % A.ncombo, mt = bi / A.ncombo;  // the column tiles / branches of a position strip are neighbours
+  const int nt = c % A.ntiles, grp = c / A.ntiles;
+  const Group g = grp ? A.g[1] : A.g[0];
+  const int GX = A.GX, RS = A.RS, VB = A.VB;
+  const int PI = A.H * GX;
+  int t0, tlim;
+  if (A.TPI) {
+    const int n = mt / A.TPI;
+    t0 = n * PI + (mt - n * A.TPI) * 32;
+    tlim = (n + 1) * PI;
+  } else {
+    t0 = mt * 32;
+    tlim = A.T;
+  }
+  int R0, nrows;
+  {
+    const int n0 = t0 / PI, y0 = (t0 - n0 * PI) / GX;
+    const int t1 = min(t0 + 31, tlim - 1);
+    const int n1 = t1 / PI, y1 = (t1 - n1 * PI) / GX;
+    R0 = n0 * g.in_hs + y0;
+    nrows = n1 * g.in_hs + y1 - R0 + 7;
+  }
+  Xform<NI, FM> X;
+  X.setup(g, A.W, GX, RS, R0, nrows);
+  const i32x4 rw = make_rsrc(g.w);
+
+  int abase;
+  {
+    const int t = min(t0 + l31, tlim - 1);
+    const int n = t / PI, r = t - n * PI;
+    const int y = r / GX, gx = r - y * GX;
+    abase = (n * g.in_hs + y - R0) * RS + kh * GX + gx + (wv * FW) * CG * GX;  // this wave's first frequency
+  }
+  const int ncol = nt * 32 + l31;
+  floatx16 acc[FW];
+#pragma unroll
+  for (int f = 0; f < FW; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+  if (wv == 0) {  // the bias rides in frequency 1 (point p = 1)
+    const float b0 = g.bias[ncol];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[1][r] = b0;
+  }
+  const unsigned boff = (unsigned)((kh * g.cout_pad + ncol) * 16);
+  const unsigned fstep = (unsigned)(CG * g.cout_pad * 16);  // bytes per frequency block
+  const unsigned kstep = (unsigned)NFQ * fstep;             // bytes per ky
+  unsigned wso = (unsigned)(wv * FW) * fstep;               // this wave's frequencies of the next ky to fetch
+  float4 bs[NSETS][FW];
+
+  const int nchunks = A.cin / CK;
+#pragma unroll
+  for (int k = 0; k < NI; ++k)
+#pragma unroll
+    for (int n = 0; n < NFQ; ++n) X.load_piece(0, k, n);
+#pragma unroll
+  for (int k = 0; k < NI; ++k)
+#pragma unroll
+    for (int gi = 0; gi < NP + 2; ++gi) X.tgroup(V4, k, gi);
+  {
+    const int c1 = min(1, nchunks - 1);
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+#pragma unroll
+      for (int n = 0; n < NFQ; ++n) X.load_piece(c1, k, n);
+  }
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+#pragma unroll
+    for (int f = 0; f < FW; ++f) bs[s][f] = bload_f4(rw, boff, wso + f * fstep);
+    wso += kstep;
+  }
+  __syncthreads();
+
+#define RTPOSE_PIN()             \
+  asm volatile("" ::: "memory"); \
+  __builtin_amdgcn_sched_barrier(0)
+  // One step = one ky: the wave's FW frequencies x 4 MFMAs on FW alternating accumulators, a filler slot after each
+  // round of FW: A fragments of the next step, B fragments PF steps ahead, transform groups / segment loads.
+  constexpr int NG = (NP + 2) * NI;
+  static_assert(NG <= 8 * NI && NFQ <= 12 && NI <= 2, "transform work does not fit the slots of a chunk");
+  float4 a[2][FW];
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const float4* va = V4 + (chunk & 1) * VB + abase;
+    float4* vw = V4 + ((chunk + 1) & 1) * VB;
+    const int c2 = min(chunk + 2, nchunks - 1);
+#pragma unroll
+    for (int f = 0; f < FW; ++f) a[0][f] = va[f * CG * GX];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int f = 0; f < FW; ++f) {
+          const float4 av = a[ky & 1][f], bv = bs[ky % NSETS][f];
+          const float avv[4] = {av.x, av.y, av.z, av.w}, bvv[4] = {bv.x, bv.y, bv.z, bv.w};
+          acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv[j], bvv[j], acc[f], 0, 0, 0);
+        }
+        RTPOSE_PIN();
+        if (j == 0) {
+          if (ky + 1 < 7) {
+#pragma unroll
+            for (int f = 0; f < FW; ++f) a[(ky + 1) & 1][f] = va[(ky + 1) * RS + f * CG * GX];
+          }
+        } else if (j == 1) {
+#pragma unroll
+          for (int f = 0; f < FW; ++f) bs[(ky + PF) % NSETS][f] = bload_f4(rw, boff, wso + f * fstep);
+          wso += kstep;
+        } else {  // j = 2, 3: steps 0..3 the transform groups of the next chunk (they read the segment registers),
+                  // steps 4..6 - only then - the segment loads of the chunk after that (they overwrite them)
+          const int slot = 2 * ky + (j - 2);  // 0 .. 13
+#pragma unroll
+          for (int q = 0; q < NI; ++q) {
+            if (ky < 4) {
+              const int gq = slot * NI + q;
+              if (gq < NG) X.tgroup(vw, gq / (NP + 2), gq % (NP + 2));
+            } else {
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const int l = ((slot - 8) * NI + q) * 2 + h;
+                if (l < NFQ * NI) X.load_piece(c2, l / NFQ, l % NFQ);
+              }
+            }
+          }
+        }
+        RTPOSE_PIN();
+      }
+    }
+    __syncthreads();
+  }
+#undef RTPOSE_PIN
+
+  // ---- exchange: every wave needs all 12 frequencies of the accumulator registers it stores --------------
+  // LDS (the V buffers are free now): E[f][r][lane]; wave w stores registers r = 4 w .. 4 w + 3, i.e. positions
+  // 8 w + 4 kh + (0..3) of the block
+  float* E = reinterpret_cast<float*>(V4);
+#pragma unroll
+  for (int f = 0; f < FW; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) E[((wv * FW + f) * 16 + r) * 64 + lane] = acc[f][r];
+  __syncthreads();
+  const bool col_ok = ncol < g.cout;
+  float* out_base = g.out + g.out_choff + ncol;
+  int tcur = t0 + 8 * wv + 4 * kh;
+  int sn = tcur / PI, sy, sx;
+  {
+    const int r = tcur - sn * PI;
+    sy = r / GX;
+    sx = r - sy * GX;
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = 4 * wv + rr;
+    float m[NFQ];
+#pragma unroll
+    for (int f = 0; f < NFQ; ++f) m[f] = E[(f * 16 + r) * 64 + lane];
+    float S[NP], D[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      S[p] = m[2 * p + 1] + m[2 * p + 2];
+      D[p] = m[2 * p + 1] - m[2 * p + 2];
+    }
+    float y[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      float v = (i & 1) ? D[0] : S[0];
+      float pw[NP];
+#pragma unroll
+      for (int p = 1; p < NP; ++p) {
+        pw[p] = 1.f;
+        for (int e = 0; e < i; ++e) pw[p] *= T::kPts[p];
+        v = __builtin_fmaf(pw[p], (i & 1) ? D[p] : S[p], v);
+      }
+      if (i == 0) v += m[0];
+      if (i == FM - 1) v += m[NFQ - 1];
+      y[i] = v;
+    }
+    if (col_ok && tcur < tlim) {
+      const size_t q = (size_t)g.out_lead + (size_t)(sn * g.out_hs + sy) * g.out_ws + FM * sx;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const float v = A.relu ? fmaxf(y[i], 0.f) : y[i];
+        if (FM * sx + i < A.W) out_base[(q + i) * g.out_cstride] = v;
+      }
+    }
+    ++tcur;
+    if (++sx >= GX) {
+      sx = 0;
+      if (++sy >= A.H) {
+        sy = 0;
+        ++sn;
+      }
+    }
+  }
+}
+
 // ---- weight packing: U[ky][f] = sum_kx G[f][kx] w[ky][kx];  packed[chunk][ky][f][cg][cout_pad][4] ------------
 __global__ void pack_wino7_kernel(const float* __restrict__ w, const float* __restrict__ bias, int cout,
                                   int cin_src, const int32_t* __restrict__ cin_map, int cin_packed, int coutp,
@@ -571,6 +800,21 @@ static int launch_inst(const Args& a, dim3 grid, size_t lds, hipStream_t s) {
   static PerDeviceOnce attr_set;
   const int dev = current_device();
   auto kern = wino7_f32<NI, GXT, FM>;
+  if (!attr_set.is_set(dev)) {
+    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set.set(dev);
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+template <int NI>
+static int launch_small(const Args& a, dim3 grid, size_t lds, hipStream_t s) {
+  static PerDeviceOnce attr_set;
+  const int dev = current_device();
+  auto kern = wino7s_f32<NI>;
   if (!attr_set.is_set(dev)) {
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -706,6 +950,20 @@ int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
     }
   }
   const dim3 grid((unsigned)ids, 1, 1);
+  // small grids: the frequency-split form (wino7s_f32), bit-identical, 4 x the blocks
+  static int small_env = -1;
+  if (small_env < 0) {
+    const char* e = dev_env("RTPOSE_W7_SMALL");
+    small_env = e ? atoi(e) : 1;
+  }
+  if (small_env && p.fm == 6 && !a.persist && (long)a.mtiles * a.ncombo * 2 <= device_cu_count()) {
+    Args b = a;
+    b.ntiles = cout_pad(d0.cout) / 32;
+    b.ncombo = b.ntiles * ngroups;
+    const dim3 gs((unsigned)((long)b.mtiles * b.ncombo), 1, 1);
+    const size_t lds_s = p.lds > (size_t)12 * 16 * 64 * 4 ? p.lds : (size_t)12 * 16 * 64 * 4;  // V buffers, then the exchange
+    return p.ni == 1 ? launch_small<1>(b, gs, lds_s, s) : launch_small<2>(b, gs, lds_s, s);
+  }
   // 46-wide maps (368 x 368 inputs, BASELINE configs[1]): every LDS offset of the multiply loop is an immediate
   if (p.fm == 6) {
     if (p.gx == 8 && p.tpi && p.ni == 1 && p.nrows == strip_rows(8))
