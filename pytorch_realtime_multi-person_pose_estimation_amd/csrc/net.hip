@@ -152,10 +152,9 @@ int add_conv_w(rtpose_net* n, const std::string& name, int cout, int cin, int k,
   //  padded channels, takes 0.71 ms in Winograd form and 0.50 ms in the direct kernel)
   const bool w3 = en && k == 3 && c.cin_packed >= 32 && conv2d_winograd_fits(3, c.cin_packed, cout, 0, 1, 8, 8, 9);
   c.dual = en && k == 7 && c.cin_packed % 8 == 0 && cout_pad(cout) % 128 == 0;
-  // (The form is NOT chosen by batch size: at one 368 x 368 image the F(6,7) grid has only 24 blocks and the direct
-  //  kernel, which splits its tiles to fill the CUs, would be faster - 3.2 vs 4.1 ms for the 25 launches - but then
-  //  an image's maps would depend on the batch it is evaluated in.  Bit-identical results for every batch size are
-  //  kept instead; `RTPOSE_WINOGRAD=3` gives the faster single-image plan.)
+  // (The form is NOT chosen by batch size: the direct kernel sums in another order, and an image's maps would depend
+  //  on the batch it is evaluated in.  Small grids get the frequency-split launch of the same arithmetic instead,
+  //  conv_wino7.hip: wino7s_f32.)
   c.wino = w3 || (c.dual && conv2d_winograd_fits(7, c.cin_packed, cout, 0, n->N, H, W, H + 3));
   c.w_off = n->wt_floats;
   n->wt_floats += round_up((w3 || c.dual) ? rtpose_packed_weight_floats_winograd(cout, c.cin_packed, k)
