@@ -135,3 +135,24 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "rtpose_mi355x.h"\nint main(void) { return rtpose_version() == 0; }\n')
     subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
                     "-c", str(src), "-o", str(tmp_path / "hdr.o")], check=True)
+
+
+def test_winograd_fits_is_host_only_logic(capi):
+    """rtpose_conv2d_winograd_fits decides on the host (csrc/conv_wino.hip, conv_wino7.hip): 3x3 needs cin % 16 (or % 8
+    for 64 padded columns), 7x7 needs cin % 8, 128-column tiles and transformed rows that fit the LDS."""
+    lib = capi.lib
+    d = (capi.ConvDesc * 1)()
+
+    def fits(k, cin, cout, n=1, h=46, w=46, pool=0):
+        d[0].k, d[0].cin, d[0].cout, d[0].pool = k, cin, cout, pool
+        d[0].lin = capi.Layout.padded(cin, h, w, k // 2)
+        return lib.rtpose_conv2d_winograd_fits(d, n, h, w)
+
+    assert fits(3, 8, 128) == 0 and fits(3, 8, 64) == 1 and fits(3, 512, 512) == 1 and fits(1, 128, 128) == 0
+    assert fits(7, 128, 128, 32) == 1 and fits(7, 192, 128, 32) == 1 and fits(7, 128, 128, 1) == 1
+    assert fits(7, 128, 38) == 0 and fits(7, 100, 128) == 0 and fits(7, 128, 128, 1, 46, 46, pool=1) == 0
+    assert fits(7, 128, 128, 2, 184, 184) == 0      # transformed rows of a 184-wide map do not fit the LDS
+    assert fits(7, 128, 128, 4, 69, 87) == 1        # a TTA scale: two transform items per thread
+    # packed sizes: 16 / 9 of the taps for 3x3, (FM + 6) * 7 / 49 for 7x7 (F(6,7) unless RTPOSE_WINOGRAD7_M=4), + slack
+    assert lib.rtpose_packed_weight_floats_winograd(128, 128, 3) == (16 * 128 + 64) * 128
+    assert lib.rtpose_packed_weight_floats_winograd(128, 128, 7) in ((84 * 128 + 96) * 128, (70 * 128 + 96) * 128)
