@@ -57,6 +57,7 @@ struct Args {
   int cin;
   int relu, pool;
   int mtiles, ntiles, ncombo, xcd_remap;
+  int persist;  // 1: gridDim.x persistent blocks; block p keeps (n tile, group) p % ncombo and walks every (gridDim.x / ncombo)-th m tile
 };
 
 template <int WM, int WN, int CK>
@@ -75,18 +76,28 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   const int wm = wave % WM, wn = wave / WM;
   const int l31 = lane & 31, kh = lane >> 5;
 
-  // ---- block -> (m tile, n tile, group); XCD-aware order as in conv_mfma.hip ----------------
+  // ---- block -> (n tile, group) and its m tiles ------------------------------------------------
+  // one tile per block (XCD-aware order as in conv_mfma.hip), or persistent: block p keeps ONE (n tile, group) and
+  // walks the m tiles j0, j0 + jstep, ...  The first patches of the next tile are requested right after the last
+  // barrier of the current one, so their HBM latency (and the block dispatch) hides under the output transform.
   const int bi = blockIdx.x;
-  int mt, c;
-  if (A.xcd_remap) {
-    const int xcd = bi & 7, j = bi >> 3;
-    c = j % A.ncombo;
-    mt = (j / A.ncombo) * 8 + xcd;
+  int j0, jstep, c;
+  if (A.persist) {
+    c = bi % A.ncombo;
+    j0 = bi / A.ncombo;
+    jstep = gridDim.x / A.ncombo;
   } else {
-    mt = bi % A.mtiles;
-    c = bi / A.mtiles;
+    if (A.xcd_remap) {
+      const int xcd = bi & 7, j = bi >> 3;
+      c = j % A.ncombo;
+      j0 = (j / A.ncombo) * 8 + xcd;
+    } else {
+      j0 = bi % A.mtiles;
+      c = bi / A.mtiles;
+    }
+    jstep = A.mtiles;  // one tile
   }
-  if (mt >= A.mtiles) return;
+  if (j0 >= A.mtiles) return;
   const int nt = c % A.ntiles, grp = c / A.ntiles;
   const Group g = grp ? A.g[1] : A.g[0];
   const int TT = A.TY * A.TX;
@@ -106,17 +117,18 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   const i32x4 rw = make_rsrc(g.w);
   i32x4 rin;
   unsigned pvoff;
-  {
+  auto set_loader = [&](int mt) {
     auto patch_q = [&](int t) -> size_t {
       const int n = t / TT, r = t - n * TT;
       const int ty = r / A.TX, tx = r - ty * A.TX;
       return (size_t)g.in_lead + (size_t)(n * g.in_hs + 2 * ty - 1) * g.in_ws + (2 * tx - 1);
     };
-    const size_t q0 = patch_q(min(mt * NT, A.T - 1));                // uniform: lowest address of the block
+    const size_t q0 = patch_q(min(mt * NT, A.T - 1));                // uniform: lowest address of the tile
     const size_t q = patch_q(min(mt * NT + tl, A.T - 1));            // wtiles past the end re-read the last one
     rin = make_rsrc(g.in + q0 * g.in_cstride + g.in_choff);
     pvoff = (unsigned)(((q - q0) * g.in_cstride + cg * 4) * 4);
-  }
+  };
+  set_loader(j0);
   unsigned psoff[3];  // uniform byte offsets of this half's three patch rows
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
@@ -158,15 +170,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   const int ncol = nt * (32 * WN) + wn * 32 + l31;
   const int arow = wm * 32 + l31;
   floatx16 acc[16];
-#pragma unroll
-  for (int f = 0; f < 16; ++f)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-  {
-    const float b0 = g.bias[ncol];  // padded to cout_pad
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[5][r] = b0;
-  }
+  const float bias0 = g.bias[ncol];  // padded to cout_pad
   // B: lane offset (k half, column) in one register; (frequency of the pair, k group) and the step in the scalar offset
   const unsigned boff = (unsigned)((kh * g.cout_pad + ncol) * 16);
   const unsigned cgstep = (unsigned)(g.cout_pad * 16);     // bytes per channel group plane
@@ -176,7 +180,13 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
 
   const int nchunks = A.cin / CK;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) load_piece(0, i);
+  for (int i = 0; i < 12; ++i) load_piece(0, i);  // chunk 0 of the first tile
+
+  for (int mt = j0; mt < A.mtiles; mt += jstep) {
+#pragma unroll
+  for (int f = 0; f < 16; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = f == 5 ? bias0 : 0.f;
   tgroup(0, 0);
   tgroup(0, 1);
   {
@@ -185,6 +195,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
     for (int i = 0; i < 12; ++i) load_piece(c1, i);
   }
   // (B after the patch loads, as in the steady state of the loop: see conv_wino7.hip)
+  wso = 0;
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
@@ -252,7 +263,11 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
     }
     __syncthreads();
   }
-#undef RTPOSE_PIN
+  if (mt + jstep < A.mtiles) {  // chunk 0 of the next tile: in flight during the output transform below
+    set_loader(mt + jstep);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) load_piece(0, i);
+  }
 
   // ---- epilogue: output transform A^T M A, (+ReLU) (+2x2 max-pool), masked stores -----------------
   // accumulator register r of a lane = wtile row (r / 4) * 8 + 4 kh + r % 4 of the wave tile, column l31
@@ -316,6 +331,8 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
       }
     }
   }
+  }  // m tiles of this block
+#undef RTPOSE_PIN
 }
 
 // ---- weight packing: U = G g G^T, packed[chunk][f][cg][cout_pad][4]  <-  w[cout][cin_src][3][3] -----------
@@ -436,8 +453,21 @@ int conv2d_wino_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
   a.ntiles = cout_pad(d0.cout) / (32 * wn);
   a.ncombo = a.ntiles * ngroups;
   a.xcd_remap = (a.ncombo > 1 && a.mtiles >= 64) ? 1 : 0;
-  const long ids = a.xcd_remap ? (long)8 * a.ncombo * ceil_div(a.mtiles, 8) : (long)a.mtiles * a.ncombo;
+  long ids = a.xcd_remap ? (long)8 * a.ncombo * ceil_div(a.mtiles, 8) : (long)a.mtiles * a.ncombo;
   if (ids > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv2d_winograd: grid too large");
+  {
+    // persistent blocks when a CU would get more than one tile anyway (see wino_f32)
+    const int n_cu = device_cu_count();
+    static int persist_env = -1;
+    if (persist_env < 0) {
+      const char* e = dev_env("RTPOSE_W3_PERSIST");
+      persist_env = e ? atoi(e) : 1;
+    }
+    if (persist_env && (long)a.mtiles * a.ncombo > n_cu && n_cu % a.ncombo == 0) {
+      a.persist = 1;
+      ids = n_cu;
+    }
+  }
   const dim3 grid((unsigned)ids, 1, 1);
   if (ck == 16) return launch_inst<1, 4, 16>(a, grid, s);
   return launch_inst<2, 2, 8>(a, grid, s);
