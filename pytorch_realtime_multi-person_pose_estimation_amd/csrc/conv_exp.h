@@ -12,7 +12,7 @@
     defined(RTPOSE_EXP_NO_STAGE) || defined(RTPOSE_EXP_NO_FILL) || defined(RTPOSE_EXP_NO_STORE) ||      \
     defined(RTPOSE_EXP_SCALAR_STORE) || defined(RTPOSE_EXP_BSPREAD) || defined(RTPOSE_EXP_HALF_B_ON) || \
     defined(RTPOSE_EXP_STAGGER) || defined(RTPOSE_EXP_TB1X1) || defined(RTPOSE_EXP_HD) ||               \
-    defined(RTPOSE_EXP_RB2) || defined(RTPOSE_EXP_W7_PF) || defined(RTPOSE_EXP_W7_TMASK) || defined(RTPOSE_EXP_W7_LPS)
+    defined(RTPOSE_EXP_RB2) || defined(RTPOSE_EXP_W7_PF) || defined(RTPOSE_EXP_W7_TMASK) || defined(RTPOSE_EXP_W7_LPS) || defined(RTPOSE_EXP_W_EPI)
 #error "RTPOSE_EXP_* ablation switches need -DRTPOSE_DEV_BUILD (they are not part of production builds)"
 #endif
 #endif
@@ -49,6 +49,11 @@ inline const char* dev_env(const char* name) {
 #define RTPOSE_EXP_RB2 4
 #endif
 
+// Winograd kernels: accumulator registers per lane that go through the output transform + stores (16; 1 = timing-only
+// variant that shows what the epilogue costs)
+#ifndef RTPOSE_EXP_W_EPI
+#define RTPOSE_EXP_W_EPI 16
+#endif
 // F(4,7) kernel: weight prefetch distance in (ky, frequency pair) steps (<= 4: 5 register sets; 2: +5 %, 3: +0.7 %)
 #ifndef RTPOSE_EXP_W7_PF
 #define RTPOSE_EXP_W7_PF 4

@@ -270,64 +270,71 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   }
 
   // ---- epilogue: output transform A^T M A, (+ReLU) (+2x2 max-pool), masked stores -----------------
-  // accumulator register r of a lane = wtile row (r / 4) * 8 + 4 kh + r % 4 of the wave tile, column l31
-  const bool col_ok = ncol < g.cout;
-  float* out_base = g.out + g.out_choff + ncol;
-  int sn, sy, sx;
+  // accumulator register r of a lane = wtile row (r / 4) * 8 + 4 kh + r % 4 of the wave tile, column l31.
+  // Stores are raw buffer stores relative to the tile's first output pixel: 32-bit offsets (one multiply per
+  // wtile instead of 64-bit address arithmetic per store), the +1 pixel / +1 row neighbours through the scalar
+  // offset, and a lane that must not store gets an out-of-range offset instead of a branch around the store
+  // (the epilogue was 12 % of the kernel: 350 address instructions and 280 branch instructions per tile).
   {
-    const int t = mt * NT + wm * 32 + 4 * kh;
-    sn = t / TT;
-    const int r = t - sn * TT;
-    sy = r / A.TX;
-    sx = r - sy * A.TX;
-  }
-  int tcur = mt * NT + wm * 32 + 4 * kh;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float s[4][2];
-#pragma unroll
-    for (int fy = 0; fy < 4; ++fy) {
-      s[fy][0] = acc[fy * 4 + 0][r] + acc[fy * 4 + 1][r] + acc[fy * 4 + 2][r];
-      s[fy][1] = acc[fy * 4 + 1][r] - acc[fy * 4 + 2][r] - acc[fy * 4 + 3][r];
+    const bool col_ok = ncol < g.cout;
+    const int sc = A.pool ? 1 : 2;  // output pixels per wtile and direction
+    auto wt_q = [&](int n, int ty, int tx) -> int { return (n * g.out_hs + sc * ty) * g.out_ws + sc * tx; };
+    int q0;                          // uniform: first wtile of the block's tile
+    {
+      const int t = min(mt * NT, A.T - 1);
+      const int n = t / TT, r = t - n * TT;
+      const int ty = r / A.TX;
+      q0 = wt_q(n, ty, r - ty * A.TX);
     }
-    float y[2][2];
+    const i32x4 rout = make_rsrc(g.out + ((size_t)g.out_lead + (size_t)q0) * g.out_cstride + g.out_choff);
+    const unsigned cs4 = (unsigned)g.out_cstride * 4, row4 = (unsigned)g.out_ws * cs4;
+    const unsigned col4 = (unsigned)ncol * 4;
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      y[0][x] = s[0][x] + s[1][x] + s[2][x];
-      y[1][x] = s[1][x] - s[2][x] - s[3][x];
-    }
-    if (A.relu) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) y[i >> 1][i & 1] = fmaxf(y[i >> 1][i & 1], 0.f);
-    }
-    const bool ok = col_ok && tcur < A.T;
-    if (A.pool) {  // H and W even: every wtile is one pooled pixel
-      const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
-      if (ok) {
-        const size_t q = (size_t)g.out_lead + (size_t)(sn * g.out_hs + sy) * g.out_ws + sx;
-        out_base[q * g.out_cstride] = v;
+    for (int rg = 0; rg < RTPOSE_EXP_W_EPI / 4; ++rg) {
+      // 4 consecutive wtiles: one division pair, then +1 steps with a branch-free wrap
+      int tcur = mt * NT + wm * 32 + rg * 8 + 4 * kh;
+      int sn = tcur / TT, sy, sx;
+      {
+        const int r = tcur - sn * TT;
+        sy = r / A.TX;
+        sx = r - sy * A.TX;
       }
-    } else {
-      const size_t q = (size_t)g.out_lead + (size_t)(sn * g.out_hs + 2 * sy) * g.out_ws + 2 * sx;
-      const bool x1 = 2 * sx + 1 < A.W, y1 = 2 * sy + 1 < A.H;
-      if (ok) {
-        out_base[q * g.out_cstride] = y[0][0];
-        if (x1) out_base[(q + 1) * g.out_cstride] = y[0][1];
-        if (y1) {
-          out_base[(q + g.out_ws) * g.out_cstride] = y[1][0];
-          if (x1) out_base[(q + g.out_ws + 1) * g.out_cstride] = y[1][1];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = rg * 4 + rr;
+        float s[4][2];
+#pragma unroll
+        for (int fy = 0; fy < 4; ++fy) {
+          s[fy][0] = acc[fy * 4 + 0][r] + acc[fy * 4 + 1][r] + acc[fy * 4 + 2][r];
+          s[fy][1] = acc[fy * 4 + 1][r] - acc[fy * 4 + 2][r] - acc[fy * 4 + 3][r];
         }
-      }
-    }
-    // next row: +1, +1, +1, +5 wtiles
-    const int d = (r & 3) == 3 ? 5 : 1;
-    tcur += d;
-    sx += d;
-    while (sx >= A.TX) {
-      sx -= A.TX;
-      if (++sy >= A.TY) {
-        sy = 0;
-        ++sn;
+        float y[2][2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          y[0][x] = s[0][x] + s[1][x] + s[2][x];
+          y[1][x] = s[1][x] - s[2][x] - s[3][x];
+        }
+        if (A.relu) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[i >> 1][i & 1] = fmaxf(y[i >> 1][i & 1], 0.f);
+        }
+        const bool ok = col_ok && tcur < A.T;
+        const unsigned off = (unsigned)(wt_q(sn, sy, sx) - q0) * cs4 + col4;
+        if (A.pool) {  // H and W even: every wtile is one pooled pixel
+          const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+          bstore(v, rout, ok ? off : kNoStore, 0);
+        } else {
+          const bool x1 = 2 * sx + 1 < A.W, y1 = 2 * sy + 1 < A.H;
+          bstore(y[0][0], rout, ok ? off : kNoStore, 0);
+          bstore(y[0][1], rout, (ok && x1) ? off : kNoStore, cs4);
+          bstore(y[1][0], rout, (ok && y1) ? off : kNoStore, row4);
+          bstore(y[1][1], rout, (ok && x1 && y1) ? off : kNoStore, row4 + cs4);
+        }
+        ++tcur;  // next wtile of the group
+        const bool wx = sx + 1 >= A.TX, wy = wx && sy + 1 >= A.TY;
+        sx = wx ? 0 : sx + 1;
+        sy = wy ? 0 : (wx ? sy + 1 : sy);
+        sn += wy ? 1 : 0;
       }
     }
   }

@@ -391,7 +391,7 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
     sx = r - sy * GX;
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+  for (int r = 0; r < RTPOSE_EXP_W_EPI; ++r) {
     float S[NP], D[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {

@@ -49,6 +49,14 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* p) {
   u.s.cfg = 0x00020000;    // raw buffer, 32-bit data format
   return u.v;
 }
+__device__ void llvm_raw_buffer_store_f32(float v, i32x4 rsrc, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.raw.buffer.store.f32");
+// one dword per lane; a lane whose voff is >= the descriptor's range (kNoStore) stores nothing: masked stores
+// without a branch around them
+constexpr unsigned kNoStore = 0x7fffffffu;
+__device__ __forceinline__ void bstore(float v, i32x4 r, unsigned voff, unsigned soff) {
+  llvm_raw_buffer_store_f32(v, r, (int)voff, (int)soff, 0);
+}
 __device__ __forceinline__ F4 bload(i32x4 r, unsigned voff, unsigned soff) {
   const f32x4 v = llvm_raw_buffer_load_v4f32(r, (int)voff, (int)soff, 0);
   return F4{f2{v.x, v.y}, f2{v.z, v.w}};
