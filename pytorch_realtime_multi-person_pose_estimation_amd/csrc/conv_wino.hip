@@ -18,14 +18,17 @@
 //    the accumulator of frequency (1,1) (A^T e11 A = all-ones).
 //  * A block = 4 waves = (32 WM) consecutive wtiles of the flattened (n, ty, tx) order x (32 WN) output
 //    columns; no 2-D tile waste on the 46 x 46 maps (23 x 23 wtiles).
-//  * Input transform: every thread loads HALF a 4 x 4 patch of 4 channels (3 rows x 4 pixels, 16-byte
-//    loads straight from the shared-gap NHWC layout: the zero gap is the conv padding), forms 8
-//    frequencies with 16 float4 adds and writes them to LDS as V[f][c/4][wtile][4] - the layout the A
-//    operand is read from with one conflict-free ds_read_b128 per 4 MFMAs.  Double-buffered per
-//    channel chunk: the patch of chunk c+2 is in flight and chunk c+1 is transformed while chunk c is
+//  * Input transform: every thread loads HALF a 4 x 4 patch of 4 channels (3 rows x 4 pixels, 16-byte raw
+//    buffer loads straight from the shared-gap NHWC layout: the zero gap is the conv padding), forms 8
+//    frequencies in two groups of 16 packed instructions (fp32 VALU work is paid for in matrix throughput,
+//    DESIGN.md §3.0) and writes them to LDS as V[f][c/4][wtile][4], wtile slots rotated per channel group against
+//    bank conflicts - the layout the A operand is read from with one ds_read_b128 per 4 MFMAs.  Double-buffered
+//    per channel chunk: the patch of chunk c+2 is in flight and chunk c+1 is transformed while chunk c is
 //    multiplied; one barrier per chunk.
 //  * B operand = transformed weights U[chunk][f][c/4][cout][4], packed once
-//    (rtpose_pack_conv_weights_winograd), straight from L2 to registers two frequencies ahead.
+//    (rtpose_pack_conv_weights_winograd), straight from L2 to registers two steps (4 frequencies) ahead.
+//  * With more tiles than CUs the blocks are persistent: one (n tile, group) per block, every
+//    (256 / ncombo)-th m tile in turn, the next tile's first patches requested before the output transform.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>

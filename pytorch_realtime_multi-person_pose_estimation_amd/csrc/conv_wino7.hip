@@ -1,31 +1,35 @@
-// fp32 7x7 convolution in 1-D Winograd form F(4, 7) along x, direct along y, for gfx950 (MI355X):
-// stride 1, "same" padding, fused bias (+ReLU).
+// fp32 7x7 convolution in 1-D Winograd form F(FM, 7) along x (FM = 6; 4 behind RTPOSE_WINOGRAD7_M=4), direct along y,
+// for gfx950 (MI355X): stride 1, "same" padding, fused bias (+ReLU).
 //
 // Stands in for the 7x7 nn.Conv2d + nn.ReLU modules of the refinement stages 2..6
 // (lib/network/rtpose_vgg.py:108-127: Mconv1..5_stageN_L1/L2, cin 185 or 128 -> 128), which are 65 % of
-// the network's flops.  Along x every group of 4 consecutive outputs is computed from 10 "frequencies"
-// (Toom-Cook interpolation points 0, +-1, +-2, +-1/2, +-3/2, inf):
+// the network's flops.  Along x every group of FM consecutive outputs is computed from NFQ = FM + 6 "frequencies"
+// (Toom-Cook interpolation points 0, +-1, +-2, +-1/2, +-3/2 [, +-2/3], inf; struct WT below):
 //
-//   out[y][4 gx + i][o] = sum_f AT[i][f] * sum_ky sum_c  V[y + ky - 3][gx][f][c] * U[ky][f][c][o]
-//   V[r][gx][f][c] = sum_n BT[f][n] * in[r][4 gx - 3 + n][c]         U[ky][f][c][o] = sum_kx G[f][kx] * w[o][c][ky][kx]
+//   out[y][FM gx + i][o] = sum_f AT[i][f] * sum_ky sum_c  V[y + ky - 3][gx][f][c] * U[ky][f][c][o]
+//   V[r][gx][f][c] = sum_n BT[f][n] * in[r][FM gx - 3 + n][c]        U[ky][f][c][o] = sum_kx G[f][kx] * w[o][c][ky][kx]
 //
-// i.e. 70 multiplies per 4 outputs and input channel instead of 196 (2.8x fewer matrix-core flops).
-// Measured against the fp64 sum the fp32 result is ~2e-5 off where the direct fp32 sum is ~1e-6 off
-// (output magnitude ~4); through the whole network the stage outputs move by < 1e-5 (contract: 1e-3).
+// i.e. 7 NFQ multiplies per FM outputs and input channel instead of 49 FM: 3.5x fewer matrix-core flops for F(6,7)
+// (84 per 6 outputs), 2.8x for F(4,7).  Through the whole network the stage outputs move by 1.5e-5 (F(6,7)) resp.
+// 1e-5 (F(4,7)) against the direct sum (contract: 1e-3); F(8,7) would be 1e-4 and is not offered.
 //
-// MI355X shape:
-//  * "position" = one group of 4 output pixels.  A wave owns all 10 frequencies of 32 consecutive
-//    positions (flattened (n, y, gx) order) x 32 output columns = 10 v_mfma_f32_32x32x2_f32
-//    accumulators (160 AGPRs, one wave per SIMD); the output transform AT is lane-local and the bias
-//    rides in the accumulator of the point p = 1 (its AT column is all ones).  A block = 4 waves =
-//    32 positions x 128 columns.
-//  * V lives in LDS per 8-channel chunk as [padded row][f][c/4][gx][4 floats]: one transformed input row
-//    serves the 7 output rows around it, the A fragment of (ky, f) is one ds_read_b128 per lane at
-//    (row(lane) + ky, f, gx(lane)).  Double-buffered: the 10-pixel input segments of chunk c+2 are in
-//    flight and chunk c+1 is transformed (VALU, in the shadow of the MFMAs) while chunk c is multiplied;
-//    one barrier per chunk (280 MFMAs per wave).
-//  * B = transformed filters, packed [chunk][ky][f][c/4][cout][4] by rtpose_pack_conv_weights_winograd,
-//    straight from L2 to registers three frequency pairs ahead.
+// MI355X shape (DESIGN.md §3.0):
+//  * "position" = one group of FM output pixels.  A wave owns all NFQ frequencies of 32 consecutive positions x 32
+//    output columns = NFQ v_mfma_f32_32x32x2_f32 accumulators (192 AGPRs, one wave per SIMD); the output transform
+//    AT is lane-local and the bias rides in the accumulator of the point p = 1 (its AT column is all ones).
+//    A block = 4 waves = 32 positions x 128 columns (wino7_f32), or - small grids - 32 positions x 32 columns with
+//    the four waves splitting the frequencies (wino7s_f32); both sum in the same order: bit-identical results.
+//  * V lives in LDS per 8-channel chunk as [padded row][f][c/4][gx][4 floats]: one transformed input row serves
+//    the 7 output rows around it, the A fragment of (ky, f) is one ds_read_b128 per lane at
+//    (row(lane) + ky, f, gx(lane)).  Double-buffered: the input segments of chunk c+2 are in flight and chunk c+1 is
+//    transformed while chunk c is multiplied; one barrier per chunk (336 MFMAs per wave).
+//  * fp32 VALU instructions run on the ALUs the fp32 MFMAs use, so the multiply loop has no vector address
+//    arithmetic (raw buffer loads: fixed per-lane offset + scalar offset; LDS offsets are immediates where the
+//    row geometry is a template parameter) and the transform is packed (float2) and issued in few full groups.
+//  * B = transformed filters, packed [chunk][ky][f][c/4][cout][4] by rtpose_pack_conv_weights_winograd, straight
+//    from L2 to registers up to four (ky, frequency pair) steps ahead.
+//  * Launches with >= 256 tiles that are not whole rounds run as persistent blocks sharing (tile, chunk) units; a
+//    split tile is continued by the next block from the saved sums (same summation order, wino7_segment).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
