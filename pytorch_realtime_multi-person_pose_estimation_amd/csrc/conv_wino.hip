@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   constexpr int CG = CK / 4;   // 16-byte channel groups per chunk
   constexpr int G = CK / 8;    // 8-deep k groups per chunk (4 MFMAs each)
   static_assert(WM * WN == 4, "4 waves");
-  static_assert(NT * CG * 2 == 256, "one half patch per thread and chunk");
+  constexpr int IPT = NT * CG * 2 / 256;  // half patches per thread and chunk: 1, or 2 = one whole 4 x 4 patch
+  static_assert(NT * CG * 2 == 256 * IPT && (IPT == 1 || IPT == 2), "half patches per thread");
   constexpr int VBUF = 16 * CG * NT;  // float4 per V buffer
   extern __shared__ __attribute__((aligned(16))) float4 V4[];
 
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   //   upper half (waves 0,1): (d0, d1, d2), sgn +1 -> fy 0, 1;   lower half (waves 2,3): (d2, d3, d1), sgn -1 -> fy 2, 3
   // - the same instruction stream for both halves, no branch inside the pinned MFMA loop.
   const int cg = tid % CG, tl = (tid / CG) % NT;
-  const int half = __builtin_amdgcn_readfirstlane(tid / (CG * NT));
+  const int half = IPT == 2 ? 0 : __builtin_amdgcn_readfirstlane(tid / (CG * NT));  // (IPT 2: both halves, natural rows)
   const float sgn = half ? -1.f : 1.f;
   // every global operand comes through a raw buffer load: per-lane byte offset in ONE register for the whole
   // kernel, everything that moves (chunk, patch row / column, frequency) in the scalar offset
@@ -132,14 +133,15 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
     pvoff = (unsigned)(((q - q0) * g.in_cstride + cg * 4) * 4);
   };
   set_loader(j0);
-  unsigned psoff[3];  // uniform byte offsets of this half's three patch rows
+  constexpr int NROW = IPT == 2 ? 4 : 3, NPC = 4 * NROW;  // patch rows / 16-byte pieces a thread loads per chunk
+  unsigned psoff[NROW];  // uniform byte offsets of the patch rows (of this half)
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
+  for (int r = 0; r < NROW; ++r) {
     const int row = half ? (r == 0 ? 2 : r == 1 ? 3 : 1) : r;
     psoff[r] = (unsigned)(row * g.in_ws * g.in_cstride * 4);
   }
   const unsigned pxb = (unsigned)g.in_cstride * 4;  // bytes per pixel
-  F4 p[3][4], ta[4], tb[4];
+  F4 p[NROW][4], ta[4], tb[4];
   auto load_piece = [&](int chunk, int i) {
     p[i >> 2][i & 3] = bload(rin, pvoff, (unsigned)chunk * (CK * 4) + psoff[i >> 2] + (i & 3) * pxb);
   };
@@ -149,16 +151,23 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   //  banks: SQ_LDS_BANK_CONFLICT was 7 % of the kernel's cycles)
   constexpr int SW = 16 / CG;
   const int vst = (half * 8 * CG + cg) * NT + ((tl + SW * cg) % NT);
-  // transform in two groups of 16 packed VALU instructions (few, full groups: see wino_common.h)
+  // transform in 2 IPT groups of 16 packed VALU instructions (few, full groups: see wino_common.h): rows, then
+  // columns + LDS writes; with a whole patch (IPT 2) first for fy 0, 1 and then for fy 2, 3
   auto tgroup = [&](int buf, int gidx) {
-    if (gidx == 0) {
+    const int hh = gidx >> 1;  // which half of the frequencies (IPT 2 only)
+    if ((gidx & 1) == 0) {
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
-        ta[x] = sub4(p[0][x], p[2][x]);
-        tb[x] = fma4(sgn, p[1][x], p[2][x]);
+        if (IPT == 2 && hh) {  // fy 2: d2 - d1, fy 3: d1 - d3
+          ta[x] = sub4(p[2][x], p[1][x]);
+          tb[x] = sub4(p[1][x], p[NROW - 1][x]);
+        } else {               // fy 0: d0 - d2, fy 1: d1 + d2   (half patches: the permuted rows and sgn do both)
+          ta[x] = sub4(p[0][x], p[2][x]);
+          tb[x] = fma4(sgn, p[1][x], p[2][x]);
+        }
       }
     } else {
-      float4* v = V4 + buf * VBUF + vst;
+      float4* v = V4 + buf * VBUF + vst + hh * 8 * CG * NT;
 #pragma unroll
       for (int o = 0; o < 8; ++o) {
         const F4* t = (o & 4) ? tb : ta;
@@ -183,19 +192,19 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
 
   const int nchunks = A.cin / CK;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) load_piece(0, i);  // chunk 0 of the first tile
+  for (int i = 0; i < NPC; ++i) load_piece(0, i);  // chunk 0 of the first tile
 
   for (int mt = j0; mt < A.mtiles; mt += jstep) {
 #pragma unroll
   for (int f = 0; f < 16; ++f)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[f][r] = f == 5 ? bias0 : 0.f;
-  tgroup(0, 0);
-  tgroup(0, 1);
+#pragma unroll
+  for (int gq = 0; gq < 2 * IPT; ++gq) tgroup(0, gq);
   {
     const int c1 = min(1, nchunks - 1);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) load_piece(c1, i);
+    for (int i = 0; i < NPC; ++i) load_piece(c1, i);
   }
   // (B after the patch loads, as in the steady state of the loop: see conv_wino7.hip)
   wso = 0;
@@ -253,12 +262,19 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
               RTPOSE_EXP_B(bload_f4(rw, boff, wso + ((i / G) * CG + 2 * (i % G)) * cgstep), bs[s & 3][i / G][i % G]);
           if (slot == SLOTS - 1) wso += bstep;
         }
-        if (RTPOSE_EXP_STAGE && slot == SLOTS - 1) {
-          if (s < 2) {
-            tgroup(nbuf, s);
-          } else {
-            load_piece(c2, 2 * (s - 2));
-            load_piece(c2, 2 * (s - 2) + 1);
+        if (RTPOSE_EXP_STAGE) {
+          if (IPT == 1) {  // groups in the last slots of steps 0, 1; two patch loads in the last slot of steps 2..7
+            if (slot == SLOTS - 1) {
+              if (s < 2) {
+                tgroup(nbuf, s);
+              } else {
+                load_piece(c2, 2 * (s - 2));
+                load_piece(c2, 2 * (s - 2) + 1);
+              }
+            }
+          } else {         // 4 groups in the middle and last slots of steps 0, 1; 16 loads in the B slots of steps 2..5
+            if (s < 2 && (slot == SLOTS / 2 - 1 || slot == SLOTS - 1)) tgroup(nbuf, 2 * s + (slot == SLOTS - 1));
+            if (s >= 2 && s < 6 && slot >= SLOTS - 4) load_piece(c2, 4 * (s - 2) + slot - (SLOTS - 4));
           }
         }
         RTPOSE_PIN();
@@ -269,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   if (mt + jstep < A.mtiles) {  // chunk 0 of the next tile: in flight during the output transform below
     set_loader(mt + jstep);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) load_piece(0, i);
+    for (int i = 0; i < NPC; ++i) load_piece(0, i);
   }
 
   // ---- epilogue: output transform A^T M A, (+ReLU) (+2x2 max-pool), masked stores -----------------
@@ -402,16 +418,17 @@ static int launch_inst(const Args& a, dim3 grid, hipStream_t s) {
 
 // channel chunk the packed Winograd weights of a conv are laid out for (the kernel instance is chosen by
 // the padded output width: >= 128 columns -> 32 wtiles x 128 columns, 16-channel chunks; 64 -> 64 x 64, 8)
-static int wino_ck(int cout) { return cout_pad(cout) % 128 == 0 ? 16 : 8; }
+// channel chunk of a conv: 16, or 8 where the input has only a multiple of 8 channels and the block is the 64 x 64 one
+static int wino_ck(int cout, int cin) { return (cout_pad(cout) % 128 == 0 || cin % 16 == 0) ? 16 : 8; }
 
-int conv2d_wino_ok(int cin, int cout, int k) { return k == 3 && cin > 0 && cin % wino_ck(cout) == 0; }
+int conv2d_wino_ok(int cin, int cout, int k) { return k == 3 && cin > 0 && cin % wino_ck(cout, cin) == 0; }
 
 int conv2d_wino_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s) {
   using namespace wino;
   if (!d || ngroups < 1 || ngroups > 2) return fail(RTPOSE_E_INVAL, "conv2d_winograd: ngroups must be 1 or 2");
   const rtpose_conv_desc& d0 = d[0];
   if (!conv2d_wino_ok(d0.cin, d0.cout, d0.k))
-    return fail(RTPOSE_E_INVAL, "conv2d_winograd: k must be 3 and cin a multiple of %d", wino_ck(d0.cout));
+    return fail(RTPOSE_E_INVAL, "conv2d_winograd: k must be 3 and cin a multiple of %d", wino_ck(d0.cout, d0.cin));
   if (N <= 0 || H <= 0 || W <= 0) return fail(RTPOSE_E_INVAL, "conv2d_winograd: empty tensor");
   if (d0.pool && ((H | W) & 1)) return fail(RTPOSE_E_INVAL, "conv2d_winograd: fused pool needs even H and W");
   Args a;
@@ -457,8 +474,8 @@ int conv2d_wino_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
   a.cin = d0.cin;
   a.relu = d0.relu;
   a.pool = d0.pool;
-  const int ck = wino_ck(d0.cout);
-  const int wm = ck == 16 ? 1 : 2, wn = 4 / wm;
+  const int ck = wino_ck(d0.cout, d0.cin);
+  const int wm = cout_pad(d0.cout) % 128 == 0 ? 1 : 2, wn = 4 / wm;
   a.mtiles = ceil_div(a.T, 32 * wm);
   a.ntiles = cout_pad(d0.cout) / (32 * wn);
   a.ncombo = a.ntiles * ngroups;
@@ -479,20 +496,22 @@ int conv2d_wino_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
     }
   }
   const dim3 grid((unsigned)ids, 1, 1);
-  if (ck == 16) return launch_inst<1, 4, 16>(a, grid, s);
+  if (wm == 1) return launch_inst<1, 4, 16>(a, grid, s);
+  // 64 columns (conv1_2): 64 wtiles x 64 columns; 16-channel chunks with a whole patch per thread where cin allows
+  if (ck == 16) return launch_inst<2, 2, 16>(a, grid, s);
   return launch_inst<2, 2, 8>(a, grid, s);
 }
 
 int pack_weights_wino_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map,
                              int cin_packed, float* wp, float* bp, hipStream_t s) {
   if (!conv2d_wino_ok(cin_packed, cout, 3) || (cin_packed < cin_src && !cin_map))
-    return fail(RTPOSE_E_INVAL, "pack_winograd: cin_packed must be a multiple of %d and >= cin_src", wino_ck(cout));
+    return fail(RTPOSE_E_INVAL, "pack_winograd: cin_packed must be a multiple of %d and >= cin_src", wino_ck(cout, cin_packed));
   const int coutp = cout_pad(cout);
   const size_t total = (size_t)16 * cin_packed * coutp;
   const int threads = 256;
   const unsigned blocks = (unsigned)((total + threads - 1) / threads);
   hipLaunchKernelGGL(wino::pack_wino_kernel, dim3(blocks), dim3(threads), 0, s, w, bias, cout, cin_src, cin_map,
-                     cin_packed, wino_ck(cout), coutp, wp, bp);
+                     cin_packed, wino_ck(cout, cin_packed), coutp, wp, bp);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }
