@@ -559,10 +559,13 @@ __global__ __launch_bounds__(256, 1) void wino7s_f32(const Args A) {
   const unsigned boff = (unsigned)((kh * g.cout_pad + ncol) * 16);
   const unsigned fstep = (unsigned)(CG * g.cout_pad * 16);  // bytes per frequency block
   const unsigned kstep = (unsigned)NFQ * fstep;             // bytes per ky
+  const int nchunks = A.cin / CK;
   unsigned wso = (unsigned)(wv * FW) * fstep;               // this wave's frequencies of the next ky to fetch
+  // (the prefetch runs PF whole ky steps = 3 x 12 frequency blocks ahead - more than the slack behind the packed
+  //  filters: past the last step it re-reads the last one)
+  const unsigned wso_max = wso + (unsigned)(nchunks * 7 - 1) * kstep;
   float4 bs[NSETS][FW];
 
-  const int nchunks = A.cin / CK;
 #pragma unroll
   for (int k = 0; k < NI; ++k)
 #pragma unroll
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(256, 1) void wino7s_f32(const Args A) {
   for (int s = 0; s < PF; ++s) {
 #pragma unroll
     for (int f = 0; f < FW; ++f) bs[s][f] = bload_f4(rw, boff, wso + f * fstep);
-    wso += kstep;
+    wso = min(wso + kstep, wso_max);
   }
   __syncthreads();
 
@@ -619,7 +622,7 @@ __global__ __launch_bounds__(256, 1) void wino7s_f32(const Args A) {
         } else if (j == 1) {
 #pragma unroll
           for (int f = 0; f < FW; ++f) bs[(ky + PF) % NSETS][f] = bload_f4(rw, boff, wso + f * fstep);
-          wso += kstep;
+          wso = min(wso + kstep, wso_max);
         } else {  // j = 2, 3: steps 0..3 the transform groups of the next chunk (they read the segment registers),
                   // steps 4..6 - only then - the segment loads of the chunk after that (they overwrite them)
           const int slot = 2 * ky + (j - 2);  // 0 .. 13

@@ -13,7 +13,7 @@ TOL = 1e-4  # relative to max|ref|; fp32 fma-chain vs ATen summation order
 
 
 def _run_conv(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, seed, groups=1, cin_pad=None,
-              winograd=False, only_images=None):
+              winograd=False, only_images=None, skip_ref=False):
     lib, Layout = capi.lib, capi.Layout
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -24,11 +24,13 @@ def _run_conv(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, see
     for gi in range(groups):
         wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
         b = torch.randn(cout, generator=g) * 0.1
-        y = F.conv2d(x[:n], wt, b, padding=k // 2)
-        if relu:
-            y = F.relu(y)
-        if pool:
-            y = F.max_pool2d(y, 2, 2, 0)
+        y = None
+        if not skip_ref:   # (the CPU reference is the slow part of a case)
+            y = F.conv2d(x[:n], wt, b, padding=k // 2)
+            if relu:
+                y = F.relu(y)
+            if pool:
+                y = F.max_pool2d(y, 2, 2, 0)
         ws.append(wt.to(dev))
         bs.append(b.to(dev))
         refs.append(y)
@@ -209,6 +211,41 @@ def test_winograd_rejects_what_it_cannot_do(capi, cuda):
     d[0].k, d[0].cin, d[0].cout = 5, 16, 128
     assert lib.rtpose_conv2d_winograd(d, 1, 1, 8, 8, None) != 0
     assert "k must be 3" in capi.last_error()
+
+
+def test_winograd_random_geometries_match_direct(capi, cuda):
+    """Both Winograd kernels against the direct kernel (GPU vs GPU, same packed inputs) over random geometries:
+    odd / tiny / wide maps, every W modulo 6 and 2, strips crossing images, one and two branches, persistent and
+    small-grid launches of the 7x7 form."""
+    import random
+    rnd = random.Random(20260924)
+    lib = capi.lib
+    d = (capi.ConvDesc * 1)()
+    tried = 0
+    for _ in range(40):
+        k = rnd.choice((3, 7))
+        n = rnd.choice((1, 2, 3, 5, 14))
+        h, w = rnd.randint(3, 40), rnd.randint(3, 60)
+        cin = rnd.choice((16, 32, 48, 64)) if k == 3 else rnd.choice((8, 24, 64))
+        cout = rnd.choice((64, 128, 200)) if k == 3 else rnd.choice((128, 256))
+        groups = rnd.choice((1, 2))
+        relu = rnd.choice((0, 1))
+        pool = 1 if (k == 3 and h % 2 == 0 and w % 2 == 0 and rnd.random() < 0.3) else 0
+        pin = k // 2 + rnd.choice((0, 1))
+        d[0].k, d[0].cin, d[0].cout, d[0].pool = k, cin, cout, pool
+        d[0].lin = capi.Layout.padded(cin, h, w, pin)
+        if not lib.rtpose_conv2d_winograd_fits(d, n, h, w):
+            continue
+        tried += 1
+        seed = rnd.randint(0, 10 ** 6)
+        wino, _ = _run_conv(capi, cuda, n, h, w, cin, cout, k, relu, pool, pin, 1, seed=seed, groups=groups,
+                            winograd=True, skip_ref=True)
+        direct, _ = _run_conv(capi, cuda, n, h, w, cin, cout, k, relu, pool, pin, 1, seed=seed, groups=groups,
+                              skip_ref=True)
+        for a, b in zip(wino, direct):
+            err = (a - b).abs().max().item()
+            assert err <= 1e-4 * max(1.0, b.abs().max().item()), (k, n, h, w, cin, cout, groups, pool, err)
+    assert tried >= 25
 
 
 def test_conv_rejects_bad_geometry(capi, cuda):
