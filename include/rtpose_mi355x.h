@@ -122,9 +122,10 @@ int rtpose_conv2d(const rtpose_conv_desc* d, int ngroups, int N, int H, int W,
  * Same module boundary as rtpose_conv2d (nn.Conv2d + nn.ReLU (+ nn.MaxPool2d) of
  * lib/network/rtpose_vgg.py:23-35, :49-55, :108-127), fewer matrix-core multiplies:
  *   k = 3: F(2x2, 3x3), 16 instead of 36 multiplies per 2 x 2 outputs and input channel (2.25x);
- *   k = 7: F(4, 7) along x, direct along y: 70 instead of 196 per 4 outputs (2.8x), no fused pool.
+ *   k = 7: F(6, 7) along x, direct along y: 84 instead of 294 per 6 outputs (3.5x), no fused pool
+ *          (F(4, 7), 70 instead of 196 per 4 outputs, with RTPOSE_WINOGRAD7_M=4 in the environment of the process).
  * fp32 MFMA throughout; results differ from the direct sum by rounding only (k = 3: a few ulp,
- * k = 7: ~2e-5 at magnitude 4; whole network < 1e-5 on the stage outputs; contract 1e-3).
+ * k = 7: ~3e-5 at magnitude 4; whole network < 4e-5 on the stage outputs; contract 1e-3).
  * The descriptor is rtpose_conv_desc with `w_packed` from rtpose_pack_conv_weights_winograd
  * (transformed filters: 16/9 resp. 70/49 the size) and out_cmap = NULL.
  * rtpose_conv2d_winograd_fits: 1 when the conv described by `d` (k, cin, cout, pool, lin.hs) has a
