@@ -153,3 +153,50 @@ def test_net_oracle_reproduces_reference_golden(pkg):
     assert np.abs(heat.numpy() - z["heat"]).max() <= 1e-5
     for i in range(12):
         assert np.abs(saved[i].numpy() - z["saved%d" % i]).max() <= 1e-5
+
+
+def test_winograd_tables_of_the_kernels_are_the_toom_cook_construction():
+    """The input-transform tables hard-coded in csrc/conv_wino7.hip (struct WT<4>, WT<6>) equal the exact Toom-Cook
+    construction (oracle/winograd_tables.py) to fp32 rounding, and that construction reproduces a 7-tap correlation
+    exactly (rational arithmetic); the 3x3 kernel's F(2,3) matrices likewise."""
+    import re
+    from fractions import Fraction as Fr
+    from oracle import winograd_tables as wt
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "pytorch_realtime_multi-person_pose_estimation_amd", "csrc", "conv_wino7.hip")).read()
+    for m, pts in ((4, wt.POINTS_F4_7), (6, wt.POINTS_F6_7)):
+        n = m + 6
+        AT, G, BT = wt.toom_cook(m, 7, pts)
+        # exactness of the algorithm itself
+        d = [Fr(3 * i * i - 7 * i + 1, 5) for i in range(n)]
+        g = [Fr(2 * k - 5, 3) for k in range(7)]
+        U = [sum(G[f][k] * g[k] for k in range(7)) for f in range(n)]
+        V = [sum(BT[f][i] * d[i] for i in range(n)) for f in range(n)]
+        for i in range(m):
+            assert sum(AT[i][f] * U[f] * V[f] for f in range(n)) == sum(d[i + k] * g[k] for k in range(7))
+        # the table in the kernel source
+        blk = src[src.index("struct WT<%d> {" % m):]
+        blk = blk[blk.index("kBT[%d][%d] = {" % (n, n)):]
+        blk = blk[:blk.index("};")]
+        vals = [float(x) for x in re.findall(r"(-?\d+\.?\d*)f", blk.split("= {", 1)[1])]
+        assert len(vals) == n * n
+        for f in range(n):
+            for i in range(n):
+                assert abs(vals[f * n + i] - float(BT[f][i])) <= 1e-7 * max(1.0, abs(float(BT[f][i]))), (m, f, i)
+        # output transform used by the epilogue: AT[i][2p+1] = +p^i, AT[i][2p+2] = (-p)^i, bias column = point 1
+        assert all(AT[i][1] == 1 for i in range(m))
+    # F(2,3) as the 3x3 kernel uses it (csrc/conv_wino.hip: rows of B^T, G, A^T written out in the code): the same
+    # construction with rows rescaled by +-1 / 2; exact
+    BT = [[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]]
+    G = [[1, 0, 0], [Fr(1, 2), Fr(1, 2), Fr(1, 2)], [Fr(1, 2), Fr(-1, 2), Fr(1, 2)], [0, 0, 1]]
+    AT = [[1, 1, 1, 0], [0, 1, -1, -1]]
+    d = [Fr(7, 3), Fr(-2), Fr(5, 7), Fr(11, 2)]
+    g = [Fr(3, 4), Fr(-5, 3), Fr(2)]
+    for i in range(2):
+        assert sum(AT[i][f] * sum(G[f][k] * g[k] for k in range(3)) * sum(BT[f][j] * d[j] for j in range(4))
+                   for f in range(4)) == sum(d[i + k] * g[k] for k in range(3))
+    ATc, Gc, BTc = wt.toom_cook(2, 3, wt.POINTS_F2_3)
+    for f in range(4):   # row f of the construction = a multiple of the kernel's row (G / A^T carry the inverse factor)
+        nz = [j for j in range(4) if BT[f][j] != 0][0]
+        fac = BTc[f][nz] / BT[f][nz]
+        assert [x * fac for x in BT[f]] == BTc[f]
