@@ -361,6 +361,226 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
 #undef RTPOSE_PIN
 }
 
+// Small grids (few images): the same arithmetic on more blocks, as wino7s_f32 (conv_wino7.hip).  A block = 32 wtiles x
+// 32 columns; its four waves split the FREQUENCIES (wave w: fy = w, fx = 0..3) and exchange the accumulators through
+// LDS before the output transform.  Every frequency sum runs over the chunks, k groups and k pairs in the order of
+// wino_f32, the output transform is the same expression: bit-identical results, 4x (128-column blocks) or 2x
+// (64-column blocks) as many blocks.  16-channel chunks only.
+__global__ __launch_bounds__(256, 1) void wino3s_f32(const Args A) {
+  constexpr int NT = 32, CK = 16, CG = 4, G = 2, SW = 16 / CG;
+  constexpr int VBUF = 16 * CG * NT;  // float4 per V buffer
+  extern __shared__ __attribute__((aligned(16))) float4 V4[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int bi = blockIdx.x;
+  const int c = bi % A.ncombo, mt = bi / A.ncombo;
+  const int nt = c % A.ntiles, grp = c / A.ntiles;
+  const Group g = grp ? A.g[1] : A.g[0];
+  const int TT = A.TY * A.TX;
+
+  // ---- input transform role: half a 4 x 4 patch of 4 channels, exactly as wino_f32 (IPT = 1) ------------
+  const int cg = tid % CG, tl = (tid / CG) % NT;
+  const int half = __builtin_amdgcn_readfirstlane(tid / (CG * NT));
+  const float sgn = half ? -1.f : 1.f;
+  const i32x4 rw = make_rsrc(g.w);
+  i32x4 rin;
+  unsigned pvoff;
+  {
+    auto patch_q = [&](int t) -> size_t {
+      const int n = t / TT, r = t - n * TT;
+      const int ty = r / A.TX, tx = r - ty * A.TX;
+      return (size_t)g.in_lead + (size_t)(n * g.in_hs + 2 * ty - 1) * g.in_ws + (2 * tx - 1);
+    };
+    const size_t q0 = patch_q(min(mt * NT, A.T - 1));
+    const size_t q = patch_q(min(mt * NT + tl, A.T - 1));
+    rin = make_rsrc(g.in + q0 * g.in_cstride + g.in_choff);
+    pvoff = (unsigned)(((q - q0) * g.in_cstride + cg * 4) * 4);
+  }
+  unsigned psoff[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int row = half ? (r == 0 ? 2 : r == 1 ? 3 : 1) : r;
+    psoff[r] = (unsigned)(row * g.in_ws * g.in_cstride * 4);
+  }
+  const unsigned pxb = (unsigned)g.in_cstride * 4;
+  F4 p[3][4], ta[4], tb[4];
+  auto load_piece = [&](int chunk, int i) {
+    p[i >> 2][i & 3] = bload(rin, pvoff, (unsigned)chunk * (CK * 4) + psoff[i >> 2] + (i & 3) * pxb);
+  };
+  const int vst = (half * 8 * CG + cg) * NT + ((tl + SW * cg) % NT);
+  auto tgroup = [&](int buf, int gidx) {
+    if (gidx == 0) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        ta[x] = sub4(p[0][x], p[2][x]);
+        tb[x] = fma4(sgn, p[1][x], p[2][x]);
+      }
+    } else {
+      float4* v = V4 + buf * VBUF + vst;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        const F4* t = (o & 4) ? tb : ta;
+        const int fx = o & 3;
+        v[o * CG * NT] = to_float4(fx == 0 ? sub4(t[0], t[2]) : fx == 1 ? add4(t[1], t[2]) : fx == 2 ? sub4(t[2], t[1])
+                                                                                          : sub4(t[1], t[3]));
+      }
+    }
+  };
+
+  // ---- MFMA role: frequencies 4 wv .. 4 wv + 3 of the 32 x 32 tile ---------------------------------------
+  const int ncol = nt * 32 + l31;
+  floatx16 acc[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+  if (wv == 1) {  // the bias rides in frequency (1,1) = 5
+    const float b0 = g.bias[ncol];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[1][r] = b0;
+  }
+  const unsigned boff = (unsigned)((kh * g.cout_pad + ncol) * 16);
+  const unsigned cgstep = (unsigned)(g.cout_pad * 16);  // bytes per channel group plane
+  const unsigned fstep = (unsigned)CG * cgstep;         // bytes per frequency
+  const unsigned cstep = 16 * fstep;                    // bytes per chunk
+  const int nchunks = A.cin / CK;
+  float4 bcur[4][G], bnxt[4][G];
+  auto load_b = [&](float4 (&dst)[4][G], int chunk) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi)
+        dst[f][gi] = bload_f4(rw, boff, (unsigned)chunk * cstep + (unsigned)(4 * wv + f) * fstep + 2 * gi * cgstep);
+  };
+#pragma unroll
+  for (int i = 0; i < 12; ++i) load_piece(0, i);
+  tgroup(0, 0);
+  tgroup(0, 1);
+  {
+    const int c1 = min(1, nchunks - 1);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) load_piece(c1, i);
+  }
+  load_b(bcur, 0);
+  __syncthreads();
+
+#define RTPOSE_PIN()             \
+  asm volatile("" ::: "memory"); \
+  __builtin_amdgcn_sched_barrier(0)
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const float4* vab = V4 + (chunk & 1) * VBUF;
+    const int nbuf = (chunk + 1) & 1;
+    const int c2 = min(chunk + 2, nchunks - 1);
+    float4 a[4][G];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi)
+        a[f][gi] = vab[((4 * wv + f) * CG + 2 * gi + kh) * NT + ((wv * 0 + l31 + SW * (2 * gi + kh)) % NT)];
+    load_b(bnxt, min(chunk + 1, nchunks - 1));  // the next chunk's B fragments (the last chunk re-reads its own)
+    tgroup(nbuf, 0);
+    RTPOSE_PIN();
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const float4 av = a[f][gi], bv = bcur[f][gi];
+          const float avv[4] = {av.x, av.y, av.z, av.w}, bvv[4] = {bv.x, bv.y, bv.z, bv.w};
+          acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv[j], bvv[j], acc[f], 0, 0, 0);
+        }
+        RTPOSE_PIN();
+        if (gi == 0 && j == 1) tgroup(nbuf, 1);
+        if (gi == 1) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) load_piece(c2, 3 * j + q);
+        }
+        RTPOSE_PIN();
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi) bcur[f][gi] = bnxt[f][gi];
+    __syncthreads();
+  }
+#undef RTPOSE_PIN
+
+  // ---- exchange through LDS (the V buffers are free), then output transform + stores as in wino_f32 ------
+  float* E = reinterpret_cast<float*>(V4);  // E[f][r][lane]: 16 x 16 x 64 floats = the two V buffers
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) E[((4 * wv + f) * 16 + r) * 64 + lane] = acc[f][r];
+  __syncthreads();
+  {
+    const bool col_ok = ncol < g.cout;
+    const int sc = A.pool ? 1 : 2;
+    auto wt_q = [&](int n, int ty, int tx) -> int { return (n * g.out_hs + sc * ty) * g.out_ws + sc * tx; };
+    int q0;
+    {
+      const int t = min(mt * NT, A.T - 1);
+      const int n = t / TT, r = t - n * TT;
+      const int ty = r / A.TX;
+      q0 = wt_q(n, ty, r - ty * A.TX);
+    }
+    const i32x4 rout = make_rsrc(g.out + ((size_t)g.out_lead + (size_t)q0) * g.out_cstride + g.out_choff);
+    const unsigned cs4 = (unsigned)g.out_cstride * 4, row4 = (unsigned)g.out_ws * cs4;
+    const unsigned col4 = (unsigned)ncol * 4;
+    // wave wv stores accumulator registers 4 wv .. 4 wv + 3 = wtiles 8 wv + 4 kh + (0..3) of the tile
+    int tcur = mt * NT + 8 * wv + 4 * kh;
+    int sn = tcur / TT, sy, sx;
+    {
+      const int r = tcur - sn * TT;
+      sy = r / A.TX;
+      sx = r - sy * A.TX;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = 4 * wv + rr;
+      float m[16];
+#pragma unroll
+      for (int f = 0; f < 16; ++f) m[f] = E[(f * 16 + r) * 64 + lane];
+      float s[4][2];
+#pragma unroll
+      for (int fy = 0; fy < 4; ++fy) {
+        s[fy][0] = m[fy * 4 + 0] + m[fy * 4 + 1] + m[fy * 4 + 2];
+        s[fy][1] = m[fy * 4 + 1] - m[fy * 4 + 2] - m[fy * 4 + 3];
+      }
+      float y[2][2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        y[0][x] = s[0][x] + s[1][x] + s[2][x];
+        y[1][x] = s[1][x] - s[2][x] - s[3][x];
+      }
+      if (A.relu) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i >> 1][i & 1] = fmaxf(y[i >> 1][i & 1], 0.f);
+      }
+      const bool ok = col_ok && tcur < A.T;
+      const unsigned off = (unsigned)(wt_q(sn, sy, sx) - q0) * cs4 + col4;
+      if (A.pool) {
+        const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+        bstore(v, rout, ok ? off : kNoStore, 0);
+      } else {
+        const bool x1 = 2 * sx + 1 < A.W, y1 = 2 * sy + 1 < A.H;
+        bstore(y[0][0], rout, ok ? off : kNoStore, 0);
+        bstore(y[0][1], rout, (ok && x1) ? off : kNoStore, cs4);
+        bstore(y[1][0], rout, (ok && y1) ? off : kNoStore, row4);
+        bstore(y[1][1], rout, (ok && x1 && y1) ? off : kNoStore, row4 + cs4);
+      }
+      ++tcur;
+      const bool wx = sx + 1 >= A.TX, wy = wx && sy + 1 >= A.TY;
+      sx = wx ? 0 : sx + 1;
+      sy = wy ? 0 : (wx ? sy + 1 : sy);
+      sn += wy ? 1 : 0;
+    }
+  }
+}
+
 // ---- weight packing: U = G g G^T, packed[chunk][f][cg][cout_pad][4]  <-  w[cout][cin_src][3][3] -----------
 __global__ void pack_wino_kernel(const float* __restrict__ w, const float* __restrict__ bias, int cout,
                                  int cin_src, const int32_t* __restrict__ cin_map, int cin_packed, int ck,
@@ -496,6 +716,24 @@ int conv2d_wino_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
     }
   }
   const dim3 grid((unsigned)ids, 1, 1);
+  if (ck == 16 && !a.persist && (long)a.mtiles * a.ncombo * 2 <= device_cu_count()) {
+    // small grids: the frequency-split form (wino3s_f32), bit-identical, 32 x 32 tiles
+    Args b = a;
+    b.mtiles = ceil_div(a.T, 32);
+    b.ntiles = cout_pad(d0.cout) / 32;
+    b.ncombo = b.ntiles * ngroups;
+    static PerDeviceOnce attr_set;
+    const int dev = current_device();
+    if (!attr_set.is_set(dev)) {
+      RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino3s_f32),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr_set.set(dev);
+    }
+    hipLaunchKernelGGL(wino3s_f32, dim3((unsigned)((long)b.mtiles * b.ncombo)), dim3(256),
+                       (size_t)2 * 16 * 4 * 32 * 16, s, b);
+    RTPOSE_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   if (wm == 1) return launch_inst<1, 4, 16>(a, grid, s);
   // 64 columns (conv1_2): 64 wtiles x 64 columns; 16-channel chunks with a whole patch per thread where cin allows
   if (ck == 16) return launch_inst<2, 2, 16>(a, grid, s);

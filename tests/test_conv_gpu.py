@@ -164,6 +164,20 @@ def test_winograd7_persistent_blocks_split_tiles(capi, cuda):
         assert torch.equal(o[:3], sm)
 
 
+def test_winograd3_small_grid_form_is_bit_identical(capi, cuda):
+    """3x3, 9 x 46 x 46, 256 -> 512: 152 m tiles x 4 n tiles run as whole 32 x 128 tiles (wino_f32); the first image
+    alone is a small grid and runs in the frequency-split form (wino3s_f32, 32 x 32 tiles): same bits.  Also the
+    64-column block (conv1_2-like, pooled) against its small-grid form."""
+    big, refs = _run_conv(capi, cuda, 9, 46, 46, 256, 512, 3, 1, 0, 1, 1, seed=21, winograd=True)
+    one, _ = _run_conv(capi, cuda, 9, 46, 46, 256, 512, 3, 1, 0, 1, 1, seed=21, winograd=True, only_images=1)
+    assert (big[0] - refs[0]).abs().max().item() <= TOL * max(1.0, refs[0].abs().max().item())
+    assert torch.equal(big[0][:1], one[0])
+    big, _ = _run_conv(capi, cuda, 6, 96, 80, 64, 64, 3, 1, 1, 1, 1, seed=22, winograd=True, skip_ref=True)
+    one, _ = _run_conv(capi, cuda, 6, 96, 80, 64, 64, 3, 1, 1, 1, 1, seed=22, winograd=True, only_images=1,
+                       skip_ref=True)
+    assert torch.equal(big[0][:1], one[0])
+
+
 WINO_CASES = [
     # n, h, w, cin, cout, relu, pool, pad_in, pad_out       (k = 3; csrc/conv_wino.hip)
     (2, 46, 46, 256, 512, 1, 0, 1, 1),     # conv4_1: 32 wtiles x 128 columns, 4 N tiles, XCD-ordered grid
