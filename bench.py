@@ -128,6 +128,30 @@ def cpu_baseline(sample_scenes):
     n_post = heat.shape[0]
     t_post = (t_nms + t_pp) / n_post
     per_img = t_net / n_net + t_post
+    # BASELINE.json configs[0] on THIS box: the picture_demo.py flow on readme/ski.jpg (674 x 712 -> net input
+    # 1 x 3 x 368 x 392, maps 46 x 49).  /root/reference does not exist here, so the pixels are synthetic and the
+    # arithmetic is the port's; with random weights the maps are junk, so the post step is timed on a synthetic
+    # 46 x 49 scene of the same geometry instead of on them (with real weights it is ~1-10 ms either way).
+    c1 = None
+    try:
+        x1 = torch.rand(1, 3, 368, 392, generator=g) - 0.5
+        net_oracle.forward(sd, x1)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            net_oracle.forward(sd, x1)
+        t_c1 = (time.perf_counter() - t0) / 3
+        h1, p1, _ = synth.make_batch(1, 368, 392, seed=7)
+        t0 = time.perf_counter()
+        jl1 = post_oracle.nms(h1[0])
+        if use_ref:
+            post_oracle.ref_process_paf(jl1, post_oracle.upsample_nearest(h1[0], 8), post_oracle.upsample_nearest(p1[0], 8))
+        else:
+            post_oracle.process_paf(jl1, p1[0], 8)
+        t_c1p = time.perf_counter() - t0
+        c1 = {"net_s": round(t_c1, 4), "post_s": round(t_c1p, 4), "images_per_s": round(1.0 / (t_c1 + t_c1p), 3),
+              "what": "configs[0] geometry (1 x 3 x 368 x 392, maps 46 x 49): oracle-port forward + NMS + process_paf"}
+    except Exception as e:   # noqa: BLE001
+        c1 = {"error": str(e)[:200]}
     return {"value": round(1.0 / per_img, 3), "unit": "images/s", "cores": threads, "kind": "port",
             "post_kind": "reference" if use_ref else "port",
             "cpu_model": _cpu_model(), "os_cpu_count": logical, "sched_affinity": avail,
@@ -135,6 +159,7 @@ def cpu_baseline(sample_scenes):
             "net_bs1_img_s": round(n_net / t_net, 3), "net_bs32_img_s": round(1.0 / t_b32, 3),
             "post_img_s": round(1.0 / t_post, 1),
             "end_to_end_bs32_img_s": round(1.0 / (t_b32 + t_post), 3),
+            "config1_picture_demo": c1,
             "sample": "net: %d images 368x368 at bs=1 (%.3f s/img) + one bs=32 pass (%.3f s/img) through the torch-CPU "
                       "fp32 oracle port, %d threads; post: %d synthetic scenes, restated C NMS (%.2f ms/img) + %s "
                       "(%.2f ms/img), 1 thread"
@@ -227,7 +252,9 @@ def main():
     pipeline = importlib.import_module(PKG + ".pipeline")
     lib = pkg._capi.lib
 
-    rank, local_rank, world = par.init_from_env("nccl")
+    # (under torchrun even a world of one joins an RCCL process group and gathers through it)
+    rank, local_rank, world = par.init_from_env("nccl", always=True)
+    collective = torch.distributed.is_initialized()
     if world != args.gpus:
         log("warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -253,8 +280,8 @@ def main():
     def step():
         bufs = est.enqueue(x, scene)
         n_local, words = bufs.n, bufs.words
-        if world > 1:
-            allrec = par.gather_records(bufs.result.view(n_local, words), world)
+        if collective:
+            allrec = par.gather_records(bufs.result.view(n_local, words), world, force=True)
             host = allrec.cpu()                      # D2H + sync
         else:
             host = dec.fetch(bufs)                   # pinned D2H + stream sync
@@ -268,16 +295,28 @@ def main():
         step()
 
     plan = model.plan_for(x)
-    lib.rtpose_net_set_profiling(plan.handle, 1)
     nl = lib.rtpose_net_num_launches(plan.handle)
-    k7_ms, k7_flops, k7_exec, k7_n, k7_wino, net_ms = 0.0, 0.0, 0.0, 0, 0, 0.0
 
+    # ---- the timed region: EXACTLY --steps steps of the production configuration (no per-launch events, no
+    # library queries), bracketed by barrier + synchronize on both sides -------------------------------------
     torch.cuda.synchronize()
     par.barrier(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         bufs, host = step()
-        # per-launch HIP events of this step's forward (recorded on the launch stream)
+    torch.cuda.synchronize()
+    par.barrier(dev)
+    elapsed = time.perf_counter() - t0
+    elapsed = par.max_over_ranks(elapsed, dev)
+
+    # ---- roofline leg, AFTER the timed region: the same step with per-launch HIP events recorded on the launch
+    # stream (rtpose_net_set_profiling), for the average duration of the dominant kernel ------------------------
+    k7_ms, k7_flops, k7_exec, k7_n, k7_wino, net_ms, k7_form = 0.0, 0.0, 0.0, 0, 0, 0.0, 0
+    prof_steps = max(3, min(args.steps, 8))
+    lib.rtpose_net_set_profiling(plan.handle, 1)
+    step()                                      # (the first profiled forward creates the events)
+    for _ in range(prof_steps):
+        step()
         ms, k, fl, fx, wf = C.c_float(), C.c_int(), C.c_double(), C.c_double(), C.c_int()
         for i in range(nl):
             lib.rtpose_net_launch_info(plan.handle, i, C.byref(ms), C.byref(k), C.byref(fl), None, 0)
@@ -288,13 +327,13 @@ def main():
                     k7_ms += ms.value
                     k7_flops += fl.value
                     k7_exec += fx.value
-                    k7_wino += wf.value
+                    k7_wino += 1 if wf.value else 0
+                    k7_form = wf.value
                     k7_n += 1
-    torch.cuda.synchronize()
-    par.barrier(dev)
-    elapsed = time.perf_counter() - t0
-    elapsed = par.max_over_ranks(elapsed, dev)
     lib.rtpose_net_set_profiling(plan.handle, 0)
+    status = model.device_status(plan) if not bf16 else 0
+    if status:
+        raise SystemExit("device error word %d after the run (split-tile hand-over timed out)" % status)
 
     flags = int(np.bitwise_or.reduce(np.asarray(host).reshape(-1, bufs.words)[:, dec.RES_HEADER + 2]))
     if flags:
@@ -322,13 +361,14 @@ def main():
                        "weights": "seeded He init (no checkpoint offline)",
                        "decoder_input": "synthetic scene + 1e-3 * net output (blend kernel timed)",
                        "humans_per_batch": humans_per_batch, "peaks_per_batch": peaks_per_batch,
-                       "parallelism": "image-sharded, all_gather of result records only" if world > 1 else "single GPU"},
+                       "parallelism": ("image-sharded, all_gather of result records only" if world > 1 else
+                                       "single GPU, RCCL all_gather of a world of one" if collective else "single GPU")},
             "net_tflops_end_to_end": round(fps / world * GFLOP_PER_IMAGE / 1e3, 2),
-            "net_ms_per_step_events": round(net_ms / args.steps, 3),
+            "net_ms_per_step_events": round(net_ms / prof_steps, 3),
             "roofline": {"bound": "mfma",
                          "kernel": ("conv_mfma_bf16<7,16,0,..,SP=2>" if x3 else
                                     "conv_mfma_bf16<7,32,0>" if bf16 else
-                                    "wino7_f32 (F(%s,7) Winograd along x)" % os.environ.get("RTPOSE_WINOGRAD7_M", "6") if wino7 else "conv_mfma_f32<7,16,0>") +
+                                    "wino7_f32 (F(%d,7) Winograd along x)" % k7_form if wino7 else "conv_mfma_f32<7,16,0>") +
                                    " (7x7 stage convs, 68% of the network's direct-convolution FLOPs)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None,
@@ -337,6 +377,10 @@ def main():
                          # frac may exceed 1; executed_frac = issued MFMA flops / time / peak is the
                          # matrix-pipe utilisation and cannot.
                          "executed": round(executed, 2), "executed_frac": round(executed / peak, 4),
+                         "note": "achieved = SURVEY 8(d) direct-convolution flops / event time (the contract's "
+                                 "definition; > peak in Winograd form). executed = MFMA flops the launch issues "
+                                 "(= SQ_INSTS_MFMA x 4096, profiles/) / event time: the matrix-pipe roofline fraction. "
+                                 "Events are taken in %d extra steps after the timed region." % prof_steps,
                          "launches_timed": k7_n,
                          "flops_per_launch": round(k7_flops / max(k7_n, 1)),
                          "avg_launch_ms": round(k7_ms / max(k7_n, 1), 4)},
@@ -353,7 +397,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if collective:
         torch.distributed.destroy_process_group()
 
 

@@ -2,7 +2,7 @@
 // (include/rtpose_mi355x.h): plan -> arenas (hipMalloc) -> weights -> forward -> decode -> records.
 // Build:  hipcc --offload-arch=gfx950 -O2 -Iinclude examples/c_host.cpp \
 //             -Lpytorch_realtime_multi-person_pose_estimation_amd/lib -lrtpose_mi355x -o examples/c_host
-// Run:    LD_LIBRARY_PATH=pytorch_realtime_multi-person_pose_estimation_amd/lib examples/c_host [batch] [dtype]
+// Run:    LD_LIBRARY_PATH=pytorch_realtime_multi-person_pose_estimation_amd/lib examples/c_host [batch] [dtype] [auto|direct|f47]
 // Weights are random (no checkpoint offline): the program demonstrates the call sequence and prints
 // the throughput; a real host would hand rtpose_net_load_conv the 92 OIHW tensors of pose_model.pth.
 #include <hip/hip_runtime.h>
@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -35,10 +36,20 @@
 int main(int argc, char** argv) {
   const int N = argc > 1 ? std::atoi(argv[1]) : 8, H = 368, W = 368;
   const int dtype = argc > 2 ? std::atoi(argv[2]) : RTPOSE_DTYPE_F32;  // 0 fp32, 1 bf16, 2 bf16x3
-  std::printf("%s, batch %d, dtype %d\n", rtpose_version(), N, dtype);
+  // arithmetic of the fp32 convs, chosen per plan through the ABI: default (F(2x2,3x3) + F(6,7)), "auto" (per layer
+  // by the amplification estimate of the loaded filters), "direct" (no Winograd form), "f47"
+  const char* mode = argc > 3 ? argv[3] : "default";
+  std::printf("%s, batch %d, dtype %d, winograd %s\n", rtpose_version(), N, dtype, mode);
 
+  rtpose_net_options opt;
+  opt.struct_bytes = sizeof(opt);
+  opt.dtype = dtype;
+  opt.winograd3 = !std::strcmp(mode, "direct") ? 0 : RTPOSE_WINO_DEFAULT;
+  opt.winograd7 = !std::strcmp(mode, "auto") ? RTPOSE_WINO7_AUTO : !std::strcmp(mode, "direct") ? 0
+                  : !std::strcmp(mode, "f47") ? 4 : RTPOSE_WINO_DEFAULT;
+  opt.amp_limit = 0.f;  // library default
   rtpose_net* net = nullptr;
-  CK(rtpose_net_create_ex(N, H, W, dtype, &net));
+  CK(rtpose_net_create_opts(N, H, W, &opt, &net));
   void *ws = nullptr, *wt = nullptr;
   const size_t ws_bytes = rtpose_net_workspace_bytes(net), wt_bytes = rtpose_net_weight_bytes(net);
   HK(hipMalloc(&ws, ws_bytes));
@@ -68,6 +79,22 @@ int main(int argc, char** argv) {
     HK(hipStreamSynchronize(s));
     HK(hipFree(dwp));
     HK(hipFree(dbp));
+  }
+
+  // fixes the per-layer forms of an "auto" plan (reads the amplification estimates back once)
+  CK(rtpose_net_finalize_weights(net, s));
+  {
+    int nform[7] = {0, 0, 0, 0, 0, 0, 0};
+    float amp_max[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < rtpose_net_num_convs(net); ++i) {
+      int form = 0;
+      float amp[3];
+      CK(rtpose_net_conv_numerics(net, i, &form, amp, s));
+      ++nform[form];
+      for (int j = 0; j < 3; ++j) amp_max[j] = amp[j] > amp_max[j] ? amp[j] : amp_max[j];
+    }
+    std::printf("convs by form: direct %d, F(2x2,3x3) %d, F(4,7) %d, F(6,7) %d; worst amplification estimates "
+                "%.1f / %.1f / %.1f\n", nform[0], nform[3], nform[4], nform[6], amp_max[0], amp_max[1], amp_max[2]);
   }
 
   // input batch: dense NCHW fp32 in [-0.5, 0.5) (rtpose_preprocess range)
@@ -114,6 +141,10 @@ int main(int argc, char** argv) {
   }
   std::printf("%d x (forward + decode + D2H) of %d images: %.1f images/s; maps %dx%d; %ld peaks, %ld humans, "
               "overflow flags %ld\n", iters, N, iters * N / sec, h, w, peaks, humans, flags);
+  int status = -1;
+  CK(rtpose_net_device_status(net, &status, s));
+  std::printf("device status %d, workspace %.2f GB (incl. the persistent kernels' hand-over scratch), weights %.2f GB\n",
+              status, ws_bytes / 1e9, wt_bytes / 1e9);
   rtpose_net_destroy(net);
   (void)hipFree(ws);
   (void)hipFree(wt);

@@ -111,6 +111,10 @@ typedef struct rtpose_conv_desc {
                    written at channel out_cmap[n] of the pixel (absolute, lout.choff
                    ignored) - folds channel_shuffle / concat of the ShuffleNetV2
                    blocks (rtpose_shufflenetV2.py:56-62) into the store        */
+  int32_t wino_m; /* rtpose_conv2d_winograd*, k = 7 only: 6 = F(6,7), 4 = F(4,7), 0 = the
+                   library default (6; 4 with RTPOSE_WINOGRAD7_M=4 in the environment).
+                   `w_packed` must come from the packing of the same m.  Ignored by
+                   rtpose_conv2d and for k != 7.                              */
 } rtpose_conv_desc;
 
 /* Launch one conv, or `ngroups` (<= 2) convs of identical geometry in one
@@ -122,8 +126,9 @@ int rtpose_conv2d(const rtpose_conv_desc* d, int ngroups, int N, int H, int W,
  * Same module boundary as rtpose_conv2d (nn.Conv2d + nn.ReLU (+ nn.MaxPool2d) of
  * lib/network/rtpose_vgg.py:23-35, :49-55, :108-127), fewer matrix-core multiplies:
  *   k = 3: F(2x2, 3x3), 16 instead of 36 multiplies per 2 x 2 outputs and input channel (2.25x);
- *   k = 7: F(6, 7) along x, direct along y: 84 instead of 294 per 6 outputs (3.5x), no fused pool
- *          (F(4, 7), 70 instead of 196 per 4 outputs, with RTPOSE_WINOGRAD7_M=4 in the environment of the process).
+ *   k = 7: F(6, 7) along x, direct along y: 84 instead of 294 per 6 outputs (3.5x), no fused pool;
+ *          or F(4, 7), 70 instead of 196 per 4 outputs (2.8x), selected per launch with
+ *          rtpose_conv_desc.wino_m = 4 and the matching packing (rtpose_pack_conv_weights_winograd7).
  * fp32 MFMA throughout; results differ from the direct sum by rounding only (k = 3: a few ulp,
  * k = 7: ~3e-5 at magnitude 4; whole network < 4e-5 on the stage outputs; contract 1e-3).
  * The descriptor is rtpose_conv_desc with `w_packed` from rtpose_pack_conv_weights_winograd
@@ -140,6 +145,34 @@ int rtpose_pack_conv_weights_winograd(const float* w_oihw, const float* bias, in
                                       void* stream);
 int rtpose_conv2d_winograd(const rtpose_conv_desc* d, int ngroups, int N, int H, int W,
                            void* stream);
+/* k = 7 with an explicit form m (4 or 6; 0 = default), see rtpose_conv_desc.wino_m */
+size_t rtpose_packed_weight_floats_winograd7(int cout, int cin, int m);
+int rtpose_pack_conv_weights_winograd7(const float* w_oihw, const float* bias, int cout,
+                                       int cin_src, int m, const int32_t* cin_map,
+                                       int cin_packed, float* w_packed, float* bias_packed,
+                                       void* stream);
+/* The 7x7 kernel balances launches whose tiles do not come out as whole rounds over the CUs by
+ * running persistent blocks that split tiles (results bit-identical either way).  A split tile is
+ * handed from one block to the next through `scratch`: device memory OWNED BY THE CALLER
+ * (256-byte aligned, rtpose_conv2d_winograd_scratch_bytes() of it, for the current device),
+ * because the library allocates nothing on the forward path.  One scratch serves all launches that
+ * are serialised on one stream.  With scratch = NULL (and through rtpose_conv2d_winograd) every
+ * launch runs one block per tile.  The last int of the flag area is a device error word: bit 0 is
+ * raised if a hand-over wait ever ran out (results of that launch are then invalid);
+ * rtpose_conv2d_winograd_scratch_error copies it back (synchronises the stream). */
+size_t rtpose_conv2d_winograd_scratch_bytes(void);
+int rtpose_conv2d_winograd_ex(const rtpose_conv_desc* d, int ngroups, int N, int H, int W,
+                              void* scratch, size_t scratch_bytes, void* stream);
+int rtpose_conv2d_winograd_scratch_error(const void* scratch, int* error_word, void* stream);
+/* Amplification estimate of a filter bank w[cout][cin][k][k] (device, OIHW fp32) in Winograd form:
+ * k = 3 -> F(2x2,3x3); k = 7 -> F(m,7), m = 4 or 6 (0 = default).  Writes ONE float to the device
+ * address `amp_device`: the worst ratio over the output channels of the element-wise rounding-error
+ * BOUND of the form to the direct sum's for inputs of uniform magnitude,
+ *   max_i sum_f |AT[i][f]| (sum_n |BT[f][n]|) sum_{c,ky} |U[ky][f][c][o]|  /  sum_{c,ky,kx} |w[o][c][ky][kx]|
+ * (i.i.d. Gaussian filters: 3.3, 62, 115).  The rtpose_vgg executor uses it to choose the form of a
+ * layer (rtpose_net_options.winograd7 = RTPOSE_WINO7_AUTO). */
+int rtpose_winograd_amplification(const float* w_oihw, int cout, int cin, int k, int m,
+                                  float* amp_device, void* stream);
 
 /* ---- fused pointwise chain of the ShuffleNetV2 pose network (BASELINE configs[3]) ----
  * stands in for lib/network/rtpose_shufflenetV2.py BasicBlock (:22-63): conv_bn_relu 1x1, optionally
@@ -355,6 +388,31 @@ int rtpose_net_create(int N, int H, int W, rtpose_net** out);
 #define RTPOSE_DTYPE_BF16 1
 #define RTPOSE_DTYPE_BF16X3 2 /* split bf16 operands, 3 MFMAs per product: fp32-grade results */
 int rtpose_net_create_ex(int N, int H, int W, int dtype, rtpose_net** out);
+/* Per-plan choice of the arithmetic of the fp32 convs (the Winograd forms sum fewer, transformed
+ * products: results differ from the direct sum by rounding, bounds in DESIGN.md §3.0).  The weight
+ * arena of fp32 plans holds every packing a plan may choose (direct, F(2x2,3x3), F(4,7), F(6,7)), so
+ * plans with different options share one arena and the choice costs nothing at run time.
+ *   winograd3: RTPOSE_WINO_DEFAULT (= on, unless RTPOSE_WINOGRAD=0|7 in the environment), 0 = direct
+ *              3x3 kernels, 1 = F(2x2,3x3)
+ *   winograd7: RTPOSE_WINO_DEFAULT (= F(6,7); the environment's RTPOSE_WINOGRAD=0|3 -> direct,
+ *              RTPOSE_WINOGRAD7_M=4 -> F(4,7)), 0 = direct, 4 = F(4,7), 6 = F(6,7), RTPOSE_WINO7_AUTO =
+ *              per layer the fastest form whose amplification estimate (rtpose_winograd_amplification of
+ *              the loaded filters) is <= amp_limit: F(6,7), else F(4,7), else direct; decided by
+ *              rtpose_net_finalize_weights
+ *   amp_limit: RTPOSE_WINO7_AUTO only; <= 0 = the library default (256: twice what i.i.d. Gaussian
+ *              filters give in F(6,7))
+ * Fields are ignored by bf16 / bf16x3 plans.  A form that has no kernel instance at the plan's
+ * geometry falls back to the next one (F(6,7) -> F(4,7) -> direct) whatever the options say. */
+#define RTPOSE_WINO_DEFAULT (-1)
+#define RTPOSE_WINO7_AUTO 1
+typedef struct rtpose_net_options {
+  uint32_t struct_bytes; /* sizeof(rtpose_net_options) of the caller */
+  int32_t dtype;         /* RTPOSE_DTYPE_*                            */
+  int32_t winograd3;
+  int32_t winograd7;
+  float amp_limit;
+} rtpose_net_options;
+int rtpose_net_create_opts(int N, int H, int W, const rtpose_net_options* opt, rtpose_net** out);
 int rtpose_net_dtype(const rtpose_net* net);
 void rtpose_net_destroy(rtpose_net* net);
 size_t rtpose_net_workspace_bytes(const rtpose_net* net);
@@ -372,6 +430,20 @@ int rtpose_net_conv_info(const rtpose_net* net, int idx, char* name,
 /* Pack one conv's OIHW weight + bias (device pointers) into the weight arena */
 int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw,
                          const float* bias, void* stream);
+/* After the last rtpose_net_load_conv: fixes the form of every conv of an RTPOSE_WINO7_AUTO plan from
+ * the amplification estimates of the filters just loaded (synchronises `stream` once to read them).
+ * Optional for the other modes and called by the first forward if the host did not. */
+int rtpose_net_finalize_weights(rtpose_net* net, void* stream);
+/* Arithmetic of conv idx in this plan: *form = 0 direct, 3 = F(2x2,3x3), 4 = F(4,7), 6 = F(6,7);
+ * amp[3] = amplification estimates of the loaded filters in F(2x2,3x3) / F(4,7) / F(6,7) (0 where the
+ * form does not apply; synchronises `stream` if they have not been read back yet).  Either may be NULL. */
+int rtpose_net_conv_numerics(rtpose_net* net, int idx, int* form, float* amp, void* stream);
+/* Device-side error word of the plan (synchronises `stream`): bit 0 = a split-tile hand-over of a
+ * persistent 7x7 launch timed out (see rtpose_conv2d_winograd_ex); 0 = none.  The word is cleared. */
+int rtpose_net_device_status(rtpose_net* net, int* error_word, void* stream);
+/* 1 when forwards of this plan replay a captured hipGraph (RTPOSE_GRAPH=1 in the environment and the capture
+ * succeeded), else 0. */
+int rtpose_net_graph_active(const rtpose_net* net);
 /* Enqueue the whole forward on `stream`: x is dense NCHW fp32 [N,3,H,W]. */
 int rtpose_net_forward(rtpose_net* net, const float* x_nchw, void* stream);
 /* The net's own NHWC8 input buffer, for producers that write it directly
@@ -516,7 +588,8 @@ size_t rtpose_decode_result_bytes(const rtpose_decode_cfg* cfg, int N);
  * heat: 19-channel (>= num_keypoints used) map, paf: 38-channel map, any
  * layout (dense HWC = lead 0, ws = w, hs = h, cstride = C).
  * `result` (device, rtpose_decode_result_bytes) receives, per image:
- *   int32 header[8]: n_peaks, n_humans, overflow_flags, 0...
+ *   int32 header[8]: n_peaks, n_humans, overflow_flags, max_peaks_per_part, max_humans (the
+ *                    capacities the record is laid out for: a block describes itself), 0...
  *   int32 part_count[18]
  *   rtpose_peak peaks[18 * max_peaks_per_part]   (grouped by part, cid order)
  *   int32 human_parts[max_humans][18]            (cid, -1 = absent)

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("RTPOSE_LIB_PATH") or os.path.join(_HERE, "lib", "libr
 NUM_PART = 18
 NUM_LIMB = 19
 DTYPE_F32, DTYPE_BF16, DTYPE_BF16X3 = 0, 1, 2
+WINO_DEFAULT, WINO7_AUTO = -1, 1
 NMS_NO_REFINE, NMS_GAUSSIAN = 1, 2
 
 
@@ -41,7 +42,17 @@ class ConvDesc(C.Structure):
     _fields_ = [("inp", C.c_void_p), ("w_packed", C.c_void_p), ("bias_packed", C.c_void_p),
                 ("out", C.c_void_p), ("lin", Layout), ("lout", Layout), ("cin", C.c_int32),
                 ("cout", C.c_int32), ("k", C.c_int32), ("relu", C.c_int32), ("pool", C.c_int32),
-                ("out_cmap", C.c_void_p)]
+                ("out_cmap", C.c_void_p), ("wino_m", C.c_int32)]
+
+
+class NetOptions(C.Structure):
+    """rtpose_net_options: per-plan arithmetic of the fp32 convs (header §3)."""
+    _fields_ = [("struct_bytes", C.c_uint32), ("dtype", C.c_int32), ("winograd3", C.c_int32),
+                ("winograd7", C.c_int32), ("amp_limit", C.c_float)]
+
+    @classmethod
+    def make(cls, dtype=0, winograd3=-1, winograd7=-1, amp_limit=0.0):
+        return cls(C.sizeof(cls), dtype, winograd3, winograd7, amp_limit)
 
 
 class PwDesc(C.Structure):
@@ -92,6 +103,12 @@ _SIGS = {
     "rtpose_packed_weight_floats_winograd": (_sz, [_i, _i, _i]),
     "rtpose_pack_conv_weights_winograd": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "rtpose_conv2d_winograd": (_i, [C.POINTER(ConvDesc), _i, _i, _i, _i, _vp]),
+    "rtpose_packed_weight_floats_winograd7": (_sz, [_i, _i, _i]),
+    "rtpose_pack_conv_weights_winograd7": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "rtpose_conv2d_winograd_scratch_bytes": (_sz, []),
+    "rtpose_conv2d_winograd_ex": (_i, [C.POINTER(ConvDesc), _i, _i, _i, _i, _vp, _sz, _vp]),
+    "rtpose_conv2d_winograd_scratch_error": (_i, [_vp, C.POINTER(_i), _vp]),
+    "rtpose_winograd_amplification": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "rtpose_packed_pw_floats": (_sz, [_i, _i]),
     "rtpose_pack_pw_weights": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "rtpose_pw_fused": (_i, [C.POINTER(PwDesc), _i, _i, _i, _vp]),
@@ -117,6 +134,11 @@ _SIGS = {
     "rtpose_layout_axpby": (_i, [_vp, _LP, _vp, _i, _i, _i, _i, C.c_float, C.c_float, _vp]),
     "rtpose_net_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
     "rtpose_net_create_ex": (_i, [_i, _i, _i, _i, C.POINTER(_vp)]),
+    "rtpose_net_create_opts": (_i, [_i, _i, _i, C.POINTER(NetOptions), C.POINTER(_vp)]),
+    "rtpose_net_finalize_weights": (_i, [_vp, _vp]),
+    "rtpose_net_conv_numerics": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_float), _vp]),
+    "rtpose_net_device_status": (_i, [_vp, C.POINTER(_i), _vp]),
+    "rtpose_net_graph_active": (_i, [_vp]),
     "rtpose_net_dtype": (_i, [_vp]),
     "rtpose_packed_weight_bytes_bf16": (_sz, [_i, _i, _i]),
     "rtpose_pack_conv_weights_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),

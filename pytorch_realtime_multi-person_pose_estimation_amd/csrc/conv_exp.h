@@ -12,7 +12,8 @@
     defined(RTPOSE_EXP_NO_STAGE) || defined(RTPOSE_EXP_NO_FILL) || defined(RTPOSE_EXP_NO_STORE) ||      \
     defined(RTPOSE_EXP_SCALAR_STORE) || defined(RTPOSE_EXP_BSPREAD) || defined(RTPOSE_EXP_HALF_B_ON) || \
     defined(RTPOSE_EXP_STAGGER) || defined(RTPOSE_EXP_TB1X1) || defined(RTPOSE_EXP_HD) ||               \
-    defined(RTPOSE_EXP_RB2) || defined(RTPOSE_EXP_W7_PF) || defined(RTPOSE_EXP_W7_TMASK) || defined(RTPOSE_EXP_W7_LPS) || defined(RTPOSE_EXP_W_EPI)
+    defined(RTPOSE_EXP_RB2) || defined(RTPOSE_EXP_W7_PF) || defined(RTPOSE_EXP_W7_TMASK) || defined(RTPOSE_EXP_W7_LPS) || defined(RTPOSE_EXP_W_EPI) || \
+    defined(RTPOSE_EXP_W3_SWOLD) || defined(RTPOSE_EXP_W7_CGMAJOR) || defined(RTPOSE_EXP_TIMELINE3)
 #error "RTPOSE_EXP_* ablation switches need -DRTPOSE_DEV_BUILD (they are not part of production builds)"
 #endif
 #endif
@@ -37,6 +38,14 @@ inline const char* dev_env(const char* name) {
 #define RTPOSE_TSTAMP(slot)
 #endif
 
+// per-tile stamps of the persistent 3x3 Winograd kernel (tools/timeline_w3.py)
+#ifdef RTPOSE_EXP_TIMELINE3
+#define RTPOSE_TSTAMP3(ti, slot) \
+  if (A.dbg && threadIdx.x == 0 && (ti) < 6) A.dbg[((size_t)blockIdx.x * 6 + (ti)) * 8 + (slot)] = __builtin_amdgcn_s_memtime()
+#else
+#define RTPOSE_TSTAMP3(ti, slot)
+#endif
+
 // fp32 1x1 convs: CK-channel sub-chunks per LDS buffer (4: -20 % on the 1x1 layers)
 #ifndef RTPOSE_EXP_TB1X1
 #define RTPOSE_EXP_TB1X1 1
@@ -53,6 +62,18 @@ inline const char* dev_env(const char* name) {
 // variant that shows what the epilogue costs)
 #ifndef RTPOSE_EXP_W_EPI
 #define RTPOSE_EXP_W_EPI 16
+#endif
+// 3x3 Winograd kernel: rotation of the wtile slots per channel group in LDS (8 / CG: write-conflict-free;
+// round 2 used 16 / CG)
+#ifdef RTPOSE_EXP_W3_SWOLD
+#define RTPOSE_EXP_W3_SW(CG) (16 / (CG))
+#else
+#define RTPOSE_EXP_W3_SW(CG) (8 / (CG))
+#endif
+// 7x7 Winograd kernel: transform items of a row ordered channel-group-major (1) so that the 8 lanes of a
+// ds_write_b128 group hit 8 distinct 16-byte slots; 0 = round 2's (gx, cg) order (2-way conflicts on every write)
+#ifndef RTPOSE_EXP_W7_CGMAJOR
+#define RTPOSE_EXP_W7_CGMAJOR 1
 #endif
 // F(4,7) kernel: weight prefetch distance in (ky, frequency pair) steps (<= 4: 5 register sets; 2: +5 %, 3: +0.7 %)
 #ifndef RTPOSE_EXP_W7_PF

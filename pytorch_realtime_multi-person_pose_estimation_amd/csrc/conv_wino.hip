@@ -31,6 +31,7 @@
 //    (256 / ncombo)-th m tile in turn, the next tile's first patches requested before the output transform.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdlib>
 
 #include "common.h"
@@ -51,6 +52,7 @@ struct Group {
   int in_cstride, in_choff, in_ws, in_hs, in_lead;
   int out_cstride, out_choff, out_ws, out_hs, out_lead;
   int cout, cout_pad;
+  size_t in_bytes, w_bytes, out_bytes;  // extents of the three allocations from in / w / out (hardware bounds clamp)
 };
 
 struct Args {
@@ -60,6 +62,7 @@ struct Args {
   int cin;
   int relu, pool;
   int mtiles, ntiles, ncombo, xcd_remap;
+  unsigned long long* dbg;  // RTPOSE_EXP_TIMELINE builds only: 6 tiles x 8 u64 stamps per block
   int persist;  // 1: gridDim.x persistent blocks; block p keeps (n tile, group) p % ncombo and walks every (gridDim.x / ncombo)-th m tile
 };
 
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   // kernel, everything that moves (chunk, patch row / column, frequency) in the scalar offset
   // (the input descriptor is based at the block's first patch, so the 32-bit offsets stay small whatever the
   // size of the activation buffer)
-  const i32x4 rw = make_rsrc(g.w);
+  const i32x4 rw = make_rsrc(g.w, g.w_bytes);
   i32x4 rin;
   unsigned pvoff;
   auto set_loader = [&](int mt) {
@@ -129,7 +132,8 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
     };
     const size_t q0 = patch_q(min(mt * NT, A.T - 1));                // uniform: lowest address of the tile
     const size_t q = patch_q(min(mt * NT + tl, A.T - 1));            // wtiles past the end re-read the last one
-    rin = make_rsrc(g.in + q0 * g.in_cstride + g.in_choff);
+    const size_t o0 = q0 * g.in_cstride + g.in_choff;
+    rin = make_rsrc(g.in + o0, g.in_bytes - o0 * 4);
     pvoff = (unsigned)(((q - q0) * g.in_cstride + cg * 4) * 4);
   };
   set_loader(j0);
@@ -146,10 +150,13 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
     p[i >> 2][i & 3] = bload(rin, pvoff, (unsigned)chunk * (CK * 4) + psoff[i >> 2] + (i & 3) * pxb);
   };
   // V[f][cg][wtile], f = fy * 4 + fx; this thread writes fy in {2 half, 2 half + 1}; B^T over x as over the rows
-  // (wtile slots are rotated by SW per channel group: the 16 lanes of a write phase - 16 / CG wtiles x CG groups -
-  //  then land in 16 distinct 16-byte bank slots; unrotated, the CG planes of a wtile are 512 B apart = the same
-  //  banks: SQ_LDS_BANK_CONFLICT was 7 % of the kernel's cycles)
-  constexpr int SW = 16 / CG;
+  // (wtile slots are rotated by SW = 8 / CG per channel group.  A ds_write_b128 is serviced in groups of 8 CONTIGUOUS
+  //  lanes on 32 banks = 8 16-byte slots: the 8 lanes of a group - 8 / CG wtiles x CG groups - must land in 8 distinct
+  //  slots modulo 8.  Unrotated, the CG planes of a wtile are 512 B apart = the same banks (SQ_LDS_BANK_CONFLICT was
+  //  7 % of the kernel's cycles); round 2's rotation by 16 / CG was derived for 16-lane groups and left every write
+  //  2-way conflicted: 26 % (this instance) / 36 % (conv1_2) of SQ_LDS_IDX_ACTIVE.  The A reads - ds_read_b128, groups
+  //  of 16 lanes that are complete residue systems modulo 16 - are conflict-free under any rotation.)
+  constexpr int SW = RTPOSE_EXP_W3_SW(CG);
   const int vst = (half * 8 * CG + cg) * NT + ((tl + SW * cg) % NT);
   // transform in 2 IPT groups of 16 packed VALU instructions (few, full groups: see wino_common.h): rows, then
   // columns + LDS writes; with a whole patch (IPT 2) first for fy 0, 1 and then for fy 2, 3
@@ -194,7 +201,9 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
 #pragma unroll
   for (int i = 0; i < NPC; ++i) load_piece(0, i);  // chunk 0 of the first tile
 
+  [[maybe_unused]] int ti = 0;  // tile counter of this block (timeline builds)
   for (int mt = j0; mt < A.mtiles; mt += jstep) {
+  RTPOSE_TSTAMP3(ti, 0);
 #pragma unroll
   for (int f = 0; f < 16; ++f)
 #pragma unroll
@@ -217,6 +226,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
     wso += bstep;
   }
   __syncthreads();
+  RTPOSE_TSTAMP3(ti, 1);
 
   // One step = the two frequencies 2s, 2s+1 = 8 G MFMAs on two alternating accumulators.  Between MFMA
   // pairs, in a fixed (pinned) order: the A fragments of the next step (LDS), the B fragments two steps
@@ -282,6 +292,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
     }
     __syncthreads();
   }
+  RTPOSE_TSTAMP3(ti, 2);
   if (mt + jstep < A.mtiles) {  // chunk 0 of the next tile: in flight during the output transform below
     set_loader(mt + jstep);
 #pragma unroll
@@ -305,7 +316,8 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
       const int ty = r / A.TX;
       q0 = wt_q(n, ty, r - ty * A.TX);
     }
-    const i32x4 rout = make_rsrc(g.out + ((size_t)g.out_lead + (size_t)q0) * g.out_cstride + g.out_choff);
+    const size_t oo0 = ((size_t)g.out_lead + (size_t)q0) * g.out_cstride + g.out_choff;
+    const i32x4 rout = make_rsrc(g.out + oo0, g.out_bytes - oo0 * 4);
     const unsigned cs4 = (unsigned)g.out_cstride * 4, row4 = (unsigned)g.out_ws * cs4;
     const unsigned col4 = (unsigned)ncol * 4;
 #pragma unroll
@@ -357,6 +369,14 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
       }
     }
   }
+  RTPOSE_TSTAMP3(ti, 3);
+#ifdef RTPOSE_EXP_TIMELINE3
+  if (ti < 6) {  // when the stores of this tile have been acknowledged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RTPOSE_TSTAMP3(ti, 4);
+  }
+#endif
+  ++ti;
   }  // m tiles of this block
 #undef RTPOSE_PIN
 }
@@ -367,7 +387,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
 // wino_f32, the output transform is the same expression: bit-identical results, 4x (128-column blocks) or 2x
 // (64-column blocks) as many blocks.  16-channel chunks only.
 __global__ __launch_bounds__(256, 1) void wino3s_f32(const Args A) {
-  constexpr int NT = 32, CK = 16, CG = 4, G = 2, SW = 16 / CG;
+  constexpr int NT = 32, CK = 16, CG = 4, G = 2, SW = RTPOSE_EXP_W3_SW(CG);
   constexpr int VBUF = 16 * CG * NT;  // float4 per V buffer
   extern __shared__ __attribute__((aligned(16))) float4 V4[];
   const int tid = threadIdx.x;
@@ -384,7 +404,7 @@ __global__ __launch_bounds__(256, 1) void wino3s_f32(const Args A) {
   const int cg = tid % CG, tl = (tid / CG) % NT;
   const int half = __builtin_amdgcn_readfirstlane(tid / (CG * NT));
   const float sgn = half ? -1.f : 1.f;
-  const i32x4 rw = make_rsrc(g.w);
+  const i32x4 rw = make_rsrc(g.w, g.w_bytes);
   i32x4 rin;
   unsigned pvoff;
   {
@@ -395,7 +415,8 @@ __global__ __launch_bounds__(256, 1) void wino3s_f32(const Args A) {
     };
     const size_t q0 = patch_q(min(mt * NT, A.T - 1));
     const size_t q = patch_q(min(mt * NT + tl, A.T - 1));
-    rin = make_rsrc(g.in + q0 * g.in_cstride + g.in_choff);
+    const size_t o0 = q0 * g.in_cstride + g.in_choff;
+    rin = make_rsrc(g.in + o0, g.in_bytes - o0 * 4);
     pvoff = (unsigned)(((q - q0) * g.in_cstride + cg * 4) * 4);
   }
   unsigned psoff[3];
@@ -527,7 +548,8 @@ __global__ __launch_bounds__(256, 1) void wino3s_f32(const Args A) {
       const int ty = r / A.TX;
       q0 = wt_q(n, ty, r - ty * A.TX);
     }
-    const i32x4 rout = make_rsrc(g.out + ((size_t)g.out_lead + (size_t)q0) * g.out_cstride + g.out_choff);
+    const size_t oo0 = ((size_t)g.out_lead + (size_t)q0) * g.out_cstride + g.out_choff;
+    const i32x4 rout = make_rsrc(g.out + oo0, g.out_bytes - oo0 * 4);
     const unsigned cs4 = (unsigned)g.out_cstride * 4, row4 = (unsigned)g.out_ws * cs4;
     const unsigned col4 = (unsigned)ncol * 4;
     // wave wv stores accumulator registers 4 wv .. 4 wv + 3 = wtiles 8 wv + 4 kh + (0..3) of the tile
@@ -618,6 +640,11 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, const float* __res
   wp[i] = v;
 }
 
+#ifdef RTPOSE_EXP_TIMELINE3
+static unsigned long long* g_dbgw3_buf = nullptr;
+static unsigned g_dbgw3_blocks = 0;
+#endif
+
 template <int WM, int WN, int CK>
 static int launch_inst(const Args& a, dim3 grid, hipStream_t s) {
   static PerDeviceOnce attr_set;
@@ -629,12 +656,42 @@ static int launch_inst(const Args& a, dim3 grid, hipStream_t s) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set.set(dev);
   }
+#ifdef RTPOSE_EXP_TIMELINE3
+  {  // developer build: per-tile stamps of the LAST launch of this instance family (tools/timeline_w3.py)
+    static int only_wm = -1;
+    if (only_wm < 0) {
+      const char* e = dev_env("RTPOSE_TIMELINE_WM");  // 1: <1,4,16> launches, 2: conv1_2
+      only_wm = e ? atoi(e) : 1;
+    }
+    Args b = a;
+    if (WM == only_wm && grid.x <= 1024) {
+      if (!g_dbgw3_buf) (void)hipMalloc(&g_dbgw3_buf, (size_t)1024 * 6 * 8 * 8);
+      (void)hipMemsetAsync(g_dbgw3_buf, 0, (size_t)grid.x * 6 * 64, s);
+      b.dbg = g_dbgw3_buf;
+      g_dbgw3_blocks = grid.x;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, b);
+    RTPOSE_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+#endif
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 }  // namespace wino
+
+#ifdef RTPOSE_EXP_TIMELINE3
+extern "C" int rtpose_debug_timeline_w3_dump(unsigned long long* host, unsigned cap_blocks) {
+  using namespace wino;
+  if (!g_dbgw3_buf) return 0;
+  (void)hipDeviceSynchronize();
+  const unsigned n = g_dbgw3_blocks < cap_blocks ? g_dbgw3_blocks : cap_blocks;
+  (void)hipMemcpy(host, g_dbgw3_buf, (size_t)n * 6 * 64, hipMemcpyDeviceToHost);
+  return (int)n;
+}
+#endif
 
 // channel chunk the packed Winograd weights of a conv are laid out for (the kernel instance is chosen by
 // the padded output width: >= 128 columns -> 32 wtiles x 128 columns, 16-channel chunks; 64 -> 64 x 64, 8)
@@ -682,6 +739,10 @@ int conv2d_wino_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
     g.out_lead = di.lout.lead;
     g.cout = di.cout;
     g.cout_pad = cout_pad(di.cout);
+    g.in_bytes = rtpose_layout_pixels(&di.lin, N, H, W) * (size_t)di.lin.cstride * sizeof(float);
+    g.w_bytes = rtpose_packed_weight_floats_winograd(di.cout, di.cin, 3) * sizeof(float);
+    g.out_bytes = rtpose_layout_pixels(&di.lout, N, di.pool ? H / 2 : H, di.pool ? W / 2 : W) *
+                  (size_t)di.lout.cstride * sizeof(float);
   }
   a.N = N;
   a.H = H;
@@ -754,16 +815,28 @@ int pack_weights_wino_launch(const float* w, const float* bias, int cout, int ci
   return 0;
 }
 
-// k = 7: csrc/conv_wino7.hip
-int conv2d_wino7_fits(int cin, int cout, int N, int H, int W, int hs);
-int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
-int pack_weights_wino7_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map,
-                              int cin_packed, float* wp, float* bp, hipStream_t s);
-size_t packed_weight_floats_wino7(int cout, int cin);
+// MFMA flops a launch ISSUES (what SQ_INSTS_MFMA x 4096 counts): whole tiles of 32 WM wtiles x all 16 frequencies
+double conv2d_wino_issued_flops(int cin, int cout, int N, int H, int W) {
+  const int wm = cout_pad(cout) % 128 == 0 ? 1 : 2;
+  const double T = (double)N * ceil_div(H, 2) * ceil_div(W, 2);
+  const double tiles = std::ceil(T / (32.0 * wm));
+  return 2.0 * tiles * 32.0 * wm * 16.0 * (double)cin * cout_pad(cout);
+}
 
-int conv2d_winograd_fits(int k, int cin, int cout, int pool, int N, int H, int W, int hs) {
+// k = 7: csrc/conv_wino7.hip
+int conv2d_wino7_fits(int cin, int cout, int N, int H, int W, int hs, int fm);
+int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, int fm, void* scratch,
+                        size_t scratch_bytes, hipStream_t s);
+int pack_weights_wino7_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map,
+                              int cin_packed, int fm, float* wp, float* bp, hipStream_t s);
+size_t packed_weight_floats_wino7(int cout, int cin, int fm);
+size_t conv2d_wino7_scratch_bytes(int blocks);
+int* conv2d_wino7_scratch_err(void* scratch, int blocks);
+int wino_amplification_launch(const float* w, int cout, int cin, int k, int fm, float* amp, hipStream_t s);
+
+int conv2d_winograd_fits(int k, int cin, int cout, int pool, int N, int H, int W, int hs, int fm) {
   if (k == 3) return conv2d_wino_ok(cin, cout, 3);
-  if (k == 7) return !pool && conv2d_wino7_fits(cin, cout, N, H, W, hs);
+  if (k == 7) return !pool && conv2d_wino7_fits(cin, cout, N, H, W, hs, fm);
   return 0;
 }
 
@@ -772,29 +845,65 @@ int conv2d_winograd_fits(int k, int cin, int cout, int pool, int N, int H, int W
 extern "C" {
 
 int rtpose_conv2d_winograd_fits(const rtpose_conv_desc* d, int N, int H, int W) {
-  return d ? rtpose::conv2d_winograd_fits(d->k, d->cin, d->cout, d->pool, N, H, W, d->lin.hs) : 0;
+  return d ? rtpose::conv2d_winograd_fits(d->k, d->cin, d->cout, d->pool, N, H, W, d->lin.hs, d->wino_m) : 0;
+}
+
+size_t rtpose_packed_weight_floats_winograd7(int cout, int cin, int m) {
+  return rtpose::packed_weight_floats_wino7(cout, cin, m);
 }
 
 size_t rtpose_packed_weight_floats_winograd(int cout, int cin, int k) {
-  if (k == 7) return rtpose::packed_weight_floats_wino7(cout, cin);
+  if (k == 7) return rtpose::packed_weight_floats_wino7(cout, cin, 0);
   // + 4 (chunk, frequency) blocks: the B prefetch runs two steps ahead
   return (size_t)(16 * cin + 64) * rtpose::cout_pad(cout);
+}
+
+int rtpose_pack_conv_weights_winograd7(const float* w_oihw, const float* bias, int cout, int cin_src, int m,
+                                       const int32_t* cin_map, int cin_packed, float* w_packed,
+                                       float* bias_packed, void* stream) {
+  return rtpose::pack_weights_wino7_launch(w_oihw, bias, cout, cin_src, cin_map, cin_packed, m, w_packed, bias_packed,
+                                           rtpose::as_stream(stream));
 }
 
 int rtpose_pack_conv_weights_winograd(const float* w_oihw, const float* bias, int cout, int cin_src, int k,
                                       const int32_t* cin_map, int cin_packed, float* w_packed,
                                       float* bias_packed, void* stream) {
   if (k == 7)
-    return rtpose::pack_weights_wino7_launch(w_oihw, bias, cout, cin_src, cin_map, cin_packed, w_packed,
+    return rtpose::pack_weights_wino7_launch(w_oihw, bias, cout, cin_src, cin_map, cin_packed, 0, w_packed,
                                              bias_packed, rtpose::as_stream(stream));
   if (k != 3) return rtpose::fail(RTPOSE_E_INVAL, "pack_winograd: k must be 3 or 7");
   return rtpose::pack_weights_wino_launch(w_oihw, bias, cout, cin_src, cin_map, cin_packed, w_packed,
                                           bias_packed, rtpose::as_stream(stream));
 }
 
-int rtpose_conv2d_winograd(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, void* stream) {
-  if (d && d[0].k == 7) return rtpose::conv2d_wino7_launch(d, ngroups, N, H, W, rtpose::as_stream(stream));
+size_t rtpose_conv2d_winograd_scratch_bytes(void) {
+  return rtpose::conv2d_wino7_scratch_bytes(rtpose::device_cu_count());
+}
+
+int rtpose_conv2d_winograd_ex(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, void* scratch,
+                              size_t scratch_bytes, void* stream) {
+  if (d && d[0].k == 7)
+    return rtpose::conv2d_wino7_launch(d, ngroups, N, H, W, d[0].wino_m, scratch, scratch_bytes,
+                                       rtpose::as_stream(stream));
   return rtpose::conv2d_wino_launch(d, ngroups, N, H, W, rtpose::as_stream(stream));
+}
+
+int rtpose_conv2d_winograd_scratch_error(const void* scratch, int* error_word, void* stream) {
+  if (!scratch || !error_word) return rtpose::fail(RTPOSE_E_INVAL, "winograd_scratch_error: NULL argument");
+  int* err = rtpose::conv2d_wino7_scratch_err(const_cast<void*>(scratch), rtpose::device_cu_count());
+  hipStream_t s = rtpose::as_stream(stream);
+  RTPOSE_HIP_CHECK(hipMemcpyAsync(error_word, err, sizeof(int), hipMemcpyDeviceToHost, s));
+  RTPOSE_HIP_CHECK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int rtpose_conv2d_winograd(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, void* stream) {
+  return rtpose_conv2d_winograd_ex(d, ngroups, N, H, W, nullptr, 0, stream);
+}
+
+int rtpose_winograd_amplification(const float* w_oihw, int cout, int cin, int k, int m, float* amp_device,
+                                  void* stream) {
+  return rtpose::wino_amplification_launch(w_oihw, cout, cin, k, m, amp_device, rtpose::as_stream(stream));
 }
 
 }  // extern "C"

@@ -33,9 +33,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
-#include <map>
-#include <mutex>
-#include <utility>
 
 #include "common.h"
 #include "conv_exp.h"
@@ -43,7 +40,7 @@
 
 namespace rtpose {
 
-int wino_scratch(hipStream_t s, int blocks, size_t floats_per_block, float** partial, int** flags);
+size_t packed_weight_floats_wino7(int cout, int cin, int fm);
 
 namespace wino7 {
 
@@ -104,6 +101,7 @@ struct Group {
   int in_cstride, in_choff, in_ws, in_hs, in_lead;
   int out_cstride, out_choff, out_ws, out_hs, out_lead;
   int cout, cout_pad;
+  size_t in_bytes, w_bytes;  // extents of the allocations from in / w (hardware bounds clamp of the buffer loads)
 };
 
 struct Args {
@@ -116,8 +114,9 @@ struct Args {
   int VB;       // float4 per V buffer
   int mtiles, ntiles, ncombo, xcd_remap;
   int persist;      // 1: gridDim.x blocks share the (tile, chunk) units evenly (see wino7_f32)
-  float* scratch;   // persist: one accumulator tile per block (4 waves x 160 registers x 64 lanes)
-  int* flags;       // persist: flags[p] = 1 while the sums block p saved wait for block p + 1
+  float* scratch;   // persist: one accumulator tile per block (4 waves x 12 x 16 registers x 64 lanes)
+  int* flags;       // persist: flags[p] = 1 while the sums block p saved wait for block p + 1 (cleared at launch)
+  int* err;         // persist: device error word (bit 0: a hand-over wait ran out, the tile's results are invalid)
 };
 
 constexpr int CK = 8, CG = 2;   // channels per chunk, 16-byte channel groups per chunk
@@ -155,12 +154,15 @@ struct Xform {
     const int tid = threadIdx.x;
     const int nitems = nrows * GX * CG;
     const long qbase = (long)g.in_lead + (long)(R0 - 3) * g.in_ws - 3;
-    rin = make_rsrc(g.in + qbase * g.in_cstride + g.in_choff);
+    const size_t o0 = (size_t)qbase * g.in_cstride + g.in_choff;
+    rin = make_rsrc(g.in + o0, g.in_bytes - o0 * 4);
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
       const int i = min(tid + k * 256, nitems - 1);  // surplus threads repeat the last item (same value, same slot)
       const int r = i / (GX * CG), rem = i - r * (GX * CG);
-      const int gx = rem >> 1, cg = rem & 1;
+      // channel-group-major inside a row: the 8 contiguous lanes a ds_write_b128 is serviced in then write 8
+      // consecutive 16-byte slots (gx, cg interleaved they hit 4 slots twice: 12.5 % of SQ_LDS_IDX_ACTIVE in round 2)
+      const int cg = RTPOSE_EXP_W7_CGMAJOR ? rem / GX : (rem & 1), gx = RTPOSE_EXP_W7_CGMAJOR ? rem - cg * GX : (rem >> 1);
       voff[k] = (unsigned)((((long)r * g.in_ws + FM * gx) * g.in_cstride + cg * 4) * 4);
       vdst[k] = r * RS + cg * GX + gx;
 #pragma unroll
@@ -247,7 +249,7 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   // ---- input transform role: NI items (row, gx, channel group), see Xform ----------------------------
   Xform<NI, FM> X;
   X.setup(g, A.W, GX, RS, R0, nrows);
-  const i32x4 rw = make_rsrc(g.w);
+  const i32x4 rw = make_rsrc(g.w, g.w_bytes);
   auto load_piece = [&](int chunk, int k, int n) { X.load_piece(chunk, k, n); };
   auto tgroup = [&](float4* vw, int k, int gidx) { X.tgroup(vw, k, gidx); };
 
@@ -270,9 +272,21 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
     const float b0 = g.bias[ncol];  // padded to cout_pad
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[1][r] = b0;
-  } else {  // continue the sums the previous block started (it did so first thing: the wait is a formality)
+  } else {
+    // Continue the sums the previous block started.  It saved them FIRST THING in its life, so the wait is a
+    // formality provided block p - 1 is dispatched no later than block p - the order the hardware dispatches a 1-D
+    // grid in (the launch has one block per CU, all resident).  The wait is bounded all the same (~1 s): if it runs
+    // out, the error word is raised (rtpose_net_device_status / the caller of rtpose_conv2d_winograd_ex reads it)
+    // and the block goes on with whatever the slot holds instead of hanging the GPU.
     if (tid == 0) {
-      while (__hip_atomic_load(A.flags + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) __builtin_amdgcn_s_sleep(8);
+      unsigned spins = 0;
+      while (__hip_atomic_load(A.flags + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 22)) {
+          __hip_atomic_fetch_or(A.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -536,7 +550,7 @@ __global__ __launch_bounds__(256, 1) void wino7s_f32(const Args A) {
   }
   Xform<NI, FM> X;
   X.setup(g, A.W, GX, RS, R0, nrows);
-  const i32x4 rw = make_rsrc(g.w);
+  const i32x4 rw = make_rsrc(g.w, g.w_bytes);
 
   int abase;
   {
@@ -753,9 +767,10 @@ __global__ void pack_wino7_kernel(const float* __restrict__ w, const float* __re
   wp[i] = v;
 }
 
-// Which F(FM, 7): 6 unless RTPOSE_WINOGRAD7_M=4 (environment, read once per process: the packed filters of every
-// plan of the process must agree).
-static int wino7_fm() {
+// Which F(FM, 7) a conv runs in is a property of the launch (rtpose_conv_desc.wino_m; the rtpose_vgg executor
+// chooses per plan and per layer, csrc/net.hip).  0 = the default: 6, or 4 with RTPOSE_WINOGRAD7_M=4 in the
+// environment of the process (read once).
+int wino7_default_fm() {
   static int fm = 0;
   if (!fm) {
     const char* e = getenv("RTPOSE_WINOGRAD7_M");
@@ -763,6 +778,7 @@ static int wino7_fm() {
   }
   return fm;
 }
+static int resolve_fm(int fm) { return fm == 0 ? wino7_default_fm() : fm; }
 
 struct Plan {
   int fm, nfq, gx, rs, nrows, ni, tpi, mtiles;
@@ -770,8 +786,8 @@ struct Plan {
   size_t lds;
 };
 
-static int make_plan(int N, int H, int W, int hs, Plan* p) {
-  p->fm = wino7_fm();
+static int make_plan(int N, int H, int W, int hs, int fm, Plan* p) {
+  p->fm = fm;
   p->nfq = p->fm + 6;
   p->gx = ceil_div(W, p->fm);
   p->rs = row_stride(p->gx, p->nfq);
@@ -832,61 +848,149 @@ static int launch_small(const Args& a, dim3 grid, size_t lds, hipStream_t s) {
   return 0;
 }
 
-}  // namespace wino7
-
-// Scratch of the persistent kernels (this file and conv_wino.hip): one accumulator tile + one flag per block, per
-// (device, stream) - launches on one stream are serialised, launches on different streams must not share slots.
-// Never freed (a few per process).
-int wino_scratch(hipStream_t s, int blocks, size_t floats_per_block, float** partial, int** flags) {
-  struct Scratch {
-    float* partial = nullptr;
-    int* flags = nullptr;
-    int blocks = 0;
-    size_t floats = 0;
-  };
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, Scratch> pool;
-  std::lock_guard<std::mutex> lock(mu);
-  Scratch& sc = pool[std::make_pair(current_device(), s)];
-  if (sc.blocks < blocks + 1 || sc.floats < floats_per_block) {
-    // (a replaced allocation is leaked on purpose: an earlier launch on the stream may still be using it)
-    const size_t n = (size_t)(blocks + 1 > sc.blocks ? blocks + 1 : sc.blocks);
-    const size_t fl = floats_per_block > sc.floats ? floats_per_block : sc.floats;
-    RTPOSE_HIP_CHECK(hipMalloc(&sc.partial, n * fl * sizeof(float)));
-    RTPOSE_HIP_CHECK(hipMalloc(&sc.flags, n * sizeof(int)));
-    RTPOSE_HIP_CHECK(hipMemsetAsync(sc.flags, 0, n * sizeof(int), s));
-    sc.blocks = (int)n;
-    sc.floats = fl;
+// ---- amplification estimate of a filter bank in a Winograd form ("numerics") ----------------
+// For inputs of uniform magnitude X the products of output channel o sum, in absolute value, to
+//   direct:    X * sum_{c,ky,kx} |w[o][c][ky][kx]|
+//   Winograd:  X * max_i sum_f |AT[i][f]| * (sum_n |BT[f][n]|) * sum_{c,ky} |U[ky][f][c][o]|
+// and the rounding error of either sum is bounded by (a depth factor) x 2^-24 x that quantity.  amp = the worst
+// ratio of the two over the output channels: how much larger the element-wise error BOUND of the form is than the
+// direct sum's for these filters (i.i.d. Gaussian filters: F(2x2,3x3) 3.3, F(4,7) 62, F(6,7) 115; measured errors stay
+// below the bound, tests/test_wino_numerics_gpu.py).  One block per output channel, result by atomicMax on the bit
+// pattern of a non-negative float.
+__global__ void wino_amp_kernel(const float* __restrict__ w, int cout, int cin, int k, int fm, float* __restrict__ amp) {
+  __shared__ float red[17][256];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  float sf[16], den = 0.f;
+#pragma unroll
+  for (int f = 0; f < 16; ++f) sf[f] = 0.f;
+  const int nfq = fm + 6;
+  for (int c = tid; c < cin; c += 256) {
+    const float* gw = w + ((size_t)o * cin + c) * k * k;
+    if (k == 3) {
+      float u[4][3];
+      for (int x = 0; x < 3; ++x) {
+        const float g0 = gw[x], g1 = gw[3 + x], g2 = gw[6 + x];
+        u[0][x] = g0;
+        u[1][x] = 0.5f * (g0 + g1 + g2);
+        u[2][x] = 0.5f * (g0 - g1 + g2);
+        u[3][x] = g2;
+        den += fabsf(g0) + fabsf(g1) + fabsf(g2);
+      }
+      for (int fy = 0; fy < 4; ++fy) {
+        sf[fy * 4 + 0] += fabsf(u[fy][0]);
+        sf[fy * 4 + 1] += fabsf(0.5f * (u[fy][0] + u[fy][1] + u[fy][2]));
+        sf[fy * 4 + 2] += fabsf(0.5f * (u[fy][0] - u[fy][1] + u[fy][2]));
+        sf[fy * 4 + 3] += fabsf(u[fy][2]);
+      }
+    } else {
+      const double pts[11] = {0.0, 1.0, -1.0, 2.0, -2.0, 0.5, -0.5, 1.5, -1.5, 2.0 / 3.0, -2.0 / 3.0};
+      for (int ky = 0; ky < 7; ++ky) {
+        const float* row = gw + ky * 7;
+        for (int kx = 0; kx < 7; ++kx) den += fabsf(row[kx]);
+        for (int f = 0; f < nfq; ++f) {
+          double v;
+          if (f == nfq - 1) {
+            v = row[6];
+          } else {
+            double nf = 1.0;
+            for (int l = 0; l < nfq - 1; ++l)
+              if (l != f) nf *= pts[f] - pts[l];
+            double sacc = 0.0, pw = 1.0;
+            for (int kx = 0; kx < 7; ++kx) {
+              sacc += pw * (double)row[kx];
+              pw *= pts[f];
+            }
+            v = sacc / nf;
+          }
+          sf[f] += fabsf((float)v);
+        }
+      }
+    }
   }
-  *partial = sc.partial;
-  *flags = sc.flags;
-  return 0;
+#pragma unroll
+  for (int f = 0; f < 16; ++f) red[f][tid] = sf[f];
+  red[16][tid] = den;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st)
+      for (int f = 0; f < 17; ++f) red[f][tid] += red[f][tid + st];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float num = 0.f;
+    if (k == 3) {
+      const float a[2][4] = {{1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, 1.f, 1.f}};  // |AT|; every row of |BT| sums to 2
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) {
+          float v = 0.f;
+          for (int fy = 0; fy < 4; ++fy)
+            for (int fx = 0; fx < 4; ++fx) v += a[i][fy] * a[j][fx] * 4.f * red[fy * 4 + fx][0];
+          num = fmaxf(num, v);
+        }
+    } else {
+      const float pabs[12] = {0.f, 1.f, 1.f, 2.f, 2.f, 0.5f, 0.5f, 1.5f, 1.5f, 0.666666667f, 0.666666667f, 0.f};
+      for (int i = 0; i < fm; ++i) {
+        float v = 0.f;
+        for (int f = 0; f < nfq; ++f) {
+          float b = 0.f;  // sum_n |BT[f][n]| of the kernel's (row-scaled) table
+          for (int n = 0; n < nfq; ++n) b += fabsf(fm == 4 ? WT<4>::kBT[f < 10 ? f : 0][n < 10 ? n : 0] : WT<6>::kBT[f][n]);
+          float ai;  // |AT[i][f]| = |p_f|^i; the point 0 only reaches output 0, infinity only output fm - 1
+          if (f == 0) ai = i == 0 ? 1.f : 0.f;
+          else if (f == nfq - 1) ai = i == fm - 1 ? 1.f : 0.f;
+          else {
+            ai = 1.f;
+            for (int e = 0; e < i; ++e) ai *= pabs[f];
+          }
+          v += ai * b * red[f][0];
+        }
+        num = fmaxf(num, v);
+      }
+    }
+    const float r = red[16][0] > 0.f ? num / red[16][0] : 0.f;
+    atomicMax(reinterpret_cast<int*>(amp), __float_as_int(r));
+  }
 }
 
-// 1 when the 7x7 conv can run in F(4,7) form at this geometry (a kernel instance exists and the
+}  // namespace wino7
+
+int wino7_default_fm() { return wino7::wino7_default_fm(); }
+
+// Hand-over scratch of the persistent launches: [flags: blocks + 1 ints][error word][pad to 256 B][one accumulator
+// tile per block].  It is the CALLER's memory (the rtpose_vgg executor places it in its workspace; a caller of
+// rtpose_conv2d_winograd_ex passes it): the forward path allocates nothing and can be stream-captured.  One scratch
+// serves launches that are serialised on one stream; concurrent launches need one each.
+static size_t wino7_scratch_flag_bytes(int blocks) { return round_up((size_t)(blocks + 2) * sizeof(int), 256); }
+int* conv2d_wino7_scratch_err(void* scratch, int blocks) { return static_cast<int*>(scratch) + blocks + 1; }
+size_t conv2d_wino7_scratch_bytes(int blocks) {
+  return wino7_scratch_flag_bytes(blocks) + (size_t)blocks * (4 * 12 * 16 * 64) * sizeof(float);
+}
+
+// 1 when the 7x7 conv can run in F(fm, 7) form at this geometry (a kernel instance exists and the
 // transformed rows of a block fit the LDS), else 0: callers then use the direct kernel
-int conv2d_wino7_fits(int cin, int cout, int N, int H, int W, int hs) {
-  if (cin <= 0 || cin % wino7::CK || cout_pad(cout) % 128 || N <= 0 || H <= 0 || W <= 0) return 0;
+int conv2d_wino7_fits(int cin, int cout, int N, int H, int W, int hs, int fm) {
+  fm = wino7::resolve_fm(fm);
+  if ((fm != 4 && fm != 6) || cin <= 0 || cin % wino7::CK || cout_pad(cout) % 128 || N <= 0 || H <= 0 || W <= 0) return 0;
   wino7::Plan p;
-  if (wino7::make_plan(N, H, W, hs, &p)) return 0;
+  if (wino7::make_plan(N, H, W, hs, fm, &p)) return 0;
   return p.ni <= 2 && p.lds <= 156 * 1024;
 }
 
-// FM of the F(FM, 7) form this process uses (for flop accounting)
-int conv2d_wino7_fm() { return wino7::wino7_fm(); }
-
-// position strips (block rows of the launch grid) of an N x H x W conv
-int conv2d_wino7_tiles(int N, int H, int W, int hs) {
+// MFMA flops a launch ISSUES (what SQ_INSTS_MFMA x 4096 counts): every strip is 32 positions, padded per image
+double conv2d_wino7_issued_flops(int cin, int cout, int N, int H, int W, int hs, int fm) {
+  fm = wino7::resolve_fm(fm);
   wino7::Plan p;
-  return wino7::make_plan(N, H, W, hs, &p) ? 0 : p.mtiles;
+  if (wino7::make_plan(N, H, W, hs, fm, &p)) return 0.0;
+  return 2.0 * p.mtiles * 32.0 * 7.0 * p.nfq * (double)cin * cout_pad(cout);
 }
 
-int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s) {
+int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, int fm, void* scratch,
+                        size_t scratch_bytes, hipStream_t s) {
   using namespace wino7;
+  fm = resolve_fm(fm);
   if (!d || ngroups < 1 || ngroups > 2) return fail(RTPOSE_E_INVAL, "conv2d_winograd: ngroups must be 1 or 2");
   const rtpose_conv_desc& d0 = d[0];
-  if (d0.k != 7 || d0.pool || !conv2d_wino7_fits(d0.cin, d0.cout, N, H, W, d0.lin.hs))
-    return fail(RTPOSE_E_INVAL, "conv2d_winograd: no F(4,7) instance for cin %d cout %d at %d x %d x %d", d0.cin,
+  if (d0.k != 7 || d0.pool || !conv2d_wino7_fits(d0.cin, d0.cout, N, H, W, d0.lin.hs, fm))
+    return fail(RTPOSE_E_INVAL, "conv2d_winograd: no F(%d,7) instance for cin %d cout %d at %d x %d x %d", fm, d0.cin,
                 d0.cout, N, H, W);
   Args a;
   memset(&a, 0, sizeof(a));
@@ -919,9 +1023,11 @@ int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
     g.out_lead = di.lout.lead;
     g.cout = di.cout;
     g.cout_pad = cout_pad(di.cout);
+    g.in_bytes = rtpose_layout_pixels(&di.lin, N, H, W) * (size_t)di.lin.cstride * sizeof(float);
+    g.w_bytes = packed_weight_floats_wino7(di.cout, di.cin, fm) * sizeof(float);
   }
   Plan p;
-  make_plan(N, H, W, d0.lin.hs, &p);
+  make_plan(N, H, W, d0.lin.hs, fm, &p);
   a.N = N;
   a.H = H;
   a.W = W;
@@ -941,7 +1047,8 @@ int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
   {
     // persistent form: as many blocks as CUs share the (tile, chunk) units evenly; worth it (and valid: a tile
     // may be split between at most two blocks) when there are at least as many tiles as CUs and the tiles do
-    // not already come out as whole rounds
+    // not already come out as whole rounds.  It needs the caller's hand-over scratch; without one (or with one
+    // that is too small for this device) the launch runs one block per tile - same results, bit for bit.
     const int n_cu = device_cu_count();
     const long tiles = (long)a.mtiles * a.ncombo;
     static int persist_env = -1;
@@ -949,9 +1056,13 @@ int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
       const char* e = dev_env("RTPOSE_W7_PERSIST");
       persist_env = e ? atoi(e) : 1;
     }
-    if (persist_env && tiles >= n_cu && tiles % n_cu != 0) {
-      const int rc = wino_scratch(s, n_cu, (size_t)4 * 12 * 16 * 64, &a.scratch, &a.flags);
-      if (rc) return rc;
+    if (persist_env && tiles >= n_cu && tiles % n_cu != 0 && scratch && scratch_bytes >= conv2d_wino7_scratch_bytes(n_cu)) {
+      if ((uintptr_t)scratch & 255) return fail(RTPOSE_E_INVAL, "conv2d_winograd: scratch must be 256-byte aligned");
+      a.flags = static_cast<int*>(scratch);
+      a.err = a.flags + n_cu + 1;
+      a.scratch = reinterpret_cast<float*>(static_cast<char*>(scratch) + wino7_scratch_flag_bytes(n_cu));
+      // flags are cleared at launch start (not only by the consumer): an aborted launch cannot leave one up
+      RTPOSE_HIP_CHECK(hipMemsetAsync(a.flags, 0, (size_t)(n_cu + 1) * sizeof(int), s));
       a.persist = 1;
       ids = n_cu;
     }
@@ -985,11 +1096,13 @@ int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
 }
 
 int pack_weights_wino7_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map,
-                              int cin_packed, float* wp, float* bp, hipStream_t s) {
+                              int cin_packed, int fm, float* wp, float* bp, hipStream_t s) {
+  fm = wino7::resolve_fm(fm);
+  if (fm != 4 && fm != 6) return fail(RTPOSE_E_INVAL, "pack_winograd: F(m,7) exists for m = 4 and m = 6");
   if (cin_packed % wino7::CK || cin_packed <= 0 || (cin_packed < cin_src && !cin_map))
     return fail(RTPOSE_E_INVAL, "pack_winograd: cin_packed must be a multiple of 8 and >= cin_src");
   const int coutp = cout_pad(cout);
-  const int nfq = wino7::wino7_fm() + 6;
+  const int nfq = fm + 6;
   const size_t total = (size_t)7 * nfq * cin_packed * coutp;
   const int threads = 256;
   const unsigned blocks = (unsigned)((total + threads - 1) / threads);
@@ -999,9 +1112,20 @@ int pack_weights_wino7_launch(const float* w, const float* bias, int cout, int c
   return 0;
 }
 
-size_t packed_weight_floats_wino7(int cout, int cin) {
+size_t packed_weight_floats_wino7(int cout, int cin, int fm) {
   // + 5 steps (10 frequency blocks of 8 x cout_pad floats): the B prefetch runs up to five steps ahead
-  return (size_t)(7 * (wino7::wino7_fm() + 6) * cin + 96) * cout_pad(cout);
+  return (size_t)(7 * (wino7::resolve_fm(fm) + 6) * cin + 96) * cout_pad(cout);
+}
+
+// amp (device, one float) <- amplification estimate of w[cout][cin][k][k] in F(2x2,3x3) (k = 3) or F(fm,7) (k = 7)
+int wino_amplification_launch(const float* w, int cout, int cin, int k, int fm, float* amp, hipStream_t s) {
+  if (k == 7) fm = wino7::resolve_fm(fm);
+  if (!w || !amp || cout <= 0 || cin <= 0 || !(k == 3 || (k == 7 && (fm == 4 || fm == 6))))
+    return fail(RTPOSE_E_INVAL, "winograd_amplification: k must be 3, or 7 with m = 4 or 6");
+  RTPOSE_HIP_CHECK(hipMemsetAsync(amp, 0, sizeof(float), s));
+  hipLaunchKernelGGL(wino7::wino_amp_kernel, dim3((unsigned)cout), dim3(256), 0, s, w, cout, cin, k, k == 7 ? fm : 0, amp);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
 }
 
 }  // namespace rtpose

@@ -9,7 +9,7 @@ constexpr int kLdsPairs = 110 * 110;   // candidate-score matrix entries that fi
 constexpr int kLdsRows = 720;          // subset rows (21 floats each) that fit in LDS
 
 // word (4-byte) offsets inside one image's result record
-constexpr int kResHeader = 0;      // [0] n_peaks [1] n_humans [2] overflow flags
+constexpr int kResHeader = 0;      // [0] n_peaks [1] n_humans [2] overflow flags [3] max_peaks_per_part [4] max_humans
 constexpr int kResPartCount = 8;   // int32[18]
 constexpr int kResPeaks = 32;      // rtpose_peak[18 * pcap], then human tables
 

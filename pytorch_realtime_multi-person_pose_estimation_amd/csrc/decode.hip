@@ -652,9 +652,15 @@ __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* 
   }
 }
 
-__global__ void clear_header_kernel(int32_t* __restrict__ result, int result_words, int N) {
+// header + part counts of every record <- 0, except header[3] / [4] = the capacities the record is laid out for
+// (max_peaks_per_part, max_humans): a record block describes itself, a consumer that parses it later - after the
+// producer has grown its tables - does not need the producer's cfg of that moment.
+__global__ void clear_header_kernel(int32_t* __restrict__ result, int result_words, int N, int pcap, int hcap) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N * kResPeaks) result[(size_t)(i / kResPeaks) * result_words + (i % kResPeaks)] = 0;
+  if (i < N * kResPeaks) {
+    const int wd = i % kResPeaks;
+    result[(size_t)(i / kResPeaks) * result_words + wd] = wd == kResHeader + 3 ? pcap : wd == kResHeader + 4 ? hcap : 0;
+  }
 }
 
 static MapView to_view(const float* base, const rtpose_layout* l) {
@@ -698,7 +704,8 @@ int nms_launch(const float* heat, const rtpose_layout* lheat, int N, int h, int 
   if (N <= 0 || h <= 0 || w <= 0) return fail(RTPOSE_E_INVAL, "decode: empty batch");
   const int words = decode_result_words(cfg);
   int32_t* res = static_cast<int32_t*>(result);
-  hipLaunchKernelGGL(clear_header_kernel, dim3(ceil_div(N * kResPeaks, 256)), dim3(256), 0, s, res, words, N);
+  hipLaunchKernelGGL(clear_header_kernel, dim3(ceil_div(N * kResPeaks, 256)), dim3(256), 0, s, res, words, N,
+                     cfg->max_peaks_per_part, cfg->max_humans);
   if (flags & ~(RTPOSE_NMS_NO_REFINE | RTPOSE_NMS_GAUSSIAN)) return fail(RTPOSE_E_INVAL, "nms: unknown flag");
   if (flags) {
     const size_t dyn = (size_t)2 * 25 * cfg->upsample * cfg->upsample * sizeof(float);

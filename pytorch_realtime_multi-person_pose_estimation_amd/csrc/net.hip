@@ -24,8 +24,19 @@
 
 namespace rtpose {
 int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
-int conv2d_winograd_fits(int k, int cin, int cout, int pool, int N, int H, int W, int hs);
-int conv2d_wino7_fm();
+int conv2d_winograd_fits(int k, int cin, int cout, int pool, int N, int H, int W, int hs, int fm);
+int conv2d_wino_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
+int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, int fm, void* scratch,
+                        size_t scratch_bytes, hipStream_t s);
+double conv2d_wino_issued_flops(int cin, int cout, int N, int H, int W);
+double conv2d_wino7_issued_flops(int cin, int cout, int N, int H, int W, int hs, int fm);
+size_t conv2d_wino7_scratch_bytes(int blocks);
+int* conv2d_wino7_scratch_err(void* scratch, int blocks);
+size_t packed_weight_floats_wino7(int cout, int cin, int fm);
+int pack_weights_wino7_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map,
+                              int cin_packed, int fm, float* wp, float* bp, hipStream_t s);
+int wino_amplification_launch(const float* w, int cout, int cin, int k, int fm, float* amp, hipStream_t s);
+int wino7_default_fm();
 int pack_weights_launch(const float* w, const float* bias, int cout, int cin_src, int k,
                         const int32_t* cin_map, int cin_packed, float* wp, float* bp, hipStream_t s);
 // bf16 path (conv_mfma_bf16.hip)
@@ -51,9 +62,15 @@ struct ConvW {
   std::string name;
   int cout = 0, cin_src = 0, cin_packed = 0, k = 0;
   bool cat_perm = false;   // input channels follow the cat([L1,L2,out1]) order
-  bool wino = false;       // fp32 plans: this plan runs the conv in Winograd form (csrc/conv_wino.hip, conv_wino7.hip)
-  bool dual = false;       // 7x7: the arena holds the Winograd packing at w_off AND the direct one at w_off_direct
-  size_t w_off_direct = 0;
+  // fp32 plans.  The arena holds EVERY packing a plan may run the conv in (it is shared by all plans of a module,
+  // whatever their geometry and options): the direct one at w_off, and - where the form has a kernel for these
+  // channel counts - F(2x2,3x3) at w_off_w3, F(4,7) / F(6,7) at w_off_w4 / w_off_w6.
+  bool has_w3 = false, has_w7 = false;
+  size_t w_off_w3 = 0, w_off_w4 = 0, w_off_w6 = 0;
+  size_t amp_off = 0;      // 3 floats in the arena: amplification estimates in F(2x2,3x3) / F(4,7) / F(6,7) (0 = n/a)
+  float amp[3] = {0.f, 0.f, 0.f};  // host copy (rtpose_net_finalize_weights)
+  int form = 0;            // what THIS plan runs the conv in: 0 direct, 3 = F(2x2,3x3), 4 = F(4,7), 6 = F(6,7)
+  int H = 0, W = 0;        // map size the conv runs at in this plan
   size_t w_off = 0, b_off = 0;  // float offsets in the weight arena
 };
 
@@ -82,7 +99,13 @@ struct rtpose_net {
   int N = 0, H = 0, W = 0;       // input
   int bf16 = 0;                  // 1: bf16 activations/weights, fp32 accumulate (BASELINE config 3)
   int split = 0;                 // bf16 plans only: 1 = "bf16x3" split operands (hi + lo bf16 per value)
-  int wino = 1;                  // fp32 plans: Winograd for the eligible 3x3 convs (RTPOSE_WINOGRAD=0 turns it off)
+  int w3 = 1;                    // fp32 plans: F(2x2,3x3) for the eligible 3x3 convs (rtpose_net_options.winograd3)
+  int w7 = 6;                    // fp32 plans: 0 direct, 4 / 6 = F(4,7) / F(6,7), RTPOSE_WINO7_AUTO = per layer by amp_limit
+  float amp_limit = 256.f;
+  bool forms_final = false;      // forms chosen (AUTO: after the amplification estimates were read back)
+  bool amps_read = false;
+  int n_cu = 0;                  // CUs of the device the plan was created for (sizes the hand-over scratch)
+  size_t scratch_off = 0, scratch_bytes = 0;  // persistent 7x7 launches: hand-over scratch inside the workspace
   int x0f_buf = -1;              // bf16 plans: fp32 NHWC8 staging buffer for rtpose_preprocess_u8
   int H3 = 0, W3 = 0;            // stride-8 map
   std::vector<Buf> bufs;
@@ -144,31 +167,65 @@ int add_conv_w(rtpose_net* n, const std::string& name, int cout, int cin, int k,
   c.cin_packed = cat_perm ? kCatC : (n->bf16 ? ceil_div(cin, 16) * 16 : ceil_div(cin, 8) * 8);
   c.k = k;
   c.cat_perm = cat_perm;
-  // The weight arena is shared by every plan of a module (any N x H x W), so its layout may not depend on
-  // the geometry.  3x3: the Winograd form always applies, one packing.  7x7: whether F(4,7) fits depends on
-  // the map width (LDS), so such a conv keeps BOTH packings and each plan picks one (c.wino).
-  const bool en = !n->bf16 && n->wino && (n->wino == 1 || n->wino == k);
-  // (3x3 with < 32 input channels stays direct: nothing to amortise the transforms over - conv1_1, 3 -> 64 on 8
-  //  padded channels, takes 0.71 ms in Winograd form and 0.50 ms in the direct kernel)
-  const bool w3 = en && k == 3 && c.cin_packed >= 32 && conv2d_winograd_fits(3, c.cin_packed, cout, 0, 1, 8, 8, 9);
-  c.dual = en && k == 7 && c.cin_packed % 8 == 0 && cout_pad(cout) % 128 == 0;
-  // (The form is NOT chosen by batch size: the direct kernel sums in another order, and an image's maps would depend
-  //  on the batch it is evaluated in.  Small grids get the frequency-split launch of the same arithmetic instead,
-  //  conv_wino7.hip: wino7s_f32.)
-  c.wino = w3 || (c.dual && conv2d_winograd_fits(7, c.cin_packed, cout, 0, n->N, H, W, H + 3));
-  c.w_off = n->wt_floats;
-  n->wt_floats += round_up((w3 || c.dual) ? rtpose_packed_weight_floats_winograd(cout, c.cin_packed, k)
-                           : n->split     ? rtpose_packed_weight_bytes_bf16x3(cout, c.cin_packed, k) / 4
-                           : n->bf16      ? rtpose_packed_weight_bytes_bf16(cout, c.cin_packed, k) / 4
-                                          : rtpose_packed_weight_floats(cout, c.cin_packed, k), 64);
-  if (c.dual) {
-    c.w_off_direct = n->wt_floats;
-    n->wt_floats += round_up(rtpose_packed_weight_floats(cout, c.cin_packed, k), 64);
+  c.H = H;
+  c.W = W;
+  auto take = [&](size_t floats) {
+    const size_t off = n->wt_floats;
+    n->wt_floats += round_up(floats, 64);
+    return off;
+  };
+  if (n->bf16) {
+    c.w_off = take(n->split ? rtpose_packed_weight_bytes_bf16x3(cout, c.cin_packed, k) / 4
+                            : rtpose_packed_weight_bytes_bf16(cout, c.cin_packed, k) / 4);
+  } else {
+    // The weight arena is shared by every plan of a module (any N x H x W, any rtpose_net_options), so its layout
+    // depends on the channel counts only: the direct packing, plus every Winograd packing that has a kernel.
+    // (3x3 with < 32 input channels stays direct: nothing to amortise the transforms over - conv1_1, 3 -> 64 on 8
+    //  padded channels, takes 0.71 ms in Winograd form and 0.50 ms in the direct kernel)
+    c.w_off = take(rtpose_packed_weight_floats(cout, c.cin_packed, k));
+    c.has_w3 = k == 3 && c.cin_packed >= 32 && conv2d_winograd_fits(3, c.cin_packed, cout, 0, 1, 8, 8, 9, 0);
+    c.has_w7 = k == 7 && c.cin_packed % 8 == 0 && cout_pad(cout) % 128 == 0;
+    if (c.has_w3) c.w_off_w3 = take(rtpose_packed_weight_floats_winograd(cout, c.cin_packed, 3));
+    if (c.has_w7) {
+      c.w_off_w4 = take(packed_weight_floats_wino7(cout, c.cin_packed, 4));
+      c.w_off_w6 = take(packed_weight_floats_wino7(cout, c.cin_packed, 6));
+    }
+    c.amp_off = take(4);
   }
-  c.b_off = n->wt_floats;
-  n->wt_floats += round_up(rtpose_packed_bias_floats(cout), 64);
+  c.b_off = take(rtpose_packed_bias_floats(cout));
   n->convs.push_back(c);
   return (int)n->convs.size() - 1;
+}
+
+// The form plan `n` runs conv `c` in.  (It is NOT chosen by batch size: the direct kernel sums in another order, and
+// an image's maps would depend on the batch it is evaluated in.  Small grids get the frequency-split launch of the
+// same arithmetic instead, conv_wino7.hip: wino7s_f32.)  A form without a kernel instance at the plan's geometry -
+// F(m,7) on maps so wide that the transformed rows of a block do not fit the LDS - falls back to the next one.
+int pick_form(const rtpose_net* n, const ConvW& c) {
+  if (n->bf16) return 0;
+  if (c.k == 3) return (c.has_w3 && n->w3) ? 3 : 0;
+  if (c.k != 7 || !c.has_w7 || !n->w7) return 0;
+  auto fits = [&](int fm) {
+    return conv2d_winograd_fits(7, c.cin_packed, c.cout, 0, n->N, c.H, c.W, c.H + 3, fm) != 0;
+  };
+  if (n->w7 == RTPOSE_WINO7_AUTO) {
+    if (c.amp[2] <= n->amp_limit && fits(6)) return 6;
+    if (c.amp[1] <= n->amp_limit && fits(4)) return 4;
+    return 0;
+  }
+  if (n->w7 == 6 && fits(6)) return 6;
+  return fits(4) ? 4 : 0;
+}
+
+void pick_forms(rtpose_net* n) {
+  for (ConvW& c : n->convs) c.form = pick_form(n, c);
+  // the two branches of a grouped launch run one kernel: the more conservative form of the two
+  for (Op& o : n->ops) {
+    if (o.kind != OP_CONV || o.ngroups < 2) continue;
+    ConvW &a = n->convs[o.conv_idx[0]], &b = n->convs[o.conv_idx[1]];
+    const int f = a.form < b.form ? a.form : b.form;  // 0 < 3 < 4 < 6: direct is the lowest
+    a.form = b.form = f;
+  }
 }
 
 void add_conv_op(rtpose_net* n, int H, int W, int ngroups, const int* conv_idx, const int* in_buf,
@@ -302,6 +359,14 @@ void build_plan(rtpose_net* n) {
     U[b][5] = add_buf(n, 128, 0, H3, W3);
   }
   for (int s = 0; s < 6; ++s) n->save_buf[s] = add_buf(n, 57, 0, H3, W3, true);  // always fp32
+  if (!n->bf16) {
+    // hand-over scratch of the persistent 7x7 launches (conv_wino7.hip): part of the workspace, so that the
+    // forward allocates nothing, rtpose_net_workspace_bytes tells the whole truth and the launch list can be
+    // stream-captured.  One scratch: the launches of a plan are serialised on one stream.
+    n->scratch_off = round_up(n->ws_floats, 64);
+    n->scratch_bytes = conv2d_wino7_scratch_bytes(n->n_cu);
+    n->ws_floats = n->scratch_off + round_up(n->scratch_bytes / 4, 64);
+  }
 
   // ---- launches ------------------------------------------------------------------
   add_simple_op(n, OP_INPUT, "nchw_to_nhwc8", H0, W0, -1, 0, X0, 0, 3);
@@ -380,28 +445,55 @@ rtpose_layout slice(const Buf& b, int choff) {
 
 extern "C" {
 
-int rtpose_net_create_ex(int N, int H, int W, int dtype, rtpose_net** out) {
+int rtpose_net_create_opts(int N, int H, int W, const rtpose_net_options* opt, rtpose_net** out) {
   if (!out) return fail(RTPOSE_E_INVAL, "net_create: out is NULL");
+  if (!opt || opt->struct_bytes < sizeof(rtpose_net_options))
+    return fail(RTPOSE_E_INVAL, "net_create: options missing or struct_bytes smaller than this library's rtpose_net_options");
+  const int dtype = opt->dtype;
   if (N <= 0 || H < 8 || W < 8) return fail(RTPOSE_E_INVAL, "net_create: need N>=1 and H,W>=8");
   if (dtype != RTPOSE_DTYPE_F32 && dtype != RTPOSE_DTYPE_BF16 && dtype != RTPOSE_DTYPE_BF16X3)
     return fail(RTPOSE_E_INVAL, "net_create: dtype must be RTPOSE_DTYPE_F32, _BF16 or _BF16X3");
   if (dtype != RTPOSE_DTYPE_F32 && ((H | W) & 7))
     return fail(RTPOSE_E_INVAL, "net_create: the bf16 plan needs H and W to be multiples of 8 "
                                 "(crop_with_factor pads to that, im_transform.py:128-132)");
+  if (opt->winograd3 < RTPOSE_WINO_DEFAULT || opt->winograd3 > 1)
+    return fail(RTPOSE_E_INVAL, "net_create: winograd3 must be RTPOSE_WINO_DEFAULT, 0 or 1");
+  if (opt->winograd7 != RTPOSE_WINO_DEFAULT && opt->winograd7 != 0 && opt->winograd7 != 4 && opt->winograd7 != 6 &&
+      opt->winograd7 != RTPOSE_WINO7_AUTO)
+    return fail(RTPOSE_E_INVAL, "net_create: winograd7 must be RTPOSE_WINO_DEFAULT, 0, 4, 6 or RTPOSE_WINO7_AUTO");
   rtpose_net* n = new rtpose_net();
   n->N = N;
   n->H = H;
   n->W = W;
   n->bf16 = dtype != RTPOSE_DTYPE_F32;
   n->split = dtype == RTPOSE_DTYPE_BF16X3;
+  n->n_cu = device_cu_count();
   {
-    // production knob (numerics: Winograd results differ from the direct sum by a few ulp)
+    // defaults of the two fields: on, unless the environment of the process says otherwise (RTPOSE_WINOGRAD =
+    // 0: direct kernels everywhere, 3 / 7: only that kernel size in Winograd form; RTPOSE_WINOGRAD7_M=4: F(4,7))
     const char* e = getenv("RTPOSE_WINOGRAD");
-    n->wino = !e ? 1 : e[0] == '0' ? 0 : e[0] == '3' ? 3 : e[0] == '7' ? 7 : 1;  // "3" / "7": only that kernel size
+    const int env = !e ? 1 : e[0] == '0' ? 0 : e[0] == '3' ? 3 : e[0] == '7' ? 7 : 1;
+    n->w3 = opt->winograd3 != RTPOSE_WINO_DEFAULT ? opt->winograd3 : (env == 1 || env == 3);
+    n->w7 = opt->winograd7 != RTPOSE_WINO_DEFAULT ? opt->winograd7 : ((env == 1 || env == 7) ? wino7_default_fm() : 0);
+    n->amp_limit = opt->amp_limit > 0.f ? opt->amp_limit : 256.f;
   }
   build_plan(n);
+  if (n->w7 != RTPOSE_WINO7_AUTO) {  // AUTO waits for the filters (rtpose_net_finalize_weights)
+    pick_forms(n);
+    n->forms_final = true;
+  }
   *out = n;
   return 0;
+}
+
+int rtpose_net_create_ex(int N, int H, int W, int dtype, rtpose_net** out) {
+  rtpose_net_options o;
+  o.struct_bytes = sizeof(o);
+  o.dtype = dtype;
+  o.winograd3 = RTPOSE_WINO_DEFAULT;
+  o.winograd7 = RTPOSE_WINO_DEFAULT;
+  o.amp_limit = 0.f;
+  return rtpose_net_create_opts(N, H, W, &o, out);
 }
 
 int rtpose_net_create(int N, int H, int W, rtpose_net** out) {
@@ -438,6 +530,8 @@ int rtpose_net_bind(rtpose_net* net, void* workspace, size_t workspace_bytes, vo
     g = nullptr;
   }
   net->forwards = 0;
+  net->amps_read = false;
+  if (net->w7 == RTPOSE_WINO7_AUTO) net->forms_final = false;
   net->ws = static_cast<float*>(workspace);
   net->wt = static_cast<float*>(weights);
   hipStream_t s = as_stream(stream);
@@ -474,19 +568,90 @@ int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw, const fl
   if (idx < 0 || idx >= (int)net->convs.size()) return fail(RTPOSE_E_INVAL, "net_load_conv: bad index");
   const ConvW& c = net->convs[idx];
   const int32_t* map = c.cat_perm ? reinterpret_cast<const int32_t*>(net->wt + net->catmap_off) : nullptr;
+  hipStream_t s = as_stream(stream);
   if (net->bf16)
     return pack_weights_bf16_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed,
-                                    net->wt + c.w_off, net->wt + c.b_off, net->split, as_stream(stream));
-  if (c.dual) {
-    const int rc = pack_weights_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed,
-                                       net->wt + c.w_off_direct, net->wt + c.b_off, as_stream(stream));
+                                    net->wt + c.w_off, net->wt + c.b_off, net->split, s);
+  // every packing the arena holds for this conv (the plans that share the arena choose among them), and the
+  // amplification estimate of each Winograd form
+  net->amps_read = false;
+  if (net->w7 == RTPOSE_WINO7_AUTO) net->forms_final = false;
+  int rc = pack_weights_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed, net->wt + c.w_off,
+                               net->wt + c.b_off, s);
+  if (rc) return rc;
+  float* amp = net->wt + c.amp_off;
+  RTPOSE_HIP_CHECK(hipMemsetAsync(amp, 0, 4 * sizeof(float), s));
+  if (c.has_w3) {
+    rc = rtpose_pack_conv_weights_winograd(w_oihw, bias, c.cout, c.cin_src, 3, map, c.cin_packed,
+                                           net->wt + c.w_off_w3, net->wt + c.b_off, stream);
+    if (!rc) rc = wino_amplification_launch(w_oihw, c.cout, c.cin_src, 3, 0, amp + 0, s);
     if (rc) return rc;
   }
-  if (c.wino || c.dual)
-    return rtpose_pack_conv_weights_winograd(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed,
-                                             net->wt + c.w_off, net->wt + c.b_off, stream);
-  return pack_weights_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed, net->wt + c.w_off,
-                             net->wt + c.b_off, as_stream(stream));
+  if (c.has_w7) {
+    rc = pack_weights_wino7_launch(w_oihw, bias, c.cout, c.cin_src, map, c.cin_packed, 4, net->wt + c.w_off_w4,
+                                   net->wt + c.b_off, s);
+    if (!rc)
+      rc = pack_weights_wino7_launch(w_oihw, bias, c.cout, c.cin_src, map, c.cin_packed, 6, net->wt + c.w_off_w6,
+                                     net->wt + c.b_off, s);
+    if (!rc) rc = wino_amplification_launch(w_oihw, c.cout, c.cin_src, 7, 4, amp + 1, s);
+    if (!rc) rc = wino_amplification_launch(w_oihw, c.cout, c.cin_src, 7, 6, amp + 2, s);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+static int read_amps(rtpose_net* net, hipStream_t s) {
+  if (net->amps_read || net->bf16) return 0;
+  // one contiguous read-back of the arena span that holds the estimates would drag the packed filters along;
+  // 92 small copies once per weight load are cheaper
+  for (ConvW& c : net->convs)
+    RTPOSE_HIP_CHECK(hipMemcpyAsync(c.amp, net->wt + c.amp_off, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+  RTPOSE_HIP_CHECK(hipStreamSynchronize(s));
+  net->amps_read = true;
+  return 0;
+}
+
+int rtpose_net_finalize_weights(rtpose_net* net, void* stream) {
+  if (!net || !net->bound) return fail(RTPOSE_E_STATE, "net_finalize_weights: net not bound");
+  if (net->forms_final) return 0;
+  const int rc = read_amps(net, as_stream(stream));
+  if (rc) return rc;
+  pick_forms(net);
+  net->forms_final = true;
+  for (hipGraphExec_t& g : net->gexec) {  // a captured launch list may hold other forms
+    if (g) (void)hipGraphExecDestroy(g);
+    g = nullptr;
+  }
+  return 0;
+}
+
+int rtpose_net_conv_numerics(rtpose_net* net, int idx, int* form, float* amp, void* stream) {
+  if (!net || !net->bound) return fail(RTPOSE_E_STATE, "net_conv_numerics: net not bound");
+  if (idx < 0 || idx >= (int)net->convs.size()) return fail(RTPOSE_E_INVAL, "net_conv_numerics: bad index");
+  int rc = rtpose_net_finalize_weights(net, stream);
+  if (!rc && amp) rc = read_amps(net, as_stream(stream));
+  if (rc) return rc;
+  const ConvW& c = net->convs[idx];
+  if (form) *form = c.form;
+  if (amp)
+    for (int i = 0; i < 3; ++i) amp[i] = c.amp[i];
+  return 0;
+}
+
+int rtpose_net_graph_active(const rtpose_net* net) {
+  return net && net->graph_mode == 1 && (net->gexec[0] || net->gexec[1]) ? 1 : 0;
+}
+
+int rtpose_net_device_status(rtpose_net* net, int* error_word, void* stream) {
+  if (!net || !net->bound || !error_word) return fail(RTPOSE_E_STATE, "net_device_status: net not bound / NULL argument");
+  *error_word = 0;
+  if (net->bf16 || !net->scratch_bytes) return 0;
+  hipStream_t s = as_stream(stream);
+  int* err = conv2d_wino7_scratch_err(net->ws + net->scratch_off, net->n_cu);
+  RTPOSE_HIP_CHECK(hipMemcpyAsync(error_word, err, sizeof(int), hipMemcpyDeviceToHost, s));
+  RTPOSE_HIP_CHECK(hipMemsetAsync(err, 0, sizeof(int), s));
+  RTPOSE_HIP_CHECK(hipStreamSynchronize(s));
+  return 0;
 }
 
 int rtpose_net_set_keep_intermediates(rtpose_net* net, int keep) {
@@ -515,17 +680,16 @@ int rtpose_net_launch_executed_flops(const rtpose_net* net, int i, double* flops
   int wino = 0;
   if (o.kind == OP_CONV)
     for (int g = 0; g < o.ngroups; ++g) {
+      // what the matrix pipe is issued (SQ_INSTS_MFMA x 4096 of a launch): whole tiles, padded channels and columns
       const ConvW& c = net->convs[o.conv_idx[g]];
-      const double kc = (double)c.cin_packed * cout_pad(c.cout);
-      if (c.wino && c.k == 3) {         // 16 frequencies per 2 x 2 wtile
-        fl += 2.0 * net->N * ceil_div(o.H, 2) * ceil_div(o.W, 2) * 16.0 * kc;
-        wino = 1;
-      } else if (c.wino && c.k == 7) {  // FM + 6 frequencies x 7 rows per group of FM pixels
-        const int fm = conv2d_wino7_fm();
-        fl += 2.0 * net->N * o.H * ceil_div(o.W, fm) * 7.0 * (fm + 6) * kc;
-        wino = 1;
+      if (c.form == 3) {         // 16 frequencies per 2 x 2 wtile
+        fl += conv2d_wino_issued_flops(c.cin_packed, c.cout, net->N, o.H, o.W);
+        wino = 3;
+      } else if (c.form) {       // FM + 6 frequencies x 7 rows per group of FM pixels, 32-position strips per image
+        fl += conv2d_wino7_issued_flops(c.cin_packed, c.cout, net->N, o.H, o.W, o.H + 3, c.form);
+        wino = c.form;
       } else {
-        fl += 2.0 * net->N * o.H * o.W * (double)c.k * c.k * kc;
+        fl += 2.0 * net->N * o.H * o.W * (double)c.k * c.k * (double)c.cin_packed * cout_pad(c.cout);
       }
     }
   if (flops) *flops = fl;
@@ -574,6 +738,10 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
 static int net_forward_impl(rtpose_net* net, const float* x_nchw, void* stream) {
   if (!net || !net->bound) return fail(RTPOSE_E_STATE, "net_forward: net not bound");
   hipStream_t s = as_stream(stream);
+  if (!net->forms_final) {  // RTPOSE_WINO7_AUTO and the host did not call rtpose_net_finalize_weights
+    const int rcf = rtpose_net_finalize_weights(net, stream);
+    if (rcf) return rcf;
+  }
   const bool prof = net->profiling && !net->ev.empty();
   const size_t nops = net->ops.size();
   if (net->graph_mode < 0) {
@@ -670,7 +838,8 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
           const Buf& bo = net->bufs[o.out_buf[g]];
           d[g].in = net->ws + bi.off_floats;
           d[g].out = net->ws + bo.off_floats;
-          d[g].w_packed = net->wt + ((c.dual && !c.wino) ? c.w_off_direct : c.w_off);
+          d[g].w_packed = net->wt + (c.form == 3 ? c.w_off_w3 : c.form == 4 ? c.w_off_w4 : c.form == 6 ? c.w_off_w6 : c.w_off);
+          d[g].wino_m = c.form == 4 || c.form == 6 ? c.form : 0;
           d[g].bias_packed = net->wt + c.b_off;
           d[g].lin = slice(bi, o.in_choff[g]);
           d[g].lout = slice(bo, o.out_choff[g]);
@@ -689,11 +858,12 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
           d[g].pool = o.pool;
           d[g].out_cmap = nullptr;
         }
-        bool wino = true;  // grouped convs share geometry, hence the form
-        for (int g = 0; g < o.ngroups; ++g) wino = wino && net->convs[o.conv_idx[g]].wino;
-        rc = net->bf16 ? conv2d_bf16_launch(d, o.ngroups, N, o.H, o.W, o.out_f32, net->split, s)
-             : wino    ? rtpose_conv2d_winograd(d, o.ngroups, N, o.H, o.W, s)
-                       : conv2d_launch(d, o.ngroups, N, o.H, o.W, s);
+        const int form = net->convs[o.conv_idx[0]].form;  // grouped convs run one form (pick_forms)
+        rc = net->bf16   ? conv2d_bf16_launch(d, o.ngroups, N, o.H, o.W, o.out_f32, net->split, s)
+             : form == 3 ? conv2d_wino_launch(d, o.ngroups, N, o.H, o.W, s)
+             : form      ? conv2d_wino7_launch(d, o.ngroups, N, o.H, o.W, form, net->ws + net->scratch_off,
+                                               net->scratch_bytes, s)
+                         : conv2d_launch(d, o.ngroups, N, o.H, o.W, s);
         break;
       }
       case OP_POOL: {

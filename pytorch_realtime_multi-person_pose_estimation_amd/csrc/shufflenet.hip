@@ -824,6 +824,7 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
           d[g].relu = o.relu;
           d[g].pool = 0;
           d[g].out_cmap = imap(o.cmap[g]);
+          d[g].wino_m = 0;
         }
         // bf16 plans: the two heads write the fp32 output record, everything else 2-byte activations
         rc = n->bf16 ? conv2d_bf16_launch(d, o.ngroups, n->N, o.H, o.W, o.out_buf[0] == n->out_buf, 0, s)

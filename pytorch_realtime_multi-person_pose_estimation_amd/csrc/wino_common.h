@@ -36,7 +36,13 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ f32x4 llvm_raw_buffer_load_v4f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm(
     "llvm.amdgcn.raw.buffer.load.v4f32");
-__device__ __forceinline__ i32x4 make_rsrc(const void* p) {
+// `bytes` = what is addressable from p (the rest of the tensor / packed filter the pointer lies in): the hardware
+// clamps every access against it - an over-read returns zeros and an over-write is dropped instead of touching a
+// neighbouring allocation (a weight prefetch that ran 3 ky steps past the packed filters once reached a committed
+// kernel with the clamp off).  Descriptors are based at a block's own first element, so the 32-bit range only
+// saturates for tensors beyond 2 GiB from there, which the per-lane offsets cannot reach anyway.
+constexpr unsigned kMaxRange = 0x7ffffffeu;
+__device__ __forceinline__ i32x4 make_rsrc(const void* p, size_t bytes) {
   union {
     struct {
       const void* p;
@@ -45,14 +51,14 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* p) {
     i32x4 v;
   } u;
   u.s.p = p;
-  u.s.range = 0x7ffffffe;  // bytes addressable from p
-  u.s.cfg = 0x00020000;    // raw buffer, 32-bit data format
+  u.s.range = bytes < (size_t)kMaxRange ? (unsigned)bytes : kMaxRange;  // bytes addressable from p
+  u.s.cfg = 0x00020000;                                                 // raw buffer, 32-bit data format
   return u.v;
 }
 __device__ void llvm_raw_buffer_store_f32(float v, i32x4 rsrc, int voffset, int soffset, int aux) __asm(
     "llvm.amdgcn.raw.buffer.store.f32");
-// one dword per lane; a lane whose voff is >= the descriptor's range (kNoStore) stores nothing: masked stores
-// without a branch around them
+// one dword per lane; a lane whose voff is >= the descriptor's range (kNoStore > kMaxRange) stores nothing: masked
+// stores without a branch around them
 constexpr unsigned kNoStore = 0x7fffffffu;
 __device__ __forceinline__ void bstore(float v, i32x4 r, unsigned voff, unsigned soff) {
   llvm_raw_buffer_store_f32(v, r, (int)voff, (int)soff, 0);

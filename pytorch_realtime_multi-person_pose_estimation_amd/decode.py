@@ -73,9 +73,15 @@ def fetch(bufs):
     return bufs.host.numpy().reshape(bufs.n, bufs.words)
 
 
-def parse_image(rec, cfg):
-    """One image's record -> dict(peaks=[P,5] float32 joint_list, parts=[H,18], score=[H], flags)."""
-    pcap, hcap = cfg.max_peaks_per_part, cfg.max_humans
+def parse_image(rec, cfg=None):
+    """One image's record -> dict(peaks=[P,5] float32 joint_list, parts=[H,18], score=[H], flags).
+    The capacities the record was written with are read from its own header (words 3, 4); ``cfg`` is only
+    consulted for records without them."""
+    pcap, hcap = int(rec[RES_HEADER + 3]), int(rec[RES_HEADER + 4])
+    if pcap <= 0 or hcap <= 0:
+        if cfg is None:
+            raise _capi.RtposeError("record carries no capacities and no cfg was given")
+        pcap, hcap = cfg.max_peaks_per_part, cfg.max_humans
     counts = rec[RES_PART_COUNT:RES_PART_COUNT + NUM_PART]
     pk = rec[RES_PEAKS:RES_PEAKS + 4 * NUM_PART * pcap].reshape(NUM_PART, pcap, 4)
     rows = []

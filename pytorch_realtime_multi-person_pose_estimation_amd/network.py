@@ -52,12 +52,14 @@ def _sequential(table, relu_after_last):
 class _Plan(object):
     """One native executor instance (fixed N, H, W) + its workspace."""
 
-    def __init__(self, n, h, w, weights, device, dtype=_capi.DTYPE_F32):
+    def __init__(self, n, h, w, weights, device, dtype=_capi.DTYPE_F32, wino=(-1, -1, 0.0)):
         handle = C.c_void_p()
-        check(lib.rtpose_net_create_ex(n, h, w, dtype, C.byref(handle)), "rtpose_net_create_ex")
+        opts = _capi.NetOptions.make(dtype, *wino)
+        check(lib.rtpose_net_create_opts(n, h, w, C.byref(opts), C.byref(handle)), "rtpose_net_create_opts")
         self.handle = handle
         self.shape = (n, h, w)
         self.dtype = dtype
+        self.wino = wino
         ws_bytes = lib.rtpose_net_workspace_bytes(handle)
         self.workspace = torch.empty(ws_bytes // 4 + 64, dtype=torch.float32, device=device)
         check(lib.rtpose_net_bind(handle, ptr(self.workspace), ws_bytes, ptr(weights),
@@ -99,6 +101,42 @@ class RtposeVGG(NativeStateMixin, nn.Module):
         self._init_native_state()   # plans / weight arenas per (device, dtype), see _native_state.py
         self.keep_intermediates = True   # reference forward returns all 12 stage outputs
         self.compute_dtype = 'fp32'
+        self._wino = (_capi.WINO_DEFAULT, _capi.WINO_DEFAULT, 0.0)
+
+    def set_winograd(self, winograd3=None, winograd7=None, amp_limit=None):
+        """Arithmetic of the fp32 convs of plans created from now on (``rtpose_net_options``):
+        ``winograd3``: None = library default (on), False / True = direct kernels / F(2x2,3x3);
+        ``winograd7``: None = default (F(6,7)), 0 = direct, 4 / 6 = F(4,7) / F(6,7), 'auto' = per layer the
+        fastest form whose amplification estimate for the loaded filters is <= ``amp_limit`` (default 256).
+        All forms read one weight arena; results of different forms differ by rounding only."""
+        w3 = _capi.WINO_DEFAULT if winograd3 is None else int(bool(winograd3))
+        if winograd7 is None:
+            w7 = _capi.WINO_DEFAULT
+        elif winograd7 == 'auto':
+            w7 = _capi.WINO7_AUTO
+        elif winograd7 in (0, 4, 6):
+            w7 = int(winograd7)
+        else:
+            raise ValueError("winograd7 must be None, 0, 4, 6 or 'auto'")
+        self._wino = (w3, w7, float(amp_limit or 0.0))
+        return self
+
+    def conv_numerics(self, plan):
+        """[(state_dict prefix, form, (amp F(2x2,3x3), amp F(4,7), amp F(6,7)))] of a plan: form 0 = direct kernel,
+        3 = F(2x2,3x3), 4 / 6 = F(m,7); amp = rtpose_winograd_amplification of the loaded filters (0 = n/a)."""
+        out = []
+        form = C.c_int()
+        amp = (C.c_float * 3)()
+        for i, (nm, _) in enumerate(self._convs()):
+            check(lib.rtpose_net_conv_numerics(plan.handle, i, C.byref(form), amp, current_stream()))
+            out.append((nm, form.value, tuple(amp)))
+        return out
+
+    def device_status(self, plan):
+        """Device-side error word of a plan (0 = fine; synchronises the stream)."""
+        word = C.c_int()
+        check(lib.rtpose_net_device_status(plan.handle, C.byref(word), current_stream()))
+        return word.value
 
     def set_compute_dtype(self, dtype):
         """'fp32' (reference arithmetic, v_mfma_f32_32x32x2_f32), 'bf16' (BASELINE config 3:
@@ -155,6 +193,10 @@ class RtposeVGG(NativeStateMixin, nn.Module):
         torch.cuda.current_stream().synchronize()  # temporaries above may be freed
         self._weights_key[wkey] = key
 
+    def _finalize(self, plan):
+        # fixes the per-layer forms of an 'auto' plan from the filters in the arena (no-op otherwise)
+        check(lib.rtpose_net_finalize_weights(plan.handle, current_stream()), "rtpose_net_finalize_weights")
+
     def plan_for(self, x):
         if not x.is_cuda:
             raise _capi.RtposeError(
@@ -170,7 +212,8 @@ class RtposeVGG(NativeStateMixin, nn.Module):
         for callers that fill the plan's input buffer themselves (rtpose_preprocess_u8)."""
         x = _ShapeOnly(device)
         dtype = _DTYPES[self.compute_dtype]
-        key = (n, h, w, x.device.index, dtype)
+        wino = getattr(self, '_wino', (_capi.WINO_DEFAULT, _capi.WINO_DEFAULT, 0.0))
+        key = (n, h, w, x.device.index, dtype, wino)
         with self._native_lock, torch.cuda.device(x.device):
             plan = self._plans.get(key)
             if plan is None:
@@ -184,9 +227,9 @@ class RtposeVGG(NativeStateMixin, nn.Module):
                     weights = torch.zeros(wb // 4 + 64, dtype=torch.float32, device=x.device)
                     self._weights[wkey] = weights
                     self._weights_key.pop(wkey, None)
-                plan = _Plan(n, h, w, weights, x.device, dtype)
-                self._remember_plan(key, plan)
+                plan = self._build_plan(key, lambda: _Plan(n, h, w, weights, x.device, dtype, wino))
             self._sync_weights(plan, x.device)
+            self._finalize(plan)
         return plan
 
     def forward_native(self, x, keep_intermediates=False):

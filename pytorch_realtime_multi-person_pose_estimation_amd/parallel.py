@@ -21,9 +21,16 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_from_env(backend=None):
+def launched_by_torchrun():
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
+
+
+def init_from_env(backend=None, always=False):
+    """Join the process group the torchrun environment describes.  A single process needs none; with
+    ``always`` a world of ONE launched by torchrun still creates it, so that the RCCL library load, the
+    device binding and the collective itself are exercised on a 1-GPU box (tests/test_rccl_gpu.py)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or (always and launched_by_torchrun())) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -41,12 +48,13 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_records(local, world=None, group=None):
+def gather_records(local, world=None, group=None, force=False):
     """all_gather of equally shaped int32 record blocks [n_local, words] -> [world*n_local, words]
-    in rank order on every rank (one fused collective per batch, never per image)."""
+    in rank order on every rank (one fused collective per batch, never per image).  A world of one returns its
+    block as is, unless ``force`` asks for the collective anyway (needs an initialised process group)."""
     if world is None:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force and dist.is_initialized()):
         return local
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous(), group=group)

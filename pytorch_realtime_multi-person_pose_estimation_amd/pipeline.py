@@ -170,8 +170,10 @@ class StreamingPoseEstimator(object):
 
     def run(self, batches):
         """batches: iterable of uint8 arrays [B, h0, w0, 3] (BGR).  Yields one int32 record block
-        [B, words] per batch (decode.parse_image(rec, self.bufs.cfg) / humans_from_record turn them into
-        Humans; self.bufs.cfg is the capacity the block was written with - it grows on overflow)."""
+        [B, words] per batch (decode.parse_image(rec) / humans_from_record turn them into Humans).  The decode
+        tables grow on overflow, so blocks of one run may differ in width; every record carries the capacities
+        it was written with in its header (words 3, 4) and parse_image reads them from there - a consumer that
+        collects blocks first, or parses a step late, never needs this object's cfg of the moment."""
         it = iter(batches)
         try:
             cur = next(it)

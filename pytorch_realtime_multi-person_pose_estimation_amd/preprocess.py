@@ -472,15 +472,20 @@ def run_eval_batched(image_dir, anno_file, vis_dir, model, preprocess, config=No
                     if tuple(im.shape[:2]) != tuple(sizes[i]):
                         raise _capi.RtposeError("image %s is %s, the annotation file says %s"
                                                 % (info[img_ids[i]]["file_name"], im.shape[:2], sizes[i]))
+                # One plan size per bucket: a short (tail) batch runs in the bucket's `batch`-image plan with its
+                # first len(idx) slots filled - no extra plan (workspace allocation + zeroing) per tail shape, and
+                # the plan cache of a COCO run stays at one plan per size bucket.  The kernels are batch-invariant,
+                # so the results do not depend on what the unused slots hold.
                 if tta_scales is not None:
-                    paf_d, heat_d, _ = get_multiscale_outputs_batch(imgs, model, preprocess, scales=tta_scales,
+                    padded = imgs + [imgs[-1]] * (batch - len(imgs))
+                    paf_d, heat_d, _ = get_multiscale_outputs_batch(padded, model, preprocess, scales=tta_scales,
                                                                     flip=tta_flip, config=config)
                     hm, wm = heat_d.shape[1], heat_d.shape[2]
                     lheat, lpaf = _capi.Layout.dense(19, hm, wm), _capi.Layout.dense(38, hm, wm)
                     hbase, pbase = ptr(heat_d), ptr(paf_d)
                 else:
                     hn, wn = key
-                    plan = m.plan_for_shape(len(idx), hn, wn, dev)
+                    plan = m.plan_for_shape(batch, hn, wn, dev)
                     up = [torch.from_numpy(im).to(dev, non_blocking=True) for im in imgs]
                     preprocess_into_plan(plan, up, [im.shape[:2] for im in imgs], size, mode, stream)
                     check(lib.rtpose_net_set_keep_intermediates(plan.handle, 0))

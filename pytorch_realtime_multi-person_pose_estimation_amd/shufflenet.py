@@ -158,8 +158,7 @@ class Network(NativeStateMixin, nn.Module):
                     lib.rtpose_shufflenet_destroy(probe)
                     weights = torch.zeros(wb // 4 + 64, dtype=torch.float32, device=x.device)
                     self._weights[wkey] = weights
-                plan = _Plan(n, h, w, weights, x.device, dtype)
-                self._remember_plan(key, plan)
+                plan = self._build_plan(key, lambda: _Plan(n, h, w, weights, x.device, dtype))
                 self._weights_key.pop(wkey, None)   # a new plan re-binds the maps; the reload is cheap
             self._sync_weights(plan, x.device)
         return plan

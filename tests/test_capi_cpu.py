@@ -100,10 +100,12 @@ def test_compute_dtype_plans_on_the_host(capi, pkg):
     f32, bf16, x3 = sizes[capi.DTYPE_F32], sizes[capi.DTYPE_BF16], sizes[capi.DTYPE_BF16X3]
     assert 0.4 * f32[0] < bf16[0] < 0.7 * f32[0]        # 2-byte activations (+ fp32 staging / records)
     assert 0.9 * f32[0] < x3[0] < 1.2 * f32[0]          # hi + lo = the fp32 footprint
-    # weights: bf16 = half of the plain fp32 packing = the bf16x3 one; the fp32 plan keeps its 3x3 filters in
-    # Winograd form (16/9 of the taps) and its 7x7 filters twice (70/49 Winograd + the direct packing: which one
-    # a plan uses depends on its geometry, the arena is shared by all plans)
-    assert 0.45 * x3[1] < bf16[1] < 0.6 * x3[1] and 2.0 * x3[1] < f32[1] < 2.5 * x3[1]
+    # weights: bf16 = half of the plain fp32 packing = the bf16x3 one; the fp32 arena holds EVERY packing a plan may
+    # choose (rtpose_net_options; the arena is shared by all plans of a module): direct (1) + F(2x2,3x3) (16/9) for
+    # the 3x3 convs, direct (1) + F(4,7) (70/49) + F(6,7) (84/49) for the 7x7 convs
+    assert 0.45 * x3[1] < bf16[1] < 0.6 * x3[1] and 3.6 * x3[1] < f32[1] < 4.3 * x3[1], (f32[1], x3[1])
+    # ... and the workspace of an fp32 plan includes the hand-over scratch of the persistent 7x7 launches
+    assert lib.rtpose_conv2d_winograd_scratch_bytes() > 0
     assert bf16[2] == x3[2] == f32[2] - 1               # stage 6 writes its fp32 record directly (no save copy)
     h = C.c_void_p()
     assert lib.rtpose_net_create_ex(1, 364, 368, capi.DTYPE_BF16, C.byref(h)) != 0   # not a multiple of 8
@@ -156,3 +158,13 @@ def test_winograd_fits_is_host_only_logic(capi):
     # packed sizes: 16 / 9 of the taps for 3x3, (FM + 6) * 7 / 49 for 7x7 (F(6,7) unless RTPOSE_WINOGRAD7_M=4), + slack
     assert lib.rtpose_packed_weight_floats_winograd(128, 128, 3) == (16 * 128 + 64) * 128
     assert lib.rtpose_packed_weight_floats_winograd(128, 128, 7) in ((84 * 128 + 96) * 128, (70 * 128 + 96) * 128)
+    assert lib.rtpose_packed_weight_floats_winograd7(128, 128, 6) == (84 * 128 + 96) * 128
+    assert lib.rtpose_packed_weight_floats_winograd7(128, 128, 4) == (70 * 128 + 96) * 128
+    # the form is part of the descriptor: F(4,7) has more position groups per row, hence fits narrower maps only
+    d[0].wino_m = 4
+    assert fits(7, 128, 128, 32) == 1
+    d[0].wino_m = 6
+    assert fits(7, 128, 128, 32) == 1
+    d[0].wino_m = 5
+    assert fits(7, 128, 128, 32) == 0
+    d[0].wino_m = 0

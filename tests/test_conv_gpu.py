@@ -13,7 +13,7 @@ TOL = 1e-4  # relative to max|ref|; fp32 fma-chain vs ATen summation order
 
 
 def _run_conv(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, seed, groups=1, cin_pad=None,
-              winograd=False, only_images=None, skip_ref=False):
+              winograd=False, only_images=None, skip_ref=False, wino_m=0, scratch=True):
     lib, Layout = capi.lib, capi.Layout
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -47,7 +47,11 @@ def _run_conv(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, see
     obuf = torch.zeros(lib.rtpose_layout_pixels(C.byref(lout_full), n, ho, wo) * cstride_out, device=dev)
     for gi in range(groups):
         bp = torch.zeros(lib.rtpose_packed_bias_floats(cout), device=dev)
-        if winograd:
+        if winograd and k == 7 and wino_m:
+            wp = torch.zeros(lib.rtpose_packed_weight_floats_winograd7(cout, cin_p, wino_m), device=dev)
+            capi.check(lib.rtpose_pack_conv_weights_winograd7(capi.ptr(ws[gi]), capi.ptr(bs[gi]), cout, cin, wino_m,
+                                                              None, cin_p, capi.ptr(wp), capi.ptr(bp), stream))
+        elif winograd:
             wp = torch.zeros(lib.rtpose_packed_weight_floats_winograd(cout, cin_p, k), device=dev)
             capi.check(lib.rtpose_pack_conv_weights_winograd(capi.ptr(ws[gi]), capi.ptr(bs[gi]), cout, cin, k, None,
                                                              cin_p, capi.ptr(wp), capi.ptr(bp), stream))
@@ -61,9 +65,17 @@ def _run_conv(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, see
         d.lin = lin
         d.lout = Layout.padded(cstride_out, ho, wo, pad_out, choff=gi * cout + 1)
         d.cin, d.cout, d.k, d.relu, d.pool = cin_p, cout, k, int(relu), int(pool)
+        d.wino_m = wino_m if (winograd and k == 7) else 0
     if winograd:
         assert lib.rtpose_conv2d_winograd_fits(descs, n, h, w) == 1
-        capi.check(lib.rtpose_conv2d_winograd(descs, groups, n, h, w, stream), "rtpose_conv2d_winograd")
+        # the hand-over scratch of the persistent 7x7 launches is the caller's (the library allocates nothing)
+        sc = torch.zeros(lib.rtpose_conv2d_winograd_scratch_bytes() // 4, dtype=torch.int32, device=dev) if scratch else None
+        capi.check(lib.rtpose_conv2d_winograd_ex(descs, groups, n, h, w, capi.ptr(sc) if scratch else None,
+                                                 sc.numel() * 4 if scratch else 0, stream), "rtpose_conv2d_winograd_ex")
+        if scratch:
+            word = C.c_int(-1)
+            capi.check(lib.rtpose_conv2d_winograd_scratch_error(capi.ptr(sc), C.byref(word), stream))
+            assert word.value == 0, "device error word %d" % word.value
     else:
         capi.check(lib.rtpose_conv2d(descs, groups, n, h, w, stream), "rtpose_conv2d")
     for gi in range(groups):
@@ -162,6 +174,29 @@ def test_winograd7_persistent_blocks_split_tiles(capi, cuda):
                          only_images=3)
     for o, sm in zip(outs, small):
         assert torch.equal(o[:3], sm)
+    # without a scratch the same launch runs one block per tile: the same bits again
+    plain, _ = _run_conv(capi, cuda, 12, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=11, groups=2, winograd=True,
+                         scratch=False, skip_ref=True)
+    for o, pl in zip(outs, plain):
+        assert torch.equal(o, pl)
+
+
+def test_winograd7_f47_form_selected_per_launch(capi, cuda):
+    """rtpose_conv_desc.wino_m = 4 with the F(4,7) packing: the form is a property of the launch, not of the
+    process (round 2 read it from the environment); persistent split tiles (14 x 46 x 46 x 2 = 504 tiles) included."""
+    f4, refs = _run_conv(capi, cuda, 2, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=13, groups=2, winograd=True, wino_m=4)
+    f6, _ = _run_conv(capi, cuda, 2, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=13, groups=2, winograd=True, wino_m=6,
+                      skip_ref=True)
+    for a, b, r in zip(f4, f6, refs):
+        assert (a - r).abs().max().item() <= TOL * max(1.0, r.abs().max().item())
+        assert (b - r).abs().max().item() <= TOL * max(1.0, r.abs().max().item())
+        assert not torch.equal(a, b)      # two different arithmetic forms
+    big, _ = _run_conv(capi, cuda, 14, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=13, groups=2, winograd=True, wino_m=4,
+                       skip_ref=True)
+    plain, _ = _run_conv(capi, cuda, 14, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=13, groups=2, winograd=True, wino_m=4,
+                         skip_ref=True, scratch=False)
+    for a, b in zip(big, plain):
+        assert torch.equal(a, b)
 
 
 def test_winograd3_small_grid_form_is_bit_identical(capi, cuda):

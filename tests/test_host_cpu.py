@@ -299,7 +299,7 @@ def test_native_state_is_per_device_and_invalidates(pkg, monkeypatch):
     packs = []
 
     class FakePlan(object):
-        def __init__(self, n, h, w, weights, device, dtype=0):
+        def __init__(self, n, h, w, weights, device, dtype=0, wino=None):
             self.shape, self.dtype, self.weights = (n, h, w), dtype, weights
             self.workspace = torch.empty(1 << 20, dtype=torch.float32)
             self.handle = None
@@ -319,6 +319,7 @@ def test_native_state_is_per_device_and_invalidates(pkg, monkeypatch):
     monkeypatch.setattr(net.lib, "rtpose_net_create_ex", lambda *a: 0)
     monkeypatch.setattr(net.lib, "rtpose_net_weight_bytes", lambda p: 1024)
     monkeypatch.setattr(net.lib, "rtpose_net_destroy", lambda p: None)
+    monkeypatch.setattr(type(net.get_model('vgg19')), "_finalize", lambda self, plan: None)
     real_zeros = torch.zeros
     monkeypatch.setattr(torch, "zeros", lambda *a, **k: real_zeros(*a, **{kk: v for kk, v in k.items() if kk != "device"}))
     m = net.get_model('vgg19')
@@ -352,3 +353,38 @@ def test_native_state_is_per_device_and_invalidates(pkg, monkeypatch):
     for k in range(5):
         m.plan_for_shape(1, 64 + 8 * k, 64, d1)
     assert sum(1 for key in m._plans if key[3] == 1) <= 3 and any(key[3] == 0 for key in m._plans)
+    # plans with other rtpose_net_options are other plans, on the SAME weight arena
+    m.always_resync = False
+    pa = m.plan_for_shape(2, 64, 64, d0)
+    pb = m.set_winograd(winograd7=4).plan_for_shape(2, 64, 64, d0)
+    pc = m.set_winograd(winograd7='auto', amp_limit=100.0).plan_for_shape(2, 64, 64, d0)
+    assert pa is not pb and pb is not pc and pa.weights is pb.weights is pc.weights
+    assert m.set_winograd().plan_for_shape(2, 64, 64, d0) is pa
+    with pytest.raises(ValueError):
+        m.set_winograd(winograd7=5)
+
+
+def test_modules_can_be_deep_copied_and_pickled(pkg):
+    """copy.deepcopy(model), torch.save(model) and pickle (multiprocessing spawn, EMA / SWA copies, whole-model
+    checkpoints) see parameters and settings; plans, arenas and the lock are rebuilt by the copy."""
+    import copy
+    import io
+    import pickle
+    import torch
+    sn = importlib.import_module(PKG_NAME + ".shufflenet")
+    for m in (pkg.get_model('vgg19'), sn.Network(1.0)):
+        m.always_resync = True
+        if hasattr(m, "set_winograd"):
+            m.set_winograd(winograd7=4)
+        c = copy.deepcopy(m)
+        assert c._plans == {} and c._weights == {} and c._native_lock is not m._native_lock and c.always_resync
+        assert all(torch.equal(a, b) and a.data_ptr() != b.data_ptr()
+                   for a, b in zip(m.state_dict().values(), c.state_dict().values()))
+        buf = io.BytesIO()
+        torch.save(m, buf)
+        buf.seek(0)
+        r = torch.load(buf, weights_only=False)
+        assert list(r.state_dict()) == list(m.state_dict()) and r._plans == {}
+        p = pickle.loads(pickle.dumps(m))
+        assert getattr(p, "_wino", None) == getattr(m, "_wino", None)
+        p.invalidate_weights()          # the rebuilt lock works
