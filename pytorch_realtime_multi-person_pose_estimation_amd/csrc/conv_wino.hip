@@ -122,9 +122,11 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   // (the input descriptor is based at the block's first patch, so the 32-bit offsets stay small whatever the
   // size of the activation buffer)
   const i32x4 rw = make_rsrc(g.w, g.w_bytes);
-  i32x4 rin;
-  unsigned pvoff;
-  auto set_loader = [&](int mt) {
+  // two patch loaders: the tile being multiplied and the block's NEXT tile, whose first two chunks are fetched (and
+  // the first one transformed) under the last two chunks of this one - see the tile loop
+  i32x4 rin, rin_nx;
+  unsigned pvoff, pvoff_nx;
+  auto set_loader = [&](int mt, i32x4& r_, unsigned& v_) {
     auto patch_q = [&](int t) -> size_t {
       const int n = t / TT, r = t - n * TT;
       const int ty = r / A.TX, tx = r - ty * A.TX;
@@ -133,10 +135,10 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
     const size_t q0 = patch_q(min(mt * NT, A.T - 1));                // uniform: lowest address of the tile
     const size_t q = patch_q(min(mt * NT + tl, A.T - 1));            // wtiles past the end re-read the last one
     const size_t o0 = q0 * g.in_cstride + g.in_choff;
-    rin = make_rsrc(g.in + o0, g.in_bytes - o0 * 4);
-    pvoff = (unsigned)(((q - q0) * g.in_cstride + cg * 4) * 4);
+    r_ = make_rsrc(g.in + o0, g.in_bytes - o0 * 4);
+    v_ = (unsigned)(((q - q0) * g.in_cstride + cg * 4) * 4);
   };
-  set_loader(j0);
+  set_loader(j0, rin, pvoff);
   constexpr int NROW = IPT == 2 ? 4 : 3, NPC = 4 * NROW;  // patch rows / 16-byte pieces a thread loads per chunk
   unsigned psoff[NROW];  // uniform byte offsets of the patch rows (of this half)
 #pragma unroll
@@ -146,9 +148,10 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   }
   const unsigned pxb = (unsigned)g.in_cstride * 4;  // bytes per pixel
   F4 p[NROW][4], ta[4], tb[4];
-  auto load_piece = [&](int chunk, int i) {
-    p[i >> 2][i & 3] = bload(rin, pvoff, (unsigned)chunk * (CK * 4) + psoff[i >> 2] + (i & 3) * pxb);
+  auto load_piece_from = [&](const i32x4& r_, unsigned v_, int chunk, int i) {
+    p[i >> 2][i & 3] = bload(r_, v_, (unsigned)chunk * (CK * 4) + psoff[i >> 2] + (i & 3) * pxb);
   };
+  auto load_piece = [&](int chunk, int i) { load_piece_from(rin, pvoff, chunk, i); };
   // V[f][cg][wtile], f = fy * 4 + fx; this thread writes fy in {2 half, 2 half + 1}; B^T over x as over the rows
   // (wtile slots are rotated by SW = 8 / CG per channel group.  A ds_write_b128 is serviced in groups of 8 CONTIGUOUS
   //  lanes on 32 banks = 8 16-byte slots: the 8 lanes of a group - 8 / CG wtiles x CG groups - must land in 8 distinct
@@ -197,26 +200,33 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   unsigned wso = 0;                                        // uniform byte offset of the next step to fetch
   float4 bs[4][2][G];  // [step % 4][frequency of the pair][k group]
 
-  const int nchunks = A.cin / CK;
+  const int nchunks = A.cin / CK;  // >= 2 (host)
+  // (no __builtin_assume(nchunks >= 2) / do-while here: either removes the compiler's second copy of the accumulator
+  //  initialisation on the "loop not entered" path - and with it the register allocation that keeps the chunk loop
+  //  free of spills: 70-105 VGPRs went to scratch INSIDE the loop)
+  // ---- the chunk pipeline runs ACROSS the tiles of a persistent block -------------------------------------------
+  // Steady state of chunk c: multiply chunk c from V[par], transform chunk c + 1 (in the patch registers) into
+  // V[par ^ 1], fetch chunk c + 2 into the patch registers.  At the end of a tile "chunk c + 1 / c + 2" are the first
+  // chunks of the block's NEXT tile: when a tile's multiply loop ends, the next tile's chunk 0 sits transformed in
+  // LDS and its chunk 1 is in flight - a tile starts multiplying right after its B fragments arrive, with no
+  // exposed patch latency, transform or barrier.  (Round 2 fetched the next chunk 0 under the output transform,
+  // transformed it at the tile start and then waited a full memory latency for chunk 1: 8-11 us per tile that the one
+  // block per CU could not hide - 45 % of conv1_2, whose tiles multiply for 13.6 us.)
+  // (the 8-channel-chunk instance - cin = 8 x odd at 64 columns, not a layer of rtpose_vgg - keeps a per-tile B ring:
+  //  with the wrap the compiler peels its short chunk loop and spills 0.5 KB per lane)
+  constexpr bool BRING = CK == 16;
+  int par = 0;  // V buffer of the chunk being multiplied
 #pragma unroll
   for (int i = 0; i < NPC; ++i) load_piece(0, i);  // chunk 0 of the first tile
-
-  [[maybe_unused]] int ti = 0;  // tile counter of this block (timeline builds)
-  for (int mt = j0; mt < A.mtiles; mt += jstep) {
-  RTPOSE_TSTAMP3(ti, 0);
-#pragma unroll
-  for (int f = 0; f < 16; ++f)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[f][r] = f == 5 ? bias0 : 0.f;
 #pragma unroll
   for (int gq = 0; gq < 2 * IPT; ++gq) tgroup(0, gq);
-  {
-    const int c1 = min(1, nchunks - 1);
 #pragma unroll
-    for (int i = 0; i < NPC; ++i) load_piece(c1, i);
-  }
-  // (B after the patch loads, as in the steady state of the loop: see conv_wino7.hip)
-  wso = 0;
+  for (int i = 0; i < NPC; ++i) load_piece(1, i);
+  // B fragments of steps 0, 1 (after the patch loads, as in the steady state of the loop: see conv_wino7.hip).  The
+  // B ring runs across tiles as well: the last chunk of a tile prefetches steps 0, 1 of the next tile's chunk 0
+  // (wso wraps to 0 there), so that the first 32 MFMAs of a tile need nothing from memory and the stores of the
+  // previous tile's output transform - older vector-memory operations that every later vmcnt wait has to see
+  // retired first - drain underneath them.
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
@@ -226,6 +236,33 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
     wso += bstep;
   }
   __syncthreads();
+
+  [[maybe_unused]] int ti = 0;  // tile counter of this block (timeline builds)
+  for (int mt = j0; mt < A.mtiles; mt += jstep) {
+  RTPOSE_TSTAMP3(ti, 0);
+  const bool has_next = mt + jstep < A.mtiles;
+  // (without a next tile the "next" loader re-reads this tile's first chunks: valid addresses, results never used)
+  if (has_next) {
+    set_loader(mt + jstep, rin_nx, pvoff_nx);
+  } else {
+    rin_nx = rin;
+    pvoff_nx = pvoff;
+  }
+#pragma unroll
+  for (int f = 0; f < 16; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = f == 5 ? bias0 : 0.f;
+  if (!BRING && mt != j0) {  // (8-channel chunks: the B ring restarts with every tile)
+    wso = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int fs = 0; fs < 2; ++fs)
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) bs[s2][fs][gi] = bload_f4(rw, boff, wso + (fs * CG + 2 * gi) * cgstep);
+      wso += bstep;
+    }
+  }
   RTPOSE_TSTAMP3(ti, 1);
 
   // One step = the two frequencies 2s, 2s+1 = 8 G MFMAs on two alternating accumulators.  Between MFMA
@@ -238,12 +275,18 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   constexpr int SLOTS = 4 * G;  // MFMA pairs (= filler slots) per step
   float4 a[2][2][G];            // [step % 2][frequency of the pair][k group]
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const float4* vab = V4 + (chunk & 1) * VBUF;
+    const float4* vab = V4 + par * VBUF;
     const float4* va[G];  // per k group: plane (2 gi + kh), this lane's rotated wtile slot
 #pragma unroll
     for (int gi = 0; gi < G; ++gi) va[gi] = vab + (2 * gi + kh) * NT + ((arow + SW * (2 * gi + kh)) % NT);
-    const int nbuf = (chunk + 1) & 1;
-    const int c2 = min(chunk + 2, nchunks - 1);  // the last chunks re-stage themselves (never read)
+    const int nbuf = par ^ 1;
+    // what the load slots of this chunk fetch: chunk + 2 of this tile, or - in the last two chunks - chunk 0 / 1 of
+    // the next one (uniform selects, no branch in the pinned instruction stream)
+    const bool nx = chunk + 2 >= nchunks;
+    const int c2 = nx ? chunk + 2 - nchunks : chunk + 2;
+    const i32x4 rl = nx ? rin_nx : rin;
+    const unsigned pvl = nx ? pvoff_nx : pvoff;
+    auto load_next = [&](int i) { load_piece_from(rl, pvl, c2, i); };
 #pragma unroll
     for (int fs = 0; fs < 2; ++fs)
 #pragma unroll
@@ -270,7 +313,8 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
           const int i = slot - 2 * G;
           bs[(s + 2) & 3][i / G][i % G] =
               RTPOSE_EXP_B(bload_f4(rw, boff, wso + ((i / G) * CG + 2 * (i % G)) * cgstep), bs[s & 3][i / G][i % G]);
-          if (slot == SLOTS - 1) wso += bstep;
+          // (after step 5 of a tile's last chunk the ring wraps to the first steps of the next tile's chunk 0)
+          if (slot == SLOTS - 1) wso = (BRING && s == 5 && chunk == nchunks - 1) ? 0u : wso + bstep;
         }
         if (RTPOSE_EXP_STAGE) {
           if (IPT == 1) {  // groups in the last slots of steps 0, 1; two patch loads in the last slot of steps 2..7
@@ -278,26 +322,24 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
               if (s < 2) {
                 tgroup(nbuf, s);
               } else {
-                load_piece(c2, 2 * (s - 2));
-                load_piece(c2, 2 * (s - 2) + 1);
+                load_next(2 * (s - 2));
+                load_next(2 * (s - 2) + 1);
               }
             }
           } else {         // 4 groups in the middle and last slots of steps 0, 1; 16 loads in the B slots of steps 2..5
             if (s < 2 && (slot == SLOTS / 2 - 1 || slot == SLOTS - 1)) tgroup(nbuf, 2 * s + (slot == SLOTS - 1));
-            if (s >= 2 && s < 6 && slot >= SLOTS - 4) load_piece(c2, 4 * (s - 2) + slot - (SLOTS - 4));
+            if (s >= 2 && s < 6 && slot >= SLOTS - 4) load_next(4 * (s - 2) + slot - (SLOTS - 4));
           }
         }
         RTPOSE_PIN();
       }
     }
     __syncthreads();
+    par ^= 1;
   }
   RTPOSE_TSTAMP3(ti, 2);
-  if (mt + jstep < A.mtiles) {  // chunk 0 of the next tile: in flight during the output transform below
-    set_loader(mt + jstep);
-#pragma unroll
-    for (int i = 0; i < NPC; ++i) load_piece(0, i);
-  }
+  rin = rin_nx;  // the next tile becomes the current one (its chunk 0 is in V[par], its chunk 1 in flight)
+  pvoff = pvoff_nx;
 
   // ---- epilogue: output transform A^T M A, (+ReLU) (+2x2 max-pool), masked stores -----------------
   // accumulator register r of a lane = wtile row (r / 4) * 8 + 4 kh + r % 4 of the wave tile, column l31.

@@ -388,3 +388,94 @@ def test_modules_can_be_deep_copied_and_pickled(pkg):
         p = pickle.loads(pickle.dumps(m))
         assert getattr(p, "_wino", None) == getattr(m, "_wino", None)
         p.invalidate_weights()          # the rebuilt lock works
+
+
+# ---- OKS evaluator: known answers hand-derived from the published COCO keypoint evaluation rules -----------------
+# (cocodataset.org/#keypoints-eval; COCOeval.computeOks / evaluateImg / accumulate): sigma table, OKS formula,
+# greedy matching in score order, crowd / num_keypoints == 0 ground truth ignored, maxDets = 20, area ranges,
+# 101-point interpolated precision.  Expected values are computed here from those rules, not through oks_eval.
+
+_COCO_SIGMAS = [.026, .025, .025, .035, .035, .079, .079, .072, .072, .062, .062, .107, .107, .087, .087, .089, .089]
+
+
+def _person(img_id, ann_id, x0, y0, side, **kw):
+    """17 visible keypoints on a grid inside a side x side box; area = side^2."""
+    kp = []
+    for k in range(17):
+        kp += [x0 + side * (0.1 + 0.2 * (k % 5)), y0 + side * (0.1 + 0.25 * (k // 5)), 2]
+    a = {"image_id": img_id, "id": ann_id, "category_id": 1, "keypoints": kp, "num_keypoints": 17,
+         "bbox": [x0, y0, side, side], "area": float(side * side), "iscrowd": 0}
+    a.update(kw)
+    return a
+
+
+def _det(gt, score, dx=0.0, dy=0.0):
+    kp = list(gt["keypoints"])
+    for k in range(17):
+        kp[3 * k] += dx
+        kp[3 * k + 1] += dy
+        kp[3 * k + 2] = 1
+    return {"image_id": gt["image_id"], "category_id": 1, "keypoints": kp, "score": score}
+
+
+def test_oks_known_answer_single_displaced_detection(pkg):
+    """OKS = mean_k exp(-d^2 / (2 * area * (2 sigma_k)^2)); a lone detection is a TP for the thresholds <= OKS:
+    AP = (#thresholds passed) / 10."""
+    oe = importlib.import_module(PKG_NAME + ".oks_eval")
+    gt = _person(1, 1, 50.0, 60.0, 80.0)
+    d = 6.5
+    oks = float(np.mean([np.exp(-d * d / (2.0 * 6400.0 * (2 * s) ** 2)) for s in _COCO_SIGMAS]))
+    assert 0.70 < oks < 0.75, oks                       # thresholds .50 .55 .60 .65 .70 pass
+    got = oe.compute_oks([gt], [_det(gt, 1.0, dx=d)])
+    assert got.shape == (1, 1) and abs(got[0, 0] - oks) < 1e-12
+    r = oe.evaluate([gt], [_det(gt, 1.0, dx=d)])
+    # (precision is tp / (tp + fp + eps) in COCOeval: 1 - 1e-16, not 1)
+    assert abs(r["AP"] - 0.5) < 1e-9 and abs(r["AP50"] - 1.0) < 1e-9 and r["AP75"] == 0.0
+    assert abs(r["APm"] - 0.5) < 1e-9 and r["APl"] == -1.0     # area 6400 is 'medium' (32^2 .. 96^2), nothing 'large'
+    # vertical displacement counts the same; an invisible ground-truth keypoint drops out of the mean
+    gt2 = _person(1, 1, 50.0, 60.0, 80.0)
+    gt2["keypoints"][3 * 16 + 2] = 0
+    gt2["num_keypoints"] = 16
+    oks16 = float(np.mean([np.exp(-d * d / (2.0 * 6400.0 * (2 * s) ** 2)) for s in _COCO_SIGMAS[:16]]))
+    assert abs(oe.compute_oks([gt2], [_det(gt2, 1.0, dy=d)])[0, 0] - oks16) < 1e-12
+
+
+def test_oks_known_answer_101_point_interpolation(pkg):
+    """Two people, detections in score order TP, FP, TP: recall .5 .5 1, precision 1 .5 2/3 -> envelope 1 2/3 2/3;
+    the 51 recall points 0 .. 0.50 read precision 1, the 50 points 0.51 .. 1.00 read 2/3, at every OKS threshold."""
+    oe = importlib.import_module(PKG_NAME + ".oks_eval")
+    g1, g2 = _person(3, 1, 10.0, 10.0, 100.0), _person(3, 2, 300.0, 40.0, 120.0)
+    junk = _det(g1, 0.8, dx=5000.0)
+    r = oe.evaluate([g1, g2], [_det(g1, 0.9), junk, _det(g2, 0.7)])
+    want = (51 * 1.0 + 50 * (2.0 / 3.0)) / 101.0
+    assert abs(r["AP"] - want) < 1e-9 and abs(r["AP50"] - want) < 1e-9 and abs(r["AP75"] - want) < 1e-9
+    # 'large' range: both people (areas 10000, 14400) count; the junk detection's own area - its keypoint bounding
+    # box, 80 x 75 = 6000 (loadRes) - is 'medium', and an UNMATCHED detection outside the range is ignored there
+    assert abs(r["APl"] - 1.0) < 1e-9 and r["APm"] == -1.0
+    # a second detection of an already matched person is a false positive (one match per ground truth)
+    r2 = oe.evaluate([g1], [_det(g1, 0.9), _det(g1, 0.8, dx=1.0)])
+    assert abs(r2["AP"] - 1.0) < 1e-9       # TP first: precision 1 at recall 1 already
+    r3 = oe.evaluate([g1], [_det(g1, 0.8), _det(g1, 0.9, dx=5000.0)])
+    assert abs(r3["AP"] - 0.5) < 1e-9       # FP first: precision 1/2 everywhere
+
+
+def test_oks_known_answer_ignore_rules_and_max_dets(pkg):
+    """Crowd and num_keypoints == 0 ground truth is ignored and so are the detections matched to it; only the 20
+    best-scored detections of an image are evaluated; a ground truth outside the area range is ignored there."""
+    oe = importlib.import_module(PKG_NAME + ".oks_eval")
+    g1 = _person(5, 1, 10.0, 10.0, 40.0)                              # area 1600: medium
+    crowd = _person(5, 2, 200.0, 10.0, 50.0, iscrowd=1)
+    empty = _person(5, 3, 400.0, 10.0, 50.0, num_keypoints=0)
+    for k in range(17):
+        empty["keypoints"][3 * k + 2] = 0
+    inside = _det(empty, 0.92)                                        # inside the doubled box of `empty`: OKS 1
+    dts = [_det(g1, 0.9), _det(crowd, 0.95), _det(crowd, 0.93, dx=0.5), inside]
+    r = oe.evaluate([g1, crowd, empty], dts)
+    assert abs(r["AP"] - 1.0) < 1e-9 and abs(r["APm"] - 1.0) < 1e-9 and r["APl"] == -1.0
+    # the same with a junk detection scored above the true positive: FP, TP -> precision 1/2 at every recall
+    r = oe.evaluate([g1, crowd, empty], dts + [_det(g1, 0.99, dx=4000.0)])
+    assert abs(r["AP"] - 0.5) < 1e-9
+    # maxDets = 20: the perfect detection ranks 21st and is never looked at
+    many = [_det(g1, 0.5 + 0.01 * i, dx=3000.0 + 50 * i) for i in range(20)] + [_det(g1, 0.4)]
+    assert oe.evaluate([g1], many)["AP"] == 0.0
+    assert abs(oe.evaluate([g1], many[1:])["AP"] - 1.0 / 20.0) < 1e-9   # now 20th of 20: precision 1/20 at recall 1

@@ -169,3 +169,22 @@ def test_ski_oracles_reproduce_the_reference_run(ski, pkg):
                 assert tuple(want[hid, p]) == (float(int(jl[cid, 0])) / (49 * 8), float(int(jl[cid, 1])) / (46 * 8),
                                                float(jl[cid, 2]))
         assert np.float32(ski["score"][hid]) == r["score"][hid]
+
+
+def test_append_result_matches_reference(pkg, pre):
+    """evaluate/coco_eval.py:117-154 executed unmodified (oracle/make_golden_append.py -> tests/golden/
+    append_result.json) against the product's append_result on the same seeded humans: image_id, category_id,
+    the hard-coded score 1.0 and all 51 keypoint values (ORDER_COCO order, + 0.5, visibility 1) exactly."""
+    from oracle import make_golden_append as mga
+    common = importlib.import_module(PKG_NAME + ".common")
+    with open(os.path.join(GOLD, "append_result.json")) as f:
+        gold = json.load(f)
+    assert len(gold) == len(mga.CASES)
+    for (seed, n, p, up, image_id), want in zip(mga.CASES, gold):
+        outputs = []
+        pre.append_result(image_id, mga.build(mga.people(seed, n, p), common.Human, common.BodyPart), up, outputs)
+        assert len(outputs) == len(want) == n
+        for a, b in zip(outputs, want):
+            assert a["image_id"] == b["image_id"] == image_id and a["category_id"] == b["category_id"] == 1
+            assert a["score"] == b["score"] == 1.0
+            assert [float(v) for v in a["keypoints"]] == b["keypoints"]
