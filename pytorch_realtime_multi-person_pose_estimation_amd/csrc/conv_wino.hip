@@ -14,8 +14,8 @@
 //    [wtiles x cin] . [cin x cout]; a wave owns ALL 16 frequencies of a 32-wtile x 32-column tile
 //    = 16 v_mfma_f32_32x32x2_f32 accumulators = 256 registers (the AGPR half of the 512 a wave gets at
 //    one wave per SIMD), so the output transform A^T M A is lane-local: no cross-wave exchange, and
-//    the fused 2 x 2 max-pool is a max over the 4 outputs a lane just produced.  The bias is added after
-//    the transform.
+//    the fused 2 x 2 max-pool is a max over the 4 outputs a lane just produced.  The bias rides in
+//    the accumulator of frequency (1,1) (A^T e11 A = all-ones).
 //  * A block = 4 waves = (32 WM) consecutive wtiles of the flattened (n, ty, tx) order x (32 WN) output
 //    columns; no 2-D tile waste on the 46 x 46 maps (23 x 23 wtiles).
 //  * Input transform: every thread loads HALF a 4 x 4 patch of 4 channels (3 rows x 4 pixels, 16-byte raw
@@ -72,12 +72,6 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   constexpr int CG = CK / 4;   // 16-byte channel groups per chunk
   constexpr int G = CK / 8;    // 8-deep k groups per chunk (4 MFMAs each)
   static_assert(WM * WN == 4, "4 waves");
-  // B prefetch distance in steps (a ring of 4 register sets allows 3).  Every vector-memory operation of a wave retires
-  // through ONE in-order counter: a wait for B fragments issued PFD steps ago also waits for every patch load issued
-  // before them, so PFD steps (x 0.43 us) is the memory latency the WHOLE loop tolerates - patch loads from HBM
-  // (conv1_2's 1.1 GB input) included.  With 2 steps conv1_2's chunks took 11.4 k cycles for 8.2 k of MFMAs.
-  constexpr int PFD = RTPOSE_EXP_W3_PFD;
-  static_assert(PFD == 2 || PFD == 3, "B prefetch distance");
   constexpr int IPT = NT * CG * 2 / 256;  // half patches per thread and chunk: 1, or 2 = one whole 4 x 4 patch
   static_assert(NT * CG * 2 == 256 * IPT && (IPT == 1 || IPT == 2), "half patches per thread");
   constexpr int VBUF = 16 * CG * NT;  // float4 per V buffer
@@ -198,6 +192,7 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   const int ncol = nt * (32 * WN) + wn * 32 + l31;
   const int arow = wm * 32 + l31;
   floatx16 acc[16];
+  const float bias0 = g.bias[ncol];  // padded to cout_pad
   // B: lane offset (k half, column) in one register; (frequency of the pair, k group) and the step in the scalar offset
   const unsigned boff = (unsigned)((kh * g.cout_pad + ncol) * 16);
   const unsigned cgstep = (unsigned)(g.cout_pad * 16);     // bytes per channel group plane
@@ -227,13 +222,13 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   for (int gq = 0; gq < 2 * IPT; ++gq) tgroup(0, gq);
 #pragma unroll
   for (int i = 0; i < NPC; ++i) load_piece(1, i);
-  // B fragments of steps 0 .. PFD - 1 (after the patch loads, as in the steady state of the loop: see conv_wino7.hip).  The
+  // B fragments of steps 0, 1 (after the patch loads, as in the steady state of the loop: see conv_wino7.hip).  The
   // B ring runs across tiles as well: the last chunk of a tile prefetches steps 0, 1 of the next tile's chunk 0
   // (wso wraps to 0 there), so that the first 32 MFMAs of a tile need nothing from memory and the stores of the
   // previous tile's output transform - older vector-memory operations that every later vmcnt wait has to see
   // retired first - drain underneath them.
 #pragma unroll
-  for (int s2 = 0; s2 < PFD; ++s2) {
+  for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
     for (int fs = 0; fs < 2; ++fs)
 #pragma unroll
@@ -256,11 +251,11 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
 #pragma unroll
   for (int f = 0; f < 16; ++f)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[f][r] = f == 5 ? bias0 : 0.f;
   if (!BRING && mt != j0) {  // (8-channel chunks: the B ring restarts with every tile)
     wso = 0;
 #pragma unroll
-    for (int s2 = 0; s2 < PFD; ++s2) {
+    for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
       for (int fs = 0; fs < 2; ++fs)
 #pragma unroll
@@ -306,9 +301,8 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
           const float4 b0 = bs[s & 3][0][gi], b1 = bs[s & 3][1][gi];
           const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
           const float b0v[4] = {b0.x, b0.y, b0.z, b0.w}, b1v[4] = {b1.x, b1.y, b1.z, b1.w};
-          // (B first: the accumulators hold the transposed tile - lane = wtile, registers = channels; see the epilogue)
-          acc[2 * s] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0v[j], a0v[j], acc[2 * s], 0, 0, 0);
-          acc[2 * s + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1v[j], a1v[j], acc[2 * s + 1], 0, 0, 0);
+          acc[2 * s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[j], b0v[j], acc[2 * s], 0, 0, 0);
+          acc[2 * s + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[j], b1v[j], acc[2 * s + 1], 0, 0, 0);
         }
         RTPOSE_PIN();
         if (slot < 2 * G) {  // A of the next step (the first step of a chunk is read after the barrier)
@@ -317,10 +311,10 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
                 RTPOSE_EXP_A(va[slot % G][(2 * (s + 1) + slot / G) * CG * NT], a[s & 1][slot / G][slot % G]);
         } else {             // B two steps ahead
           const int i = slot - 2 * G;
-          bs[(s + PFD) & 3][i / G][i % G] =
+          bs[(s + 2) & 3][i / G][i % G] =
               RTPOSE_EXP_B(bload_f4(rw, boff, wso + ((i / G) * CG + 2 * (i % G)) * cgstep), bs[s & 3][i / G][i % G]);
-          // (PFD steps before the end of a tile's last chunk the ring wraps to the first steps of the next tile's chunk 0)
-          if (slot == SLOTS - 1) wso = (BRING && s == 7 - PFD && chunk == nchunks - 1) ? 0u : wso + bstep;
+          // (after step 5 of a tile's last chunk the ring wraps to the first steps of the next tile's chunk 0)
+          if (slot == SLOTS - 1) wso = (BRING && s == 5 && chunk == nchunks - 1) ? 0u : wso + bstep;
         }
         if (RTPOSE_EXP_STAGE) {
           if (IPT == 1) {  // groups in the last slots of steps 0, 1; two patch loads in the last slot of steps 2..7
@@ -347,16 +341,22 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
   rin = rin_nx;  // the next tile becomes the current one (its chunk 0 is in V[par], its chunk 1 in flight)
   pvoff = pvoff_nx;
 
-  // ---- epilogue: output transform A^T M A, + bias, (+ReLU) (+2x2 max-pool), masked stores -----------------------
-  // The MFMAs above take the B fragment as their first operand, i.e. they accumulate the TRANSPOSED tile: a lane owns
-  // ONE wtile (l31) and its 16 accumulator registers are 16 output channels - four runs (r / 4) of 4 consecutive
-  // channels (r / 4) * 8 + 4 kh + r % 4 of the wave's 32 columns.  Hence: one address computation per lane and tile
-  // (round 2 stepped 16 wtile positions per lane), the transform of 4 channels at once on packed pairs, and 16-byte
-  // stores - 16 per lane (4 with the fused pool) instead of 64 dword stores.  Straight-line code: ReLU is a max with
-  // 0 or -inf, masked lanes get an out-of-range offset.  (Round 2's epilogue took 8.9 k cycles of an 86 k-cycle tile
-  // of the stage-1 convs and 7.4 k of a 55 k-cycle tile of conv1_2: ~1100 VALU, 47 branches, 64 stores.)
-  // The bias is added AFTER the transform (wino3s_f32 does the same: the two launch forms stay bit-identical).
+  // (Tried in round 3 and rejected, profiles/r03_wino3_timeline_*: accumulating the TRANSPOSED tile - B fragment as the
+  //  first MFMA operand, so that a lane owns one wtile and its 16 registers are 4 runs of 4 channels - with one address
+  //  computation per lane and 16 16-byte stores instead of 64 dword stores: 816 instead of ~1100 VALU instructions, but
+  //  the epilogue went from 8.9 k to 10.5-11.7 k cycles and the store drain from 0.3 k to 1.0 k: a lane's 16 bytes land
+  //  in a cache line of their own (pixels are 512 B apart), while the dword stores below put 32 lanes on one 128-byte
+  //  line.  A B prefetch distance of 3 steps instead of 2: +2 % time.  The transform below on packed pairs of wtiles:
+  //  66 spilled registers.  Note for 16-byte stores in general: a VALU write of the store's data registers in the NEXT
+  //  basic block is not separated from it by the compiler's hazard nops - it corrupted 4 lanes in 16.)
+  // ---- epilogue: output transform A^T M A, (+ReLU) (+2x2 max-pool), masked stores -----------------
+  // accumulator register r of a lane = wtile row (r / 4) * 8 + 4 kh + r % 4 of the wave tile, column l31.
+  // Stores are raw buffer stores relative to the tile's first output pixel: 32-bit offsets (one multiply per
+  // wtile instead of 64-bit address arithmetic per store), the +1 pixel / +1 row neighbours through the scalar
+  // offset, and a lane that must not store gets an out-of-range offset instead of a branch around the store
+  // (the epilogue was 12 % of the kernel: 350 address instructions and 280 branch instructions per tile).
   {
+    const bool col_ok = ncol < g.cout;
     const int sc = A.pool ? 1 : 2;  // output pixels per wtile and direction
     auto wt_q = [&](int n, int ty, int tx) -> int { return (n * g.out_hs + sc * ty) * g.out_ws + sc * tx; };
     int q0;                          // uniform: first wtile of the block's tile
@@ -368,54 +368,54 @@ __global__ __launch_bounds__(256, 1) void wino_f32(const Args A) {
     }
     const size_t oo0 = ((size_t)g.out_lead + (size_t)q0) * g.out_cstride + g.out_choff;
     const i32x4 rout = make_rsrc(g.out + oo0, g.out_bytes - oo0 * 4);
-    const i32x4 rbias = make_rsrc(g.bias, (size_t)g.cout_pad * 4);
     const unsigned cs4 = (unsigned)g.out_cstride * 4, row4 = (unsigned)g.out_ws * cs4;
-    // this lane's wtile
-    const int t = mt * NT + arow;
-    const bool tok = t < A.T;
-    const int tc = min(t, A.T - 1);
-    const int sn = tc / TT, rem = tc - sn * TT;
-    const int sy = rem / A.TX, sx = rem - sy * A.TX;
-    const unsigned off = (unsigned)(wt_q(sn, sy, sx) - q0) * cs4;
-    const bool x1 = 2 * sx + 1 < A.W, y1 = 2 * sy + 1 < A.H;
-    const int cbase = nt * (32 * WN) + wn * 32 + 4 * kh;  // first channel of run 0
-    const float lo = A.relu ? 0.f : -__builtin_inff();
-    F4 bias4[4];
+    const unsigned col4 = (unsigned)ncol * 4;
 #pragma unroll
-    for (int qg = 0; qg < 4; ++qg) bias4[qg] = bload(rbias, (unsigned)(cbase + 8 * qg) * 4, 0);
-#pragma unroll
-    for (int qg = 0; qg < RTPOSE_EXP_W_EPI / 4; ++qg) {
-      const int ch = cbase + 8 * qg;
-      auto M = [&](int f) -> F4 {
-        return F4{f2{acc[f][4 * qg], acc[f][4 * qg + 1]}, f2{acc[f][4 * qg + 2], acc[f][4 * qg + 3]}};
-      };
-      F4 sv[4][2];
-#pragma unroll
-      for (int fy = 0; fy < 4; ++fy) {
-        const F4 m0 = M(fy * 4 + 0), m1 = M(fy * 4 + 1), m2 = M(fy * 4 + 2), m3 = M(fy * 4 + 3);
-        sv[fy][0] = add4(add4(m0, m1), m2);
-        sv[fy][1] = sub4p(sub4p(m1, m2), m3);
+    for (int rg = 0; rg < RTPOSE_EXP_W_EPI / 4; ++rg) {
+      // 4 consecutive wtiles: one division pair, then +1 steps with a branch-free wrap
+      int tcur = mt * NT + wm * 32 + rg * 8 + 4 * kh;
+      int sn = tcur / TT, sy, sx;
+      {
+        const int r = tcur - sn * TT;
+        sy = r / A.TX;
+        sx = r - sy * A.TX;
       }
-      float4 y[2][2];
 #pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        const float4 a0 = to_float4(add4(add4(add4(sv[0][x], sv[1][x]), sv[2][x]), bias4[qg]));
-        const float4 a1 = to_float4(add4(sub4p(sub4p(sv[1][x], sv[2][x]), sv[3][x]), bias4[qg]));
-        y[0][x] = make_float4(fmaxf(a0.x, lo), fmaxf(a0.y, lo), fmaxf(a0.z, lo), fmaxf(a0.w, lo));
-        y[1][x] = make_float4(fmaxf(a1.x, lo), fmaxf(a1.y, lo), fmaxf(a1.z, lo), fmaxf(a1.w, lo));
-      }
-      const bool ok = tok && ch < g.cout;  // cout is a multiple of 4 (host): a run is stored whole or not at all
-      const unsigned o = off + (unsigned)ch * 4;
-      if (A.pool) {  // H and W even: every wtile is one pooled pixel
-        auto mx = [](float a, float b, float c, float d) { return fmaxf(fmaxf(a, b), fmaxf(c, d)); };
-        const float4 v = make_float4(mx(y[0][0].x, y[0][1].x, y[1][0].x, y[1][1].x), mx(y[0][0].y, y[0][1].y, y[1][0].y, y[1][1].y),
-                                     mx(y[0][0].z, y[0][1].z, y[1][0].z, y[1][1].z), mx(y[0][0].w, y[0][1].w, y[1][0].w, y[1][1].w));
-        bstore4(v, rout, ok ? o : kNoStore, 0);
-      } else {
-        bstore4(y[0][0], rout, ok ? o : kNoStore, 0);
-        bstore4(y[0][1], rout, (ok && x1) ? o : kNoStore, cs4);
-        bstore4(y[1][0], rout, (ok && y1) ? o : kNoStore, row4);
-        bstore4(y[1][1], rout, (ok && x1 && y1) ? o : kNoStore, row4 + cs4);
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = rg * 4 + rr;
+        float s[4][2];
+#pragma unroll
+        for (int fy = 0; fy < 4; ++fy) {
+          s[fy][0] = acc[fy * 4 + 0][r] + acc[fy * 4 + 1][r] + acc[fy * 4 + 2][r];
+          s[fy][1] = acc[fy * 4 + 1][r] - acc[fy * 4 + 2][r] - acc[fy * 4 + 3][r];
+        }
+        float y[2][2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          y[0][x] = s[0][x] + s[1][x] + s[2][x];
+          y[1][x] = s[1][x] - s[2][x] - s[3][x];
+        }
+        if (A.relu) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[i >> 1][i & 1] = fmaxf(y[i >> 1][i & 1], 0.f);
+        }
+        const bool ok = col_ok && tcur < A.T;
+        const unsigned off = (unsigned)(wt_q(sn, sy, sx) - q0) * cs4 + col4;
+        if (A.pool) {  // H and W even: every wtile is one pooled pixel
+          const float v = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+          bstore(v, rout, ok ? off : kNoStore, 0);
+        } else {
+          const bool x1 = 2 * sx + 1 < A.W, y1 = 2 * sy + 1 < A.H;
+          bstore(y[0][0], rout, ok ? off : kNoStore, 0);
+          bstore(y[0][1], rout, (ok && x1) ? off : kNoStore, cs4);
+          bstore(y[1][0], rout, (ok && y1) ? off : kNoStore, row4);
+          bstore(y[1][1], rout, (ok && x1 && y1) ? off : kNoStore, row4 + cs4);
+        }
+        ++tcur;  // next wtile of the group
+        const bool wx = sx + 1 >= A.TX, wy = wx && sy + 1 >= A.TY;
+        sx = wx ? 0 : sx + 1;
+        sy = wy ? 0 : (wx ? sy + 1 : sy);
+        sn += wy ? 1 : 0;
       }
     }
   }
@@ -507,7 +507,11 @@ __global__ __launch_bounds__(256, 1) void wino3s_f32(const Args A) {
   for (int f = 0; f < 4; ++f)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-  const float bias0 = g.bias[ncol];  // padded to cout_pad; added after the output transform, as in wino_f32
+  if (wv == 1) {  // the bias rides in frequency (1,1) = 5
+    const float b0 = g.bias[ncol];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[1][r] = b0;
+  }
   const unsigned boff = (unsigned)((kh * g.cout_pad + ncol) * 16);
   const unsigned cgstep = (unsigned)(g.cout_pad * 16);  // bytes per channel group plane
   const unsigned fstep = (unsigned)CG * cgstep;         // bytes per frequency
@@ -621,8 +625,8 @@ __global__ __launch_bounds__(256, 1) void wino3s_f32(const Args A) {
       float y[2][2];
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
-        y[0][x] = s[0][x] + s[1][x] + s[2][x] + bias0;
-        y[1][x] = s[1][x] - s[2][x] - s[3][x] + bias0;
+        y[0][x] = s[0][x] + s[1][x] + s[2][x];
+        y[1][x] = s[1][x] - s[2][x] - s[3][x];
       }
       if (A.relu) {
 #pragma unroll
@@ -744,9 +748,9 @@ extern "C" int rtpose_debug_timeline_w3_dump(unsigned long long* host, unsigned 
 // channel chunk of a conv: 16, or 8 where the input has only a multiple of 8 channels and the block is the 64 x 64 one
 static int wino_ck(int cout, int cin) { return (cout_pad(cout) % 128 == 0 || cin % 16 == 0) ? 16 : 8; }
 
-// (cout a multiple of 4: the epilogue stores runs of 4 channels; at least two chunks: the chunk pipeline)
+// (at least two chunks: the chunk pipeline of wino_f32 fetches two chunks ahead, across tiles)
 int conv2d_wino_ok(int cin, int cout, int k) {
-  return k == 3 && cin > 0 && cout > 0 && cout % 4 == 0 && cin % wino_ck(cout, cin) == 0 && cin / wino_ck(cout, cin) >= 2;
+  return k == 3 && cin > 0 && cin % wino_ck(cout, cin) == 0 && cin / wino_ck(cout, cin) >= 2;
 }
 
 int conv2d_wino_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s) {

@@ -26,15 +26,6 @@ __device__ __forceinline__ F4 mul4(float s, F4 a) {
 }
 __device__ __forceinline__ F4 add4(F4 a, F4 b) { return F4{a.lo + b.lo, a.hi + b.hi}; }
 __device__ __forceinline__ F4 sub4(F4 a, F4 b) { return F4{a.lo - b.lo, a.hi - b.hi}; }
-// a - b in ONE packed instruction (the compiler splits a packed subtraction into two v_sub_f32 whenever the
-// operands do not come out of a packed producer; same bits either way).  For straight-line code outside the pinned
-// multiply loops (the output transforms).
-__device__ __forceinline__ f2 pk_sub(f2 a, f2 b) {
-  f2 d;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-__device__ __forceinline__ F4 sub4p(F4 a, F4 b) { return F4{pk_sub(a.lo, b.lo), pk_sub(a.hi, b.hi)}; }
 __device__ __forceinline__ float4 to_float4(F4 a) { return make_float4(a.lo.x, a.lo.y, a.hi.x, a.hi.y); }
 
 // Raw buffer loads: address = base (4 SGPRs) + per-lane byte offset (1 VGPR, fixed for the whole kernel) + uniform
@@ -71,12 +62,6 @@ __device__ void llvm_raw_buffer_store_f32(float v, i32x4 rsrc, int voffset, int 
 constexpr unsigned kNoStore = 0x7fffffffu;
 __device__ __forceinline__ void bstore(float v, i32x4 r, unsigned voff, unsigned soff) {
   llvm_raw_buffer_store_f32(v, r, (int)voff, (int)soff, 0);
-}
-__device__ void llvm_raw_buffer_store_v4f32(f32x4 v, i32x4 rsrc, int voffset, int soffset, int aux) __asm(
-    "llvm.amdgcn.raw.buffer.store.v4f32");
-// 16 bytes per lane (dword-aligned addresses suffice); masked like bstore
-__device__ __forceinline__ void bstore4(float4 v, i32x4 r, unsigned voff, unsigned soff) {
-  llvm_raw_buffer_store_v4f32(f32x4{v.x, v.y, v.z, v.w}, r, (int)voff, (int)soff, 0);
 }
 __device__ __forceinline__ F4 bload(i32x4 r, unsigned voff, unsigned soff) {
   const f32x4 v = llvm_raw_buffer_load_v4f32(r, (int)voff, (int)soff, 0);

@@ -150,7 +150,8 @@ def test_winograd_fits_is_host_only_logic(capi):
         d[0].lin = capi.Layout.padded(cin, h, w, k // 2)
         return lib.rtpose_conv2d_winograd_fits(d, n, h, w)
 
-    assert fits(3, 8, 128) == 0 and fits(3, 8, 64) == 1 and fits(3, 512, 512) == 1 and fits(1, 128, 128) == 0
+    assert fits(3, 8, 128) == 0 and fits(3, 24, 64) == 1 and fits(3, 512, 512) == 1 and fits(1, 128, 128) == 0
+    assert fits(3, 8, 64) == 0 and fits(3, 16, 128) == 0 and fits(3, 32, 128) == 1    # at least two chunks
     assert fits(7, 128, 128, 32) == 1 and fits(7, 192, 128, 32) == 1 and fits(7, 128, 128, 1) == 1
     assert fits(7, 128, 38) == 0 and fits(7, 100, 128) == 0 and fits(7, 128, 128, 1, 46, 46, pool=1) == 0
     assert fits(7, 128, 128, 2, 184, 184) == 0      # transformed rows of a 184-wide map do not fit the LDS

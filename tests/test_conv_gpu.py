@@ -220,9 +220,9 @@ WINO_CASES = [
     (1, 96, 80, 64, 64, 1, 1, 1, 1),       # conv1_2: 64 wtiles x 64 columns, 8-channel chunks, fused pool
     (1, 100, 92, 128, 256, 1, 0, 1, 1),    # conv3_1
     (2, 23, 17, 64, 128, 0, 0, 1, 0),      # odd H and W: the last wtile row / column is half outside
-    (1, 12, 10, 16, 24, 0, 0, 1, 0),       # tiny: one partial block, ragged cout
+    (1, 12, 10, 32, 24, 0, 0, 1, 0),       # tiny: one partial block, ragged cout (two chunks: the minimum)
     (5, 6, 6, 32, 40, 1, 1, 1, 3),         # wtile strips spanning several images + pool
-    (3, 7, 5, 8, 64, 1, 0, 2, 1),          # one 8-channel chunk (no double buffering to speak of)
+    (3, 7, 5, 24, 64, 1, 0, 2, 1),         # three 8-channel chunks (cin not a multiple of 16)
 ]
 
 
@@ -253,7 +253,8 @@ def test_winograd_rejects_what_it_cannot_do(capi, cuda):
         d[0].lin = capi.Layout.padded(cin, h, w, k // 2)
         return lib.rtpose_conv2d_winograd_fits(d, n, h, w)
 
-    assert fits(3, 8, 128) == 0 and fits(3, 8, 64) == 1 and fits(3, 512, 512) == 1 and fits(1, 128, 128) == 0
+    assert fits(3, 8, 128) == 0 and fits(3, 24, 64) == 1 and fits(3, 512, 512) == 1 and fits(1, 128, 128) == 0
+    assert fits(3, 8, 64) == 0 and fits(3, 16, 128) == 0 and fits(3, 32, 128) == 1    # at least two chunks
     assert fits(7, 128, 128, 32) == 1 and fits(7, 192, 128, 32) == 1
     assert fits(7, 128, 38) == 0            # 64 padded columns: the stage heads are 1x1 anyway
     assert fits(7, 128, 128, 2, 184, 184) == 0   # transformed rows of a 184-wide map do not fit the LDS
@@ -275,7 +276,7 @@ def test_winograd_random_geometries_match_direct(capi, cuda):
         k = rnd.choice((3, 7))
         n = rnd.choice((1, 2, 3, 5, 14))
         h, w = rnd.randint(3, 40), rnd.randint(3, 60)
-        cin = rnd.choice((16, 32, 48, 64)) if k == 3 else rnd.choice((8, 24, 64))
+        cin = rnd.choice((32, 48, 64, 96)) if k == 3 else rnd.choice((8, 24, 64))
         cout = rnd.choice((64, 128, 200)) if k == 3 else rnd.choice((128, 256))
         groups = rnd.choice((1, 2))
         relu = rnd.choice((0, 1))
