@@ -122,6 +122,18 @@ typedef struct rtpose_conv_desc {
 int rtpose_conv2d(const rtpose_conv_desc* d, int ngroups, int N, int H, int W,
                   void* stream);
 
+/* ---- the first layer: nn.Conv2d(3, 64, 3, 1, 1) (+ nn.ReLU), conv1_1 of the VGG-19 front end
+ * (lib/network/rtpose_vgg.py:23-35, `model0.0`; csrc/conv_first.hip).  Reads the image where it is -
+ * dense NCHW fp32 (`x_nchw`), or, with x_nchw = NULL, a layout buffer with >= 3 channels per pixel
+ * (`x_layout` / `lx`: the plan's NHWC8 input written by rtpose_preprocess_u8) - and writes 64 channels
+ * into `out` / `lout`: no NCHW -> NHWC conversion pass, no padding of the 3 input channels to 8.
+ * `w_packed` (rtpose_conv_first_packed_floats() floats) from rtpose_pack_conv_first(w [64,3,3,3], bias [64]). */
+size_t rtpose_conv_first_packed_floats(void);
+int rtpose_pack_conv_first(const float* w_oihw, const float* bias, float* w_packed, void* stream);
+int rtpose_conv_first(const float* x_nchw, const float* x_layout, const rtpose_layout* lx,
+                      const float* w_packed, float* out, const rtpose_layout* lout, int relu, int N,
+                      int H, int W, void* stream);
+
 /* ---- fp32 Winograd forms of the 3x3 and 7x7 convs (csrc/conv_wino.hip, csrc/conv_wino7.hip) ------
  * Same module boundary as rtpose_conv2d (nn.Conv2d + nn.ReLU (+ nn.MaxPool2d) of
  * lib/network/rtpose_vgg.py:23-35, :49-55, :108-127), fewer matrix-core multiplies:

@@ -1,0 +1,199 @@
+// The first layer of the VGG-19 front end for gfx950 (MI355X): conv1_1 = nn.Conv2d(3, 64, 3, 1, 1) + nn.ReLU
+// (lib/network/rtpose_vgg.py:23-35, `model0.0` of the state_dict), fp32, reading the image where the caller left
+// it: dense NCHW (rtpose_net_forward; the reference hands its module an NCHW tensor, rtpose_vgg.py:158) or the
+// NHWC8 input buffer the image-prep kernel filled (rtpose_net_forward_prepared).
+//
+// Why its own kernel: K = 27 (3 channels x 9 taps) is no contraction to speak of - 0.23 GMAC per image against the
+// 1.1 GB the layer WRITES for a 32-image batch.  The generic implicit-GEMM kernel (conv_mfma.hip) ran it on 8 padded
+// channels at 0.50 ms after a separate 0.10 ms NCHW -> NHWC8 pass; its bound is the HBM write, 1.11 GB / ~4.5 TB/s =
+// 0.25 ms.  Here one block owns an 8 x 32 pixel tile of one image: the 3 x 10 x 34 halo is fetched once from the
+// image (masked loads give the zero padding), the 27 taps are the K dimension of v_mfma_f32_32x32x2_f32 directly
+// (K = 28, one zero row), the 28 x 64 filter matrix lives in registers (28 values per lane), the A operand of a step
+// is ONE ds_read_b32 per lane at a compile-time offset, and a wave's 2 rows x 64 channels leave as 128-byte runs per
+// pixel (lane = channel).  No im2col buffer, no layout conversion pass, no 8-channel padding of the input.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace rtpose {
+
+namespace first {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int TH = 8, TW = 32;        // pixel tile of a block (4 waves x 2 rows)
+constexpr int HH = TH + 2, WW = TW + 2;
+constexpr int KS = 14;                // K = 28 in steps of 2
+
+struct Args {
+  const float* x_nchw;    // dense [N, 3, H, W], or NULL: read `x_lay` below
+  const float* x_lay;     // shared-gap NHWC buffer with >= 3 channels per pixel (the plan's NHWC8 input)
+  int xl_cstride, xl_choff, xl_ws, xl_hs, xl_lead;
+  const float* wp;        // packed filters [2 k halves][32 lanes][2 column halves][14 steps] (pack_first_kernel)
+  const float* bias;      // 64 floats
+  float* out;
+  int o_cstride, o_choff, o_ws, o_hs, o_lead;
+  int N, H, W, relu, tiles_x, tiles_y;
+};
+
+// k = c * 9 + dy * 3 + dx (k = 27: the zero row) -> offset of the tap in the LDS halo [3][HH][WW]
+__host__ __device__ constexpr int tap_off(int k) {
+  return k >= 27 ? 0 : ((k / 9) * HH + (k % 9) / 3) * WW + (k % 3);
+}
+
+__global__ __launch_bounds__(256) void conv_first_kernel(const Args A) {
+  __shared__ float halo[3 * HH * WW];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, kh = lane >> 5;
+  int b = blockIdx.x;
+  const int tx = b % A.tiles_x;
+  b /= A.tiles_x;
+  const int ty = b % A.tiles_y, n = b / A.tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+
+  // ---- halo: rows y0 - 1 .. y0 + TH, columns x0 - 1 .. x0 + TW of the 3 channels; outside the image = 0 ----
+  for (int i = tid; i < 3 * HH * WW; i += 256) {
+    const int c = i / (HH * WW), r = i - c * (HH * WW);
+    const int yy = y0 - 1 + r / WW, xx = x0 - 1 + r % WW;
+    float v = 0.f;
+    if (yy >= 0 && yy < A.H && xx >= 0 && xx < A.W) {
+      v = A.x_nchw ? A.x_nchw[((size_t)(n * 3 + c) * A.H + yy) * A.W + xx]
+                   : A.x_lay[((size_t)A.xl_lead + (size_t)(n * A.xl_hs + yy) * A.xl_ws + xx) * A.xl_cstride + A.xl_choff + c];
+    }
+    halo[i] = v;
+  }
+  // ---- filters: 28 values per lane (k = 2 step + kh, column = half * 32 + l31), bias in the accumulators ----
+  float wv[2][KS];
+  {
+    const float4* w4 = reinterpret_cast<const float4*>(A.wp + (size_t)(kh * 32 + l31) * (2 * KS));
+#pragma unroll
+    for (int q = 0; q < 2 * KS / 4; ++q) {
+      const float4 t = w4[q];
+      const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wv[(4 * q + e) / KS][(4 * q + e) % KS] = tv[e];
+    }
+  }
+  floatx16 acc[2][2];  // [row of the wave][column half]
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    const float b0 = A.bias[nh * 32 + l31];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nh][r] = b0;
+  }
+  __syncthreads();
+
+  // ---- 14 K steps: A = halo[tap(2 step + kh)] at (row 2 wave + mt, pixel l31) ----------------------------
+  const float* hb = halo + (2 * wave) * WW + l31;
+#pragma unroll
+  for (int st = 0; st < KS; ++st) {
+    const int off = kh ? tap_off(2 * st + 1) : tap_off(2 * st);
+    const float a0 = hb[off], a1 = hb[off + WW];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      acc[0][nh] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, wv[nh][st], acc[0][nh], 0, 0, 0);
+      acc[1][nh] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, wv[nh][st], acc[1][nh], 0, 0, 0);
+    }
+  }
+
+  // ---- store: register r of a lane = pixel x0 + (r / 4) * 8 + 4 kh + r % 4 of the row, channel half * 32 + l31 ----
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int y = y0 + 2 * wave + mt;
+    if (y >= A.H) continue;
+    float* orow = A.out + ((size_t)A.o_lead + (size_t)(n * A.o_hs + y) * A.o_ws + x0) * A.o_cstride + A.o_choff + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int px = (r >> 2) * 8 + 4 * kh + (r & 3);
+      if (x0 + px < A.W) {
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          const float v = acc[mt][nh][r];
+          orow[(size_t)px * A.o_cstride + nh * 32] = A.relu ? fmaxf(v, 0.f) : v;
+        }
+      }
+    }
+  }
+}
+
+// w[64][3][3][3] (OIHW) -> wp[kh][l31][half][step] = w[half * 32 + l31][k = 2 step + kh] (k = 27: 0); bias copied
+__global__ void pack_first_kernel(const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ wp,
+                                  float* __restrict__ bp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 64) bp[i] = bias ? bias[i] : 0.f;
+  if (i >= 2 * 32 * 2 * KS) return;
+  const int st = i % KS, nh = (i / KS) % 2, l31 = (i / (2 * KS)) % 32, kh = i / (2 * KS * 32);
+  const int k = 2 * st + kh, o = nh * 32 + l31;
+  wp[i] = k < 27 ? w[o * 27 + k] : 0.f;
+}
+
+}  // namespace first
+
+size_t conv_first_packed_floats() { return (size_t)2 * 32 * 2 * first::KS + 64; }
+
+int conv_first_pack_launch(const float* w_oihw, const float* bias, float* wp, hipStream_t s) {
+  hipLaunchKernelGGL(first::pack_first_kernel, dim3(ceil_div(2 * 32 * 2 * first::KS, 256)), dim3(256), 0, s, w_oihw, bias,
+                     wp, wp + 2 * 32 * 2 * first::KS);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// x_nchw != NULL: dense NCHW source; else the layout `lx` on `x_lay` (>= 3 channels per pixel)
+int conv_first_launch(const float* x_nchw, const float* x_lay, const rtpose_layout* lx, const float* wp, float* out,
+                      const rtpose_layout* lo, int relu, int N, int H, int W, hipStream_t s) {
+  using namespace first;
+  if ((!x_nchw && (!x_lay || !lx)) || !wp || !out || !lo || N <= 0 || H <= 0 || W <= 0)
+    return fail(RTPOSE_E_INVAL, "conv_first: bad arguments");
+  if (lo->choff + 64 > lo->cstride) return fail(RTPOSE_E_INVAL, "conv_first: output slice exceeds cstride");
+  Args a;
+  memset(&a, 0, sizeof(a));
+  a.x_nchw = x_nchw;
+  a.x_lay = x_lay;
+  if (lx) {
+    a.xl_cstride = lx->cstride;
+    a.xl_choff = lx->choff;
+    a.xl_ws = lx->ws;
+    a.xl_hs = lx->hs;
+    a.xl_lead = lx->lead;
+  }
+  a.wp = wp;
+  a.bias = wp + 2 * 32 * 2 * KS;
+  a.out = out;
+  a.o_cstride = lo->cstride;
+  a.o_choff = lo->choff;
+  a.o_ws = lo->ws;
+  a.o_hs = lo->hs;
+  a.o_lead = lo->lead;
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.relu = relu;
+  a.tiles_x = ceil_div(W, TW);
+  a.tiles_y = ceil_div(H, TH);
+  const long blocks = (long)N * a.tiles_x * a.tiles_y;
+  if (blocks > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv_first: grid too large");
+  hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace rtpose
+
+extern "C" {
+
+size_t rtpose_conv_first_packed_floats(void) { return rtpose::conv_first_packed_floats(); }
+
+int rtpose_pack_conv_first(const float* w_oihw, const float* bias, float* w_packed, void* stream) {
+  if (!w_oihw || !w_packed) return rtpose::fail(RTPOSE_E_INVAL, "pack_conv_first: NULL argument");
+  return rtpose::conv_first_pack_launch(w_oihw, bias, w_packed, rtpose::as_stream(stream));
+}
+
+int rtpose_conv_first(const float* x_nchw, const float* x_layout, const rtpose_layout* lx, const float* w_packed,
+                      float* out, const rtpose_layout* lout, int relu, int N, int H, int W, void* stream) {
+  return rtpose::conv_first_launch(x_nchw, x_layout, lx, w_packed, out, lout, relu, N, H, W, rtpose::as_stream(stream));
+}
+
+}  // extern "C"

@@ -37,6 +37,11 @@ int pack_weights_wino7_launch(const float* w, const float* bias, int cout, int c
                               int cin_packed, int fm, float* wp, float* bp, hipStream_t s);
 int wino_amplification_launch(const float* w, int cout, int cin, int k, int fm, float* amp, hipStream_t s);
 int wino7_default_fm();
+// conv1_1 (conv_first.hip)
+size_t conv_first_packed_floats();
+int conv_first_pack_launch(const float* w_oihw, const float* bias, float* wp, hipStream_t s);
+int conv_first_launch(const float* x_nchw, const float* x_lay, const rtpose_layout* lx, const float* wp, float* out,
+                      const rtpose_layout* lo, int relu, int N, int H, int W, hipStream_t s);
 int pack_weights_launch(const float* w, const float* bias, int cout, int cin_src, int k,
                         const int32_t* cin_map, int cin_packed, float* wp, float* bp, hipStream_t s);
 // bf16 path (conv_mfma_bf16.hip)
@@ -65,6 +70,8 @@ struct ConvW {
   // fp32 plans.  The arena holds EVERY packing a plan may run the conv in (it is shared by all plans of a module,
   // whatever their geometry and options): the direct one at w_off, and - where the form has a kernel for these
   // channel counts - F(2x2,3x3) at w_off_w3, F(4,7) / F(6,7) at w_off_w4 / w_off_w6.
+  bool first = false;      // conv1_1 (3 -> 64, 3x3): its own kernel, packing at w_off_first (csrc/conv_first.hip)
+  size_t w_off_first = 0;
   bool has_w3 = false, has_w7 = false;
   size_t w_off_w3 = 0, w_off_w4 = 0, w_off_w6 = 0;
   size_t amp_off = 0;      // 3 floats in the arena: amplification estimates in F(2x2,3x3) / F(4,7) / F(6,7) (0 = n/a)
@@ -191,6 +198,8 @@ int add_conv_w(rtpose_net* n, const std::string& name, int cout, int cin, int k,
       c.w_off_w6 = take(packed_weight_floats_wino7(cout, c.cin_packed, 6));
     }
     c.amp_off = take(4);
+    c.first = k == 3 && cin == 3 && cout == 64;
+    if (c.first) c.w_off_first = take(conv_first_packed_floats());
   }
   c.b_off = take(rtpose_packed_bias_floats(cout));
   n->convs.push_back(c);
@@ -579,6 +588,10 @@ int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw, const fl
   int rc = pack_weights_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed, net->wt + c.w_off,
                                net->wt + c.b_off, s);
   if (rc) return rc;
+  if (c.first) {
+    rc = conv_first_pack_launch(w_oihw, bias, net->wt + c.w_off_first, s);
+    if (rc) return rc;
+  }
   float* amp = net->wt + c.amp_off;
   RTPOSE_HIP_CHECK(hipMemsetAsync(amp, 0, 4 * sizeof(float), s));
   if (c.has_w3) {
@@ -827,6 +840,9 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
           break;
         }
         if (!x_nchw) break;  // forward_prepared: the input buffer was written by the caller
+        // fp32 plans: conv1_1 reads the NCHW image itself (conv_first.hip) when it runs in the same call; the
+        // conversion remains for graph replay, whose captured launch list reads the plan's own input buffer
+        if (last > 1 && net->convs[net->ops[1].conv_idx[0]].first) break;
         rc = rtpose_nchw_to_layout(x_nchw, net->ws + b.off_floats, &b.lay, 3, 8, N, o.H, o.W, stream);
         break;
       }
@@ -857,6 +873,13 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
           d[g].relu = o.relu;
           d[g].pool = o.pool;
           d[g].out_cmap = nullptr;
+        }
+        if (!net->bf16 && net->convs[o.conv_idx[0]].first) {
+          const ConvW& c = net->convs[o.conv_idx[0]];
+          const bool direct_src = x_nchw && first == 0;  // the image itself; else the plan's NHWC8 input buffer
+          rc = conv_first_launch(direct_src ? x_nchw : nullptr, d[0].in, &d[0].lin, net->wt + c.w_off_first, d[0].out,
+                                 &d[0].lout, o.relu, N, o.H, o.W, s);
+          break;
         }
         const int form = net->convs[o.conv_idx[0]].form;  // grouped convs run one form (pick_forms)
         rc = net->bf16   ? conv2d_bf16_launch(d, o.ngroups, N, o.H, o.W, o.out_f32, net->split, s)

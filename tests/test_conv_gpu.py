@@ -305,3 +305,37 @@ def test_conv_rejects_bad_geometry(capi, cuda):
     d[0].cin = 16
     assert lib.rtpose_conv2d(d, 1, 1, 8, 8, None) != 0
     assert "k must be" in capi.last_error()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 72), (1, 37, 45), (3, 8, 8), (1, 368, 368)])
+def test_first_layer_kernel_matches_torch_cpu_from_both_sources(capi, cuda, shape):
+    """conv1_1 (3 -> 64, 3x3, pad 1) + ReLU (csrc/conv_first.hip) against torch's CPU conv2d, reading the image as
+    dense NCHW and from an NHWC8 layout buffer (the two sources the executor feeds it from): same bits both ways,
+    gaps of the output layout untouched, ragged tiles (H, W not multiples of 8 / 32)."""
+    lib, Layout = capi.lib, capi.Layout
+    n, h, w = shape
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    x = torch.rand(n, 3, h, w, generator=g) - 0.5
+    wt = torch.randn(64, 3, 3, 3, generator=g) * (2.0 / 27) ** 0.5
+    b = torch.randn(64, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, wt, b, padding=1))
+    stream = capi.current_stream()
+    wp = torch.zeros(lib.rtpose_conv_first_packed_floats(), device=cuda)
+    capi.check(lib.rtpose_pack_conv_first(capi.ptr(wt.to(cuda)), capi.ptr(b.to(cuda)), capi.ptr(wp), stream))
+    lout = Layout.padded(64 + 5, h, w, 1, choff=3)
+    outs = []
+    xd = x.contiguous().to(cuda)
+    lin = Layout.padded(8, h, w, 1)
+    xin = torch.zeros(lib.rtpose_layout_pixels(C.byref(lin), n, h, w) * 8, device=cuda)
+    capi.check(lib.rtpose_nchw_to_layout(capi.ptr(xd), capi.ptr(xin), C.byref(lin), 3, 8, n, h, w, stream))
+    for src in ("nchw", "layout"):
+        obuf = torch.zeros(lib.rtpose_layout_pixels(C.byref(lout), n, h, w) * (64 + 5), device=cuda)
+        capi.check(lib.rtpose_conv_first(capi.ptr(xd) if src == "nchw" else None, capi.ptr(xin), C.byref(lin), capi.ptr(wp),
+                                         capi.ptr(obuf), C.byref(lout), 1, n, h, w, stream), "rtpose_conv_first")
+        o = torch.empty(n, 64, h, w, device=cuda)
+        capi.check(lib.rtpose_layout_to_nchw(capi.ptr(obuf), C.byref(lout), capi.ptr(o), 64, n, h, w, stream))
+        torch.cuda.synchronize()
+        assert abs(obuf.abs().sum().item() - o.abs().sum().item()) <= 1e-3 * max(1.0, o.abs().sum().item())
+        outs.append(o.cpu())
+    assert (outs[0] - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
+    assert torch.equal(outs[0], outs[1])
