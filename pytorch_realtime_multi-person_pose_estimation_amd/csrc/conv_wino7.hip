@@ -206,19 +206,33 @@ struct Xform {
 // unsplit one: the block with the first chunks (cb == 0, ce < all) saves its raw accumulators to scratch slot
 // `slot` and raises the flag; the block with the last chunks (cb > 0) starts from them instead of from zero and
 // stores the tile.  Results are bit-identical however the launch is cut.
-template <int NI, int GXT, int FM>
+// FS = 2: the "two waves per SIMD" form.  A block has 8 waves; wave w = (fh = w / 4, wn = w % 4) owns the frequencies
+// [fh NFW, (fh + 1) NFW) of the wave tile wn (NFW = NFQ / 2 = 6 accumulators = 96 AGPRs, so two waves fit a SIMD's
+// 512 registers).  Every frequency sum still runs over chunks, ky and k pairs in the order of the 4-wave form and
+// of wino7s_f32: bit-identical results.  Why: a single wave issues a v_mfma_f32_32x32x2_f32 every ~71 cycles at
+// best (tools/exp/mfma_issue.hip; 65 with a second wave on the SIMD), and whatever else it issues - the transform's
+// VALU groups, LDS writes, waits - stops its MFMAs altogether; with a sibling the matrix pipe keeps running.  The input
+// transform is done by the waves 0..3 only (one per SIMD): the same number of VALU instructions per CU as before,
+// issued while the sibling multiplies.  The halves exchange their accumulators through LDS before the output
+// transform (each wave finishes 16 of the 32 positions).
+template <int NI, int GXT, int FM, int FS>
 __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const int mt, const int c, const int cb,
                                               const int ce, const int nch, const int slot) {
   using T = WT<FM>;
   // frequencies, +-point pairs, B register sets (F(6,7) with two transform items per thread: 3 sets, weights only 2
   // steps ahead - the registers go to the second item's 12 segments)
-  constexpr int NFQ = T::NFQ, NP = T::NP, NSETS = (FM == 6 && NI == 2) ? 3 : T::NSETS;
-  constexpr int NPS = 7 * NFQ / 2;                           // (ky, frequency pair) steps per chunk (NPS % NSETS == 0)
+  constexpr int NFQ = T::NFQ, NP = T::NP;
+  constexpr int NFW = NFQ / FS;                              // frequencies of a wave
+  static_assert(NFW % 2 == 0, "frequency pairs");
+  constexpr int NSETS = FS == 2 ? 3 : (FM == 6 && NI == 2) ? 3 : T::NSETS;
+  constexpr int NPS = 7 * NFW / 2;                           // (ky, frequency pair) steps per chunk (NPS % NSETS == 0)
   constexpr int PF = RTPOSE_EXP_W7_PF < NSETS ? RTPOSE_EXP_W7_PF : NSETS - 1;  // B prefetch distance in steps
   static_assert(NPS % NSETS == 0, "B register sets must rotate in step with the chunk");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = FS == 2 ? (wv & 3) : wv, fh = FS == 2 ? (wv >> 2) : 0;
+  const bool xf = wv < 4;  // this wave takes part in the input transform
   const int l31 = lane & 31, kh = lane >> 5;
   const int nt = c % A.ntiles, grp = c / A.ntiles;
   const Group g = grp ? A.g[1] : A.g[0];
@@ -259,19 +273,22 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
     const int t = min(t0 + l31, tlim - 1);  // positions past the end repeat the last one (not stored)
     const int n = t / PI, r = t - n * PI;
     const int y = r / GX, gx = r - y * GX;
-    abase = (n * g.in_hs + y - R0) * RS + kh * GX + gx;
+    abase = (n * g.in_hs + y - R0) * RS + kh * GX + gx + (fh * NFW) * CG * GX;  // this wave's first frequency
   }
   const int ncol = nt * 128 + wn * 32 + l31;
-  floatx16 acc[NFQ];
-  float* sp = A.scratch + ((size_t)(slot * 4 + wn) * (NFQ * 16)) * 64 + lane;  // this wave's rows of the scratch slot
+  floatx16 acc[NFW];
+  // this wave's rows of the scratch slot (frequency-major: the slot looks the same whichever form wrote it)
+  float* sp = A.scratch + ((size_t)(slot * 4 + wn) * (NFQ * 16) + (size_t)fh * NFW * 16) * 64 + lane;
   if (cb == 0) {
 #pragma unroll
-    for (int f = 0; f < NFQ; ++f)
+    for (int f = 0; f < NFW; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-    const float b0 = g.bias[ncol];  // padded to cout_pad
+    if (fh == 0) {
+      const float b0 = g.bias[ncol];  // padded to cout_pad
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[1][r] = b0;
+      for (int r = 0; r < 16; ++r) acc[1][r] = b0;
+    }
   } else {
     // Continue the sums the previous block started.  It saved them FIRST THING in its life, so the wait is a
     // formality provided block p - 1 is dispatched no later than block p - the order the hardware dispatches a 1-D
@@ -291,7 +308,7 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll
-    for (int f = 0; f < NFQ; ++f)
+    for (int f = 0; f < NFW; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[f][r] = sp[(f * 16 + r) * 64];
     __syncthreads();  // all reads done before the slot is handed back
@@ -299,18 +316,28 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   }
   const unsigned boff = (unsigned)((kh * g.cout_pad + ncol) * 16);
   const unsigned fstep = (unsigned)(CG * g.cout_pad * 16);  // bytes per frequency block
-  unsigned wso = (unsigned)cb * (2 * NPS) * fstep;          // uniform byte offset of the next B step to fetch
+  // uniform byte offset of the next B fragment to fetch: the packed filters are [chunk][ky][f]; a wave walks its own
+  // NFW frequencies of every ky (bnext advances it, skipping the sibling's frequencies)
+  unsigned wso = ((unsigned)cb * (7 * NFQ) + (unsigned)(fh * NFW)) * fstep;
+  int bl = 0;  // fragments fetched so far, modulo NFW (compile-time after unrolling)
+  auto bnext = [&](int& cnt) {
+    wso += fstep;
+    if (++cnt == NFW) {
+      cnt = 0;
+      if (FS > 1) wso += (unsigned)(NFQ - NFW) * fstep;
+    }
+  };
   float4 bs[NSETS][2];
 
+  if (xf) {
 #pragma unroll
-  for (int k = 0; k < NI; ++k)
+    for (int k = 0; k < NI; ++k)
 #pragma unroll
-    for (int n = 0; n < NFQ; ++n) load_piece(cb, k, n);
+      for (int n = 0; n < NFQ; ++n) load_piece(cb, k, n);
 #pragma unroll
-  for (int k = 0; k < NI; ++k)
+    for (int k = 0; k < NI; ++k)
 #pragma unroll
-    for (int gi = 0; gi < NP + 2; ++gi) tgroup(V4, k, gi);
-  {
+      for (int gi = 0; gi < NP + 2; ++gi) tgroup(V4, k, gi);
     const int c1 = min(cb + 1, ce - 1);
 #pragma unroll
     for (int k = 0; k < NI; ++k)
@@ -323,8 +350,9 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
 #pragma unroll
   for (int s = 0; s < PF; ++s) {
     bs[s][0] = bload_f4(rw, boff, wso);
-    bs[s][1] = bload_f4(rw, boff, wso + fstep);
-    wso += 2 * fstep;
+    bnext(bl);
+    bs[s][1] = bload_f4(rw, boff, wso);
+    bnext(bl);
   }
   __syncthreads();
 
@@ -335,7 +363,7 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   // filler slot after every second one.  Slot 0 / 1: the A fragments of the next step (LDS); slot 2 / 3: the B
   // fragments PF steps ahead (L2).  Slot 3 of the first steps also carries transform work of the NEXT chunk: its
   // 6 NI groups (steps 0..11), then the 10 NI segment loads of the chunk after that, two per step.
-  constexpr int NG = (NP + 2) * NI, GSTR = NI == 1 ? 2 : 1, LS = NG * GSTR;  // groups, their step stride, first load step
+  constexpr int NG = (NP + 2) * NI, GSTR = (NI == 1 && FS == 1) ? 2 : 1, LS = NG * GSTR;  // groups, their step stride, first load step
   constexpr int LPS = RTPOSE_EXP_W7_LPS, LSTEPS = (NFQ * NI + LPS - 1) / LPS;    // segment loads per step, steps with loads
   static_assert(LS + LSTEPS <= NPS, "transform work does not fit the steps of a chunk");
   float4 a[2][2];
@@ -347,7 +375,7 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
     a[0][1] = va[CG * GX];
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
-      const int fp = ps % (NFQ / 2);
+      const int fp = ps % (NFW / 2);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         {
@@ -360,14 +388,14 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
         RTPOSE_PIN();
         if (j < 2) {  // A of the next step (the first step of a chunk is read after the barrier)
           if (ps + 1 < NPS) {
-            const int kyn = (ps + 1) / (NFQ / 2), fn = 2 * ((ps + 1) % (NFQ / 2)) + j;
+            const int kyn = (ps + 1) / (NFW / 2), fn = 2 * ((ps + 1) % (NFW / 2)) + j;
             a[(ps + 1) & 1][j] = RTPOSE_EXP_A(va[kyn * RS + fn * CG * GX], a[ps & 1][j]);
           }
         } else {      // B PF steps ahead
           bs[(ps + PF) % NSETS][j - 2] = RTPOSE_EXP_B(bload_f4(rw, boff, wso), bs[ps % NSETS][j - 2]);
-          wso += fstep;
+          bnext(bl);
         }
-        if (RTPOSE_EXP_STAGE && j == 3) {
+        if (RTPOSE_EXP_STAGE && j == 3 && xf) {
           if (ps % GSTR == 0 && ps / GSTR < NG) {
             if (RTPOSE_EXP_W7_TMASK & 1) tgroup(vw, (ps / GSTR) / (NP + 2), (ps / GSTR) % (NP + 2));
           } else if (ps >= LS && ps < LS + LSTEPS && (RTPOSE_EXP_W7_TMASK & 2)) {  // LPS segment loads per step
@@ -388,7 +416,7 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   // ---- first part of a split tile: hand the sums over ------------------------------------------------
   if (ce < nch) {
 #pragma unroll
-    for (int f = 0; f < NFQ; ++f)
+    for (int f = 0; f < NFW; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sp[(f * 16 + r) * 64] = acc[f][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -401,7 +429,21 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   // accumulator register r of a lane = position (r / 4) * 8 + 4 kh + r % 4 of the block, column l31
   const bool col_ok = ncol < g.cout;
   float* out_base = g.out + g.out_choff + ncol;
-  int tcur = t0 + 4 * kh;
+  // FS = 2: wave (wn, fh) finishes the accumulator registers [8 fh, 8 fh + 8) = positions 16 fh .. 16 fh + 15 of the
+  // tile and gets the sibling's NFW frequencies of those registers through LDS (the V buffers are free now):
+  // E[wn][writer's fh][f][r % 8][lane]
+  constexpr int R0E = 16 / FS;  // registers a wave finishes
+  float* E = reinterpret_cast<float*>(V4);
+  if (FS == 2) {
+    float* ew = E + (size_t)((wn * 2 + fh) * NFW * 8) * 64 + lane;
+#pragma unroll
+    for (int f = 0; f < NFW; ++f)
+#pragma unroll
+      for (int rl = 0; rl < 8; ++rl) ew[(f * 8 + rl) * 64] = fh ? acc[f][rl] : acc[f][8 + rl];  // what the sibling finishes
+    __syncthreads();
+  }
+  const float* er = E + (size_t)((wn * 2 + (1 - fh)) * NFW * 8) * 64 + lane;
+  int tcur = t0 + (FS == 2 ? 16 * fh : 0) + 4 * kh;
   int sn = tcur / PI, sy, sx;
   {
     const int r = tcur - sn * PI;
@@ -409,12 +451,27 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
     sx = r - sy * GX;
   }
 #pragma unroll
-  for (int r = 0; r < RTPOSE_EXP_W_EPI; ++r) {
+  for (int rr = 0; rr < (RTPOSE_EXP_W_EPI < R0E ? RTPOSE_EXP_W_EPI : R0E); ++rr) {
+    const int r = rr;  // position stepping below depends on r % 4 only
+    float m[NFQ];
+    if (FS == 2) {
+      // (the two halves of the select are resolved per wave: fh is uniform)
+#pragma unroll
+      for (int f = 0; f < NFW; ++f) {
+        const float own = fh ? acc[f][8 + rr] : acc[f][rr];
+        const float oth = er[(f * 8 + rr) * 64];
+        m[f] = fh ? oth : own;
+        m[NFW + f] = fh ? own : oth;
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < NFQ; ++f) m[f] = acc[f % NFW][rr];
+    }
     float S[NP], D[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      S[p] = acc[2 * p + 1][r] + acc[2 * p + 2][r];
-      D[p] = acc[2 * p + 1][r] - acc[2 * p + 2][r];
+      S[p] = m[2 * p + 1] + m[2 * p + 2];
+      D[p] = m[2 * p + 1] - m[2 * p + 2];
     }
     // out_i = [i == 0] M_0 + sum_p p^i (S_p for even i, D_p for odd i) + [i == FM - 1] M_inf
     float y[FM];
@@ -428,8 +485,8 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
         for (int e = 0; e < i; ++e) pw[p] *= T::kPts[p];  // compile-time constant
         v = __builtin_fmaf(pw[p], (i & 1) ? D[p] : S[p], v);
       }
-      if (i == 0) v += acc[0][r];
-      if (i == FM - 1) v += acc[NFQ - 1][r];
+      if (i == 0) v += m[0];
+      if (i == FM - 1) v += m[NFQ - 1];
       y[i] = v;
     }
     if (col_ok && tcur < tlim) {
@@ -451,6 +508,7 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
       }
     }
   }
+  if (FS == 2) __syncthreads();  // the exchange area is the next segment's V buffer
 }
 
 // Grid: either one block per tile (persist = 0; XCD-aware order as in conv_mfma.hip), or - when there are at
@@ -461,8 +519,8 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
 // per tile).  Order inside a block: the FIRST chunks of its last tile first (saved for block p + 1), the whole
 // tiles, and the LAST chunks of its first tile at the very end, continuing the sums block p - 1 saved at its start:
 // nobody waits, and the sums run in the order of an unsplit tile.
-template <int NI, int GXT, int FM>
-__global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
+template <int NI, int GXT, int FM, int FS>
+__global__ __launch_bounds__(256 * FS, 1) void wino7_f32(const Args A) {
   extern __shared__ __attribute__((aligned(16))) float4 V4[];
   const int nch = A.cin / CK;
   long u0, u1;
@@ -505,7 +563,7 @@ __global__ __launch_bounds__(256, 1) void wino7_f32(const Args A) {
     }
     const int mt = tile / A.ncombo, c = tile - mt * A.ncombo;
     // slot: a block saves into its own, and continues from its predecessor's
-    wino7_segment<NI, GXT, FM>(A, V4, mt, c, cb, ce, nch, cb > 0 ? (int)blockIdx.x - 1 : (int)blockIdx.x);
+    wino7_segment<NI, GXT, FM, FS>(A, V4, mt, c, cb, ce, nch, cb > 0 ? (int)blockIdx.x - 1 : (int)blockIdx.x);
   }
 }
 
@@ -818,17 +876,20 @@ static int make_plan(int N, int H, int W, int hs, int fm, Plan* p) {
   return 0;
 }
 
-template <int NI, int GXT, int FM>
+template <int NI, int GXT, int FM, int FS = 1>
 static int launch_inst(const Args& a, dim3 grid, size_t lds, hipStream_t s) {
   static PerDeviceOnce attr_set;
   const int dev = current_device();
-  auto kern = wino7_f32<NI, GXT, FM>;
+  auto kern = wino7_f32<NI, GXT, FM, FS>;
   if (!attr_set.is_set(dev)) {
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set.set(dev);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  // FS = 2: the accumulator exchange of the epilogue (4 wave tiles x 2 halves x 6 frequencies x 8 registers x 64
+  // lanes) lives where the V buffers were
+  const size_t ex = FS == 2 ? (size_t)4 * 2 * (FM + 6) / 2 * 8 * 64 * sizeof(float) : 0;
+  hipLaunchKernelGGL(kern, grid, dim3(256 * FS), lds > ex ? lds : ex, s, a);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -1084,9 +1145,18 @@ int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
   }
   // 46-wide maps (368 x 368 inputs, BASELINE configs[1]): every LDS offset of the multiply loop is an immediate
   if (p.fm == 6) {
-    if (p.gx == 8 && p.tpi && p.ni == 1 && p.nrows == strip_rows(8))
-      return launch_inst<1, 8, 6>(a, grid, (size_t)2 * strip_rows(8) * row_stride(8, 12) * 16, s);
-    if (p.ni == 1) return launch_inst<1, 0, 6>(a, grid, p.lds, s);
+    // two waves per SIMD (8-wave blocks, the frequencies split between sibling waves: wino7_segment FS = 2) wherever
+    // a thread transforms one item per chunk; bit-identical to the 4-wave form (RTPOSE_W7_FS=1 in developer builds)
+    static int fs_env = -1;
+    if (fs_env < 0) {
+      const char* e = dev_env("RTPOSE_W7_FS");
+      fs_env = e ? atoi(e) : 2;
+    }
+    if (p.gx == 8 && p.tpi && p.ni == 1 && p.nrows == strip_rows(8)) {
+      const size_t lds8 = (size_t)2 * strip_rows(8) * row_stride(8, 12) * 16;
+      return fs_env == 2 ? launch_inst<1, 8, 6, 2>(a, grid, lds8, s) : launch_inst<1, 8, 6>(a, grid, lds8, s);
+    }
+    if (p.ni == 1) return fs_env == 2 ? launch_inst<1, 0, 6, 2>(a, grid, p.lds, s) : launch_inst<1, 0, 6>(a, grid, p.lds, s);
     return launch_inst<2, 0, 6>(a, grid, p.lds, s);
   }
   if (p.gx == 12 && p.tpi && p.ni == 1 && p.nrows == strip_rows(12))

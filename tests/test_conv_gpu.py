@@ -321,7 +321,8 @@ def test_first_layer_kernel_matches_torch_cpu_from_both_sources(capi, cuda, shap
     ref = F.relu(F.conv2d(x, wt, b, padding=1))
     stream = capi.current_stream()
     wp = torch.zeros(lib.rtpose_conv_first_packed_floats(), device=cuda)
-    capi.check(lib.rtpose_pack_conv_first(capi.ptr(wt.to(cuda)), capi.ptr(b.to(cuda)), capi.ptr(wp), stream))
+    wd, bd = wt.to(cuda), b.to(cuda)      # (named: a temporary would be freed - and its block reused - before the launch)
+    capi.check(lib.rtpose_pack_conv_first(capi.ptr(wd), capi.ptr(bd), capi.ptr(wp), stream))
     lout = Layout.padded(64 + 5, h, w, 1, choff=3)
     outs = []
     xd = x.contiguous().to(cuda)

@@ -233,7 +233,8 @@ def test_amplification_estimate_matches_its_definition(capi, cuda):
     for kind in ("he", "pos", "smooth"):
         for k, m in ((3, 0), (7, 4), (7, 6)):
             wts = _weights(kind, 24, 40, k, g)
-            capi.check(lib.rtpose_winograd_amplification(capi.ptr(wts.to(cuda)), 24, 40, k, m, capi.ptr(amp),
+            wd = wts.to(cuda)
+            capi.check(lib.rtpose_winograd_amplification(capi.ptr(wd), 24, 40, k, m, capi.ptr(amp),
                                                          capi.current_stream()))
             got, want = amp.item(), _amp_exact(wts, k, m)
             assert abs(got - want) <= 2e-3 * want, (kind, k, m, got, want)
