@@ -224,9 +224,11 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   constexpr int NFQ = T::NFQ, NP = T::NP;
   constexpr int NFW = NFQ / FS;                              // frequencies of a wave
   static_assert(NFW % 2 == 0, "frequency pairs");
-  constexpr int NSETS = FS == 2 ? 3 : (FM == 6 && NI == 2) ? 3 : T::NSETS;
+  constexpr int NSETS = FS == 2 ? RTPOSE_EXP_W7_FS2SETS : (FM == 6 && NI == 2) ? 3 : T::NSETS;
   constexpr int NPS = 7 * NFW / 2;                           // (ky, frequency pair) steps per chunk (NPS % NSETS == 0)
-  constexpr int PF = RTPOSE_EXP_W7_PF < NSETS ? RTPOSE_EXP_W7_PF : NSETS - 1;  // B prefetch distance in steps
+  // B prefetch distance in steps.  The 8-wave form needs the deepest ring it can have: a step is 8 MFMAs of the wave's
+  // own, and with 2 steps (3 sets) the layer took 0.603 ms, with 4 (7 sets) 0.527, with 6 0.522 (4-wave form: 0.544)
+  constexpr int PF = FS == 2 ? NSETS - 1 : (RTPOSE_EXP_W7_PF < NSETS ? RTPOSE_EXP_W7_PF : NSETS - 1);
   static_assert(NPS % NSETS == 0, "B register sets must rotate in step with the chunk");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
