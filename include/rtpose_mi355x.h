@@ -134,6 +134,16 @@ int rtpose_conv_first(const float* x_nchw, const float* x_layout, const rtpose_l
                       const float* w_packed, float* out, const rtpose_layout* lout, int relu, int N,
                       int H, int W, void* stream);
 
+/* ---- two pointwise convs back to back: nn.Conv2d(128, 128, 1) + nn.ReLU -> nn.Conv2d(128, cout2 <= 64, 1), the
+ * Mconv6 / Mconv7 pair that ends every stage-2..6 branch (lib/network/rtpose_vgg.py:120-127), as ONE launch
+ * (csrc/conv_tail.hip; `ngroups` <= 2 branches per grid).  d1[g] / d2[g] are rtpose_conv_desc of the two convs
+ * with the plain k = 1 packing (rtpose_pack_conv_weights); d1[g].out / lout are ignored - the 128-channel
+ * intermediate never leaves the CU - and d2[g] reads it.  Same sums, in the same order, as two rtpose_conv2d
+ * launches.  rtpose_conv1x1_pair_fits: 1 if the pair has this shape. */
+int rtpose_conv1x1_pair_fits(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int ngroups);
+int rtpose_conv1x1_pair(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int ngroups, int N,
+                        int H, int W, void* stream);
+
 /* ---- fp32 Winograd forms of the 3x3 and 7x7 convs (csrc/conv_wino.hip, csrc/conv_wino7.hip) ------
  * Same module boundary as rtpose_conv2d (nn.Conv2d + nn.ReLU (+ nn.MaxPool2d) of
  * lib/network/rtpose_vgg.py:23-35, :49-55, :108-127), fewer matrix-core multiplies:

@@ -99,6 +99,8 @@ _SIGS = {
     "rtpose_packed_bias_floats": (_sz, [_i]),
     "rtpose_pack_conv_weights": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "rtpose_conv2d": (_i, [C.POINTER(ConvDesc), _i, _i, _i, _i, _vp]),
+    "rtpose_conv1x1_pair_fits": (_i, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _i]),
+    "rtpose_conv1x1_pair": (_i, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _i, _i, _i, _i, _vp]),
     "rtpose_conv_first_packed_floats": (_sz, []),
     "rtpose_pack_conv_first": (_i, [_vp, _vp, _vp, _vp]),
     "rtpose_conv_first": (_i, [_vp, _vp, _LP, _vp, _vp, _LP, _i, _i, _i, _i, _vp]),

@@ -235,6 +235,11 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = FS == 2 ? (wv & 3) : wv, fh = FS == 2 ? (wv >> 2) : 0;
   const bool xf = wv < 4;  // this wave takes part in the input transform
+#if RTPOSE_EXP_W7_PRIO == 1
+  if (FS == 2 && xf) __builtin_amdgcn_s_setprio(1);
+#elif RTPOSE_EXP_W7_PRIO == 2
+  if (FS == 2 && !xf) __builtin_amdgcn_s_setprio(1);
+#endif
   const int l31 = lane & 31, kh = lane >> 5;
   const int nt = c % A.ntiles, grp = c / A.ntiles;
   const Group g = grp ? A.g[1] : A.g[0];

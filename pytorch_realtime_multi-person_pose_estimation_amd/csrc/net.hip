@@ -37,6 +37,9 @@ int pack_weights_wino7_launch(const float* w, const float* bias, int cout, int c
                               int cin_packed, int fm, float* wp, float* bp, hipStream_t s);
 int wino_amplification_launch(const float* w, int cout, int cin, int k, int fm, float* amp, hipStream_t s);
 int wino7_default_fm();
+// Mconv6 + Mconv7 of a stage as one launch (conv_tail.hip)
+int conv_tail_launch(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int ngroups, int N, int H, int W,
+                     hipStream_t s);
 // conv1_1 (conv_first.hip)
 size_t conv_first_packed_floats();
 int conv_first_pack_launch(const float* w_oihw, const float* bias, float* wp, hipStream_t s);
@@ -81,7 +84,7 @@ struct ConvW {
   size_t w_off = 0, b_off = 0;  // float offsets in the weight arena
 };
 
-enum OpKind { OP_INPUT, OP_CONV, OP_POOL, OP_COPY };
+enum OpKind { OP_INPUT, OP_CONV, OP_POOL, OP_COPY, OP_TAIL };
 
 struct Op {
   OpKind kind;
@@ -90,6 +93,7 @@ struct Op {
   // conv
   int ngroups = 0;
   int conv_idx[2] = {-1, -1};
+  int conv2_idx[2] = {-1, -1};  // OP_TAIL: the second conv of the back-to-back pair
   int in_buf[2] = {-1, -1}, out_buf[2] = {-1, -1};
   int in_choff[2] = {0, 0}, out_choff[2] = {0, 0};
   int relu = 0, pool = 0;
@@ -421,11 +425,32 @@ void build_plan(rtpose_net* n) {
     int u0[2] = {U[0][0], U[1][0]};
     ci[0] = cws[0][s - 2][0]; ci[1] = cws[1][s - 2][0];
     add_conv_op(n, H3, W3, 2, ci, in0, zz, u0, zz, 1, 0);
-    for (int i = 1; i < 6; ++i) {
+    for (int i = 1; i < (n->bf16 ? 6 : 5); ++i) {
       const int ui[2] = {U[0][i - 1], U[1][i - 1]};
       const int uo[2] = {U[0][i], U[1][i]};
       ci[0] = cws[0][s - 2][i]; ci[1] = cws[1][s - 2][i];
       add_conv_op(n, H3, W3, 2, ci, ui, zz, uo, zz, 1, 0);
+    }
+    if (!n->bf16) {
+      // fp32: Mconv6 (128 -> 128, ReLU) + Mconv7 (128 -> 38 | 19) of both branches as ONE back-to-back launch
+      // (conv_tail.hip): the 128-channel intermediate never leaves the CU
+      const int ui4[2] = {U[0][4], U[1][4]};
+      const int outb[2] = {cout_buf, cout_buf};
+      ci[0] = cws[0][s - 2][6]; ci[1] = cws[1][s - 2][6];
+      add_conv_op(n, H3, W3, 2, ci, ui4, zz, outb, head_off, 0, 0);
+      Op& t = n->ops.back();
+      t.kind = OP_TAIL;
+      t.ks = 1;
+      for (int b = 0; b < 2; ++b) {
+        t.conv2_idx[b] = t.conv_idx[b];
+        t.conv_idx[b] = cws[b][s - 2][5];
+        const ConvW& c1 = n->convs[t.conv_idx[b]];
+        t.flops += 2.0 * n->N * H3 * W3 * (double)c1.cout * c1.cin_src;
+      }
+      t.name = n->convs[t.conv_idx[0]].name + "+" + n->convs[t.conv2_idx[0]].name + "|" +
+               n->convs[t.conv_idx[1]].name + "+" + n->convs[t.conv2_idx[1]].name;
+      add_simple_op(n, OP_COPY, "save" + std::to_string(s), H3, W3, cout_buf, kCatPaf, n->save_buf[s - 1], 0, 57);
+      continue;
     }
     const int ui[2] = {U[0][5], U[1][5]};
     ci[0] = cws[0][s - 2][6]; ci[1] = cws[1][s - 2][6];
@@ -691,6 +716,12 @@ int rtpose_net_launch_executed_flops(const rtpose_net* net, int i, double* flops
   const Op& o = net->ops[i];
   double fl = 0.0;
   int wino = 0;
+  if (o.kind == OP_TAIL)
+    for (int g = 0; g < o.ngroups; ++g)
+      for (int ci : {o.conv_idx[g], o.conv2_idx[g]}) {
+        const ConvW& c = net->convs[ci];
+        fl += 2.0 * net->N * o.H * o.W * (double)c.cin_packed * cout_pad(c.cout);
+      }
   if (o.kind == OP_CONV)
     for (int g = 0; g < o.ngroups; ++g) {
       // what the matrix pipe is issued (SQ_INSTS_MFMA x 4096 of a launch): whole tiles, padded channels and columns
@@ -714,7 +745,7 @@ int rtpose_net_launch_info(rtpose_net* net, int i, float* ms, int* k, double* fl
                            int name_cap) {
   if (!net || i < 0 || i >= (int)net->ops.size()) return fail(RTPOSE_E_INVAL, "launch_info: bad index");
   const Op& o = net->ops[i];
-  if (k) *k = o.kind == OP_CONV ? o.ks : 0;
+  if (k) *k = (o.kind == OP_CONV || o.kind == OP_TAIL) ? o.ks : 0;
   if (flops) *flops = o.flops;
   if (name && name_cap > 0) snprintf(name, name_cap, "%s", o.name.c_str());
   if (ms) {
@@ -887,6 +918,33 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
              : form      ? conv2d_wino7_launch(d, o.ngroups, N, o.H, o.W, form, net->ws + net->scratch_off,
                                                net->scratch_bytes, s)
                          : conv2d_launch(d, o.ngroups, N, o.H, o.W, s);
+        break;
+      }
+      case OP_TAIL: {
+        rtpose_conv_desc d1[2], d2[2];
+        for (int g = 0; g < o.ngroups; ++g) {
+          const ConvW &c1 = net->convs[o.conv_idx[g]], &c2 = net->convs[o.conv2_idx[g]];
+          const Buf& bi = net->bufs[o.in_buf[g]];
+          const Buf& bo = net->bufs[o.out_buf[g]];
+          memset(&d1[g], 0, sizeof(d1[g]));
+          memset(&d2[g], 0, sizeof(d2[g]));
+          d1[g].in = net->ws + bi.off_floats;
+          d1[g].lin = slice(bi, o.in_choff[g]);
+          d1[g].w_packed = net->wt + c1.w_off;
+          d1[g].bias_packed = net->wt + c1.b_off;
+          d1[g].cin = c1.cin_packed;
+          d1[g].cout = c1.cout;
+          d1[g].k = 1;
+          d1[g].relu = 1;
+          d2[g].w_packed = net->wt + c2.w_off;
+          d2[g].bias_packed = net->wt + c2.b_off;
+          d2[g].cin = c2.cin_packed;
+          d2[g].cout = c2.cout;
+          d2[g].k = 1;
+          d2[g].out = net->ws + bo.off_floats;
+          d2[g].lout = slice(bo, o.out_choff[g]);
+        }
+        rc = conv_tail_launch(d1, d2, o.ngroups, N, o.H, o.W, s);
         break;
       }
       case OP_POOL: {

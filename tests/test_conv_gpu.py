@@ -340,3 +340,82 @@ def test_first_layer_kernel_matches_torch_cpu_from_both_sources(capi, cuda, shap
         outs.append(o.cpu())
     assert (outs[0] - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("shape", [(2, 46, 46), (1, 9, 13), (3, 23, 17)])
+def test_pointwise_pair_is_bit_identical_to_two_launches(capi, cuda, shape):
+    """Mconv6 + Mconv7 as one back-to-back launch (csrc/conv_tail.hip, both branches grouped) against the same two
+    convs as separate rtpose_conv2d launches: identical bits (same summation order), gaps of the concat-style
+    output buffer untouched, and against torch's CPU conv2d within the usual tolerance."""
+    lib, Layout = capi.lib, capi.Layout
+    n, h, w = shape
+    g = torch.Generator().manual_seed(h * 100 + w)
+    stream = capi.current_stream()
+    couts = (38, 19)
+    xs = [torch.randn(n, 128, h, w, generator=g) for _ in range(2)]
+    w1 = [torch.randn(128, 128, 1, 1, generator=g) * (2.0 / 128) ** 0.5 for _ in range(2)]
+    b1 = [torch.randn(128, generator=g) * 0.1 for _ in range(2)]
+    w2 = [torch.randn(c, 128, 1, 1, generator=g) * (2.0 / 128) ** 0.5 for c in couts]
+    b2 = [torch.randn(c, generator=g) * 0.1 for c in couts]
+    lin = Layout.padded(128, h, w, 0)
+    lmid = Layout.padded(128, h, w, 0)
+    keep = []
+
+    def dev(t):
+        t = t.contiguous().to(cuda)
+        keep.append(t)
+        return t
+
+    def pack(wt, b, cout):
+        wp = torch.zeros(lib.rtpose_packed_weight_floats(cout, 128, 1), device=cuda)
+        bp = torch.zeros(lib.rtpose_packed_bias_floats(cout), device=cuda)
+        capi.check(lib.rtpose_pack_conv_weights(capi.ptr(dev(wt)), capi.ptr(dev(b)), cout, 128, 1, None, 128, capi.ptr(wp),
+                                                capi.ptr(bp), stream))
+        keep.extend([wp, bp])
+        return wp, bp
+
+    xin, p1, p2 = [], [], []
+    for gi in range(2):
+        buf = torch.zeros(lib.rtpose_layout_pixels(C.byref(lin), n, h, w) * 128, device=cuda)
+        capi.check(lib.rtpose_nchw_to_layout(capi.ptr(dev(xs[gi])), capi.ptr(buf), C.byref(lin), 128, 128, n, h, w, stream))
+        xin.append(buf)
+        p1.append(pack(w1[gi], b1[gi], 128))
+        p2.append(pack(w2[gi], b2[gi], couts[gi]))
+    results = []
+    for fused in (True, False):
+        lcat = Layout.padded(192, h, w, 3)
+        cat = torch.zeros(lib.rtpose_layout_pixels(C.byref(lcat), n, h, w) * 192, device=cuda)
+        mids = [torch.zeros(lib.rtpose_layout_pixels(C.byref(lmid), n, h, w) * 128, device=cuda) for _ in range(2)]
+        d1, d2 = (capi.ConvDesc * 2)(), (capi.ConvDesc * 2)()
+        for gi in range(2):
+            d1[gi].inp, d1[gi].w_packed, d1[gi].bias_packed, d1[gi].out = (xin[gi].data_ptr(), p1[gi][0].data_ptr(),
+                                                                         p1[gi][1].data_ptr(), mids[gi].data_ptr())
+            d1[gi].lin, d1[gi].lout = lin, lmid
+            d1[gi].cin, d1[gi].cout, d1[gi].k, d1[gi].relu, d1[gi].pool = 128, 128, 1, 1, 0
+            d2[gi].inp, d2[gi].w_packed, d2[gi].bias_packed, d2[gi].out = (mids[gi].data_ptr(), p2[gi][0].data_ptr(),
+                                                                         p2[gi][1].data_ptr(), cat.data_ptr())
+            d2[gi].lin = lmid
+            d2[gi].lout = Layout.padded(192, h, w, 3, choff=128 if gi == 0 else 166)
+            d2[gi].cin, d2[gi].cout, d2[gi].k, d2[gi].relu, d2[gi].pool = 128, couts[gi], 1, 0, 0
+        if fused:
+            assert lib.rtpose_conv1x1_pair_fits(d1, d2, 2) == 1
+            capi.check(lib.rtpose_conv1x1_pair(d1, d2, 2, n, h, w, stream), "rtpose_conv1x1_pair")
+        else:
+            capi.check(lib.rtpose_conv2d(d1, 2, n, h, w, stream), "rtpose_conv2d")
+            capi.check(lib.rtpose_conv2d(d2, 2, n, h, w, stream), "rtpose_conv2d")
+        outs = []
+        for gi in range(2):
+            o = torch.empty(n, couts[gi], h, w, device=cuda)
+            lo = Layout.padded(192, h, w, 3, choff=128 if gi == 0 else 166)
+            capi.check(lib.rtpose_layout_to_nchw(capi.ptr(cat), C.byref(lo), capi.ptr(o), couts[gi], n, h, w, stream))
+            outs.append(o.cpu())
+        torch.cuda.synchronize()
+        inner = sum(o.abs().sum().item() for o in outs)
+        assert abs(cat.abs().sum().item() - inner) <= 1e-3 * max(1.0, inner), "wrote outside the two head slices"
+        results.append(outs)
+    for gi in range(2):
+        ref = F.conv2d(F.relu(F.conv2d(xs[gi], w1[gi], b1[gi])), w2[gi], b2[gi])
+        assert (results[0][gi] - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
+        assert torch.equal(results[0][gi], results[1][gi])
+    d1[0].cout = 64
+    assert lib.rtpose_conv1x1_pair_fits(d1, d2, 2) == 0

@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+run() { echo "=== $1"; RTPOSE_LIB_PATH=$PWD/tools/exp/lib_r3_$1.so timeout 300 python tools/profile_layers.py 32 368 368 5 fp32 2>&1 | grep -E "model2_1.0|model2_1.2|^k=7|sum of"; }
+( run base; run prio1; run prio2; run base ) > gpurun_out/s8_prio.log 2>&1
+cat gpurun_out/s8_prio.log
