@@ -1,7 +1,8 @@
 // The two trailing 1x1 convolutions of a refinement-stage branch as ONE back-to-back GEMM launch, fp32, gfx950 (MI355X):
 //   Mconv6_stageN_Lb = nn.Conv2d(128, 128, 1) + nn.ReLU,  Mconv7_stageN_Lb = nn.Conv2d(128, 38 | 19, 1)
-// (lib/network/rtpose_vgg.py:120-127: the last two entries of every stage-2..6 block), both branches of the stage in
-// one grid.  As two launches of the generic kernel (conv_mfma.hip) these K = 128 GEMMs ran at 0.35 of the fp32 MFMA
+// (lib/network/rtpose_vgg.py:120-127: the last two entries of every stage-2..6 block) and the stage-1 pair
+//   conv5_4_CPM_Lb = nn.Conv2d(128, 512, 1) + nn.ReLU,  conv5_5_CPM_Lb = nn.Conv2d(512, 38 | 19, 1)   (:101-105),
+// both branches of the stage in one grid.  As two launches of the generic kernel (conv_mfma.hip) these K = 128 GEMMs ran at 0.35 of the fp32 MFMA
 // peak - per-block prologue / epilogue as long as the multiply loop - and the 128-channel intermediate made a
 // 35 MB round trip per branch.  Here a block owns 64 pixels of one branch:
 //   X [64 px x 128 ch] -> LDS -> GEMM 1 (4 waves x 32 columns, v_mfma_f32_32x32x2_f32) -> + bias, ReLU -> LDS (the A
@@ -42,15 +43,23 @@ struct Args {
   int N, H, W, M, mtiles, ngroups;
 };
 
-__global__ __launch_bounds__(256, 3) void tail_kernel(const Args A) {
-  __shared__ __attribute__((aligned(16))) float4 X[(KC / 4) * PS];
-  float4* const T = X;  // the intermediate takes the input tile's place (one barrier after GEMM 1)
-  __shared__ int qin[BM], qout[BM];
+// NP = passes of 128 intermediate columns: 1 for Mconv6 / Mconv7 (128 -> 128 -> 38 | 19), 4 for the stage-1 pair
+// conv5_4_CPM / conv5_5_CPM (128 -> 512 -> 38 | 19, rtpose_vgg.py:95-105): GEMM 1 produces 128 columns at a time, GEMM 2
+// consumes them as the next 128 of its K = 512 - the accumulators of GEMM 2 live across the passes, k ascending.
+template <int NP>
+__global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void tail_kernel(const Args A) {
+  extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+  float4* const X = lds4;
+  // one pass: the intermediate takes the input tile's place (a barrier after GEMM 1); several: its own buffer
+  float4* const T = NP == 1 ? lds4 : lds4 + (KC / 4) * PS;
+  int* const qin = reinterpret_cast<int*>(lds4 + (NP == 1 ? 1 : 2) * (KC / 4) * PS);
+  int* const qout = qin + BM;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
   const int mt = blockIdx.x / A.ngroups, grp = blockIdx.x - mt * A.ngroups;
   const Group g = grp ? A.g[1] : A.g[0];
+  constexpr int N1T = N1 * NP;  // columns of GEMM 1 = K of GEMM 2
 
   // ---- pixel -> element offsets of the block's 64 pixels (pixels past the end repeat the last one; not stored) ----
   if (tid < BM) {
@@ -61,13 +70,11 @@ __global__ __launch_bounds__(256, 3) void tail_kernel(const Args A) {
     qin[tid] = (g.in_lead + (n * g.in_hs + y) * g.in_ws + x) * g.in_cstride + g.in_choff;
     qout[tid] = (g.out_lead + (n * g.out_hs + y) * g.out_ws + x) * g.out_cstride + g.out_choff;
   }
-  // ---- B fragments of GEMM 1 (this wave's 32 columns, all 16 k groups) and both biases: issued before the wait ----
-  const int col1 = wave * 32 + l31;
+  // ---- B fragments of GEMM 1, pass 0 (this wave's 32 columns, all 16 k groups): issued before the wait ----
   float4 b1v[KC / 8];
 #pragma unroll
   for (int gi = 0; gi < KC / 8; ++gi)
-    b1v[gi] = reinterpret_cast<const float4*>(g.w1)[(size_t)(2 * gi + kh) * N1 + col1];
-  const float bias1 = g.b1[col1];
+    b1v[gi] = reinterpret_cast<const float4*>(g.w1)[(size_t)(2 * gi + kh) * N1T + wave * 32 + l31];
   __syncthreads();
 
   // ---- X tile: 64 px x 32 planes of 16 bytes; consecutive lanes = consecutive planes of a pixel (512 B runs) ----
@@ -79,57 +86,71 @@ __global__ __launch_bounds__(256, 3) void tail_kernel(const Args A) {
   }
   __syncthreads();
 
-  // ---- GEMM 1: 64 px x 32 columns per wave, K = 128 ---------------------------------------------------------
-  floatx16 acc[2];
-#pragma unroll
-  for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mf][r] = bias1;
-#pragma unroll
-  for (int gi = 0; gi < KC / 8; ++gi) {
-    const float4 a0 = X[(2 * gi + kh) * PS + l31], a1 = X[(2 * gi + kh) * PS + 32 + l31];
-    const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
-    const float bv[4] = {b1v[gi].x, b1v[gi].y, b1v[gi].z, b1v[gi].w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[j], bv[j], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[j], bv[j], acc[1], 0, 0, 0);
-    }
-  }
-  // B fragments of GEMM 2 (requested now: their latency hides under the LDS round trip of the intermediate)
   const int mf2 = wave & 1, nf2 = wave >> 1;
   const int col2 = nf2 * 32 + l31;
-  float4 b2v[N1 / 8];
-#pragma unroll
-  for (int gi = 0; gi < N1 / 8; ++gi)
-    b2v[gi] = reinterpret_cast<const float4*>(g.w2)[(size_t)(2 * gi + kh) * N2 + col2];
-  const float bias2 = g.b2[col2];
-  // ReLU, then the intermediate in the A layout: T[column / 4][pixel].[column % 4]
-  // (register r of a lane = pixel (r / 4) * 8 + 4 kh + r % 4 of the fragment, column col1)
-  __syncthreads();  // every wave has read its last X fragment
+  floatx16 acc2;
   {
-    float* Tf = reinterpret_cast<float*>(T) + ((col1 >> 2) * PS) * 4 + (col1 & 3);
+    const float bias2 = g.b2[col2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = bias2;
+  }
+#pragma unroll 1
+  for (int ps = 0; ps < NP; ++ps) {
+    // ---- GEMM 1: 64 px x 32 columns per wave, K = 128 -------------------------------------------------------
+    const int col1 = ps * N1 + wave * 32 + l31;
+    const float bias1 = g.b1[col1];
+    floatx16 acc[2];
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int px = mf * 32 + (r >> 2) * 8 + 4 * kh + (r & 3);
-        Tf[px * 4] = fmaxf(acc[mf][r], 0.f);
+      for (int r = 0; r < 16; ++r) acc[mf][r] = bias1;
+#pragma unroll
+    for (int gi = 0; gi < KC / 8; ++gi) {
+      const float4 a0 = X[(2 * gi + kh) * PS + l31], a1 = X[(2 * gi + kh) * PS + 32 + l31];
+      const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+      const float bv[4] = {b1v[gi].x, b1v[gi].y, b1v[gi].z, b1v[gi].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[j], bv[j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[j], bv[j], acc[1], 0, 0, 0);
       }
-  }
-  __syncthreads();
+    }
+    // B fragments of GEMM 2 for this pass' 128 k rows (requested now: their latency hides under the LDS round trip
+    // of the intermediate), and GEMM 1's for the next pass
+    float4 b2v[N1 / 8];
+#pragma unroll
+    for (int gi = 0; gi < N1 / 8; ++gi)
+      b2v[gi] = reinterpret_cast<const float4*>(g.w2)[(size_t)(ps * (N1 / 4) + 2 * gi + kh) * N2 + col2];
+    if (ps + 1 < NP) {
+#pragma unroll
+      for (int gi = 0; gi < KC / 8; ++gi)
+        b1v[gi] = reinterpret_cast<const float4*>(g.w1)[(size_t)(2 * gi + kh) * N1T + (ps + 1) * N1 + wave * 32 + l31];
+    }
+    // ReLU, then the intermediate in the A layout: T[column / 4][pixel].[column % 4]
+    // (register r of a lane = pixel (r / 4) * 8 + 4 kh + r % 4 of the fragment, column wave * 32 + l31 of the pass)
+    __syncthreads();  // every wave has read its last X fragment (one pass) / its last T fragment of the previous pass
+    {
+      const int cl = wave * 32 + l31;
+      float* Tf = reinterpret_cast<float*>(T) + ((cl >> 2) * PS) * 4 + (cl & 3);
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int px = mf * 32 + (r >> 2) * 8 + 4 * kh + (r & 3);
+          Tf[px * 4] = fmaxf(acc[mf][r], 0.f);
+        }
+    }
+    __syncthreads();
 
-  // ---- GEMM 2: 32 px x 32 columns per wave (2 x 2 waves), K = 128 ---------------------------------------------
-  floatx16 acc2;
+    // ---- GEMM 2: 32 px x 32 columns per wave (2 x 2 waves), the next 128 of its K ----------------------------
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc2[r] = bias2;
+    for (int gi = 0; gi < N1 / 8; ++gi) {
+      const float4 a = T[(2 * gi + kh) * PS + mf2 * 32 + l31];
+      const float av[4] = {a.x, a.y, a.z, a.w};
+      const float bv[4] = {b2v[gi].x, b2v[gi].y, b2v[gi].z, b2v[gi].w};
 #pragma unroll
-  for (int gi = 0; gi < N1 / 8; ++gi) {
-    const float4 a = T[(2 * gi + kh) * PS + mf2 * 32 + l31];
-    const float av[4] = {a.x, a.y, a.z, a.w};
-    const float bv[4] = {b2v[gi].x, b2v[gi].y, b2v[gi].z, b2v[gi].w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc2, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc2, 0, 0, 0);
+    }
   }
   if (col2 < g.cout2) {
 #pragma unroll
@@ -142,12 +163,13 @@ __global__ __launch_bounds__(256, 3) void tail_kernel(const Args A) {
 
 }  // namespace tail
 
-// Two grouped 1x1 convs back to back: d1[g] = 128 -> 128 (+ReLU), d2[g] = 128 -> cout2 <= 64 (no ReLU) reading d1[g]'s
+// Two grouped 1x1 convs back to back: d1[g] = 128 -> 128 | 512 (+ReLU), d2[g] = that -> cout2 <= 64 (no ReLU) reading d1[g]'s
 // output, which is never written.  Descriptors as for rtpose_conv2d (k = 1, plain packing); d1[g].out / lout are ignored.
 int conv_tail_fits(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int ngroups) {
   if (!d1 || !d2 || ngroups < 1 || ngroups > 2) return 0;
   for (int i = 0; i < ngroups; ++i) {
-    if (d1[i].k != 1 || d2[i].k != 1 || d1[i].cin != tail::KC || d1[i].cout != tail::N1 || d2[i].cin != tail::N1 ||
+    if (d1[i].k != 1 || d2[i].k != 1 || d1[i].cin != tail::KC || (d1[i].cout != tail::N1 && d1[i].cout != 4 * tail::N1) ||
+        d1[i].cout != d1[0].cout || d2[i].cin != d1[i].cout ||
         d2[i].cout > tail::N2 || d2[i].cout < 1 || !d1[i].relu || d2[i].relu || d1[i].pool || d2[i].pool ||
         d1[i].out_cmap || d2[i].out_cmap || (d1[i].lin.cstride % 4) || (d1[i].lin.choff % 4) ||
         d1[i].lin.choff + tail::KC > d1[i].lin.cstride || d2[i].lout.choff + d2[i].cout > d2[i].lout.cstride)
@@ -160,7 +182,7 @@ int conv_tail_launch(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int
                      hipStream_t s) {
   using namespace tail;
   if (!conv_tail_fits(d1, d2, ngroups) || N <= 0 || H <= 0 || W <= 0)
-    return fail(RTPOSE_E_INVAL, "conv_tail: needs 128 -> 128 (+ReLU) -> <= 64 pointwise convs");
+    return fail(RTPOSE_E_INVAL, "conv_tail: needs 128 -> 128 | 512 (+ReLU) -> <= 64 pointwise convs");
   const long M = (long)N * H * W;
   if (M > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv_tail: tensor too large");
   Args a;
@@ -195,7 +217,20 @@ int conv_tail_launch(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int
   a.M = (int)M;
   a.mtiles = ceil_div((int)M, BM);
   a.ngroups = ngroups;
-  hipLaunchKernelGGL(tail_kernel, dim3((unsigned)a.mtiles * ngroups), dim3(256), 0, s, a);
+  const int np = d1[0].cout / N1;
+  const size_t lds = (size_t)(np == 1 ? 1 : 2) * (KC / 4) * PS * sizeof(float4) + 2 * BM * sizeof(int);
+  if (np == 1) {
+    hipLaunchKernelGGL(tail_kernel<1>, dim3((unsigned)a.mtiles * ngroups), dim3(256), lds, s, a);
+  } else {
+    static PerDeviceOnce attr_set;
+    const int dev = current_device();
+    if (!attr_set.is_set(dev)) {
+      RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel<4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      attr_set.set(dev);
+    }
+    hipLaunchKernelGGL(tail_kernel<4>, dim3((unsigned)a.mtiles * ngroups), dim3(256), lds, s, a);
+  }
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }

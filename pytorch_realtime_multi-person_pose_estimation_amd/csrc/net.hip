@@ -410,11 +410,28 @@ void build_plan(rtpose_net* n) {
     add_conv_op(n, H3, W3, 2, ci, T1, zz, T2, zz, 1, 0);
     ci[0] = cw1[0][2]; ci[1] = cw1[1][2];
     add_conv_op(n, H3, W3, 2, ci, T2, zz, T3, zz, 1, 0);
-    ci[0] = cw1[0][3]; ci[1] = cw1[1][3];
-    add_conv_op(n, H3, W3, 2, ci, T3, zz, T4, zz, 1, 0);
-    ci[0] = cw1[0][4]; ci[1] = cw1[1][4];
     const int outb[2] = {CATb, CATb};
-    add_conv_op(n, H3, W3, 2, ci, T4, zz, outb, head_off, 0, 0);
+    if (!n->bf16) {
+      // fp32: conv5_4_CPM (128 -> 512, ReLU) + conv5_5_CPM (512 -> 38 | 19) as one back-to-back launch (conv_tail.hip)
+      ci[0] = cw1[0][4]; ci[1] = cw1[1][4];
+      add_conv_op(n, H3, W3, 2, ci, T3, zz, outb, head_off, 0, 0);
+      Op& t = n->ops.back();
+      t.kind = OP_TAIL;
+      t.ks = 1;
+      for (int b = 0; b < 2; ++b) {
+        t.conv2_idx[b] = t.conv_idx[b];
+        t.conv_idx[b] = cw1[b][3];
+        const ConvW& c1 = n->convs[t.conv_idx[b]];
+        t.flops += 2.0 * n->N * H3 * W3 * (double)c1.cout * c1.cin_src;
+      }
+      t.name = n->convs[t.conv_idx[0]].name + "+" + n->convs[t.conv2_idx[0]].name + "|" +
+               n->convs[t.conv_idx[1]].name + "+" + n->convs[t.conv2_idx[1]].name;
+    } else {
+      ci[0] = cw1[0][3]; ci[1] = cw1[1][3];
+      add_conv_op(n, H3, W3, 2, ci, T3, zz, T4, zz, 1, 0);
+      ci[0] = cw1[0][4]; ci[1] = cw1[1][4];
+      add_conv_op(n, H3, W3, 2, ci, T4, zz, outb, head_off, 0, 0);
+    }
     add_simple_op(n, OP_COPY, "save1", H3, W3, CATb, kCatPaf, n->save_buf[0], 0, 57);
   }
   for (int s = 2; s <= 6; ++s) {

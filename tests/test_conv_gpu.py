@@ -342,23 +342,23 @@ def test_first_layer_kernel_matches_torch_cpu_from_both_sources(capi, cuda, shap
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("shape", [(2, 46, 46), (1, 9, 13), (3, 23, 17)])
+@pytest.mark.parametrize("shape", [(2, 46, 46, 128), (1, 9, 13, 128), (3, 23, 17, 128), (2, 46, 46, 512), (1, 11, 7, 512)])
 def test_pointwise_pair_is_bit_identical_to_two_launches(capi, cuda, shape):
     """Mconv6 + Mconv7 as one back-to-back launch (csrc/conv_tail.hip, both branches grouped) against the same two
     convs as separate rtpose_conv2d launches: identical bits (same summation order), gaps of the concat-style
     output buffer untouched, and against torch's CPU conv2d within the usual tolerance."""
     lib, Layout = capi.lib, capi.Layout
-    n, h, w = shape
+    n, h, w, mid = shape            # mid = 128: Mconv6 / Mconv7; 512: conv5_4_CPM / conv5_5_CPM of stage 1
     g = torch.Generator().manual_seed(h * 100 + w)
     stream = capi.current_stream()
     couts = (38, 19)
     xs = [torch.randn(n, 128, h, w, generator=g) for _ in range(2)]
-    w1 = [torch.randn(128, 128, 1, 1, generator=g) * (2.0 / 128) ** 0.5 for _ in range(2)]
-    b1 = [torch.randn(128, generator=g) * 0.1 for _ in range(2)]
-    w2 = [torch.randn(c, 128, 1, 1, generator=g) * (2.0 / 128) ** 0.5 for c in couts]
+    w1 = [torch.randn(mid, 128, 1, 1, generator=g) * (2.0 / 128) ** 0.5 for _ in range(2)]
+    b1 = [torch.randn(mid, generator=g) * 0.1 for _ in range(2)]
+    w2 = [torch.randn(c, mid, 1, 1, generator=g) * (2.0 / mid) ** 0.5 for c in couts]
     b2 = [torch.randn(c, generator=g) * 0.1 for c in couts]
     lin = Layout.padded(128, h, w, 0)
-    lmid = Layout.padded(128, h, w, 0)
+    lmid = Layout.padded(mid, h, w, 0)
     keep = []
 
     def dev(t):
@@ -367,9 +367,10 @@ def test_pointwise_pair_is_bit_identical_to_two_launches(capi, cuda, shape):
         return t
 
     def pack(wt, b, cout):
-        wp = torch.zeros(lib.rtpose_packed_weight_floats(cout, 128, 1), device=cuda)
+        cin = wt.shape[1]
+        wp = torch.zeros(lib.rtpose_packed_weight_floats(cout, cin, 1), device=cuda)
         bp = torch.zeros(lib.rtpose_packed_bias_floats(cout), device=cuda)
-        capi.check(lib.rtpose_pack_conv_weights(capi.ptr(dev(wt)), capi.ptr(dev(b)), cout, 128, 1, None, 128, capi.ptr(wp),
+        capi.check(lib.rtpose_pack_conv_weights(capi.ptr(dev(wt)), capi.ptr(dev(b)), cout, cin, 1, None, cin, capi.ptr(wp),
                                                 capi.ptr(bp), stream))
         keep.extend([wp, bp])
         return wp, bp
@@ -379,24 +380,24 @@ def test_pointwise_pair_is_bit_identical_to_two_launches(capi, cuda, shape):
         buf = torch.zeros(lib.rtpose_layout_pixels(C.byref(lin), n, h, w) * 128, device=cuda)
         capi.check(lib.rtpose_nchw_to_layout(capi.ptr(dev(xs[gi])), capi.ptr(buf), C.byref(lin), 128, 128, n, h, w, stream))
         xin.append(buf)
-        p1.append(pack(w1[gi], b1[gi], 128))
+        p1.append(pack(w1[gi], b1[gi], mid))
         p2.append(pack(w2[gi], b2[gi], couts[gi]))
     results = []
     for fused in (True, False):
         lcat = Layout.padded(192, h, w, 3)
         cat = torch.zeros(lib.rtpose_layout_pixels(C.byref(lcat), n, h, w) * 192, device=cuda)
-        mids = [torch.zeros(lib.rtpose_layout_pixels(C.byref(lmid), n, h, w) * 128, device=cuda) for _ in range(2)]
+        mids = [torch.zeros(lib.rtpose_layout_pixels(C.byref(lmid), n, h, w) * mid, device=cuda) for _ in range(2)]
         d1, d2 = (capi.ConvDesc * 2)(), (capi.ConvDesc * 2)()
         for gi in range(2):
             d1[gi].inp, d1[gi].w_packed, d1[gi].bias_packed, d1[gi].out = (xin[gi].data_ptr(), p1[gi][0].data_ptr(),
                                                                          p1[gi][1].data_ptr(), mids[gi].data_ptr())
             d1[gi].lin, d1[gi].lout = lin, lmid
-            d1[gi].cin, d1[gi].cout, d1[gi].k, d1[gi].relu, d1[gi].pool = 128, 128, 1, 1, 0
+            d1[gi].cin, d1[gi].cout, d1[gi].k, d1[gi].relu, d1[gi].pool = 128, mid, 1, 1, 0
             d2[gi].inp, d2[gi].w_packed, d2[gi].bias_packed, d2[gi].out = (mids[gi].data_ptr(), p2[gi][0].data_ptr(),
                                                                          p2[gi][1].data_ptr(), cat.data_ptr())
             d2[gi].lin = lmid
             d2[gi].lout = Layout.padded(192, h, w, 3, choff=128 if gi == 0 else 166)
-            d2[gi].cin, d2[gi].cout, d2[gi].k, d2[gi].relu, d2[gi].pool = 128, couts[gi], 1, 0, 0
+            d2[gi].cin, d2[gi].cout, d2[gi].k, d2[gi].relu, d2[gi].pool = mid, couts[gi], 1, 0, 0
         if fused:
             assert lib.rtpose_conv1x1_pair_fits(d1, d2, 2) == 1
             capi.check(lib.rtpose_conv1x1_pair(d1, d2, 2, n, h, w, stream), "rtpose_conv1x1_pair")
