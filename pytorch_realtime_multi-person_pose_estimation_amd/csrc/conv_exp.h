@@ -13,7 +13,7 @@
     defined(RTPOSE_EXP_SCALAR_STORE) || defined(RTPOSE_EXP_BSPREAD) || defined(RTPOSE_EXP_HALF_B_ON) || \
     defined(RTPOSE_EXP_STAGGER) || defined(RTPOSE_EXP_TB1X1) || defined(RTPOSE_EXP_HD) ||               \
     defined(RTPOSE_EXP_RB2) || defined(RTPOSE_EXP_W7_PF) || defined(RTPOSE_EXP_W7_TMASK) || defined(RTPOSE_EXP_W7_LPS) || defined(RTPOSE_EXP_W_EPI) || \
-    defined(RTPOSE_EXP_W3_SWOLD) || defined(RTPOSE_EXP_W7_PRIO) || defined(RTPOSE_EXP_W7_FS2SETS) || defined(RTPOSE_EXP_W7_CGMAJOR) || defined(RTPOSE_EXP_TIMELINE3)
+    defined(RTPOSE_EXP_W3_SWOLD) || defined(RTPOSE_EXP_W7_XSPLIT) || defined(RTPOSE_EXP_W7_PRIO) || defined(RTPOSE_EXP_W7_FS2SETS) || defined(RTPOSE_EXP_W7_CGMAJOR) || defined(RTPOSE_EXP_TIMELINE3)
 #error "RTPOSE_EXP_* ablation switches need -DRTPOSE_DEV_BUILD (they are not part of production builds)"
 #endif
 #endif
@@ -73,6 +73,10 @@ inline const char* dev_env(const char* name) {
 // 7x7 Winograd kernel, 8-wave form: B register sets (3 or 7; prefetch distance = min(RTPOSE_EXP_W7_PF, sets - 1))
 #ifndef RTPOSE_EXP_W7_FS2SETS
 #define RTPOSE_EXP_W7_FS2SETS 7
+#endif
+// 7x7 Winograd kernel, 8-wave form: 1 = sibling waves share the input transform of an item (half the groups each)
+#ifndef RTPOSE_EXP_W7_XSPLIT
+#define RTPOSE_EXP_W7_XSPLIT 0
 #endif
 // 7x7 Winograd kernel, 8-wave form: issue priority (s_setprio) of the transforming waves: 0 none, 1 higher, 2 lower
 #ifndef RTPOSE_EXP_W7_PRIO

@@ -158,7 +158,8 @@ struct Xform {
     rin = make_rsrc(g.in + o0, g.in_bytes - o0 * 4);
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
-      const int i = min(tid + k * 256, nitems - 1);  // surplus threads repeat the last item (same value, same slot)
+      // (8-wave form: the threads 256.. mirror the items of 0..255 - sibling waves share the transform of an item)
+      const int i = min((tid & 255) + k * 256, nitems - 1);  // surplus threads repeat the last item (same value, same slot)
       const int r = i / (GX * CG), rem = i - r * (GX * CG);
       // channel-group-major inside a row: the 8 contiguous lanes a ds_write_b128 is serviced in then write 8
       // consecutive 16-byte slots (gx, cg interleaved they hit 4 slots twice: 12.5 % of SQ_LDS_IDX_ACTIVE in round 2)
@@ -234,7 +235,13 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = FS == 2 ? (wv & 3) : wv, fh = FS == 2 ? (wv >> 2) : 0;
-  const bool xf = wv < 4;  // this wave takes part in the input transform
+  // Who transforms.  RTPOSE_EXP_W7_XSPLIT = 0: the waves 0..3 (one per SIMD) do all of it while the sibling multiplies.
+  // 1: both siblings load an item's segments and each forms half of its frequency groups (even / odd group index):
+  // twice the segment loads (L2 hits), the VALU groups and LDS writes split evenly - neither sibling waits at the
+  // chunk barrier for the other's transform.
+  constexpr bool XSPLIT = FS == 2 && RTPOSE_EXP_W7_XSPLIT;
+  const bool xf = XSPLIT || wv < 4;  // this wave takes part in the input transform
+  auto my_group = [&](int gi) { return !XSPLIT || (gi & 1) == fh; };
 #if RTPOSE_EXP_W7_PRIO == 1
   if (FS == 2 && xf) __builtin_amdgcn_s_setprio(1);
 #elif RTPOSE_EXP_W7_PRIO == 2
@@ -344,7 +351,8 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
 #pragma unroll
     for (int k = 0; k < NI; ++k)
 #pragma unroll
-      for (int gi = 0; gi < NP + 2; ++gi) tgroup(V4, k, gi);
+      for (int gi = 0; gi < NP + 2; ++gi)
+        if (my_group(gi)) tgroup(V4, k, gi);
     const int c1 = min(cb + 1, ce - 1);
 #pragma unroll
     for (int k = 0; k < NI; ++k)
@@ -404,7 +412,8 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
         }
         if (RTPOSE_EXP_STAGE && j == 3 && xf) {
           if (ps % GSTR == 0 && ps / GSTR < NG) {
-            if (RTPOSE_EXP_W7_TMASK & 1) tgroup(vw, (ps / GSTR) / (NP + 2), (ps / GSTR) % (NP + 2));
+            if ((RTPOSE_EXP_W7_TMASK & 1) && my_group((ps / GSTR) % (NP + 2)))
+              tgroup(vw, (ps / GSTR) / (NP + 2), (ps / GSTR) % (NP + 2));
           } else if (ps >= LS && ps < LS + LSTEPS && (RTPOSE_EXP_W7_TMASK & 2)) {  // LPS segment loads per step
 #pragma unroll
             for (int q = 0; q < LPS; ++q) {

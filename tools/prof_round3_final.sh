@@ -24,3 +24,5 @@ python $R/tools/latency_b1.py > $O/r03_latency_b1.txt 2>&1
 python $R/tools/bench_config5.py > $O/r03_config5.json 2>/dev/null
 python $R/tools/bench_tta.py 32 3 > $O/r03_tta.txt 2>&1
 python $R/tools/bench_streaming.py > $O/r03_streaming.txt 2>&1
+cd $R && python -c "import __graft_entry__ as g; g.smoke()" > $O/r03_smoke.txt 2>&1
+for args in "32 0" "11 0" "8 0 auto" "32 2" "32 1"; do LD_LIBRARY_PATH=$R/pytorch_realtime_multi-person_pose_estimation_amd/lib $R/examples/c_host $args; done > $O/r03_c_host.txt 2>&1
