@@ -23,7 +23,7 @@ def model_and_sd(pkg, cuda):
     return m, sd
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 64, 72), (1, 3, 56, 40)])
+@pytest.mark.parametrize("shape", [(2, 3, 64, 72), (1, 3, 56, 40), (1, 3, 61, 75), (3, 3, 40, 88), (5, 3, 104, 24)])
 def test_forward_matches_oracle(model_and_sd, cuda, shape):
     from oracle import net_oracle
     m, sd = model_and_sd
