@@ -167,6 +167,16 @@ int rtpose_pack_conv_weights_winograd(const float* w_oihw, const float* bias, in
                                       void* stream);
 int rtpose_conv2d_winograd(const rtpose_conv_desc* d, int ngroups, int N, int H, int W,
                            void* stream);
+/* k = 3 with an explicit form m: 0 / 2 = F(2x2,3x3) (as above), 4 = F(4x4,3x3) (csrc/conv_wino4.hip): 36 instead of
+ * 144 multiplies per 4 x 4 outputs and input channel (4x fewer than the direct sum), interpolation points
+ * 0, +-3/4, +-3/2, inf; cin a multiple of 8, >= 32; transformed filters 36/9 the size.  Launch with
+ * rtpose_conv_desc.wino_m = 4 and this packing.  Results differ from the direct sum by rounding only
+ * (element-wise error bound ~3x F(2x2,3x3)'s, tests/test_wino_numerics_gpu.py). */
+size_t rtpose_packed_weight_floats_winograd3(int cout, int cin, int m);
+int rtpose_pack_conv_weights_winograd3(const float* w_oihw, const float* bias, int cout,
+                                       int cin_src, int m, const int32_t* cin_map,
+                                       int cin_packed, float* w_packed, float* bias_packed,
+                                       void* stream);
 /* k = 7 with an explicit form m (4 or 6; 0 = default), see rtpose_conv_desc.wino_m */
 size_t rtpose_packed_weight_floats_winograd7(int cout, int cin, int m);
 int rtpose_pack_conv_weights_winograd7(const float* w_oihw, const float* bias, int cout,

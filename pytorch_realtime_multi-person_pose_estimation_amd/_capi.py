@@ -108,6 +108,8 @@ _SIGS = {
     "rtpose_packed_weight_floats_winograd": (_sz, [_i, _i, _i]),
     "rtpose_pack_conv_weights_winograd": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "rtpose_conv2d_winograd": (_i, [C.POINTER(ConvDesc), _i, _i, _i, _i, _vp]),
+    "rtpose_packed_weight_floats_winograd3": (_sz, [_i, _i, _i]),
+    "rtpose_pack_conv_weights_winograd3": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "rtpose_packed_weight_floats_winograd7": (_sz, [_i, _i, _i]),
     "rtpose_pack_conv_weights_winograd7": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "rtpose_conv2d_winograd_scratch_bytes": (_sz, []),

@@ -13,7 +13,8 @@
     defined(RTPOSE_EXP_SCALAR_STORE) || defined(RTPOSE_EXP_BSPREAD) || defined(RTPOSE_EXP_HALF_B_ON) || \
     defined(RTPOSE_EXP_STAGGER) || defined(RTPOSE_EXP_TB1X1) || defined(RTPOSE_EXP_HD) ||               \
     defined(RTPOSE_EXP_RB2) || defined(RTPOSE_EXP_W7_PF) || defined(RTPOSE_EXP_W7_TMASK) || defined(RTPOSE_EXP_W7_LPS) || defined(RTPOSE_EXP_W_EPI) || \
-    defined(RTPOSE_EXP_W3_SWOLD) || defined(RTPOSE_EXP_W7_XSPLIT) || defined(RTPOSE_EXP_W7_PRIO) || defined(RTPOSE_EXP_W7_FS2SETS) || defined(RTPOSE_EXP_W7_CGMAJOR) || defined(RTPOSE_EXP_TIMELINE3)
+    defined(RTPOSE_EXP_W3_SWOLD) || defined(RTPOSE_EXP_W7_XSPLIT) || defined(RTPOSE_EXP_W7_PRIO) || defined(RTPOSE_EXP_W7_FS2SETS) || defined(RTPOSE_EXP_W7_CGMAJOR) || defined(RTPOSE_EXP_TIMELINE3) || \
+    defined(RTPOSE_EXP_W4_NOXF) || defined(RTPOSE_EXP_W4_NOLOAD) || defined(RTPOSE_EXP_W4_AUX) || defined(RTPOSE_EXP_W4_L0)
 #error "RTPOSE_EXP_* ablation switches need -DRTPOSE_DEV_BUILD (they are not part of production builds)"
 #endif
 #endif
@@ -129,4 +130,17 @@ inline const char* dev_env(const char* name) {
 #define RTPOSE_EXP_STAGE 0
 #else
 #define RTPOSE_EXP_STAGE 1
+#endif
+
+// conv_wino16.hip: B ring entries / prefetch distance (frequencies)
+#ifndef RTPOSE_W16_NB
+#define RTPOSE_W16_NB 8
+#endif
+#ifndef RTPOSE_W16_PF
+#define RTPOSE_W16_PF 6
+#endif
+
+// conv_wino4.hip: first pair step of a chunk's patch loads
+#ifndef RTPOSE_EXP_W4_L0
+#define RTPOSE_EXP_W4_L0 6
 #endif

@@ -753,6 +753,8 @@ int conv2d_wino_ok(int cin, int cout, int k) {
   return k == 3 && cin > 0 && cin % wino_ck(cout, cin) == 0 && cin / wino_ck(cout, cin) >= 2;
 }
 
+int conv2d_wino16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
+
 int conv2d_wino_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s) {
   using namespace wino;
   if (!d || ngroups < 1 || ngroups > 2) return fail(RTPOSE_E_INVAL, "conv2d_winograd: ngroups must be 1 or 2");
@@ -848,7 +850,15 @@ int conv2d_wino_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
     RTPOSE_HIP_CHECK(hipGetLastError());
     return 0;
   }
-  if (wm == 1) return launch_inst<1, 4, 16>(a, grid, s);
+  if (wm == 1) {
+    static int use16 = -1;  // developer switch: the two-waves-per-SIMD form (conv_wino16.hip)
+    if (use16 < 0) {
+      const char* e = dev_env("RTPOSE_W3_16");
+      use16 = e ? atoi(e) : 0;
+    }
+    if (use16) return conv2d_wino16_launch(d, ngroups, N, H, W, s);
+    return launch_inst<1, 4, 16>(a, grid, s);
+  }
   // 64 columns (conv1_2): 64 wtiles x 64 columns; 16-channel chunks with a whole patch per thread where cin allows
   if (ck == 16) return launch_inst<2, 2, 16>(a, grid, s);
   return launch_inst<2, 2, 8>(a, grid, s);
@@ -886,9 +896,16 @@ size_t packed_weight_floats_wino7(int cout, int cin, int fm);
 size_t conv2d_wino7_scratch_bytes(int blocks);
 int* conv2d_wino7_scratch_err(void* scratch, int blocks);
 int wino_amplification_launch(const float* w, int cout, int cin, int k, int fm, float* amp, hipStream_t s);
+// k = 3, F(4x4,3x3): csrc/conv_wino4.hip
+int conv2d_wino4_ok(int cin, int cout);
+size_t packed_weight_floats_wino4(int cout, int cin);
+int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
+int pack_weights_wino4_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map,
+                              int cin_packed, float* wp, float* bp, hipStream_t s);
+int wino4_amplification_launch(const float* w, int cout, int cin, float* amp, hipStream_t s);
 
 int conv2d_winograd_fits(int k, int cin, int cout, int pool, int N, int H, int W, int hs, int fm) {
-  if (k == 3) return conv2d_wino_ok(cin, cout, 3);
+  if (k == 3) return fm == 4 ? conv2d_wino4_ok(cin, cout) : conv2d_wino_ok(cin, cout, 3);
   if (k == 7) return !pool && conv2d_wino7_fits(cin, cout, N, H, W, hs, fm);
   return 0;
 }
@@ -909,6 +926,22 @@ size_t rtpose_packed_weight_floats_winograd(int cout, int cin, int k) {
   if (k == 7) return rtpose::packed_weight_floats_wino7(cout, cin, 0);
   // + 4 (chunk, frequency) blocks: the B prefetch runs two steps ahead
   return (size_t)(16 * cin + 64) * rtpose::cout_pad(cout);
+}
+
+size_t rtpose_packed_weight_floats_winograd3(int cout, int cin, int m) {
+  if (m == 4) return rtpose::packed_weight_floats_wino4(cout, cin);
+  return rtpose_packed_weight_floats_winograd(cout, cin, 3);
+}
+
+int rtpose_pack_conv_weights_winograd3(const float* w_oihw, const float* bias, int cout, int cin_src, int m,
+                                       const int32_t* cin_map, int cin_packed, float* w_packed,
+                                       float* bias_packed, void* stream) {
+  if (m == 4)
+    return rtpose::pack_weights_wino4_launch(w_oihw, bias, cout, cin_src, cin_map, cin_packed, w_packed, bias_packed,
+                                             rtpose::as_stream(stream));
+  if (m != 0 && m != 2) return rtpose::fail(RTPOSE_E_INVAL, "pack_winograd3: m must be 0 / 2 (F(2x2,3x3)) or 4 (F(4x4,3x3))");
+  return rtpose::pack_weights_wino_launch(w_oihw, bias, cout, cin_src, cin_map, cin_packed, w_packed, bias_packed,
+                                          rtpose::as_stream(stream));
 }
 
 int rtpose_pack_conv_weights_winograd7(const float* w_oihw, const float* bias, int cout, int cin_src, int m,
@@ -938,6 +971,7 @@ int rtpose_conv2d_winograd_ex(const rtpose_conv_desc* d, int ngroups, int N, int
   if (d && d[0].k == 7)
     return rtpose::conv2d_wino7_launch(d, ngroups, N, H, W, d[0].wino_m, scratch, scratch_bytes,
                                        rtpose::as_stream(stream));
+  if (d && d[0].k == 3 && d[0].wino_m == 4) return rtpose::conv2d_wino4_launch(d, ngroups, N, H, W, rtpose::as_stream(stream));
   return rtpose::conv2d_wino_launch(d, ngroups, N, H, W, rtpose::as_stream(stream));
 }
 
@@ -956,6 +990,7 @@ int rtpose_conv2d_winograd(const rtpose_conv_desc* d, int ngroups, int N, int H,
 
 int rtpose_winograd_amplification(const float* w_oihw, int cout, int cin, int k, int m, float* amp_device,
                                   void* stream) {
+  if (k == 3 && m == 4) return rtpose::wino4_amplification_launch(w_oihw, cout, cin, amp_device, rtpose::as_stream(stream));
   return rtpose::wino_amplification_launch(w_oihw, cout, cin, k, m, amp_device, rtpose::as_stream(stream));
 }
 

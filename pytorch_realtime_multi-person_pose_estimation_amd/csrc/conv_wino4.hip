@@ -1,0 +1,611 @@
+// fp32 Winograd F(4x4, 3x3) convolution for gfx950 (MI355X): stride 1, "same" padding, fused bias (+ReLU) (+2x2 max-pool).
+//
+// Stands in for the 3x3 nn.Conv2d + nn.ReLU (+ nn.MaxPool2d) modules of the VGG-19 front end and of stage 1
+// (lib/network/rtpose_vgg.py:23-35, :95-105) where the plan selects the form (rtpose_net_options.winograd3 = 4 and the
+// layer's amplification estimate is below amp_limit; rtpose_conv_desc.wino_m = 4 for a single launch).  A "wtile" is a
+// 4 x 4 block of output pixels, computed from a 6 x 6 input patch through 36 "frequencies":
+//
+//   Y = A^T [ sum_c (G g_c G^T) o (B^T d_c B) ] A        36 multiplies per 16 outputs and input channel instead of 144
+//
+// i.e. 4x fewer matrix-core flops than the direct sum and 1.78x fewer than F(2x2,3x3) (conv_wino.hip), paid for with
+// transforms that are no longer additions only.  Interpolation points 0, +-3/4, +-3/2, inf: every entry of B^T and A^T
+// is a dyadic fraction (exact in fp32), and of the symmetric point pairs tried (oracle/winograd_tables.py,
+// DESIGN.md §3.0) this one has the smallest measured element-wise error - gamma ~5 against 20 for the textbook points
+// 0, +-1, +-2 (F(2x2,3x3): 1.5..18; the 7x7 forms the network already runs: F(4,7) 277, F(6,7) 439).
+//
+// MI355X shape:
+//  * a block = 8 waves = 32 wtiles x 64 output columns, two waves per SIMD; wave (wm, wn) owns all 36 frequencies of
+//    16 wtiles x 16 columns on v_mfma_f32_16x16x4_f32: 36 accumulators x 4 registers = 144 of the 256 a wave may hold
+//    at two waves per SIMD.  The output transform is lane-local (a lane holds 4 consecutive wtiles of one column).
+//  * channel chunks of 8: per chunk and frequency PAIR a wave issues 4 MFMAs fed by ONE ds_read_b128 (A: the pair's
+//    values of channels 2 kq, 2 kq + 1 for wtile r16) and ONE 16-byte buffer load (B: the same for column r16),
+//    5 pairs ahead in a 6-entry register ring.  MFMA j of a frequency contracts the channels {2 kq + j : kq = 0..3}.
+//  * the 2-D input transform does not fit beside 144 accumulators in one piece (a 6 x 6 patch of 4 channels is 144
+//    registers), so it runs in two 1-D stages through LDS, each 12 packed fmas + 6 LDS accesses of 16 bytes per item:
+//      stage 1  item (wtile, channel group, patch row y): 6 pixels -> B^T along x -> U[fx][y]        waves 0..5 (y = wave)
+//      stage 2  item (wtile, channel group, fx): U[fx][0..5] -> B^T along y -> V[fx * 6 + fy]         waves 2..7 (fx = wave - 2)
+//    (three items per SIMD either way).  Pipeline over the "positions" (tile, chunk) of a persistent block, one barrier
+//    per chunk: while chunk s is multiplied from V[s & 1], stage 2 turns U[(s + 1) & 1] into V[(s + 1) & 1], stage 1 turns the
+//    patch rows of s + 2 (in registers) into U[s & 1], and the rows of s + 3 are requested.  Siblings on a SIMD take
+//    their transform turns one step apart, so the matrix pipe always has a wave that multiplies.
+//  * patch rows / columns past the image (the last wtile row / column when H, W are not multiples of 4) are CLAMPED
+//    to the zero gap row / column of the shared-gap layout: they would only meet outputs that are not stored, but
+//    through the transforms they cancel only up to rounding, and an image would depend on its neighbour in the batch.
+//  * B = transformed filters packed [chunk][frequency pair][kq][cout_pad][2 frequencies][2 channels]
+//    (rtpose_pack_conv_weights_winograd3, m = 4).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+
+#include "common.h"
+#include "conv_exp.h"
+#include "wino_common.h"
+
+namespace rtpose {
+
+namespace wino4 {
+
+using namespace winoc;
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct Group {
+  const float* in;
+  const float* w;
+  const float* bias;
+  float* out;
+  int in_cstride, in_choff, in_ws, in_hs, in_lead;
+  int out_cstride, out_choff, out_ws, out_hs, out_lead;
+  int cout, cout_pad;
+  size_t in_bytes, w_bytes, out_bytes;
+};
+
+struct Args {
+  Group g[2];
+  int N, H, W;
+  int TY, TX, T;  // wtiles per column / row of an image, and in the whole batch
+  int cin;
+  int relu, pool;
+  int mtiles, ntiles, ncombo, xcd_remap;
+  int persist;
+};
+
+constexpr int NT = 32;    // wtiles per block
+constexpr int NC = 64;    // output columns per block
+constexpr int CK = 8;     // channels per chunk
+constexpr int NFP = 18;   // frequency pairs
+constexpr int NB = 6;     // B ring entries (one per frequency pair)
+constexpr int PF = 5;     // B prefetch distance in pairs
+constexpr int VBUF = NFP * 4 * NT;  // float4 per V buffer: [pair][kq][wtile]
+constexpr int UBUF = 36 * 2 * NT;   // float4 per U buffer: [fx][y][channel group][wtile]
+static_assert(NFP % NB == 0, "the B ring rotates in step with the chunk");
+
+// B^T of F(4,3) for the points 0, +-3/4, +-3/2, inf along one axis (rows scaled by N_f; the filter transform divides):
+//   [81/64 0 -45/16 0 1 0], [0 -+27/16 -9/4 +-3/4 1 0], [0 -+27/32 -9/16 +-3/2 1 0], [0 81/64 0 -45/16 0 1]
+// the +-p rows share their even and odd halves: 12 fmas on 4 channels = 24 packed instructions
+__device__ __forceinline__ void bt6(const F4 (&d)[6], F4 (&v)[6]) {
+  v[0] = fma4(1.265625f, d[0], fma4(-2.8125f, d[2], d[4]));
+  const F4 e1 = fma4(-2.25f, d[2], d[4]), o1 = fma4(-2.25f, d[1], d[3]);
+  v[1] = fma4(0.75f, o1, e1);
+  v[2] = fma4(-0.75f, o1, e1);
+  const F4 e2 = fma4(-0.5625f, d[2], d[4]), o2 = fma4(-0.5625f, d[1], d[3]);
+  v[3] = fma4(1.5f, o2, e2);
+  v[4] = fma4(-1.5f, o2, e2);
+  v[5] = fma4(1.265625f, d[1], fma4(-2.8125f, d[3], d[5]));
+}
+
+// A^T of F(4,3) along one axis: [1 1 1 1 1 0], [0 3/4 -3/4 3/2 -3/2 0], [0 9/16 9/16 9/4 9/4 0], [0 27/64 -27/64 27/8 -27/8 1]
+__device__ __forceinline__ f2 splat(float s) { return f2{s, s}; }
+// (in halves - outputs 0, 1 / 2, 3 - so that the epilogue can work on two output rows at a time)
+__device__ __forceinline__ void at4_lo(const f2 (&m)[6], f2& y0, f2& y1) {
+  const f2 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  y0 = (m[0] + s12) + s34;
+  y1 = __builtin_elementwise_fma(splat(1.5f), d34, splat(0.75f) * d12);
+}
+__device__ __forceinline__ void at4_hi(const f2 (&m)[6], f2& y2, f2& y3) {
+  const f2 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  y2 = __builtin_elementwise_fma(splat(2.25f), s34, splat(0.5625f) * s12);
+  y3 = __builtin_elementwise_fma(splat(3.375f), d34, splat(0.421875f) * d12) + m[5];
+}
+
+__global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
+  extern __shared__ __attribute__((aligned(16))) float4 L4[];
+  float4* const V4 = L4;
+  float4* const U4 = L4 + 2 * VBUF;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv & 1, wn = wv >> 1;  // row tile (16 wtiles) and 16-column slice of the wave
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  // ---- block -> (n tile, group) and its m tiles (as wino_f32) ----------------------------------------------------
+  const int bi = blockIdx.x;
+  int j0, jstep, c;
+  if (A.persist) {
+    c = bi % A.ncombo;
+    j0 = bi / A.ncombo;
+    jstep = gridDim.x / A.ncombo;
+  } else {
+    if (A.xcd_remap) {
+      const int xcd = bi & 7, j = bi >> 3;
+      c = j % A.ncombo;
+      j0 = (j / A.ncombo) * 8 + xcd;
+    } else {
+      j0 = bi % A.mtiles;
+      c = bi / A.mtiles;
+    }
+    jstep = A.mtiles;
+  }
+  if (j0 >= A.mtiles) return;
+  const int nt = c % A.ntiles, grp = c / A.ntiles;
+  const Group g = grp ? A.g[1] : A.g[0];
+  const int TT = A.TY * A.TX;
+
+  // ---- transform roles ----------------------------------------------------------------------------------------------
+  const bool s1 = wv < 6, s2 = wv >= 2;
+  const int turn = wv >> 2;               // siblings on a SIMD (waves w, w + 4) take their turns one step apart
+  const int wl = lane & 31, cg = lane >> 5;
+  const int py = wv;                      // stage 1: patch row
+  const int fx = max(wv - 2, 0);          // stage 2: frequency along x
+  const i32x4 rw = make_rsrc(g.w, g.w_bytes);
+  // the "load cursor": the (tile, chunk) position whose patch rows are requested next, 3 positions ahead of the multiply
+  i32x4 rin;
+  unsigned pv[4];  // byte offsets of pixel 0 and of the pixels 3, 4, 5 (clamped to the gap column) of the row
+  int lt = j0, lc = 3;
+  const unsigned pxb = (unsigned)g.in_cstride * 4;
+  auto set_loader = [&](int mt, i32x4& r_, unsigned (&v_)[4]) {
+    size_t q0;
+    {
+      const int t = min(mt * NT, A.T - 1);
+      const int n = t / TT, r = t - n * TT;
+      const int ty = r / A.TX, tx = r - ty * A.TX;
+      q0 = (size_t)g.in_lead + (size_t)(n * g.in_hs + 4 * ty - 1) * g.in_ws + (4 * tx - 1);
+    }
+    const int t = min(mt * NT + wl, A.T - 1);
+    const int n = t / TT, r = t - n * TT;
+    const int ty = r / A.TX, tx = r - ty * A.TX;
+    const int yy = min(4 * ty - 1 + py, A.H);  // rows past the image: the zero gap row
+    const size_t qq = (size_t)g.in_lead + (size_t)(n * g.in_hs + yy) * g.in_ws + (4 * tx - 1);
+    const size_t o0 = q0 * g.in_cstride + g.in_choff;
+    r_ = make_rsrc(g.in + o0, g.in_bytes - o0 * 4);
+    v_[0] = (unsigned)(((qq - q0) * g.in_cstride + cg * 4) * 4);
+#pragma unroll
+    for (int n5 = 3; n5 < 6; ++n5) v_[n5 - 2] = v_[0] + (unsigned)min(n5, A.W + 1 - 4 * tx) * pxb;  // columns past W: the gap column
+  };
+  F4 p[6];
+  auto load_piece = [&](const i32x4& r_, const unsigned (&v_)[4], int chunk, int n5) {
+    const unsigned cb = (unsigned)chunk * (CK * 4);
+#ifdef RTPOSE_EXP_W4_AUX  // cache policy bits of the patch loads (1 sc0, 2 nt, 16 sc1)
+    const f32x4 t = n5 < 3 ? llvm_raw_buffer_load_v4f32(r_, (int)v_[0], (int)(cb + n5 * pxb), RTPOSE_EXP_W4_AUX)
+                           : llvm_raw_buffer_load_v4f32(r_, (int)v_[n5 - 2], (int)cb, RTPOSE_EXP_W4_AUX);
+    p[n5] = F4{f2{t.x, t.y}, f2{t.z, t.w}};
+#else
+    p[n5] = n5 < 3 ? bload(r_, v_[0], cb + n5 * pxb) : bload(r_, v_[n5 - 2], cb);
+#endif
+  };
+  const int ust = (py * 2 + cg) * NT + wl;          // U[fx][y = py][cg][wtile], + fx * 6 * 2 * NT
+  const int uld = ((fx * 6) * 2 + cg) * NT + wl;    // U[fx][y][cg][wtile], + y * 2 * NT
+  const int vst = ((fx * 3) * 4 + 2 * cg) * NT + wl;  // V[pair = fx * 3 + fy / 2][kq = 2 cg + h][wtile]
+  auto stage1 = [&](int ubuf) {
+    F4 u[6];
+    bt6(p, u);
+    float4* dst = U4 + ubuf * UBUF + ust;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) dst[f * 6 * 2 * NT] = to_float4(u[f]);
+  };
+  F4 q[6];
+  auto stage2_read = [&](int ubuf) {
+    const float4* src = U4 + ubuf * UBUF + uld;
+#pragma unroll
+    for (int y = 0; y < 6; ++y) {
+      const float4 t = src[y * 2 * NT];
+      q[y] = F4{f2{t.x, t.y}, f2{t.z, t.w}};
+    }
+  };
+  auto stage2 = [&](int vbuf) {
+    F4 v[6];
+    bt6(q, v);
+    float4* dst = V4 + vbuf * VBUF + vst;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {  // frequencies fx * 6 + 2 i, + 1: channels (0, 1) -> plane 2 cg, (2, 3) -> plane 2 cg + 1
+      dst[i * 4 * NT] = make_float4(v[2 * i].lo.x, v[2 * i].lo.y, v[2 * i + 1].lo.x, v[2 * i + 1].lo.y);
+      dst[i * 4 * NT + NT] = make_float4(v[2 * i].hi.x, v[2 * i].hi.y, v[2 * i + 1].hi.x, v[2 * i + 1].hi.y);
+    }
+  };
+
+  // ---- MFMA roles ---------------------------------------------------------------------------------------------------
+  const int ncol = nt * NC + wn * 16 + r16;
+  floatx4 acc[36];
+  const float bias0 = g.bias[ncol];
+  const unsigned boff = (unsigned)((kq * g.cout_pad + ncol) * 16);
+  const unsigned fstep = (unsigned)(4 * g.cout_pad * 16);  // bytes per (chunk, frequency pair)
+  unsigned wso = 0;
+  float4 bs[NB];
+  const int nchunks = A.cin / CK;  // >= 3 (host)
+
+  // ---- prologue: V[0] <- position 0, U[1] <- position 1, patch rows of position 2 in flight ---------------------------
+  set_loader(j0, rin, pv);
+  // (the loads and the U reads are issued by all 8 waves - the waves 6, 7 / 0, 1 discard theirs: a load under a
+  //  wave-uniform branch keeps its 24 destination registers alive around the whole loop for the register allocator)
+#pragma unroll
+  for (int i = 0; i < 6; ++i) load_piece(rin, pv, 0, i);
+  if (s1) stage1(0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) load_piece(rin, pv, 1, i);
+#pragma unroll
+  for (int f = 0; f < PF; ++f) {
+    bs[f] = bload_f4(rw, boff, wso);
+    wso += fstep;
+  }
+  __syncthreads();
+  stage2_read(0);
+  if (s2) stage2(0);
+  if (s1) stage1(1);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) load_piece(rin, pv, 2, i);
+  __syncthreads();
+
+  int par = 0;
+#define RTPOSE_PIN()             \
+  asm volatile("" ::: "memory"); \
+  __builtin_amdgcn_sched_barrier(0)
+  for (int mt = j0; mt < A.mtiles; mt += jstep) {
+#pragma unroll
+    for (int f = 0; f < 36; ++f)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[f][v] = 0.f;
+
+    float4 a[2];
+#pragma unroll 1
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const float4* va = V4 + par * VBUF + kq * NT + wm * 16 + r16;
+      const int nbuf = par ^ 1;
+      // position + 3: the chunk whose patch rows are requested now (past the block's last tile: that tile again)
+      if (lc == nchunks) {
+        lc = 0;
+        lt += jstep;
+        if (lt < A.mtiles) set_loader(lt, rin, pv);
+      }
+      const int c3 = lc++;
+      const bool last = chunk == nchunks - 1;
+      a[0] = va[0];
+#pragma unroll
+      for (int fp = 0; fp < NFP; ++fp) {
+        const float4 av = a[fp & 1], bv = bs[fp % NB];
+        acc[2 * fp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[2 * fp], 0, 0, 0);
+        acc[2 * fp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[2 * fp + 1], 0, 0, 0);
+        acc[2 * fp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[2 * fp], 0, 0, 0);
+        acc[2 * fp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[2 * fp + 1], 0, 0, 0);
+        RTPOSE_PIN();
+        if (fp < NFP - 1) a[(fp + 1) & 1] = RTPOSE_EXP_A(va[(fp + 1) * 4 * NT], a[fp & 1]);
+        // B PF pairs ahead; PF before the end of a tile's last chunk the ring wraps to the next tile
+        bs[(fp + PF) % NB] = RTPOSE_EXP_B(bload_f4(rw, boff, wso), bs[fp % NB]);
+        wso = (fp == NFP - 1 - PF && last) ? 0u : wso + fstep;
+        if (RTPOSE_EXP_STAGE) {
+#ifdef RTPOSE_EXP_W4_NOXF  // timing only: the patch loads without the transform
+          if (fp == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) asm volatile("" ::"v"(p[i].lo.x), "v"(p[i].lo.y), "v"(p[i].hi.x), "v"(p[i].hi.y));
+          } else if (fp >= 6 && fp < 12) {
+            load_piece(rin, pv, c3, fp - 6);
+          }
+#else
+          if (fp < 2) {
+            if (s1 && fp == turn) stage1(par);            // patch rows of position + 2 -> U[par]
+          } else if (fp < 4) {
+            if (fp == 2 + turn) stage2_read(nbuf);        // U[par ^ 1] = position + 1
+          } else if (fp < 6) {
+            if (s2 && fp == 4 + turn) stage2(nbuf);       // -> V[par ^ 1]
+          }
+#ifndef RTPOSE_EXP_W4_NOLOAD  // (timing only: the transform on stale registers)
+          if (fp >= RTPOSE_EXP_W4_L0 && fp < RTPOSE_EXP_W4_L0 + 6) load_piece(rin, pv, c3, fp - RTPOSE_EXP_W4_L0);  // patch rows of position + 3
+#endif
+#endif
+        }
+        RTPOSE_PIN();
+      }
+      __syncthreads();
+      par ^= 1;
+    }
+    // ---- epilogue: output transform A^T M A, + bias (+ReLU) (+2x2 max-pool), masked stores ------------------------
+    // register v of acc[f] = wtile wm * 16 + 4 kq + v of the tile, column ncol: 16 lanes = 64 contiguous bytes
+    {
+      const bool col_ok = ncol < g.cout;
+      const int sc = A.pool ? 2 : 4;
+      auto wt_q = [&](int n, int ty, int tx) -> int { return (n * g.out_hs + sc * ty) * g.out_ws + sc * tx; };
+      int q0;
+      {
+        const int t = min(mt * NT, A.T - 1);
+        const int n = t / TT, r = t - n * TT;
+        const int ty = r / A.TX;
+        q0 = wt_q(n, ty, r - ty * A.TX);
+      }
+      const size_t oo0 = ((size_t)g.out_lead + (size_t)q0) * g.out_cstride + g.out_choff;
+      const i32x4 rout = make_rsrc(g.out + oo0, g.out_bytes - oo0 * 4);
+      const unsigned cs4 = (unsigned)g.out_cstride * 4, row4 = (unsigned)g.out_ws * cs4;
+      const unsigned col4 = (unsigned)ncol * 4;
+      int tcur = mt * NT + wm * 16 + 4 * kq;
+      int sn = tcur / TT, sy, sx;
+      {
+        const int r = tcur - sn * TT;
+        sy = r / A.TX;
+        sx = r - sy * A.TX;
+      }
+#pragma unroll
+      for (int vp = 0; vp < 2; ++vp) {
+        // geometry of the two wtiles of the pair
+        unsigned off[2];
+        bool okv[2];
+        int ylim[2], xlim[2];  // valid output rows / columns of the wtile (<= 4)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          okv[e] = col_ok && tcur < A.T;
+          off[e] = (unsigned)(wt_q(sn, sy, sx) - q0) * cs4 + col4;
+          ylim[e] = A.H - 4 * sy;
+          xlim[e] = A.W - 4 * sx;
+          ++tcur;
+          const bool wx = sx + 1 >= A.TX, wy = wx && sy + 1 >= A.TY;
+          sx = wx ? 0 : sx + 1;
+          sy = wy ? 0 : (wx ? sy + 1 : sy);
+          sn += wy ? 1 : 0;
+        }
+        // two output rows at a time (24 registers of row sums instead of 48: the next tile's prefetched patch rows
+        // and filter ring stay in registers through the epilogue)
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+          // pass 1: along y (fy -> output rows 2 ih, 2 ih + 1) for every fx
+          f2 s[6][2];
+#pragma unroll
+          for (int x = 0; x < 6; ++x) {
+            f2 m[6];
+#pragma unroll
+            for (int y = 0; y < 6; ++y) m[y] = f2{acc[x * 6 + y][2 * vp], acc[x * 6 + y][2 * vp + 1]};
+            if (ih == 0) at4_lo(m, s[x][0], s[x][1]);
+            else at4_hi(m, s[x][0], s[x][1]);
+          }
+          // pass 2: along x (fx -> output column j)
+          f2 yy[2][4];
+#pragma unroll
+          for (int il = 0; il < 2; ++il) {
+            f2 m[6];
+#pragma unroll
+            for (int x = 0; x < 6; ++x) m[x] = s[x][il];
+            at4_lo(m, yy[il][0], yy[il][1]);
+            at4_hi(m, yy[il][2], yy[il][3]);
+          }
+          if (A.pool) {
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {
+              f2 mx = __builtin_elementwise_max(__builtin_elementwise_max(yy[0][2 * jh], yy[0][2 * jh + 1]),
+                                                __builtin_elementwise_max(yy[1][2 * jh], yy[1][2 * jh + 1]));
+              mx = mx + splat(bias0);
+              if (A.relu) mx = __builtin_elementwise_max(mx, splat(0.f));
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const bool ok = okv[e] && 2 * ih < ylim[e] && 2 * jh < xlim[e];
+                bstore(mx[e], rout, ok ? off[e] : kNoStore, ih * row4 + jh * cs4);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int il = 0; il < 2; ++il)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int i = 2 * ih + il;
+                f2 o = yy[il][j] + splat(bias0);
+                if (A.relu) o = __builtin_elementwise_max(o, splat(0.f));
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                  const bool ok = okv[e] && i < ylim[e] && j < xlim[e];
+                  bstore(o[e], rout, ok ? off[e] : kNoStore, i * row4 + j * cs4);
+                }
+              }
+          }
+        }
+      }
+    }
+  }  // m tiles of this block
+#undef RTPOSE_PIN
+}
+
+// ---- weight packing: U = G g G^T for the points 0, +-3/4, +-3/2, inf (double arithmetic, one rounding) -------------
+// packed[chunk][pair][kq][cout_pad][f2][e]: frequency f = fx * 6 + fy = 2 pair + f2, channel chunk * 8 + 2 kq + e
+__device__ __forceinline__ double g43(int f, int k) {
+  // rows of G (the B^T rows above are scaled by N_f, G divides by it)
+  const double G[6][3] = {{64.0 / 81.0, 0.0, 0.0},
+                          {-128.0 / 243.0, -32.0 / 81.0, -8.0 / 27.0},
+                          {-128.0 / 243.0, 32.0 / 81.0, -8.0 / 27.0},
+                          {32.0 / 243.0, 16.0 / 81.0, 8.0 / 27.0},
+                          {32.0 / 243.0, -16.0 / 81.0, 8.0 / 27.0},
+                          {0.0, 0.0, 1.0}};
+  return G[f][k];
+}
+__device__ __forceinline__ double u43(const float* gw, int fxi, int fyi) {
+  double v = 0.0;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) v += g43(fyi, ky) * g43(fxi, kx) * (double)gw[ky * 3 + kx];
+  return v;
+}
+
+__global__ void pack_wino4_kernel(const float* __restrict__ w, const float* __restrict__ bias, int cout, int cin_src,
+                                  const int32_t* __restrict__ cin_map, int cin_packed, int coutp,
+                                  float* __restrict__ wp, float* __restrict__ bp) {
+  const size_t total = (size_t)36 * cin_packed * coutp;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)coutp) bp[i] = (i < (size_t)cout && bias) ? bias[i] : 0.f;
+  if (i >= total) return;
+  const int e = i & 1, fh = (i >> 1) & 1;
+  size_t r = i >> 2;
+  const int n = r % coutp;
+  r /= coutp;
+  const int kq = r & 3;
+  r >>= 2;
+  const int fp = r % NFP;
+  const int chunk = r / NFP;
+  const int cc = chunk * CK + 2 * kq + e;
+  const int src = cin_map ? cin_map[cc] : (cc < cin_src ? cc : -1);
+  float v = 0.f;
+  if (n < cout && src >= 0 && src < cin_src) {
+    const int f = 2 * fp + fh;
+    v = (float)u43(w + ((size_t)n * cin_src + src) * 9, f / 6, f % 6);
+  }
+  wp[i] = v;
+}
+
+// amplification estimate of a 3x3 filter bank in F(4x4,3x3) (the definition: conv_wino7.hip, wino_amp_kernel)
+__global__ void wino4_amp_kernel(const float* __restrict__ w, int cout, int cin, float* __restrict__ amp) {
+  __shared__ float red[37][256];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  float sf[36], den = 0.f;
+#pragma unroll
+  for (int f = 0; f < 36; ++f) sf[f] = 0.f;
+  for (int cidx = tid; cidx < cin; cidx += 256) {
+    const float* gw = w + ((size_t)o * cin + cidx) * 9;
+    for (int k = 0; k < 9; ++k) den += fabsf(gw[k]);
+#pragma unroll
+    for (int f = 0; f < 36; ++f) sf[f] += fabsf((float)u43(gw, f / 6, f % 6));
+  }
+#pragma unroll
+  for (int f = 0; f < 36; ++f) red[f][tid] = sf[f];
+  red[36][tid] = den;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st)
+      for (int f = 0; f < 37; ++f) red[f][tid] += red[f][tid + st];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float at[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f},
+                            {0.f, 0.75f, 0.75f, 1.5f, 1.5f, 0.f},
+                            {0.f, 0.5625f, 0.5625f, 2.25f, 2.25f, 0.f},
+                            {0.f, 0.421875f, 0.421875f, 3.375f, 3.375f, 1.f}};      // |A^T|
+    const float bsum[6] = {5.078125f, 5.6875f, 5.6875f, 3.90625f, 3.90625f, 5.078125f};  // sum_n |B^T[f][n]|
+    float num = 0.f;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        float v = 0.f;
+        for (int fxi = 0; fxi < 6; ++fxi)
+          for (int fyi = 0; fyi < 6; ++fyi) v += at[i][fyi] * at[j][fxi] * bsum[fyi] * bsum[fxi] * red[fxi * 6 + fyi][0];
+        num = fmaxf(num, v);
+      }
+    const float r = red[36][0] > 0.f ? num / red[36][0] : 0.f;
+    atomicMax(reinterpret_cast<int*>(amp), __float_as_int(r));
+  }
+}
+
+}  // namespace wino4
+
+// 1 when the 3x3 conv has an F(4x4,3x3) instance: 8-channel chunks, at least 3 of them (the transform pipeline is 3 deep)
+int conv2d_wino4_ok(int cin, int cout) { return cout > 0 && cin % 8 == 0 && cin >= 32; }
+
+size_t packed_weight_floats_wino4(int cout, int cin) { return (size_t)36 * cin * cout_pad(cout); }
+
+int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s) {
+  using namespace wino4;
+  if (!d || ngroups < 1 || ngroups > 2) return fail(RTPOSE_E_INVAL, "conv2d_winograd (4x4): ngroups must be 1 or 2");
+  const rtpose_conv_desc& d0 = d[0];
+  if (d0.k != 3 || !conv2d_wino4_ok(d0.cin, d0.cout))
+    return fail(RTPOSE_E_INVAL, "conv2d_winograd (4x4): k must be 3 and cin a multiple of 8, >= 32");
+  if (N <= 0 || H <= 0 || W <= 0) return fail(RTPOSE_E_INVAL, "conv2d_winograd: empty tensor");
+  if (d0.pool && ((H | W) & 1)) return fail(RTPOSE_E_INVAL, "conv2d_winograd: fused pool needs even H and W");
+  Args a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < ngroups; ++i) {
+    const rtpose_conv_desc& di = d[i];
+    if (di.k != 3 || di.cin != d0.cin || di.relu != d0.relu || di.pool != d0.pool ||
+        cout_pad(di.cout) != cout_pad(d0.cout) || di.lin.ws != d0.lin.ws || di.lin.hs != d0.lin.hs)
+      return fail(RTPOSE_E_INVAL, "conv2d_winograd: grouped convs must share geometry");
+    if (di.lin.ws < W + 1 || di.lin.hs < H + 1 || di.lin.lead < di.lin.ws + 1)
+      return fail(RTPOSE_E_INVAL, "conv2d_winograd: input layout gap smaller than the conv padding");
+    if ((di.lin.cstride % 4) || (di.lin.choff % 4))
+      return fail(RTPOSE_E_INVAL, "conv2d_winograd: input slice must be 16-byte aligned");
+    if (di.lin.choff + di.cin > di.lin.cstride)
+      return fail(RTPOSE_E_INVAL, "conv2d_winograd: input slice exceeds cstride");
+    if (di.out_cmap) return fail(RTPOSE_E_INVAL, "conv2d_winograd: out_cmap is not supported");
+    Group& g = a.g[i];
+    g.in = di.in;
+    g.w = di.w_packed;
+    g.bias = di.bias_packed;
+    g.out = di.out;
+    g.in_cstride = di.lin.cstride;
+    g.in_choff = di.lin.choff;
+    g.in_ws = di.lin.ws;
+    g.in_hs = di.lin.hs;
+    g.in_lead = di.lin.lead;
+    g.out_cstride = di.lout.cstride;
+    g.out_choff = di.lout.choff;
+    g.out_ws = di.lout.ws;
+    g.out_hs = di.lout.hs;
+    g.out_lead = di.lout.lead;
+    g.cout = di.cout;
+    g.cout_pad = cout_pad(di.cout);
+    g.in_bytes = rtpose_layout_pixels(&di.lin, N, H, W) * (size_t)di.lin.cstride * sizeof(float);
+    g.w_bytes = packed_weight_floats_wino4(di.cout, di.cin) * sizeof(float);
+    g.out_bytes = rtpose_layout_pixels(&di.lout, N, di.pool ? H / 2 : H, di.pool ? W / 2 : W) *
+                  (size_t)di.lout.cstride * sizeof(float);
+  }
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.TY = ceil_div(H, 4);
+  a.TX = ceil_div(W, 4);
+  const long T = (long)N * a.TY * a.TX;
+  if (T > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv2d_winograd: tensor too large");
+  a.T = (int)T;
+  a.cin = d0.cin;
+  a.relu = d0.relu;
+  a.pool = d0.pool;
+  a.mtiles = ceil_div(a.T, NT);
+  a.ntiles = cout_pad(d0.cout) / NC;
+  a.ncombo = a.ntiles * ngroups;
+  a.xcd_remap = (a.ncombo > 1 && a.mtiles >= 64) ? 1 : 0;
+  long ids = a.xcd_remap ? (long)8 * a.ncombo * ceil_div(a.mtiles, 8) : (long)a.mtiles * a.ncombo;
+  if (ids > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv2d_winograd: grid too large");
+  const int n_cu = device_cu_count();
+  if ((long)a.mtiles * a.ncombo > n_cu && n_cu % a.ncombo == 0) {
+    a.persist = 1;
+    ids = n_cu;
+  }
+  static PerDeviceOnce attr_set;
+  const int dev = current_device();
+  if (!attr_set.is_set(dev)) {
+    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_f32),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_set.set(dev);
+  }
+  hipLaunchKernelGGL(wino4_f32, dim3((unsigned)ids), dim3(512), (size_t)(2 * VBUF + 2 * UBUF) * sizeof(float4), s, a);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int pack_weights_wino4_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map,
+                              int cin_packed, float* wp, float* bp, hipStream_t s) {
+  if (!conv2d_wino4_ok(cin_packed, cout) || (cin_packed < cin_src && !cin_map))
+    return fail(RTPOSE_E_INVAL, "pack_winograd (4x4): cin_packed must be a multiple of 8, >= 32 and >= cin_src");
+  const int coutp = cout_pad(cout);
+  const size_t total = (size_t)36 * cin_packed * coutp;
+  const int threads = 256;
+  const unsigned blocks = (unsigned)((total + threads - 1) / threads);
+  hipLaunchKernelGGL(wino4::pack_wino4_kernel, dim3(blocks), dim3(threads), 0, s, w, bias, cout, cin_src, cin_map,
+                     cin_packed, coutp, wp, bp);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int wino4_amplification_launch(const float* w, int cout, int cin, float* amp, hipStream_t s) {
+  hipLaunchKernelGGL(wino4::wino4_amp_kernel, dim3(cout), dim3(256), 0, s, w, cout, cin, amp);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// MFMA flops a launch ISSUES: whole tiles of 32 wtiles x all 36 frequencies
+double conv2d_wino4_issued_flops(int cin, int cout, int N, int H, int W) {
+  const double T = (double)N * ceil_div(H, 4) * ceil_div(W, 4);
+  const double tiles = std::ceil(T / 32.0);
+  return 2.0 * tiles * 32.0 * 36.0 * (double)cin * cout_pad(cout);
+}
+
+}  // namespace rtpose

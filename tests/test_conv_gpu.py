@@ -51,6 +51,10 @@ def _run_conv(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, see
             wp = torch.zeros(lib.rtpose_packed_weight_floats_winograd7(cout, cin_p, wino_m), device=dev)
             capi.check(lib.rtpose_pack_conv_weights_winograd7(capi.ptr(ws[gi]), capi.ptr(bs[gi]), cout, cin, wino_m,
                                                               None, cin_p, capi.ptr(wp), capi.ptr(bp), stream))
+        elif winograd and k == 3 and wino_m:
+            wp = torch.zeros(lib.rtpose_packed_weight_floats_winograd3(cout, cin_p, wino_m), device=dev)
+            capi.check(lib.rtpose_pack_conv_weights_winograd3(capi.ptr(ws[gi]), capi.ptr(bs[gi]), cout, cin, wino_m,
+                                                              None, cin_p, capi.ptr(wp), capi.ptr(bp), stream))
         elif winograd:
             wp = torch.zeros(lib.rtpose_packed_weight_floats_winograd(cout, cin_p, k), device=dev)
             capi.check(lib.rtpose_pack_conv_weights_winograd(capi.ptr(ws[gi]), capi.ptr(bs[gi]), cout, cin, k, None,
@@ -65,7 +69,7 @@ def _run_conv(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, see
         d.lin = lin
         d.lout = Layout.padded(cstride_out, ho, wo, pad_out, choff=gi * cout + 1)
         d.cin, d.cout, d.k, d.relu, d.pool = cin_p, cout, k, int(relu), int(pool)
-        d.wino_m = wino_m if (winograd and k == 7) else 0
+        d.wino_m = wino_m if winograd else 0
     if winograd:
         assert lib.rtpose_conv2d_winograd_fits(descs, n, h, w) == 1
         # the hand-over scratch of the persistent 7x7 launches is the caller's (the library allocates nothing)
@@ -234,6 +238,40 @@ def test_winograd_matches_torch_cpu(capi, cuda, case):
     ref = refs[0]
     err = (outs[0] - ref).abs().max().item()
     assert err <= TOL * max(1.0, ref.abs().max().item()), "max abs err %g" % err
+
+
+WINO4_CASES = [
+    # n, h, w, cin (packed), cout, relu, pool, pad_in, pad_out      (k = 3, F(4x4,3x3): csrc/conv_wino4.hip)
+    (2, 46, 46, 256, 512, 1, 0, 1, 1),     # conv4_1: 8 column tiles, H, W % 4 == 2 (clamped patch rows / columns)
+    (1, 46, 46, 128, 128, 1, 0, 3, 1),     # stage-1 conv reading the P = 3 concat layout
+    (3, 96, 80, 64, 64, 1, 1, 1, 1),       # conv1_2 shape: fused pool, one column tile
+    (1, 100, 92, 128, 256, 1, 0, 1, 1),    # H, W % 4 == 0
+    (2, 45, 47, 32, 64, 0, 0, 1, 0),       # odd sizes (W % 4 == 3, H % 4 == 1), no ReLU, 4 chunks
+    (5, 7, 9, 40, 24, 1, 0, 1, 3),         # tiny maps: a block spans several images; ragged cout; 5 chunks
+    (1, 30, 44, 72, 128, 1, 1, 2, 0),      # pool with H % 4 == 2; gap wider than the padding
+    (40, 46, 46, 64, 128, 1, 0, 1, 1),     # persistent blocks: 180 m tiles x 2 column tiles > 256
+]
+
+
+@pytest.mark.parametrize("case", WINO4_CASES)
+def test_winograd4_matches_torch_cpu(capi, cuda, case):
+    n, h, w, cin, cout, relu, pool, pin, pout = case
+    outs, refs = _run_conv(capi, cuda, n, h, w, cin, cout, 3, relu, pool, pin, pout, seed=hash(case) % 1000,
+                           cin_pad=cin, winograd=True, wino_m=4)
+    ref = refs[0]
+    err = (outs[0] - ref).abs().max().item()
+    assert err <= TOL * max(1.0, ref.abs().max().item()), "max abs err %g" % err
+
+
+def test_winograd4_grouped_branches_and_batch_invariance(capi, cuda):
+    outs, refs = _run_conv(capi, cuda, 2, 46, 46, 128, 128, 3, 1, 0, 3, 3, seed=9, groups=2, winograd=True, wino_m=4)
+    for o, r in zip(outs, refs):
+        assert (o - r).abs().max().item() <= TOL * max(1.0, r.abs().max().item())
+    # an image's result does not depend on its neighbours in the batch (clamped patch rows / columns)
+    big, _ = _run_conv(capi, cuda, 3, 45, 47, 64, 64, 3, 1, 0, 1, 1, seed=31, winograd=True, wino_m=4, skip_ref=True)
+    one, _ = _run_conv(capi, cuda, 3, 45, 47, 64, 64, 3, 1, 0, 1, 1, seed=31, winograd=True, wino_m=4, skip_ref=True,
+                       only_images=1)
+    assert torch.equal(big[0][:1], one[0])
 
 
 def test_winograd_grouped_branches_and_direct_agree(capi, cuda):
