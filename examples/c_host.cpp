@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
   rtpose_net_options opt;
   opt.struct_bytes = sizeof(opt);
   opt.dtype = dtype;
-  opt.winograd3 = !std::strcmp(mode, "direct") ? 0 : RTPOSE_WINO_DEFAULT;
+  opt.winograd3 = !std::strcmp(mode, "direct") ? 0 : !std::strcmp(mode, "auto") ? RTPOSE_WINO3_AUTO : RTPOSE_WINO_DEFAULT;
   opt.winograd7 = !std::strcmp(mode, "auto") ? RTPOSE_WINO7_AUTO : !std::strcmp(mode, "direct") ? 0
                   : !std::strcmp(mode, "f47") ? 4 : RTPOSE_WINO_DEFAULT;
   opt.amp_limit = 0.f;  // library default
@@ -84,17 +84,18 @@ int main(int argc, char** argv) {
   // fixes the per-layer forms of an "auto" plan (reads the amplification estimates back once)
   CK(rtpose_net_finalize_weights(net, s));
   {
-    int nform[7] = {0, 0, 0, 0, 0, 0, 0};
-    float amp_max[3] = {0.f, 0.f, 0.f};
+    int nform[44] = {0};
+    float amp_max[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < rtpose_net_num_convs(net); ++i) {
       int form = 0;
-      float amp[3];
+      float amp[4];
       CK(rtpose_net_conv_numerics(net, i, &form, amp, s));
       ++nform[form];
-      for (int j = 0; j < 3; ++j) amp_max[j] = amp[j] > amp_max[j] ? amp[j] : amp_max[j];
+      for (int j = 0; j < 4; ++j) amp_max[j] = amp[j] > amp_max[j] ? amp[j] : amp_max[j];
     }
-    std::printf("convs by form: direct %d, F(2x2,3x3) %d, F(4,7) %d, F(6,7) %d; worst amplification estimates "
-                "%.1f / %.1f / %.1f\n", nform[0], nform[3], nform[4], nform[6], amp_max[0], amp_max[1], amp_max[2]);
+    std::printf("convs by form: direct %d, F(2x2,3x3) %d, F(4x4,3x3) %d, F(4,7) %d, F(6,7) %d; worst amplification "
+                "estimates %.1f / %.1f / %.1f / %.1f\n", nform[0], nform[3], nform[43], nform[4], nform[6], amp_max[0],
+                amp_max[3], amp_max[1], amp_max[2]);
   }
 
   // input batch: dense NCHW fp32 in [-0.5, 0.5) (rtpose_preprocess range)

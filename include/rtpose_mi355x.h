@@ -201,7 +201,7 @@ int rtpose_conv2d_winograd_scratch_error(const void* scratch, int* error_word, v
  * address `amp_device`: the worst ratio over the output channels of the element-wise rounding-error
  * BOUND of the form to the direct sum's for inputs of uniform magnitude,
  *   max_i sum_f |AT[i][f]| (sum_n |BT[f][n]|) sum_{c,ky} |U[ky][f][c][o]|  /  sum_{c,ky,kx} |w[o][c][ky][kx]|
- * (i.i.d. Gaussian filters: 3.3, 62, 115).  The rtpose_vgg executor uses it to choose the form of a
+ * (i.i.d. Gaussian filters: 3.3, 62, 115; k = 3, m = 4 - F(4x4,3x3): see DESIGN.md §3.0).  The rtpose_vgg executor uses it to choose the form of a
  * layer (rtpose_net_options.winograd7 = RTPOSE_WINO7_AUTO). */
 int rtpose_winograd_amplification(const float* w_oihw, int cout, int cin, int k, int m,
                                   float* amp_device, void* stream);
@@ -424,19 +424,22 @@ int rtpose_net_create_ex(int N, int H, int W, int dtype, rtpose_net** out);
  * products: results differ from the direct sum by rounding, bounds in DESIGN.md §3.0).  The weight
  * arena of fp32 plans holds every packing a plan may choose (direct, F(2x2,3x3), F(4,7), F(6,7)), so
  * plans with different options share one arena and the choice costs nothing at run time.
- *   winograd3: RTPOSE_WINO_DEFAULT (= on, unless RTPOSE_WINOGRAD=0|7 in the environment), 0 = direct
- *              3x3 kernels, 1 = F(2x2,3x3)
+ *   winograd3: RTPOSE_WINO_DEFAULT (= F(4x4,3x3); the environment's RTPOSE_WINOGRAD=0|7 -> direct,
+ *              RTPOSE_WINOGRAD3_M=2 -> F(2x2,3x3)), 0 = direct 3x3 kernels, 1 = F(2x2,3x3), 4 = F(4x4,3x3)
+ *              (layers without an F(4x4,3x3) instance: F(2x2,3x3)), RTPOSE_WINO3_AUTO = per layer F(4x4,3x3) if its
+ *              amplification estimate is <= amp_limit, else F(2x2,3x3); decided by rtpose_net_finalize_weights
  *   winograd7: RTPOSE_WINO_DEFAULT (= F(6,7); the environment's RTPOSE_WINOGRAD=0|3 -> direct,
  *              RTPOSE_WINOGRAD7_M=4 -> F(4,7)), 0 = direct, 4 = F(4,7), 6 = F(6,7), RTPOSE_WINO7_AUTO =
  *              per layer the fastest form whose amplification estimate (rtpose_winograd_amplification of
  *              the loaded filters) is <= amp_limit: F(6,7), else F(4,7), else direct; decided by
  *              rtpose_net_finalize_weights
- *   amp_limit: RTPOSE_WINO7_AUTO only; <= 0 = the library default (256: twice what i.i.d. Gaussian
+ *   amp_limit: the AUTO modes only; <= 0 = the library default (256: twice what i.i.d. Gaussian
  *              filters give in F(6,7))
  * Fields are ignored by bf16 / bf16x3 plans.  A form that has no kernel instance at the plan's
  * geometry falls back to the next one (F(6,7) -> F(4,7) -> direct) whatever the options say. */
 #define RTPOSE_WINO_DEFAULT (-1)
 #define RTPOSE_WINO7_AUTO 1
+#define RTPOSE_WINO3_AUTO 3
 typedef struct rtpose_net_options {
   uint32_t struct_bytes; /* sizeof(rtpose_net_options) of the caller */
   int32_t dtype;         /* RTPOSE_DTYPE_*                            */
@@ -462,13 +465,13 @@ int rtpose_net_conv_info(const rtpose_net* net, int idx, char* name,
 /* Pack one conv's OIHW weight + bias (device pointers) into the weight arena */
 int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw,
                          const float* bias, void* stream);
-/* After the last rtpose_net_load_conv: fixes the form of every conv of an RTPOSE_WINO7_AUTO plan from
+/* After the last rtpose_net_load_conv: fixes the form of every conv of an RTPOSE_WINO7_AUTO / RTPOSE_WINO3_AUTO plan from
  * the amplification estimates of the filters just loaded (synchronises `stream` once to read them).
  * Optional for the other modes and called by the first forward if the host did not. */
 int rtpose_net_finalize_weights(rtpose_net* net, void* stream);
-/* Arithmetic of conv idx in this plan: *form = 0 direct, 3 = F(2x2,3x3), 4 = F(4,7), 6 = F(6,7);
- * amp[3] = amplification estimates of the loaded filters in F(2x2,3x3) / F(4,7) / F(6,7) (0 where the
- * form does not apply; synchronises `stream` if they have not been read back yet).  Either may be NULL. */
+/* Arithmetic of conv idx in this plan: *form = 0 direct, 3 = F(2x2,3x3), 43 = F(4x4,3x3), 4 = F(4,7), 6 = F(6,7);
+ * amp[4] = amplification estimates of the loaded filters in F(2x2,3x3) / F(4,7) / F(6,7) / F(4x4,3x3) (0 where
+ * the form does not apply; synchronises `stream` if they have not been read back yet).  Either may be NULL. */
 int rtpose_net_conv_numerics(rtpose_net* net, int idx, int* form, float* amp, void* stream);
 /* Device-side error word of the plan (synchronises `stream`): bit 0 = a split-tile hand-over of a
  * persistent 7x7 launch timed out (see rtpose_conv2d_winograd_ex); 0 = none.  The word is cleared. */

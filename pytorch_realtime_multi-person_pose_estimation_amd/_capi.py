@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("RTPOSE_LIB_PATH") or os.path.join(_HERE, "lib", "libr
 NUM_PART = 18
 NUM_LIMB = 19
 DTYPE_F32, DTYPE_BF16, DTYPE_BF16X3 = 0, 1, 2
-WINO_DEFAULT, WINO7_AUTO = -1, 1
+WINO_DEFAULT, WINO7_AUTO, WINO3_AUTO = -1, 1, 3
 NMS_NO_REFINE, NMS_GAUSSIAN = 1, 2
 
 

@@ -37,6 +37,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "conv_exp.h"
@@ -75,24 +76,36 @@ constexpr int NT = 32;    // wtiles per block
 constexpr int NC = 64;    // output columns per block
 constexpr int CK = 8;     // channels per chunk
 constexpr int NFP = 18;   // frequency pairs
+constexpr int NPW = 9;    // frequency pairs of a wave (the two waves of a SIMD split the 18)
+constexpr int NFW = 18;   // frequencies of a wave
 constexpr int NB = 6;     // B ring entries (one per frequency pair)
 constexpr int PF = 5;     // B prefetch distance in pairs
 constexpr int VBUF = NFP * 4 * NT;  // float4 per V buffer: [pair][kq][wtile]
 constexpr int UBUF = 36 * 2 * NT;   // float4 per U buffer: [fx][y][channel group][wtile]
-static_assert(NFP % NB == 0, "the B ring rotates in step with the chunk");
+static_assert((2 * NPW) % NB == 0, "the B ring rotates in step with two chunks");
 
 // B^T of F(4,3) for the points 0, +-3/4, +-3/2, inf along one axis (rows scaled by N_f; the filter transform divides):
 //   [81/64 0 -45/16 0 1 0], [0 -+27/16 -9/4 +-3/4 1 0], [0 -+27/32 -9/16 +-3/2 1 0], [0 81/64 0 -45/16 0 1]
 // the +-p rows share their even and odd halves: 12 fmas on 4 channels = 24 packed instructions
-__device__ __forceinline__ void bt6(const F4 (&d)[6], F4 (&v)[6]) {
-  v[0] = fma4(1.265625f, d[0], fma4(-2.8125f, d[2], d[4]));
-  const F4 e1 = fma4(-2.25f, d[2], d[4]), o1 = fma4(-2.25f, d[1], d[3]);
-  v[1] = fma4(0.75f, o1, e1);
-  v[2] = fma4(-0.75f, o1, e1);
-  const F4 e2 = fma4(-0.5625f, d[2], d[4]), o2 = fma4(-0.5625f, d[1], d[3]);
-  v[3] = fma4(1.5f, o2, e2);
-  v[4] = fma4(-1.5f, o2, e2);
-  v[5] = fma4(1.265625f, d[1], fma4(-2.8125f, d[3], d[5]));
+// Every row goes to `out(f, value)` as soon as it is formed (the scheduler is fenced between the groups): the six
+// inputs plus a few temporaries are all the registers the transform holds at any time, not inputs + six outputs.
+template <class Out>
+__device__ __forceinline__ void bt6(const F4 (&d)[6], Out out) {
+  out(0, fma4(1.265625f, d[0], fma4(-2.8125f, d[2], d[4])));
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const F4 e1 = fma4(-2.25f, d[2], d[4]), o1 = fma4(-2.25f, d[1], d[3]);
+    out(1, fma4(0.75f, o1, e1));
+    out(2, fma4(-0.75f, o1, e1));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const F4 e2 = fma4(-0.5625f, d[2], d[4]), o2 = fma4(-0.5625f, d[1], d[3]);
+    out(3, fma4(1.5f, o2, e2));
+    out(4, fma4(-1.5f, o2, e2));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  out(5, fma4(1.265625f, d[1], fma4(-2.8125f, d[3], d[5])));
 }
 
 // A^T of F(4,3) along one axis: [1 1 1 1 1 0], [0 3/4 -3/4 3/2 -3/2 0], [0 9/16 9/16 9/4 9/4 0], [0 27/64 -27/64 27/8 -27/8 1]
@@ -111,20 +124,31 @@ __device__ __forceinline__ void at4_hi(const f2 (&m)[6], f2& y2, f2& y3) {
 
 __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
   extern __shared__ __attribute__((aligned(16))) float4 L4[];
-  float4* const V4 = L4;
-  float4* const U4 = L4 + 2 * VBUF;
+  // LDS: [V0][U1][V1][U0] - the two buffers that are dead at a tile boundary (V1, U0) are adjacent: the exchange area
+  auto Vb = [&](int i) -> float4* { return L4 + i * (VBUF + UBUF); };
+  auto Ub = [&](int i) -> float4* { return L4 + (1 - i) * (VBUF + UBUF) + VBUF; };
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wv & 1, wn = wv >> 1;  // row tile (16 wtiles) and 16-column slice of the wave
+  const int wn = wv & 3, fh = wv >> 2;  // 16-column slice and frequency half (pairs 9 fh .. 9 fh + 8) of the wave
   const int r16 = lane & 15, kq = lane >> 4;
 
   // ---- block -> (n tile, group) and its m tiles (as wino_f32) ----------------------------------------------------
   const int bi = blockIdx.x;
   int j0, jstep, c;
   if (A.persist) {
+    // Workgroups go round-robin to the 8 XCDs.  The ncombo blocks that multiply the SAME m tiles (one per column tile /
+    // group) sit on one XCD: they fetch the same patch rows, 32 bytes of a 128-byte line per chunk, and only if the
+    // XCD's 4 MB L2 has to hold 32 / ncombo m tiles' lines instead of 32 do the lines survive until the next chunk
+    // takes its 32 bytes.  (The filters of all column tiles then stream through every L2; they are read in long runs.)
+#if RTPOSE_EXP_W4_XCDMAP
+    const int xcd = bi & 7, idx = bi >> 3;
+    c = idx % A.ncombo;
+    j0 = (idx / A.ncombo) * 8 + xcd;
+#else
     c = bi % A.ncombo;
     j0 = bi / A.ncombo;
+#endif
     jstep = gridDim.x / A.ncombo;
   } else {
     if (A.xcd_remap) {
@@ -145,6 +169,11 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
   // ---- transform roles ----------------------------------------------------------------------------------------------
   const bool s1 = wv < 6, s2 = wv >= 2;
   const int turn = wv >> 2;               // siblings on a SIMD (waves w, w + 4) take their turns one step apart
+  // stage 1 lanes: (wtile, channel group) = (lane / 2, lane % 2) - the two lanes that share a pixel's 32 bytes are
+  // neighbours, so the patch loads touch 32 lines per instruction, not 64; stage 2 lanes: (lane % 32, lane / 32) - a
+  // plane of V per channel-group half.  U[fx][y][cg][wtile ^ 4 cg]: the swizzle keeps both access patterns off each
+  // other's banks (8 consecutive stage-1 lanes write 4 + 4 slots of two planes).
+  const int wl1 = lane >> 1, cg1 = lane & 1;
   const int wl = lane & 31, cg = lane >> 5;
   const int py = wv;                      // stage 1: patch row
   const int fx = max(wv - 2, 0);          // stage 2: frequency along x
@@ -162,41 +191,35 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
       const int ty = r / A.TX, tx = r - ty * A.TX;
       q0 = (size_t)g.in_lead + (size_t)(n * g.in_hs + 4 * ty - 1) * g.in_ws + (4 * tx - 1);
     }
-    const int t = min(mt * NT + wl, A.T - 1);
+    const int t = min(mt * NT + wl1, A.T - 1);
     const int n = t / TT, r = t - n * TT;
     const int ty = r / A.TX, tx = r - ty * A.TX;
     const int yy = min(4 * ty - 1 + py, A.H);  // rows past the image: the zero gap row
     const size_t qq = (size_t)g.in_lead + (size_t)(n * g.in_hs + yy) * g.in_ws + (4 * tx - 1);
     const size_t o0 = q0 * g.in_cstride + g.in_choff;
     r_ = make_rsrc(g.in + o0, g.in_bytes - o0 * 4);
-    v_[0] = (unsigned)(((qq - q0) * g.in_cstride + cg * 4) * 4);
+    v_[0] = (unsigned)(((qq - q0) * g.in_cstride + cg1 * 4) * 4);
 #pragma unroll
     for (int n5 = 3; n5 < 6; ++n5) v_[n5 - 2] = v_[0] + (unsigned)min(n5, A.W + 1 - 4 * tx) * pxb;  // columns past W: the gap column
   };
+  // (a value defined by an empty asm costs nothing and ends the live range of what was there: the waves that skip a
+  //  load or an LDS read under a wave-uniform branch would otherwise keep the 24 registers alive around the whole loop)
+  auto undefine = [&](F4& x) { asm volatile("" : "=v"(x.lo.x), "=v"(x.lo.y), "=v"(x.hi.x), "=v"(x.hi.y)); };
   F4 p[6];
   auto load_piece = [&](const i32x4& r_, const unsigned (&v_)[4], int chunk, int n5) {
     const unsigned cb = (unsigned)chunk * (CK * 4);
-#ifdef RTPOSE_EXP_W4_AUX  // cache policy bits of the patch loads (1 sc0, 2 nt, 16 sc1)
-    const f32x4 t = n5 < 3 ? llvm_raw_buffer_load_v4f32(r_, (int)v_[0], (int)(cb + n5 * pxb), RTPOSE_EXP_W4_AUX)
-                           : llvm_raw_buffer_load_v4f32(r_, (int)v_[n5 - 2], (int)cb, RTPOSE_EXP_W4_AUX);
-    p[n5] = F4{f2{t.x, t.y}, f2{t.z, t.w}};
-#else
     p[n5] = n5 < 3 ? bload(r_, v_[0], cb + n5 * pxb) : bload(r_, v_[n5 - 2], cb);
-#endif
   };
-  const int ust = (py * 2 + cg) * NT + wl;          // U[fx][y = py][cg][wtile], + fx * 6 * 2 * NT
-  const int uld = ((fx * 6) * 2 + cg) * NT + wl;    // U[fx][y][cg][wtile], + y * 2 * NT
+  const int ust = (py * 2 + cg1) * NT + (wl1 ^ (4 * cg1));     // U[fx][y = py][cg][wtile ^ 4 cg], + fx * 6 * 2 * NT
+  const int uld = ((fx * 6) * 2 + cg) * NT + (wl ^ (4 * cg));  // U[fx][y][cg][wtile ^ 4 cg], + y * 2 * NT
   const int vst = ((fx * 3) * 4 + 2 * cg) * NT + wl;  // V[pair = fx * 3 + fy / 2][kq = 2 cg + h][wtile]
   auto stage1 = [&](int ubuf) {
-    F4 u[6];
-    bt6(p, u);
-    float4* dst = U4 + ubuf * UBUF + ust;
-#pragma unroll
-    for (int f = 0; f < 6; ++f) dst[f * 6 * 2 * NT] = to_float4(u[f]);
+    float4* dst = Ub(ubuf) + ust;
+    bt6(p, [&](int f, F4 u) { dst[f * 6 * 2 * NT] = to_float4(u); });
   };
   F4 q[6];
   auto stage2_read = [&](int ubuf) {
-    const float4* src = U4 + ubuf * UBUF + uld;
+    const float4* src = Ub(ubuf) + uld;
 #pragma unroll
     for (int y = 0; y < 6; ++y) {
       const float4 t = src[y * 2 * NT];
@@ -204,30 +227,35 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
     }
   };
   auto stage2 = [&](int vbuf) {
-    F4 v[6];
-    bt6(q, v);
-    float4* dst = V4 + vbuf * VBUF + vst;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {  // frequencies fx * 6 + 2 i, + 1: channels (0, 1) -> plane 2 cg, (2, 3) -> plane 2 cg + 1
-      dst[i * 4 * NT] = make_float4(v[2 * i].lo.x, v[2 * i].lo.y, v[2 * i + 1].lo.x, v[2 * i + 1].lo.y);
-      dst[i * 4 * NT + NT] = make_float4(v[2 * i].hi.x, v[2 * i].hi.y, v[2 * i + 1].hi.x, v[2 * i + 1].hi.y);
-    }
+    float4* dst = Vb(vbuf) + vst;
+    // frequencies fx * 6 + 2 i, + 1 share a 16-byte slot: channels (0, 1) -> plane 2 cg, (2, 3) -> plane 2 cg + 1
+    F4 ev;
+    bt6(q, [&](int f, F4 v) {
+      if (f & 1) {
+        dst[(f >> 1) * 4 * NT] = make_float4(ev.lo.x, ev.lo.y, v.lo.x, v.lo.y);
+        dst[(f >> 1) * 4 * NT + NT] = make_float4(ev.hi.x, ev.hi.y, v.hi.x, v.hi.y);
+      } else {
+        ev = v;
+      }
+    });
   };
 
   // ---- MFMA roles ---------------------------------------------------------------------------------------------------
+  // acc[l][0]: frequency 18 fh + l of the row tile this wave FINISHES (row tile fh), acc[l][1]: of the other row tile,
+  // handed to the sibling (wave wv ^ 4) before the output transform
   const int ncol = nt * NC + wn * 16 + r16;
-  floatx4 acc[36];
+  floatx4 acc[NFW][2];
   const float bias0 = g.bias[ncol];
   const unsigned boff = (unsigned)((kq * g.cout_pad + ncol) * 16);
   const unsigned fstep = (unsigned)(4 * g.cout_pad * 16);  // bytes per (chunk, frequency pair)
-  unsigned wso = 0;
+  const unsigned wbase = (unsigned)fh * (NPW * fstep);
+  unsigned wso = wbase;
   float4 bs[NB];
-  const int nchunks = A.cin / CK;  // >= 3 (host)
+  const int nchunks = A.cin / CK;  // even, >= 4 (host)
+  const int aoff = fh * NPW * 4 * NT + kq * NT + r16;  // A: pair 9 fh + i, plane kq, wtile (row tile) * 16 + r16
 
   // ---- prologue: V[0] <- position 0, U[1] <- position 1, patch rows of position 2 in flight ---------------------------
   set_loader(j0, rin, pv);
-  // (the loads and the U reads are issued by all 8 waves - the waves 6, 7 / 0, 1 discard theirs: a load under a
-  //  wave-uniform branch keeps its 24 destination registers alive around the whole loop for the register allocator)
 #pragma unroll
   for (int i = 0; i < 6; ++i) load_piece(rin, pv, 0, i);
   if (s1) stage1(0);
@@ -246,71 +274,139 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
   for (int i = 0; i < 6; ++i) load_piece(rin, pv, 2, i);
   __syncthreads();
 
-  int par = 0;
 #define RTPOSE_PIN()             \
   asm volatile("" ::: "memory"); \
   __builtin_amdgcn_sched_barrier(0)
   for (int mt = j0; mt < A.mtiles; mt += jstep) {
 #pragma unroll
-    for (int f = 0; f < 36; ++f)
+    for (int f = 0; f < NFW; ++f)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) acc[f][v] = 0.f;
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[f][rt][v] = 0.f;
 
-    float4 a[2];
+    float4 a0, a1;
 #pragma unroll 1
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-      const float4* va = V4 + par * VBUF + kq * NT + wm * 16 + r16;
-      const int nbuf = par ^ 1;
-      // position + 3: the chunk whose patch rows are requested now (past the block's last tile: that tile again)
-      if (lc == nchunks) {
-        lc = 0;
-        lt += jstep;
-        if (lt < A.mtiles) set_loader(lt, rin, pv);
-      }
-      const int c3 = lc++;
-      const bool last = chunk == nchunks - 1;
-      a[0] = va[0];
+    for (int c2 = 0; c2 < nchunks; c2 += 2) {
 #pragma unroll
-      for (int fp = 0; fp < NFP; ++fp) {
-        const float4 av = a[fp & 1], bv = bs[fp % NB];
-        acc[2 * fp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[2 * fp], 0, 0, 0);
-        acc[2 * fp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[2 * fp + 1], 0, 0, 0);
-        acc[2 * fp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[2 * fp], 0, 0, 0);
-        acc[2 * fp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[2 * fp + 1], 0, 0, 0);
-        RTPOSE_PIN();
-        if (fp < NFP - 1) a[(fp + 1) & 1] = RTPOSE_EXP_A(va[(fp + 1) * 4 * NT], a[fp & 1]);
-        // B PF pairs ahead; PF before the end of a tile's last chunk the ring wraps to the next tile
-        bs[(fp + PF) % NB] = RTPOSE_EXP_B(bload_f4(rw, boff, wso), bs[fp % NB]);
-        wso = (fp == NFP - 1 - PF && last) ? 0u : wso + fstep;
-        if (RTPOSE_EXP_STAGE) {
-#ifdef RTPOSE_EXP_W4_NOXF  // timing only: the patch loads without the transform
-          if (fp == 0) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) asm volatile("" ::"v"(p[i].lo.x), "v"(p[i].lo.y), "v"(p[i].hi.x), "v"(p[i].hi.y));
-          } else if (fp >= 6 && fp < 12) {
-            load_piece(rin, pv, c3, fp - 6);
-          }
-#else
-          if (fp < 2) {
-            if (s1 && fp == turn) stage1(par);            // patch rows of position + 2 -> U[par]
-          } else if (fp < 4) {
-            if (fp == 2 + turn) stage2_read(nbuf);        // U[par ^ 1] = position + 1
-          } else if (fp < 6) {
-            if (s2 && fp == 4 + turn) stage2(nbuf);       // -> V[par ^ 1]
-          }
-#ifndef RTPOSE_EXP_W4_NOLOAD  // (timing only: the transform on stale registers)
-          if (fp >= RTPOSE_EXP_W4_L0 && fp < RTPOSE_EXP_W4_L0 + 6) load_piece(rin, pv, c3, fp - RTPOSE_EXP_W4_L0);  // patch rows of position + 3
-#endif
-#endif
+      for (int h = 0; h < 2; ++h) {  // chunk c2 + h multiplies from V[h]
+        const float4* va = Vb(h) + aoff;
+        // position + 3: the chunk whose patch rows are requested now (past the block's last tile: that tile again)
+        if (lc == nchunks) {
+          lc = 0;
+          lt += jstep;
+          if (lt < A.mtiles) set_loader(lt, rin, pv);
         }
-        RTPOSE_PIN();
+        const int c3 = lc++;
+        a0 = va[fh * 16];
+        a1 = va[(fh ^ 1) * 16];
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+          const float4 bv = bs[(h * NPW + i) % NB];
+          acc[2 * i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bv.x, acc[2 * i][0], 0, 0, 0);
+          acc[2 * i + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bv.z, acc[2 * i + 1][0], 0, 0, 0);
+          acc[2 * i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bv.y, acc[2 * i][0], 0, 0, 0);
+          acc[2 * i + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bv.w, acc[2 * i + 1][0], 0, 0, 0);
+          RTPOSE_PIN();
+          if (i < NPW - 1) a0 = RTPOSE_EXP_A(va[(i + 1) * 4 * NT + fh * 16], a0);
+          {
+            // B PF pairs ahead.  After a chunk's ninth pair the sibling's nine are skipped; after the tile's last chunk
+            // the ring wraps to the next tile.
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int L = h * NPW + i + PF;
+            bs[L % NB] = RTPOSE_EXP_B(bload_f4(rw, boff, wso), bs[(h * NPW + i) % NB]);
+            if (L % NPW == NPW - 1) wso = (c2 + L / NPW == nchunks - 1) ? wbase : wso + (NPW + 1) * fstep;
+            else wso += fstep;
+          }
+          RTPOSE_PIN();
+          acc[2 * i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bv.x, acc[2 * i][1], 0, 0, 0);
+          acc[2 * i + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bv.z, acc[2 * i + 1][1], 0, 0, 0);
+          acc[2 * i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bv.y, acc[2 * i][1], 0, 0, 0);
+          acc[2 * i + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bv.w, acc[2 * i + 1][1], 0, 0, 0);
+          RTPOSE_PIN();
+          if (i < NPW - 1) a1 = RTPOSE_EXP_A(va[(i + 1) * 4 * NT + (fh ^ 1) * 16], a1);
+          if (RTPOSE_EXP_STAGE) {
+            if (i < 2) {
+              if (s1 && i == turn) stage1(h);              // patch rows of position + 2 -> U[h]
+            } else if (i < 4) {
+              if (i == 2 + turn) {                         // U[h ^ 1] = position + 1
+                if (s2) stage2_read(h ^ 1);
+                else
+#pragma unroll
+                  for (int y = 0; y < 6; ++y) undefine(q[y]);
+              }
+            } else if (i < 6) {
+              if (s2 && i == 4 + turn) stage2(h ^ 1);      // -> V[h ^ 1]
+            }
+#ifndef RTPOSE_EXP_W4_NOLOAD  // (timing only: the transform on stale registers)
+            if (i >= RTPOSE_EXP_W4_L0 && i < RTPOSE_EXP_W4_L0 + 3) {
+              if (s1) {
+                load_piece(rin, pv, c3, 2 * (i - RTPOSE_EXP_W4_L0));  // patch rows of position + 3
+                load_piece(rin, pv, c3, 2 * (i - RTPOSE_EXP_W4_L0) + 1);
+              } else {
+                undefine(p[2 * (i - RTPOSE_EXP_W4_L0)]);
+                undefine(p[2 * (i - RTPOSE_EXP_W4_L0) + 1]);
+              }
+            }
+#endif
+          }
+          RTPOSE_PIN();
+        }
+        __syncthreads();
       }
-      __syncthreads();
-      par ^= 1;
     }
-    // ---- epilogue: output transform A^T M A, + bias (+ReLU) (+2x2 max-pool), masked stores ------------------------
-    // register v of acc[f] = wtile wm * 16 + 4 kq + v of the tile, column ncol: 16 lanes = 64 contiguous bytes
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    // 1. every wave runs the first pass of the output transform (along y) on its own frequencies fx = 3 fh .. 3 fh + 2,
+    //    for both row tiles;  2. the siblings (waves w, w ^ 4: same columns, the two frequency halves) swap the row
+    //    sums of the row tile they do not finish, through the two LDS buffers that are dead at a tile boundary (V1, U0),
+    //    in two rounds (one per wtile pair);  3. second pass (along x), + bias (+ReLU) (+2x2 max-pool), masked stores.
+    // Register v of acc[l][0] = wtile fh * 16 + 4 kq + v of the tile, column ncol: 16 lanes = 64 contiguous bytes.
+    f2 sk[3][2][4], sr[3][2][4];  // [fx - 3 fh][wtile pair][output row]: kept row tile, received from the sibling
     {
+      float4* const E = L4 + VBUF + UBUF;
+#pragma unroll
+      for (int vp = 0; vp < 2; ++vp) {
+        f2 sg[3][4];
+#pragma unroll
+        for (int xl = 0; xl < 3; ++xl) {
+          f2 m[6];
+#pragma unroll
+          for (int y = 0; y < 6; ++y) m[y] = f2{acc[xl * 6 + y][1][2 * vp], acc[xl * 6 + y][1][2 * vp + 1]};
+          at4_lo(m, sg[xl][0], sg[xl][1]);
+          at4_hi(m, sg[xl][2], sg[xl][3]);
+        }
+#pragma unroll
+        for (int xl = 0; xl < 3; ++xl)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+            E[(wv * 6 + xl * 2 + hh) * 64 + lane] =
+                make_float4(sg[xl][2 * hh].x, sg[xl][2 * hh].y, sg[xl][2 * hh + 1].x, sg[xl][2 * hh + 1].y);
+#pragma unroll
+        for (int xl = 0; xl < 3; ++xl) {
+          f2 m[6];
+#pragma unroll
+          for (int y = 0; y < 6; ++y) m[y] = f2{acc[xl * 6 + y][0][2 * vp], acc[xl * 6 + y][0][2 * vp + 1]};
+          at4_lo(m, sk[xl][vp][0], sk[xl][vp][1]);
+          at4_hi(m, sk[xl][vp][2], sk[xl][vp][3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int xl = 0; xl < 3; ++xl)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const float4 t = E[((wv ^ 4) * 6 + xl * 2 + hh) * 64 + lane];
+            sr[xl][vp][2 * hh] = f2{t.x, t.y};
+            sr[xl][vp][2 * hh + 1] = f2{t.z, t.w};
+          }
+        __syncthreads();
+      }
+    }
+    auto finish = [&](auto fhc) {
+      constexpr int FH = decltype(fhc)::value;
+      // row sums of fx = 0..5: the wave's own 3 FH .. 3 FH + 2, the sibling's from sr
+      auto S = [&](int x, int vp, int i) -> f2 { return (x / 3 == FH) ? sk[x % 3][vp][i] : sr[x % 3][vp][i]; };
       const bool col_ok = ncol < g.cout;
       const int sc = A.pool ? 2 : 4;
       auto wt_q = [&](int n, int ty, int tx) -> int { return (n * g.out_hs + sc * ty) * g.out_ws + sc * tx; };
@@ -325,7 +421,7 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
       const i32x4 rout = make_rsrc(g.out + oo0, g.out_bytes - oo0 * 4);
       const unsigned cs4 = (unsigned)g.out_cstride * 4, row4 = (unsigned)g.out_ws * cs4;
       const unsigned col4 = (unsigned)ncol * 4;
-      int tcur = mt * NT + wm * 16 + 4 * kq;
+      int tcur = mt * NT + FH * 16 + 4 * kq;
       int sn = tcur / TT, sy, sx;
       {
         const int r = tcur - sn * TT;
@@ -350,27 +446,15 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
           sy = wy ? 0 : (wx ? sy + 1 : sy);
           sn += wy ? 1 : 0;
         }
-        // two output rows at a time (24 registers of row sums instead of 48: the next tile's prefetched patch rows
-        // and filter ring stay in registers through the epilogue)
 #pragma unroll
         for (int ih = 0; ih < 2; ++ih) {
-          // pass 1: along y (fy -> output rows 2 ih, 2 ih + 1) for every fx
-          f2 s[6][2];
-#pragma unroll
-          for (int x = 0; x < 6; ++x) {
-            f2 m[6];
-#pragma unroll
-            for (int y = 0; y < 6; ++y) m[y] = f2{acc[x * 6 + y][2 * vp], acc[x * 6 + y][2 * vp + 1]};
-            if (ih == 0) at4_lo(m, s[x][0], s[x][1]);
-            else at4_hi(m, s[x][0], s[x][1]);
-          }
-          // pass 2: along x (fx -> output column j)
+          // second pass: along x (fx -> output column j) for the output rows 2 ih, 2 ih + 1
           f2 yy[2][4];
 #pragma unroll
           for (int il = 0; il < 2; ++il) {
             f2 m[6];
 #pragma unroll
-            for (int x = 0; x < 6; ++x) m[x] = s[x][il];
+            for (int x = 0; x < 6; ++x) m[x] = S(x, vp, 2 * ih + il);
             at4_lo(m, yy[il][0], yy[il][1]);
             at4_hi(m, yy[il][2], yy[il][3]);
           }
@@ -404,7 +488,9 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
           }
         }
       }
-    }
+    };
+    if (fh == 0) finish(std::integral_constant<int, 0>{});
+    else finish(std::integral_constant<int, 1>{});
   }  // m tiles of this block
 #undef RTPOSE_PIN
 }
@@ -499,7 +585,7 @@ __global__ void wino4_amp_kernel(const float* __restrict__ w, int cout, int cin,
 }  // namespace wino4
 
 // 1 when the 3x3 conv has an F(4x4,3x3) instance: 8-channel chunks, at least 3 of them (the transform pipeline is 3 deep)
-int conv2d_wino4_ok(int cin, int cout) { return cout > 0 && cin % 8 == 0 && cin >= 32; }
+int conv2d_wino4_ok(int cin, int cout) { return cout > 0 && cin % 16 == 0 && cin >= 32; }
 
 size_t packed_weight_floats_wino4(int cout, int cin) { return (size_t)36 * cin * cout_pad(cout); }
 
@@ -508,7 +594,7 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
   if (!d || ngroups < 1 || ngroups > 2) return fail(RTPOSE_E_INVAL, "conv2d_winograd (4x4): ngroups must be 1 or 2");
   const rtpose_conv_desc& d0 = d[0];
   if (d0.k != 3 || !conv2d_wino4_ok(d0.cin, d0.cout))
-    return fail(RTPOSE_E_INVAL, "conv2d_winograd (4x4): k must be 3 and cin a multiple of 8, >= 32");
+    return fail(RTPOSE_E_INVAL, "conv2d_winograd (4x4): k must be 3 and cin a multiple of 16, >= 32");
   if (N <= 0 || H <= 0 || W <= 0) return fail(RTPOSE_E_INVAL, "conv2d_winograd: empty tensor");
   if (d0.pool && ((H | W) & 1)) return fail(RTPOSE_E_INVAL, "conv2d_winograd: fused pool needs even H and W");
   Args a;
@@ -565,7 +651,7 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
   long ids = a.xcd_remap ? (long)8 * a.ncombo * ceil_div(a.mtiles, 8) : (long)a.mtiles * a.ncombo;
   if (ids > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv2d_winograd: grid too large");
   const int n_cu = device_cu_count();
-  if ((long)a.mtiles * a.ncombo > n_cu && n_cu % a.ncombo == 0) {
+  if ((long)a.mtiles * a.ncombo > n_cu && n_cu % (8 * a.ncombo) == 0) {
     a.persist = 1;
     ids = n_cu;
   }
@@ -584,7 +670,7 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
 int pack_weights_wino4_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map,
                               int cin_packed, float* wp, float* bp, hipStream_t s) {
   if (!conv2d_wino4_ok(cin_packed, cout) || (cin_packed < cin_src && !cin_map))
-    return fail(RTPOSE_E_INVAL, "pack_winograd (4x4): cin_packed must be a multiple of 8, >= 32 and >= cin_src");
+    return fail(RTPOSE_E_INVAL, "pack_winograd (4x4): cin_packed must be a multiple of 16, >= 32 and >= cin_src");
   const int coutp = cout_pad(cout);
   const size_t total = (size_t)36 * cin_packed * coutp;
   const int threads = 256;

@@ -36,6 +36,8 @@ size_t packed_weight_floats_wino7(int cout, int cin, int fm);
 int pack_weights_wino7_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map,
                               int cin_packed, int fm, float* wp, float* bp, hipStream_t s);
 int wino_amplification_launch(const float* w, int cout, int cin, int k, int fm, float* amp, hipStream_t s);
+int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
+double conv2d_wino4_issued_flops(int cin, int cout, int N, int H, int W);
 int wino7_default_fm();
 // Mconv6 + Mconv7 of a stage as one launch (conv_tail.hip)
 int conv_tail_launch(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int ngroups, int N, int H, int W,
@@ -72,14 +74,14 @@ struct ConvW {
   bool cat_perm = false;   // input channels follow the cat([L1,L2,out1]) order
   // fp32 plans.  The arena holds EVERY packing a plan may run the conv in (it is shared by all plans of a module,
   // whatever their geometry and options): the direct one at w_off, and - where the form has a kernel for these
-  // channel counts - F(2x2,3x3) at w_off_w3, F(4,7) / F(6,7) at w_off_w4 / w_off_w6.
+  // channel counts - F(2x2,3x3) at w_off_w3, F(4x4,3x3) at w_off_w43, F(4,7) / F(6,7) at w_off_w4 / w_off_w6.
   bool first = false;      // conv1_1 (3 -> 64, 3x3): its own kernel, packing at w_off_first (csrc/conv_first.hip)
   size_t w_off_first = 0;
-  bool has_w3 = false, has_w7 = false;
-  size_t w_off_w3 = 0, w_off_w4 = 0, w_off_w6 = 0;
-  size_t amp_off = 0;      // 3 floats in the arena: amplification estimates in F(2x2,3x3) / F(4,7) / F(6,7) (0 = n/a)
-  float amp[3] = {0.f, 0.f, 0.f};  // host copy (rtpose_net_finalize_weights)
-  int form = 0;            // what THIS plan runs the conv in: 0 direct, 3 = F(2x2,3x3), 4 = F(4,7), 6 = F(6,7)
+  bool has_w3 = false, has_w43 = false, has_w7 = false;
+  size_t w_off_w3 = 0, w_off_w43 = 0, w_off_w4 = 0, w_off_w6 = 0;
+  size_t amp_off = 0;      // 4 floats in the arena: amplification estimates in F(2x2,3x3) / F(4,7) / F(6,7) / F(4x4,3x3) (0 = n/a)
+  float amp[4] = {0.f, 0.f, 0.f, 0.f};  // host copy (rtpose_net_finalize_weights)
+  int form = 0;            // what THIS plan runs the conv in: 0 direct, 3 = F(2x2,3x3), 43 = F(4x4,3x3), 4 = F(4,7), 6 = F(6,7)
   int H = 0, W = 0;        // map size the conv runs at in this plan
   size_t w_off = 0, b_off = 0;  // float offsets in the weight arena
 };
@@ -110,7 +112,7 @@ struct rtpose_net {
   int N = 0, H = 0, W = 0;       // input
   int bf16 = 0;                  // 1: bf16 activations/weights, fp32 accumulate (BASELINE config 3)
   int split = 0;                 // bf16 plans only: 1 = "bf16x3" split operands (hi + lo bf16 per value)
-  int w3 = 1;                    // fp32 plans: F(2x2,3x3) for the eligible 3x3 convs (rtpose_net_options.winograd3)
+  int w3 = 4;                    // fp32 plans, 3x3 convs: 0 direct, 1 = F(2x2,3x3), 4 = F(4x4,3x3), RTPOSE_WINO3_AUTO = per layer by amp_limit
   int w7 = 6;                    // fp32 plans: 0 direct, 4 / 6 = F(4,7) / F(6,7), RTPOSE_WINO7_AUTO = per layer by amp_limit
   float amp_limit = 256.f;
   bool forms_final = false;      // forms chosen (AUTO: after the amplification estimates were read back)
@@ -196,7 +198,9 @@ int add_conv_w(rtpose_net* n, const std::string& name, int cout, int cin, int k,
     c.w_off = take(rtpose_packed_weight_floats(cout, c.cin_packed, k));
     c.has_w3 = k == 3 && c.cin_packed >= 32 && conv2d_winograd_fits(3, c.cin_packed, cout, 0, 1, 8, 8, 9, 0);
     c.has_w7 = k == 7 && c.cin_packed % 8 == 0 && cout_pad(cout) % 128 == 0;
+    c.has_w43 = c.has_w3 && conv2d_winograd_fits(3, c.cin_packed, cout, 0, 1, 8, 8, 9, 4);
     if (c.has_w3) c.w_off_w3 = take(rtpose_packed_weight_floats_winograd(cout, c.cin_packed, 3));
+    if (c.has_w43) c.w_off_w43 = take(rtpose_packed_weight_floats_winograd3(cout, c.cin_packed, 4));
     if (c.has_w7) {
       c.w_off_w4 = take(packed_weight_floats_wino7(cout, c.cin_packed, 4));
       c.w_off_w6 = take(packed_weight_floats_wino7(cout, c.cin_packed, 6));
@@ -216,7 +220,11 @@ int add_conv_w(rtpose_net* n, const std::string& name, int cout, int cin, int k,
 // F(m,7) on maps so wide that the transformed rows of a block do not fit the LDS - falls back to the next one.
 int pick_form(const rtpose_net* n, const ConvW& c) {
   if (n->bf16) return 0;
-  if (c.k == 3) return (c.has_w3 && n->w3) ? 3 : 0;
+  if (c.k == 3) {
+    if (!c.has_w3 || !n->w3) return 0;
+    if (c.has_w43 && (n->w3 == 4 || (n->w3 == RTPOSE_WINO3_AUTO && c.amp[3] <= n->amp_limit))) return 43;
+    return 3;
+  }
   if (c.k != 7 || !c.has_w7 || !n->w7) return 0;
   auto fits = [&](int fm) {
     return conv2d_winograd_fits(7, c.cin_packed, c.cout, 0, n->N, c.H, c.W, c.H + 3, fm) != 0;
@@ -230,13 +238,15 @@ int pick_form(const rtpose_net* n, const ConvW& c) {
   return fits(4) ? 4 : 0;
 }
 
+bool forms_need_amps(const rtpose_net* n) { return n->w7 == RTPOSE_WINO7_AUTO || n->w3 == RTPOSE_WINO3_AUTO; }
+
 void pick_forms(rtpose_net* n) {
   for (ConvW& c : n->convs) c.form = pick_form(n, c);
   // the two branches of a grouped launch run one kernel: the more conservative form of the two
   for (Op& o : n->ops) {
     if (o.kind != OP_CONV || o.ngroups < 2) continue;
     ConvW &a = n->convs[o.conv_idx[0]], &b = n->convs[o.conv_idx[1]];
-    const int f = a.form < b.form ? a.form : b.form;  // 0 < 3 < 4 < 6: direct is the lowest
+    const int f = a.form < b.form ? a.form : b.form;  // 3x3: 0 < 3 < 43, 7x7: 0 < 4 < 6: direct is the lowest
     a.form = b.form = f;
   }
 }
@@ -507,8 +517,9 @@ int rtpose_net_create_opts(int N, int H, int W, const rtpose_net_options* opt, r
   if (dtype != RTPOSE_DTYPE_F32 && ((H | W) & 7))
     return fail(RTPOSE_E_INVAL, "net_create: the bf16 plan needs H and W to be multiples of 8 "
                                 "(crop_with_factor pads to that, im_transform.py:128-132)");
-  if (opt->winograd3 < RTPOSE_WINO_DEFAULT || opt->winograd3 > 1)
-    return fail(RTPOSE_E_INVAL, "net_create: winograd3 must be RTPOSE_WINO_DEFAULT, 0 or 1");
+  if (opt->winograd3 != RTPOSE_WINO_DEFAULT && opt->winograd3 != 0 && opt->winograd3 != 1 && opt->winograd3 != 4 &&
+      opt->winograd3 != RTPOSE_WINO3_AUTO)
+    return fail(RTPOSE_E_INVAL, "net_create: winograd3 must be RTPOSE_WINO_DEFAULT, 0, 1, 4 or RTPOSE_WINO3_AUTO");
   if (opt->winograd7 != RTPOSE_WINO_DEFAULT && opt->winograd7 != 0 && opt->winograd7 != 4 && opt->winograd7 != 6 &&
       opt->winograd7 != RTPOSE_WINO7_AUTO)
     return fail(RTPOSE_E_INVAL, "net_create: winograd7 must be RTPOSE_WINO_DEFAULT, 0, 4, 6 or RTPOSE_WINO7_AUTO");
@@ -524,12 +535,16 @@ int rtpose_net_create_opts(int N, int H, int W, const rtpose_net_options* opt, r
     // 0: direct kernels everywhere, 3 / 7: only that kernel size in Winograd form; RTPOSE_WINOGRAD7_M=4: F(4,7))
     const char* e = getenv("RTPOSE_WINOGRAD");
     const int env = !e ? 1 : e[0] == '0' ? 0 : e[0] == '3' ? 3 : e[0] == '7' ? 7 : 1;
-    n->w3 = opt->winograd3 != RTPOSE_WINO_DEFAULT ? opt->winograd3 : (env == 1 || env == 3);
+    // (RTPOSE_WINOGRAD3_M=2: F(2x2,3x3) instead of F(4x4,3x3))
+    const char* e3 = getenv("RTPOSE_WINOGRAD3_M");
+    n->w3 = opt->winograd3 != RTPOSE_WINO_DEFAULT ? opt->winograd3
+            : (env == 1 || env == 3)              ? ((e3 && e3[0] == '2') ? 1 : 4)
+                                                  : 0;
     n->w7 = opt->winograd7 != RTPOSE_WINO_DEFAULT ? opt->winograd7 : ((env == 1 || env == 7) ? wino7_default_fm() : 0);
     n->amp_limit = opt->amp_limit > 0.f ? opt->amp_limit : 256.f;
   }
   build_plan(n);
-  if (n->w7 != RTPOSE_WINO7_AUTO) {  // AUTO waits for the filters (rtpose_net_finalize_weights)
+  if (!forms_need_amps(n)) {  // AUTO waits for the filters (rtpose_net_finalize_weights)
     pick_forms(n);
     n->forms_final = true;
   }
@@ -582,7 +597,7 @@ int rtpose_net_bind(rtpose_net* net, void* workspace, size_t workspace_bytes, vo
   }
   net->forwards = 0;
   net->amps_read = false;
-  if (net->w7 == RTPOSE_WINO7_AUTO) net->forms_final = false;
+  if (forms_need_amps(net)) net->forms_final = false;
   net->ws = static_cast<float*>(workspace);
   net->wt = static_cast<float*>(weights);
   hipStream_t s = as_stream(stream);
@@ -626,7 +641,7 @@ int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw, const fl
   // every packing the arena holds for this conv (the plans that share the arena choose among them), and the
   // amplification estimate of each Winograd form
   net->amps_read = false;
-  if (net->w7 == RTPOSE_WINO7_AUTO) net->forms_final = false;
+  if (forms_need_amps(net)) net->forms_final = false;
   int rc = pack_weights_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed, net->wt + c.w_off,
                                net->wt + c.b_off, s);
   if (rc) return rc;
@@ -640,6 +655,12 @@ int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw, const fl
     rc = rtpose_pack_conv_weights_winograd(w_oihw, bias, c.cout, c.cin_src, 3, map, c.cin_packed,
                                            net->wt + c.w_off_w3, net->wt + c.b_off, stream);
     if (!rc) rc = wino_amplification_launch(w_oihw, c.cout, c.cin_src, 3, 0, amp + 0, s);
+    if (rc) return rc;
+  }
+  if (c.has_w43) {
+    rc = rtpose_pack_conv_weights_winograd3(w_oihw, bias, c.cout, c.cin_src, 4, map, c.cin_packed,
+                                            net->wt + c.w_off_w43, net->wt + c.b_off, stream);
+    if (!rc) rc = rtpose_winograd_amplification(w_oihw, c.cout, c.cin_src, 3, 4, amp + 3, stream);
     if (rc) return rc;
   }
   if (c.has_w7) {
@@ -660,7 +681,7 @@ static int read_amps(rtpose_net* net, hipStream_t s) {
   // one contiguous read-back of the arena span that holds the estimates would drag the packed filters along;
   // 92 small copies once per weight load are cheaper
   for (ConvW& c : net->convs)
-    RTPOSE_HIP_CHECK(hipMemcpyAsync(c.amp, net->wt + c.amp_off, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    RTPOSE_HIP_CHECK(hipMemcpyAsync(c.amp, net->wt + c.amp_off, 4 * sizeof(float), hipMemcpyDeviceToHost, s));
   RTPOSE_HIP_CHECK(hipStreamSynchronize(s));
   net->amps_read = true;
   return 0;
@@ -689,7 +710,7 @@ int rtpose_net_conv_numerics(rtpose_net* net, int idx, int* form, float* amp, vo
   const ConvW& c = net->convs[idx];
   if (form) *form = c.form;
   if (amp)
-    for (int i = 0; i < 3; ++i) amp[i] = c.amp[i];
+    for (int i = 0; i < 4; ++i) amp[i] = c.amp[i];
   return 0;
 }
 
@@ -746,6 +767,9 @@ int rtpose_net_launch_executed_flops(const rtpose_net* net, int i, double* flops
       if (c.form == 3) {         // 16 frequencies per 2 x 2 wtile
         fl += conv2d_wino_issued_flops(c.cin_packed, c.cout, net->N, o.H, o.W);
         wino = 3;
+      } else if (c.form == 43) {  // 36 frequencies per 4 x 4 wtile
+        fl += conv2d_wino4_issued_flops(c.cin_packed, c.cout, net->N, o.H, o.W);
+        wino = 43;
       } else if (c.form) {       // FM + 6 frequencies x 7 rows per group of FM pixels, 32-position strips per image
         fl += conv2d_wino7_issued_flops(c.cin_packed, c.cout, net->N, o.H, o.W, o.H + 3, c.form);
         wino = c.form;
@@ -902,8 +926,12 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
           const Buf& bo = net->bufs[o.out_buf[g]];
           d[g].in = net->ws + bi.off_floats;
           d[g].out = net->ws + bo.off_floats;
-          d[g].w_packed = net->wt + (c.form == 3 ? c.w_off_w3 : c.form == 4 ? c.w_off_w4 : c.form == 6 ? c.w_off_w6 : c.w_off);
-          d[g].wino_m = c.form == 4 || c.form == 6 ? c.form : 0;
+          d[g].w_packed = net->wt + (c.form == 3    ? c.w_off_w3
+                                     : c.form == 43 ? c.w_off_w43
+                                     : c.form == 4  ? c.w_off_w4
+                                     : c.form == 6  ? c.w_off_w6
+                                                    : c.w_off);
+          d[g].wino_m = c.form == 4 || c.form == 6 ? c.form : c.form == 43 ? 4 : 0;
           d[g].bias_packed = net->wt + c.b_off;
           d[g].lin = slice(bi, o.in_choff[g]);
           d[g].lout = slice(bo, o.out_choff[g]);
@@ -931,7 +959,8 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
         }
         const int form = net->convs[o.conv_idx[0]].form;  // grouped convs run one form (pick_forms)
         rc = net->bf16   ? conv2d_bf16_launch(d, o.ngroups, N, o.H, o.W, o.out_f32, net->split, s)
-             : form == 3 ? conv2d_wino_launch(d, o.ngroups, N, o.H, o.W, s)
+             : form == 3  ? conv2d_wino_launch(d, o.ngroups, N, o.H, o.W, s)
+             : form == 43 ? conv2d_wino4_launch(d, o.ngroups, N, o.H, o.W, s)
              : form      ? conv2d_wino7_launch(d, o.ngroups, N, o.H, o.W, form, net->ws + net->scratch_off,
                                                net->scratch_bytes, s)
                          : conv2d_launch(d, o.ngroups, N, o.H, o.W, s);

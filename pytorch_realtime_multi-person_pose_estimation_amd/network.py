@@ -105,11 +105,21 @@ class RtposeVGG(NativeStateMixin, nn.Module):
 
     def set_winograd(self, winograd3=None, winograd7=None, amp_limit=None):
         """Arithmetic of the fp32 convs of plans created from now on (``rtpose_net_options``):
-        ``winograd3``: None = library default (on), False / True = direct kernels / F(2x2,3x3);
+        ``winograd3``: None = library default (F(4x4,3x3)), False / 0 = direct kernels, True / 2 = F(2x2,3x3),
+        4 = F(4x4,3x3), 'auto' = per layer F(4x4,3x3) if its amplification estimate is <= ``amp_limit``, else F(2x2,3x3);
         ``winograd7``: None = default (F(6,7)), 0 = direct, 4 / 6 = F(4,7) / F(6,7), 'auto' = per layer the
         fastest form whose amplification estimate for the loaded filters is <= ``amp_limit`` (default 256).
         All forms read one weight arena; results of different forms differ by rounding only."""
-        w3 = _capi.WINO_DEFAULT if winograd3 is None else int(bool(winograd3))
+        if winograd3 is None:
+            w3 = _capi.WINO_DEFAULT
+        elif winograd3 == 'auto':
+            w3 = _capi.WINO3_AUTO
+        elif winograd3 is True or winograd3 == 2:
+            w3 = 1
+        elif winograd3 is False or winograd3 in (0, 4):
+            w3 = int(winograd3)
+        else:
+            raise ValueError("winograd3 must be None, False / 0, True / 2, 4 or 'auto'")
         if winograd7 is None:
             w7 = _capi.WINO_DEFAULT
         elif winograd7 == 'auto':
@@ -122,11 +132,12 @@ class RtposeVGG(NativeStateMixin, nn.Module):
         return self
 
     def conv_numerics(self, plan):
-        """[(state_dict prefix, form, (amp F(2x2,3x3), amp F(4,7), amp F(6,7)))] of a plan: form 0 = direct kernel,
-        3 = F(2x2,3x3), 4 / 6 = F(m,7); amp = rtpose_winograd_amplification of the loaded filters (0 = n/a)."""
+        """[(state_dict prefix, form, (amp F(2x2,3x3), amp F(4,7), amp F(6,7), amp F(4x4,3x3)))] of a plan: form 0 =
+        direct kernel, 3 = F(2x2,3x3), 43 = F(4x4,3x3), 4 / 6 = F(m,7); amp = rtpose_winograd_amplification of the
+        loaded filters (0 = n/a)."""
         out = []
         form = C.c_int()
-        amp = (C.c_float * 3)()
+        amp = (C.c_float * 4)()
         for i, (nm, _) in enumerate(self._convs()):
             check(lib.rtpose_net_conv_numerics(plan.handle, i, C.byref(form), amp, current_stream()))
             out.append((nm, form.value, tuple(amp)))

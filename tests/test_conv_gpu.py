@@ -247,8 +247,8 @@ WINO4_CASES = [
     (3, 96, 80, 64, 64, 1, 1, 1, 1),       # conv1_2 shape: fused pool, one column tile
     (1, 100, 92, 128, 256, 1, 0, 1, 1),    # H, W % 4 == 0
     (2, 45, 47, 32, 64, 0, 0, 1, 0),       # odd sizes (W % 4 == 3, H % 4 == 1), no ReLU, 4 chunks
-    (5, 7, 9, 40, 24, 1, 0, 1, 3),         # tiny maps: a block spans several images; ragged cout; 5 chunks
-    (1, 30, 44, 72, 128, 1, 1, 2, 0),      # pool with H % 4 == 2; gap wider than the padding
+    (5, 7, 9, 48, 24, 1, 0, 1, 3),         # tiny maps: a block spans several images; ragged cout; 6 chunks
+    (1, 30, 44, 80, 128, 1, 1, 2, 0),      # pool with H % 4 == 2; gap wider than the padding
     (40, 46, 46, 64, 128, 1, 0, 1, 1),     # persistent blocks: 180 m tiles x 2 column tiles > 256
 ]
 
