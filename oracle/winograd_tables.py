@@ -43,3 +43,4 @@ def toom_cook(m, r, points):
 POINTS_F4_7 = [0, 1, -1, 2, -2, Fr(1, 2), Fr(-1, 2), Fr(3, 2), Fr(-3, 2)]
 POINTS_F6_7 = POINTS_F4_7 + [Fr(2, 3), Fr(-2, 3)]
 POINTS_F2_3 = [0, 1, -1]
+POINTS_F4_3 = [0, Fr(3, 4), Fr(-3, 4), Fr(3, 2), Fr(-3, 2)]   # F(4x4,3x3), csrc/conv_wino4.hip

@@ -200,3 +200,42 @@ def test_winograd_tables_of_the_kernels_are_the_toom_cook_construction():
         nz = [j for j in range(4) if BT[f][j] != 0][0]
         fac = BTc[f][nz] / BT[f][nz]
         assert [x * fac for x in BT[f]] == BTc[f]
+
+
+def test_f43_constants_of_the_kernel_are_the_toom_cook_construction():
+    """F(4x4,3x3) (csrc/conv_wino4.hip, points 0, +-3/4, +-3/2, inf): the construction is exact, every entry of B^T and
+    A^T is a dyadic fraction (exactly representable in fp32), and the constants written out in the kernel's bt6 /
+    at4_lo / at4_hi / g43 are those entries."""
+    import re
+    from fractions import Fraction as Fr
+    from oracle import winograd_tables as wt
+    AT, G, BT = wt.toom_cook(4, 3, wt.POINTS_F4_3)
+    d = [Fr(3 * i * i - 7 * i + 1, 5) for i in range(6)]
+    g = [Fr(3, 4), Fr(-5, 3), Fr(2)]
+    for i in range(4):
+        assert sum(AT[i][f] * sum(G[f][k] * g[k] for k in range(3)) * sum(BT[f][j] * d[j] for j in range(6))
+                   for f in range(6)) == sum(d[i + k] * g[k] for k in range(3))
+    for M in (AT, BT):
+        for row in M:
+            for v in row:
+                assert v.denominator & (v.denominator - 1) == 0 and float(v) == float(np.float32(float(v)))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "pytorch_realtime_multi-person_pose_estimation_amd", "csrc", "conv_wino4.hip")).read()
+    bt6 = src[src.index("__device__ __forceinline__ void bt6("):src.index("// A^T of F(4,3) along one axis")]
+    consts = sorted({abs(float(x)) for x in re.findall(r"(-?\d+\.\d+)f", bt6)})
+    # rows 0 / 5: 81/64, -45/16, 1;  +-3/4: E = d4 - 9/4 d2, O = 3/4 (d3 - 9/4 d1);  +-3/2: E = d4 - 9/16 d2, O = 3/2 (d3 - 9/16 d1)
+    assert consts == sorted([81 / 64, 45 / 16, 9 / 4, 3 / 4, 9 / 16, 3 / 2])
+    assert BT[0] == [Fr(81, 64), 0, Fr(-45, 16), 0, 1, 0] and BT[5] == [0, Fr(81, 64), 0, Fr(-45, 16), 0, 1]
+    assert BT[1] == [0, Fr(-27, 16), Fr(-9, 4), Fr(3, 4), 1, 0] and BT[2] == [0, Fr(27, 16), Fr(-9, 4), Fr(-3, 4), 1, 0]
+    assert BT[3] == [0, Fr(-27, 32), Fr(-9, 16), Fr(3, 2), 1, 0] and BT[4] == [0, Fr(27, 32), Fr(-9, 16), Fr(-3, 2), 1, 0]
+    assert Fr(3, 4) * Fr(9, 4) == Fr(27, 16) and Fr(3, 2) * Fr(9, 16) == Fr(27, 32)
+    at = src[src.index("__device__ __forceinline__ void at4_lo("):src.index("__global__ __launch_bounds__(512, 1) void wino4_f32")]
+    consts = sorted({float(x) for x in re.findall(r"splat\((\d+\.\d+)f\)", at)})
+    assert consts == sorted([3 / 4, 3 / 2, 9 / 16, 9 / 4, 27 / 64, 27 / 8])
+    assert AT == [[1, 1, 1, 1, 1, 0], [0, Fr(3, 4), Fr(-3, 4), Fr(3, 2), Fr(-3, 2), 0],
+                  [0, Fr(9, 16), Fr(9, 16), Fr(9, 4), Fr(9, 4), 0], [0, Fr(27, 64), Fr(-27, 64), Fr(27, 8), Fr(-27, 8), 1]]
+    gsrc = src[src.index("const double G[6][3] = {"):]
+    gsrc = gsrc[:gsrc.index("};")]
+    vals = [Fr(int(a), int(b)) if b else Fr(int(float(a))) for a, b in
+            re.findall(r"(-?\d+)\.0(?: / (\d+)\.0)?", gsrc.split("= {", 1)[1])]
+    assert vals == [v for row in G for v in row]

@@ -37,7 +37,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # profiles/r03_wino_gamma.json / DESIGN.md §3.0): the limits are ~2x the worst measured value of each form.
 # Worst measured (28 input x filter statistics each): direct3 30, F(2x2,3x3) 18, direct7 120, F(4,7) 277, F(6,7) 439;
 # zero-mean Gaussian inputs and filters: 4.3, 2.1, 5.3, 51, 108.
-GAMMA_LIMIT = {"direct3": 64.0, "F(2x2,3x3)": 48.0, "direct7": 256.0, "F(4,7)": 600.0, "F(6,7)": 1000.0}
+GAMMA_LIMIT = {"direct3": 64.0, "F(2x2,3x3)": 48.0, "F(4x4,3x3)": 160.0, "direct7": 256.0, "F(4,7)": 600.0,
+               "F(6,7)": 1000.0}
 HETEROGENEOUS = ("logu_px", "heavy")
 
 
@@ -78,7 +79,8 @@ def _weights(kind, cout, cin, k, g):
 
 
 def _gpu_conv(capi, dev, x, wts, bias, k, form, relu=0, pool=0):
-    """x [n,cin,h,w], wts [cout,cin,k,k] (CPU fp32) through the C ABI; form: 'direct', 3, 4 or 6."""
+    """x [n,cin,h,w], wts [cout,cin,k,k] (CPU fp32) through the C ABI; form: 'direct', 3 (F(2x2,3x3)), 43 (F(4x4,3x3)),
+    4 or 6 (F(m,7))."""
     lib, Layout = capi.lib, capi.Layout
     n, cin, h, w = x.shape
     cout = wts.shape[0]
@@ -101,6 +103,10 @@ def _gpu_conv(capi, dev, x, wts, bias, k, form, relu=0, pool=0):
         wp = torch.zeros(lib.rtpose_packed_weight_floats_winograd(cout, cin, 3), device=dev)
         capi.check(lib.rtpose_pack_conv_weights_winograd(capi.ptr(wd), capi.ptr(bd), cout, cin, 3, None, cin,
                                                          capi.ptr(wp), capi.ptr(bp), stream))
+    elif form == 43:
+        wp = torch.zeros(lib.rtpose_packed_weight_floats_winograd3(cout, cin, 4), device=dev)
+        capi.check(lib.rtpose_pack_conv_weights_winograd3(capi.ptr(wd), capi.ptr(bd), cout, cin, 4, None, cin,
+                                                          capi.ptr(wp), capi.ptr(bp), stream))
     else:
         wp = torch.zeros(lib.rtpose_packed_weight_floats_winograd7(cout, cin, form), device=dev)
         capi.check(lib.rtpose_pack_conv_weights_winograd7(capi.ptr(wd), capi.ptr(bd), cout, cin, form, None, cin,
@@ -109,7 +115,7 @@ def _gpu_conv(capi, dev, x, wts, bias, k, form, relu=0, pool=0):
     d[0].inp, d[0].w_packed, d[0].bias_packed, d[0].out = xin.data_ptr(), wp.data_ptr(), bp.data_ptr(), obuf.data_ptr()
     d[0].lin, d[0].lout = lin, lout
     d[0].cin, d[0].cout, d[0].k, d[0].relu, d[0].pool = cin, cout, k, relu, pool
-    d[0].wino_m = form if form in (4, 6) else 0
+    d[0].wino_m = form if form in (4, 6) else 4 if form == 43 else 0
     if form == "direct":
         capi.check(lib.rtpose_conv2d(d, 1, n, h, w, stream), "rtpose_conv2d")
     else:
@@ -184,7 +190,8 @@ def test_7x7_forms_elementwise_error_bound(capi, cuda, kw):
 
 @pytest.mark.parametrize("kw", ("he", "pos", "smooth", "ref_init_x30"))
 def test_3x3_form_elementwise_error_bound(capi, cuda, kw):
-    """F(2x2,3x3): 128 -> 128 (the <1,4,16> instance, 13 launches of a forward) and 64 -> 64 (conv1_2's <2,2,16>)."""
+    """F(2x2,3x3): 128 -> 128 (the <1,4,16> instance) and 64 -> 64 (conv1_2's <2,2,16>); F(4x4,3x3) (csrc/conv_wino4.hip,
+    the plan default) on the same shapes - 46 x 46 and 48 x 40 maps: clamped patch rows / columns and exact tiles."""
     g = torch.Generator().manual_seed(2000 + len(kw))
     failures = []
     for (n, c, h, w, cout) in ((2, 128, 46, 46, 128), (1, 64, 48, 40, 64)):
@@ -192,10 +199,10 @@ def test_3x3_form_elementwise_error_bound(capi, cuda, kw):
         bias = torch.randn(cout, generator=g) * 0.1
         for kx in INPUT_KINDS:
             x = _inputs(kx, n, c, h, w, g)
-            outs = {f: _gpu_conv(capi, cuda, x, wts, bias, 3, f) for f in ("direct", 3)}
-            for f, name in (("direct", "direct3"), (3, "F(2x2,3x3)")):
-                het = kx in HETEROGENEOUS and f == 3
-                y64, s = _ref64(x, wts, bias, 3, (3, 3) if het else None)
+            outs = {f: _gpu_conv(capi, cuda, x, wts, bias, 3, f) for f in ("direct", 3, 43)}
+            for f, name in (("direct", "direct3"), (3, "F(2x2,3x3)"), (43, "F(4x4,3x3)")):
+                het = kx in HETEROGENEOUS and f != "direct"
+                y64, s = _ref64(x, wts, bias, 3, ((5, 5) if f == 43 else (3, 3)) if het else None)
                 gamma = ((outs[f].double() - y64).abs() / (U * s)).max().item()
                 _record(name, kx, kw, gamma)
                 if not gamma <= GAMMA_LIMIT[name]:
@@ -207,11 +214,11 @@ def test_3x3_form_elementwise_error_bound(capi, cuda, kw):
 
 def _amp_exact(wts, k, m):
     """The definition in include/rtpose_mi355x.h from the exact Toom-Cook matrices (oracle/winograd_tables.py)."""
-    from oracle.winograd_tables import toom_cook, POINTS_F4_7, POINTS_F6_7, POINTS_F2_3
+    from oracle.winograd_tables import toom_cook, POINTS_F4_7, POINTS_F6_7, POINTS_F2_3, POINTS_F4_3
     wd = wts.double().numpy()
     f = lambda M: np.array([[float(v) for v in row] for row in M])   # noqa: E731
     if k == 3:
-        AT, G, BT = map(f, toom_cook(2, 3, POINTS_F2_3))
+        AT, G, BT = map(f, toom_cook(4, 3, POINTS_F4_3) if m == 4 else toom_cook(2, 3, POINTS_F2_3))
         Uf = np.einsum('ay,bx,ocyx->ocab', G, G, wd)
         a, b = np.abs(AT), np.abs(BT).sum(1)
         sfreq = np.abs(Uf).sum(1)
@@ -231,7 +238,7 @@ def test_amplification_estimate_matches_its_definition(capi, cuda):
     amp = torch.zeros(1, device=cuda)
     seen = {}
     for kind in ("he", "pos", "smooth"):
-        for k, m in ((3, 0), (7, 4), (7, 6)):
+        for k, m in ((3, 0), (3, 4), (7, 4), (7, 6)):
             wts = _weights(kind, 24, 40, k, g)
             wd = wts.to(cuda)
             capi.check(lib.rtpose_winograd_amplification(capi.ptr(wd), 24, 40, k, m, capi.ptr(amp),
@@ -239,10 +246,12 @@ def test_amplification_estimate_matches_its_definition(capi, cuda):
             got, want = amp.item(), _amp_exact(wts, k, m)
             assert abs(got - want) <= 2e-3 * want, (kind, k, m, got, want)
             seen[(kind, k, m)] = got
-    # orientation: i.i.d. Gaussian filters ~3.3 / 62 / 115; F(6,7) amplifies more than F(4,7) for every kind
+    # orientation: i.i.d. Gaussian filters ~3.3 / 62 / 115; F(6,7) amplifies more than F(4,7) for every kind, and
+    # F(4x4,3x3) more than F(2x2,3x3)
     assert 2.5 < seen[("he", 3, 0)] < 4.5 and 40 < seen[("he", 7, 4)] < 90 and 80 < seen[("he", 7, 6)] < 160
+    print("F(4x4,3x3) amplification estimates:", {k[0]: round(v, 1) for k, v in seen.items() if k[1:] == (3, 4)})
     for kind in ("he", "pos", "smooth"):
-        assert seen[(kind, 7, 6)] > seen[(kind, 7, 4)]
+        assert seen[(kind, 7, 6)] > seen[(kind, 7, 4)] and seen[(kind, 3, 4)] > seen[(kind, 3, 0)]
 
 
 @pytest.fixture(scope="module")
@@ -271,13 +280,14 @@ def test_form_is_chosen_per_plan_through_the_abi(model_and_sd, cuda):
     outs = {}
     try:
         for name, kw, want7, want3 in (
-                ("default", dict(), [6], [3]),
+                ("default", dict(), [6], [43]),
                 ("direct", dict(winograd3=False, winograd7=0), [0], [0]),
-                ("f47", dict(winograd7=4), [4], [3]),
+                ("f47", dict(winograd7=4), [4], [43]),
                 ("f67_w3off", dict(winograd3=False, winograd7=6), [6], [0]),
-                ("auto_all", dict(winograd7='auto', amp_limit=1e9), [6], [3]),
-                ("auto_f47", dict(winograd7='auto', amp_limit=90.0), [4], [3]),
-                ("auto_none", dict(winograd7='auto', amp_limit=1.0), [0], [3])):
+                ("f23", dict(winograd3=True), [6], [3]),
+                ("auto_all", dict(winograd3='auto', winograd7='auto', amp_limit=1e9), [6], [43]),
+                ("auto_f47", dict(winograd7='auto', amp_limit=90.0), [4], [43]),
+                ("auto_none", dict(winograd3='auto', winograd7='auto', amp_limit=1.0), [0], [3])):
             m.set_winograd(**kw)
             plan = m.forward_native(xd, keep_intermediates=False)
             assert _forms(m, plan, 7) == want7, (name, _forms(m, plan, 7))
@@ -287,14 +297,18 @@ def test_form_is_chosen_per_plan_through_the_abi(model_and_sd, cuda):
             assert m.device_status(plan) == 0
             outs[name] = (paf, heat)
             amps = [a for (_, _, a), (_, mod) in zip(m.conv_numerics(plan), m._convs()) if mod.kernel_size[0] == 7]
-            assert all(40 < a[1] < 90 and 80 < a[2] < 160 and a[0] == 0 for a in amps)
+            assert all(40 < a[1] < 90 and 80 < a[2] < 160 and a[0] == 0 and a[3] == 0 for a in amps)
+            amps3 = [a for (_, _, a), (_, mod) in zip(m.conv_numerics(plan), m._convs())
+                     if mod.kernel_size[0] == 3 and mod.in_channels >= 32]
+            assert all(a[3] > a[0] > 0 and a[1] == 0 for a in amps3)
     finally:
         m.set_winograd()
-    assert len([k for k in m._weights if k[1] == 0]) == 1          # one fp32 arena served all seven plans
+    assert len([k for k in m._weights if k[1] == 0]) == 1          # one fp32 arena served all eight plans
     assert torch.equal(outs["default"][0], outs["auto_all"][0])    # same forms, same bits
     assert torch.equal(outs["f47"][0], outs["auto_f47"][0])
     assert not torch.equal(outs["default"][0], outs["direct"][0])  # the forms differ by rounding ...
     assert not torch.equal(outs["default"][0], outs["f47"][0])
+    assert not torch.equal(outs["default"][0], outs["f23"][0])
     assert (outs["default"][0] - outs["direct"][0]).abs().max().item() <= 2e-4   # ... and only by rounding
 
 
