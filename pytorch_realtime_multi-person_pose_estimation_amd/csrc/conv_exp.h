@@ -132,7 +132,7 @@ inline const char* dev_env(const char* name) {
 #define RTPOSE_EXP_STAGE 1
 #endif
 
-// conv_wino16.hip: B ring entries / prefetch distance (frequencies)
+// tools/exp/conv_wino16.hip (experiment record): B ring entries / prefetch distance (frequencies)
 #ifndef RTPOSE_W16_NB
 #define RTPOSE_W16_NB 8
 #endif

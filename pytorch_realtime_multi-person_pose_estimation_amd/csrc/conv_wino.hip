@@ -753,8 +753,6 @@ int conv2d_wino_ok(int cin, int cout, int k) {
   return k == 3 && cin > 0 && cin % wino_ck(cout, cin) == 0 && cin / wino_ck(cout, cin) >= 2;
 }
 
-int conv2d_wino16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s);
-
 int conv2d_wino_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s) {
   using namespace wino;
   if (!d || ngroups < 1 || ngroups > 2) return fail(RTPOSE_E_INVAL, "conv2d_winograd: ngroups must be 1 or 2");
@@ -850,15 +848,7 @@ int conv2d_wino_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
     RTPOSE_HIP_CHECK(hipGetLastError());
     return 0;
   }
-  if (wm == 1) {
-    static int use16 = -1;  // developer switch: the two-waves-per-SIMD form (conv_wino16.hip)
-    if (use16 < 0) {
-      const char* e = dev_env("RTPOSE_W3_16");
-      use16 = e ? atoi(e) : 0;
-    }
-    if (use16) return conv2d_wino16_launch(d, ngroups, N, H, W, s);
-    return launch_inst<1, 4, 16>(a, grid, s);
-  }
+  if (wm == 1) return launch_inst<1, 4, 16>(a, grid, s);
   // 64 columns (conv1_2): 64 wtiles x 64 columns; 16-channel chunks with a whole patch per thread where cin allows
   if (ck == 16) return launch_inst<2, 2, 16>(a, grid, s);
   return launch_inst<2, 2, 8>(a, grid, s);
