@@ -495,6 +495,258 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
 #undef RTPOSE_PIN
 }
 
+// Small grids (few images): the same arithmetic on 8x as many blocks.  A block = 6 waves = 16 wtiles x 16 columns;
+// wave w multiplies the six frequencies fx = w (3 pairs x 4 MFMAs per chunk), the waves 0..2 run stage 1 of the input
+// transform (two patch rows each), the waves 3..5 stage 2 (two fx each).  Every frequency still sums over the chunks
+// and the two channel halves of a chunk in wino4_f32's order, the transforms are the same functions of the same
+// values: bit-identical results.  Before the output transform the waves exchange their row sums through LDS; the
+// waves 0..3 finish one (wtile pair, output row pair) each.  One 368 x 368 image, conv3_2: 34 x 16 = 544 blocks of
+// 74 KB LDS (two per CU) instead of 17 x 4 = 68.
+constexpr int NTS = 16;                   // wtiles per block
+constexpr int VBUFS = NFP * 4 * NTS;      // float4 per V buffer: [pair][kq][wtile]
+constexpr int UBUFS = 36 * 2 * NTS;       // float4 per U buffer: [fx][y][channel group][wtile ^ 4 cg]
+
+__global__ __launch_bounds__(384, 2) void wino4s_f32(const Args A) {
+  extern __shared__ __attribute__((aligned(16))) float4 L4[];
+  auto Vb = [&](int i) -> float4* { return L4 + i * VBUFS; };
+  auto Ub = [&](int i) -> float4* { return L4 + 2 * VBUFS + i * UBUFS; };
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..5: the frequencies fx = wv
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  // block -> (m tile, 16-column tile, group)
+  const int bi = blockIdx.x;
+  const int mt = bi % A.mtiles, c = bi / A.mtiles;
+  const int nt = c % A.ntiles, grp = c / A.ntiles;
+  const Group g = grp ? A.g[1] : A.g[0];
+  const int TT = A.TY * A.TX;
+  const int nchunks = A.cin / CK;  // even, >= 4 (host)
+
+  // ---- transform roles ----------------------------------------------------------------------------------------------
+  const bool s1 = wv < 3;
+  const int hi5 = lane >> 5;
+  const int wl1 = (lane >> 1) & 15, cg1 = lane & 1, py = 2 * (s1 ? wv : 0) + hi5;  // stage 1: (wtile, channel group, patch row)
+  const int wl = lane & 15, cg = (lane >> 4) & 1, fx = 2 * (s1 ? 0 : wv - 3) + hi5;  // stage 2: (wtile, channel group, fx)
+  const i32x4 rw = make_rsrc(g.w, g.w_bytes);
+  i32x4 rin;
+  unsigned pv0, pvx;  // byte offset of pixel 0 of the row; pixels of the row before the gap column (W + 1 - 4 tx)
+  const unsigned pxb = (unsigned)g.in_cstride * 4;
+  {
+    size_t q0;
+    {
+      const int t = min(mt * NTS, A.T - 1);
+      const int n = t / TT, r = t - n * TT;
+      const int ty = r / A.TX, tx = r - ty * A.TX;
+      q0 = (size_t)g.in_lead + (size_t)(n * g.in_hs + 4 * ty - 1) * g.in_ws + (4 * tx - 1);
+    }
+    const int t = min(mt * NTS + wl1, A.T - 1);
+    const int n = t / TT, r = t - n * TT;
+    const int ty = r / A.TX, tx = r - ty * A.TX;
+    const int yy = min(4 * ty - 1 + py, A.H);  // rows past the image: the zero gap row
+    const size_t qq = (size_t)g.in_lead + (size_t)(n * g.in_hs + yy) * g.in_ws + (4 * tx - 1);
+    const size_t o0 = q0 * g.in_cstride + g.in_choff;
+    rin = make_rsrc(g.in + o0, g.in_bytes - o0 * 4);
+    pv0 = (unsigned)(((qq - q0) * g.in_cstride + cg1 * 4) * 4);
+    pvx = (unsigned)(A.W + 1 - 4 * tx);
+  }
+  auto undefine = [&](F4& x) { asm volatile("" : "=v"(x.lo.x), "=v"(x.lo.y), "=v"(x.hi.x), "=v"(x.hi.y)); };
+  F4 p[6];
+  auto load_piece = [&](int chunk, int n5) {
+    const unsigned cb = (unsigned)min(chunk, nchunks - 1) * (CK * 4);  // (past the last chunk: that chunk again)
+    p[n5] = n5 < 3 ? bload(rin, pv0, cb + n5 * pxb) : bload(rin, pv0 + min((unsigned)n5, pvx) * pxb, cb);
+  };
+  const int ust = (py * 2 + cg1) * NTS + (wl1 ^ (4 * cg1));     // U[fx][y = py][cg][wtile ^ 4 cg], + fx * 6 * 2 * NTS
+  const int uld = ((fx * 6) * 2 + cg) * NTS + (wl ^ (4 * cg));  // U[fx][y][cg][wtile ^ 4 cg], + y * 2 * NTS
+  const int vst = ((fx * 3) * 4 + 2 * cg) * NTS + wl;           // V[pair = fx * 3 + fy / 2][kq = 2 cg + h][wtile]
+  auto stage1 = [&](int ubuf) {
+    float4* dst = Ub(ubuf) + ust;
+    bt6(p, [&](int f, F4 u) { dst[f * 6 * 2 * NTS] = to_float4(u); });
+  };
+  F4 q[6];
+  auto stage2_read = [&](int ubuf) {
+    const float4* src = Ub(ubuf) + uld;
+#pragma unroll
+    for (int y = 0; y < 6; ++y) {
+      const float4 t = src[y * 2 * NTS];
+      q[y] = F4{f2{t.x, t.y}, f2{t.z, t.w}};
+    }
+  };
+  auto stage2 = [&](int vbuf) {
+    float4* dst = Vb(vbuf) + vst;
+    F4 ev;
+    bt6(q, [&](int f, F4 v) {
+      if (f & 1) {
+        dst[(f >> 1) * 4 * NTS] = make_float4(ev.lo.x, ev.lo.y, v.lo.x, v.lo.y);
+        dst[(f >> 1) * 4 * NTS + NTS] = make_float4(ev.hi.x, ev.hi.y, v.hi.x, v.hi.y);
+      } else {
+        ev = v;
+      }
+    });
+  };
+
+  // ---- MFMA role: frequencies wv * 6 .. wv * 6 + 5 = pairs 3 wv .. 3 wv + 2, 16 wtiles x 16 columns --------------------
+  const int ncol = nt * 16 + r16;
+  floatx4 acc[6];
+#pragma unroll
+  for (int f = 0; f < 6; ++f)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[f][v] = 0.f;
+  const unsigned boff = (unsigned)((kq * g.cout_pad + ncol) * 16);
+  const unsigned fstep = (unsigned)(4 * g.cout_pad * 16);  // bytes per (chunk, frequency pair)
+  unsigned wso = (unsigned)wv * 3 * fstep;
+  float4 bs[6];  // the pairs of two chunks
+  const int aoff = wv * 3 * 4 * NTS + kq * NTS + r16;
+
+  // ---- prologue: V[0] <- chunk 0, U[1] <- chunk 1, patch rows of chunk 2 in flight ---------------------------------------
+#pragma unroll
+  for (int i = 0; i < 6; ++i) load_piece(0, i);
+  if (s1) stage1(0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) load_piece(1, i);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    bs[i] = bload_f4(rw, boff, wso);
+    wso += fstep;
+  }
+  wso += (NFP - 3) * fstep;
+  __syncthreads();
+  if (!s1) {
+    stage2_read(0);
+    stage2(0);
+  }
+  if (s1) stage1(1);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) load_piece(2, i);
+  __syncthreads();
+
+#pragma unroll 1
+  for (int c2 = 0; c2 < nchunks; c2 += 2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // chunk c2 + h multiplies from V[h]
+      const float4* va = Vb(h) + aoff;
+      // the filter pairs of the next chunk (past the last one: clamped by the descriptor, unused)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        bs[((h ^ 1) * 3) + i] = bload_f4(rw, boff, wso);
+        wso += fstep;
+      }
+      wso += (NFP - 3) * fstep;
+      // transform work of this chunk period: stage 1 of chunk + 2 -> U[h], stage 2 of chunk + 1: U[h ^ 1] -> V[h ^ 1]
+      if (s1) {
+        stage1(h);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) load_piece(c2 + h + 3, i);
+      } else {
+        stage2_read(h ^ 1);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float4 av = va[i * 4 * NTS], bv = bs[h * 3 + i];
+        acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[2 * i], 0, 0, 0);
+        acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[2 * i + 1], 0, 0, 0);
+        acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[2 * i], 0, 0, 0);
+        acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[2 * i + 1], 0, 0, 0);
+      }
+      if (!s1) stage2(h ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: row sums (first pass of the output transform, along y) of the wave's fx -> LDS; the waves 0..3 run the
+  // second pass for one (wtile pair, output row pair) each ----------------------------------------------------------------
+  {
+    float4* const E = L4;  // [fx][wtile pair][row pair][lane]
+#pragma unroll
+    for (int vp = 0; vp < 2; ++vp) {
+      f2 m[6], sg[4];
+#pragma unroll
+      for (int y = 0; y < 6; ++y) m[y] = f2{acc[y][2 * vp], acc[y][2 * vp + 1]};
+      at4_lo(m, sg[0], sg[1]);
+      at4_hi(m, sg[2], sg[3]);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+        E[((wv * 2 + vp) * 2 + hh) * 64 + lane] = make_float4(sg[2 * hh].x, sg[2 * hh].y, sg[2 * hh + 1].x, sg[2 * hh + 1].y);
+    }
+    __syncthreads();
+    if (wv < 4) {
+      const int vp = wv >> 1, ih = wv & 1;
+      f2 sl[6][2];
+#pragma unroll
+      for (int x = 0; x < 6; ++x) {
+        const float4 t = E[((x * 2 + vp) * 2 + ih) * 64 + lane];
+        sl[x][0] = f2{t.x, t.y};
+        sl[x][1] = f2{t.z, t.w};
+      }
+      const bool col_ok = ncol < g.cout;
+      const float bias0 = g.bias[ncol];
+      const int sc = A.pool ? 2 : 4;
+      auto wt_q = [&](int n, int ty, int tx) -> int { return (n * g.out_hs + sc * ty) * g.out_ws + sc * tx; };
+      int q0;
+      {
+        const int t = min(mt * NTS, A.T - 1);
+        const int n = t / TT, r = t - n * TT;
+        const int ty = r / A.TX;
+        q0 = wt_q(n, ty, r - ty * A.TX);
+      }
+      const size_t oo0 = ((size_t)g.out_lead + (size_t)q0) * g.out_cstride + g.out_choff;
+      const i32x4 rout = make_rsrc(g.out + oo0, g.out_bytes - oo0 * 4);
+      const unsigned cs4 = (unsigned)g.out_cstride * 4, row4 = (unsigned)g.out_ws * cs4;
+      const unsigned col4 = (unsigned)ncol * 4;
+      unsigned off[2];
+      bool okv[2];
+      int ylim[2], xlim[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int tcur = mt * NTS + 4 * kq + 2 * vp + e;
+        const int sn = tcur / TT, r = tcur - sn * TT;
+        const int sy = r / A.TX, sx = r - sy * A.TX;
+        okv[e] = col_ok && tcur < A.T;
+        off[e] = (unsigned)(wt_q(sn, sy, sx) - q0) * cs4 + col4;
+        ylim[e] = A.H - 4 * sy;
+        xlim[e] = A.W - 4 * sx;
+      }
+      f2 yy[2][4];
+#pragma unroll
+      for (int il = 0; il < 2; ++il) {
+        f2 m[6];
+#pragma unroll
+        for (int x = 0; x < 6; ++x) m[x] = sl[x][il];
+        at4_lo(m, yy[il][0], yy[il][1]);
+        at4_hi(m, yy[il][2], yy[il][3]);
+      }
+      if (A.pool) {
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {
+          f2 mx = __builtin_elementwise_max(__builtin_elementwise_max(yy[0][2 * jh], yy[0][2 * jh + 1]),
+                                            __builtin_elementwise_max(yy[1][2 * jh], yy[1][2 * jh + 1]));
+          mx = mx + splat(bias0);
+          if (A.relu) mx = __builtin_elementwise_max(mx, splat(0.f));
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const bool ok = okv[e] && 2 * ih < ylim[e] && 2 * jh < xlim[e];
+            bstore(mx[e], rout, ok ? off[e] : kNoStore, ih * row4 + jh * cs4);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int il = 0; il < 2; ++il)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = 2 * ih + il;
+            f2 o = yy[il][j] + splat(bias0);
+            if (A.relu) o = __builtin_elementwise_max(o, splat(0.f));
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const bool ok = okv[e] && i < ylim[e] && j < xlim[e];
+              bstore(o[e], rout, ok ? off[e] : kNoStore, i * row4 + j * cs4);
+            }
+          }
+      }
+    }
+  }
+}
+
 // ---- weight packing: U = G g G^T for the points 0, +-3/4, +-3/2, inf (double arithmetic, one rounding) -------------
 // packed[chunk][pair][kq][cout_pad][f2][e]: frequency f = fx * 6 + fy = 2 pair + f2, channel chunk * 8 + 2 kq + e
 __device__ __forceinline__ double g43(int f, int k) {
@@ -651,9 +903,30 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
   long ids = a.xcd_remap ? (long)8 * a.ncombo * ceil_div(a.mtiles, 8) : (long)a.mtiles * a.ncombo;
   if (ids > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv2d_winograd: grid too large");
   const int n_cu = device_cu_count();
-  if ((long)a.mtiles * a.ncombo > n_cu && n_cu % (8 * a.ncombo) == 0) {
+  // launches that fill at most half the CUs with 32 x 64 tiles run the 16 x 16 form (measured: at one round and beyond
+  // the big tiles win - the small form fetches the filters four times as often; tools/r3_session27.sh)
+  const bool small = (long)a.mtiles * a.ncombo * 2 <= n_cu;
+  if (!small && (long)a.mtiles * a.ncombo > n_cu && n_cu % (8 * a.ncombo) == 0) {
     a.persist = 1;
     ids = n_cu;
+  }
+  if (small) {
+    // small grids: the 16 x 16 form (wino4s_f32), bit-identical, 8x the blocks
+    Args b = a;
+    b.mtiles = ceil_div(a.T, NTS);
+    b.ntiles = cout_pad(d0.cout) / 16;
+    b.ncombo = b.ntiles * ngroups;
+    static PerDeviceOnce attr_s;
+    const int dev_s = current_device();
+    if (!attr_s.is_set(dev_s)) {
+      RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4s_f32),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      attr_s.set(dev_s);
+    }
+    hipLaunchKernelGGL(wino4s_f32, dim3((unsigned)((long)b.mtiles * b.ncombo)), dim3(384),
+                       (size_t)(2 * VBUFS + 2 * UBUFS) * sizeof(float4), s, b);
+    RTPOSE_HIP_CHECK(hipGetLastError());
+    return 0;
   }
   static PerDeviceOnce attr_set;
   const int dev = current_device();

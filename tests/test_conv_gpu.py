@@ -274,6 +274,27 @@ def test_winograd4_grouped_branches_and_batch_invariance(capi, cuda):
     assert torch.equal(big[0][:1], one[0])
 
 
+def test_winograd4_small_grid_form_is_bit_identical(capi, cuda):
+    """Few tiles (batch 1): F(4x4,3x3) launches its 16 x 16 form (wino4s_f32: six waves split the frequencies) - the same
+    sums in the same order as the 32 x 64 kernel with its persistent blocks: an image's result does not depend on the
+    batch it is evaluated in."""
+    big, refs = _run_conv(capi, cuda, 9, 46, 46, 256, 512, 3, 1, 0, 1, 1, seed=21, winograd=True, wino_m=4)
+    one, _ = _run_conv(capi, cuda, 9, 46, 46, 256, 512, 3, 1, 0, 1, 1, seed=21, winograd=True, wino_m=4, only_images=1)
+    assert (big[0] - refs[0]).abs().max().item() <= TOL * max(1.0, refs[0].abs().max().item())
+    assert torch.equal(big[0][:1], one[0])
+    # fused pool, one column tile of 64 (four of 16 in the small form), odd tile counts, two branches
+    big, _ = _run_conv(capi, cuda, 20, 96, 80, 64, 64, 3, 1, 1, 1, 1, seed=22, winograd=True, wino_m=4, skip_ref=True)
+    one, _ = _run_conv(capi, cuda, 20, 96, 80, 64, 64, 3, 1, 1, 1, 1, seed=22, winograd=True, wino_m=4, only_images=1,
+                       skip_ref=True)
+    assert torch.equal(big[0][:1], one[0])
+    big, _ = _run_conv(capi, cuda, 40, 45, 47, 128, 128, 3, 1, 0, 3, 3, seed=23, groups=2, winograd=True, wino_m=4,
+                       skip_ref=True)
+    two, _ = _run_conv(capi, cuda, 40, 45, 47, 128, 128, 3, 1, 0, 3, 3, seed=23, groups=2, winograd=True, wino_m=4,
+                       only_images=2, skip_ref=True)
+    for a, b in zip(big, two):
+        assert torch.equal(a[:2], b)
+
+
 def test_winograd_grouped_branches_and_direct_agree(capi, cuda):
     outs, refs = _run_conv(capi, cuda, 2, 46, 46, 128, 128, 3, 1, 0, 3, 3, seed=9, groups=2, winograd=True)
     direct, _ = _run_conv(capi, cuda, 2, 46, 46, 128, 128, 3, 1, 0, 3, 3, seed=9, groups=2)
