@@ -70,6 +70,7 @@ struct Args {
   int relu, pool;
   int mtiles, ntiles, ncombo, xcd_remap;
   int persist;
+  int mt0;  // first m tile of this launch (a layer may run as a persistent launch of whole rounds + a launch of the rest)
 };
 
 constexpr int NT = 32;    // wtiles per block
@@ -186,12 +187,12 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
   auto set_loader = [&](int mt, i32x4& r_, unsigned (&v_)[4]) {
     size_t q0;
     {
-      const int t = min(mt * NT, A.T - 1);
+      const int t = min((A.mt0 + mt) * NT, A.T - 1);
       const int n = t / TT, r = t - n * TT;
       const int ty = r / A.TX, tx = r - ty * A.TX;
       q0 = (size_t)g.in_lead + (size_t)(n * g.in_hs + 4 * ty - 1) * g.in_ws + (4 * tx - 1);
     }
-    const int t = min(mt * NT + wl1, A.T - 1);
+    const int t = min((A.mt0 + mt) * NT + wl1, A.T - 1);
     const int n = t / TT, r = t - n * TT;
     const int ty = r / A.TX, tx = r - ty * A.TX;
     const int yy = min(4 * ty - 1 + py, A.H);  // rows past the image: the zero gap row
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
       auto wt_q = [&](int n, int ty, int tx) -> int { return (n * g.out_hs + sc * ty) * g.out_ws + sc * tx; };
       int q0;
       {
-        const int t = min(mt * NT, A.T - 1);
+        const int t = min((A.mt0 + mt) * NT, A.T - 1);
         const int n = t / TT, r = t - n * TT;
         const int ty = r / A.TX;
         q0 = wt_q(n, ty, r - ty * A.TX);
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
       const i32x4 rout = make_rsrc(g.out + oo0, g.out_bytes - oo0 * 4);
       const unsigned cs4 = (unsigned)g.out_cstride * 4, row4 = (unsigned)g.out_ws * cs4;
       const unsigned col4 = (unsigned)ncol * 4;
-      int tcur = mt * NT + FH * 16 + 4 * kq;
+      int tcur = (A.mt0 + mt) * NT + FH * 16 + 4 * kq;
       int sn = tcur / TT, sy, sx;
       {
         const int r = tcur - sn * TT;
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(384, 2) void wino4s_f32(const Args A) {
 
   // block -> (m tile, 16-column tile, group)
   const int bi = blockIdx.x;
-  const int mt = bi % A.mtiles, c = bi / A.mtiles;
+  const int mt = A.mt0 + bi % A.mtiles, c = bi / A.mtiles;
   const int nt = c % A.ntiles, grp = c / A.ntiles;
   const Group g = grp ? A.g[1] : A.g[0];
   const int TT = A.TY * A.TX;
@@ -903,17 +904,12 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
   long ids = a.xcd_remap ? (long)8 * a.ncombo * ceil_div(a.mtiles, 8) : (long)a.mtiles * a.ncombo;
   if (ids > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv2d_winograd: grid too large");
   const int n_cu = device_cu_count();
-  // launches that fill at most half the CUs with 32 x 64 tiles run the 16 x 16 form (measured: at one round and beyond
-  // the big tiles win - the small form fetches the filters four times as often; tools/r3_session27.sh)
-  const bool small = (long)a.mtiles * a.ncombo * 2 <= n_cu;
-  if (!small && (long)a.mtiles * a.ncombo > n_cu && n_cu % (8 * a.ncombo) == 0) {
-    a.persist = 1;
-    ids = n_cu;
-  }
-  if (small) {
-    // small grids: the 16 x 16 form (wino4s_f32), bit-identical, 8x the blocks
-    Args b = a;
-    b.mtiles = ceil_div(a.T, NTS);
+  auto launch_small = [&](const Args& a0, int mt0_32, long wtiles) -> int {
+    // the 16 x 16 form (wino4s_f32), bit-identical, 8x the blocks: `wtiles` wtiles from m tile mt0_32 (in 32-wtile units) on
+    Args b = a0;
+    b.persist = 0;
+    b.mt0 = 2 * mt0_32;
+    b.mtiles = (int)((wtiles + NTS - 1) / NTS);
     b.ntiles = cout_pad(d0.cout) / 16;
     b.ncombo = b.ntiles * ngroups;
     static PerDeviceOnce attr_s;
@@ -927,6 +923,26 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
                        (size_t)(2 * VBUFS + 2 * UBUFS) * sizeof(float4), s, b);
     RTPOSE_HIP_CHECK(hipGetLastError());
     return 0;
+  };
+  // launches that fill at most half the CUs with 32 x 64 tiles run the 16 x 16 form (measured: at one round and beyond
+  // the big tiles win - the small form fetches the filters four times as often; tools/r3_session27.sh)
+  if ((long)a.mtiles * a.ncombo * 2 <= n_cu) return launch_small(a, 0, a.T);
+  int rest = 0;  // m tiles left to a second launch
+  if ((long)a.mtiles * a.ncombo > n_cu && n_cu % (8 * a.ncombo) == 0) {
+    // Persistent blocks: block (column tile / group c, q) takes the m tiles q, q + Pc, ...  When the tiles do not come out
+    // as whole rounds and what is left over is at most a quarter of a round, the whole rounds run here and the rest as a
+    // second launch in the 16 x 16 form: 2 rounds + a short launch instead of 3 (conv4_3_CPM, the stage-1 convs: 0.60 ->
+    // 0.53 ms, 0.17 -> 0.155), 1 + a short one instead of 2 (conv4_4_CPM: 0.21 -> 0.15).  Half a round left over is
+    // cheaper as a half-empty round of big tiles (conv4_1 / conv4_2: 0.51 -> 0.54 ms with the cut), and at 8.27 rounds
+    // (conv3_x) the cut changes nothing.  The forms are bit-identical, so the cut is invisible in the results.
+    const int Pc = n_cu / a.ncombo;
+    const int r = a.mtiles % Pc;
+    if (r && (long)r * a.ncombo * 4 <= n_cu) {
+      rest = r;
+      a.mtiles -= r;
+    }
+    a.persist = 1;
+    ids = n_cu;
   }
   static PerDeviceOnce attr_set;
   const int dev = current_device();
@@ -937,6 +953,7 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
   }
   hipLaunchKernelGGL(wino4_f32, dim3((unsigned)ids), dim3(512), (size_t)(2 * VBUF + 2 * UBUF) * sizeof(float4), s, a);
   RTPOSE_HIP_CHECK(hipGetLastError());
+  if (rest) return launch_small(a, a.mtiles, (long)a.T - (long)a.mtiles * NT);
   return 0;
 }
 

@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # profiles/r03_wino_gamma.json / DESIGN.md §3.0): the limits are ~2x the worst measured value of each form.
 # Worst measured (28 input x filter statistics each): direct3 30, F(2x2,3x3) 18, direct7 120, F(4,7) 277, F(6,7) 439;
 # zero-mean Gaussian inputs and filters: 4.3, 2.1, 5.3, 51, 108.
-GAMMA_LIMIT = {"direct3": 64.0, "F(2x2,3x3)": 48.0, "F(4x4,3x3)": 160.0, "direct7": 256.0, "F(4,7)": 600.0,
+GAMMA_LIMIT = {"direct3": 64.0, "F(2x2,3x3)": 48.0, "F(4x4,3x3)": 100.0, "direct7": 256.0, "F(4,7)": 600.0,
                "F(6,7)": 1000.0}
 HETEROGENEOUS = ("logu_px", "heavy")
 

@@ -1,4 +1,4 @@
-# round-3 evidence (fp32 plan: conv1_1 kernel, F(2x2,3x3) with the cross-tile pipeline, F(6,7) in the 8-wave form):
+# round-3 evidence (fp32 plan: conv1_1 kernel, F(4x4,3x3) for the 3x3 convs, F(6,7) in the 8-wave form):
 # GPU tests, the bench line, rocprofv3 kernel trace of the same command, per-launch events, PMC passes (SQ set;
 # FETCH_SIZE; WRITE_SIZE + MFMA counts: separate passes, --kernel-trace only), and the secondary tools.
 # Summaries -> gpurun_out/r03_*; copied into profiles/ by hand.
@@ -20,6 +20,8 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU
   [ -n "$db" ] && python $R/tools/rocpd_summary.py $db | grep -E "wino|conv_mfma_f32|conv_first|counter" >> $O/r03_pmc_counters.txt
   rm -rf $O/r03_pmc
 done
+RTPOSE_WINOGRAD3_M=2 python $R/tools/profile_layers.py 32 368 368 5 fp32 > $O/r03_fp32_layers_f23.txt 2>&1
+python $R/tools/bench_conv3.py > $O/r03_conv3_forms.txt 2>&1
 python $R/tools/latency_b1.py > $O/r03_latency_b1.txt 2>&1
 python $R/tools/bench_config5.py > $O/r03_config5.json 2>/dev/null
 python $R/tools/bench_tta.py 32 3 > $O/r03_tta.txt 2>&1
