@@ -557,6 +557,8 @@ __global__ __launch_bounds__(384, 2) void wino4s_f32(const Args A) {
     const unsigned cb = (unsigned)min(chunk, nchunks - 1) * (CK * 4);  // (past the last chunk: that chunk again)
     p[n5] = n5 < 3 ? bload(rin, pv0, cb + n5 * pxb) : bload(rin, pv0 + min((unsigned)n5, pvx) * pxb, cb);
   };
+  // (SQ_LDS_BANK_CONFLICT is 14 % of SQ_LDS_IDX_ACTIVE in this kernel - 0 in wino4_f32 - and a further swizzle of the
+  //  two fx a stage-2 wave reads did not change it; the kernel is ~1 % of a batch-32 forward)
   const int ust = (py * 2 + cg1) * NTS + (wl1 ^ (4 * cg1));     // U[fx][y = py][cg][wtile ^ 4 cg], + fx * 6 * 2 * NTS
   const int uld = ((fx * 6) * 2 + cg) * NTS + (wl ^ (4 * cg));  // U[fx][y][cg][wtile ^ 4 cg], + y * 2 * NTS
   const int vst = ((fx * 3) * 4 + 2 * cg) * NTS + wl;           // V[pair = fx * 3 + fy / 2][kq = 2 cg + h][wtile]

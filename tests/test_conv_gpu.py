@@ -13,11 +13,12 @@ TOL = 1e-4  # relative to max|ref|; fp32 fma-chain vs ATen summation order
 
 
 def _run_conv(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, seed, groups=1, cin_pad=None,
-              winograd=False, only_images=None, skip_ref=False, wino_m=0, scratch=True):
+              winograd=False, only_images=None, skip_ref=False, wino_m=0, scratch=True, first_image=0):
     lib, Layout = capi.lib, capi.Layout
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, cin, h, w, generator=g)
-    if only_images:   # the same random stream, but only the first images go through the kernel
+    if only_images:   # the same random stream, but only some images go through the kernel
+        x = x[first_image:first_image + only_images]
         n = only_images
     cin_p = cin_pad or ((cin + 7) // 8 * 8)
     ws, bs, refs = [], [], []
@@ -293,6 +294,15 @@ def test_winograd4_small_grid_form_is_bit_identical(capi, cuda):
                        only_images=2, skip_ref=True)
     for a, b in zip(big, two):
         assert torch.equal(a[:2], b)
+    # the stage-1 geometry of the bench: 144 m tiles x 4 (column tile, branch) on 256 CUs = 2.25 rounds -> two persistent
+    # rounds + the last 16 m tiles as a second launch in the small form; the cut is invisible
+    big, _ = _run_conv(capi, cuda, 32, 46, 46, 128, 128, 3, 1, 0, 3, 3, seed=24, groups=2, winograd=True, wino_m=4,
+                       skip_ref=True)
+    for first, count in ((0, 2), (30, 2)):
+        part, _ = _run_conv(capi, cuda, 32, 46, 46, 128, 128, 3, 1, 0, 3, 3, seed=24, groups=2, winograd=True, wino_m=4,
+                            skip_ref=True, only_images=count, first_image=first)
+        for a, b in zip(big, part):
+            assert torch.equal(a[first:first + count], b)
 
 
 def test_winograd_grouped_branches_and_direct_agree(capi, cuda):

@@ -1,11 +1,12 @@
 """Time one 3x3 conv launch through the C ABI in its forms: direct, F(2x2,3x3), F(4x4,3x3).
    python tools/bench_conv3.py [N H W cin cout pool groups] ...   (default: the rtpose_vgg 3x3 shapes at batch 32)"""
 import ctypes as C
+import os
 import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from importlib import import_module
 
 pkg = import_module("pytorch_realtime_multi-person_pose_estimation_amd")
