@@ -14,7 +14,7 @@
     defined(RTPOSE_EXP_STAGGER) || defined(RTPOSE_EXP_TB1X1) || defined(RTPOSE_EXP_HD) ||               \
     defined(RTPOSE_EXP_RB2) || defined(RTPOSE_EXP_W7_PF) || defined(RTPOSE_EXP_W7_TMASK) || defined(RTPOSE_EXP_W7_LPS) || defined(RTPOSE_EXP_W_EPI) || \
     defined(RTPOSE_EXP_W3_SWOLD) || defined(RTPOSE_EXP_W7_XSPLIT) || defined(RTPOSE_EXP_W7_PRIO) || defined(RTPOSE_EXP_W7_FS2SETS) || defined(RTPOSE_EXP_W7_CGMAJOR) || defined(RTPOSE_EXP_TIMELINE3) || \
-    defined(RTPOSE_EXP_W4_NOXF) || defined(RTPOSE_EXP_W4_NOLOAD) || defined(RTPOSE_EXP_W4_XCDMAP) || defined(RTPOSE_EXP_W4_AUX) || defined(RTPOSE_EXP_W4_L0)
+    defined(RTPOSE_EXP_W4_NOXF) || defined(RTPOSE_EXP_W4_NOLOAD) || defined(RTPOSE_EXP_W4_XCDMAP) || defined(RTPOSE_EXP_W7_NULLDESC) || defined(RTPOSE_EXP_W4_AUX) || defined(RTPOSE_EXP_W4_L0)
 #error "RTPOSE_EXP_* ablation switches need -DRTPOSE_DEV_BUILD (they are not part of production builds)"
 #endif
 #endif
@@ -147,4 +147,9 @@ inline const char* dev_env(const char* name) {
 // conv_wino4.hip: persistent blocks of one m tile on one XCD (1) or spread over the XCDs (0)
 #ifndef RTPOSE_EXP_W4_XCDMAP
 #define RTPOSE_EXP_W4_XCDMAP 1
+#endif
+// conv_wino7.hip, 8-wave form: 1 = the non-transforming waves issue the segment loads too, through a zero-extent descriptor
+// (exact vmcnt bookkeeping; what gave the F(4x4,3x3) kernel 6 % measured 0 % here: 14.18 vs 14.12..14.19 ms of 7x7 time)
+#ifndef RTPOSE_EXP_W7_NULLDESC
+#define RTPOSE_EXP_W7_NULLDESC 0
 #endif

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
   const int py = wv;                      // stage 1: patch row
   const int fx = max(wv - 2, 0);          // stage 2: frequency along x
   const i32x4 rw = make_rsrc(g.w, g.w_bytes);
+  const i32x4 rnull = make_rsrc(g.in, 0);
   // the "load cursor": the (tile, chunk) position whose patch rows are requested next, 3 positions ahead of the multiply
   i32x4 rin;
   unsigned pv[4];  // byte offsets of pixel 0 and of the pixels 3, 4, 5 (clamped to the gap column) of the row
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
           if (lt < A.mtiles) set_loader(lt, rin, pv);
         }
         const int c3 = lc++;
+        const i32x4 rl = s1 ? rin : rnull;
         a0 = va[fh * 16];
         a1 = va[(fh ^ 1) * 16];
 #pragma unroll
@@ -331,24 +333,18 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
             if (i < 2) {
               if (s1 && i == turn) stage1(h);              // patch rows of position + 2 -> U[h]
             } else if (i < 4) {
-              if (i == 2 + turn) {                         // U[h ^ 1] = position + 1
-                if (s2) stage2_read(h ^ 1);
-                else
-#pragma unroll
-                  for (int y = 0; y < 6; ++y) undefine(q[y]);
-              }
+              if (i == 2 + turn) stage2_read(h ^ 1);       // U[h ^ 1] = position + 1 (the waves 0, 1 read and discard: see the loads)
             } else if (i < 6) {
               if (s2 && i == 4 + turn) stage2(h ^ 1);      // -> V[h ^ 1]
             }
 #ifndef RTPOSE_EXP_W4_NOLOAD  // (timing only: the transform on stale registers)
             if (i >= RTPOSE_EXP_W4_L0 && i < RTPOSE_EXP_W4_L0 + 3) {
-              if (s1) {
-                load_piece(rin, pv, c3, 2 * (i - RTPOSE_EXP_W4_L0));  // patch rows of position + 3
-                load_piece(rin, pv, c3, 2 * (i - RTPOSE_EXP_W4_L0) + 1);
-              } else {
-                undefine(p[2 * (i - RTPOSE_EXP_W4_L0)]);
-                undefine(p[2 * (i - RTPOSE_EXP_W4_L0) + 1]);
-              }
+              // Issued by ALL waves: the waves 6, 7 (no stage-1 item) go through a descriptor of zero extent - every lane is
+              // out of range, nothing is fetched.  Under a wave-uniform branch the compiler's vmcnt bookkeeping has to assume
+              // the loads were NOT issued: every later wait for a filter fragment then also waited for these patch loads,
+              // one or two steps after their issue (0.92 -> see DESIGN.md §3.0).
+              load_piece(rl, pv, c3, 2 * (i - RTPOSE_EXP_W4_L0));  // patch rows of position + 3
+              load_piece(rl, pv, c3, 2 * (i - RTPOSE_EXP_W4_L0) + 1);
             }
 #endif
           }
@@ -547,7 +543,7 @@ __global__ __launch_bounds__(384, 2) void wino4s_f32(const Args A) {
     const int yy = min(4 * ty - 1 + py, A.H);  // rows past the image: the zero gap row
     const size_t qq = (size_t)g.in_lead + (size_t)(n * g.in_hs + yy) * g.in_ws + (4 * tx - 1);
     const size_t o0 = q0 * g.in_cstride + g.in_choff;
-    rin = make_rsrc(g.in + o0, g.in_bytes - o0 * 4);
+    rin = make_rsrc(g.in + o0, s1 ? g.in_bytes - o0 * 4 : 0);
     pv0 = (unsigned)(((qq - q0) * g.in_cstride + cg1 * 4) * 4);
     pvx = (unsigned)(A.W + 1 - 4 * tx);
   }
@@ -636,13 +632,12 @@ __global__ __launch_bounds__(384, 2) void wino4s_f32(const Args A) {
       }
       wso += (NFP - 3) * fstep;
       // transform work of this chunk period: stage 1 of chunk + 2 -> U[h], stage 2 of chunk + 1: U[h ^ 1] -> V[h ^ 1]
-      if (s1) {
-        stage1(h);
+      // (the patch loads are issued by all six waves - the waves 3..5 through a descriptor of zero extent -, not under the
+      //  wave-uniform branch: the compiler's vmcnt bookkeeping would have to assume they were not issued, see wino4_f32)
+      if (s1) stage1(h);
+      else stage2_read(h ^ 1);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) load_piece(c2 + h + 3, i);
-      } else {
-        stage2_read(h ^ 1);
-      }
+      for (int i = 0; i < 6; ++i) load_piece(c2 + h + 3, i);
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const float4 av = va[i * 4 * NTS], bv = bs[h * 3 + i];

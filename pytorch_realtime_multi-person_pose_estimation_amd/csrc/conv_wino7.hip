@@ -277,6 +277,10 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
   // ---- input transform role: NI items (row, gx, channel group), see Xform ----------------------------
   Xform<NI, FM> X;
   X.setup(g, A.W, GX, RS, R0, nrows);
+  // (RTPOSE_EXP_W7_NULLDESC, off: the waves 4..7 of the 8-wave form issue the segment loads too, through a descriptor of
+  //  zero extent, so that the loads are not under a wave-uniform branch and the compiler's vmcnt bookkeeping stays exact -
+  //  the fix that gave conv_wino4.hip 6 %; measured 0 % here, the deep filter ring already covers it)
+  if (RTPOSE_EXP_W7_NULLDESC && !xf) X.rin = make_rsrc(g.in, 0);
   const i32x4 rw = make_rsrc(g.w, g.w_bytes);
   auto load_piece = [&](int chunk, int k, int n) { X.load_piece(chunk, k, n); };
   auto tgroup = [&](float4* vw, int k, int gidx) { X.tgroup(vw, k, gidx); };
@@ -410,9 +414,9 @@ __device__ __forceinline__ void wino7_segment(const Args& A, float4* V4, const i
           bs[(ps + PF) % NSETS][j - 2] = RTPOSE_EXP_B(bload_f4(rw, boff, wso), bs[ps % NSETS][j - 2]);
           bnext(bl);
         }
-        if (RTPOSE_EXP_STAGE && j == 3 && xf) {
+        if (RTPOSE_EXP_STAGE && j == 3 && (xf || RTPOSE_EXP_W7_NULLDESC)) {
           if (ps % GSTR == 0 && ps / GSTR < NG) {
-            if ((RTPOSE_EXP_W7_TMASK & 1) && my_group((ps / GSTR) % (NP + 2)))
+            if (xf && (RTPOSE_EXP_W7_TMASK & 1) && my_group((ps / GSTR) % (NP + 2)))
               tgroup(vw, (ps / GSTR) / (NP + 2), (ps / GSTR) % (NP + 2));
           } else if (ps >= LS && ps < LS + LSTEPS && (RTPOSE_EXP_W7_TMASK & 2)) {  // LPS segment loads per step
 #pragma unroll
