@@ -210,7 +210,13 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
   F4 p[6];
   auto load_piece = [&](const i32x4& r_, const unsigned (&v_)[4], int chunk, int n5) {
     const unsigned cb = (unsigned)chunk * (CK * 4);
+#ifdef RTPOSE_EXP_W4_AUX  // cache policy bits of the patch loads (1 sc0, 2 nt, 16 sc1): no effect / nt 2x slower
+    const f32x4 t = n5 < 3 ? llvm_raw_buffer_load_v4f32(r_, (int)v_[0], (int)(cb + n5 * pxb), RTPOSE_EXP_W4_AUX)
+                           : llvm_raw_buffer_load_v4f32(r_, (int)v_[n5 - 2], (int)cb, RTPOSE_EXP_W4_AUX);
+    p[n5] = F4{f2{t.x, t.y}, f2{t.z, t.w}};
+#else
     p[n5] = n5 < 3 ? bload(r_, v_[0], cb + n5 * pxb) : bload(r_, v_[n5 - 2], cb);
+#endif
   };
   const int ust = (py * 2 + cg1) * NT + (wl1 ^ (4 * cg1));     // U[fx][y = py][cg][wtile ^ 4 cg], + fx * 6 * 2 * NT
   const int uld = ((fx * 6) * 2 + cg) * NT + (wl ^ (4 * cg));  // U[fx][y][cg][wtile ^ 4 cg], + y * 2 * NT
