@@ -940,7 +940,12 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
     // (conv3_x) the cut changes nothing.  The forms are bit-identical, so the cut is invisible in the results.
     const int Pc = n_cu / a.ncombo;
     const int r = a.mtiles % Pc;
-    if (r && (long)r * a.ncombo * 4 <= n_cu) {
+    static int cut_pct = -1;  // developer switch: largest left-over (in % of a round) that is cut off
+    if (cut_pct < 0) {
+      const char* e = dev_env("RTPOSE_W4_CUT_PCT");
+      cut_pct = e ? atoi(e) : 25;
+    }
+    if (r && (long)r * a.ncombo * 100 <= (long)cut_pct * n_cu) {
       rest = r;
       a.mtiles -= r;
     }
