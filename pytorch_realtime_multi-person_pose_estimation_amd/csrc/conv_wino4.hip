@@ -13,13 +13,18 @@
 // DESIGN.md §3.0) this one has the smallest measured element-wise error - gamma ~5 against 20 for the textbook points
 // 0, +-1, +-2 (F(2x2,3x3): 1.5..18; the 7x7 forms the network already runs: F(4,7) 277, F(6,7) 439).
 //
-// MI355X shape:
-//  * a block = 8 waves = 32 wtiles x 64 output columns, two waves per SIMD; wave (wm, wn) owns all 36 frequencies of
-//    16 wtiles x 16 columns on v_mfma_f32_16x16x4_f32: 36 accumulators x 4 registers = 144 of the 256 a wave may hold
-//    at two waves per SIMD.  The output transform is lane-local (a lane holds 4 consecutive wtiles of one column).
-//  * channel chunks of 8: per chunk and frequency PAIR a wave issues 4 MFMAs fed by ONE ds_read_b128 (A: the pair's
-//    values of channels 2 kq, 2 kq + 1 for wtile r16) and ONE 16-byte buffer load (B: the same for column r16),
-//    5 pairs ahead in a 6-entry register ring.  MFMA j of a frequency contracts the channels {2 kq + j : kq = 0..3}.
+// MI355X shape (wino4_f32; the small-grid form wino4s_f32 is described at its definition):
+//  * a block = 8 waves = 32 wtiles x 64 output columns, two waves per SIMD, on v_mfma_f32_16x16x4_f32.  The two waves
+//    of a SIMD split the FREQUENCIES: wave (fh, wn) owns the 18 frequencies 18 fh .. 18 fh + 17 of 32 wtiles (two row tiles
+//    of 16) x the 16 columns 16 wn ..: 36 accumulators x 4 registers = 144 of the 256 a wave may hold at two waves per
+//    SIMD.  (A wave with all 36 frequencies of ONE row tile has the same 144 registers but fetches every filter fragment
+//    for 4 MFMAs instead of 8: 32 B/clk per CU of filter data through the 64 B/clk vector-memory path - 1.18 ms per
+//    256 -> 256 layer against 1.02.)  Before the output transform the siblings (waves w, w ^ 4) swap the first-pass row sums
+//    of the row tile they do not finish through the LDS buffers that are dead at a tile boundary.
+//  * channel chunks of 8: per chunk and frequency PAIR a wave issues 8 MFMAs fed by TWO ds_read_b128 (A: the pair's
+//    values of channels 2 kq, 2 kq + 1 for wtile r16 of each row tile) and ONE 16-byte buffer load (B: the same for column
+//    r16), 5 pairs ahead in a 6-entry register ring (two chunks are unrolled so that the ring rotates in step).  MFMA j of a
+//    frequency contracts the channels {2 kq + j : kq = 0..3}.
 //  * the 2-D input transform does not fit beside 144 accumulators in one piece (a 6 x 6 patch of 4 channels is 144
 //    registers), so it runs in two 1-D stages through LDS, each 12 packed fmas + 6 LDS accesses of 16 bytes per item:
 //      stage 1  item (wtile, channel group, patch row y): 6 pixels -> B^T along x -> U[fx][y]        waves 0..5 (y = wave)
@@ -27,7 +32,12 @@
 //    (three items per SIMD either way).  Pipeline over the "positions" (tile, chunk) of a persistent block, one barrier
 //    per chunk: while chunk s is multiplied from V[s & 1], stage 2 turns U[(s + 1) & 1] into V[(s + 1) & 1], stage 1 turns the
 //    patch rows of s + 2 (in registers) into U[s & 1], and the rows of s + 3 are requested.  Siblings on a SIMD take
-//    their transform turns one step apart, so the matrix pipe always has a wave that multiplies.
+//    their transform turns one step apart, so the matrix pipe always has a wave that multiplies.  Every wave issues the
+//    patch loads and the U reads - the waves without an item through a zero-extent descriptor / into registers nobody
+//    uses: a load under a wave-uniform branch makes the compiler's vmcnt bookkeeping assume the worst at every join.
+//  * persistent blocks when there are more tiles than CUs; the blocks that multiply the SAME m tiles (one per column tile
+//    / branch) sit on one XCD and share the patch lines in its L2; a left-over of at most a quarter round runs as a
+//    second launch in the small form.
 //  * patch rows / columns past the image (the last wtile row / column when H, W are not multiples of 4) are CLAMPED
 //    to the zero gap row / column of the shared-gap layout: they would only meet outputs that are not stored, but
 //    through the transforms they cancel only up to rounding, and an image would depend on its neighbour in the batch.
@@ -321,8 +331,6 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
           {
             // B PF pairs ahead.  After a chunk's ninth pair the sibling's nine are skipped; after the tile's last chunk
             // the ring wraps to the next tile.
-            constexpr int dummy = 0;
-            (void)dummy;
             const int L = h * NPW + i + PF;
             bs[L % NB] = RTPOSE_EXP_B(bload_f4(rw, boff, wso), bs[(h * NPW + i) % NB]);
             if (L % NPW == NPW - 1) wso = (c2 + L / NPW == nchunks - 1) ? wbase : wso + (NPW + 1) * fstep;
