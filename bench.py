@@ -312,6 +312,7 @@ def main():
     # ---- roofline leg, AFTER the timed region: the same step with per-launch HIP events recorded on the launch
     # stream (rtpose_net_set_profiling), for the average duration of the dominant kernel ------------------------
     k7_ms, k7_flops, k7_exec, k7_n, k7_wino, net_ms, k7_form = 0.0, 0.0, 0.0, 0, 0, 0.0, 0
+    k3_ms, k3_flops, k3_exec, k3_n, k3_form = 0.0, 0.0, 0.0, 0, 0   # the second kernel family: the 3x3 convs
     prof_steps = max(3, min(args.steps, 8))
     lib.rtpose_net_set_profiling(plan.handle, 1)
     step()                                      # (the first profiled forward creates the events)
@@ -330,6 +331,13 @@ def main():
                     k7_wino += 1 if wf.value else 0
                     k7_form = wf.value
                     k7_n += 1
+                elif k.value == 3:
+                    lib.rtpose_net_launch_executed_flops(plan.handle, i, C.byref(fx), C.byref(wf))
+                    k3_ms += ms.value
+                    k3_flops += fl.value
+                    k3_exec += fx.value
+                    k3_form = max(k3_form, wf.value)
+                    k3_n += 1
     lib.rtpose_net_set_profiling(plan.handle, 0)
     status = model.device_status(plan) if not bf16 else 0
     if status:
@@ -385,6 +393,18 @@ def main():
                          "flops_per_launch": round(k7_flops / max(k7_n, 1)),
                          "avg_launch_ms": round(k7_ms / max(k7_n, 1), 4)},
         }
+        if k3_ms > 0:
+            # not part of the contract's roofline object: the same accounting for the 3x3 convs (conv1_1 .. conv4_4_CPM
+            # and the stage-1 convs), the second-largest share of the step
+            out["roofline_3x3"] = {
+                "kernel": ("wino4_f32 / wino4s_f32 (F(4x4,3x3))" if k3_form == 43 else
+                           "wino_f32 (F(2x2,3x3))" if k3_form == 3 else "direct / bf16 kernels") +
+                          " + conv_first_kernel (conv1_1)",
+                "ms_per_forward": round(k3_ms / prof_steps, 3), "launches_per_forward": k3_n // prof_steps,
+                "achieved": round(k3_flops / (k3_ms * 1e-3) / 1e12, 2), "executed": round(k3_exec / (k3_ms * 1e-3) / 1e12, 2),
+                "executed_frac": round(k3_exec / (k3_ms * 1e-3) / 1e12 / peak, 4), "peak": peak, "unit": "TFLOP/s",
+                "note": "achieved = direct-convolution flops / event time; executed = MFMA flops issued (whole tiles, "
+                        "36 frequencies per 4 x 4 outputs in F(4x4,3x3)) / event time"}
         if world == 1 and not args.no_traffic and "ROCPROF" not in "".join(os.environ.keys()).upper():
             # free this process's GPU memory pressure is irrelevant (288 GB); the child runs its own plan
             tr = measure_traffic(dtype=args.dtype)
