@@ -364,6 +364,14 @@ def test_winograd_random_geometries_match_direct(capi, cuda):
         for a, b in zip(wino, direct):
             err = (a - b).abs().max().item()
             assert err <= 1e-4 * max(1.0, b.abs().max().item()), (k, n, h, w, cin, cout, groups, pool, err)
+        d[0].wino_m = 4
+        if k == 3 and lib.rtpose_conv2d_winograd_fits(d, n, h, w):   # the F(4x4,3x3) form of the same conv
+            wino4, _ = _run_conv(capi, cuda, n, h, w, cin, cout, k, relu, pool, pin, 1, seed=seed, groups=groups,
+                                 winograd=True, skip_ref=True, wino_m=4)
+            for a, b in zip(wino4, direct):
+                err = (a - b).abs().max().item()
+                assert err <= 1e-4 * max(1.0, b.abs().max().item()), ("F(4x4,3x3)", n, h, w, cin, cout, groups, pool, err)
+        d[0].wino_m = 0
     assert tried >= 25
 
 
