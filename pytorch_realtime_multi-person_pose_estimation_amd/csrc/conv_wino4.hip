@@ -936,7 +936,7 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
     return 0;
   };
   // launches that fill at most half the CUs with 32 x 64 tiles run the 16 x 16 form (measured: at one round and beyond
-  // the big tiles win - the small form fetches the filters four times as often; tools/r3_session27.sh)
+  // the big tiles win - the small form fetches the filters four times as often; tools/r3_sessions/session27.sh)
   if ((long)a.mtiles * a.ncombo * 2 <= n_cu) return launch_small(a, 0, a.T);
   int rest = 0;  // m tiles left to a second launch
   if ((long)a.mtiles * a.ncombo > n_cu && n_cu % (8 * a.ncombo) == 0) {

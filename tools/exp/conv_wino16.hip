@@ -1,6 +1,6 @@
 // EXPERIMENT RECORD (round 3, not part of the library): the F(2x2,3x3) kernel re-tiled for two waves per SIMD on
 // 16 x 16 x 4 MFMAs.  Measured 3.4 % faster than wino_f32<1,4,16> over the 13 launches it covers (11.30 -> 10.92 ms of
-// 3x3 time at batch 32; tools/r3_session11.sh, profiles/r03_wino16_experiment.txt), then superseded by the F(4x4,3x3)
+// 3x3 time at batch 32; tools/r3_sessions/session11.sh, profiles/r03_wino16_experiment.txt), then superseded by the F(4x4,3x3)
 // form (csrc/conv_wino4.hip, 8.8 ms), which kept its wave layout ideas.  To build it: add it to SRCS of csrc/Makefile and
 // route conv2d_wino_launch's wm == 1 case to conv2d_wino16_launch.
 // fp32 Winograd F(2x2, 3x3) convolution on 16 x 16 matrix-core tiles, TWO WAVES PER SIMD, for gfx950 (MI355X): the

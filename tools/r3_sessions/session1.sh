@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU session 1 of round 3: A/B of the Winograd kernel variants, per-tile timeline of the 3x3 kernel, full GPU tests
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ( timeout 600 tools/r3_variants.sh run ) > gpurun_out/s1_variants.log 2>&1

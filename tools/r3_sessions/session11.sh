@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 session 11: the two-waves-per-SIMD 3x3 Winograd form (conv_wino16.hip) behind RTPOSE_W3_16 (developer builds)
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export RTPOSE_LIB_PATH=$PWD/tools/exp/lib_r3_base.so
 echo "=== conv tests with RTPOSE_W3_16=1 (bit-identity tests against the small-grid form are expected to differ)"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 session 25: wino4_f32 persistent scheduling: whole tiles strided (0) / contiguous (3) / split (1)
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export RTPOSE_LIB_PATH=$PWD/tools/exp/lib_r3_base.so
 for sp in 0 3 1; do
   echo "=== RTPOSE_W4_SPLIT=$sp"

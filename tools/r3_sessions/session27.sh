@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 session 27: where the 16 x 16 form of F(4x4,3x3) stops paying (rounds of 32 x 64 tiles)
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export RTPOSE_LIB_PATH=$PWD/tools/exp/lib_r3_base.so
 for r in 0 1 2 4; do
   for n in 1 2 4 8 16; do

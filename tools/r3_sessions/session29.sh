@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 session 29: checks after the small-form LDS swizzle + the two-launch test; c_host with the new forms
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 timeout 900 python -m pytest tests/test_conv_gpu.py -q -x -k "winograd4" 2>&1 | tail -4
 timeout 300 python tools/latency_b1.py 2>&1 | grep fp32
 for args in "32 0" "8 0 auto"; do LD_LIBRARY_PATH=$PWD/pytorch_realtime_multi-person_pose_estimation_amd/lib examples/c_host $args; done 2>&1 | grep -v amdgpu

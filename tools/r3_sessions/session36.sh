@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 session 36: hipGraph replay at batch 1 (latency) and batch 32 (bench), alternating
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 for g in 0 1 0 1; do
   echo "RTPOSE_GRAPH=$g: $(RTPOSE_GRAPH=$g timeout 300 python tools/latency_b1.py 2>&1 | grep -E '^fp32|^bf16 ' | tr '\n' ' ')"
 done

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 run() { echo "=== $1 FS=$2"; RTPOSE_W7_FS=$2 RTPOSE_LIB_PATH=$PWD/tools/exp/lib_r3_$1.so timeout 300 python tools/profile_layers.py 32 368 368 5 fp32 2>&1 | grep -E "model2_1.0|model2_1.2|^k=7|sum of"; }
