@@ -105,7 +105,7 @@ class RtposeVGG(NativeStateMixin, nn.Module):
 
     def set_winograd(self, winograd3=None, winograd7=None, amp_limit=None):
         """Arithmetic of the fp32 convs of plans created from now on (``rtpose_net_options``):
-        ``winograd3``: None = library default (F(4x4,3x3)), False / 0 = direct kernels, True / 2 = F(2x2,3x3),
+        ``winograd3``: None = library default (F(4x4,3x3)), False / 0 = direct kernels, True / 1 / 2 = F(2x2,3x3),
         4 = F(4x4,3x3), 'auto' = per layer F(4x4,3x3) if its amplification estimate is <= ``amp_limit``, else F(2x2,3x3);
         ``winograd7``: None = default (F(6,7)), 0 = direct, 4 / 6 = F(4,7) / F(6,7), 'auto' = per layer the
         fastest form whose amplification estimate for the loaded filters is <= ``amp_limit`` (default 256).
@@ -114,12 +114,12 @@ class RtposeVGG(NativeStateMixin, nn.Module):
             w3 = _capi.WINO_DEFAULT
         elif winograd3 == 'auto':
             w3 = _capi.WINO3_AUTO
-        elif winograd3 is True or winograd3 == 2:
+        elif winograd3 in (1, 2):        # (True == 1)
             w3 = 1
-        elif winograd3 is False or winograd3 in (0, 4):
+        elif winograd3 in (0, 4):        # (False == 0)
             w3 = int(winograd3)
         else:
-            raise ValueError("winograd3 must be None, False / 0, True / 2, 4 or 'auto'")
+            raise ValueError("winograd3 must be None, False / 0, True / 1 / 2, 4 or 'auto'")
         if winograd7 is None:
             w7 = _capi.WINO_DEFAULT
         elif winograd7 == 'auto':

@@ -362,6 +362,17 @@ def test_native_state_is_per_device_and_invalidates(pkg, monkeypatch):
     assert m.set_winograd().plan_for_shape(2, 64, 64, d0) is pa
     with pytest.raises(ValueError):
         m.set_winograd(winograd7=5)
+    # rtpose_net_options.winograd3: default / direct / F(2x2,3x3) / F(4x4,3x3) / per-layer AUTO
+    from importlib import import_module
+    capi = import_module(pkg.__name__ + "._capi")
+    for arg, want in ((None, capi.WINO_DEFAULT), (False, 0), (0, 0), (True, 1), (1, 1), (2, 1), (4, 4), ('auto', capi.WINO3_AUTO)):
+        assert m.set_winograd(winograd3=arg)._wino[0] == want, arg
+    pd = m.set_winograd(winograd3=2).plan_for_shape(2, 64, 64, d0)
+    assert pd is not pa and pd.weights is pa.weights
+    for bad in (3, 1.5, 'f43'):
+        with pytest.raises(ValueError):
+            m.set_winograd(winograd3=bad)
+    m.set_winograd()
 
 
 def test_modules_can_be_deep_copied_and_pickled(pkg):
