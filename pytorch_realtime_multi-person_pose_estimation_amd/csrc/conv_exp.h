@@ -14,7 +14,7 @@
     defined(RTPOSE_EXP_STAGGER) || defined(RTPOSE_EXP_TB1X1) || defined(RTPOSE_EXP_HD) ||               \
     defined(RTPOSE_EXP_RB2) || defined(RTPOSE_EXP_W7_PF) || defined(RTPOSE_EXP_W7_TMASK) || defined(RTPOSE_EXP_W7_LPS) || defined(RTPOSE_EXP_W_EPI) || \
     defined(RTPOSE_EXP_W3_SWOLD) || defined(RTPOSE_EXP_W7_XSPLIT) || defined(RTPOSE_EXP_W7_PRIO) || defined(RTPOSE_EXP_W7_FS2SETS) || defined(RTPOSE_EXP_W7_CGMAJOR) || defined(RTPOSE_EXP_TIMELINE3) || \
-    defined(RTPOSE_EXP_W4_NOXF) || defined(RTPOSE_EXP_W4_NOLOAD) || defined(RTPOSE_EXP_W4_XCDMAP) || defined(RTPOSE_EXP_W7_NULLDESC) || defined(RTPOSE_EXP_W4_AUX) || defined(RTPOSE_EXP_W4_L0)
+    defined(RTPOSE_EXP_W4_NOXF) || defined(RTPOSE_EXP_W4_NOLOAD) || defined(RTPOSE_EXP_W4_XCDMAP) || defined(RTPOSE_EXP_W4_A3) || defined(RTPOSE_EXP_W4_PRIO) || defined(RTPOSE_EXP_TIMELINE4) || defined(RTPOSE_EXP_W7_NULLDESC) || defined(RTPOSE_EXP_W4_AUX) || defined(RTPOSE_EXP_W4_L0)
 #error "RTPOSE_EXP_* ablation switches need -DRTPOSE_DEV_BUILD (they are not part of production builds)"
 #endif
 #endif
@@ -45,6 +45,16 @@ inline const char* dev_env(const char* name) {
   if (A.dbg && threadIdx.x == 0 && (ti) < 6) A.dbg[((size_t)blockIdx.x * 6 + (ti)) * 8 + (slot)] = __builtin_amdgcn_s_memtime()
 #else
 #define RTPOSE_TSTAMP3(ti, slot)
+#endif
+
+// per-chunk stamps of every wave of the F(4x4,3x3) kernel over a block's first tile (tools/timeline_w4.py): slot 0 = first
+// MFMA of the chunk may issue (after the barrier), 1 = last MFMA issued (before the barrier), chunk 63 = epilogue begin / end
+#ifdef RTPOSE_EXP_TIMELINE4
+#define RTPOSE_TSTAMP4(chunk, slot)                                                                           \
+  if (A.dbg && (threadIdx.x & 63) == 0 && (chunk) < 64)                                                        \
+  A.dbg[(((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 64 + (chunk)) * 2 + (slot)] = __builtin_amdgcn_s_memtime()
+#else
+#define RTPOSE_TSTAMP4(chunk, slot)
 #endif
 
 // fp32 1x1 convs: CK-channel sub-chunks per LDS buffer (4: -20 % on the 1x1 layers)
@@ -152,4 +162,12 @@ inline const char* dev_env(const char* name) {
 // (exact vmcnt bookkeeping; what gave the F(4x4,3x3) kernel 6 % measured 0 % here: 14.18 vs 14.12..14.19 ms of 7x7 time)
 #ifndef RTPOSE_EXP_W7_NULLDESC
 #define RTPOSE_EXP_W7_NULLDESC 0
+#endif
+// conv_wino4.hip: s_setprio scheme of the two waves of a SIMD (0 none, 1 alternate per step, 2 younger wave high, 3 alternate per chunk)
+#ifndef RTPOSE_EXP_W4_PRIO
+#define RTPOSE_EXP_W4_PRIO 0
+#endif
+// conv_wino4.hip: A fragments in a ring of three (requested 8 MFMAs ahead) instead of two (4 ahead)
+#ifndef RTPOSE_EXP_W4_A3
+#define RTPOSE_EXP_W4_A3 0
 #endif

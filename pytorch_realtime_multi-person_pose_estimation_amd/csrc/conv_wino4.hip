@@ -46,6 +46,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -81,6 +82,9 @@ struct Args {
   int mtiles, ntiles, ncombo, xcd_remap;
   int persist;
   int mt0;  // first m tile of this launch (a layer may run as a persistent launch of whole rounds + a launch of the rest)
+#ifdef RTPOSE_EXP_TIMELINE4
+  unsigned long long* dbg;  // developer build: [block][wave][64 chunks][2] s_memtime stamps of the block's first tile
+#endif
 };
 
 constexpr int NT = 32;    // wtiles per block
@@ -317,17 +321,48 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
         }
         const int c3 = lc++;
         const i32x4 rl = s1 ? rin : rnull;
+        if (mt == j0) RTPOSE_TSTAMP4(c2 + h, 0);
+#if RTPOSE_EXP_W4_A3
+        // A fragments in a ring of three: the fragment of half-step k + 2 (k = 2 i + row tile) is requested right after the
+        // MFMAs of half-step k are issued - 8 MFMAs ahead instead of 4.  (Per-wave timelines, tools/timeline_w4.py: a wave
+        // took 455..800 cycles per 256-cycle step, two LDS round trips per step on its critical path.)
+        float4 ar[3];
+        ar[0] = va[fh * 16];
+        ar[1] = va[(fh ^ 1) * 16];
+#else
         a0 = va[fh * 16];
         a1 = va[(fh ^ 1) * 16];
+#endif
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
+#if RTPOSE_EXP_W4_PRIO == 1  // the siblings of a SIMD take the matrix pipe's priority in turns, step by step
+          if (fh == (i & 1)) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+#elif RTPOSE_EXP_W4_PRIO == 2  // the younger sibling (wave w + 4) always has it
+          if (i == 0 && fh) __builtin_amdgcn_s_setprio(1);
+#elif RTPOSE_EXP_W4_PRIO == 3  // in turns, chunk by chunk
+          if (i == 0) {
+            if (fh == h) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+          }
+#endif
           const float4 bv = bs[(h * NPW + i) % NB];
+#if RTPOSE_EXP_W4_A3
+          const float4 a0 = ar[(2 * i) % 3], a1 = ar[(2 * i + 1) % 3];
+#endif
           acc[2 * i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bv.x, acc[2 * i][0], 0, 0, 0);
           acc[2 * i + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bv.z, acc[2 * i + 1][0], 0, 0, 0);
           acc[2 * i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bv.y, acc[2 * i][0], 0, 0, 0);
           acc[2 * i + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bv.w, acc[2 * i + 1][0], 0, 0, 0);
           RTPOSE_PIN();
+#if RTPOSE_EXP_W4_PRIO >= 4  // yield the matrix pipe to the sibling after every group of 4 MFMAs
+          __builtin_amdgcn_s_sleep(RTPOSE_EXP_W4_PRIO - 3);
+#endif
+#if RTPOSE_EXP_W4_A3
+          if (i < NPW - 1) ar[(2 * i + 2) % 3] = RTPOSE_EXP_A(va[(i + 1) * 4 * NT + fh * 16], ar[(2 * i) % 3]);
+#else
           if (i < NPW - 1) a0 = RTPOSE_EXP_A(va[(i + 1) * 4 * NT + fh * 16], a0);
+#endif
           {
             // B PF pairs ahead.  After a chunk's ninth pair the sibling's nine are skipped; after the tile's last chunk
             // the ring wraps to the next tile.
@@ -342,7 +377,14 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
           acc[2 * i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bv.y, acc[2 * i][1], 0, 0, 0);
           acc[2 * i + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bv.w, acc[2 * i + 1][1], 0, 0, 0);
           RTPOSE_PIN();
+#if RTPOSE_EXP_W4_PRIO >= 4
+          __builtin_amdgcn_s_sleep(RTPOSE_EXP_W4_PRIO - 3);
+#endif
+#if RTPOSE_EXP_W4_A3
+          if (i < NPW - 1) ar[(2 * i + 3) % 3] = RTPOSE_EXP_A(va[(i + 1) * 4 * NT + (fh ^ 1) * 16], ar[(2 * i + 1) % 3]);
+#else
           if (i < NPW - 1) a1 = RTPOSE_EXP_A(va[(i + 1) * 4 * NT + (fh ^ 1) * 16], a1);
+#endif
           if (RTPOSE_EXP_STAGE) {
             if (i < 2) {
               if (s1 && i == turn) stage1(h);              // patch rows of position + 2 -> U[h]
@@ -364,9 +406,11 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
           }
           RTPOSE_PIN();
         }
+        if (mt == j0) RTPOSE_TSTAMP4(c2 + h, 1);
         __syncthreads();
       }
     }
+    if (mt == j0) RTPOSE_TSTAMP4(63, 0);
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------
     // 1. every wave runs the first pass of the output transform (along y) on its own frequencies fx = 3 fh .. 3 fh + 2,
@@ -502,6 +546,7 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
     };
     if (fh == 0) finish(std::integral_constant<int, 0>{});
     else finish(std::integral_constant<int, 1>{});
+    if (mt == j0) RTPOSE_TSTAMP4(63, 1);
   }  // m tiles of this block
 #undef RTPOSE_PIN
 }
@@ -848,6 +893,11 @@ __global__ void wino4_amp_kernel(const float* __restrict__ w, int cout, int cin,
 
 }  // namespace wino4
 
+#ifdef RTPOSE_EXP_TIMELINE4
+static unsigned long long* g_dbgw4_buf = nullptr;
+static unsigned g_dbgw4_blocks = 0;
+#endif
+
 // 1 when the 3x3 conv has an F(4x4,3x3) instance: 8-channel chunks, at least 3 of them (the transform pipeline is 3 deep)
 int conv2d_wino4_ok(int cin, int cout) { return cout > 0 && cin % 16 == 0 && cin >= 32; }
 
@@ -967,6 +1017,23 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set.set(dev);
   }
+#ifdef RTPOSE_EXP_TIMELINE4
+  {  // developer build: stamps of the LAST launch with the channel counts RTPOSE_TIMELINE_W4="cin,cout" (default 256,256)
+    static int want_cin = -1, want_cout = 256;
+    if (want_cin < 0) {
+      const char* e = dev_env("RTPOSE_TIMELINE_W4");
+      want_cin = 256;
+      if (e) sscanf(e, "%d,%d", &want_cin, &want_cout);
+    }
+    a.dbg = nullptr;
+    if (d0.cin == want_cin && d0.cout == want_cout && ids <= 1024) {
+      if (!g_dbgw4_buf) (void)hipMalloc(&g_dbgw4_buf, (size_t)1024 * 8 * 64 * 2 * 8);
+      (void)hipMemsetAsync(g_dbgw4_buf, 0, (size_t)ids * 8 * 64 * 2 * 8, s);
+      a.dbg = g_dbgw4_buf;
+      g_dbgw4_blocks = (unsigned)ids;
+    }
+  }
+#endif
   hipLaunchKernelGGL(wino4_f32, dim3((unsigned)ids), dim3(512), (size_t)(2 * VBUF + 2 * UBUF) * sizeof(float4), s, a);
   RTPOSE_HIP_CHECK(hipGetLastError());
   if (rest) return launch_small(a, a.mtiles, (long)a.T - (long)a.mtiles * NT);
@@ -1001,3 +1068,14 @@ double conv2d_wino4_issued_flops(int cin, int cout, int N, int H, int W) {
 }
 
 }  // namespace rtpose
+
+#ifdef RTPOSE_EXP_TIMELINE4
+extern "C" int rtpose_debug_timeline_w4_dump(unsigned long long* host, unsigned cap_blocks) {
+  using namespace rtpose;
+  if (!g_dbgw4_buf) return 0;
+  (void)hipDeviceSynchronize();
+  const unsigned n = g_dbgw4_blocks < cap_blocks ? g_dbgw4_blocks : cap_blocks;
+  (void)hipMemcpy(host, g_dbgw4_buf, (size_t)n * 8 * 64 * 2 * 8, hipMemcpyDeviceToHost);
+  return (int)n;
+}
+#endif
