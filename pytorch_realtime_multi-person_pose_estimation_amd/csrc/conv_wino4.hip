@@ -218,9 +218,6 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
 #pragma unroll
     for (int n5 = 3; n5 < 6; ++n5) v_[n5 - 2] = v_[0] + (unsigned)min(n5, A.W + 1 - 4 * tx) * pxb;  // columns past W: the gap column
   };
-  // (a value defined by an empty asm costs nothing and ends the live range of what was there: the waves that skip a
-  //  load or an LDS read under a wave-uniform branch would otherwise keep the 24 registers alive around the whole loop)
-  auto undefine = [&](F4& x) { asm volatile("" : "=v"(x.lo.x), "=v"(x.lo.y), "=v"(x.hi.x), "=v"(x.hi.y)); };
   F4 p[6];
   auto load_piece = [&](const i32x4& r_, const unsigned (&v_)[4], int chunk, int n5) {
     const unsigned cb = (unsigned)chunk * (CK * 4);
@@ -606,7 +603,6 @@ __global__ __launch_bounds__(384, 2) void wino4s_f32(const Args A) {
     pv0 = (unsigned)(((qq - q0) * g.in_cstride + cg1 * 4) * 4);
     pvx = (unsigned)(A.W + 1 - 4 * tx);
   }
-  auto undefine = [&](F4& x) { asm volatile("" : "=v"(x.lo.x), "=v"(x.lo.y), "=v"(x.hi.x), "=v"(x.hi.y)); };
   F4 p[6];
   auto load_piece = [&](int chunk, int n5) {
     const unsigned cb = (unsigned)min(chunk, nchunks - 1) * (CK * 4);  // (past the last chunk: that chunk again)
