@@ -239,3 +239,26 @@ def test_f43_constants_of_the_kernel_are_the_toom_cook_construction():
     vals = [Fr(int(a), int(b)) if b else Fr(int(float(a))) for a, b in
             re.findall(r"(-?\d+)\.0(?: / (\d+)\.0)?", gsrc.split("= {", 1)[1])]
     assert vals == [v for row in G for v in row]
+
+
+def test_f43_restatement_stays_inside_its_error_bound():
+    """oracle/winograd43_oracle.py (numpy float32 restatement of the F(4x4,3x3) form, exact Toom-Cook matrices) against
+    the float64 direct sum: |err| <= gamma 2^-24 sum |x||w| with the limit the GPU test applies to the kernel
+    (tests/test_wino_numerics_gpu.py: 100), on zero-mean and on all-positive data, map sizes that are and are not
+    multiples of 4."""
+    from oracle.winograd43_oracle import conv3x3_f43
+    rng = np.random.default_rng(7)
+    for (cin, cout, H, W, positive) in ((48, 5, 9, 14, False), (32, 4, 8, 8, True)):
+        x = rng.standard_normal((cin, H, W)).astype(np.float32)
+        w = (rng.standard_normal((cout, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5).astype(np.float32)
+        b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+        if positive:
+            x, w = np.abs(x) * 50 + 100, np.abs(w)
+        y = conv3x3_f43(x, w, b)
+        xt, wt = torch.from_numpy(x).double()[None], torch.from_numpy(w).double()
+        ref = torch.nn.functional.conv2d(xt, wt, torch.from_numpy(b).double(), padding=1)[0].numpy()
+        S = torch.nn.functional.conv2d(xt.abs(), wt.abs(), torch.from_numpy(b).double().abs(), padding=1)[0].numpy()
+        gamma = (np.abs(y.astype(np.float64) - ref) / (2.0 ** -24 * S)).max()
+        assert gamma <= 100.0, (cin, H, W, positive, gamma)
+        assert np.abs(y - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+

@@ -210,6 +210,25 @@ def test_3x3_form_elementwise_error_bound(capi, cuda, kw):
     assert not failures, failures
 
 
+def test_f43_kernel_against_its_cpu_restatement(capi, cuda):
+    """csrc/conv_wino4.hip against oracle/winograd43_oracle.py (numpy float32, exact Toom-Cook matrices) on the same
+    inputs: both are within gamma 2^-24 sum|x||w| of the float64 sum, so they are within twice that of each other - and
+    in practice much closer, which is what the second assertion pins (same transforms, same rounding points; only the
+    order of the channel sums differs)."""
+    from oracle.winograd43_oracle import conv3x3_f43
+    g = torch.Generator().manual_seed(43)
+    for (n, cin, h, w, cout) in ((2, 32, 10, 13, 8), (1, 64, 8, 8, 64)):
+        x = torch.randn(n, cin, h, w, generator=g)
+        wts = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.1
+        y_gpu = _gpu_conv(capi, cuda, x, wts, bias, 3, 43)
+        y_cpu = torch.from_numpy(np.stack([conv3x3_f43(x[i].numpy(), wts.numpy(), bias.numpy()) for i in range(n)]))
+        _, s = _ref64(x, wts, bias, 3, None)
+        d = (y_gpu.double() - y_cpu.double()).abs()
+        assert (d / (U * s)).max().item() <= 2 * GAMMA_LIMIT["F(4x4,3x3)"]
+        assert d.max().item() <= 2e-5 * max(1.0, y_cpu.abs().max().item())
+
+
 # ---- amplification estimate and the choice of the form through the ABI ---------------------------------------
 
 def _amp_exact(wts, k, m):
