@@ -764,7 +764,9 @@ int rtpose_net_launch_executed_flops(const rtpose_net* net, int i, double* flops
     for (int g = 0; g < o.ngroups; ++g) {
       // what the matrix pipe is issued (SQ_INSTS_MFMA x 4096 of a launch): whole tiles, padded channels and columns
       const ConvW& c = net->convs[o.conv_idx[g]];
-      if (c.form == 3) {         // 16 frequencies per 2 x 2 wtile
+      if (c.first && !net->bf16) {  // conv_first_kernel: 8 x 32 pixel tiles, K = 28 (27 taps + a zero row), 64 columns
+        fl += 2.0 * net->N * ceil_div(o.H, 8) * ceil_div(o.W, 32) * 256.0 * 28.0 * 64.0;
+      } else if (c.form == 3) {         // 16 frequencies per 2 x 2 wtile
         fl += conv2d_wino_issued_flops(c.cin_packed, c.cout, net->N, o.H, o.W);
         wino = 3;
       } else if (c.form == 43) {  // 36 frequencies per 4 x 4 wtile
