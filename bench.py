@@ -20,8 +20,12 @@ no work is skipped and the decoder still depends on what the network wrote.
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
                 --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+         python bench.py --gpus N ...      (N > 1 started plain: re-executes itself through
+                                            torch.distributed.run with N ranks and relays rank 0's line)
 One process per GPU, weak scaling (32 images per GPU), one RCCL all_gather of the
-result records per step.  Rank 0 prints ONE JSON line.
+result records per step.  Rank 0 prints ONE JSON line; `ranks_seen` in it is the size of
+the process group the timed region really ran in, and a WORLD_SIZE that is not --gpus is an
+error, never a one-GPU measurement labelled N.
 """
 import argparse
 import ctypes as C
@@ -232,6 +236,47 @@ def measure_traffic(timeout_s=150, dtype="fp32"):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def stub_main(args, par):
+    """TEST INFRASTRUCTURE: the contract's skeleton - one process per rank, barrier + timing of exactly --steps steps,
+    max over ranks, one all_gather of the result records per step, rank 0 prints ONE line - on CPU ranks over gloo with a
+    stand-in step (a record block filled with the rank's number).  Proves that `bench.py --gpus N` started plain really
+    runs N ranks and says so; it measures nothing."""
+    rank, _, world = par.init_from_env("gloo", always=True)
+    dev = torch.device("cpu")
+    words = 64
+    blk = torch.full((BATCH, words), rank, dtype=torch.int32)
+    seen = set()
+
+    def step():
+        allrec = par.gather_records(blk, world, force=torch.distributed.is_initialized())
+        seen.update(int(v) for v in allrec[:, 0].unique())
+        return allrec
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    par.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        allrec = step()
+    par.barrier(dev)
+    local = time.perf_counter() - t0
+    elapsed = par.max_over_ranks(local, dev)
+    per_rank = par.all_gather_floats(local, dev)
+    ranks_seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    ok = sorted(seen) == list(range(world)) and tuple(allrec.shape) == (world * BATCH, words)
+    if rank == 0:
+        print(json.dumps({"metric": "STUB - launcher / gather skeleton only, not a measurement", "value": None,
+                          "unit": "images/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+                          "data": "stub", "config": {"workload": "stub step on CPU ranks (gloo)", "global_batch": BATCH * world},
+                          "records_from_ranks": sorted(seen), "gathered_block_ok": ok,
+                          "per_rank_s": [round(v, 6) for v in per_rank]}), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,10 +288,22 @@ def main():
                     help="fp32 = BASELINE.json configs[1] (the contract, default); bf16 = the configs[2] "
                          "arithmetic (bf16 operands, fp32 accumulate); bf16x3 = split bf16 operands, 3 MFMAs per "
                          "product (fp32-grade maps from the bf16 pipe) - both on the same workload, for reference")
+    # test infrastructure (tests/test_host_cpu.py): the launcher / barrier / timing / gather skeleton on CPU ranks
+    # over gloo with a stand-in for the GPU step.  Its line says so and is not a measurement.
+    ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    pkg = importlib.import_module(PKG)
     par = importlib.import_module(PKG + ".parallel")
+    if args.gpus > 1 and not par.launched_by_torchrun():
+        # started plain: run the N ranks ourselves (the driver's own launch line), relay their output
+        raise SystemExit(par.relaunch_under_torchrun(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    if par.env_world()[2] != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d - refusing to label a %d-rank run as %d GPUs"
+                         % (args.gpus, par.env_world()[2], par.env_world()[2], args.gpus))
+    if args.stub_step:
+        return stub_main(args, par)
+
+    pkg = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
     dec = importlib.import_module(PKG + ".decode")
     pipeline = importlib.import_module(PKG + ".pipeline")
@@ -255,8 +312,6 @@ def main():
     # (under torchrun even a world of one joins an RCCL process group and gathers through it)
     rank, local_rank, world = par.init_from_env("nccl", always=True)
     collective = torch.distributed.is_initialized()
-    if world != args.gpus:
-        log("warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path for the product)")
     dev = torch.device("cuda", local_rank)
@@ -296,6 +351,18 @@ def main():
 
     plan = model.plan_for(x)
     nl = lib.rtpose_net_num_launches(plan.handle)
+    # arithmetic of the plan as rtpose_net_conv_numerics reports it (fp32: the guarded per-layer AUTO choice is the
+    # library default; the estimates are those of the filters loaded above)
+    numerics = None
+    if not bf16:
+        names = {0: "direct", 3: "F(2x2,3x3)", 43: "F(4x4,3x3)", 4: "F(4,7)", 6: "F(6,7)"}
+        forms, worst = {}, {}
+        for _, form, amp in model.conv_numerics(plan):
+            forms[names[form]] = forms.get(names[form], 0) + 1
+            for nm, a in zip(("F(2x2,3x3)", "F(4,7)", "F(6,7)", "F(4x4,3x3)"), amp):
+                worst[nm] = round(max(worst.get(nm, 0.0), a), 1)
+        numerics = {"mode": "library default: per-layer AUTO, the fastest form whose amplification estimate <= amp_limit",
+                    "amp_limit": 256.0, "convs_by_form": forms, "worst_amplification_estimate": worst}
 
     # ---- the timed region: EXACTLY --steps steps of the production configuration (no per-launch events, no
     # library queries), bracketed by barrier + synchronize on both sides -------------------------------------
@@ -306,8 +373,20 @@ def main():
         bufs, host = step()
     torch.cuda.synchronize()
     par.barrier(dev)
-    elapsed = time.perf_counter() - t0
-    elapsed = par.max_over_ranks(elapsed, dev)
+    elapsed_local = time.perf_counter() - t0
+    elapsed = par.max_over_ranks(elapsed_local, dev)
+    per_rank_s = par.all_gather_floats(elapsed_local, dev)
+    ranks_seen = torch.distributed.get_world_size() if collective else 1
+    gather_us = None
+    if collective:      # the exchange step on its own, after the timed region: all_gather of one step's record block
+        blk = bufs.result.view(bufs.n, bufs.words)
+        torch.cuda.synchronize()
+        par.barrier(dev)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            par.gather_records(blk, world, force=True)
+        torch.cuda.synchronize()
+        gather_us = par.max_over_ranks((time.perf_counter() - t0) / 20 * 1e6, dev)
 
     # ---- roofline leg, AFTER the timed region: the same step with per-launch HIP events recorded on the launch
     # stream (rtpose_net_set_profiling), for the average duration of the dominant kernel ------------------------
@@ -355,7 +434,7 @@ def main():
         wino7 = k7_wino == k7_n and k7_n > 0
         out = {
             "metric": "end-to-end persons-posed FPS at 368x368 (net+pafprocess)",
-            "value": round(fps, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "value": round(fps, 2), "unit": "images/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("rtpose VGG19 368x368 batch=32 synthetic images, single MI355X, %s "
@@ -369,8 +448,14 @@ def main():
                        "weights": "seeded He init (no checkpoint offline)",
                        "decoder_input": "synthetic scene + 1e-3 * net output (blend kernel timed)",
                        "humans_per_batch": humans_per_batch, "peaks_per_batch": peaks_per_batch,
+                       "conv_numerics": numerics,
                        "parallelism": ("image-sharded, all_gather of result records only" if world > 1 else
                                        "single GPU, RCCL all_gather of a world of one" if collective else "single GPU")},
+            "per_rank_images_per_s": {"min": round(BATCH * args.steps / max(per_rank_s), 2),
+                                      "max": round(BATCH * args.steps / min(per_rank_s), 2)},
+            "gather_us_per_step": None if gather_us is None else round(gather_us, 1),
+            "multi_gpu_note": ("N > 1 has never run on hardware from this code (1-GPU leases only): unmeasured"
+                               if world == 1 else "measured on %d ranks" % ranks_seen),
             "net_tflops_end_to_end": round(fps / world * GFLOP_PER_IMAGE / 1e3, 2),
             "net_ms_per_step_events": round(net_ms / prof_steps, 3),
             "roofline": {"bound": "mfma",

@@ -111,10 +111,12 @@ typedef struct rtpose_conv_desc {
                    written at channel out_cmap[n] of the pixel (absolute, lout.choff
                    ignored) - folds channel_shuffle / concat of the ShuffleNetV2
                    blocks (rtpose_shufflenetV2.py:56-62) into the store        */
-  int32_t wino_m; /* rtpose_conv2d_winograd*, k = 7 only: 6 = F(6,7), 4 = F(4,7), 0 = the
-                   library default (6; 4 with RTPOSE_WINOGRAD7_M=4 in the environment).
-                   `w_packed` must come from the packing of the same m.  Ignored by
-                   rtpose_conv2d and for k != 7.                              */
+  int32_t wino_m; /* rtpose_conv2d_winograd* only (rtpose_conv2d ignores it): the form of THIS launch.
+                   k = 3: 0 or 2 = F(2x2,3x3), 4 = F(4x4,3x3);  k = 7: 6 = F(6,7), 4 = F(4,7), 0 = the
+                   library default (6; 4 with RTPOSE_WINOGRAD7_M=4 in the environment).  `w_packed` must
+                   come from the packing of the same form.  Any other value is refused
+                   (RTPOSE_E_INVAL): ZERO-INITIALISE descriptors (memset / `= {0}`) - the struct has
+                   grown by trailing fields and may again.                                  */
 } rtpose_conv_desc;
 
 /* Launch one conv, or `ngroups` (<= 2) convs of identical geometry in one
@@ -169,7 +171,7 @@ int rtpose_conv2d_winograd(const rtpose_conv_desc* d, int ngroups, int N, int H,
                            void* stream);
 /* k = 3 with an explicit form m: 0 / 2 = F(2x2,3x3) (as above), 4 = F(4x4,3x3) (csrc/conv_wino4.hip): 36 instead of
  * 144 multiplies per 4 x 4 outputs and input channel (4x fewer than the direct sum), interpolation points
- * 0, +-3/4, +-3/2, inf; cin a multiple of 8, >= 32; transformed filters 36/9 the size.  Launch with
+ * 0, +-3/4, +-3/2, inf; cin a multiple of 16, >= 32; transformed filters 36/9 the size.  Launch with
  * rtpose_conv_desc.wino_m = 4 and this packing.  Results differ from the direct sum by rounding only
  * (element-wise error bound ~3x F(2x2,3x3)'s, tests/test_wino_numerics_gpu.py). */
 size_t rtpose_packed_weight_floats_winograd3(int cout, int cin, int m);
@@ -424,15 +426,19 @@ int rtpose_net_create_ex(int N, int H, int W, int dtype, rtpose_net** out);
  * products: results differ from the direct sum by rounding, bounds in DESIGN.md §3.0).  The weight
  * arena of fp32 plans holds every packing a plan may choose (direct, F(2x2,3x3), F(4,7), F(6,7)), so
  * plans with different options share one arena and the choice costs nothing at run time.
- *   winograd3: RTPOSE_WINO_DEFAULT (= F(4x4,3x3); the environment's RTPOSE_WINOGRAD=0|7 -> direct,
- *              RTPOSE_WINOGRAD3_M=2 -> F(2x2,3x3)), 0 = direct 3x3 kernels, 1 = F(2x2,3x3), 4 = F(4x4,3x3)
- *              (layers without an F(4x4,3x3) instance: F(2x2,3x3)), RTPOSE_WINO3_AUTO = per layer F(4x4,3x3) if its
- *              amplification estimate is <= amp_limit, else F(2x2,3x3); decided by rtpose_net_finalize_weights
- *   winograd7: RTPOSE_WINO_DEFAULT (= F(6,7); the environment's RTPOSE_WINOGRAD=0|3 -> direct,
- *              RTPOSE_WINOGRAD7_M=4 -> F(4,7)), 0 = direct, 4 = F(4,7), 6 = F(6,7), RTPOSE_WINO7_AUTO =
- *              per layer the fastest form whose amplification estimate (rtpose_winograd_amplification of
- *              the loaded filters) is <= amp_limit: F(6,7), else F(4,7), else direct; decided by
- *              rtpose_net_finalize_weights
+ *   winograd3: RTPOSE_WINO_DEFAULT (= RTPOSE_WINO3_AUTO since round 4; the environment's RTPOSE_WINOGRAD=0|7 ->
+ *              direct, RTPOSE_WINOGRAD3_M=2|4 -> F(2x2,3x3) | F(4x4,3x3) forced), 0 = direct 3x3 kernels,
+ *              1 = F(2x2,3x3), 4 = F(4x4,3x3) forced (layers without an F(4x4,3x3) instance: F(2x2,3x3)),
+ *              RTPOSE_WINO3_AUTO = per layer F(4x4,3x3) if its amplification estimate is <= amp_limit, else
+ *              F(2x2,3x3); decided by rtpose_net_finalize_weights
+ *   winograd7: RTPOSE_WINO_DEFAULT (= RTPOSE_WINO7_AUTO since round 4; the environment's RTPOSE_WINOGRAD=0|3 ->
+ *              direct, RTPOSE_WINOGRAD7_M=4|6 -> F(4,7) | F(6,7) forced), 0 = direct, 4 = F(4,7), 6 = F(6,7)
+ *              forced, RTPOSE_WINO7_AUTO = per layer the fastest form whose amplification estimate
+ *              (rtpose_winograd_amplification of the loaded filters) is <= amp_limit: F(6,7), else F(4,7),
+ *              else direct; decided by rtpose_net_finalize_weights
+ *   The default is the guarded one because the forms' error bounds scale with the estimate and nobody can
+ *   vouch for filters that have not been seen (pose_model.pth, README.md:19): i.i.d. Gaussian / He filters
+ *   estimate 115-120 in F(6,7) and 42-43 in F(4x4,3x3) and keep the fast forms; +-1 edge filters (273) do not.
  *   amp_limit: the AUTO modes only; <= 0 = the library default (256: twice what i.i.d. Gaussian
  *              filters give in F(6,7))
  * Fields are ignored by bf16 / bf16x3 plans.  A form that has no kernel instance at the plan's
@@ -467,7 +473,10 @@ int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw,
                          const float* bias, void* stream);
 /* After the last rtpose_net_load_conv: fixes the form of every conv of an RTPOSE_WINO7_AUTO / RTPOSE_WINO3_AUTO plan from
  * the amplification estimates of the filters just loaded (synchronises `stream` once to read them).
- * Optional for the other modes and called by the first forward if the host did not. */
+ * Optional for the other modes and called by the next forward if the host did not.  Plans that share one
+ * weight arena may be loaded through any one of them: every fp32 rtpose_net_load_conv advances the arena's
+ * generation, and each plan re-reads the estimates and re-decides its forms (here, in rtpose_net_forward* and
+ * in rtpose_net_conv_numerics) when the generation it decided at is no longer the arena's. */
 int rtpose_net_finalize_weights(rtpose_net* net, void* stream);
 /* Arithmetic of conv idx in this plan: *form = 0 direct, 3 = F(2x2,3x3), 43 = F(4x4,3x3), 4 = F(4,7), 6 = F(6,7);
  * amp[4] = amplification estimates of the loaded filters in F(2x2,3x3) / F(4,7) / F(6,7) / F(4x4,3x3) (0 where
@@ -482,7 +491,9 @@ int rtpose_net_graph_active(const rtpose_net* net);
 /* Enqueue the whole forward on `stream`: x is dense NCHW fp32 [N,3,H,W]. */
 int rtpose_net_forward(rtpose_net* net, const float* x_nchw, void* stream);
 /* The net's own NHWC8 input buffer, for producers that write it directly
- * (rtpose_preprocess_u8), and the forward that then skips the NCHW conversion. */
+ * (rtpose_preprocess_u8), and the forward that then skips the NCHW conversion.
+ * The view holds what the PRODUCER wrote: rtpose_net_forward of an fp32 plan reads the NCHW
+ * image directly (conv1_1, csrc/conv_first.hip) and does not refresh it. */
 int rtpose_net_input_view(const rtpose_net* net, float** base, rtpose_layout* layout);
 int rtpose_net_forward_prepared(rtpose_net* net, void* stream);
 /* Copy stage output `which` (0..11 = saved_for_loss order: out1_1, out1_2,

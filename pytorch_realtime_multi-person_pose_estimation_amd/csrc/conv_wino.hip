@@ -904,8 +904,17 @@ int conv2d_winograd_fits(int k, int cin, int cout, int pool, int N, int H, int W
 
 extern "C" {
 
+// rtpose_conv_desc.wino_m selects the form per launch: k = 3: 0 / 2 = F(2x2,3x3), 4 = F(4x4,3x3); k = 7: 0 = library
+// default, 4 / 6 = F(m,7).  Anything else is a descriptor that was not zero-initialised: refuse it instead of running a
+// kernel on the wrong packing.
+static bool wino_m_valid(const rtpose_conv_desc* d) {
+  const int m = d->wino_m;
+  return d->k == 3 ? (m == 0 || m == 2 || m == 4) : d->k == 7 ? (m == 0 || m == 4 || m == 6) : true;
+}
+
 int rtpose_conv2d_winograd_fits(const rtpose_conv_desc* d, int N, int H, int W) {
-  return d ? rtpose::conv2d_winograd_fits(d->k, d->cin, d->cout, d->pool, N, H, W, d->lin.hs, d->wino_m) : 0;
+  if (!d || !wino_m_valid(d)) return 0;
+  return rtpose::conv2d_winograd_fits(d->k, d->cin, d->cout, d->pool, N, H, W, d->lin.hs, d->wino_m == 2 ? 0 : d->wino_m);
 }
 
 size_t rtpose_packed_weight_floats_winograd7(int cout, int cin, int m) {
@@ -958,6 +967,10 @@ size_t rtpose_conv2d_winograd_scratch_bytes(void) {
 
 int rtpose_conv2d_winograd_ex(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, void* scratch,
                               size_t scratch_bytes, void* stream) {
+  for (int g = 0; d && g < ngroups && g < 2; ++g)
+    if (!wino_m_valid(&d[g]) || d[g].wino_m != d[0].wino_m)
+      return rtpose::fail(RTPOSE_E_INVAL, "conv2d_winograd: rtpose_conv_desc.wino_m must be 0 / 2 / 4 for k = 3 and 0 / 4 / 6 "
+                                          "for k = 7, the same in every group (zero-initialise descriptors)");
   if (d && d[0].k == 7)
     return rtpose::conv2d_wino7_launch(d, ngroups, N, H, W, d[0].wino_m, scratch, scratch_bytes,
                                        rtpose::as_stream(stream));

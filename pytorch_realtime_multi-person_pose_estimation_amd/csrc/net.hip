@@ -17,7 +17,9 @@
 //    map has even height and width.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -112,11 +114,12 @@ struct rtpose_net {
   int N = 0, H = 0, W = 0;       // input
   int bf16 = 0;                  // 1: bf16 activations/weights, fp32 accumulate (BASELINE config 3)
   int split = 0;                 // bf16 plans only: 1 = "bf16x3" split operands (hi + lo bf16 per value)
-  int w3 = 4;                    // fp32 plans, 3x3 convs: 0 direct, 1 = F(2x2,3x3), 4 = F(4x4,3x3), RTPOSE_WINO3_AUTO = per layer by amp_limit
-  int w7 = 6;                    // fp32 plans: 0 direct, 4 / 6 = F(4,7) / F(6,7), RTPOSE_WINO7_AUTO = per layer by amp_limit
+  int w3 = RTPOSE_WINO3_AUTO;    // fp32 plans, 3x3 convs: 0 direct, 1 = F(2x2,3x3), 4 = F(4x4,3x3), RTPOSE_WINO3_AUTO = per layer by amp_limit (the default)
+  int w7 = RTPOSE_WINO7_AUTO;    // fp32 plans: 0 direct, 4 / 6 = F(4,7) / F(6,7), RTPOSE_WINO7_AUTO = per layer by amp_limit (the default)
   float amp_limit = 256.f;
   bool forms_final = false;      // forms chosen (AUTO: after the amplification estimates were read back)
   bool amps_read = false;
+  uint64_t seen_gen = ~0ull;     // generation of the weight arena the estimates / forms above were taken from
   int n_cu = 0;                  // CUs of the device the plan was created for (sizes the hand-over scratch)
   size_t scratch_off = 0, scratch_bytes = 0;  // persistent 7x7 launches: hand-over scratch inside the workspace
   int x0f_buf = -1;              // bf16 plans: fp32 NHWC8 staging buffer for rtpose_preprocess_u8
@@ -148,6 +151,26 @@ struct rtpose_net {
 };
 
 namespace {
+
+// Plans of one module share ONE weight arena, and any of them may be the one a reload is issued through
+// (rtpose_net_load_conv).  The forms of an AUTO plan depend on the filters, so every plan must notice a reload made
+// through a sibling: the arena's generation - a host-side counter keyed by the arena's base address, bumped by every
+// fp32 rtpose_net_load_conv - is compared with the one the plan's estimates were read at (rtpose_net.seen_gen) before
+// every forward / finalize / conv_numerics.  (An arena freed and another allocated at the same address just continues
+// the count; rtpose_net_bind forgets the plan's generation.)
+std::mutex g_arena_mu;
+std::unordered_map<const void*, uint64_t> g_arena_gen;
+
+uint64_t arena_generation(const void* wt) {
+  std::lock_guard<std::mutex> lk(g_arena_mu);
+  auto it = g_arena_gen.find(wt);
+  return it == g_arena_gen.end() ? 0 : it->second;
+}
+
+void arena_bump(const void* wt) {
+  std::lock_guard<std::mutex> lk(g_arena_mu);
+  ++g_arena_gen[wt];
+}
 
 constexpr int kCatC = 192;      // [out1 128 | PAF 38 | heat 19 | pad 7]
 constexpr int kCatPaf = 128, kCatHeat = 166;
@@ -238,7 +261,20 @@ int pick_form(const rtpose_net* n, const ConvW& c) {
   return fits(4) ? 4 : 0;
 }
 
-bool forms_need_amps(const rtpose_net* n) { return n->w7 == RTPOSE_WINO7_AUTO || n->w3 == RTPOSE_WINO3_AUTO; }
+bool forms_need_amps(const rtpose_net* n) {
+  return !n->bf16 && (n->w7 == RTPOSE_WINO7_AUTO || n->w3 == RTPOSE_WINO3_AUTO);
+}
+
+// the filters in the arena changed since this plan last looked (through this plan or a sibling): estimates and AUTO
+// forms are stale
+void sync_arena_generation(rtpose_net* n) {
+  if (n->bf16 || !n->bound) return;
+  const uint64_t g = arena_generation(n->wt);
+  if (g == n->seen_gen) return;
+  n->seen_gen = g;
+  n->amps_read = false;
+  if (forms_need_amps(n)) n->forms_final = false;
+}
 
 void pick_forms(rtpose_net* n) {
   for (ConvW& c : n->convs) c.form = pick_form(n, c);
@@ -376,10 +412,11 @@ void build_plan(rtpose_net* n) {
     T1[b] = add_buf(n, 128, 1, H3, W3);
     T2[b] = add_buf(n, 128, 1, H3, W3);
     T3[b] = add_buf(n, 128, 0, H3, W3);
-    T4[b] = add_buf(n, 512, 0, H3, W3);
+    // (fp32 plans run the trailing 1x1 pairs back to back, conv_tail.hip: their intermediates never reach HBM)
+    T4[b] = n->bf16 ? add_buf(n, 512, 0, H3, W3) : -1;
     for (int i = 0; i < 4; ++i) U[b][i] = add_buf(n, 128, 3, H3, W3);
     U[b][4] = add_buf(n, 128, 0, H3, W3);
-    U[b][5] = add_buf(n, 128, 0, H3, W3);
+    U[b][5] = n->bf16 ? add_buf(n, 128, 0, H3, W3) : -1;
   }
   for (int s = 0; s < 6; ++s) n->save_buf[s] = add_buf(n, 57, 0, H3, W3, true);  // always fp32
   if (!n->bf16) {
@@ -537,10 +574,20 @@ int rtpose_net_create_opts(int N, int H, int W, const rtpose_net_options* opt, r
     const int env = !e ? 1 : e[0] == '0' ? 0 : e[0] == '3' ? 3 : e[0] == '7' ? 7 : 1;
     // (RTPOSE_WINOGRAD3_M=2: F(2x2,3x3) instead of F(4x4,3x3))
     const char* e3 = getenv("RTPOSE_WINOGRAD3_M");
+    // Round 4: the default is the GUARDED choice - per layer, the fastest form whose amplification estimate for the
+    // filters actually loaded stays under amp_limit (256): nobody here has seen pose_model.pth (README.md:19), and a
+    // forced F(6,7) / F(4x4,3x3) would run whatever it holds.  He-init / N(0, 0.01) filters estimate 115-120 and
+    // 42-43, so the bench plan keeps its forms bit for bit; RTPOSE_WINOGRAD3_M / RTPOSE_WINOGRAD7_M force a form.
+    const char* e7 = getenv("RTPOSE_WINOGRAD7_M");
     n->w3 = opt->winograd3 != RTPOSE_WINO_DEFAULT ? opt->winograd3
-            : (env == 1 || env == 3)              ? ((e3 && e3[0] == '2') ? 1 : 4)
+            : (env == 1 || env == 3)              ? ((e3 && e3[0] == '2')   ? 1
+                                                     : (e3 && e3[0] == '4') ? 4
+                                                                            : RTPOSE_WINO3_AUTO)
                                                   : 0;
-    n->w7 = opt->winograd7 != RTPOSE_WINO_DEFAULT ? opt->winograd7 : ((env == 1 || env == 7) ? wino7_default_fm() : 0);
+    n->w7 = opt->winograd7 != RTPOSE_WINO_DEFAULT ? opt->winograd7
+            : (env == 1 || env == 7)              ? ((e7 && (e7[0] == '4' || e7[0] == '6')) ? wino7_default_fm()
+                                                                                           : RTPOSE_WINO7_AUTO)
+                                                  : 0;
     n->amp_limit = opt->amp_limit > 0.f ? opt->amp_limit : 256.f;
   }
   build_plan(n);
@@ -597,11 +644,18 @@ int rtpose_net_bind(rtpose_net* net, void* workspace, size_t workspace_bytes, vo
   }
   net->forwards = 0;
   net->amps_read = false;
+  net->seen_gen = ~0ull;
   if (forms_need_amps(net)) net->forms_final = false;
   net->ws = static_cast<float*>(workspace);
   net->wt = static_cast<float*>(weights);
   hipStream_t s = as_stream(stream);
   if (zero_workspace) RTPOSE_HIP_CHECK(hipMemsetAsync(workspace, 0, rtpose_net_workspace_bytes(net), s));
+  // the hand-over flags and the device error word of the persistent 7x7 launches must start at zero whatever the
+  // caller says about the rest of the workspace
+  else if (!net->bf16 && net->scratch_bytes)
+    RTPOSE_HIP_CHECK(hipMemsetAsync(net->ws + net->scratch_off, 0,
+                                    (size_t)((char*)(conv2d_wino7_scratch_err(net->ws + net->scratch_off, net->n_cu) + 1) -
+                                             (char*)(net->ws + net->scratch_off)), s));
   // channel map of the concat input: packed c -> source channel of cat([L1,L2,out1])
   int32_t map[kCatC];
   for (int c = 0; c < kCatC; ++c) {
@@ -639,7 +693,8 @@ int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw, const fl
     return pack_weights_bf16_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed,
                                     net->wt + c.w_off, net->wt + c.b_off, net->split, s);
   // every packing the arena holds for this conv (the plans that share the arena choose among them), and the
-  // amplification estimate of each Winograd form
+  // amplification estimate of each Winograd form; every plan on this arena re-reads them (sync_arena_generation)
+  arena_bump(net->wt);
   net->amps_read = false;
   if (forms_need_amps(net)) net->forms_final = false;
   int rc = pack_weights_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed, net->wt + c.w_off,
@@ -689,6 +744,7 @@ static int read_amps(rtpose_net* net, hipStream_t s) {
 
 int rtpose_net_finalize_weights(rtpose_net* net, void* stream) {
   if (!net || !net->bound) return fail(RTPOSE_E_STATE, "net_finalize_weights: net not bound");
+  sync_arena_generation(net);
   if (net->forms_final) return 0;
   const int rc = read_amps(net, as_stream(stream));
   if (rc) return rc;
@@ -704,7 +760,7 @@ int rtpose_net_finalize_weights(rtpose_net* net, void* stream) {
 int rtpose_net_conv_numerics(rtpose_net* net, int idx, int* form, float* amp, void* stream) {
   if (!net || !net->bound) return fail(RTPOSE_E_STATE, "net_conv_numerics: net not bound");
   if (idx < 0 || idx >= (int)net->convs.size()) return fail(RTPOSE_E_INVAL, "net_conv_numerics: bad index");
-  int rc = rtpose_net_finalize_weights(net, stream);
+  int rc = rtpose_net_finalize_weights(net, stream);  // (notices a reload made through a sibling plan)
   if (!rc && amp) rc = read_amps(net, as_stream(stream));
   if (rc) return rc;
   const ConvW& c = net->convs[idx];
@@ -825,7 +881,8 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
 static int net_forward_impl(rtpose_net* net, const float* x_nchw, void* stream) {
   if (!net || !net->bound) return fail(RTPOSE_E_STATE, "net_forward: net not bound");
   hipStream_t s = as_stream(stream);
-  if (!net->forms_final) {  // RTPOSE_WINO7_AUTO and the host did not call rtpose_net_finalize_weights
+  sync_arena_generation(net);
+  if (!net->forms_final) {  // AUTO forms, and the host did not call rtpose_net_finalize_weights since the last load
     const int rcf = rtpose_net_finalize_weights(net, stream);
     if (rcf) return rcf;
   }
@@ -916,7 +973,12 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
         if (!x_nchw) break;  // forward_prepared: the input buffer was written by the caller
         // fp32 plans: conv1_1 reads the NCHW image itself (conv_first.hip) when it runs in the same call; the
         // conversion remains for graph replay, whose captured launch list reads the plan's own input buffer
-        if (last > 1 && net->convs[net->ops[1].conv_idx[0]].first) break;
+        {
+          bool first_reads_image = false;  // is conv1_1 (looked up by its flag, not by position) part of this call?
+          for (size_t j = first + 1; j < last && !first_reads_image; ++j)
+            first_reads_image = net->ops[j].kind == OP_CONV && net->convs[net->ops[j].conv_idx[0]].first;
+          if (first_reads_image) break;
+        }
         rc = rtpose_nchw_to_layout(x_nchw, net->ws + b.off_floats, &b.lay, 3, 8, N, o.H, o.W, stream);
         break;
       }

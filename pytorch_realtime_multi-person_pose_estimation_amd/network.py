@@ -105,10 +105,11 @@ class RtposeVGG(NativeStateMixin, nn.Module):
 
     def set_winograd(self, winograd3=None, winograd7=None, amp_limit=None):
         """Arithmetic of the fp32 convs of plans created from now on (``rtpose_net_options``):
-        ``winograd3``: None = library default (F(4x4,3x3)), False / 0 = direct kernels, True / 1 / 2 = F(2x2,3x3),
-        4 = F(4x4,3x3), 'auto' = per layer F(4x4,3x3) if its amplification estimate is <= ``amp_limit``, else F(2x2,3x3);
-        ``winograd7``: None = default (F(6,7)), 0 = direct, 4 / 6 = F(4,7) / F(6,7), 'auto' = per layer the
-        fastest form whose amplification estimate for the loaded filters is <= ``amp_limit`` (default 256).
+        ``winograd3``: None = library default ('auto' since round 4), False / 0 = direct kernels, True / 1 / 2 =
+        F(2x2,3x3), 4 = F(4x4,3x3) forced, 'auto' = per layer F(4x4,3x3) if its amplification estimate is <=
+        ``amp_limit``, else F(2x2,3x3);
+        ``winograd7``: None = library default ('auto'), 0 = direct, 4 / 6 = F(4,7) / F(6,7) forced, 'auto' = per layer
+        the fastest form whose amplification estimate for the loaded filters is <= ``amp_limit`` (default 256).
         All forms read one weight arena; results of different forms differ by rounding only."""
         if winograd3 is None:
             w3 = _capi.WINO_DEFAULT

@@ -28,7 +28,7 @@ def launched_by_torchrun():
 def init_from_env(backend=None, always=False):
     """Join the process group the torchrun environment describes.  A single process needs none; with
     ``always`` a world of ONE launched by torchrun still creates it, so that the RCCL library load, the
-    device binding and the collective itself are exercised on a 1-GPU box (tests/test_rccl_gpu.py)."""
+    device binding and the collective itself are exercised on a 1-GPU box (tests/test_runtime_gpu.py)."""
     rank, local_rank, world = env_world()
     if (world > 1 or (always and launched_by_torchrun())) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -91,3 +91,37 @@ def batch_schedule(n_items, rank, world, batch):
         i0 = lo + b * batch
         out.append((i0, max(0, min(batch, hi - i0))))
     return out
+
+
+def all_gather_floats(value, device):
+    """[value of rank 0, ..., value of rank G-1] on every rank (per-rank timings of the bench line)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = torch.empty(dist.get_world_size(), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(out, t)
+    return [float(v) for v in out.cpu()]
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def relaunch_under_torchrun(script, argv, nproc, python=None):
+    """Run ``script argv`` as ``nproc`` ranks of ONE node - ``python -m torch.distributed.run --nnodes=1
+    --nproc-per-node nproc --master-addr 127.0.0.1 --master-port <free> script argv`` - with this process's
+    stdout / stderr, and return its exit code.  A tool asked for N > 1 GPUs calls this when it was started plain, so
+    that `--gpus N` can never silently measure one GPU (the reference's own multi-GPU mechanism, nn.DataParallel in
+    demo/picture_demo.py:47, needs no launcher either)."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC only on these hosts (RCCL needs it)
+    cmd = [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(nproc)),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script] + list(argv)
+    return subprocess.call(cmd, env=env)

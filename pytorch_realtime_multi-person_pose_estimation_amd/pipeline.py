@@ -15,6 +15,19 @@ from . import _capi, decode as dec
 from ._capi import lib, check, ptr, current_stream
 
 
+def _raise_on_device_error(model, plan):
+    """The persistent 7x7 launches hand split tiles from block to block through device flags with a bounded wait
+    (csrc/conv_wino7.hip); a wait that ran out leaves bit 0 in the plan's device error word and the maps of that launch
+    are invalid.  Checked where the host has just synchronised anyway (records fetched): never silently wrong."""
+    status = getattr(model, 'device_status', None)
+    if status is None or getattr(plan, 'dtype', 0) != _capi.DTYPE_F32:
+        return
+    word = status(plan)
+    if word:
+        raise _capi.RtposeError("device error word %d: a split-tile hand-over of a persistent 7x7 launch timed out "
+                                "(shared / CU-masked device?); the maps of this batch are invalid" % word)
+
+
 class PoseEstimator(object):
     def __init__(self, model, config=None, max_peaks_per_part=32, max_humans=64):
         self.model = model
@@ -54,6 +67,7 @@ class PoseEstimator(object):
             bufs = self._buffers(n, x.device)
             dec.decode_enqueue(hbase, lheat, pbase, lpaf, n, h, w, bufs)
         bufs.map_hw = (h, w)
+        bufs.plan = plan
         return bufs
 
     def __call__(self, x, scene=None, scene_alpha=1e-3):
@@ -61,6 +75,7 @@ class PoseEstimator(object):
         while True:
             bufs = self.enqueue(x, scene, scene_alpha)
             recs = dec.fetch(bufs)
+            _raise_on_device_error(self.model, bufs.plan)
             flags = int(np.bitwise_or.reduce(recs[:, dec.RES_HEADER + 2]))
             if flags & dec.OVERFLOW_PEAKS and self.max_peaks_per_part < dec.MAX_PEAKS_LIMIT:
                 self.max_peaks_per_part = min(2 * self.max_peaks_per_part, dec.MAX_PEAKS_LIMIT)
@@ -153,6 +168,7 @@ class StreamingPoseEstimator(object):
         while True:
             dec.decode_enqueue(hbase, lheat, pbase, lpaf, self.B, h, w, self.bufs)
             recs = dec.fetch(self.bufs).copy()                 # D2H of the records + stream sync
+            _raise_on_device_error(m, plan)
             flags = int(np.bitwise_or.reduce(recs[:, dec.RES_HEADER + 2]))
             if not flags:
                 return recs

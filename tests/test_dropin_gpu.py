@@ -437,3 +437,107 @@ def test_batched_eval_driver_equals_serial_run_eval(compat, cuda, tmp_path):
             got = [o for o in out_t if o["image_id"] == iid]
             assert len(got) == len(exp)
     assert 0.0 <= ap_t <= 1.0
+
+
+def _smooth_image(seed, h0, w0):
+    rng = np.random.default_rng(seed)
+    low = rng.integers(0, 256, (h0 // 8 + 2, w0 // 8 + 2, 3))
+    big = np.kron(low, np.ones((8, 8, 1)))[:h0, :w0]
+    return np.clip(big + rng.integers(-10, 11, big.shape), 0, 255).astype(np.uint8)
+
+
+def test_reduced_precision_tta_composition_against_the_oracle(compat, cuda):
+    """BASELINE configs[2] AS CONFIGURED - bf16 x 4 scales x flip - against the CPU side: the composition of
+    evaluate/coco_eval.py:197-242 (handle_paf_and_heat) over lib/network/rtpose_vgg.py:158-198, i.e.
+    oracle/tta_oracle.py:multiscale driven by oracle/net_oracle.py:forward_bf16_emulated (and
+    forward_bf16x3_emulated for the bf16x3 plan), image prep by the pinned host restatements.  The batched
+    GPU-resident path (get_multiscale_outputs_batch: uint8 upload, one prep launch per scale, 2B-image plans, fused
+    flip-merge + resize + average) must sit inside the contract of the arithmetic it runs in: bf16 3e-2 of the map's
+    max and rms 6e-3 (tests/test_bf16_gpu.py), bf16x3 1e-3 absolute (the fp32 contract).  IMAGE_SIZE is 128 here so
+    that the float64 emulation of 8 forwards per image finishes in seconds on the host."""
+    from lib.network.rtpose_vgg import get_model
+    from oracle import net_oracle, tta_oracle
+    pre = importlib.import_module(PKG_NAME + ".preprocess")
+    decm = importlib.import_module(PKG_NAME + ".decode")
+    model = get_model('vgg19')
+    sd = net_oracle.he_init_state_dict(model, seed=0)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    cfg = decm.default_config()
+    cfg.DATASET.IMAGE_SIZE = 128
+    scales = (0.5, 1.0, 1.5, 2.0)
+    imgs = [_smooth_image(71, 100, 120), _smooth_image(72, 100, 120)]
+    report = {}
+    for dt, emu in (('bf16', net_oracle.forward_bf16_emulated), ('bf16x3', net_oracle.forward_bf16x3_emulated)):
+        def forward(x, emu=emu):
+            (paf, heat), _ = emu(sd, torch.from_numpy(np.ascontiguousarray(x, np.float32)))
+            return paf[0].permute(1, 2, 0).contiguous().numpy(), heat[0].permute(1, 2, 0).contiguous().numpy()
+        model.set_compute_dtype(dt)
+        try:
+            with torch.no_grad():
+                paf_b, heat_b, s_b = pre.get_multiscale_outputs_batch(imgs, model, 'rtpose', scales=scales, flip=True,
+                                                                      config=cfg)
+        finally:
+            model.set_compute_dtype('fp32')
+        paf_b, heat_b = paf_b.cpu().numpy(), heat_b.cpu().numpy()
+        for i, img in enumerate(imgs):
+            paf_o, heat_o, s1 = tta_oracle.multiscale(img, forward, 'rtpose', scales, True, base=128)
+            assert s1 == s_b and paf_o.shape == paf_b[i].shape and heat_o.shape == heat_b[i].shape
+            for nm, got, want in (("paf", paf_b[i], paf_o), ("heat", heat_b[i], heat_o)):
+                err = np.abs(got - want)
+                mx = max(1.0, float(np.abs(want).max()))
+                rms = float(np.sqrt((err.astype(np.float64) ** 2).mean()))
+                report["%s/img%d/%s" % (dt, i, nm)] = [float(err.max()), rms, mx]
+                if dt == 'bf16':
+                    assert err.max() <= 3e-2 * mx and rms <= 6e-3 * mx, (dt, i, nm, err.max(), rms, mx)
+                else:
+                    assert err.max() <= 1e-3, (dt, i, nm, err.max())
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        import json
+        with open(os.path.join(ROOT, "gpurun_out", "tta_reduced_precision_vs_oracle.json"), "w") as f:
+            json.dump({"unit": "[max|err|, rms err, max(1, max|oracle|)] of the merged maps, GPU vs CPU emulation",
+                       "scales": scales, "flip": True, "IMAGE_SIZE": 128, "cases": report}, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def test_reduced_precision_tta_keypoints_against_fp32_tta(compat, cuda):
+    """configs[2] fallback metric (no COCO, no pose_model.pth): keypoints decoded from the merged TTA maps
+    (4 scales x flip, synthetic scenes blended over them) in bf16 >= 98 % identical to the fp32 TTA's within 1 px with
+    the same people; bf16x3: identical."""
+    from lib.network.rtpose_vgg import get_model
+    from oracle import net_oracle
+    pre = importlib.import_module(PKG_NAME + ".preprocess")
+    decm = importlib.import_module(PKG_NAME + ".decode")
+    synth = importlib.import_module(PKG_NAME + ".synth")
+    model = get_model('vgg19')
+    model.load_state_dict(net_oracle.he_init_state_dict(model, seed=0))
+    model = model.cuda().eval()
+    cfg = decm.default_config()
+    cfg.DATASET.IMAGE_SIZE = 184
+    n, h0, w0 = 4, 184, 232
+    imgs = [_smooth_image(80 + i, h0, w0) for i in range(n)]
+    heat_s, paf_s, _ = synth.make_batch(n, h0, w0, seed=5, max_people=3)
+    heat_s, paf_s = torch.from_numpy(heat_s).to(cuda), torch.from_numpy(paf_s).to(cuda)
+    res = {}
+    for dt in ('fp32', 'bf16', 'bf16x3'):
+        model.set_compute_dtype(dt)
+        try:
+            with torch.no_grad():
+                paf, heat, _ = pre.get_multiscale_outputs_batch(imgs, model, 'rtpose', flip=True, config=cfg)
+        finally:
+            model.set_compute_dtype('fp32')
+        assert tuple(heat.shape) == tuple(heat_s.shape)
+        # He-init outputs are O(4): alpha 2e-2 superimposes ~0.1 of network-made texture on the scene
+        res[dt] = decm.decode_maps((heat_s + 2e-2 * heat).contiguous(), (paf_s + 2e-2 * paf).contiguous(), cfg)
+    assert sum(len(r["parts"]) for r in res['fp32']) >= n
+    for dt, need in (('bf16', 0.98), ('bf16x3', 1.0)):
+        tot = same = 0
+        for a, b in zip(res['fp32'], res[dt]):
+            assert a["peaks"].shape == b["peaks"].shape, "%s: %d vs %d peaks" % (dt, len(a["peaks"]), len(b["peaks"]))
+            assert np.array_equal(a["parts"], b["parts"]), "%s: person / part assignment differs" % dt
+            d = np.abs(a["peaks"][:, 0:2] - b["peaks"][:, 0:2]).max(axis=1)
+            tot += len(d)
+            same += int((d <= (1.0 if dt == 'bf16' else 0.0)).sum())
+        assert tot > 0 and same >= need * tot, "%s: only %d of %d keypoints agree" % (dt, same, tot)

@@ -168,6 +168,34 @@ def test_two_rank_shard_and_gather_gloo(tmp_path):
     assert p.returncode == 0 and "GATHER_OK" in p.stdout, p.stdout[-3000:]
 
 
+def test_bench_started_plain_with_gpus_2_runs_two_ranks_and_says_so():
+    """north_star: throughput "reported at 1, 2, 4 and 8 GPUs".  `python bench.py --gpus 2` started WITHOUT a launcher
+    re-executes itself through torch.distributed.run with two ranks (the driver's own launch line) and relays rank 0's
+    ONE line; `ranks_seen` is the size of the process group the timed region ran in.  The GPU step is replaced by
+    bench.py's stub (--stub-step: gloo on CPU ranks), everything else - relaunch, barrier, max-over-ranks timing, one
+    all_gather of the record block per step - is the production skeleton.  A WORLD_SIZE that disagrees with --gpus is
+    an error, not a mislabelled measurement."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    bench = os.path.join(ROOT, "bench.py")
+    p = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub-step"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 3 and out["data"] == "stub"
+    assert out["records_from_ranks"] == [0, 1] and out["gathered_block_ok"] and len(out["per_rank_s"]) == 2
+    assert out["value"] is None                                   # a stub line can never pass for a measurement
+    # a launcher world that is not --gpus: refused
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29411")
+    p = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--stub-step"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, env=env2)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr and not p.stdout.strip()
+
+
 def test_resize_linear_restatement_close_to_float_bilinear(pkg):
     """cv2.resize INTER_LINEAR (uint8, fixed point) restatement: identity at scale 1, within
     1 LSB of a float half-pixel bilinear elsewhere, and the ski.jpg geometry of SURVEY §3.1."""

@@ -331,6 +331,115 @@ def test_form_is_chosen_per_plan_through_the_abi(model_and_sd, cuda):
     assert (outs["default"][0] - outs["direct"][0]).abs().max().item() <= 2e-4   # ... and only by rounding
 
 
+def _edge_filter_state_dict(sd, prefix):
+    """`sd` with the 7x7 filters of conv `prefix` replaced by +-1 edge detectors (+c in column 0, -c in column 6 of
+    every (output, input channel, row)): F(6,7) amplification estimate 273 > the default amp_limit 256, F(4,7) 156."""
+    out = {k: v.clone() for k, v in sd.items()}
+    w = out[prefix + ".weight"]
+    c = (2.0 / (w.shape[1] * 14)) ** 0.5        # He scale for the 14 non-zero taps per input channel
+    e = torch.zeros_like(w)
+    e[:, :, :, 0] = c
+    e[:, :, :, 6] = -c
+    out[prefix + ".weight"] = e
+    return out
+
+
+def test_default_is_the_guarded_choice_and_one_hostile_layer_drops_alone(pkg, model_and_sd, cuda):
+    """The library default of an fp32 plan (nothing set: what a user who loads pose_model.pth gets, README.md:19 /
+    lib/network/rtpose_vgg.py:108-127) is the per-layer AUTO choice under amp_limit 256: with He filters every 7x7
+    conv runs F(6,7) and every eligible 3x3 conv F(4x4,3x3) - bit for bit the forced plan - and with the filters of
+    ONE 7x7 conv replaced by +-1 edge detectors (estimate 273) that conv's launch alone (both branches of the grouped
+    grid) drops to F(4,7), the outputs staying inside the contract."""
+    from oracle import net_oracle
+    _, sd = model_and_sd
+    x = torch.rand(2, 3, 64, 72, generator=torch.Generator().manual_seed(14)) - 0.5
+    xd = x.to(cuda)
+    m = pkg.get_model('vgg19')
+    m.load_state_dict(sd)
+    m = m.cuda().float().eval()
+    with torch.no_grad():
+        (p0, h0), _ = m(xd)
+    plan = m.plan_for(xd)
+    num = {nm: (form, amp) for nm, form, amp in m.conv_numerics(plan)}
+    k7 = [nm for nm, mod in m._convs() if mod.kernel_size[0] == 7]
+    k3 = [nm for nm, mod in m._convs() if mod.kernel_size[0] == 3 and mod.in_channels >= 32]
+    assert all(num[nm][0] == 6 and num[nm][1][2] <= 256.0 for nm in k7)
+    assert all(num[nm][0] == 43 and num[nm][1][3] <= 256.0 for nm in k3)
+    m.set_winograd(winograd3=4, winograd7=6)                   # the forced forms of round 3
+    try:
+        with torch.no_grad():
+            (p1, h1), _ = m(xd)
+    finally:
+        m.set_winograd()
+    assert torch.equal(p0, p1) and torch.equal(h0, h1)
+
+    sd_e = _edge_filter_state_dict(sd, "model3_1.4")
+    m.load_state_dict(sd_e)
+    (paf_r, heat_r), saved_r = net_oracle.forward(sd_e, x)
+    with torch.no_grad():
+        (p2, h2), saved = m(xd)
+    num = {nm: (form, amp) for nm, form, amp in m.conv_numerics(plan)}
+    assert 257.0 < num["model3_1.4"][1][2] < 290.0 and 140.0 < num["model3_1.4"][1][1] < 170.0, num["model3_1.4"]
+    dropped = sorted(nm for nm in k7 if num[nm][0] != 6)
+    assert dropped == ["model3_1.4", "model3_2.4"], dropped     # the grouped launch of the two branches, nothing else
+    assert num["model3_1.4"][0] == 4 and num["model3_2.4"][0] == 4
+    assert all(num[nm][0] == 43 for nm in k3)
+    for a, b in zip(saved, saved_r):
+        assert (a.cpu() - b).abs().max().item() <= 1e-3 * max(1.0, b.abs().max().item())
+    assert m.device_status(plan) == 0
+
+
+def test_auto_forms_follow_a_reload_made_through_a_sibling_plan(pkg, model_and_sd, cuda):
+    """Plans of one module share ONE weight arena and the host re-packs through whichever plan sees the new
+    parameters first.  Every other AUTO plan must re-decide its forms from the NEW filters' estimates (round-3 advisor
+    finding: it kept the old ones): reload through plan A, then ask plan B - untouched since - for its numerics."""
+    _, sd = model_and_sd
+    m = pkg.get_model('vgg19')
+    m.load_state_dict(sd)
+    m = m.cuda().float().eval()
+    xa = (torch.rand(1, 3, 64, 72, generator=torch.Generator().manual_seed(1)) - 0.5).to(cuda)
+    xb = (torch.rand(2, 3, 64, 72, generator=torch.Generator().manual_seed(2)) - 0.5).to(cuda)
+    with torch.no_grad():
+        m(xa)
+        (pb0, _), _ = m(xb)
+    plan_a, plan_b = m.plan_for(xa), m.plan_for(xb)
+    assert plan_a is not plan_b and plan_a.workspace.data_ptr() != plan_b.workspace.data_ptr()
+    form_b = {nm: f for nm, f, _ in m.conv_numerics(plan_b)}
+    assert form_b["model3_1.4"] == 6
+    m.load_state_dict(_edge_filter_state_dict(sd, "model3_1.4"))
+    with torch.no_grad():
+        m(xa)                                                   # the re-pack goes through plan A
+    num_b = {nm: (f, a) for nm, f, a in m.conv_numerics(plan_b)}   # straight to the C ABI on plan B's handle
+    assert num_b["model3_1.4"][1][2] > 256.0, "plan B still reports the old filters' estimate"
+    assert num_b["model3_1.4"][0] == 4 and num_b["model3_2.4"][0] == 4, "plan B kept forms chosen from the OLD filters"
+    # and both plans run the same arithmetic for the same image
+    with torch.no_grad():
+        (pa, _), _ = m(xb[:1].contiguous())
+        (pb, _), _ = m(xb)
+    assert torch.equal(pa[0], pb[0]) and not torch.equal(pb, pb0)
+    # back again through plan B this time; plan A follows
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        (pb1, _), _ = m(xb)
+    assert torch.equal(pb1, pb0)
+    assert {nm: f for nm, f, _ in m.conv_numerics(plan_a)}["model3_1.4"] == 6
+
+
+def test_unknown_descriptor_form_is_refused(capi, cuda):
+    """rtpose_conv_desc.wino_m of a descriptor that was not zero-initialised: refused, not run on the wrong packing."""
+    lib = capi.lib
+    d = (capi.ConvDesc * 1)()
+    d[0].cin, d[0].cout, d[0].k = 32, 64, 3
+    for bad in (1, 3, 6, 7, -1):
+        d[0].wino_m = bad
+        assert lib.rtpose_conv2d_winograd_fits(d, 1, 16, 16) == 0
+        assert lib.rtpose_conv2d_winograd(d, 1, 1, 16, 16, capi.current_stream()) != 0
+        assert "wino_m" in capi.last_error()
+    d[0].k = 7
+    d[0].wino_m = 5
+    assert lib.rtpose_conv2d_winograd_fits(d, 1, 16, 16) == 0
+
+
 def test_options_struct_is_validated(capi):
     lib = capi.lib
     h = C.c_void_p()
@@ -360,19 +469,27 @@ def _check_stages(m, sd, x, cuda, what):
     return worst, max(b.abs().max().item() for b in saved_r)
 
 
-def test_network_on_unnormalised_inputs_large_activations_and_positive_biases(pkg, cuda):
+@pytest.mark.parametrize("shape", [(2, 64, 72), (16, 368, 368)])
+def test_network_on_unnormalised_inputs_large_activations_and_positive_biases(pkg, cuda, shape):
     """All 12 stage outputs within 1e-3 * max(1, max|ref|) of the oracle when (a) the input is raw pixel values
     (x = rand * 255, nobody subtracted 0.5), (b) the first layer is scaled so that late activations reach ~1e3,
     (c) every bias is +0.25: the post-ReLU activations of every layer are then non-negative with a mean well above
-    their spread - the regime where transform-domain cancellation costs the Winograd forms most."""
+    their spread - the regime where transform-domain cancellation costs the Winograd forms most.
+    At 2 x 64 x 72 the maps are 8 x 9 (small-grid kernels); at 16 x 368 x 368 the launches are the ones that carry the
+    bench: the 46-wide wino7_f32<1,8,6,2> instance (16 x 12 strips x 2 branches = 384 tiles, persistent with split
+    tiles) and persistent wino4_f32 rounds on every 3x3 layer."""
     from oracle import net_oracle
+    n, h, w = shape
     m = pkg.get_model('vgg19')
     sd = net_oracle.he_init_state_dict(m, seed=3)
     g = torch.Generator().manual_seed(8)
-    x = torch.rand(2, 3, 64, 72, generator=g)
+    x = torch.rand(n, 3, h, w, generator=g)
     m.load_state_dict(sd)
     m = m.cuda().float().eval()
     w0, mx0 = _check_stages(m, sd, x * 255.0, cuda, "x = rand * 255")
+    plan = m.plan_for(x.to(cuda))
+    forms = {f for _, f, _ in m.conv_numerics(plan)}
+    assert {6, 43} <= forms, forms                 # the guarded default still selects the fast forms here
     sd_b = {k: (v * 1000.0 if k.startswith("model0.0.") else v.clone()) for k, v in sd.items()}
     m.load_state_dict(sd_b)
     w1, mx1 = _check_stages(m, sd_b, x - 0.5, cuda, "first layer x 1000")
@@ -380,9 +497,10 @@ def test_network_on_unnormalised_inputs_large_activations_and_positive_biases(pk
     sd_c = {k: (torch.full_like(v, 0.25) if k.endswith(".bias") else v.clone()) for k, v in sd.items()}
     m.load_state_dict(sd_c)
     w2, mx2 = _check_stages(m, sd_c, x - 0.5, cuda, "all biases +0.25")
-    _note("hostile_network.json", {"unit": "worst |err| / max(1, max|ref|) over the 12 stage outputs",
-                                   "x = rand * 255": [w0, mx0], "first layer x 1000": [w1, mx1],
-                                   "all biases +0.25": [w2, mx2]})
+    assert m.device_status(plan) == 0
+    _note("hostile_network_%dx%dx%d.json" % shape,
+          {"unit": "worst |err| / max(1, max|ref|) over the 12 stage outputs", "x = rand * 255": [w0, mx0],
+           "first layer x 1000": [w1, mx1], "all biases +0.25": [w2, mx2]})
 
 
 def test_tier_b_fp32_end_to_end_keypoints_on_the_32_bench_images(pkg, model_and_sd, cuda):
@@ -465,12 +583,15 @@ def test_reads_past_the_tensor_are_clamped_by_the_buffer_descriptor(capi, cuda):
     """The raw buffer descriptors of the Winograd kernels carry the real extent of the tensor they address
     (wino_common.h: make_rsrc): memory past the end of the input / the packed filters is never interpreted.  The
     input and the filters are placed in front of a NaN-filled region; outputs stay finite and equal to the run
-    with a zero-filled neighbourhood."""
+    with a zero-filled neighbourhood.  F(4x4,3x3) - the plan default of 17 convs - is covered in all three launch
+    forms: the 16 x 16 small-grid kernel (wino4s_f32), one round of 32 x 64 tiles, and persistent blocks
+    (2 x 184 x 184 -> 133 m tiles x 2 column tiles = 266 tiles on 256 CUs)."""
     lib, Layout = capi.lib, capi.Layout
     stream = capi.current_stream()
     g = torch.Generator().manual_seed(3)
-    for k, form in ((3, 3), (7, 6), (7, 4)):
-        n, cin, cout, h, w = 1, 32, 128, 10, 13
+    for k, form, (n, cin, cout, h, w) in ((3, 3, (1, 32, 128, 10, 13)), (7, 6, (1, 32, 128, 10, 13)),
+                                          (7, 4, (1, 32, 128, 10, 13)), (3, 43, (1, 32, 128, 10, 13)),
+                                          (3, 43, (1, 32, 128, 200, 200)), (3, 43, (2, 32, 128, 184, 184))):
         pad = k // 2
         x = torch.randn(n, cin, h, w, generator=g).to(cuda)
         wts = (torch.randn(cout, cin, k, k, generator=g) * 0.05).to(cuda)
@@ -478,7 +599,8 @@ def test_reads_past_the_tensor_are_clamped_by_the_buffer_descriptor(capi, cuda):
         lin = Layout.padded(cin, h, w, pad)
         lout = Layout.padded(cout, h, w, 1)
         nin = lib.rtpose_layout_pixels(C.byref(lin), n, h, w) * cin
-        nw = (lib.rtpose_packed_weight_floats_winograd(cout, cin, 3) if k == 3
+        nw = (lib.rtpose_packed_weight_floats_winograd3(cout, cin, 4) if form == 43
+              else lib.rtpose_packed_weight_floats_winograd(cout, cin, 3) if k == 3
               else lib.rtpose_packed_weight_floats_winograd7(cout, cin, form))
         res = []
         for fill in (0.0, float("nan")):
@@ -488,7 +610,10 @@ def test_reads_past_the_tensor_are_clamped_by_the_buffer_descriptor(capi, cuda):
             wp.zero_()
             bp = torch.zeros(lib.rtpose_packed_bias_floats(cout), device=cuda)
             capi.check(lib.rtpose_nchw_to_layout(capi.ptr(x), capi.ptr(xin), C.byref(lin), cin, cin, n, h, w, stream))
-            if k == 3:
+            if form == 43:
+                capi.check(lib.rtpose_pack_conv_weights_winograd3(capi.ptr(wts), capi.ptr(b), cout, cin, 4, None, cin,
+                                                                  capi.ptr(wp), capi.ptr(bp), stream))
+            elif k == 3:
                 capi.check(lib.rtpose_pack_conv_weights_winograd(capi.ptr(wts), capi.ptr(b), cout, cin, 3, None, cin,
                                                                  capi.ptr(wp), capi.ptr(bp), stream))
             else:
@@ -499,11 +624,15 @@ def test_reads_past_the_tensor_are_clamped_by_the_buffer_descriptor(capi, cuda):
             d[0].inp, d[0].w_packed, d[0].bias_packed, d[0].out = xin.data_ptr(), wp.data_ptr(), bp.data_ptr(), obuf.data_ptr()
             d[0].lin, d[0].lout = lin, lout
             d[0].cin, d[0].cout, d[0].k, d[0].relu, d[0].pool = cin, cout, k, 0, 0
-            d[0].wino_m = form if k == 7 else 0
+            d[0].wino_m = form if k == 7 else 4 if form == 43 else 0
             capi.check(lib.rtpose_conv2d_winograd(d, 1, n, h, w, stream), "rtpose_conv2d_winograd")
             o = torch.empty(n, cout, h, w, device=cuda)
             capi.check(lib.rtpose_layout_to_nchw(capi.ptr(obuf), C.byref(lout), capi.ptr(o), cout, n, h, w, stream))
             torch.cuda.synchronize()
             res.append(o.cpu())
-        assert torch.isfinite(res[1]).all(), "k=%d form %d: a read past the tensor reached the outputs" % (k, form)
-        assert torch.equal(res[0], res[1])
+        what = "k=%d form %d at %dx%dx%d" % (k, form, n, h, w)
+        assert torch.isfinite(res[1]).all(), "%s: a read past the tensor reached the outputs" % what
+        assert torch.equal(res[0], res[1]), what
+        if form == 43:   # and it is the convolution: against torch's CPU conv2d
+            ref = F.conv2d(x.cpu(), wts.cpu(), b.cpu(), padding=1)
+            assert (res[1] - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), what

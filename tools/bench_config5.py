@@ -5,8 +5,9 @@ the entries are synthetic 368x368 uint8 BGR images), sharded contiguously across
 STRONG scaling: total work is fixed.
 
   python tools/bench_config5.py                      # 1 GPU
+  python tools/bench_config5.py --gpus 8             # re-executes itself through torch.distributed.run, 8 ranks
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-         --master-port 29511 tools/bench_config5.py
+         --master-port 29511 tools/bench_config5.py --gpus 8
 
 Every index entry is a distinct image: entry i's pixels are a hash of (i, pixel) evaluated on the device
 (generating 5000 images with numpy would time numpy), so every rank sees exactly the shard it owns
@@ -41,9 +42,14 @@ def main():
     ap.add_argument("--images", type=int, default=5000)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", choices=("fp32", "bf16", "bf16x3"), default="fp32")
+    ap.add_argument("--gpus", type=int, default=0, help="ranks (0 = whatever the launcher's WORLD_SIZE says, else 1)")
     args = ap.parse_args()
-    pkg = importlib.import_module(PKG)
     par = importlib.import_module(PKG + ".parallel")
+    if args.gpus > 1 and not par.launched_by_torchrun():
+        raise SystemExit(par.relaunch_under_torchrun(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    if args.gpus and par.env_world()[2] != args.gpus:
+        raise SystemExit("bench_config5.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, par.env_world()[2]))
+    pkg = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
     dec = importlib.import_module(PKG + ".decode")
     pre = importlib.import_module(PKG + ".preprocess")
@@ -103,6 +109,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "config 5: fixed 5000-image set, images/s (strong scaling)",
                           "value": round(args.images / elapsed, 2), "unit": "images/s", "n_gpus": world,
+                          "ranks_seen": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                           "images": args.images, "batch_per_rank": B, "batches_per_rank": len(sched),
                           "seconds": round(elapsed, 3), "dtype": args.dtype, "scaling": "strong",
                           "index": "%d distinct synthetic uint8 images (device hash of (entry, pixel)), contiguous "
