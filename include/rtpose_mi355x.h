@@ -255,6 +255,17 @@ int rtpose_pack_pw_weights(const float* w_oi, const float* bias, int cout, int c
                            float* w_packed, float* bias_packed, void* stream);
 int rtpose_pw_fused(const rtpose_pw_desc* d, int N, int H, int W, void* stream);
 
+/* ---- conv5 + both heads of the ShuffleNetV2 pose network as ONE back-to-back GEMM launch (csrc/pw_head.hip):
+ *   slim.conv_bn_relu('conv5', 464, 1024, 1) -> { self.paf = nn.Conv2d(1024, 38, 1), self.heatmap = nn.Conv2d(1024, 19, 1) }
+ * (lib/network/rtpose_shufflenetV2.py:104, :107-108, :143-147).  d1 = the wide conv (+ReLU): `in` / `lin` a contiguous
+ * slice of cin channels (a multiple of 16), w_packed [cin / 4][coutp][4] with cout = coutp a multiple of 256; d1->out is
+ * ignored - the intermediate never leaves the registers.  d2 = the heads: ONE shared matrix [coutp1 / 4][64][4] whose
+ * columns sit at their output channels (rtpose_pack_pw_weights with col_off; columns nobody owns must be zero), bias
+ * [64]; 64 channels are stored at d2->lout.choff (16 bytes per lane, no column map).  Both GEMMs run transposed so
+ * that the accumulators of the first are the B operand of the second (see the source).  fp32 in / accumulate / out. */
+int rtpose_pw_head_fits(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2);
+int rtpose_pw_head(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2, int N, int H, int W, void* stream);
+
 /* bf16 form (the bf16 plan of BASELINE configs[3]): bf16 activations and pointwise weights, fp32 accumulate
  * (v_mfma_f32_32x32x16_bf16), depthwise taps / biases fp32, outputs rounded to bf16 (round-to-nearest-even)
  * or written fp32 (out_f32 != 0: the two heads).  In the desc `in`, `out`, `pt_src` point at 2-byte elements

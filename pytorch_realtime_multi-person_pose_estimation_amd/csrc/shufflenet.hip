@@ -40,6 +40,9 @@ int pw_fused_launch(const rtpose_pw_desc* d, int N, int H, int W, hipStream_t s)
 int pack_pw_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map, int K,
                    int coutp, int col_off, float* wp, float* bp, hipStream_t s);
 int pw_halo_stride(const rtpose_layout& l, int H, int W);
+// conv5 + the two heads as one back-to-back launch (pw_head.hip)
+int pw_head_launch(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2, int N, int H, int W, hipStream_t s);
+int pw_zero_columns_launch(float* wp, float* bp, int K, int coutp, int c0, int c1, hipStream_t s);
 // ... and of the bf16 plan (pw_fused_bf16.hip)
 int pw_fused_bf16_launch(const rtpose_pw_desc* d, int out_f32, int N, int H, int W, hipStream_t s);
 int pack_pw_bf16_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map, int K,
@@ -90,6 +93,7 @@ struct SLayer {
                               // start at (the two heads share one 64-column matrix)
   int colmap_id = -1, ncols = 0;  // fused bf16 plans: packed column i is output channel maps[colmap_id][i]
                               // (-1: identity), ncols columns are packed / stored
+  int zero_c0 = 0, zero_c1 = 0;   // columns of a shared packed matrix that no layer writes and this layer's load zeroes
 };
 
 struct SBuf {
@@ -98,7 +102,7 @@ struct SBuf {
   int C = 0, H = 0, W = 0;
 };
 
-enum OKind { O_INPUT, O_STEM, O_POOL3, O_DW, O_PW, O_COPYMAP, O_PWF, O_STEMPOOL };
+enum OKind { O_INPUT, O_STEM, O_POOL3, O_DW, O_PW, O_COPYMAP, O_PWF, O_STEMPOOL, O_HEAD };
 
 struct SOp {
   OKind kind;
@@ -511,9 +515,42 @@ void build(rtpose_shufflenet* n) {
     const int l5 = add_layer(n, L_PW, "network.6", 1024, in_c, up8(2 * in_hp), M_in);
     const int lp = add_layer(n, L_PW, "paf", 38, 1024, 1024, -1);
     const int lh = add_layer(n, L_PW, "heatmap", 19, 1024, 1024, -1);
-    const int F = add_buf(n, 1024, 0, Hc, Wc);
+    // fp32 fused plans: conv5 and the heads are ONE launch (pw_head.hip) - the 1024-channel feature has no buffer
+    const bool one_launch = n->fused && !n->bf16;
+    const int F = one_launch ? -1 : add_buf(n, 1024, 0, Hc, Wc);
     const int OUT = add_buf(n, 64, 0, Hc, Wc, true);  // fp32 [PAF 0..37 | 2 pad | heat 40..58 | pad]
     n->out_buf = OUT;
+    if (one_launch) {
+      // the heads share a 64-column matrix whose columns sit AT their output channels (PAF 0..37, heat-map 40..58):
+      // the kernel stores 16 bytes per lane, no column map; the columns nobody owns are zeroed at load time
+      SLayer& P = n->layers[lp];
+      SLayer& Hh = n->layers[lh];
+      P.coutp = Hh.coutp = 64;
+      Hh.col_off = 40;
+      P.ncols = 38;
+      Hh.ncols = 19;
+      P.zero_c0 = 38;
+      P.zero_c1 = 40;
+      Hh.zero_c0 = 59;
+      Hh.zero_c1 = 64;
+      Hh.w_off = P.w_off = n->wt_floats;
+      n->wt_floats += round_up((size_t)(1024 + 32) * 64, 64);
+      Hh.b_off = P.b_off = n->wt_floats;
+      n->wt_floats += 64;
+      SOp o;
+      o.kind = O_HEAD;
+      o.name = "conv5+paf+heatmap";
+      o.H = Hc;
+      o.W = Wc;
+      o.layer[0] = l5;
+      o.layer[1] = lp;
+      o.in_buf[0] = in_buf;
+      o.out_buf[0] = OUT;
+      o.relu = 1;
+      o.flops = 2.0 * n->N * Hc * Wc * (1024.0 * in_c + 1024.0 * 57);
+      n->ops.push_back(o);
+      return;
+    }
     if (n->fused) {
       // the two heads as ONE 64-column GEMM: PAF in columns 0..37, heat-map in 38..56 of a shared packed
       // matrix (38 + 19 = 57 <= 64); the column -> channel map puts them at [0, 38) and [40, 59)
@@ -660,9 +697,12 @@ int rtpose_shufflenet_load(rtpose_shufflenet* n, int idx, const float* w, const 
         return pack_pw_bf16_launch(w, b, l.cout, l.cin, map, l.cin_packed, l.ncols, cmap, l.coutp, l.col_off,
                                    n->wt + l.w_off, n->wt + l.b_off, s);
       }
-      if (l.coutp)  // shares a packed matrix with another layer (the heads of a fused plan)
-        return pack_pw_launch(w, b, l.cout, l.cin, map, l.cin_packed, l.coutp, l.col_off, n->wt + l.w_off,
-                              n->wt + l.b_off, s);
+      if (l.coutp) {  // shares a packed matrix with another layer (the heads of a fused plan)
+        const int rc = pack_pw_launch(w, b, l.cout, l.cin, map, l.cin_packed, l.coutp, l.col_off, n->wt + l.w_off,
+                                      n->wt + l.b_off, s);
+        if (rc || l.zero_c1 <= l.zero_c0) return rc;
+        return pw_zero_columns_launch(n->wt + l.w_off, n->wt + l.b_off, l.cin_packed, l.coutp, l.zero_c0, l.zero_c1, s);
+      }
       if (n->bf16)
         return pack_weights_bf16_launch(w, b, l.cout, l.cin, 1, map, l.cin_packed, n->wt + l.w_off,
                                         n->wt + l.b_off, 0, s);
@@ -804,6 +844,29 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
         } else {
           rc = pw_fused_launch(&d, n->N, o.H, o.W, s);
         }
+        break;
+      }
+      case O_HEAD: {
+        const SLayer &l1 = n->layers[o.layer[0]], &l2 = n->layers[o.layer[1]];
+        const SBuf& bi = n->bufs[o.in_buf[0]];
+        const SBuf& bo = n->bufs[o.out_buf[0]];
+        rtpose_pw_desc d1, d2;
+        memset(&d1, 0, sizeof(d1));
+        memset(&d2, 0, sizeof(d2));
+        d1.in = n->ws + bi.off;
+        d1.lin = slice(bi, 0);
+        d1.w_packed = n->wt + l1.w_off;
+        d1.bias_packed = n->wt + l1.b_off;
+        d1.cin = l1.cin_packed;
+        d1.cout = d1.coutp = cout_pad(l1.cout);
+        d1.relu = 1;
+        d2.w_packed = n->wt + l2.w_off;
+        d2.bias_packed = n->wt + l2.b_off;
+        d2.cin = d1.coutp;
+        d2.cout = d2.coutp = 64;
+        d2.out = n->ws + bo.off;
+        d2.lout = slice(bo, 0);
+        rc = pw_head_launch(&d1, &d2, n->N, o.H, o.W, s);
         break;
       }
       case O_PW: {

@@ -299,6 +299,72 @@ def test_unit_bf16_four_run_layout(capi, cuda, h):
     assert ((got - ref).abs() > 1e-6).float().mean().item() < 0.05    # ... and almost everywhere identical
 
 
+@pytest.mark.parametrize("n,h,w,cin,c1", [(2, 46, 46, 464, 1024), (1, 9, 7, 32, 256), (3, 13, 11, 48, 512),
+                                          (1, 5, 5, 464, 1024)])
+def test_wide_conv_and_heads_in_one_launch(capi, cuda, n, h, w, cin, c1):
+    """rtpose_pw_head (csrc/pw_head.hip): conv5 (cin -> c1, ReLU) + the two heads (c1 -> 38 | 19) of
+    lib/network/rtpose_shufflenetV2.py:104-108, :143-147 as one launch against F.conv2d on the CPU - the K = 464 / 1024
+    shape of the network, a short-K shape whose last chunk is whole (32), one with a two-group last chunk (48), pixel
+    counts that are not a multiple of the 32-pixel work item, an input slice at a channel offset inside a wider
+    pixel, and more waves than work items."""
+    g = torch.Generator().manual_seed(n * 1000 + cin)
+    x = torch.randn(n, cin, h, w, generator=g)
+    w1 = torch.randn(c1, cin, generator=g) / cin ** 0.5
+    b1 = torch.randn(c1, generator=g) * 0.1
+    wp_, bp_ = torch.randn(38, c1, generator=g) / c1 ** 0.5, torch.randn(38, generator=g) * 0.1
+    wh_, bh_ = torch.randn(19, c1, generator=g) / c1 ** 0.5, torch.randn(19, generator=g) * 0.1
+    f = F.relu(F.conv2d(x, w1[:, :, None, None], b1))
+    ref_p, ref_h = F.conv2d(f, wp_[:, :, None, None], bp_), F.conv2d(f, wh_[:, :, None, None], bh_)
+    lib, stream = capi.lib, capi.current_stream()
+    choff = 8
+    lin = capi.Layout.padded(cin + 16, h, w, 1, choff)      # the conv's input is a slice of a wider pixel
+    xin = torch.full((lib.rtpose_layout_pixels(C.byref(lin), n, h, w) * lin.cstride,), float("nan"), device=cuda)
+    xin.view(-1, lin.cstride)[:, choff:choff + cin] = 0.0  # (gap pixels of the slice: zero; the rest of the pixel: NaN)
+    capi.check(lib.rtpose_nchw_to_layout(capi.ptr(x.to(cuda).contiguous()), capi.ptr(xin), C.byref(lin), cin, cin, n, h, w,
+                                         stream))
+    w1p = torch.zeros(lib.rtpose_packed_pw_floats(cin, c1) + 64 * c1, device=cuda)
+    b1p = torch.zeros(c1, device=cuda)
+    w2p = torch.full((lib.rtpose_packed_pw_floats(c1, 64) + 64 * 64,), float("nan"), device=cuda)
+    b2p = torch.full((64,), float("nan"), device=cuda)
+    dev = lambda t: t.contiguous().to(cuda)   # noqa: E731
+    keep = [dev(w1), dev(b1), dev(wp_), dev(bp_), dev(wh_), dev(bh_)]
+    capi.check(lib.rtpose_pack_pw_weights(capi.ptr(keep[0]), capi.ptr(keep[1]), c1, cin, None, cin, c1, 0,
+                                          capi.ptr(w1p), capi.ptr(b1p), stream))
+    w2p[:c1 * 64].zero_()      # columns nobody owns must be zero (the executor zeroes them at load time)
+    b2p.zero_()
+    capi.check(lib.rtpose_pack_pw_weights(capi.ptr(keep[2]), capi.ptr(keep[3]), 38, c1, None, c1, 64, 0,
+                                          capi.ptr(w2p), capi.ptr(b2p), stream))
+    capi.check(lib.rtpose_pack_pw_weights(capi.ptr(keep[4]), capi.ptr(keep[5]), 19, c1, None, c1, 64, 40,
+                                          capi.ptr(w2p), capi.ptr(b2p), stream))
+    lout = capi.Layout.dense(72, h, w, 4)
+    out = torch.full((lib.rtpose_layout_pixels(C.byref(lout), n, h, w) * 72,), 7.0, device=cuda)
+    d1, d2 = capi.PwDesc(), capi.PwDesc()
+    d1.inp, d1.w_packed, d1.bias_packed = xin.data_ptr(), w1p.data_ptr(), b1p.data_ptr()
+    d1.lin, d1.cin, d1.cout, d1.coutp, d1.relu = lin, cin, c1, c1, 1
+    d2.w_packed, d2.bias_packed, d2.out = w2p.data_ptr(), b2p.data_ptr(), out.data_ptr()
+    d2.lout, d2.cin, d2.cout, d2.coutp, d2.relu = lout, c1, 64, 64, 0
+    assert lib.rtpose_pw_head_fits(C.byref(d1), C.byref(d2)) == 1
+    capi.check(lib.rtpose_pw_head(C.byref(d1), C.byref(d2), n, h, w, stream), "rtpose_pw_head")
+    torch.cuda.synchronize()
+    px = out.view(-1, 72).cpu()
+    assert torch.equal(px[:, :4], torch.full_like(px[:, :4], 7.0)) and torch.equal(px[:, 68:], torch.full_like(px[:, 68:], 7.0))
+    got = px[:, 4:68].reshape(n, h, w, 64).permute(0, 3, 1, 2)
+    scale = max(1.0, ref_p.abs().max().item())
+    assert (got[:, 0:38] - ref_p).abs().max().item() <= TOL * scale
+    assert (got[:, 40:59] - ref_h).abs().max().item() <= TOL * scale
+    assert got[:, 38:40].abs().max().item() == 0.0 and got[:, 59:64].abs().max().item() == 0.0
+    # the same launch again: bit-identical (fixed summation order, no atomics)
+    out2 = torch.full_like(out, 7.0)
+    d2.out = out2.data_ptr()
+    capi.check(lib.rtpose_pw_head(C.byref(d1), C.byref(d2), n, h, w, stream), "rtpose_pw_head")
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    # shapes without an instance are refused, not mis-run
+    d1.cin = cin + 8
+    assert lib.rtpose_pw_head_fits(C.byref(d1), C.byref(d2)) == 0
+    assert lib.rtpose_pw_head(C.byref(d1), C.byref(d2), n, h, w, stream) != 0
+
+
 def test_bad_arguments_fail_loudly(capi, cuda):
     d = capi.PwDesc()
     assert capi.lib.rtpose_pw_fused(C.byref(d), 1, 8, 8, None) != 0
