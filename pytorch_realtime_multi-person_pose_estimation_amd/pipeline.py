@@ -110,7 +110,9 @@ class StreamingPoseEstimator(object):
     """
 
     def __init__(self, model, batch, h0, w0, preprocess='rtpose', config=None, max_peaks_per_part=32,
-                 max_humans=64):
+                 max_humans=64, scene=None, scene_alpha=1e-3):
+        """scene = (heat [B,h,w,19], paf [B,h,w,38]) device tensors, bench / tests only: the decoder then sees
+        scene + scene_alpha * maps, bench.py's decoder-input definition for a network without trained weights."""
         import torch
         from . import preprocess as pre
         self.model = model
@@ -130,6 +132,7 @@ class StreamingPoseEstimator(object):
         for e in self.consumed:
             e.record(torch.cuda.current_stream())
         self.max_peaks_per_part, self.max_humans = max_peaks_per_part, max_humans
+        self.scene, self.scene_alpha = scene, scene_alpha
         cfg = dec.make_cfg(self.config, max_peaks_per_part, max_humans)
         self.bufs = dec.DecodeBuffers(cfg, batch, self.dev)
         self._torch = torch
@@ -148,7 +151,9 @@ class StreamingPoseEstimator(object):
             self.devbuf[slot].copy_(self.host[slot], non_blocking=True)
             self.uploaded[slot].record(self.copy_stream)
 
-    def _compute(self, slot):
+    def _enqueue(self, slot):
+        """Everything of one batch on the compute stream, asynchronously: wait for its upload, image prep, forward,
+        (scene blend,) decode, D2H of the records into the pinned block.  Returns what _finish needs."""
         torch = self._torch
         m = self.model
         main = torch.cuda.current_stream()
@@ -165,10 +170,22 @@ class StreamingPoseEstimator(object):
         check(lib.rtpose_net_forward_prepared(plan.handle, s), "rtpose_net_forward_prepared")
         pbase, lpaf, _, h, w = m.output_view(plan, 0)
         hbase, lheat, _, _, _ = m.output_view(plan, 1)
+        if self.scene is not None:      # bench / tests only, see PoseEstimator.enqueue
+            sh, sp = self.scene
+            check(lib.rtpose_layout_axpby(hbase, C.byref(lheat), ptr(sh), 19, self.B, h, w, self.scene_alpha, 1.0, s))
+            check(lib.rtpose_layout_axpby(pbase, C.byref(lpaf), ptr(sp), 38, self.B, h, w, self.scene_alpha, 1.0, s))
+        dec.decode_enqueue(hbase, lheat, pbase, lpaf, self.B, h, w, self.bufs)
+        self.bufs.host.copy_(self.bufs.result, non_blocking=True)
+        return plan, (hbase, lheat, pbase, lpaf, h, w)
+
+    def _finish(self, state):
+        """Wait for the batch enqueued by _enqueue and return its records (a copy: the pinned block is reused)."""
+        torch = self._torch
+        plan, (hbase, lheat, pbase, lpaf, h, w) = state
         while True:
-            dec.decode_enqueue(hbase, lheat, pbase, lpaf, self.B, h, w, self.bufs)
-            recs = dec.fetch(self.bufs).copy()                 # D2H of the records + stream sync
-            _raise_on_device_error(m, plan)
+            torch.cuda.current_stream().synchronize()
+            recs = self.bufs.host.numpy().reshape(self.B, self.bufs.words).copy()
+            _raise_on_device_error(self.model, plan)
             flags = int(np.bitwise_or.reduce(recs[:, dec.RES_HEADER + 2]))
             if not flags:
                 return recs
@@ -183,13 +200,21 @@ class StreamingPoseEstimator(object):
                 raise _capi.RtposeError("decode tables overflowed at maximum capacity (flags=%d)" % flags)
             self.bufs = dec.DecodeBuffers(dec.make_cfg(self.config, self.max_peaks_per_part, self.max_humans),
                                           self.B, self.dev)
+            dec.decode_enqueue(hbase, lheat, pbase, lpaf, self.B, h, w, self.bufs)
+            self.bufs.host.copy_(self.bufs.result, non_blocking=True)
 
     def run(self, batches):
         """batches: iterable of uint8 arrays [B, h0, w0, 3] (BGR).  Yields one int32 record block
         [B, words] per batch (decode.parse_image(rec) / humans_from_record turn them into Humans).  The decode
         tables grow on overflow, so blocks of one run may differ in width; every record carries the capacities
         it was written with in its header (words 3, 4) and parse_image reads them from there - a consumer that
-        collects blocks first, or parses a step late, never needs this object's cfg of the moment."""
+        collects blocks first, or parses a step late, never needs this object's cfg of the moment.
+
+        Order per batch k (round 4): enqueue k's kernels and the D2H of its records (asynchronous), THEN copy batch
+        k + 1 from the caller's (pageable) array into pinned memory and start its H2D on the copy stream - both under
+        k's kernels - and only then wait for k's records.  Round 3 staged k + 1 BEFORE enqueueing k: the GPU idled
+        for the host copy (~3 ms of a 23 ms batch) and the host-to-host rate sat at 0.70-0.75 of the device-resident
+        one; now the GPU only waits for the host's ~1 ms of launch calls between two batches."""
         it = iter(batches)
         try:
             cur = next(it)
@@ -198,13 +223,14 @@ class StreamingPoseEstimator(object):
         slot = 0
         self._upload(slot, cur)
         while True:
+            state = self._enqueue(slot)
             try:
                 nxt = next(it)
             except StopIteration:
                 nxt = None
             if nxt is not None:
-                self._upload(slot ^ 1, nxt)     # next batch's H2D runs under this batch's kernels
-            yield self._compute(slot)
+                self._upload(slot ^ 1, nxt)     # host copy + H2D of the next batch under this batch's kernels
+            yield self._finish(state)
             if nxt is None:
                 return
             slot ^= 1

@@ -160,3 +160,62 @@ def seeded_shufflenet_state_dict(model, seed=0):
         else:
             sd[k] = torch.randn(v.shape, generator=g) * 0.1
     return sd
+
+
+# ---- counter-based hash shared with the torch-free C++ host (examples/c_host.cpp: hash_uniform) ---------------------
+def hash_uniform(stream, count):
+    """float64 [count]: element idx of stream `stream`, uniform in [0, 1) with 53 bits - splitmix64 of a counter,
+    the same bits as examples/c_host.cpp:hash_uniform produces."""
+    with np.errstate(over="ignore"):
+        z = (np.uint64(stream) * np.uint64(0x9E3779B97F4A7C15)
+             + np.arange(count, dtype=np.uint64) * np.uint64(0xD1B54A32D192ED03) + np.uint64(0x2545F4914F6CDD1D))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def hashed_state_dict(model):
+    """The stand-in for pose_model.pth that examples/c_host.cpp generates: conv i (state_dict order) takes stream 2 i
+    for its OIHW weights - uniform with the He variance 2 / fan_in - and stream 2 i + 1 for its bias (+-0.05)."""
+    import torch
+    sd = {}
+    keys = list(model.state_dict().keys())
+    convs = [k[:-len(".weight")] for k in keys if k.endswith(".weight")]
+    for i, prefix in enumerate(convs):
+        shape = tuple(model.state_dict()[prefix + ".weight"].shape)
+        fan_in = shape[1] * shape[2] * shape[3]
+        sc = np.sqrt(24.0 / fan_in)
+        w = ((hash_uniform(2 * i, int(np.prod(shape))) - 0.5) * sc).astype(np.float32).reshape(shape)
+        b = ((hash_uniform(2 * i + 1, shape[0]) - 0.5) * 0.1).astype(np.float32)
+        sd[prefix + ".weight"] = torch.from_numpy(w)
+        sd[prefix + ".bias"] = torch.from_numpy(b)
+    return {k: sd[k] for k in keys}
+
+
+def hashed_input(n, h=368, w=368):
+    """float32 [n, 3, h, w] in [-0.5, 0.5): stream 1000 of the hash (examples/c_host.cpp's input batch)."""
+    return (hash_uniform(1000, n * 3 * h * w) - 0.5).astype(np.float32).reshape(n, 3, h, w)
+
+
+def record_digest(recs):
+    """FNV-1a 64 over the words a result record DEFINES (header[0..4], part counts, the counted peaks of every part,
+    the first n_humans rows of human_parts and human_score) of int32 records [N, words] - examples/c_host.cpp prints
+    the same number."""
+    h = 0xCBF29CE484222325
+    recs = np.ascontiguousarray(recs, dtype=np.int32)
+
+    def feed(h, words):
+        for byte in np.ascontiguousarray(words, dtype=np.int32).tobytes():
+            h = ((h ^ byte) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+        return h
+    for r in recs:
+        pcap, hcap, nh = int(r[3]), int(r[4]), int(r[1])
+        h = feed(h, r[0:5])
+        h = feed(h, r[8:26])
+        for p in range(18):
+            h = feed(h, r[32 + 4 * p * pcap:32 + 4 * p * pcap + 4 * int(r[8 + p])])
+        off = 32 + 4 * 18 * pcap
+        h = feed(h, r[off:off + 18 * nh])
+        h = feed(h, r[off + 18 * hcap:off + 18 * hcap + nh])
+    return h

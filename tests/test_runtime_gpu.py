@@ -109,3 +109,55 @@ def test_c_host_runs_the_whole_path_without_python(cuda):
         assert m and float(m.group(1)) > 50.0, p.stdout[-2000:]
         assert "device status 0" in p.stdout, p.stdout[-2000:]
         print(p.stdout.strip().splitlines()[-1])
+
+
+def test_c_host_decodes_people_and_its_records_equal_the_python_paths(cuda, tmp_path):
+    """The C path of demo/picture_demo.py:57-61 (get_outputs -> paf_to_pose_cpp over lib/pafprocess/pafprocess.h:53-59)
+    exercised for CONTENT: examples/c_host generates hash-seeded He-scale weights and images, blends the scene this test
+    wrote over the maps and decodes; the Python path (get_model + PoseEstimator) on the same weights, images and
+    scene must give the same records - people > 0, equal digest, equal raw words wherever a record defines them."""
+    import importlib
+    import numpy as np
+    import torch
+    exe = os.path.join(ROOT, "examples", "c_host")
+    if not os.path.exists(exe):
+        pytest.skip("examples/c_host not built (python -c 'import __graft_entry__ as g; g.build()')")
+    sys.path.insert(0, ROOT)
+    pkg = importlib.import_module(PKG_NAME)
+    synth = importlib.import_module(PKG_NAME + ".synth")
+    pipeline = importlib.import_module(PKG_NAME + ".pipeline")
+    dec = importlib.import_module(PKG_NAME + ".decode")
+    n = 4
+    heat_s, paf_s, _ = synth.make_batch(n, 368, 368, seed=100)
+    scene, dump = tmp_path / "scene.bin", tmp_path / "records.bin"
+    with open(scene, "wb") as f:
+        f.write(np.ascontiguousarray(heat_s, np.float32).tobytes())
+        f.write(np.ascontiguousarray(paf_s, np.float32).tobytes())
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, PKG_NAME, "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    p = subprocess.run([exe, str(n), "0", "default", str(scene), str(dump)], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:]
+    m = re.search(r"(\d+) peaks, (\d+) humans, overflow flags (\d+)", p.stdout)
+    d = re.search(r"record digest ([0-9a-f]{16})", p.stdout)
+    assert m and d, p.stdout[-2000:]
+    peaks, humans, flags = (int(v) for v in m.groups())
+    assert peaks >= 18 * n // 2 and humans >= n and flags == 0, p.stdout[-2000:]
+    assert "device status 0" in p.stdout
+
+    model = pkg.get_model('vgg19')
+    model.load_state_dict(synth.hashed_state_dict(model))
+    model = model.cuda().float().eval()
+    est = pipeline.PoseEstimator(model, max_peaks_per_part=256, max_humans=256)
+    x = torch.from_numpy(synth.hashed_input(n)).to(cuda)
+    bufs = est.enqueue(x, (torch.from_numpy(heat_s).to(cuda), torch.from_numpy(paf_s).to(cuda)), 1e-3)
+    recs = dec.fetch(bufs).copy()
+    got = np.fromfile(dump, dtype=np.int32).reshape(n, -1)
+    assert got.shape == recs.shape
+    assert int(recs[:, 0].sum()) == peaks and int(recs[:, 1].sum()) == humans
+    assert "%016x" % synth.record_digest(recs) == d.group(1) == "%016x" % synth.record_digest(got)
+    for i in range(n):
+        a, b = dec.parse_image(recs[i]), dec.parse_image(got[i])
+        assert np.array_equal(a["peaks"], b["peaks"]) and np.array_equal(a["parts"], b["parts"])
+        assert np.array_equal(a["score"], b["score"]) and len(a["parts"]) >= 1
+    print(p.stdout.strip().splitlines()[-3])
