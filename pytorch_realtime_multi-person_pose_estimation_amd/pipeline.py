@@ -99,14 +99,16 @@ class PoseEstimator(object):
 
 
 class StreamingPoseEstimator(object):
-    """Host images in, host records out, with the PCIe legs overlapped with compute.
+    """Host images in, host records out, the host's share of a batch hidden under the previous batch's kernels.
 
     The reference moves one fp32 image per call (`get_outputs`, evaluate/coco_eval.py:96-110: H2D of
-    1.6 MB, D2H of 0.48 MB of maps).  Here a batch of uint8 BGR images (3 B/pixel) is uploaded on a
-    separate copy stream while the previous batch is still in the network; the compute stream does
+    1.6 MB, D2H of 0.48 MB of maps).  Here a batch of uint8 BGR images (3 B/pixel) is copied into pinned memory
+    and its H2D is queued while the previous batch is still in the network; the GPU then does
     resize + pad + normalise (rtpose_preprocess_u8) straight into the plan's input buffer, the
     forward and the decode; only the fixed-size result records come back.  Two pinned host / device
-    staging pairs ping-pong; events order the two streams (no host synchronisation inside a batch).
+    staging pairs ping-pong.  ONE stream (round 4): the 13 MB H2D of a 32-image batch takes 0.24 ms on the compute
+    stream - 1 % of an fp32 batch - while the same copy on a second stream took 8.9 ms (tools/exp/host_copy_probe.py,
+    profiles/r04_streaming_probe.txt).
     """
 
     def __init__(self, model, batch, h0, w0, preprocess='rtpose', config=None, max_peaks_per_part=32,
@@ -124,13 +126,9 @@ class StreamingPoseEstimator(object):
         self.hr, self.wr = pre._cv_round(h0 * self.im_scale), pre._cv_round(w0 * self.im_scale)
         self.hn, self.wn = pre._factor_closest(self.hr, factor), pre._factor_closest(self.wr, factor)
         self.dev = torch.device('cuda', torch.cuda.current_device())
-        self.copy_stream = torch.cuda.Stream(device=self.dev)
         self.host = [torch.empty((batch, h0, w0, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
         self.devbuf = [torch.empty((batch, h0, w0, 3), dtype=torch.uint8, device=self.dev) for _ in range(2)]
-        self.uploaded = [torch.cuda.Event() for _ in range(2)]
-        self.consumed = [torch.cuda.Event() for _ in range(2)]
-        for e in self.consumed:
-            e.record(torch.cuda.current_stream())
+        self.done = torch.cuda.Event()      # recorded behind the D2H of a batch's records
         self.max_peaks_per_part, self.max_humans = max_peaks_per_part, max_humans
         self.scene, self.scene_alpha = scene, scene_alpha
         cfg = dec.make_cfg(self.config, max_peaks_per_part, max_humans)
@@ -145,19 +143,19 @@ class StreamingPoseEstimator(object):
             raise _capi.RtposeError("StreamingPoseEstimator: every batch must be uint8 [%d, %d, %d, 3], got %s %s "
                                     "(pad a short final batch with copies and drop their records)"
                                     % (self.B, self.h0, self.w0, images.dtype, images.shape))
-        self.host[slot].copy_(torch.from_numpy(images))       # host -> pinned (the caller's array may be pageable)
-        with torch.cuda.stream(self.copy_stream):
-            self.copy_stream.wait_event(self.consumed[slot])   # the kernels that read this slot are done
-            self.devbuf[slot].copy_(self.host[slot], non_blocking=True)
-            self.uploaded[slot].record(self.copy_stream)
+        # host -> pinned (the caller's array may be pageable), then the H2D queued on the compute stream: behind the
+        # kernels of the batch in flight, in front of this batch's own.  Slot `slot` was last read two batches ago.
+        # (a plain memcpy, NOT torch's copy_: ATen splits a 13 MB CPU copy over every core, and the OpenMP workers that
+        #  then spin-wait starve the HIP runtime's own threads - every third batch stalled for 30-80 ms, measured with
+        #  tools/exp/stall_probe.py; np.copyto takes 0.2 ms on one core)
+        np.copyto(self.host[slot].numpy(), images)
+        self.devbuf[slot].copy_(self.host[slot], non_blocking=True)
 
     def _enqueue(self, slot):
         """Everything of one batch on the compute stream, asynchronously: wait for its upload, image prep, forward,
         (scene blend,) decode, D2H of the records into the pinned block.  Returns what _finish needs."""
         torch = self._torch
         m = self.model
-        main = torch.cuda.current_stream()
-        main.wait_event(self.uploaded[slot])
         plan = m.plan_for_shape(self.B, self.hn, self.wn, self.dev)
         s = current_stream()
         img_bytes = self.h0 * self.w0 * 3
@@ -165,7 +163,6 @@ class StreamingPoseEstimator(object):
         self._pre.preprocess_into_plan(plan, [base + b * img_bytes for b in range(self.B)],
                                        [(self.h0, self.w0)] * self.B, int(self.config.DATASET.IMAGE_SIZE),
                                        self.mode, s)                      # ONE launch for the whole batch
-        self.consumed[slot].record(main)
         check(lib.rtpose_net_set_keep_intermediates(plan.handle, 0))
         check(lib.rtpose_net_forward_prepared(plan.handle, s), "rtpose_net_forward_prepared")
         pbase, lpaf, _, h, w = m.output_view(plan, 0)
@@ -176,6 +173,7 @@ class StreamingPoseEstimator(object):
             check(lib.rtpose_layout_axpby(pbase, C.byref(lpaf), ptr(sp), 38, self.B, h, w, self.scene_alpha, 1.0, s))
         dec.decode_enqueue(hbase, lheat, pbase, lpaf, self.B, h, w, self.bufs)
         self.bufs.host.copy_(self.bufs.result, non_blocking=True)
+        self.done.record(torch.cuda.current_stream())
         return plan, (hbase, lheat, pbase, lpaf, h, w)
 
     def _finish(self, state):
@@ -183,7 +181,7 @@ class StreamingPoseEstimator(object):
         torch = self._torch
         plan, (hbase, lheat, pbase, lpaf, h, w) = state
         while True:
-            torch.cuda.current_stream().synchronize()
+            self.done.synchronize()     # the records of THIS batch (the next batch's H2D may still be queued)
             recs = self.bufs.host.numpy().reshape(self.B, self.bufs.words).copy()
             _raise_on_device_error(self.model, plan)
             flags = int(np.bitwise_or.reduce(recs[:, dec.RES_HEADER + 2]))
@@ -202,6 +200,7 @@ class StreamingPoseEstimator(object):
                                           self.B, self.dev)
             dec.decode_enqueue(hbase, lheat, pbase, lpaf, self.B, h, w, self.bufs)
             self.bufs.host.copy_(self.bufs.result, non_blocking=True)
+            self.done.record(torch.cuda.current_stream())
 
     def run(self, batches):
         """batches: iterable of uint8 arrays [B, h0, w0, 3] (BGR).  Yields one int32 record block
@@ -211,10 +210,9 @@ class StreamingPoseEstimator(object):
         collects blocks first, or parses a step late, never needs this object's cfg of the moment.
 
         Order per batch k (round 4): enqueue k's kernels and the D2H of its records (asynchronous), THEN copy batch
-        k + 1 from the caller's (pageable) array into pinned memory and start its H2D on the copy stream - both under
-        k's kernels - and only then wait for k's records.  Round 3 staged k + 1 BEFORE enqueueing k: the GPU idled
-        for the host copy (~3 ms of a 23 ms batch) and the host-to-host rate sat at 0.70-0.75 of the device-resident
-        one; now the GPU only waits for the host's ~1 ms of launch calls between two batches."""
+        k + 1 from the caller's (pageable) array into pinned memory and queue its H2D - under k's kernels - and only
+        then wait for k's records (an event behind their D2H).  Between two batches the GPU waits for the host's
+        ~0.5 ms of launch calls and the 0.24 ms H2D."""
         it = iter(batches)
         try:
             cur = next(it)

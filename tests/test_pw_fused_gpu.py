@@ -348,6 +348,8 @@ def test_wide_conv_and_heads_in_one_launch(capi, cuda, n, h, w, cin, c1):
     torch.cuda.synchronize()
     px = out.view(-1, 72).cpu()
     assert torch.equal(px[:, :4], torch.full_like(px[:, :4], 7.0)) and torch.equal(px[:, 68:], torch.full_like(px[:, 68:], 7.0))
+    assert torch.equal(px[n * h * w:], torch.full_like(px[n * h * w:], 7.0))      # nothing past the last pixel
+    px = px[:n * h * w]                                                           # (dense layout: pixel q = (n h + y) w + x)
     got = px[:, 4:68].reshape(n, h, w, 64).permute(0, 3, 1, 2)
     scale = max(1.0, ref_p.abs().max().item())
     assert (got[:, 0:38] - ref_p).abs().max().item() <= TOL * scale
