@@ -43,6 +43,12 @@ int pw_halo_stride(const rtpose_layout& l, int H, int W);
 // conv5 + the two heads as one back-to-back launch (pw_head.hip)
 int pw_head_launch(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2, int N, int H, int W, hipStream_t s);
 int pw_zero_columns_launch(float* wp, float* bp, int K, int coutp, int c0, int c1, hipStream_t s);
+// wave-autonomous transposed form of the fused chains (pw_t.hip) and the column-mapped fp32 packing it stores by
+int pw_t_fits(const rtpose_pw_desc* d);
+int pw_t_launch(const rtpose_pw_desc* d, int N, int H, int W, hipStream_t s);
+int pack_pw_cols_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map, int K,
+                        int ncols, const int32_t* col_map, int coutp, int col_off, float* wp, float* bp,
+                        hipStream_t s);
 // ... and of the bf16 plan (pw_fused_bf16.hip)
 int pw_fused_bf16_launch(const rtpose_pw_desc* d, int out_f32, int N, int H, int W, hipStream_t s);
 int pack_pw_bf16_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map, int K,
@@ -193,7 +199,8 @@ int add_layer(rtpose_shufflenet* n, LKind kind, const std::string& name, int cou
     case L_PW:
       wf = n->bf16 ? (n->fused ? (size_t)(cin_packed + 64) * cout_pad(cout > 0 ? cout : 1) / 2
                                : rtpose_packed_weight_bytes_bf16(cout, cin_packed, 1) / 4)
-                   : rtpose_packed_weight_floats(cout, cin_packed, 1);
+                   // (fp32 fused plans pack up to cout_pad(cout + 8) columns: a run layout's padded columns)
+                   : (size_t)(cin_packed + 32) * cout_pad(cout + 8);
       bf = rtpose_packed_bias_floats(cout);
       break;
   }
@@ -294,7 +301,8 @@ bool dw_fusable(const rtpose_shufflenet* n, int buf, int H, int W) {
 void build(rtpose_shufflenet* n) {
   // channel alignment of slices that feed a pointwise conv: 8 floats (fp32 kernel: cin % 8 == 0),
   // 16 elements for bf16 plans (one K = 16 MFMA step)
-  const int al = n->bf16 ? 16 : 8;
+  // (fp32 fused plans: 16 too - the wave-autonomous kernels of pw_t.hip / pw_head.hip walk K in pairs of 8-channel groups)
+  const int al = (n->bf16 || n->fused) ? 16 : 8;
   auto up8 = [al](int v) { return (v + al - 1) / al * al; };
   const int H0 = n->H, W0 = n->W;
   const int H1 = (H0 - 1) / 2 + 1, W1 = (W0 - 1) / 2 + 1;          // stem 3x3 s2 p1
@@ -361,21 +369,23 @@ void build(rtpose_shufflenet* n) {
     if (qt) {
       const int q = hp / 2, hh = h / 2;
       const int pg = n->bf16 ? 8 : 4;  // channels per 16-byte plane
-      std::vector<int32_t> x2(hp, -1), pln(hp / pg);
+      // (K is padded to a whole number of 16-channel steps: the extra planes repeat plane 0 under zero weights)
+      std::vector<int32_t> x2(up8(hp), -1), pln(up8(hp) / pg);
       for (int k = 0; k < hp; ++k) {
         const int p = k < q ? k : k - q;
         if (p < hh) x2[k] = 2 * p + (k < q ? 0 : 1);  // logical (h + 2p [+1]) - h
       }
-      for (int j = 0; j < hp / pg; ++j) pln[j] = pg * j < q ? q + pg * j : 3 * q + (pg * j - q);
+      for (int j = 0; j < (int)pln.size(); ++j)
+        pln[j] = pg * j >= hp ? q : (pg * j < q ? q + pg * j : 3 * q + (pg * j - q));
       M_x2 = add_map(n, x2);
       M_pl = add_map(n, pln);
     }
     // bf16 fused plans: the epilogue stores the GEMM's columns as contiguous channels, so a layer that writes
     // the even or the odd runs has its columns packed in run order: column c' = (low run | pad | high run | pad)
     int M_cols = -1;
-    if (qt && n->bf16) {
+    if (qt) {
       const int q = hp / 2, hh = h / 2;
-      std::vector<int32_t> cm(hp, -1);
+      std::vector<int32_t> cm(cout_pad(hp), -1);  // (columns past hp: zero columns of the packed matrix)
       for (int c = 0; c < hp; ++c) {
         const int p = c < q ? c : c - q;
         if (p < hh) cm[c] = c < q ? p : hh + p;
@@ -389,16 +399,17 @@ void build(rtpose_shufflenet* n) {
       n->layers[layer].coutp = cout_pad(hp);
     };
     auto plain_out = [&](int layer, int cout) {  // contiguous output channels, whole 8-channel groups stored
-      if (!(qt && n->bf16)) return;
+      if (!qt) return;
       n->layers[layer].ncols = (cout + 7) / 8 * 8;
       n->layers[layer].coutp = cout_pad(cout);
     };
     // temporaries
     const int in_phys = in_is_stage ? 2 * in_hp : in_c;
     const int T0 = add_buf(n, up8(in_phys), 0, Ho, Wo);  // conv0 branch after dw
-    const int T1a = add_buf(n, hp, 1, Hc, Wc);          // first block: 1x1 at the INPUT resolution
-    const int T1 = add_buf(n, hp, 1, Ho, Wo);
-    const int T2 = add_buf(n, hp, 0, Ho, Wo);
+    // (their channels past hp stay zero: the depthwise / pointwise convs that read them walk K = up8(hp))
+    const int T1a = add_buf(n, up8(hp), 1, Hc, Wc);     // first block: 1x1 at the INPUT resolution
+    const int T1 = add_buf(n, up8(hp), 1, Ho, Wo);
+    const int T2 = add_buf(n, up8(hp), 0, Ho, Wo);
 
     // -- block 0: two-branch (reference :47-53, :60-61) --
     {
@@ -413,8 +424,8 @@ void build(rtpose_shufflenet* n) {
       const int l_c00 = add_layer(n, L_DW, bp + "conv0.0", in_c, in_c, in_phys, M_inphys);
       const int l_c01 = add_layer(n, L_PW, bp + "conv0.1", h, in_c, up8(in_phys), M_in);
       const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, in_c, up8(in_phys), M_in);
-      const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, hp, -1);
-      const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, hp, -1);
+      const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, up8(hp), -1);
+      const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, up8(hp), -1);
       runs_out(l_c01);
       runs_out(l_c2);
       plain_out(l_c0, h);
@@ -435,11 +446,11 @@ void build(rtpose_shufflenet* n) {
         add_pwf(n, bp + "conv.0", Hc, Wc, l_c0, -1, in_buf, 0, T1a, 0, -1, 1);
         if (stride == 1 && dw_fusable(n, T1a, Hc, Wc)) {
           add_pwf(n, bp + "conv.1+conv.2", Ho, Wo, l_c2, l_c1, T1a, 0, SA, 0, M_odd, 1);
-        if (n->bf16) n->ops.back().out_choff[0] = hp;  // bf16: the odd runs as contiguous columns
+        n->ops.back().out_choff[0] = hp;  // the odd runs as contiguous columns
         } else {
           add_dw(n, bp + "conv.1", Hc, Wc, l_c1, T1a, T2, stride);
           add_pwf(n, bp + "conv.2", Ho, Wo, l_c2, -1, T2, 0, SA, 0, M_odd, 1);
-        if (n->bf16) n->ops.back().out_choff[0] = hp;  // bf16: the odd runs as contiguous columns
+        n->ops.back().out_choff[0] = hp;  // the odd runs as contiguous columns
         }
       }
     }
@@ -447,9 +458,9 @@ void build(rtpose_shufflenet* n) {
     // -- blocks 1..: pass-through half + processed half (reference :31-39, :56-59) --
     for (int b = 1; b < nblocks[si]; ++b) {
       const std::string bp = sp + std::to_string(b) + ".";
-      const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, h, hp, qt ? M_x2 : -1);
-      const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, hp, -1);
-      const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, hp, -1);
+      const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, h, qt ? up8(hp) : hp, qt ? M_x2 : -1);
+      const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, qt ? up8(hp) : hp, -1);
+      const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, qt ? up8(hp) : hp, -1);
       runs_out(l_c2);
       plain_out(l_c0, h);
       if (n->fused && dw_fusable(n, T1, Ho, Wo)) {
@@ -458,7 +469,7 @@ void build(rtpose_shufflenet* n) {
         add_pwf(n, bp + "conv.0", Ho, Wo, l_c0, -1, cur, 0, T1, 0, -1, 1);
         n->ops.back().planes_map = M_pl;
         add_pwf(n, bp + "conv.1+conv.2+x1", Ho, Wo, l_c2, l_c1, T1, 0, nxt, 0, M_odd, 1, cur, -1, 0);
-        if (n->bf16) n->ops.back().out_choff[0] = hp;  // bf16: the odd runs as contiguous columns
+        n->ops.back().out_choff[0] = hp;  // the odd runs as contiguous columns
         SOp& o = n->ops.back();
         o.pt_pairs = h / 2;
         o.pt_a = 0;
@@ -473,7 +484,7 @@ void build(rtpose_shufflenet* n) {
         n->ops.back().planes_map = M_pl;
         add_dw(n, bp + "conv.1", Ho, Wo, l_c1, T1, T2, 1);
         add_pwf(n, bp + "conv.2+x1", Ho, Wo, l_c2, -1, T2, 0, nxt, 0, M_odd, 1, cur, -1, 0);
-        if (n->bf16) n->ops.back().out_choff[0] = hp;  // bf16: the odd runs as contiguous columns
+        n->ops.back().out_choff[0] = hp;  // the odd runs as contiguous columns
         SOp& o = n->ops.back();
         o.pt_pairs = h / 2;
         o.pt_a = 0;
@@ -697,6 +708,11 @@ int rtpose_shufflenet_load(rtpose_shufflenet* n, int idx, const float* w, const 
         return pack_pw_bf16_launch(w, b, l.cout, l.cin, map, l.cin_packed, l.ncols, cmap, l.coutp, l.col_off,
                                    n->wt + l.w_off, n->wt + l.b_off, s);
       }
+      if (n->fused && l.ncols > 0 && !l.col_off && l.zero_c1 <= l.zero_c0) {  // column-mapped fp32 packing (see pw_t.hip)
+        const int32_t* cmap = l.colmap_id >= 0 ? reinterpret_cast<const int32_t*>(n->wt + n->maps[l.colmap_id].off) : nullptr;
+        return pack_pw_cols_launch(w, b, l.cout, l.cin, map, l.cin_packed, l.coutp, cmap, l.coutp, 0, n->wt + l.w_off,
+                                   n->wt + l.b_off, s);
+      }
       if (l.coutp) {  // shares a packed matrix with another layer (the heads of a fused plan)
         const int rc = pack_pw_launch(w, b, l.cout, l.cin, map, l.cin_packed, l.coutp, l.col_off, n->wt + l.w_off,
                                       n->wt + l.b_off, s);
@@ -842,7 +858,13 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
           }
           rc = pw_fused_bf16_launch(&d, f32out ? 1 : 0, n->N, o.H, o.W, s);
         } else {
-          rc = pw_fused_launch(&d, n->N, o.H, o.W, s);
+          if (l.ncols > 0 && !l.col_off) {  // run-ordered / padded columns [0, ncols) -> contiguous channels from out_choff
+            d.cout = l.ncols;
+            d.out_cmap = nullptr;
+          }
+          // the wave-autonomous transposed form where it has an instance (K a multiple of 16, >= 32), else the
+          // block-cooperative one (the 24-channel layers of stage 2's first unit)
+          rc = pw_t_fits(&d) ? pw_t_launch(&d, n->N, o.H, o.W, s) : pw_fused_launch(&d, n->N, o.H, o.W, s);
         }
         break;
       }
