@@ -255,20 +255,13 @@ int rtpose_pack_pw_weights(const float* w_oi, const float* bias, int cout, int c
                            float* w_packed, float* bias_packed, void* stream);
 int rtpose_pw_fused(const rtpose_pw_desc* d, int N, int H, int W, void* stream);
 
-/* ---- the same chain in wave-autonomous, transposed form (csrc/pw_t.hip): a work item of 32 pixels (depthwise: an
- * 8 x 4 tile) belongs to one wave, no barriers, the GEMM computed as C^T = W^T X^T so that a lane holds 4 consecutive
- * output columns of its own pixel per register quadruple (16-byte stores, no column scatter), the depthwise result
- * going from the VALU straight into the matrix pipe.  Same descriptor and packed weights as rtpose_pw_fused, for
- * chains with: cin a multiple of 16 (>= 32, <= 512), coutp 64 / 128 / 256, cout a multiple of 8, out_cmap = NULL
- * (columns [0, cout) -> the contiguous channels lout.choff ..), pass-through in its interleave form only.
- * rtpose_pw_fused_t_fits: 1 if `d` has an instance.  Layers whose columns must land in another order (the runs of
- * the four-run layout) are packed with a column map: rtpose_pack_pw_weights_cols writes packed column col_off + i =
- * output channel col_map[i] of w_oi (NULL: i; < 0 or >= cout: a zero column) for i < ncols. */
+/* Column-mapped packing: packed column col_off + i = output channel col_map[i] of w_oi (NULL: i; < 0 or >= cout: a
+ * zero column, zero bias) for i < ncols; K row c reads input channel cin_map[c] (NULL: c; < 0: a zero row).  The
+ * ShuffleNetV2 plans store a layer's columns [0, cout) as CONTIGUOUS channels (out_cmap = NULL), so a layer that
+ * writes runs of the four-run layout has its columns packed in memory order, and K may be padded with zero rows. */
 int rtpose_pack_pw_weights_cols(const float* w_oi, const float* bias, int cout, int cin_src,
                                 const int32_t* cin_map, int cin_packed, int ncols, const int32_t* col_map,
                                 int coutp, int col_off, float* w_packed, float* bias_packed, void* stream);
-int rtpose_pw_fused_t_fits(const rtpose_pw_desc* d);
-int rtpose_pw_fused_t(const rtpose_pw_desc* d, int N, int H, int W, void* stream);
 
 /* ---- conv5 + both heads of the ShuffleNetV2 pose network as ONE back-to-back GEMM launch (csrc/pw_head.hip):
  *   slim.conv_bn_relu('conv5', 464, 1024, 1) -> { self.paf = nn.Conv2d(1024, 38, 1), self.heatmap = nn.Conv2d(1024, 19, 1) }

@@ -119,8 +119,6 @@ _SIGS = {
     "rtpose_packed_pw_floats": (_sz, [_i, _i]),
     "rtpose_pack_pw_weights": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "rtpose_pw_fused": (_i, [C.POINTER(PwDesc), _i, _i, _i, _vp]),
-    "rtpose_pw_fused_t_fits": (_i, [C.POINTER(PwDesc)]),
-    "rtpose_pw_fused_t": (_i, [C.POINTER(PwDesc), _i, _i, _i, _vp]),
     "rtpose_pack_pw_weights_cols": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "rtpose_pw_head_fits": (_i, [C.POINTER(PwDesc), C.POINTER(PwDesc)]),
     "rtpose_pw_head": (_i, [C.POINTER(PwDesc), C.POINTER(PwDesc), _i, _i, _i, _vp]),

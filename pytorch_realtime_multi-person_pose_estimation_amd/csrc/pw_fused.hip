@@ -526,6 +526,37 @@ __global__ void pack_pw_kernel(const float* __restrict__ w, const float* __restr
   wp[((size_t)(c >> 2) * coutp + col_off + n) * 4 + (c & 3)] = v;
 }
 
+// packed[c / 4][coutp][4], columns [col_off, col_off + ncols): column col_off + i holds output channel col_map[i] of
+// w[cout][cin_src] (col_map NULL: i; < 0: a zero column), its K row c reads input channel cin_map[c] (NULL: c; < 0: zero)
+__global__ void pack_pw_cols_kernel(const float* __restrict__ w, const float* __restrict__ bias, int cout, int cin_src,
+                                    const int32_t* __restrict__ cin_map, int K, int ncols,
+                                    const int32_t* __restrict__ col_map, int coutp, int col_off, float* __restrict__ wp,
+                                    float* __restrict__ bp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ncols) {
+    const int n = col_map ? col_map[i] : i;
+    bp[col_off + i] = (n >= 0 && n < cout && bias) ? bias[n] : 0.f;
+  }
+  if (i >= K * ncols) return;
+  const int ci = i % ncols, c = i / ncols;
+  const int n = col_map ? col_map[ci] : ci;
+  const int src = cin_map ? cin_map[c] : (c < cin_src ? c : -1);
+  const float v = (n >= 0 && n < cout && src >= 0 && src < cin_src) ? w[(size_t)n * cin_src + src] : 0.f;
+  wp[((size_t)(c >> 2) * coutp + col_off + ci) * 4 + (c & 3)] = v;
+}
+
+
+int pack_pw_cols_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map, int K,
+                        int ncols, const int32_t* col_map, int coutp, int col_off, float* wp, float* bp,
+                        hipStream_t s) {
+  if (!w || !wp || !bp || cout <= 0 || K <= 0 || (K % 8) || ncols <= 0 || col_off < 0 || col_off + ncols > coutp)
+    return fail(RTPOSE_E_INVAL, "pack_pw_cols: bad arguments");
+  hipLaunchKernelGGL(pack_pw_cols_kernel, dim3(ceil_div(K * ncols, 256)), dim3(256), 0, s, w, bias, cout, cin_src,
+                     cin_map, K, ncols, col_map, coutp, col_off, wp, bp);
+  RTPOSE_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int pack_pw_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map, int K,
                    int coutp, int col_off, float* wp, float* bp, hipStream_t s) {
   if (!w || !wp || !bp || cout <= 0 || K <= 0 || (K % 8) || col_off < 0 || col_off + cout > coutp)
@@ -641,6 +672,13 @@ int rtpose_pack_pw_weights(const float* w_oi, const float* bias, int cout, int c
                            void* stream) {
   return pack_pw_launch(w_oi, bias, cout, cin_src, cin_map, cin_packed, coutp, col_off, w_packed, bias_packed,
                         as_stream(stream));
+}
+
+int rtpose_pack_pw_weights_cols(const float* w_oi, const float* bias, int cout, int cin_src, const int32_t* cin_map,
+                                int cin_packed, int ncols, const int32_t* col_map, int coutp, int col_off,
+                                float* w_packed, float* bias_packed, void* stream) {
+  return pack_pw_cols_launch(w_oi, bias, cout, cin_src, cin_map, cin_packed, ncols, col_map, coutp, col_off, w_packed,
+                             bias_packed, as_stream(stream));
 }
 
 int rtpose_pw_fused(const rtpose_pw_desc* d, int N, int H, int W, void* stream) {

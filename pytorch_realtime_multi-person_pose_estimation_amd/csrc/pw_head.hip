@@ -68,14 +68,20 @@ struct Args {
 template <int NF>
 __global__ __launch_bounds__(256, 1) void pw_head_f32(const Args A) {
   __shared__ __attribute__((aligned(16))) float4 xs_all[4][2 * 8 * PS];
+  // both biases live in LDS (N1 <= 1024 + 64 floats): a global load between two items would queue behind the item's
+  // stores - loads and stores share one in-order counter - and the wave would sit out their drain
+  __shared__ __attribute__((aligned(16))) float4 s_b1[256], s_b2[16];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, kh = lane >> 5;
   float4* const xs = &xs_all[wave][0];
+  for (int j = tid; j < A.N1 / 4; j += 256) s_b1[j] = gload4(A.b1 + 4 * j);
+  if (tid < 16) s_b2[tid] = gload4(A.b2 + 4 * tid);
+  __syncthreads();  // the only barrier
   const int nwaves = gridDim.x * 4;
   int item = blockIdx.x * 4 + wave;
-  if (item >= A.nitems) return;  // (no barriers anywhere: a wave may leave alone)
+  if (item >= A.nitems) return;  // (no barriers from here on: a wave may leave alone)
 
   const int HW = A.H * A.W;
   const int gtot = A.K1 >> 3;              // 8-channel k-groups of GEMM 1
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256, 1) void pw_head_f32(const Args A) {
   auto init_acc = [&](int f, int p) {  // bias of conv5 rides in the accumulator
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      const float4 b = gload4(A.b1 + (p * 32 * NF + f * 32 + rg * 8 + 4 * kh));
+      const float4 b = s_b1[p * 8 * NF + f * 8 + rg * 2 + kh];
       acc[f][rg * 4 + 0] = b.x;
       acc[f][rg * 4 + 1] = b.y;
       acc[f][rg * 4 + 2] = b.z;
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void pw_head_f32(const Args A) {
   auto init_out = [&]() {
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      const float4 b0 = gload4(A.b2 + (rg * 8 + 4 * kh)), b1 = gload4(A.b2 + (32 + rg * 8 + 4 * kh));
+      const float4 b0 = s_b2[rg * 2 + kh], b1 = s_b2[8 + rg * 2 + kh];
       o0[rg * 4 + 0] = b0.x; o0[rg * 4 + 1] = b0.y; o0[rg * 4 + 2] = b0.z; o0[rg * 4 + 3] = b0.w;
       o1[rg * 4 + 0] = b1.x; o1[rg * 4 + 1] = b1.y; o1[rg * 4 + 2] = b1.z; o1[rg * 4 + 3] = b1.w;
     }
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void pw_head_f32(const Args A) {
         const int pi = lastp ? 0 : p + 1;  // the pass whose bias the accumulators take next (next item: pass 0)
         float4 bz[4];                      // that bias, requested before the fragment is folded, written after
 #define RTPOSE_HEAD_BLOAD(F) \
-  _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) bz[rg] = gload4(A.b1 + (pi * 32 * NF + (F) * 32 + rg * 8 + 4 * kh))
+  _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) bz[rg] = s_b1[pi * 8 * NF + (F) * 8 + rg * 2 + kh]
 #define RTPOSE_HEAD_BSET(F)                                \
   _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {       \
     acc[F][rg * 4 + 0] = bz[rg].x;                         \
@@ -325,7 +331,7 @@ int pw_head_fits(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2) {
   if (!d1->relu || d2->relu || d1->dw_w || d2->dw_w || d1->pt_src || d2->pt_src || d1->in_planes || d1->out_cmap ||
       d2->out_cmap)
     return 0;
-  if (d2->cin != d1->coutp || d2->coutp != head::N2 || d2->cout < 1 || d2->cout > head::N2) return 0;
+  if (d2->cin != d1->coutp || d2->coutp != head::N2 || d2->cout < 1 || d2->cout > head::N2 || d1->coutp > 1024) return 0;
   if ((d1->lin.cstride % 4) || (d1->lin.choff % 4) || d1->lin.choff + d1->cin > d1->lin.cstride) return 0;
   if ((d2->lout.cstride % 4) || (d2->lout.choff % 4) || d2->lout.choff + head::N2 > d2->lout.cstride) return 0;
   return 1;

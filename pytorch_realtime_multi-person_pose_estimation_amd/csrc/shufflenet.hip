@@ -43,9 +43,7 @@ int pw_halo_stride(const rtpose_layout& l, int H, int W);
 // conv5 + the two heads as one back-to-back launch (pw_head.hip)
 int pw_head_launch(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2, int N, int H, int W, hipStream_t s);
 int pw_zero_columns_launch(float* wp, float* bp, int K, int coutp, int c0, int c1, hipStream_t s);
-// wave-autonomous transposed form of the fused chains (pw_t.hip) and the column-mapped fp32 packing it stores by
-int pw_t_fits(const rtpose_pw_desc* d);
-int pw_t_launch(const rtpose_pw_desc* d, int N, int H, int W, hipStream_t s);
+// column-mapped fp32 packing (pw_fused.hip): a layer's columns in the memory order of the runs it writes
 int pack_pw_cols_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map, int K,
                         int ncols, const int32_t* col_map, int coutp, int col_off, float* wp, float* bp,
                         hipStream_t s);
@@ -301,7 +299,7 @@ bool dw_fusable(const rtpose_shufflenet* n, int buf, int H, int W) {
 void build(rtpose_shufflenet* n) {
   // channel alignment of slices that feed a pointwise conv: 8 floats (fp32 kernel: cin % 8 == 0),
   // 16 elements for bf16 plans (one K = 16 MFMA step)
-  // (fp32 fused plans: 16 too - the wave-autonomous kernels of pw_t.hip / pw_head.hip walk K in pairs of 8-channel groups)
+  // (fp32 fused plans: 16 too - the wave-autonomous head kernel, pw_head.hip, walks K in pairs of 8-channel groups)
   const int al = (n->bf16 || n->fused) ? 16 : 8;
   auto up8 = [al](int v) { return (v + al - 1) / al * al; };
   const int H0 = n->H, W0 = n->W;
@@ -708,7 +706,7 @@ int rtpose_shufflenet_load(rtpose_shufflenet* n, int idx, const float* w, const 
         return pack_pw_bf16_launch(w, b, l.cout, l.cin, map, l.cin_packed, l.ncols, cmap, l.coutp, l.col_off,
                                    n->wt + l.w_off, n->wt + l.b_off, s);
       }
-      if (n->fused && l.ncols > 0 && !l.col_off && l.zero_c1 <= l.zero_c0) {  // column-mapped fp32 packing (see pw_t.hip)
+      if (n->fused && l.ncols > 0 && !l.col_off && l.zero_c1 <= l.zero_c0) {  // column-mapped fp32 packing (pw_fused.hip)
         const int32_t* cmap = l.colmap_id >= 0 ? reinterpret_cast<const int32_t*>(n->wt + n->maps[l.colmap_id].off) : nullptr;
         return pack_pw_cols_launch(w, b, l.cout, l.cin, map, l.cin_packed, l.coutp, cmap, l.coutp, 0, n->wt + l.w_off,
                                    n->wt + l.b_off, s);
@@ -862,9 +860,7 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
             d.cout = l.ncols;
             d.out_cmap = nullptr;
           }
-          // the wave-autonomous transposed form where it has an instance (K a multiple of 16, >= 32), else the
-          // block-cooperative one (the 24-channel layers of stage 2's first unit)
-          rc = pw_t_fits(&d) ? pw_t_launch(&d, n->N, o.H, o.W, s) : pw_fused_launch(&d, n->N, o.H, o.W, s);
+          rc = pw_fused_launch(&d, n->N, o.H, o.W, s);
         }
         break;
       }

@@ -197,82 +197,14 @@ def test_unit_in_the_four_run_layout(capi, cuda, h, w_map):
     assert abs(total - inside) <= 1e-3 * max(1.0, inside), "kernel wrote outside the real channels / pixels"
 
 
-def _run_t(capi, cuda, n, h, w, cin, cout, dw, relu, pad_in=1, seed=0):
-    """rtpose_pw_fused_t on a plain / depthwise chain whose K is padded to a multiple of 16 by the caller (zero weight
-    rows over zero channels) and whose stored width is cout rounded up to 8 (zero columns), against F.conv2d."""
-    g = torch.Generator().manual_seed(seed)
-    K = (cin + 15) // 16 * 16
-    cst = (cout + 7) // 8 * 8
-    coutp = (cout + 63) // 64 * 64
-    x = torch.randn(n, cin, h, w, generator=g)
-    wt = torch.randn(cout, cin, generator=g) / cin ** 0.5
-    b = torch.randn(cout, generator=g) * 0.1
-    lin = capi.Layout.padded(K, h, w, pad_in) if pad_in else capi.Layout.dense(K, h, w)
-    xin = _to_layout(capi, x, lin, K, cuda)
-    ref_in = x
-    d = capi.PwDesc()
-    keep = [xin]
-    if dw:
-        dw_w = torch.randn(cin, 1, 3, 3, generator=g) * 0.3
-        dw_b = torch.randn(cin, generator=g) * 0.1
-        ref_in = F.conv2d(x, dw_w, dw_b, padding=1, groups=cin)
-        wp = torch.zeros(9, K)
-        wp[:, :cin] = dw_w.reshape(cin, 9).t()
-        bp = torch.zeros(K)
-        bp[:cin] = dw_b
-        bp[cin:] = 3.0        # (a depthwise bias on a padding channel meets a zero weight row)
-        wp_d, bp_d = wp.to(cuda), bp.to(cuda)
-        keep += [wp_d, bp_d]
-        d.dw_w, d.dw_b = wp_d.data_ptr(), bp_d.data_ptr()
-    ref = F.conv2d(ref_in, wt[:, :, None, None], b)
-    if relu:
-        ref = F.relu(ref)
-    wpk = torch.full((capi.lib.rtpose_packed_pw_floats(K, coutp) + 64 * coutp,), float("nan"), device=cuda)
-    bpk = torch.full((coutp,), float("nan"), device=cuda)
-    wt_d, b_d = wt.contiguous().to(cuda), b.to(cuda)
-    capi.check(capi.lib.rtpose_pack_pw_weights_cols(capi.ptr(wt_d), capi.ptr(b_d), cout, cin, None, K, coutp, None, coutp, 0,
-                                                    capi.ptr(wpk), capi.ptr(bpk), capi.current_stream()))
-    cs = cst + 8
-    lout = capi.Layout.padded(cs, h, w, 1, 4)
-    out = torch.zeros(capi.lib.rtpose_layout_pixels(C.byref(lout), n, h, w) * cs, device=cuda)
-    keep += [wpk, bpk, wt_d, b_d, out]
-    d.inp, d.w_packed, d.bias_packed, d.out = xin.data_ptr(), wpk.data_ptr(), bpk.data_ptr(), out.data_ptr()
-    d.lin, d.lout = lin, lout
-    d.cin, d.cout, d.coutp, d.relu = K, cst, coutp, 1 if relu else 0
-    assert capi.lib.rtpose_pw_fused_t_fits(C.byref(d)) == 1
-    capi.check(capi.lib.rtpose_pw_fused_t(C.byref(d), n, h, w, capi.current_stream()), "rtpose_pw_fused_t")
-    got = _from_layout(capi, out, lout, cst, n, h, w, cuda)
-    total = out.abs().sum().item()
-    inside = got.abs().sum().item()
-    assert abs(total - inside) <= 1e-3 * max(1.0, inside), "kernel wrote outside the real pixels / its channel slice"
-    scale = max(1.0, ref.abs().max().item())
-    assert (got[:, :cout] - ref).abs().max().item() <= TOL * scale
-    assert got[:, cout:].abs().max().item() == 0.0 if cst > cout else True
-
-
-@pytest.mark.parametrize("cin,cout", [(32, 64), (58, 58), (64, 116), (116, 116), (120, 120), (232, 232), (240, 232),
-                                      (464, 256), (24, 19)])
-def test_transposed_form_pointwise_only(capi, cuda, cin, cout):
-    _run_t(capi, cuda, 3, 13, 17, cin, cout, dw=False, relu=True, pad_in=1, seed=cin)
-    _run_t(capi, cuda, 2, 46, 46, cin, cout, dw=False, relu=False, pad_in=0, seed=cin + 1)
-    _run_t(capi, cuda, 1, 3, 5, cin, cout, dw=False, relu=True, pad_in=1, seed=cin + 2)      # fewer pixels than one item
-
-
-@pytest.mark.parametrize("cin,cout", [(58, 58), (116, 116), (232, 232), (128, 116), (240, 232), (32, 24)])
-def test_transposed_form_depthwise_then_pointwise(capi, cuda, cin, cout):
-    _run_t(capi, cuda, 3, 13, 17, cin, cout, dw=True, relu=True, seed=cin)
-    _run_t(capi, cuda, 2, 46, 46, cin, cout, dw=True, relu=True, seed=cin + 1)
-    _run_t(capi, cuda, 1, 3, 60, cin, cout, dw=True, relu=False, seed=cin + 2)       # H < one 8 x 4 tile
-    _run_t(capi, cuda, 2, 19, 133, cin, cout, dw=True, relu=True, seed=cin + 3)      # wide map, ragged tiles
-
-
 @pytest.mark.parametrize("h,w_map", [(58, 46), (116, 46), (232, 46), (116, 70)])
-def test_unit_in_the_four_run_layout_transposed_form(capi, cuda, h, w_map):
-    """One ShuffleNetV2 unit (rtpose_shufflenetV2.py:31-39, :56-62) the way the fp32 plan runs it since round 4
-    (csrc/pw_t.hip): four-run stage buffer, launch 1 = conv.0 on x2 gathered as two runs with K padded to a multiple of 16
-    (the extra planes repeat a real plane under zero weights), launch 2 = conv.1 (depthwise, VALU -> matrix pipe) ->
-    conv.2 packed with a COLUMN MAP so that its columns are the odd runs in memory order -> 16-byte stores, + the
-    next x1 = (even-low, odd-low) interleaved -> the even runs.  Against torch: chunk -> convs -> cat -> shuffle."""
+def test_unit_in_the_four_run_layout_with_column_mapped_packing(capi, cuda, h, w_map):
+    """One ShuffleNetV2 unit (rtpose_shufflenetV2.py:31-39, :56-62) the way the fp32 plan runs it since round 4:
+    four-run stage buffer, launch 1 = conv.0 on x2 gathered as two runs with K padded to a multiple of 16 (the extra
+    planes repeat a real plane under zero weights; stored width hp, zero columns past h), launch 2 = conv.1
+    (depthwise, in LDS) -> conv.2 packed with a COLUMN MAP (rtpose_pack_pw_weights_cols) so that its columns are the odd
+    runs in memory order and are stored as contiguous channels (no out_cmap), + the next x1 = (even-low, odd-low)
+    interleaved -> the even runs.  Against torch: chunk -> convs -> cat -> channel_shuffle(2)."""
     g = torch.Generator().manual_seed(h + 1)
     n, hh_, q = 2, h // 2, (h // 2 + 3) // 4 * 4
     H = 9
@@ -334,8 +266,7 @@ def test_unit_in_the_four_run_layout_transposed_form(capi, cuda, h, w_map):
     d.inp, d.w_packed, d.bias_packed, d.out = cur.data_ptr(), wp0.data_ptr(), bp0.data_ptr(), t1.data_ptr()
     d.lin, d.lout, d.cin, d.cout, d.coutp, d.relu = lay, lt1, Kp, (h + 7) // 8 * 8, coutp, 1
     d.in_planes = pln_d.data_ptr()
-    assert capi.lib.rtpose_pw_fused_t_fits(C.byref(d)) == 1
-    capi.check(capi.lib.rtpose_pw_fused_t(C.byref(d), n, H, w_map, capi.current_stream()), "conv.0")
+    capi.check(capi.lib.rtpose_pw_fused(C.byref(d), n, H, w_map, capi.current_stream()), "conv.0")
     wdp = torch.zeros(9, Kp)
     wdp[:, :h] = wd.reshape(h, 9).t()
     bdp = torch.zeros(Kp)
@@ -348,8 +279,7 @@ def test_unit_in_the_four_run_layout_transposed_form(capi, cuda, h, w_map):
     d2.lin, d2.lout, d2.cin, d2.cout, d2.coutp, d2.relu = lt1, lodd, Kp, hp, coutp, 1
     d2.pt_src, d2.lpt = cur.data_ptr(), lay
     d2.pt_pairs, d2.pt_a, d2.pt_b, d2.pt_split, d2.pt_d0, d2.pt_d1 = hh_, 0, 2 * q, hh_, 0, q
-    assert capi.lib.rtpose_pw_fused_t_fits(C.byref(d2)) == 1
-    capi.check(capi.lib.rtpose_pw_fused_t(C.byref(d2), n, H, w_map, capi.current_stream()), "conv.1+conv.2+x1")
+    capi.check(capi.lib.rtpose_pw_fused(C.byref(d2), n, H, w_map, capi.current_stream()), "conv.1+conv.2+x1")
     got = _from_layout(capi, nxt, lay, C4, n, H, w_map, cuda)[:, perm]
     scale = max(1.0, ref.abs().max().item())
     assert (got[:, 0::2] - ref[:, 0::2]).abs().max().item() == 0.0          # the pass-through half is a copy

@@ -1,3 +1,7 @@
+// EXPERIMENT (round 4, not part of the library; measurements: profiles/r04_shufflenet_pw_t_experiment.txt).
+// To try it: copy into csrc/, add to the Makefile's SRCS, declare rtpose_pw_fused_t[_fits] and route O_PWF launches of
+// csrc/shufflenet.hip through pw_t_fits / pw_t_launch.
+//
 // Wave-autonomous, transposed form of the fused pointwise chain of the ShuffleNetV2 pose network - fp32,
 // v_mfma_f32_32x32x2_f32, gfx950 (BASELINE configs[3]).  Same module boundary as pw_fused.hip:
 //     [conv_bn depthwise 3x3 ->] conv_bn_relu 1x1 [+ the pass-through half + channel_shuffle]
@@ -23,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "conv_exp.h"
 
 namespace rtpose {
 
@@ -60,17 +65,21 @@ struct Args {
   int N, H, W, M;
   int K, coutp, cout, relu;
   int nitems, tiles_x, tiles_y;
+  int npass;  // column passes of 32 NF columns: a work item is (pixel item, pass), item index = pixel item * npass + pass
 };
 
 #define RTPOSE_PWT_PIN()         \
   asm volatile("" ::: "memory"); \
   __builtin_amdgcn_sched_barrier(0)
 
-template <int NF, bool DW>
-__global__ __launch_bounds__(256, 1) void pw_t_f32(const Args A) {
+// WPS = waves per SIMD the kernel is built for: 2 (NF <= 4: <= 256 registers) lets a second wave's MFMAs cover a
+// wave's own stalls - store drains, the first loads of a work item - which one wave per SIMD sits out
+template <int NF, bool DW, int WPS>
+__global__ __launch_bounds__(256, WPS) void pw_t_f32(const Args A) {
   constexpr int NS = DW ? 8 : 4;                        // staged 16-byte pieces per lane and chunk
   constexpr int XS4 = DW ? 8 * PSH : 8 * PS;            // float4 per chunk buffer
-  // LDS (dynamic): [4 waves][2 chunk buffers][XS4] | DW: [10][K / 4] depthwise taps + bias | [K / 4] plane table
+  // LDS (dynamic): [4 waves][2 chunk buffers][XS4] | DW: [10][K / 4] depthwise taps + bias | [coutp / 4] bias |
+  // [K / 4] plane table
   extern __shared__ __attribute__((aligned(16))) float4 smem4[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -79,8 +88,12 @@ __global__ __launch_bounds__(256, 1) void pw_t_f32(const Args A) {
   const int k4 = A.K >> 2;
   float4* const xs = smem4 + wave * (2 * XS4);
   float4* const s_dw = smem4 + 4 * 2 * XS4;
-  int* const s_plane = reinterpret_cast<int*>(s_dw + (DW ? 10 * k4 : 0));
+  float4* const s_bias = s_dw + (DW ? 10 * k4 : 0);
+  int* const s_plane = reinterpret_cast<int*>(s_bias + (A.coutp >> 2));
   for (int j = tid; j < k4; j += 256) s_plane[j] = A.in_planes ? A.in_planes[j] : 4 * j;
+  // the bias lives in LDS: a global load in the epilogue would queue behind the item's own stores (one in-order
+  // counter for loads and stores) and the wave would sit out their whole drain before its next MFMA
+  for (int j = tid; j < (A.coutp >> 2); j += 256) s_bias[j] = gload4(A.bias + 4 * j);
   if (DW)
     for (int i = tid; i < 10 * k4; i += 256)
       s_dw[i] = i < 9 * k4 ? gload4(A.dw_w + 4 * (size_t)i) : gload4(A.dw_b + 4 * (size_t)(i - 9 * k4));
@@ -103,13 +116,16 @@ __global__ __launch_bounds__(256, 1) void pw_t_f32(const Args A) {
     unsigned sq[DW ? 1 : 4];  // plain: element offsets of the four staged pixels; DW: of the halo's corner pixel
     unsigned oq;              // element offset of this lane's output pixel (+ out_choff)
     unsigned pq;              // ... of its pass-through source pixel (+ pt_choff)
+    int pass;                 // column pass
     bool ovalid;
   };
   // DW: halo piece u of this lane = halo pixel hp = spx + 8 u, (hp / 10) rows and hp % 10 pixels after the corner
   // (recomputed per chunk - a handful of VALU instructions per 128 MFMAs - rather than held in 8 registers)
-  auto setup = [&](int it) -> Item {
+  auto setup = [&](int item_idx) -> Item {
     Item r;
     int n, y, x;
+    const int it = item_idx / A.npass;
+    r.pass = item_idx - it * A.npass;
     if (DW) {
       const int t = it;
       const int txi = t % A.tiles_x, rr = t / A.tiles_x;
@@ -175,8 +191,9 @@ __global__ __launch_bounds__(256, 1) void pw_t_f32(const Args A) {
   float4 wa[NF], wb[NF];  // weight fragments: two alternating sets
   float4 xa, xb;          // plain: activation fragments likewise
   float4 xd[4];           // DW: the chunk's four activation fragments = the depthwise outputs of this lane
-#define RTPOSE_PWT_WLOAD(DST, G) \
-  _Pragma("unroll") for (int f = 0; f < NF; ++f) DST[f] = gload4(w4 + ((size_t)(2 * (G)) * A.coutp + (size_t)(f * 32) + wl))
+#define RTPOSE_PWT_WLOAD(DST, G, PASS) \
+  _Pragma("unroll") for (int f = 0; f < NF; ++f)    \
+      DST[f] = gload4(w4 + ((size_t)(2 * (G)) * A.coutp + (size_t)((PASS) * 32 * NF + f * 32) + wl))
 #define RTPOSE_PWT_XLOAD(DST, BUF, GI) DST = xs[(BUF) * XS4 + (2 * (GI) + kh) * PS + l31]
 #define RTPOSE_PWT_MUL(WV, XV)                                                                         \
   {                                                                                                    \
@@ -214,23 +231,17 @@ __global__ __launch_bounds__(256, 1) void pw_t_f32(const Args A) {
   };
 
   floatx16 acc[NF];  // C^T: column fragment f, this lane's pixel
-  auto init_acc = [&]() {  // the bias rides in the accumulator
+  auto init_acc = [&]() {
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const float4 b = gload4(A.bias + (f * 32 + rg * 8 + 4 * kh));
-        acc[f][rg * 4 + 0] = b.x;
-        acc[f][rg * 4 + 1] = b.y;
-        acc[f][rg * 4 + 2] = b.z;
-        acc[f][rg * 4 + 3] = b.w;
-      }
+      for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
   };
 
   // ---- prologue of the wave ----
   Item cur = setup(item);
   stage_load(cur, 0);
-  RTPOSE_PWT_WLOAD(wa, 0);
+  RTPOSE_PWT_WLOAD(wa, 0, cur.pass);
   init_acc();
   stage_store(0);
   RTPOSE_PWT_PIN();  // (LDS serves a wave's requests in order: the reads below see the writes above)
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void pw_t_f32(const Args A) {
       const int nb = lb ^ 1;
       const bool short_chunk = lastc && ng_last == 2;
       // ---- group 0 (set A) ----
-      RTPOSE_PWT_WLOAD(wb, g0 + 1);
+      RTPOSE_PWT_WLOAD(wb, g0 + 1, cur.pass);
       stage_load(lastc ? nxt : cur, cn);  // AFTER the weight request: the next wait for weights does not wait for these
       if (!DW) { RTPOSE_PWT_XLOAD(xb, lb, 1); }
       RTPOSE_PWT_PIN();
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(256, 1) void pw_t_f32(const Args A) {
       RTPOSE_PWT_PIN();
       // ---- group 1 (set B); the last group of a two-group chunk ----
       if (!DW && short_chunk) stage_store(nb);
-      RTPOSE_PWT_WLOAD(wa, short_chunk ? 0 : g0 + 2);
+      RTPOSE_PWT_WLOAD(wa, short_chunk ? 0 : g0 + 2, short_chunk ? nxt.pass : cur.pass);
       RTPOSE_PWT_PIN();
       if (!DW) { RTPOSE_PWT_XLOAD(xa, short_chunk ? nb : lb, short_chunk ? 0 : 2); }
       RTPOSE_PWT_PIN();
@@ -269,14 +280,14 @@ __global__ __launch_bounds__(256, 1) void pw_t_f32(const Args A) {
       RTPOSE_PWT_PIN();
       if (!short_chunk) {
         // ---- group 2 (set A) ----
-        RTPOSE_PWT_WLOAD(wb, g0 + 3);
+        RTPOSE_PWT_WLOAD(wb, g0 + 3, cur.pass);
         if (!DW) { RTPOSE_PWT_XLOAD(xb, lb, 3); }
         RTPOSE_PWT_PIN();
         if (DW) { RTPOSE_PWT_MUL(wa, xd[2]); } else { RTPOSE_PWT_MUL(wa, xa); }
         RTPOSE_PWT_PIN();
         // ---- group 3 (set B): the next chunk goes to LDS, its first fragments are requested ----
         if (!DW) stage_store(nb);
-        RTPOSE_PWT_WLOAD(wa, lastc ? 0 : g0 + 4);
+        RTPOSE_PWT_WLOAD(wa, lastc ? 0 : g0 + 4, lastc ? nxt.pass : cur.pass);
         RTPOSE_PWT_PIN();
         if (!DW) { RTPOSE_PWT_XLOAD(xa, nb, 0); }
         RTPOSE_PWT_PIN();
@@ -293,13 +304,17 @@ __global__ __launch_bounds__(256, 1) void pw_t_f32(const Args A) {
 
     // ---- epilogue: (ReLU,) 16 bytes per lane and register quadruple ----
     if (cur.ovalid) {
-      float* const po = A.out + (cur.oq + (unsigned)(4 * kh));
+      const int c0 = cur.pass * 32 * NF;  // first column of the pass
+      float* const po = A.out + (cur.oq + (unsigned)(c0 + 4 * kh));
+      const float4* const pb = s_bias + (c0 >> 2) + kh;
 #pragma unroll
       for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          if (f * 32 + rg * 8 < A.cout) {  // (cout is a multiple of 8: a wave-uniform test, an immediate store offset)
-            float4 v = make_float4(acc[f][rg * 4 + 0], acc[f][rg * 4 + 1], acc[f][rg * 4 + 2], acc[f][rg * 4 + 3]);
+          if (c0 + f * 32 + rg * 8 < A.cout) {  // (cout is a multiple of 8: a wave-uniform test, an immediate store offset)
+            const float4 b = pb[f * 8 + rg * 2];
+            float4 v = make_float4(acc[f][rg * 4 + 0] + b.x, acc[f][rg * 4 + 1] + b.y, acc[f][rg * 4 + 2] + b.z,
+                                   acc[f][rg * 4 + 3] + b.w);
             if (A.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
             *reinterpret_cast<float4*>(po + (f * 32 + rg * 8)) = v;
           }
@@ -310,16 +325,19 @@ __global__ __launch_bounds__(256, 1) void pw_t_f32(const Args A) {
     // ---- pass-through half, interleave form (see pw_fused.hip): output channel j < 2 pt_pairs of the pixel takes
     //      source channel pt_a + j / 2 (j even) or pt_b + j / 2 (j odd) and lands at
     //      (j < pt_split ? pt_d0 + j : pt_d1 + j - pt_split).  A lane copies groups of 4 pairs of the item's pixels. ----
-    if (A.pt) {
+    if (A.pt && cur.pass == 0) {
       const int g4 = (A.pt_pairs + 3) >> 2;
       const bool v4ok = !(A.pt_split & 3) && !(A.pt_d0 & 3) && !((A.pt_d1 - A.pt_split) & 3);
       const bool v2ok = !(A.pt_split & 1) && !(A.pt_d0 & 1) && !((A.pt_d1 - A.pt_split) & 1);
-      for (int i0 = 0; i0 < PX * g4; i0 += 128) {  // (uniform trip count: every lane takes part in the shuffles)
-        float4 va[2], vb[2];
-        int pp[2], gg[2];
-        bool ok[2];
+      // All loads of a batch of 8 x 64 (pixel, group) pieces first, then all its stores: a store queued between two loads
+      // would make the wait for the second load sit out the store's drain (one in-order counter).
+      constexpr int PB = 8;
+      for (int i0 = 0; i0 < PX * g4; i0 += 64 * PB) {  // (uniform trip count: every lane takes part in the shuffles)
+        float4 va[PB], vb[PB];
+        int pp[PB], gg[PB];
+        bool ok[PB];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < PB; ++u) {
           const int i = min(i0 + lane + 64 * u, PX * g4 - 1);
           pp[u] = i / g4;
           gg[u] = i - pp[u] * g4;
@@ -330,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void pw_t_f32(const Args A) {
           vb[u] = gload4(A.pt + (sq + (unsigned)(A.pt_b + 4 * gg[u])));
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < PB; ++u) {
           const unsigned dq = (unsigned)__shfl((int)cur.oq, pp[u], 64) - (unsigned)A.out_choff;
           const bool pv = __shfl((int)cur.ovalid, pp[u], 64) != 0;
           if (!ok[u] || !pv) continue;
@@ -375,37 +393,7 @@ __global__ __launch_bounds__(256, 1) void pw_t_f32(const Args A) {
 }
 #undef RTPOSE_PWT_PIN
 
-// packed[c / 4][coutp][4], columns [col_off, col_off + ncols): column col_off + i holds output channel col_map[i] of
-// w[cout][cin_src] (col_map NULL: i; < 0: a zero column), its K row c reads input channel cin_map[c] (NULL: c; < 0: zero)
-__global__ void pack_pw_cols_kernel(const float* __restrict__ w, const float* __restrict__ bias, int cout, int cin_src,
-                                    const int32_t* __restrict__ cin_map, int K, int ncols,
-                                    const int32_t* __restrict__ col_map, int coutp, int col_off, float* __restrict__ wp,
-                                    float* __restrict__ bp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < ncols) {
-    const int n = col_map ? col_map[i] : i;
-    bp[col_off + i] = (n >= 0 && n < cout && bias) ? bias[n] : 0.f;
-  }
-  if (i >= K * ncols) return;
-  const int ci = i % ncols, c = i / ncols;
-  const int n = col_map ? col_map[ci] : ci;
-  const int src = cin_map ? cin_map[c] : (c < cin_src ? c : -1);
-  const float v = (n >= 0 && n < cout && src >= 0 && src < cin_src) ? w[(size_t)n * cin_src + src] : 0.f;
-  wp[((size_t)(c >> 2) * coutp + col_off + ci) * 4 + (c & 3)] = v;
-}
-
 }  // namespace pwt
-
-int pack_pw_cols_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map, int K,
-                        int ncols, const int32_t* col_map, int coutp, int col_off, float* wp, float* bp,
-                        hipStream_t s) {
-  if (!w || !wp || !bp || cout <= 0 || K <= 0 || (K % 8) || ncols <= 0 || col_off < 0 || col_off + ncols > coutp)
-    return fail(RTPOSE_E_INVAL, "pack_pw_cols: bad arguments");
-  hipLaunchKernelGGL(pwt::pack_pw_cols_kernel, dim3(ceil_div(K * ncols, 256)), dim3(256), 0, s, w, bias, cout, cin_src,
-                     cin_map, K, ncols, col_map, coutp, col_off, wp, bp);
-  RTPOSE_HIP_CHECK(hipGetLastError());
-  return 0;
-}
 
 // 1 when the chain described by `d` has an instance of this form
 int pw_t_fits(const rtpose_pw_desc* d) {
@@ -421,20 +409,26 @@ int pw_t_fits(const rtpose_pw_desc* d) {
   return 1;
 }
 
-template <int NF, bool DW>
-static int pw_t_launch_inst(const pwt::Args& a, int grid, hipStream_t s) {
+template <int NF, bool DW, int WPS>
+static int pw_t_launch_inst(const pwt::Args& a0, hipStream_t s) {
   using namespace pwt;
+  Args a = a0;
+  a.npass = a.coutp / (32 * NF);
+  a.nitems *= a.npass;
   const int k4 = a.K >> 2;
-  const size_t lds = (size_t)4 * 2 * (DW ? 8 * PSH : 8 * PS) * 16 + (DW ? (size_t)10 * k4 * 16 : 0) + (size_t)k4 * 4;
+  const size_t lds = (size_t)4 * 2 * (DW ? 8 * PSH : 8 * PS) * 16 + (DW ? (size_t)10 * k4 * 16 : 0) +
+                     (size_t)(a.coutp >> 2) * 16 + (size_t)k4 * 4;
+  const int slots = 4 * WPS * device_cu_count();  // WPS waves per SIMD
+  const int waves = a.nitems < slots ? a.nitems : slots;
   static PerDeviceOnce attr_set;
   const int dev = current_device();
-  auto kern = pw_t_f32<NF, DW>;
+  auto kern = pw_t_f32<NF, DW, WPS>;
   if (!attr_set.is_set(dev)) {
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          128 * 1024));
     attr_set.set(dev);
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(ceil_div(waves, 4)), dim3(256), lds, s, a);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -496,25 +490,26 @@ int pw_t_launch(const rtpose_pw_desc* d, int N, int H, int W, hipStream_t s) {
   a.tiles_x = ceil_div(W, TW);
   a.tiles_y = ceil_div(H, TH);
   a.nitems = dw ? N * a.tiles_x * a.tiles_y : ceil_div((int)M, PX);
-  const int waves = a.nitems < 4 * device_cu_count() ? a.nitems : 4 * device_cu_count();  // one wave per SIMD
-  const int grid = ceil_div(waves, 4);
-  switch (d->coutp) {
-    case 64: return dw ? pw_t_launch_inst<2, true>(a, grid, s) : pw_t_launch_inst<2, false>(a, grid, s);
-    case 128: return dw ? pw_t_launch_inst<4, true>(a, grid, s) : pw_t_launch_inst<4, false>(a, grid, s);
-    default: return dw ? pw_t_launch_inst<8, true>(a, grid, s) : pw_t_launch_inst<8, false>(a, grid, s);
+  // developer builds: RTPOSE_PWT_FORM=1 -> one wave per SIMD with all columns of a pixel item in one pass (NF = coutp / 32)
+  static const int wide = [] {
+    const char* e = dev_env("RTPOSE_PWT_FORM");
+    return e && e[0] == '1' ? 1 : 0;
+  }();
+  if (wide) {
+    switch (d->coutp) {
+      case 64: return dw ? pw_t_launch_inst<2, true, 1>(a, s) : pw_t_launch_inst<2, false, 1>(a, s);
+      case 128: return dw ? pw_t_launch_inst<4, true, 1>(a, s) : pw_t_launch_inst<4, false, 1>(a, s);
+      default: return dw ? pw_t_launch_inst<8, true, 1>(a, s) : pw_t_launch_inst<8, false, 1>(a, s);
+    }
   }
+  // two waves per SIMD, work items of 32 pixels x <= 128 columns (256 columns: two passes)
+  if (d->coutp == 64) return dw ? pw_t_launch_inst<2, true, 2>(a, s) : pw_t_launch_inst<2, false, 2>(a, s);
+  return dw ? pw_t_launch_inst<4, true, 2>(a, s) : pw_t_launch_inst<4, false, 2>(a, s);
 }
 
 }  // namespace rtpose
 
 extern "C" {
-
-int rtpose_pack_pw_weights_cols(const float* w_oi, const float* bias, int cout, int cin_src, const int32_t* cin_map,
-                                int cin_packed, int ncols, const int32_t* col_map, int coutp, int col_off,
-                                float* w_packed, float* bias_packed, void* stream) {
-  return rtpose::pack_pw_cols_launch(w_oi, bias, cout, cin_src, cin_map, cin_packed, ncols, col_map, coutp, col_off,
-                                     w_packed, bias_packed, rtpose::as_stream(stream));
-}
 
 int rtpose_pw_fused_t_fits(const rtpose_pw_desc* d) { return rtpose::pw_t_fits(d); }
 
