@@ -19,6 +19,7 @@
 //    BOTH stride-1 stages is the two-branch block.  Reproduced.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -342,6 +343,7 @@ void build(rtpose_shufflenet* n) {
   const int nblocks[3] = {4, 8, 4};
   int in_buf = X1, in_c = 24, in_h = 24, in_hp = 24;  // previous buffer: logical C, half h, padded hp
   bool in_is_stage = false;
+  std::vector<int32_t> in_pmap;  // previous STAGE buffer: physical channel -> logical channel (-1: nothing lives there)
   int Hc = H2, Wc = W2;
   for (int si = 0; si < 3; ++si) {
     // bf16 plans: halves padded to 64 channels (58 -> 64, 116 -> 128, 232 -> 256) so that every
@@ -353,6 +355,137 @@ void build(rtpose_shufflenet* n) {
     const int stride = si == 0 ? 2 : 1;
     const int Ho = si == 0 ? H3 : Hc, Wo = si == 0 ? W3 : Wc;
     const std::string sp = "network." + std::to_string(3 + si) + ".";
+    if (n->fused && !n->bf16) {
+      // ================= fp32 fused plans (round 4): ZERO-COPY channel shuffle ======================================
+      // torch.cat((x1, conv(x2)), 1) + channel_shuffle(2) (rtpose_shufflenetV2.py:56-62) moves no data at all here.
+      // A stage has ONE buffer of P physical channel slots that all its units work on in place:
+      //   * the pass-through half x1 of a unit stays where it is - only its LOGICAL index changes (L_u[2i] = L_{u-1}[i]);
+      //   * the processed half y = conv(x2) is written into the slots x2 just vacated (x2 is dead once conv.0 has read
+      //     it, and conv.0 is an earlier launch), through the pointwise kernel's column -> channel map;
+      //   * the next unit's x2 = L_u[h:2h] is wherever those logical channels happen to live: the GEMM gathers K as
+      //     16-byte planes (in_planes) with the weights permuted to match and zero rows for plane-mates that are not
+      //     members (they hold finite activations of other channels).
+      // Which slot a new channel takes is decided by WHEN it will be consumed: a channel born at logical position p of
+      // L_u enters x2 at unit u + 1 + min{t : p 2^t >= h}.  Channels with the same consumption time are placed together,
+      // and since a unit frees exactly the group sizes it creates (h/2, h/4, ...), every x2 is a handful of contiguous
+      // runs: K grows from h to at most h + 20 (116 -> 136 in the seventh unit of stage 3), stores stay coalesced.
+      // Round 3 copied x1 into the next buffer in every unit: 3.6 GB of HBM traffic per 128-image forward.
+      const int U = nblocks[si];
+      const int INF = 1 << 30;
+      const int in_phys = in_is_stage ? (int)in_pmap.size() : in_c;
+      auto death_from = [&](int pos, int born) {  // the unit that consumes the channel at logical position pos of L_born
+        for (int u = born + 1; u < U; ++u) {
+          if (pos >= h) return u;
+          pos *= 2;
+        }
+        return INF;
+      };
+      // unit 0 (two-branch, creates all 2h channels): slots in the order (consumption time, parity, index), every
+      // consumption group starting on a plane boundary
+      std::vector<int> phys(2 * h);
+      int P = 0;
+      {
+        std::vector<int> order(2 * h);
+        for (int j = 0; j < 2 * h; ++j) order[j] = j;
+        auto key = [&](int j) { return ((long)death_from(j, 0) << 20) | ((long)(j & 1) << 19) | j; };
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
+        int prev = -1;
+        for (int j : order) {
+          const int d = death_from(j, 0);
+          if (d != prev) P = (P + 3) / 4 * 4;
+          prev = d;
+          phys[j] = P++;
+        }
+      }
+      const int Pp = up8(P);  // physical channels of the stage buffer (a multiple of 16: conv5 / the next stage read all of it)
+      const int S = add_buf(n, Pp, 1, Ho, Wo);
+      const int Kt = up8(h);  // channels of the unit temporaries (conv.0 -> depthwise -> conv.2)
+      const int T0 = add_buf(n, up8(in_phys), 0, Ho, Wo);  // conv0 branch after a separate (stride 2) depthwise conv
+      const int T1a = add_buf(n, Kt, 1, Hc, Wc);           // first block: 1x1 at the INPUT resolution
+      const int T1 = add_buf(n, Kt, 1, Ho, Wo);
+      const int T2 = add_buf(n, Kt, 0, Ho, Wo);
+      {  // -- block 0: two-branch (reference :47-53, :60-61) --
+        const std::string bp = sp + "0.";
+        int M_in = -1;
+        if (in_is_stage) M_in = add_map(n, in_pmap);
+        std::vector<int32_t> even(h), odd(h);
+        for (int i = 0; i < h; ++i) {
+          even[i] = phys[2 * i];
+          odd[i] = phys[2 * i + 1];
+        }
+        const int M_even = add_map(n, even), M_odd = add_map(n, odd);
+        const int l_c00 = add_layer(n, L_DW, bp + "conv0.0", in_c, in_c, in_phys, M_in);
+        const int l_c01 = add_layer(n, L_PW, bp + "conv0.1", h, in_c, up8(in_phys), M_in);
+        const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, in_c, up8(in_phys), M_in);
+        const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, Kt, -1);
+        const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, Kt, -1);
+        if (stride == 1) {
+          add_pwf(n, bp + "conv0.0+conv0.1", Ho, Wo, l_c01, l_c00, in_buf, 0, S, 0, M_even, 1);
+        } else {
+          add_dw(n, bp + "conv0.0", Hc, Wc, l_c00, in_buf, T0, stride);
+          add_pwf(n, bp + "conv0.1", Ho, Wo, l_c01, -1, T0, 0, S, 0, M_even, 1);
+        }
+        add_pwf(n, bp + "conv.0", Hc, Wc, l_c0, -1, in_buf, 0, T1a, 0, -1, 1);
+        if (stride == 1) {
+          add_pwf(n, bp + "conv.1+conv.2", Ho, Wo, l_c2, l_c1, T1a, 0, S, 0, M_odd, 1);
+        } else {
+          add_dw(n, bp + "conv.1", Hc, Wc, l_c1, T1a, T2, stride);
+          add_pwf(n, bp + "conv.2", Ho, Wo, l_c2, -1, T2, 0, S, 0, M_odd, 1);
+        }
+      }
+      for (int u = 1; u < U; ++u) {  // -- blocks 1..: pass-through half + processed half (reference :31-39, :56-59) --
+        const std::string bp = sp + std::to_string(u) + ".";
+        // x2 = L_{u-1}[h:2h): the planes it touches, in ascending order; K = their channels, padded to a whole k-group
+        std::vector<int> slot2logical(Pp, -1);
+        for (int j = h; j < 2 * h; ++j) slot2logical[phys[j]] = j - h;
+        std::vector<int32_t> pln, x2map;
+        for (int pl = 0; pl < Pp / 4; ++pl) {
+          bool any = false;
+          for (int e = 0; e < 4; ++e) any = any || slot2logical[4 * pl + e] >= 0;
+          if (!any) continue;
+          pln.push_back(4 * pl);
+          for (int e = 0; e < 4; ++e) x2map.push_back(slot2logical[4 * pl + e]);
+        }
+        while (x2map.size() % 8) {  // (a zero-weight repeat of the first plane)
+          pln.push_back(pln[0]);
+          for (int e = 0; e < 4; ++e) x2map.push_back(-1);
+        }
+        const int Ku = (int)x2map.size();
+        const int M_x2 = add_map(n, x2map), M_pl = add_map(n, pln);
+        // y_u takes the slots x2 vacates: new channels in the order (consumption time, index), slots ascending
+        std::vector<int> freed(phys.begin() + h, phys.end());
+        std::sort(freed.begin(), freed.end());
+        std::vector<int> yorder(h);
+        for (int i = 0; i < h; ++i) yorder[i] = i;
+        auto ykey = [&](int i) { return ((long)death_from(2 * i + 1, u) << 20) | i; };
+        std::sort(yorder.begin(), yorder.end(), [&](int a, int b) { return ykey(a) < ykey(b); });
+        std::vector<int32_t> yslot(h);
+        for (int r = 0; r < h; ++r) yslot[yorder[r]] = freed[r];
+        const int M_y = add_map(n, yslot);
+        const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, h, Ku, M_x2);
+        const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, Kt, -1);
+        const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, Kt, -1);
+        add_pwf(n, bp + "conv.0", Ho, Wo, l_c0, -1, S, 0, T1, 0, -1, 1);
+        n->ops.back().planes_map = M_pl;
+        add_pwf(n, bp + "conv.1+conv.2", Ho, Wo, l_c2, l_c1, T1, 0, S, 0, M_y, 1);
+        std::vector<int> np(2 * h);
+        for (int i = 0; i < h; ++i) {
+          np[2 * i] = phys[i];
+          np[2 * i + 1] = yslot[i];
+        }
+        phys.swap(np);
+      }
+      in_buf = S;
+      in_c = C;
+      in_h = h;
+      in_hp = hp;
+      in_is_stage = true;
+      in_pmap.assign(Pp, -1);
+      for (int j = 0; j < C; ++j) in_pmap[phys[j]] = j;
+      Hc = Ho;
+      Wc = Wo;
+      continue;
+    }
     // two ping-pong stage buffers (P = 1: the next stage's first block runs a dw conv on them)
     const int SA = add_buf(n, 2 * hp, 1, Ho, Wo), SB = add_buf(n, 2 * hp, 1, Ho, Wo);
     std::vector<int32_t> even(h), odd(h);
@@ -402,7 +535,7 @@ void build(rtpose_shufflenet* n) {
       n->layers[layer].coutp = cout_pad(cout);
     };
     // temporaries
-    const int in_phys = in_is_stage ? 2 * in_hp : in_c;
+    const int in_phys = in_is_stage ? (int)in_pmap.size() : in_c;
     const int T0 = add_buf(n, up8(in_phys), 0, Ho, Wo);  // conv0 branch after dw
     // (their channels past hp stay zero: the depthwise / pointwise convs that read them walk K = up8(hp))
     const int T1a = add_buf(n, up8(hp), 1, Hc, Wc);     // first block: 1x1 at the INPUT resolution
@@ -413,10 +546,8 @@ void build(rtpose_shufflenet* n) {
     {
       const std::string bp = sp + "0.";
       int M_in = -1, M_inphys = -1;
-      if (in_is_stage) {  // input buffer holds [h' | pad | h' | pad]
-        std::vector<int32_t> m(in_phys, -1);
-        for (int j = 0; j < in_c; ++j) m[fphys(j, in_h, in_hp, qt)] = j;
-        M_in = add_map(n, m);
+      if (in_is_stage) {  // the previous stage's buffer: its own physical -> logical channel map
+        M_in = add_map(n, in_pmap);
         M_inphys = M_in;
       }
       const int l_c00 = add_layer(n, L_DW, bp + "conv0.0", in_c, in_c, in_phys, M_inphys);
@@ -512,16 +643,16 @@ void build(rtpose_shufflenet* n) {
     in_h = h;
     in_hp = hp;
     in_is_stage = true;
+    in_pmap.assign(2 * hp, -1);
+    for (int j = 0; j < C; ++j) in_pmap[fphys(j, h, hp, qt)] = j;
     Hc = Ho;
     Wc = Wo;
   }
 
   // ---- conv5 + heads -------------------------------------------------------------------
   {
-    std::vector<int32_t> m(2 * in_hp, -1);
-    for (int j = 0; j < in_c; ++j) m[fphys(j, in_h, in_hp, n->fused != 0)] = j;
-    const int M_in = add_map(n, m);
-    const int l5 = add_layer(n, L_PW, "network.6", 1024, in_c, up8(2 * in_hp), M_in);
+    const int M_in = add_map(n, in_pmap);
+    const int l5 = add_layer(n, L_PW, "network.6", 1024, in_c, up8((int)in_pmap.size()), M_in);
     const int lp = add_layer(n, L_PW, "paf", 38, 1024, 1024, -1);
     const int lh = add_layer(n, L_PW, "heatmap", 19, 1024, 1024, -1);
     // fp32 fused plans: conv5 and the heads are ONE launch (pw_head.hip) - the 1024-channel feature has no buffer

@@ -1,0 +1,8 @@
+#!/bin/bash
+# Round-4 session 8: zero-copy channel shuffle in the fp32 ShuffleNetV2 plan
+cd "$(dirname "$0")/../.."
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+( timeout 900 python -m pytest tests/test_shufflenet_gpu.py tests/test_pw_fused_gpu.py -q --timeout 800 2>&1 | tail -12 ) > gpurun_out/s8_tests.log 2>&1
+( VERBOSE=1 timeout 300 python tools/bench_shufflenet.py 128 10 fp32 2>&1 | grep -v amdgpu.ids ) > gpurun_out/s8_sn_fp32.log 2>&1
+tail -n 6 gpurun_out/s8_tests.log; cat gpurun_out/s8_sn_fp32.log
