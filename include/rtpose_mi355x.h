@@ -266,7 +266,8 @@ int rtpose_pack_pw_weights_cols(const float* w_oi, const float* bias, int cout, 
 /* ---- conv5 + both heads of the ShuffleNetV2 pose network as ONE back-to-back GEMM launch (csrc/pw_head.hip):
  *   slim.conv_bn_relu('conv5', 464, 1024, 1) -> { self.paf = nn.Conv2d(1024, 38, 1), self.heatmap = nn.Conv2d(1024, 19, 1) }
  * (lib/network/rtpose_shufflenetV2.py:104, :107-108, :143-147).  d1 = the wide conv (+ReLU): `in` / `lin` a contiguous
- * slice of cin channels (a multiple of 16), w_packed [cin / 4][coutp][4] with cout = coutp a multiple of 256; d1->out is
+ * slice of cin channels (a multiple of 16, <= 1024) or, with d1->in_planes, a gather of cin / 4 16-byte planes of
+ * the pixel; w_packed [cin / 4][coutp][4] with cout = coutp a multiple of 256; d1->out is
  * ignored - the intermediate never leaves the registers.  d2 = the heads: ONE shared matrix [coutp1 / 4][64][4] whose
  * columns sit at their output channels (rtpose_pack_pw_weights with col_off; columns nobody owns must be zero), bias
  * [64]; 64 channels are stored at d2->lout.choff (16 bytes per lane, no column map).  Both GEMMs run transposed so
@@ -280,8 +281,11 @@ int rtpose_pw_head(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2, int N, in
  * (out: 4-byte when out_f32), the layouts count ELEMENTS, slices are multiples of 8 elements, cin a
  * multiple of 16.  The bf16 epilogue stores the GEMM's columns [0, cout) as the CONTIGUOUS channels
  * lout.choff .. (16 bytes per lane), so a layer that writes runs of the four-run layout is packed with a
- * column map (`col_map[i]` = output channel of packed column col_off + i, < 0 = a zero column); out_cmap is
- * honoured by the fp32 epilogue only; the pass-through half exists in its interleave form only.
+ * column map (`col_map[i]` = output channel of packed column col_off + i, < 0 = a zero column).  out_cmap, if given,
+ * is read per GROUP OF 8 COLUMNS by the bf16 epilogue: the columns 8 g .. 8 g + 7 are stored as the 8 contiguous
+ * channels from out_cmap[8 g] (absolute, a multiple of 8; < 0: the group is not stored) - the zero-copy channel
+ * shuffle of the ShuffleNetV2 plans scatters a layer's output over the slot groups the unit's x2 vacated; the fp32
+ * (out_f32) epilogue reads it per column.  The pass-through half exists in its interleave form only.
  * Contract: oracle/shufflenet_oracle.py:forward_bf16_emulated (the reference has no bf16 path). */
 size_t rtpose_packed_pw_bytes_bf16(int cin_packed, int coutp);
 int rtpose_pack_pw_weights_bf16(const float* w_oi, const float* bias, int cout, int cin_src,

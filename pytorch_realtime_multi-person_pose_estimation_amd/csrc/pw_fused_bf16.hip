@@ -387,8 +387,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16(const Args A) {
         const int row = it * RPI + lrow;
         const float4 v = *reinterpret_cast<const float4*>(sl + row * PITCH2 + c16 * 8);
         const int qo = s_qout[par][wm * (32 * MF) + row];
-        if (qo >= 0 && col0 < A.cout)
-          gstore4(outh + ((unsigned)qo * (unsigned)A.out_cstride + (unsigned)(A.out_choff + col0)), v);
+        // (out_cmap: the 8 columns from col0 go to the 8 channels from out_cmap[col0] - absolute, 8-aligned, the host
+        //  keeps a group's channels contiguous; < 0: the group is not stored)
+        const int chb = A.out_cmap ? A.out_cmap[min(col0, A.cout - 8)] : A.out_choff + col0;
+        if (qo >= 0 && col0 < A.cout && chb >= 0)
+          gstore4(outh + ((unsigned)qo * (unsigned)A.out_cstride + (unsigned)chb), v);
       }
     }
 

@@ -47,10 +47,12 @@ __device__ __forceinline__ float4 gload4(const void* p) {  // explicit global ad
 constexpr int PX = 32;   // pixels of a work item (one MFMA fragment)
 constexpr int PS = 33;   // LDS plane pitch in float4 (planes 4 banks apart for the 8-lane write groups)
 constexpr int N2 = 64;   // head columns (38 + 2 + 19 + 5)
+constexpr int kMaxK1 = 1024;  // largest K of the wide conv (plane table in LDS)
 
 struct Args {
   const float* in;
   int in_cstride, in_choff, in_ws, in_hs, in_lead;
+  const int32_t* in_planes;  // optional [K1 / 4]: channel offset (inside the slice) of every 4-channel plane of K1
   const float* w1;  // [K1 / 4][N1][4]
   const float* b1;  // [N1]
   const float* w2;  // [N1 / 4][64][4]
@@ -71,12 +73,14 @@ __global__ __launch_bounds__(256, 1) void pw_head_f32(const Args A) {
   // both biases live in LDS (N1 <= 1024 + 64 floats): a global load between two items would queue behind the item's
   // stores - loads and stores share one in-order counter - and the wave would sit out their drain
   __shared__ __attribute__((aligned(16))) float4 s_b1[256], s_b2[16];
+  __shared__ int s_plane[kMaxK1 / 4];  // channel offset of every plane of K1 (the input may be a gather of planes)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, kh = lane >> 5;
   float4* const xs = &xs_all[wave][0];
   for (int j = tid; j < A.N1 / 4; j += 256) s_b1[j] = gload4(A.b1 + 4 * j);
+  for (int j = tid; j < A.K1 / 4; j += 256) s_plane[j] = A.in_planes ? A.in_planes[j] : 4 * j;
   if (tid < 16) s_b2[tid] = gload4(A.b2 + 4 * tid);
   __syncthreads();  // the only barrier
   const int nwaves = gridDim.x * 4;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void pw_head_f32(const Args A) {
   // chunk c of the pixels q -> registers.  Planes past K1 (the short last chunk) are clamped to the last valid one:
   // their LDS slots exist and are never multiplied.
   auto stage_load = [&](const unsigned* q, int c) {
-    const unsigned cofs = (unsigned)min(32 * c + 4 * spl, A.K1 - 4);
+    const unsigned cofs = (unsigned)s_plane[min(8 * c + spl, (A.K1 >> 2) - 1)];
 #pragma unroll
     for (int u = 0; u < 4; ++u) sr[u] = gload4(in_base + (q[u] + cofs));
   };
@@ -327,12 +331,12 @@ int pw_zero_columns_launch(float* wp, float* bp, int K, int coutp, int c0, int c
 // of 16; d2: the heads' shared matrix [cout1 / 4][64][4], columns at their output channels (no column map).
 int pw_head_fits(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2) {
   if (!d1 || !d2) return 0;
-  if (d1->cin <= 0 || (d1->cin % 16) || d1->cin < 32 || d1->coutp <= 0 || (d1->coutp % 256) || d1->cout != d1->coutp) return 0;
-  if (!d1->relu || d2->relu || d1->dw_w || d2->dw_w || d1->pt_src || d2->pt_src || d1->in_planes || d1->out_cmap ||
-      d2->out_cmap)
+  if (d1->cin <= 0 || (d1->cin % 16) || d1->cin < 32 || d1->cin > head::kMaxK1 || d1->coutp <= 0 || (d1->coutp % 256) ||
+      d1->cout != d1->coutp)
     return 0;
+  if (!d1->relu || d2->relu || d1->dw_w || d2->dw_w || d1->pt_src || d2->pt_src || d1->out_cmap || d2->out_cmap) return 0;
   if (d2->cin != d1->coutp || d2->coutp != head::N2 || d2->cout < 1 || d2->cout > head::N2 || d1->coutp > 1024) return 0;
-  if ((d1->lin.cstride % 4) || (d1->lin.choff % 4) || d1->lin.choff + d1->cin > d1->lin.cstride) return 0;
+  if ((d1->lin.cstride % 4) || (d1->lin.choff % 4) || (!d1->in_planes && d1->lin.choff + d1->cin > d1->lin.cstride)) return 0;
   if ((d2->lout.cstride % 4) || (d2->lout.choff % 4) || d2->lout.choff + head::N2 > d2->lout.cstride) return 0;
   return 1;
 }
@@ -356,6 +360,7 @@ int pw_head_launch(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2, int N, in
   a.in_ws = d1->lin.ws;
   a.in_hs = d1->lin.hs;
   a.in_lead = d1->lin.lead;
+  a.in_planes = d1->in_planes;
   a.w1 = d1->w_packed;
   a.b1 = d1->bias_packed;
   a.w2 = d2->w_packed;

@@ -196,11 +196,12 @@ int add_layer(rtpose_shufflenet* n, LKind kind, const std::string& name, int cou
     case L_STEM: wf = (size_t)9 * 8 * cout; bf = cout; break;
     case L_DW: wf = (size_t)9 * cin_packed; bf = cin_packed; break;
     case L_PW:
-      wf = n->bf16 ? (n->fused ? (size_t)(cin_packed + 64) * cout_pad(cout > 0 ? cout : 1) / 2
+      // (fused bf16 plans: a layer that writes whole slot groups of the stage buffer packs up to 256 columns -
+      //  116 channels in 18 groups of 8 = 144 columns run in the 256-column instance)
+      wf = n->bf16 ? (n->fused ? (size_t)(cin_packed + 64) * (cout_pad(cout > 0 ? cout : 1) < 256 ? 256 : cout_pad(cout)) / 2
                                : rtpose_packed_weight_bytes_bf16(cout, cin_packed, 1) / 4)
-                   // (fp32 fused plans pack up to cout_pad(cout + 8) columns: a run layout's padded columns)
                    : (size_t)(cin_packed + 32) * cout_pad(cout + 8);
-      bf = rtpose_packed_bias_floats(cout);
+      bf = (n->bf16 && n->fused && cout_pad(cout) < 256) ? 256 : rtpose_packed_bias_floats(cout);
       break;
   }
   n->wt_floats += round_up(wf, 64);
@@ -297,6 +298,166 @@ bool dw_fusable(const rtpose_shufflenet* n, int buf, int H, int W) {
   return n->fused != 0;
 }
 
+
+// ---- zero-copy channel shuffle: slot plan of one stage ---------------------------------------------------------------
+// torch.cat((x1, conv(x2)), 1) + channel_shuffle(2) (rtpose_shufflenetV2.py:56-62) moves no data in the fused plans.
+// A stage has ONE buffer of P physical channel slots that all its units work on in place:
+//   * the pass-through half x1 of a unit stays where it is - only its LOGICAL index changes (L_u[2i] = L_{u-1}[i]);
+//   * the processed half y = conv(x2) is written into slots x2 just vacated (x2 is dead once conv.0 has read it, and
+//     conv.0 is an earlier launch), through the pointwise kernel's column -> channel map;
+//   * the next unit's x2 = L_u[h:2h] is wherever those logical channels live: the GEMM gathers K as 16-byte planes
+//     (in_planes) with the weights permuted to match.
+// Which slots a new channel takes is decided by WHEN it will be consumed: a channel born at logical position p of L_u
+// enters x2 at unit u + 1 + min{t : p 2^t >= h}.  Channels of one producer with the same consumption time form a
+// CLASS that occupies whole groups of G slots (G = one 16-byte plane: 4 fp32 / 8 bf16 channels); a unit frees exactly
+// the class sizes it creates (h/2, h/4, ...), so the classes recycle each other's groups, every x2 is a handful of
+// contiguous runs of whole planes and K grows from h by the class padding only (116 -> 128 fp32 / 144 bf16 in stage 3).
+// Round 3 copied x1 into the next buffer in every unit: 3.6 GB (fp32) of HBM traffic per 128-image forward.
+struct ZcUnit {
+  std::vector<int32_t> planes;  // K / G entries: channel offset of every plane conv.0 gathers (K padded to kalign)
+  std::vector<int32_t> x2map;   // K entries: packed K row -> x2 channel (0 .. h-1), -1: a zero row
+  std::vector<int32_t> yslot;   // h entries: slot of y[i]
+};
+struct ZcStage {
+  int P = 0;                    // slots in use (a multiple of G)
+  std::vector<int> phys0;       // unit 0: slot of logical channel j < 2h (even j: branch conv0, odd j: branch conv)
+  std::vector<ZcUnit> units;    // units 1 .. U-1 (index u - 1)
+  std::vector<int> phys_final;  // slot of logical channel j of the stage's output
+};
+
+ZcStage zc_plan(int h, int U, int G, int kalign) {
+  const int INF = 1 << 30;
+  auto death_from = [&](int pos, int born) {  // the unit that consumes the channel at logical position pos of L_born
+    for (int u = born + 1; u < U; ++u) {
+      if (pos >= h) return u;
+      pos *= 2;
+    }
+    return INF;
+  };
+  ZcStage st;
+  int ngroups = 0;               // slot groups handed out so far
+  std::vector<int> freeg;        // free groups, ascending
+  // cnt groups for one class.  A class is read as ONE run by the gather of the unit that consumes it, so it starts on a
+  // boundary of min(128 bytes, its own size rounded up to a power of two) - 8 groups are a 128-byte line: a 64-channel
+  // bf16 class is exactly one line of every pixel, not two halves (the buffer's pixel pitch is a multiple of 128 bytes).
+  // The smallest free aligned run that fits, else new groups at the (aligned) end.
+  auto alloc = [&](int cnt) {
+    int al = 1;
+    while (al < cnt && al < 8) al *= 2;
+    std::vector<int> got;
+    int best0 = -1, bestlen = 1 << 30;
+    for (size_t i = 0; i < freeg.size();) {
+      size_t j = i;
+      while (j + 1 < freeg.size() && freeg[j + 1] == freeg[j] + 1) ++j;
+      // first aligned start inside the run [freeg[i], freeg[j]]
+      const int start = (freeg[i] + al - 1) / al * al;
+      const int len = freeg[j] - start + 1;
+      if (len >= cnt && (int)(j - i + 1) < bestlen) {
+        best0 = start;
+        bestlen = (int)(j - i + 1);
+      }
+      i = j + 1;
+    }
+    if (best0 < 0) {
+      while (ngroups % al) freeg.push_back(ngroups++);  // (the groups skipped for alignment stay free)
+      std::sort(freeg.begin(), freeg.end());
+      best0 = ngroups;
+      ngroups += cnt;
+      for (int g = best0; g < best0 + cnt; ++g) got.push_back(g);
+      return got;
+    }
+    for (int g = best0; g < best0 + cnt; ++g) {
+      got.push_back(g);
+      freeg.erase(std::find(freeg.begin(), freeg.end(), g));
+    }
+    return got;
+  };
+  // place the channels `ids` (already ordered) of one class: whole groups
+  auto place = [&](const std::vector<int>& ids, std::vector<int>& slot_of) {
+    const std::vector<int> g = alloc(((int)ids.size() + G - 1) / G);
+    for (size_t k = 0; k < ids.size(); ++k) slot_of[ids[k]] = g[k / G] * G + (int)(k % G);
+  };
+  // ---- unit 0: 2h channels, classes = (producer parity, consumption time) ----
+  st.phys0.assign(2 * h, -1);
+  for (int par = 0; par < 2; ++par) {
+    std::vector<int> deaths;
+    for (int j = par; j < 2 * h; j += 2) deaths.push_back(death_from(j, 0));
+    std::vector<int> uniq(deaths);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    for (int d : uniq) {
+      std::vector<int> ids;
+      for (int j = par; j < 2 * h; j += 2)
+        if (death_from(j, 0) == d) ids.push_back(j);
+      place(ids, st.phys0);
+    }
+  }
+  std::vector<int> phys = st.phys0;
+  for (int u = 1; u < U; ++u) {
+    ZcUnit zu;
+    // x2 = L_{u-1}[h:2h): its groups (whole classes die together: every touched group is freed)
+    std::vector<int> slot2x2((size_t)ngroups * G, -1);
+    for (int j = h; j < 2 * h; ++j) slot2x2[phys[j]] = j - h;
+    std::vector<int> touched;
+    for (int g = 0; g < ngroups; ++g) {
+      bool any = false;
+      for (int e = 0; e < G; ++e) any = any || slot2x2[g * G + e] >= 0;
+      if (any) touched.push_back(g);
+    }
+    for (int g : touched) {
+      zu.planes.push_back(g * G);
+      for (int e = 0; e < G; ++e) zu.x2map.push_back(slot2x2[g * G + e]);
+    }
+    while (zu.x2map.size() % kalign) {  // (zero-weight repeats of the first plane)
+      zu.planes.push_back(zu.planes[0]);
+      for (int e = 0; e < G; ++e) zu.x2map.push_back(-1);
+    }
+    for (int g : touched) freeg.push_back(g);
+    std::sort(freeg.begin(), freeg.end());
+    // y_u: classes by consumption time, soonest first
+    zu.yslot.assign(h, -1);
+    std::vector<int> uniq;
+    for (int i = 0; i < h; ++i) uniq.push_back(death_from(2 * i + 1, u));
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    for (int d : uniq) {
+      std::vector<int> ids;
+      for (int i = 0; i < h; ++i)
+        if (death_from(2 * i + 1, u) == d) ids.push_back(i);
+      place(ids, zu.yslot);
+    }
+    std::vector<int> np(2 * h);
+    for (int i = 0; i < h; ++i) {
+      np[2 * i] = phys[i];
+      np[2 * i + 1] = zu.yslot[i];
+    }
+    phys.swap(np);
+    st.units.push_back(zu);
+  }
+  st.P = ngroups * G;
+  st.phys_final = phys;
+  return st;
+}
+
+// the columns a producer packs / stores when its channels `slot_of` (slot of its channel i) must be written as WHOLE
+// slot groups (the bf16 epilogue stores 8 contiguous channels per lane): its groups in ascending slot order; packed column
+// c holds the producer's channel cols[c] (-1: a zero column) and lands at absolute channel chan[c]
+void zc_columns(const std::vector<int32_t>& slot_of, int G, std::vector<int32_t>* cols, std::vector<int32_t>* chan) {
+  std::vector<int> groups;
+  for (int32_t sl : slot_of) groups.push_back(sl / G);
+  std::sort(groups.begin(), groups.end());
+  groups.erase(std::unique(groups.begin(), groups.end()), groups.end());
+  cols->assign(groups.size() * G, -1);
+  chan->assign(groups.size() * G, -1);
+  for (size_t k = 0; k < groups.size(); ++k)
+    for (int e = 0; e < G; ++e) (*chan)[k * G + e] = groups[k] * G + e;
+  for (size_t i = 0; i < slot_of.size(); ++i) {
+    const int g = slot_of[i] / G;
+    const size_t k = std::lower_bound(groups.begin(), groups.end(), g) - groups.begin();
+    (*cols)[k * G + slot_of[i] % G] = (int32_t)i;
+  }
+}
+
 void build(rtpose_shufflenet* n) {
   // channel alignment of slices that feed a pointwise conv: 8 floats (fp32 kernel: cin % 8 == 0),
   // 16 elements for bf16 plans (one K = 16 MFMA step)
@@ -344,6 +505,9 @@ void build(rtpose_shufflenet* n) {
   int in_buf = X1, in_c = 24, in_h = 24, in_hp = 24;  // previous buffer: logical C, half h, padded hp
   bool in_is_stage = false;
   std::vector<int32_t> in_pmap;  // previous STAGE buffer: physical channel -> logical channel (-1: nothing lives there)
+  // ... as its readers walk it (zero-copy plans): only the planes that hold live channels are gathered - K position k
+  // is logical channel in_kmap[k] (-1: a zero row), plane k / G sits at channel in_planes_v[k / G] of the pixel
+  std::vector<int32_t> in_kmap, in_planes_v;
   int Hc = H2, Wc = W2;
   for (int si = 0; si < 3; ++si) {
     // bf16 plans: halves padded to 64 channels (58 -> 64, 116 -> 128, 232 -> 256) so that every
@@ -355,77 +519,69 @@ void build(rtpose_shufflenet* n) {
     const int stride = si == 0 ? 2 : 1;
     const int Ho = si == 0 ? H3 : Hc, Wo = si == 0 ? W3 : Wc;
     const std::string sp = "network." + std::to_string(3 + si) + ".";
-    if (n->fused && !n->bf16) {
-      // ================= fp32 fused plans (round 4): ZERO-COPY channel shuffle ======================================
-      // torch.cat((x1, conv(x2)), 1) + channel_shuffle(2) (rtpose_shufflenetV2.py:56-62) moves no data at all here.
-      // A stage has ONE buffer of P physical channel slots that all its units work on in place:
-      //   * the pass-through half x1 of a unit stays where it is - only its LOGICAL index changes (L_u[2i] = L_{u-1}[i]);
-      //   * the processed half y = conv(x2) is written into the slots x2 just vacated (x2 is dead once conv.0 has read
-      //     it, and conv.0 is an earlier launch), through the pointwise kernel's column -> channel map;
-      //   * the next unit's x2 = L_u[h:2h] is wherever those logical channels happen to live: the GEMM gathers K as
-      //     16-byte planes (in_planes) with the weights permuted to match and zero rows for plane-mates that are not
-      //     members (they hold finite activations of other channels).
-      // Which slot a new channel takes is decided by WHEN it will be consumed: a channel born at logical position p of
-      // L_u enters x2 at unit u + 1 + min{t : p 2^t >= h}.  Channels with the same consumption time are placed together,
-      // and since a unit frees exactly the group sizes it creates (h/2, h/4, ...), every x2 is a handful of contiguous
-      // runs: K grows from h to at most h + 20 (116 -> 136 in the seventh unit of stage 3), stores stay coalesced.
-      // Round 3 copied x1 into the next buffer in every unit: 3.6 GB of HBM traffic per 128-image forward.
+    if (n->fused) {
+      // ================= fused plans (round 4): ZERO-COPY channel shuffle, see zc_plan above =========================
       const int U = nblocks[si];
-      const int INF = 1 << 30;
-      const int in_phys = in_is_stage ? (int)in_pmap.size() : in_c;
-      auto death_from = [&](int pos, int born) {  // the unit that consumes the channel at logical position pos of L_born
-        for (int u = born + 1; u < U; ++u) {
-          if (pos >= h) return u;
-          pos *= 2;
-        }
-        return INF;
-      };
-      // unit 0 (two-branch, creates all 2h channels): slots in the order (consumption time, parity, index), every
-      // consumption group starting on a plane boundary
-      std::vector<int> phys(2 * h);
-      int P = 0;
-      {
-        std::vector<int> order(2 * h);
-        for (int j = 0; j < 2 * h; ++j) order[j] = j;
-        auto key = [&](int j) { return ((long)death_from(j, 0) << 20) | ((long)(j & 1) << 19) | j; };
-        std::sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
-        int prev = -1;
-        for (int j : order) {
-          const int d = death_from(j, 0);
-          if (d != prev) P = (P + 3) / 4 * 4;
-          prev = d;
-          phys[j] = P++;
-        }
-      }
-      const int Pp = up8(P);  // physical channels of the stage buffer (a multiple of 16: conv5 / the next stage read all of it)
+      const int in_phys = in_is_stage ? (int)in_kmap.size() : in_c;   // K of the layers that read the whole input buffer
+      const int G = n->bf16 ? 8 : 4;                      // channels per 16-byte plane
+      const ZcStage zs = zc_plan(h, U, G, n->bf16 ? 16 : 8);
+      // physical channels of the stage buffer: a pixel is a whole number of 128-byte lines (and a multiple of 16 channels:
+      // conv5 / the next stage read all of it)
+      const int Pp = (zs.P + 8 * G - 1) / (8 * G) * (8 * G);
       const int S = add_buf(n, Pp, 1, Ho, Wo);
-      const int Kt = up8(h);  // channels of the unit temporaries (conv.0 -> depthwise -> conv.2)
+      const int Kt = up8(h);     // channels of the unit temporaries (conv.0 -> depthwise -> conv.2)
       const int T0 = add_buf(n, up8(in_phys), 0, Ho, Wo);  // conv0 branch after a separate (stride 2) depthwise conv
       const int T1a = add_buf(n, Kt, 1, Hc, Wc);           // first block: 1x1 at the INPUT resolution
       const int T1 = add_buf(n, Kt, 1, Ho, Wo);
       const int T2 = add_buf(n, Kt, 0, Ho, Wo);
+      // a pointwise layer that writes into the stage buffer.  fp32: natural column order, the kernel scatters column i to
+      // out_cmap[i]; bf16: the columns are packed as the whole slot groups the layer owns (col_map), the kernel stores a
+      // group of 8 columns at out_cmap[first column]
+      auto to_stage = [&](int layer, const std::vector<int32_t>& slot_of) -> int {
+        if (!n->bf16) return add_map(n, slot_of);
+        std::vector<int32_t> cols, chan;
+        zc_columns(slot_of, G, &cols, &chan);
+        SLayer& L = n->layers[layer];
+        L.ncols = (int)cols.size();
+        L.coutp = L.ncols <= 64 ? 64 : (L.ncols <= 128 ? 128 : (L.ncols + 255) / 256 * 256);
+        cols.resize(L.coutp, -1);       // (columns past ncols: zero columns of the packed matrix)
+        chan.resize(L.coutp, -1);
+        L.colmap_id = add_map(n, cols);
+        return add_map(n, chan);
+      };
+      auto to_temp = [&](int layer, int cout) {  // contiguous output channels (a unit temporary): whole 8-channel groups
+        if (!n->bf16) return;
+        n->layers[layer].ncols = (cout + 7) / 8 * 8;
+        n->layers[layer].coutp = cout_pad(cout);
+      };
       {  // -- block 0: two-branch (reference :47-53, :60-61) --
         const std::string bp = sp + "0.";
-        int M_in = -1;
-        if (in_is_stage) M_in = add_map(n, in_pmap);
+        int M_in = -1, M_inpl = -1;
+        if (in_is_stage) {
+          M_in = add_map(n, in_kmap);
+          M_inpl = add_map(n, in_planes_v);
+        }
         std::vector<int32_t> even(h), odd(h);
         for (int i = 0; i < h; ++i) {
-          even[i] = phys[2 * i];
-          odd[i] = phys[2 * i + 1];
+          even[i] = zs.phys0[2 * i];
+          odd[i] = zs.phys0[2 * i + 1];
         }
-        const int M_even = add_map(n, even), M_odd = add_map(n, odd);
         const int l_c00 = add_layer(n, L_DW, bp + "conv0.0", in_c, in_c, in_phys, M_in);
         const int l_c01 = add_layer(n, L_PW, bp + "conv0.1", h, in_c, up8(in_phys), M_in);
         const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, in_c, up8(in_phys), M_in);
         const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, Kt, -1);
         const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, Kt, -1);
+        const int M_even = to_stage(l_c01, even), M_odd = to_stage(l_c2, odd);
+        to_temp(l_c0, h);
         if (stride == 1) {
           add_pwf(n, bp + "conv0.0+conv0.1", Ho, Wo, l_c01, l_c00, in_buf, 0, S, 0, M_even, 1);
+          n->ops.back().planes_map = M_inpl;
         } else {
           add_dw(n, bp + "conv0.0", Hc, Wc, l_c00, in_buf, T0, stride);
           add_pwf(n, bp + "conv0.1", Ho, Wo, l_c01, -1, T0, 0, S, 0, M_even, 1);
         }
         add_pwf(n, bp + "conv.0", Hc, Wc, l_c0, -1, in_buf, 0, T1a, 0, -1, 1);
+        n->ops.back().planes_map = M_inpl;
         if (stride == 1) {
           add_pwf(n, bp + "conv.1+conv.2", Ho, Wo, l_c2, l_c1, T1a, 0, S, 0, M_odd, 1);
         } else {
@@ -435,45 +591,16 @@ void build(rtpose_shufflenet* n) {
       }
       for (int u = 1; u < U; ++u) {  // -- blocks 1..: pass-through half + processed half (reference :31-39, :56-59) --
         const std::string bp = sp + std::to_string(u) + ".";
-        // x2 = L_{u-1}[h:2h): the planes it touches, in ascending order; K = their channels, padded to a whole k-group
-        std::vector<int> slot2logical(Pp, -1);
-        for (int j = h; j < 2 * h; ++j) slot2logical[phys[j]] = j - h;
-        std::vector<int32_t> pln, x2map;
-        for (int pl = 0; pl < Pp / 4; ++pl) {
-          bool any = false;
-          for (int e = 0; e < 4; ++e) any = any || slot2logical[4 * pl + e] >= 0;
-          if (!any) continue;
-          pln.push_back(4 * pl);
-          for (int e = 0; e < 4; ++e) x2map.push_back(slot2logical[4 * pl + e]);
-        }
-        while (x2map.size() % 8) {  // (a zero-weight repeat of the first plane)
-          pln.push_back(pln[0]);
-          for (int e = 0; e < 4; ++e) x2map.push_back(-1);
-        }
-        const int Ku = (int)x2map.size();
-        const int M_x2 = add_map(n, x2map), M_pl = add_map(n, pln);
-        // y_u takes the slots x2 vacates: new channels in the order (consumption time, index), slots ascending
-        std::vector<int> freed(phys.begin() + h, phys.end());
-        std::sort(freed.begin(), freed.end());
-        std::vector<int> yorder(h);
-        for (int i = 0; i < h; ++i) yorder[i] = i;
-        auto ykey = [&](int i) { return ((long)death_from(2 * i + 1, u) << 20) | i; };
-        std::sort(yorder.begin(), yorder.end(), [&](int a, int b) { return ykey(a) < ykey(b); });
-        std::vector<int32_t> yslot(h);
-        for (int r = 0; r < h; ++r) yslot[yorder[r]] = freed[r];
-        const int M_y = add_map(n, yslot);
-        const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, h, Ku, M_x2);
+        const ZcUnit& zu = zs.units[u - 1];
+        const int M_x2 = add_map(n, zu.x2map), M_pl = add_map(n, zu.planes);
+        const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, h, (int)zu.x2map.size(), M_x2);
         const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, Kt, -1);
         const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, Kt, -1);
+        const int M_y = to_stage(l_c2, zu.yslot);
+        to_temp(l_c0, h);
         add_pwf(n, bp + "conv.0", Ho, Wo, l_c0, -1, S, 0, T1, 0, -1, 1);
         n->ops.back().planes_map = M_pl;
         add_pwf(n, bp + "conv.1+conv.2", Ho, Wo, l_c2, l_c1, T1, 0, S, 0, M_y, 1);
-        std::vector<int> np(2 * h);
-        for (int i = 0; i < h; ++i) {
-          np[2 * i] = phys[i];
-          np[2 * i + 1] = yslot[i];
-        }
-        phys.swap(np);
       }
       in_buf = S;
       in_c = C;
@@ -481,7 +608,20 @@ void build(rtpose_shufflenet* n) {
       in_hp = hp;
       in_is_stage = true;
       in_pmap.assign(Pp, -1);
-      for (int j = 0; j < C; ++j) in_pmap[phys[j]] = j;
+      for (int j = 0; j < C; ++j) in_pmap[zs.phys_final[j]] = j;
+      in_kmap.clear();
+      in_planes_v.clear();
+      for (int pl = 0; pl < Pp / G; ++pl) {
+        bool any = false;
+        for (int e = 0; e < G; ++e) any = any || in_pmap[pl * G + e] >= 0;
+        if (!any) continue;
+        in_planes_v.push_back(pl * G);
+        for (int e = 0; e < G; ++e) in_kmap.push_back(in_pmap[pl * G + e]);
+      }
+      while (in_kmap.size() % 16) {  // (K of the readers: whole 16-channel steps; zero-weight repeats of the first plane)
+        in_planes_v.push_back(in_planes_v[0]);
+        for (int e = 0; e < G; ++e) in_kmap.push_back(-1);
+      }
       Hc = Ho;
       Wc = Wo;
       continue;
@@ -645,14 +785,17 @@ void build(rtpose_shufflenet* n) {
     in_is_stage = true;
     in_pmap.assign(2 * hp, -1);
     for (int j = 0; j < C; ++j) in_pmap[fphys(j, h, hp, qt)] = j;
+    in_kmap = in_pmap;  // (these plans read the buffer as one contiguous slice)
+    in_planes_v.clear();
     Hc = Ho;
     Wc = Wo;
   }
 
   // ---- conv5 + heads -------------------------------------------------------------------
   {
-    const int M_in = add_map(n, in_pmap);
-    const int l5 = add_layer(n, L_PW, "network.6", 1024, in_c, up8((int)in_pmap.size()), M_in);
+    const int M_in = add_map(n, in_kmap);
+    const int M_inpl = in_planes_v.empty() ? -1 : add_map(n, in_planes_v);
+    const int l5 = add_layer(n, L_PW, "network.6", 1024, in_c, up8((int)in_kmap.size()), M_in);
     const int lp = add_layer(n, L_PW, "paf", 38, 1024, 1024, -1);
     const int lh = add_layer(n, L_PW, "heatmap", 19, 1024, 1024, -1);
     // fp32 fused plans: conv5 and the heads are ONE launch (pw_head.hip) - the 1024-channel feature has no buffer
@@ -686,6 +829,7 @@ void build(rtpose_shufflenet* n) {
       o.layer[1] = lp;
       o.in_buf[0] = in_buf;
       o.out_buf[0] = OUT;
+      o.planes_map = M_inpl;
       o.relu = 1;
       o.flops = 2.0 * n->N * Hc * Wc * (1024.0 * in_c + 1024.0 * 57);
       n->ops.push_back(o);
@@ -713,6 +857,7 @@ void build(rtpose_shufflenet* n) {
       for (int i = 0; i < 19; ++i) hm[38 + i] = 40 + i;
       const int M_heads = add_map(n, hm);
       add_pwf(n, "conv5", Hc, Wc, l5, -1, in_buf, 0, F, 0, -1, 1);
+      n->ops.back().planes_map = M_inpl;
       add_pwf(n, "paf+heatmap", Hc, Wc, lp, -1, F, 0, OUT, 0, M_heads, 0, -1, -1, 0, 64);
       n->ops.back().flops = 2.0 * n->N * Hc * Wc * 1024.0 * 57;
       return;
@@ -834,8 +979,9 @@ int rtpose_shufflenet_load(rtpose_shufflenet* n, int idx, const float* w, const 
     case L_PW:
       if (n->fused && n->bf16) {  // column-mapped bf16 packing (see pw_fused_bf16.hip)
         const int32_t* cmap = l.colmap_id >= 0 ? reinterpret_cast<const int32_t*>(n->wt + n->maps[l.colmap_id].off) : nullptr;
-        return pack_pw_bf16_launch(w, b, l.cout, l.cin, map, l.cin_packed, l.ncols, cmap, l.coutp, l.col_off,
-                                   n->wt + l.w_off, n->wt + l.b_off, s);
+        // (a column-mapped layer packs ALL coutp columns: the map marks the ones past its stored width as zero columns)
+        return pack_pw_bf16_launch(w, b, l.cout, l.cin, map, l.cin_packed, cmap ? l.coutp : l.ncols, cmap, l.coutp,
+                                   l.col_off, n->wt + l.w_off, n->wt + l.b_off, s);
       }
       if (n->fused && l.ncols > 0 && !l.col_off && l.zero_c1 <= l.zero_c0) {  // column-mapped fp32 packing (pw_fused.hip)
         const int32_t* cmap = l.colmap_id >= 0 ? reinterpret_cast<const int32_t*>(n->wt + n->maps[l.colmap_id].off) : nullptr;
@@ -981,9 +1127,9 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
         }
         if (n->bf16) {
           const bool f32out = o.out_buf[0] == n->out_buf;  // the two heads write the fp32 output record
-          if (!f32out) {  // columns [0, ncols) -> contiguous channels from out_choff (no scatter in bf16)
-            d.cout = l.ncols;
-            d.out_cmap = nullptr;
+          if (!f32out) {  // columns [0, ncols): contiguous channels from out_choff (a unit temporary), or - a layer that
+            d.cout = l.ncols;  // writes into the stage buffer - whole groups of 8 at out_cmap[first column of the group]
+            d.out_cmap = l.colmap_id >= 0 ? imap(o.cmap[0]) : nullptr;
           }
           rc = pw_fused_bf16_launch(&d, f32out ? 1 : 0, n->N, o.H, o.W, s);
         } else {
@@ -1007,6 +1153,7 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
         d1.w_packed = n->wt + l1.w_off;
         d1.bias_packed = n->wt + l1.b_off;
         d1.cin = l1.cin_packed;
+        d1.in_planes = imap(o.planes_map);
         d1.cout = d1.coutp = cout_pad(l1.cout);
         d1.relu = 1;
         d2.w_packed = n->wt + l2.w_off;
