@@ -458,10 +458,12 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
                                                         Lay lo, int H, int W, int H1, int W1, int H2, int W2) {
   __shared__ float s_in[3][kSpI][kSpIP];
   __shared__ float s_st[kSpS * kSpS][kSpCP];
+  __shared__ unsigned char s_ok[kSpS * kSpS];    // conv output of the tile exists (inside the H1 x W1 map)
   const int tid = threadIdx.x;
   const int n = blockIdx.z;
   const int py0 = blockIdx.y * kSpT, px0 = blockIdx.x * kSpT;
   const int sy0 = 2 * py0, sx0 = 2 * px0;        // first conv output of the tile
+  for (int p = tid; p < kSpS * kSpS; p += 256) s_ok[p] = (sy0 + p / kSpS < H1 && sx0 + p % kSpS < W1) ? 1 : 0;
   const int iy0 = 2 * sy0 - 1, ix0 = 2 * sx0 - 1;  // first input pixel of the tile (may be -1: padding)
   {  // the input patch: all of a thread's loads are issued before the first is used (one memory round trip
      // per block instead of fifteen)
@@ -493,33 +495,46 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
     }
   }
   __syncthreads();
-  // conv outputs: a wave owns one 12-channel half (wave & 1) of the positions (wave >> 1) * 64 + lane + 128 k.
-  // The half is uniform per wave, so the 27 x 12 filter taps are SCALAR loads (SGPR operands of the FMAs):
-  // with the taps in LDS the kernel was LDS-instruction bound (4 LDS reads per 12 FMAs, 0.50 ms).
+  // conv outputs on the matrix pipe (round 4; v_mfma_f32_32x32x2_f32): the 17 x 17 positions are the M dimension (10
+  // fragments of 32), the 24 output channels N (one fragment), the 27 taps K (14 steps of 2, the last one half empty).
+  // A operand: lane (position, kh) reads tap k = 2 j + kh of ITS position from the input patch in LDS - an im2col that
+  // exists only as 14 ds_read_b32 per fragment; B operand: the filter value of channel l31 for that tap, 14 registers
+  // loaded once per block.  The scalar-FMA form this replaces issued 240 M VALU instructions per launch (address
+  // arithmetic around 27 LDS reads and 324 FMAs per position, SQ_INSTS_VALU, profiles/r04_shufflenet_pmc_sq.txt)
+  // and was bound by exactly that: 0.38 ms of an 8.9 / 4.05 ms forward.
   {
+    typedef float floatx16 __attribute__((ext_vector_type(16)));
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = wv & 1;
-    const float* wh = w + half * 12;
-    for (int p = (wv >> 1) * 64 + (tid & 63); p < kSpS * kSpS; p += 128) {
+    const int lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    float bw[14];
+    int aoff[14];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+      const int k = 2 * j + kh;            // tap-major K: k = (ky * 3 + kx) * 3 + c
+      const int t = min(k, 26) / 3, c = min(k, 26) - 3 * t;
+      const int ky = t / 3, kx = t - 3 * ky;
+      bw[j] = (l31 < kSpC && k < 27) ? w[(t * 8 + c) * kSpC + l31] : 0.f;   // packed [ky][kx][8][24]
+      aoff[j] = (c * kSpI + ky) * kSpIP + kx;                                // (k = 27 re-reads tap 26 under a zero weight)
+    }
+    const float bv = l31 < kSpC ? bias[l31] : 0.f;
+    for (int f = wv; f < (kSpS * kSpS + 31) / 32; f += 4) {
+      const int p = min(f * 32 + l31, kSpS * kSpS - 1);  // the position this lane feeds (rows past the end replay the last)
       const int sy = p / kSpS, sx = p - sy * kSpS;
-      float acc[12];
+      const float* ab = &s_in[0][2 * sy][2 * sx];
+      floatx16 acc;
 #pragma unroll
-      for (int j = 0; j < 12; ++j) acc[j] = bias[half * 12 + j];
+      for (int r = 0; r < 16; ++r) acc[r] = bv;
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float v = s_in[c][2 * sy + ky][2 * sx + kx];
-            const float* wr = wh + ((ky * 3 + kx) * 8 + c) * kSpC;  // packed [ky][kx][8][24]: uniform address
-#pragma unroll
-            for (int j = 0; j < 12; ++j) acc[j] += v * wr[j];
-          }
+      for (int j = 0; j < 14; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[aoff[j]], bw[j], acc, 0, 0, 0);
+      // C layout: lane = channel l31, register r = position (r / 4) * 8 + 4 kh + r % 4 of the fragment.
       // conv outputs outside the 184 x 184 map do not exist: -inf so that the (ceil-mode) windows ignore them
-      const bool ok = sy0 + sy < H1 && sx0 + sx < W1;
+      if (l31 < kSpC) {
 #pragma unroll
-      for (int j = 0; j < 12; ++j) s_st[p][half * 12 + j] = ok ? fmaxf(acc[j], 0.f) : -INFINITY;
+        for (int r = 0; r < 16; ++r) {
+          const int pp = f * 32 + (r >> 2) * 8 + 4 * kh + (r & 3);
+          if (pp < kSpS * kSpS) s_st[pp][l31] = s_ok[pp] ? fmaxf(acc[r], 0.f) : -INFINITY;
+        }
+      }
     }
   }
   __syncthreads();
