@@ -61,6 +61,32 @@ inline int device_cu_count() {
   return n;
 }
 
+// Division by a launch-time constant without the ~40-instruction integer division sequence: for 0 <= m < 2^31 and d >= 2,
+// floor(m / d) == (m * mul) >> (32 + shift) with l = ceil(log2 d), mul = ceil(2^(31 + l) / d) < 2^32, shift = l - 1
+// (error term m e / (d 2^(31 + l)) < 1 / d because m < 2^31 and e < d <= 2^l).  shift < 0 encodes d == 1.
+struct FastDiv {
+  unsigned mul;
+  int shift;
+};
+inline FastDiv make_fastdiv(int d) {
+  FastDiv f;
+  if (d <= 1) {
+    f.mul = 0;
+    f.shift = -1;
+    return f;
+  }
+  int l = 0;
+  while ((1ll << l) < d) ++l;
+  f.mul = (unsigned)(((1ull << (31 + l)) + (unsigned long long)d - 1) / (unsigned long long)d);
+  f.shift = l - 1;
+  return f;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ int fast_div(int m, const FastDiv f) {
+  return f.shift < 0 ? m : (int)(__umulhi((unsigned)m, f.mul) >> f.shift);
+}
+#endif
+
 // Output channels are padded to the conv kernel's N tile.
 constexpr int kConvBN = 64;
 inline int cout_pad(int cout) { return ceil_div(cout, kConvBN) * kConvBN; }

@@ -65,6 +65,9 @@ struct PwArgs {
   int N, H, W, M;
   int K, coutp, cout, relu;
   int nps;  // DW: LDS plane stride (pixels) of the staged halo
+  // divisions by launch constants (H W, W, passes per strip, tiles per row / column): a work item's pixel arithmetic was
+  // ~300 of the ~700 VALU instructions a wave issues outside its multiply loop - on ALUs it shares with the fp32 MFMAs
+  FastDiv fHW, fW, fnp, ftx, fty;
 };
 
 constexpr int kPwBM = 64;   // pixels per block
@@ -80,11 +83,18 @@ constexpr int kPwHalo = kPwTile + 2;
   asm volatile("" ::: "memory"); \
   __builtin_amdgcn_sched_barrier(0)
 
-__device__ __forceinline__ int pw_pix_q(int m, int HW, int W, int lead, int hs, int ws) {
-  const int n = m / HW, r = m - n * HW;
-  const int y = r / W, x = r - y * W;
-  return lead + (n * hs + y) * ws + x;
+struct PwPix {  // pixel m of the batch as (image, row, column)
+  int n, y, x;
+};
+__device__ __forceinline__ PwPix pw_pix(int m, int HW, int W, const FastDiv fHW, const FastDiv fW) {
+  PwPix p;
+  p.n = fast_div(m, fHW);
+  const int r = m - p.n * HW;
+  p.y = fast_div(r, fW);
+  p.x = r - p.y * W;
+  return p;
 }
+__device__ __forceinline__ int pw_q(const PwPix& p, int lead, int hs, int ws) { return lead + (p.n * hs + p.y) * ws + p.x; }
 
 // WM x WN waves (WM * WN = 4), wave tile (32 MF) x (32 NFW), WM * MF = 2.
 // PERSISTENT: the grid is 2 blocks per CU; a block walks work items (64-pixel strip, BN-column pass)
@@ -138,22 +148,22 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
   };
   auto setup = [&](int wi) -> Item {
     Item it;
-    const int tile = wi / npass;
+    const int tile = fast_div(wi, A.fnp);
     it.pass = wi - tile * npass;
     it.m0 = tile * kPwBM;
     it.n = it.y0 = it.x0 = 0;
     if (DW) {
-      const int tx = tile % tiles_x, r = tile / tiles_x;
-      const int ty = r % tiles_y;
-      it.n = r / tiles_y;
+      const int r = fast_div(tile, A.ftx), tx = tile - r * tiles_x;
+      it.n = fast_div(r, A.fty);
+      const int ty = r - it.n * tiles_y;
       it.y0 = ty * kPwTile;
       it.x0 = tx * kPwTile;
       it.q0 = A.in.lead + (it.n * A.in.hs + it.y0 - 1) * A.in.ws + it.x0 - 1;  // >= 0: lead = ws + 1
       it.q1 = 0;
     } else {
       const int ma = min(it.m0 + px, A.M - 1), mb = min(it.m0 + px + 32, A.M - 1);  // rows past the end replay the last pixel
-      it.q0 = pw_pix_q(ma, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
-      it.q1 = pw_pix_q(mb, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
+      it.q0 = pw_q(pw_pix(ma, HW, A.W, A.fHW, A.fW), A.in.lead, A.in.hs, A.in.ws);
+      it.q1 = pw_q(pw_pix(mb, HW, A.W, A.fHW, A.fW), A.in.lead, A.in.hs, A.in.ws);
     }
     return it;
   };
@@ -167,8 +177,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
     } else {
       const int m = it.m0 + tid;
       const int mc = min(m, A.M - 1);
-      s_qout[par][tid] = m < A.M ? pw_pix_q(mc, HW, A.W, A.out_lead, A.out_hs, A.out_ws) : -1;
-      s_qpt[par][tid] = A.pt.base ? pw_pix_q(mc, HW, A.W, A.pt.lead, A.pt.hs, A.pt.ws) : 0;
+      const PwPix pp = pw_pix(mc, HW, A.W, A.fHW, A.fW);
+      s_qout[par][tid] = m < A.M ? pw_q(pp, A.out_lead, A.out_hs, A.out_ws) : -1;
+      s_qpt[par][tid] = A.pt.base ? pw_q(pp, A.pt.lead, A.pt.hs, A.pt.ws) : 0;
     }
   };
   // DW: halo pixel (hy, hx) of the tile, hp = 10 hy + hx, sits hy * ws + hx pixels after the corner: the
@@ -652,6 +663,11 @@ int pw_fused_launch(const rtpose_pw_desc* d, int N, int H, int W, hipStream_t s)
     lds += (size_t)kPwPL * a.nps * 16 + (size_t)10 * d->cin * 4;
   }
   const int npass_h = d->coutp == 64 ? 1 : (d->coutp == 128 ? 1 : d->coutp / 256);
+  a.fHW = make_fastdiv(H * W);
+  a.fW = make_fastdiv(W);
+  a.fnp = make_fastdiv(npass_h);
+  a.ftx = make_fastdiv(ceil_div(W, kPwTile));
+  a.fty = make_fastdiv(ceil_div(H, kPwTile));
   const int nwork = (dw ? N * ceil_div(H, kPwTile) * ceil_div(W, kPwTile) : ceil_div(a.M, kPwBM)) * npass_h;
   const int grid = nwork < 2 * device_cu_count() ? nwork : 2 * device_cu_count();  // persistent: 2 blocks per CU
   if (d->coutp == 64) return dw ? pw_launch_inst<2, 1, 1, true>(a, grid, lds, s) : pw_launch_inst<2, 1, 1, false>(a, grid, lds, s);

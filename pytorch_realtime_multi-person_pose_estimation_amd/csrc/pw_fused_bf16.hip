@@ -77,6 +77,7 @@ struct Args {
   int N, H, W, M;
   int K, coutp, cout, relu;
   int nps;  // DW: LDS plane stride (pixels) of the staged halo
+  FastDiv fHW, fW, fnp, ftx, fty;  // divisions by launch constants (see pw_fused.hip)
 };
 
 constexpr int kBM = 64;
@@ -91,11 +92,18 @@ constexpr int kHalo = kTile + 2;
   asm volatile("" ::: "memory"); \
   __builtin_amdgcn_sched_barrier(0)
 
-__device__ __forceinline__ int pix_q(int m, int HW, int W, int lead, int hs, int ws) {
-  const int n = m / HW, r = m - n * HW;
-  const int y = r / W, x = r - y * W;
-  return lead + (n * hs + y) * ws + x;
+struct Pix {  // pixel m of the batch as (image, row, column)
+  int n, y, x;
+};
+__device__ __forceinline__ Pix pix_of(int m, int HW, int W, const FastDiv fHW, const FastDiv fW) {
+  Pix p;
+  p.n = fast_div(m, fHW);
+  const int r = m - p.n * HW;
+  p.y = fast_div(r, fW);
+  p.x = r - p.y * W;
+  return p;
 }
+__device__ __forceinline__ int pix_q(const Pix& p, int lead, int hs, int ws) { return lead + (p.n * hs + p.y) * ws + p.x; }
 
 template <int WM, int MF, int NFW, bool DW>
 __global__ __launch_bounds__(256, 2) void pw_gemm_bf16(const Args A) {
@@ -139,22 +147,22 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16(const Args A) {
   };
   auto setup = [&](int wi) -> Item {
     Item it;
-    const int tile = wi / npass;
+    const int tile = fast_div(wi, A.fnp);
     it.pass = wi - tile * npass;
     it.m0 = tile * kBM;
     it.n = it.y0 = it.x0 = 0;
     if (DW) {
-      const int tx = tile % tiles_x, r = tile / tiles_x;
-      const int ty = r % tiles_y;
-      it.n = r / tiles_y;
+      const int r = fast_div(tile, A.ftx), tx = tile - r * tiles_x;
+      it.n = fast_div(r, A.fty);
+      const int ty = r - it.n * tiles_y;
       it.y0 = ty * kTile;
       it.x0 = tx * kTile;
       it.q0 = A.in.lead + (it.n * A.in.hs + it.y0 - 1) * A.in.ws + it.x0 - 1;  // >= 0: lead = ws + 1
       it.q1 = 0;
     } else {
       const int ma = min(it.m0 + px, A.M - 1), mb = min(it.m0 + px + 32, A.M - 1);  // rows past the end replay the last pixel
-      it.q0 = pix_q(ma, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
-      it.q1 = pix_q(mb, HW, A.W, A.in.lead, A.in.hs, A.in.ws);
+      it.q0 = pix_q(pix_of(ma, HW, A.W, A.fHW, A.fW), A.in.lead, A.in.hs, A.in.ws);
+      it.q1 = pix_q(pix_of(mb, HW, A.W, A.fHW, A.fW), A.in.lead, A.in.hs, A.in.ws);
     }
     return it;
   };
@@ -168,8 +176,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16(const Args A) {
     } else {
       const int m = it.m0 + tid;
       const int mc = min(m, A.M - 1);
-      s_qout[par][tid] = m < A.M ? pix_q(mc, HW, A.W, A.out_lead, A.out_hs, A.out_ws) : -1;
-      s_qpt[par][tid] = A.pt.base ? pix_q(mc, HW, A.W, A.pt.lead, A.pt.hs, A.pt.ws) : 0;
+      const Pix pp = pix_of(mc, HW, A.W, A.fHW, A.fW);
+      s_qout[par][tid] = m < A.M ? pix_q(pp, A.out_lead, A.out_hs, A.out_ws) : -1;
+      s_qpt[par][tid] = A.pt.base ? pix_q(pp, A.pt.lead, A.pt.hs, A.pt.ws) : 0;
     }
   };
   // DW: halo pixel (hy, hx) of the tile, hp = 10 hy + hx, sits hy * ws + hx pixels after the corner: the
@@ -575,6 +584,11 @@ int pw_fused_bf16_launch(const rtpose_pw_desc* d, int out_f32, int N, int H, int
   }
   const size_t lds = ((size_t)2 * kPL * kQS + st4) * 16 + (dw ? (size_t)10 * d->cin * 4 : 0);
   const int npass_h = d->coutp <= 128 ? 1 : d->coutp / 256;
+  a.fHW = make_fastdiv(H * W);
+  a.fW = make_fastdiv(W);
+  a.fnp = make_fastdiv(npass_h);
+  a.ftx = make_fastdiv(ceil_div(W, kTile));
+  a.fty = make_fastdiv(ceil_div(H, kTile));
   const int nwork = (dw ? N * ceil_div(H, kTile) * ceil_div(W, kTile) : ceil_div(a.M, kBM)) * npass_h;
   const int grid = nwork < 2 * device_cu_count() ? nwork : 2 * device_cu_count();
   if (d->coutp == 64) return dw ? launch_inst<2, 1, 1, true>(a, grid, lds, s) : launch_inst<2, 1, 1, false>(a, grid, lds, s);

@@ -61,6 +61,7 @@ struct Args {
   int out_cstride, out_choff, out_ws, out_hs, out_lead;
   int N, H, W, M;
   int K1, N1, nitems;
+  FastDiv fHW, fW;  // divisions by launch constants (common.h)
 };
 
 #define RTPOSE_HEAD_PIN()        \
@@ -99,8 +100,8 @@ __global__ __launch_bounds__(256, 1) void pw_head_f32(const Args A) {
   // staging role of a lane: 16-byte plane spl of the pixels spx + 8 u, u < 4 (a pixel's chunk = one 128-byte line)
   const int spl = lane & 7, spx = lane >> 3;
   auto pixel_q = [&](int m, int lead, int hs, int ws) {
-    const int n = m / HW, r = m - n * HW;
-    const int y = r / A.W, x = r - y * A.W;
+    const int n = fast_div(m, A.fHW), r = m - n * HW;
+    const int y = fast_div(r, A.fW), x = r - y * A.W;
     return lead + (n * hs + y) * ws + x;
   };
   unsigned sq[4], sqn[4];  // element offsets of the lane's four staged pixels: this item / the next one
@@ -378,6 +379,8 @@ int pw_head_launch(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2, int N, in
   a.K1 = d1->cin;
   a.N1 = d1->coutp;
   a.nitems = ceil_div((int)M, PX);
+  a.fHW = make_fastdiv(H * W);
+  a.fW = make_fastdiv(W);
   const int waves = a.nitems < 4 * device_cu_count() ? a.nitems : 4 * device_cu_count();  // one wave per SIMD
   hipLaunchKernelGGL(pw_head_f32<8>, dim3(ceil_div(waves, 4)), dim3(256), 0, s, a);
   RTPOSE_HIP_CHECK(hipGetLastError());
