@@ -92,23 +92,36 @@ def test_bench_under_torchrun_matches_the_plain_run(cuda):
     assert 0.95 <= ratio <= 1.05
 
 
-def test_c_host_runs_the_whole_path_without_python(cuda):
+def test_c_host_runs_the_whole_path_without_python(cuda, tmp_path):
     """examples/c_host: rtpose_net_create_opts -> hipMalloc arenas -> bind -> load 92 convs -> finalize -> forward
-    -> decode -> D2H, for the default fp32 (Winograd) plan at a batch whose 7x7 launches run persistent blocks with
-    split tiles (11 images), and for the AUTO plan; exit code 0, a sane rate and a clean device status."""
+    -> scene blend -> decode -> D2H, for the default fp32 plan (guarded per-layer Winograd forms) at a batch whose 7x7
+    launches run persistent blocks with split tiles (11 images), for the direct-kernel plan and for the bf16 plan; exit
+    code 0, a sane rate, people decoded, no table overflow and a clean device status."""
+    import importlib
+    import numpy as np
     exe = os.path.join(ROOT, "examples", "c_host")
     if not os.path.exists(exe):
         pytest.skip("examples/c_host not built (python -c 'import __graft_entry__ as g; g.build()')")
+    sys.path.insert(0, ROOT)
+    synth = importlib.import_module(PKG_NAME + ".synth")
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.path.join(ROOT, PKG_NAME, "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
-    for args in (["11", "0"], ["8", "0", "auto"], ["8", "1"]):
-        p = subprocess.run([exe] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
-                           timeout=600)
+    for args in (["11", "0", "default"], ["8", "0", "direct"], ["8", "1", "default"]):
+        n = int(args[0])
+        heat_s, paf_s, _ = synth.make_batch(n, 368, 368, seed=100)       # the decoder input of bench.py: scene + 1e-3 maps
+        scene = tmp_path / ("scene%d.bin" % n)
+        with open(scene, "wb") as f:
+            f.write(np.ascontiguousarray(heat_s, np.float32).tobytes())
+            f.write(np.ascontiguousarray(paf_s, np.float32).tobytes())
+        p = subprocess.run([exe] + args + [str(scene)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, timeout=600)
         assert p.returncode == 0, p.stdout[-3000:]
         m = re.search(r"([0-9.]+) images/s", p.stdout)
         assert m and float(m.group(1)) > 50.0, p.stdout[-2000:]
-        assert "device status 0" in p.stdout, p.stdout[-2000:]
-        print(p.stdout.strip().splitlines()[-1])
+        assert "device status 0" in p.stdout and "overflow flags 0" in p.stdout, p.stdout[-2000:]
+        h = re.search(r"(\d+) humans", p.stdout)
+        assert h and int(h.group(1)) >= n, p.stdout[-2000:]
+        print(p.stdout.strip().splitlines()[-2])
 
 
 def test_c_host_decodes_people_and_its_records_equal_the_python_paths(cuda, tmp_path):

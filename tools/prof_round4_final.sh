@@ -42,4 +42,15 @@ python $R/tools/bench_tta.py 32 3 > $O/r04_tta.txt 2>&1
 python $R/tools/bench_streaming.py > $O/r04_streaming.txt 2>&1
 python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-traffic --dtype bf16 > $O/r04_bench_bf16.json 2>/dev/null
 cd $R && python -c "import __graft_entry__ as g; g.smoke()" > $O/r04_smoke.txt 2>&1
-for args in "32 0" "11 0" "8 0 direct" "32 2" "32 1"; do LD_LIBRARY_PATH=$R/pytorch_realtime_multi-person_pose_estimation_amd/lib $R/examples/c_host $args; done > $O/r04_c_host.txt 2>&1
+# the torch-free C++ host on bench.py's decoder input (scene + 1e-3 * maps): the scene of synth.make_batch as a file
+python - <<PY
+import importlib, sys
+import numpy as np
+sys.path.insert(0, "$R")
+synth = importlib.import_module("pytorch_realtime_multi-person_pose_estimation_amd.synth")
+for n in (32, 11, 8):
+    heat, paf, _ = synth.make_batch(n, 368, 368, seed=100)
+    with open("/tmp/scene%d.bin" % n, "wb") as f:
+        f.write(np.ascontiguousarray(heat, np.float32).tobytes()); f.write(np.ascontiguousarray(paf, np.float32).tobytes())
+PY
+for args in "32 0 default /tmp/scene32.bin" "11 0 default /tmp/scene11.bin" "8 0 direct /tmp/scene8.bin" "32 2 default /tmp/scene32.bin" "32 1 default /tmp/scene32.bin"; do LD_LIBRARY_PATH=$R/pytorch_realtime_multi-person_pose_estimation_amd/lib $R/examples/c_host $args; done > $O/r04_c_host.txt 2>&1
