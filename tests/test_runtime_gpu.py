@@ -89,7 +89,9 @@ def test_bench_under_torchrun_matches_the_plain_run(cuda):
     assert "RCCL" in b["config"]["parallelism"] and "RCCL" not in a["config"]["parallelism"]
     ratio = b["value"] / a["value"]
     print("bench.py under torchrun / plain: %.1f / %.1f img/s = %.3f" % (b["value"], a["value"], ratio))
-    assert 0.95 <= ratio <= 1.05
+    # the lower bound is the claim (the launcher and the one-rank collective cost nothing); the upper one only catches a
+    # broken plain run - the first process on a cold box has measured 6 % slower than the second
+    assert 0.95 <= ratio <= 1.10
 
 
 def test_c_host_runs_the_whole_path_without_python(cuda, tmp_path):
