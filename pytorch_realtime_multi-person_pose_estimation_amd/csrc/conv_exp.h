@@ -14,7 +14,7 @@
     defined(RTPOSE_EXP_STAGGER) || defined(RTPOSE_EXP_TB1X1) || defined(RTPOSE_EXP_HD) ||               \
     defined(RTPOSE_EXP_RB2) || defined(RTPOSE_EXP_W7_PF) || defined(RTPOSE_EXP_W7_TMASK) || defined(RTPOSE_EXP_W7_LPS) || defined(RTPOSE_EXP_W_EPI) || \
     defined(RTPOSE_EXP_W3_SWOLD) || defined(RTPOSE_EXP_W7_XSPLIT) || defined(RTPOSE_EXP_W7_PRIO) || defined(RTPOSE_EXP_W7_FS2SETS) || defined(RTPOSE_EXP_W7_CGMAJOR) || defined(RTPOSE_EXP_TIMELINE3) || \
-    defined(RTPOSE_EXP_W4_NOXF) || defined(RTPOSE_EXP_W4_NOLOAD) || defined(RTPOSE_EXP_W4_XCDMAP) || defined(RTPOSE_EXP_W4_A3) || defined(RTPOSE_EXP_W4_PRIO) || defined(RTPOSE_EXP_TIMELINE4) || defined(RTPOSE_EXP_W7_NULLDESC) || defined(RTPOSE_EXP_W4_AUX) || defined(RTPOSE_EXP_W4_L0)
+    defined(RTPOSE_EXP_W4_NOXF) || defined(RTPOSE_EXP_W4_NOLOAD) || defined(RTPOSE_EXP_W4_XCDMAP) || defined(RTPOSE_EXP_W4_A3) || defined(RTPOSE_EXP_W4_PRIO) || defined(RTPOSE_EXP_TIMELINE4) || defined(RTPOSE_EXP_W7_NULLDESC) || defined(RTPOSE_EXP_W4_AUX) || defined(RTPOSE_EXP_W4_L0) || defined(RTPOSE_EXP_STAGE_NEAR)
 #error "RTPOSE_EXP_* ablation switches need -DRTPOSE_DEV_BUILD (they are not part of production builds)"
 #endif
 #endif
@@ -135,6 +135,13 @@ inline const char* dev_env(const char* name) {
 #define RTPOSE_EXP_A(load, keep) (keep)
 #else
 #define RTPOSE_EXP_A(load, keep) (load)
+#endif
+// bf16: timing-only - every chunk re-stages chunk 0 of the tile's own halo (L2-resident after the first pass): what does
+// the LATENCY of the staging loads cost, as opposed to their issue slots and LDS writes?
+#ifdef RTPOSE_EXP_STAGE_NEAR
+#define RTPOSE_EXP_STAGE_SRC(next, own) (own)
+#else
+#define RTPOSE_EXP_STAGE_SRC(next, own) (next)
 #endif
 #ifdef RTPOSE_EXP_NO_STAGE
 #define RTPOSE_EXP_STAGE 0

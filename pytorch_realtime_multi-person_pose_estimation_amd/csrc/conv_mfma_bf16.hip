@@ -66,6 +66,15 @@ __device__ __forceinline__ bf16x8 as_bf8(const float4& v) {
 __device__ __forceinline__ unsigned short to_bf16(float v) {
   return __builtin_bit_cast(unsigned short, (__bf16)v);  // v_cvt_pk_bf16_f32: RNE
 }
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf2(float a, float b) {  // (bf16(a), bf16(b)) in one dword, a in the low half
+  const floatx2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float4 as_f4(unsigned a, unsigned b, unsigned c, unsigned d) {
+  return make_float4(__uint_as_float(a), __uint_as_float(b), __uint_as_float(c), __uint_as_float(d));
+}
 
 struct ConvGroup {
   const unsigned short* in;  // bf16 activations
@@ -84,6 +93,7 @@ struct ConvArgs {
   int cin;  // packed input channels (multiple of the chunk size)
   int relu, pool, out_f32;
   int vec_store;  // bf16 output, full N tiles, 16-byte aligned slices: transposed epilogue
+  int tr;         // vec_store without a fused pool, k x k: the transposed-product instances (template TR), no LDS in the epilogue
   int qs;       // LDS pixels per piece plane
   int hw_lds;   // MODE 1: LDS row stride of the halo (pixels)
   int tw_log2;  // MODE 1: log2(tile width); tile height = 128 >> tw_log2
@@ -96,6 +106,21 @@ struct ConvArgs {
 };
 
 constexpr int kBM = 128;
+
+// block id -> (m tile, combo = N tile + ntiles * group).  xcd_remap: the ncombo blocks of an m tile sit on one XCD (ids go
+// round-robin to the 8 XCDs), so the tile's halo is fetched into one L2.  (Round 4, measured and dropped: giving every XCD
+// the combos of ONE branch only, so that its L2 holds 1.6 instead of 3.2 MB of packed 7x7 filters - TCC hit rate 87.1 ->
+// 88.2 %, time -0.2 %; non-temporal output stores: 0 %.  profiles/r04_bf16_conv_experiments.txt)
+__device__ __forceinline__ void decode_block_id(const ConvArgs& A, int bi, int& mt, int& c) {
+  if (A.xcd_remap) {
+    const int xcd = bi & 7, j = bi >> 3;
+    c = j % A.ncombo;
+    mt = (j / A.ncombo) * 8 + xcd;
+  } else {
+    mt = bi % A.mtiles;
+    c = bi / A.mtiles;
+  }
+}
 // depth of the halo staging ring (taps between fetch and park).  The counter behind s_waitcnt
 // is in order, so every wait for a weight piece also waits for all older staging loads: a
 // staging load must be able to take a full HBM/MALL miss (1-3k cycles under load) without
@@ -131,7 +156,14 @@ __device__ __forceinline__ void tile_local_yx(int ml, int tw_log2, int& ty, int&
 // NEXT tile's halo into the idle LDS buffer instead of re-staging itself, so the next tile starts
 // its tap loop at once: the ~11k-cycle prologue (one exposed memory round trip per block) is paid
 // once per block instead of once per tile, and the epilogue's stores drain under the next tile's MFMAs.
-template <int KS, int CK, int MODE, int NBUF, int WM, int MF, int NF, int SP>
+// TR (round 4): the TRANSPOSED product - D^T = W^T X^T, i.e. the weight fragment goes in as the MFMA's row operand and the
+// pixel fragment as its column operand (the registers are the same, only their order in the instruction changes).  A lane
+// then holds ONE pixel (column l31) and 16 output channels (rows 8 (r / 4) + 4 kh + r % 4 of the fragment); with the
+// lane -> weight-column map permuted so that those rows are the channels 16 kh .. 16 kh + 15 IN ORDER, the epilogue is
+// max / convert / two 16-byte stores per fragment straight from the accumulators - no LDS transpose (64 two-byte LDS writes
+// + 8 reads per lane and tile in the slab form: by ablation a quarter of a 7x7 tile's time), no slab, no barrier before the
+// block's next tile.  Used for bf16 / split outputs of full N tiles without a fused pool (launch code: `tr`).
+template <int KS, int CK, int MODE, int NBUF, int WM, int MF, int NF, int SP, bool TR = false>
 __device__ __forceinline__ void conv_tile(const ConvArgs& A, const int grp_first, const int m0_first,
                                           const int ntile_first, float* smem, int bi = 0, const int bi_stride = 0) {
   constexpr int P = KS / 2;
@@ -253,14 +285,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const int grp_first
   if (persist) {
     for (nx_bi = bi + bi_stride; nx_bi < A.nbig; nx_bi += bi_stride) {
       int mt, c;
-      if (A.xcd_remap) {
-        const int xcd = nx_bi & 7, j = nx_bi >> 3;
-        c = j % A.ncombo;
-        mt = (j / A.ncombo) * 8 + xcd;
-      } else {
-        mt = nx_bi % A.mtiles;
-        c = nx_bi / A.mtiles;
-      }
+      decode_block_id(A, nx_bi, mt, c);
       if (mt < A.mtiles) {
         has_next = true;
         nx_m0 = mt * kBM;
@@ -323,8 +348,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const int grp_first
   //      the packed filter (the prefetch runs RB-1 taps ahead) return zero by the bounds check
   const int nchunks = A.cin / CK;
   const int ncol = ntile * BN + wn * (32 * NF) + l31;
+  // TR: fragment row l31 multiplies the weights of channel prow(l31) = 16 ((l31 >> 2) & 1) + 4 (l31 >> 3) + (l31 & 3), so that
+  // register r of lane half kh is channel 16 kh + r
+  const int wcol = TR ? ncol - l31 + 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3) : ncol;
   // piece plane of (k-step gi, lane half kh, hi/lo s) = (2 gi + kh) * SP + s
-  const unsigned lane_b = (unsigned)(kh * SP * g.cout_pad + ncol) * 16u;
+  const unsigned lane_b = (unsigned)(kh * SP * g.cout_pad + wcol) * 16u;
   const unsigned b_it_bytes = (unsigned)(CG * g.cout_pad) * 16u;       // bytes per (chunk, tap)
   const unsigned b_k_bytes = (unsigned)(2 * SP * g.cout_pad) * 16u;    // bytes per k-step
   const unsigned b_s_bytes = (unsigned)g.cout_pad * 16u;               // hi -> lo plane
@@ -379,16 +407,30 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const int grp_first
 #endif
   RTPOSE_TSTAMP(1);
 
-  float bias_r[NF];  // fetched now: at the epilogue this load's latency would be fully exposed
-#pragma unroll
-  for (int fn = 0; fn < NF; ++fn) bias_r[fn] = g.bias[ncol + fn * 32];
   floatx16 acc[MF][NF];
+  if (TR) {
+    // the 32 biases of a fragment through the scalar cache (the address is wave-uniform), selected by lane half
 #pragma unroll
-  for (int fm = 0; fm < MF; ++fm)
+    for (int fn = 0; fn < NF; ++fn) {
+      const float* bp = g.bias + (ntile * BN + wn * (32 * NF) + fn * 32);
 #pragma unroll
-    for (int fn = 0; fn < NF; ++fn)
+      for (int r = 0; r < 16; ++r) {
+        const float b = kh ? bp[16 + r] : bp[r];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[fm][fn][r] = bias_r[fn];  // bias rides in the accumulator
+        for (int fm = 0; fm < MF; ++fm) acc[fm][fn][r] = b;
+      }
+    }
+  } else {
+    float bias_r[NF];  // fetched now: at the epilogue this load's latency would be fully exposed
+#pragma unroll
+    for (int fn = 0; fn < NF; ++fn) bias_r[fn] = g.bias[ncol + fn * 32];
+#pragma unroll
+    for (int fm = 0; fm < MF; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < NF; ++fn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[fm][fn][r] = bias_r[fn];  // bias rides in the accumulator
+  }
 
   int afrag[G][MF];
 #pragma unroll
@@ -397,6 +439,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const int grp_first
     for (int fm = 0; fm < MF; ++fm) afrag[gi][fm] = (2 * gi + kh) * SP * QS + abase[fm];  // hi plane; lo = + QS
   const int rowstep = row_lds;
 
+  // pixel fragment x weight fragment (TR: the other way round - same registers, transposed accumulator)
+  auto mm = [](const float4& px, const float4& wt, const floatx16& c) __attribute__((always_inline)) -> floatx16 {
+    return TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(wt), as_bf8(px), c, 0, 0, 0)
+              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(px), as_bf8(wt), c, 0, 0, 0);
+  };
 // (RTPOSE_EXP_B / _A / _STAGE: identity in production builds, see conv_exp.h)
 #define RTPOSE_PIN()             \
   asm volatile("" ::: "memory"); \
@@ -410,13 +457,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const int grp_first
       _Pragma("unroll") for (int fn = 0; fn < NF; ++fn) {                                      \
         _Pragma("unroll") for (int fm = 0; fm < MF; ++fm) {                                    \
           if (SP == 2) { /* small terms first: hi*lo, lo*hi, then hi*hi */                     \
-            acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                             \
-                as_bf8(ACUR[n][fm][0]), as_bf8(BCUR[fn * G + n][SP - 1]), acc[fm][fn], 0, 0, 0); \
-            acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                             \
-                as_bf8(ACUR[n][fm][SP - 1]), as_bf8(BCUR[fn * G + n][0]), acc[fm][fn], 0, 0, 0); \
+            acc[fm][fn] = mm(ACUR[n][fm][0], BCUR[fn * G + n][SP - 1], acc[fm][fn]);           \
+            acc[fm][fn] = mm(ACUR[n][fm][SP - 1], BCUR[fn * G + n][0], acc[fm][fn]);           \
           }                                                                                    \
-          acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                               \
-              as_bf8(ACUR[n][fm][0]), as_bf8(BCUR[fn * G + n][0]), acc[fm][fn], 0, 0, 0);      \
+          acc[fm][fn] = mm(ACUR[n][fm][0], BCUR[fn * G + n][0], acc[fm][fn]);                  \
         }                                                                                      \
       }                                                                                        \
       RTPOSE_PIN();                                                                            \
@@ -441,7 +485,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const int grp_first
           hl[d] = hl[d + 1];                                                                   \
         }                                                                                      \
         if (ps < st_nsets) { /* uniform */                                                     \
-          hv[kHD - 1] = gload4(next_base + piece_rel(ps));                                     \
+          hv[kHD - 1] = gload4(RTPOSE_EXP_STAGE_SRC(next_base, halo_base) + piece_rel(ps));    \
           hl[kHD - 1] = (tid < st_np_total - ps * 256) ? hn_off + piece_loff(ps) : dummy_loff; \
         } else {                                                                               \
           hv[kHD - 1] = make_float4(0.f, 0.f, 0.f, 0.f);                                       \
@@ -555,7 +599,74 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const int grp_first
   float* out_f = reinterpret_cast<float*>(g.out);
   const float relu_lo = A.relu ? 0.f : -3.0e38f;  // uniform: v = max(v, relu_lo), no select
   const bool pool = MODE == 1 && A.pool;          // (the fused 2x2 max-pool exists for 2-D tiles only)
-  if (A.vec_store) {  // uniform
+  if (TR) {
+    // lane = pixel l31 of fragment fm (column of the transposed product), registers = the channels 16 kh .. 16 kh + 15 of
+    // fragment fn: 32 bytes of bf16 (split: two [hi x 8 | lo x 8] groups) = two (four) 16-byte stores, nothing through LDS
+    int on = 0, oy = 0, ox = 0;
+    if (MODE == 0) {
+      const int m = m0 + wm * (32 * MF) + l31;
+      const int HW = A.H * A.W;
+      on = m / HW;
+      const int r = m - on * HW;
+      oy = r / A.W;
+      ox = r - oy * A.W;
+    }
+    unsigned short* const ob = out_h + g.out_choff + (ntile * BN + wn * (32 * NF) + 16 * kh) * SP;
+#pragma unroll
+    for (int fm = 0; fm < MF; ++fm) {
+      bool ok;
+      size_t q;
+      if (MODE == 0) {
+        ok = m0 + wm * (32 * MF) + fm * 32 + l31 < A.M;
+        q = (size_t)g.out_lead + (size_t)(on * g.out_hs + oy) * g.out_ws + ox;
+        ox += 32;
+        while (ox >= A.W) {
+          ox -= A.W;
+          if (++oy >= A.H) {
+            oy = 0;
+            ++on;
+          }
+        }
+      } else {
+        int ty, tx;
+        tile_local_yx(wm * (32 * MF) + fm * 32 + l31, A.tw_log2, ty, tx);
+        ok = (y0 + ty < A.H) && (x0 + tx < A.W);
+        q = (size_t)g.out_lead + (size_t)(n_img * g.out_hs + y0 + ty) * g.out_ws + x0 + tx;
+      }
+      unsigned short* const op = ob + q * g.out_cstride;
+#pragma unroll
+      for (int fn = 0; fn < NF; ++fn) {
+        unsigned hi[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          hi[i] = pack_bf2(fmaxf(acc[fm][fn][2 * i], relu_lo), fmaxf(acc[fm][fn][2 * i + 1], relu_lo));
+        if (SP == 1) {
+          if (ok) {
+            gstore4(op + fn * 32, as_f4(hi[0], hi[1], hi[2], hi[3]));
+            gstore4(op + fn * 32 + 8, as_f4(hi[4], hi[5], hi[6], hi[7]));
+          }
+        } else {
+          unsigned lo[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            lo[i] = pack_bf2(fmaxf(acc[fm][fn][2 * i], relu_lo) - __uint_as_float(hi[i] << 16),
+                             fmaxf(acc[fm][fn][2 * i + 1], relu_lo) - __uint_as_float(hi[i] & 0xffff0000u));
+          if (ok) {
+            gstore4(op + fn * 64, as_f4(hi[0], hi[1], hi[2], hi[3]));
+            gstore4(op + fn * 64 + 8, as_f4(lo[0], lo[1], lo[2], lo[3]));
+            gstore4(op + fn * 64 + 16, as_f4(hi[4], hi[5], hi[6], hi[7]));
+            gstore4(op + fn * 64 + 24, as_f4(lo[4], lo[5], lo[6], lo[7]));
+          }
+        }
+      }
+    }
+    RTPOSE_TSTAMP(3);
+#ifdef RTPOSE_EXP_TIMELINE
+    __builtin_amdgcn_s_waitcnt(0);  // stores retired (vmcnt) - how long does the ack take?
+    RTPOSE_TSTAMP(4);
+    if (A.dbg && threadIdx.x == 0) A.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+#endif
+  } else if (A.vec_store) {  // uniform
     // The chunk loop ended with a barrier: the halo buffer multiplied last is dead.  Persistent blocks
     // keep the slabs inside that one buffer (the other one already holds the next tile's halo), which is
     // why a wave transposes its tile in two halves of MF/2 fragments (20 KB for the four waves).
@@ -747,7 +858,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const int grp_first
   }  // scalar epilogue
   }  // epilogue
   if (has_next) {
-    __syncthreads();  // every wave is done with its slab before the next tile's staging ring writes that buffer
+    if (!TR) __syncthreads();  // every wave is done with its slab before the next tile's staging ring writes that buffer
     grp = nx_grp;
     m0_arg = nx_m0;
     ntile = nx_nt;
@@ -761,7 +872,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& A, const int grp_first
 
 // 1-D grid, block id -> (group, N tile, M tile); XCD-aware order and half-tile tail exactly
 // as conv_mfma_f32 (conv_mfma.hip).
-template <int KS, int CK, int MODE, int NBUF, int WM, int NF, int SP>
+template <int KS, int CK, int MODE, int NBUF, int WM, int NF, int SP, bool TR>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs A) {
   constexpr int MF = 4 / WM;  // block M tile = 128 pixels either way
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -781,14 +892,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs A) {
   int bi = small ? A.nbig + ((L - A.npersist) >> 1) : L;
   int mt = 0, c = 0;
   for (;;) {  // (persistent blocks skip the padding ids of the remapped order)
-    if (A.xcd_remap) {
-      const int xcd = bi & 7, j = bi >> 3;
-      c = j % A.ncombo;
-      mt = (j / A.ncombo) * 8 + xcd;
-    } else {
-      mt = bi % A.mtiles;
-      c = bi / A.mtiles;
-    }
+    decode_block_id(A, bi, mt, c);
     if (mt < A.mtiles) break;
     if (small || stride == 0) return;
     bi += stride;
@@ -796,12 +900,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16(const ConvArgs A) {
   }
   const int nt = c % A.ntiles, grp = c / A.ntiles;
   if (MODE == 1) {
-    conv_tile<KS, CK, MODE, NBUF, WM, MF, NF, SP>(A, grp, mt, nt, smem);
+    conv_tile<KS, CK, MODE, NBUF, WM, MF, NF, SP, TR>(A, grp, mt, nt, smem);
   } else if (!small) {
-    conv_tile<KS, CK, MODE, NBUF, WM, MF, NF, SP>(A, grp, mt * kBM, nt, smem, bi, stride);
+    conv_tile<KS, CK, MODE, NBUF, WM, MF, NF, SP, TR>(A, grp, mt * kBM, nt, smem, bi, stride);
   } else {
     const int m0 = mt * kBM + ((L - A.npersist) & 1) * (kBM / 2);
-    if (m0 < A.M) conv_tile<KS, CK, MODE, NBUF, WM, MF / 2, NF, SP>(A, grp, m0, nt, smem);
+    if (m0 < A.M) conv_tile<KS, CK, MODE, NBUF, WM, MF / 2, NF, SP, TR>(A, grp, m0, nt, smem);
   }
 }
 
@@ -942,11 +1046,11 @@ static int plan_conv(const rtpose_conv_desc& d, int N, int H, int W, int sp, Con
   return 0;
 }
 
-template <int KS, int CK, int MODE, int NBUF, int WM, int NF, int SP>
-static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+template <int KS, int CK, int MODE, int NBUF, int WM, int NF, int SP, bool TR>
+static int launch_tr(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static PerDeviceOnce attr_set;  // zero-initialised; the attribute is per device
   const int dev = current_device();
-  auto kern = conv_mfma_bf16<KS, CK, MODE, NBUF, WM, NF, SP>;
+  auto kern = conv_mfma_bf16<KS, CK, MODE, NBUF, WM, NF, SP, TR>;
   if (!attr_set.is_set(dev)) {
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -955,6 +1059,14 @@ static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) 
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
+}
+// the transposed form exists for the k x k kernels (a.tr is never set for k = 1)
+template <int KS, int CK, int MODE, int NBUF, int WM, int NF, int SP>
+static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  if constexpr (KS != 1) {
+    if (a.tr) return launch_tr<KS, CK, MODE, NBUF, WM, NF, SP, true>(a, grid, lds, s);
+  }
+  return launch_tr<KS, CK, MODE, NBUF, WM, NF, SP, false>(a, grid, lds, s);
 }
 
 }  // namespace bf
@@ -1024,6 +1136,14 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
 #ifdef RTPOSE_EXP_SCALAR_STORE
   a.vec_store = 0;
 #endif
+  {
+    static int tr_env = -1;  // developer A/B: RTPOSE_BF16_TR=0 keeps the LDS-transposing epilogue
+    if (tr_env < 0) {
+      const char* e = dev_env("RTPOSE_BF16_TR");
+      tr_env = e ? atoi(e) : 1;
+    }
+    a.tr = (a.vec_store && !d0.pool && d0.k != 1 && tr_env) ? 1 : 0;
+  }
   a.qs = pl.qs;
   a.hw_lds = pl.hw_lds;
   a.tw_log2 = pl.tw_log2;
@@ -1074,7 +1194,7 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
     const size_t half_slabs = (size_t)4 * slab_bytes(mf / 2, pl.nf, sp);
     const size_t buf_bytes = (size_t)(pl.ck / 8 * sp) * pl.qs * 16;
     if (persist_env && pl.mode == 0 && pl.nbuf == 2 && d0.k != 1 && same_pitch && slots >= 8 && a.nbig > slots &&
-        (!a.vec_store || half_slabs <= buf_bytes))
+        (!a.vec_store || a.tr || half_slabs <= buf_bytes))
       a.npersist = slots;
   }
   dim3 grid((unsigned)(a.npersist + 2 * (ids - a.nbig)), 1, 1);
@@ -1103,7 +1223,7 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
 #endif
   {
     const size_t slab = (size_t)4 * slab_bytes(pl.wm == 1 ? 4 : 2, pl.nf, sp);
-    if (a.vec_store && pl.lds_bytes < slab) pl.lds_bytes = slab;
+    if (a.vec_store && !a.tr && pl.lds_bytes < slab) pl.lds_bytes = slab;
   }
   if (split) {
 #define RTPOSE_CONV_CASE_X3(KS_, MODE_, NBUF_)                                                    \

@@ -502,7 +502,7 @@ void build(rtpose_shufflenet* n) {
   // ---- stages ------------------------------------------------------------------------
   const int widths[3] = {116, 232, 464};
   const int nblocks[3] = {4, 8, 4};
-  int in_buf = X1, in_c = 24, in_h = 24, in_hp = 24;  // previous buffer: logical C, half h, padded hp
+  int in_buf = X1, in_c = 24;  // previous buffer and its logical channel count
   bool in_is_stage = false;
   std::vector<int32_t> in_pmap;  // previous STAGE buffer: physical channel -> logical channel (-1: nothing lives there)
   // ... as its readers walk it (zero-copy plans): only the planes that hold live channels are gathered - K position k
@@ -604,8 +604,6 @@ void build(rtpose_shufflenet* n) {
       }
       in_buf = S;
       in_c = C;
-      in_h = h;
-      in_hp = hp;
       in_is_stage = true;
       in_pmap.assign(Pp, -1);
       for (int j = 0; j < C; ++j) in_pmap[zs.phys_final[j]] = j;
@@ -780,8 +778,6 @@ void build(rtpose_shufflenet* n) {
     }
     in_buf = cur;
     in_c = C;
-    in_h = h;
-    in_hp = hp;
     in_is_stage = true;
     in_pmap.assign(2 * hp, -1);
     for (int j = 0; j < C; ++j) in_pmap[fphys(j, h, hp, qt)] = j;

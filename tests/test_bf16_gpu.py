@@ -25,7 +25,7 @@ def _rb(t):
 
 
 def _run_conv_bf16(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, seed, groups=1,
-                   cin_pad=None, out_f32=False):
+                   cin_pad=None, out_f32=False, aligned=False):
     lib, Layout = capi.lib, capi.Layout
     g = torch.Generator().manual_seed(seed)
     x = _rb(torch.randn(n, cin, h, w, generator=g))
@@ -50,7 +50,10 @@ def _run_conv_bf16(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out
     capi.check(lib.rtpose_nchw_to_layout_bf16(capi.ptr(xd), capi.ptr(xin), C.byref(lin), cin, cin_p, n, h, w,
                                               stream))
     ho, wo = (h // 2, w // 2) if pool else (h, w)
-    cstride_out = cout * groups + 3  # odd stride + channel offsets: exercises slices
+    # odd stride + channel offsets: exercises slices (scalar stores); aligned: 16-byte aligned slices, the layout the
+    # network uses - full N tiles then take the 16-byte-store epilogues (transposed product / LDS slabs with a fused pool)
+    cstride_out = cout * groups + (16 if aligned else 3)
+    ch0 = 8 if aligned else 1
     descs = (capi.ConvDesc * groups)()
     outs, keep = [], []
     lout_full = Layout.padded(cstride_out, ho, wo, pad_out)
@@ -67,12 +70,12 @@ def _run_conv_bf16(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out
         d = descs[gi]
         d.inp, d.w_packed, d.bias_packed, d.out = xin.data_ptr(), wp.data_ptr(), bp.data_ptr(), obuf.data_ptr()
         d.lin = lin
-        d.lout = Layout.padded(cstride_out, ho, wo, pad_out, choff=gi * cout + 1)
+        d.lout = Layout.padded(cstride_out, ho, wo, pad_out, choff=gi * cout + ch0)
         d.cin, d.cout, d.k, d.relu, d.pool = cin_p, cout, k, int(relu), int(pool)
     capi.check(lib.rtpose_conv2d_bf16(descs, groups, n, h, w, int(out_f32), stream), "rtpose_conv2d_bf16")
     for gi in range(groups):
         o = torch.empty(n, cout, ho, wo, device=dev)
-        lo = Layout.padded(cstride_out, ho, wo, pad_out, choff=gi * cout + 1)
+        lo = Layout.padded(cstride_out, ho, wo, pad_out, choff=gi * cout + ch0)
         if out_f32:
             capi.check(lib.rtpose_layout_to_nchw(capi.ptr(obuf), C.byref(lo), capi.ptr(o), cout, n, ho, wo, stream))
         else:
@@ -145,6 +148,31 @@ def test_conv_bf16_fp32_output(capi, cuda, case):
 def test_conv_bf16_grouped_and_tail(capi, cuda):
     # two branches in one grid; 5*46*46 pixels = 83 strips: exercises the half-tile tail path
     outs, refs = _run_conv_bf16(capi, cuda, 5, 46, 46, 128, 128, 7, 1, 0, 3, 3, seed=7, groups=2)
+    for o, r in zip(outs, refs):
+        _check(o, r, False)
+
+
+ALIGNED_CASES = [
+    # n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, groups
+    (2, 46, 46, 128, 128, 7, 1, 0, 3, 3, 1),   # strips, 1 x 4 waves
+    (5, 46, 46, 128, 128, 7, 1, 0, 3, 3, 2),   # two branches, persistent blocks + the half-tile tail
+    (1, 70, 66, 128, 128, 7, 0, 0, 3, 0, 1),   # 7x7 in 2-D tiles with ragged edges, no ReLU
+    (5, 6, 6, 32, 64, 7, 1, 0, 3, 3, 1),       # strips spanning several images, one 64-column tile
+    (2, 46, 46, 256, 512, 3, 1, 0, 1, 1, 1),   # 2 x 2 waves of 64 x 64, 64-channel chunks
+    (1, 100, 92, 128, 256, 3, 1, 0, 1, 1, 1),  # 2-D tiles with ragged right / bottom edges
+    (3, 23, 17, 64, 64, 3, 1, 0, 1, 3, 1),     # strips with a ragged last tile, 3x3
+    (1, 96, 80, 64, 64, 3, 1, 1, 1, 1, 1),     # fused pool: the LDS-slab epilogue stays
+]
+
+
+@pytest.mark.parametrize("case", ALIGNED_CASES)
+def test_conv_bf16_aligned_slices_take_the_16_byte_store_epilogues(capi, cuda, case):
+    """Round 4: bf16 outputs of full N tiles in 16-byte aligned slices (every k x k layer of the network) are computed as
+    the TRANSPOSED product and stored from the accumulators, 32 bytes per lane and fragment
+    (csrc/conv_mfma_bf16.hip, template TR); same contract as the scalar-store cases above, and nothing written outside the slice."""
+    n, h, w, cin, cout, k, relu, pool, pin, pout, groups = case
+    outs, refs = _run_conv_bf16(capi, cuda, n, h, w, cin, cout, k, relu, pool, pin, pout, seed=31 + k, groups=groups,
+                                aligned=True)
     for o, r in zip(outs, refs):
         _check(o, r, False)
 

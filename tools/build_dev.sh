@@ -18,7 +18,7 @@ for f in $FILES; do
   o=tools/exp/objs/$f.o
   if [ -n "$ONLY" ]; then
     if [ "$f" = "$ONLY" ]; then
-      o=tools/exp/objs/$f.variant.o
+      o=tools/exp/objs/$f.$(basename $OUT .so).o
       $CC "$@" -c $SRC/$f.hip -o $o &
     elif [ ! -f $o ] || [ $SRC/$f.hip -nt $o ]; then
       $CC -c $SRC/$f.hip -o $o &
