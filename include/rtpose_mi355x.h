@@ -117,6 +117,16 @@ typedef struct rtpose_conv_desc {
                    come from the packing of the same form.  Any other value is refused
                    (RTPOSE_E_INVAL): ZERO-INITIALISE descriptors (memset / `= {0}`) - the struct has
                    grown by trailing fields and may again.                                  */
+  int32_t in_plane_pixels;  /* F(4x4,3x3) launches (k = 3, wino_m = 4) only; every other launch refuses a non-zero
+                   value.  0: `in` is pixel-major as §1 describes.  Q > 0: the input slice is stored as CHANNEL PLANES -
+                   channel c of the pixel with index q (§1) at float ((c / 8) * Q + q) * 8 + c % 8 of `in`, c counted
+                   from channel 0 of the buffer (lin.choff, a multiple of 8, selects the first plane; lin.cstride is not
+                   used); Q >= rtpose_layout_pixels(&lin, N, H, W) is the number of pixel slots per plane.  A chunk of
+                   the kernel reads 8 channels of the 36 pixels of a patch: in planes those are whole 128-byte lines
+                   instead of a quarter of each (csrc/conv_wino4.hip; 3x3 layers of the 32-image forward -8 %).       */
+  int32_t out_plane_pixels; /* the same for the output slice (cout and lout.choff multiples of 8): a chain of F(4x4,3x3)
+                   convs keeps its intermediates in planes, its first launch reads and its last one writes pixel-major.
+                   rtpose_conv_first_planes writes planes for conv1_1.                                               */
 } rtpose_conv_desc;
 
 /* Launch one conv, or `ngroups` (<= 2) convs of identical geometry in one
@@ -135,6 +145,13 @@ int rtpose_pack_conv_first(const float* w_oihw, const float* bias, float* w_pack
 int rtpose_conv_first(const float* x_nchw, const float* x_layout, const rtpose_layout* lx,
                       const float* w_packed, float* out, const rtpose_layout* lout, int relu, int N,
                       int H, int W, void* stream);
+/* The same conv writing its 64 channels as 8 channel planes of `out_plane_pixels` pixel slots each (see
+ * rtpose_conv_desc.in_plane_pixels; out_plane_pixels >= rtpose_layout_pixels(lout, N, H, W), lout->choff a multiple of 8,
+ * lout->cstride unused): computed as the transposed product - a lane holds one pixel and 16 channels - so that 32 lanes
+ * store 1 KB runs of a plane.  Same values, bit for bit. */
+int rtpose_conv_first_planes(const float* x_nchw, const float* x_layout, const rtpose_layout* lx,
+                             const float* w_packed, float* out, const rtpose_layout* lout, int out_plane_pixels,
+                             int relu, int N, int H, int W, void* stream);
 
 /* ---- two pointwise convs back to back: nn.Conv2d(128, 128, 1) + nn.ReLU -> nn.Conv2d(128, cout2 <= 64, 1), the
  * Mconv6 / Mconv7 pair that ends every stage-2..6 branch (lib/network/rtpose_vgg.py:120-127), as ONE launch

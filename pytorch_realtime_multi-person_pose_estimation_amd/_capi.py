@@ -42,7 +42,8 @@ class ConvDesc(C.Structure):
     _fields_ = [("inp", C.c_void_p), ("w_packed", C.c_void_p), ("bias_packed", C.c_void_p),
                 ("out", C.c_void_p), ("lin", Layout), ("lout", Layout), ("cin", C.c_int32),
                 ("cout", C.c_int32), ("k", C.c_int32), ("relu", C.c_int32), ("pool", C.c_int32),
-                ("out_cmap", C.c_void_p), ("wino_m", C.c_int32)]
+                ("out_cmap", C.c_void_p), ("wino_m", C.c_int32), ("in_plane_pixels", C.c_int32),
+                ("out_plane_pixels", C.c_int32)]
 
 
 class NetOptions(C.Structure):
@@ -104,6 +105,7 @@ _SIGS = {
     "rtpose_conv_first_packed_floats": (_sz, []),
     "rtpose_pack_conv_first": (_i, [_vp, _vp, _vp, _vp]),
     "rtpose_conv_first": (_i, [_vp, _vp, _LP, _vp, _vp, _LP, _i, _i, _i, _i, _vp]),
+    "rtpose_conv_first_planes": (_i, [_vp, _vp, _LP, _vp, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
     "rtpose_conv2d_winograd_fits": (_i, [C.POINTER(ConvDesc), _i, _i, _i]),
     "rtpose_packed_weight_floats_winograd": (_sz, [_i, _i, _i]),
     "rtpose_pack_conv_weights_winograd": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),

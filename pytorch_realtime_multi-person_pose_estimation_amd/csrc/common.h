@@ -87,6 +87,17 @@ __device__ __forceinline__ int fast_div(int m, const FastDiv f) {
 }
 #endif
 
+// channel-plane slices (rtpose_conv_desc.in_plane_pixels / out_plane_pixels) exist for the F(4x4,3x3) kernel only
+inline bool desc_has_planes(const rtpose_conv_desc* d, int ngroups) {
+  for (int g = 0; d && g < ngroups && g < 2; ++g)
+    if (d[g].in_plane_pixels || d[g].out_plane_pixels) return true;
+  return false;
+}
+#define RTPOSE_REFUSE_PLANES(d, ngroups, who)                                                                        \
+  if (::rtpose::desc_has_planes(d, ngroups))                                                                         \
+  return ::rtpose::fail(RTPOSE_E_INVAL, who ": channel-plane slices (in_plane_pixels / out_plane_pixels) are read and " \
+                                            "written by F(4x4,3x3) launches only (zero-initialise descriptors)")
+
 // Output channels are padded to the conv kernel's N tile.
 constexpr int kConvBN = 64;
 inline int cout_pad(int cout) { return ceil_div(cout, kConvBN) * kConvBN; }

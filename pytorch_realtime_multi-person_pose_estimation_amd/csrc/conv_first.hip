@@ -11,6 +11,13 @@
 // (K = 28, one zero row), the 28 x 64 filter matrix lives in registers (28 values per lane), the A operand of a step
 // is ONE ds_read_b32 per lane at a compile-time offset, and a wave's 2 rows x 64 channels leave as 128-byte runs per
 // pixel (lane = channel).  No im2col buffer, no layout conversion pass, no 8-channel padding of the input.
+// Round 4, PLANES = true: the output as 8 channel planes ([channels / 8][pixel slots][8], rtpose_conv_desc.in_plane_pixels:
+// what the F(4x4,3x3) kernel of conv1_2 reads in whole lines).  Computed as the TRANSPOSED product - filters as the row
+// operand, pixels as the column operand, the same registers - so that a lane holds ONE pixel and 16 channels of a 32-channel
+// half: register r of lane half kh is channel 8 (r / 4) + 4 kh + r % 4, i.e. floats 4 kh .. 4 kh + 3 of plane r / 4 - a 16-byte
+// store per plane, and the two lane halves of the 32 pixels of a row segment fill ONE contiguous 1 KB run of that plane.
+// (First version: channels permuted so that a lane owned whole 32-byte plane entries - every store instruction then wrote
+// every other 16 bytes of two runs: conv1_1 0.30 -> 0.37 ms.)
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -33,6 +40,7 @@ struct Args {
   const float* bias;      // 64 floats
   float* out;
   int o_cstride, o_choff, o_ws, o_hs, o_lead;
+  int o_pq;               // PLANES: pixel slots per plane
   int N, H, W, relu, tiles_x, tiles_y;
 };
 
@@ -41,6 +49,7 @@ __host__ __device__ constexpr int tap_off(int k) {
   return k >= 27 ? 0 : ((k / 9) * HH + (k % 9) / 3) * WW + (k % 3);
 }
 
+template <bool PLANES>
 __global__ __launch_bounds__(256) void conv_first_kernel(const Args A) {
   __shared__ float halo[3 * HH * WW];
   const int tid = threadIdx.x;
@@ -78,11 +87,20 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const Args A) {
   floatx16 acc[2][2];  // [row of the wave][column half]
 #pragma unroll
   for (int nh = 0; nh < 2; ++nh) {
-    const float b0 = A.bias[nh * 32 + l31];
+    if (PLANES) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+      for (int r = 0; r < 16; ++r) {
+        const float b0 = A.bias[nh * 32 + 8 * (r >> 2) + 4 * kh + (r & 3)];
+        acc[0][nh][r] = b0;
+        acc[1][nh][r] = b0;
+      }
+    } else {
+      const float b0 = A.bias[nh * 32 + l31];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nh][r] = b0;
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nh][r] = b0;
+    }
   }
   __syncthreads();
 
@@ -94,11 +112,32 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const Args A) {
     const float a0 = hb[off], a1 = hb[off + WW];
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh) {
-      acc[0][nh] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, wv[nh][st], acc[0][nh], 0, 0, 0);
-      acc[1][nh] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, wv[nh][st], acc[1][nh], 0, 0, 0);
+      acc[0][nh] = PLANES ? __builtin_amdgcn_mfma_f32_32x32x2f32(wv[nh][st], a0, acc[0][nh], 0, 0, 0)
+                          : __builtin_amdgcn_mfma_f32_32x32x2f32(a0, wv[nh][st], acc[0][nh], 0, 0, 0);
+      acc[1][nh] = PLANES ? __builtin_amdgcn_mfma_f32_32x32x2f32(wv[nh][st], a1, acc[1][nh], 0, 0, 0)
+                          : __builtin_amdgcn_mfma_f32_32x32x2f32(a1, wv[nh][st], acc[1][nh], 0, 0, 0);
     }
   }
 
+  if (PLANES) {
+    // ---- store: lane = pixel x0 + l31 of the row, registers 4 j .. 4 j + 3 = floats 4 kh .. 4 kh + 3 of plane 4 half + j ----
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int y = y0 + 2 * wave + mt;
+      if (y >= A.H || x0 + l31 >= A.W) continue;
+      const size_t q = (size_t)A.o_lead + (size_t)(n * A.o_hs + y) * A.o_ws + x0 + l31;
+      float* op = A.out + ((size_t)(A.o_choff >> 3) * A.o_pq + q) * 8 + 4 * kh;
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float4 v = make_float4(acc[mt][nh][4 * j], acc[mt][nh][4 * j + 1], acc[mt][nh][4 * j + 2], acc[mt][nh][4 * j + 3]);
+          if (A.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+          *reinterpret_cast<float4*>(op + (size_t)(4 * nh + j) * A.o_pq * 8) = v;
+        }
+    }
+    return;
+  }
   // ---- store: register r of a lane = pixel x0 + (r / 4) * 8 + 4 kh + r % 4 of the row, channel half * 32 + l31 ----
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -143,11 +182,16 @@ int conv_first_pack_launch(const float* w_oihw, const float* bias, float* wp, hi
 
 // x_nchw != NULL: dense NCHW source; else the layout `lx` on `x_lay` (>= 3 channels per pixel)
 int conv_first_launch(const float* x_nchw, const float* x_lay, const rtpose_layout* lx, const float* wp, float* out,
-                      const rtpose_layout* lo, int relu, int N, int H, int W, hipStream_t s) {
+                      const rtpose_layout* lo, int out_plane_pixels, int relu, int N, int H, int W, hipStream_t s) {
   using namespace first;
-  if ((!x_nchw && (!x_lay || !lx)) || !wp || !out || !lo || N <= 0 || H <= 0 || W <= 0)
+  if ((!x_nchw && (!x_lay || !lx)) || !wp || !out || !lo || N <= 0 || H <= 0 || W <= 0 || out_plane_pixels < 0)
     return fail(RTPOSE_E_INVAL, "conv_first: bad arguments");
-  if (lo->choff + 64 > lo->cstride) return fail(RTPOSE_E_INVAL, "conv_first: output slice exceeds cstride");
+  if (out_plane_pixels) {
+    if ((lo->choff % 8) || (size_t)out_plane_pixels < rtpose_layout_pixels(lo, N, H, W))
+      return fail(RTPOSE_E_INVAL, "conv_first: channel planes start at a multiple of 8 channels and hold the layout's pixels");
+  } else if (lo->choff + 64 > lo->cstride) {
+    return fail(RTPOSE_E_INVAL, "conv_first: output slice exceeds cstride");
+  }
   Args a;
   memset(&a, 0, sizeof(a));
   a.x_nchw = x_nchw;
@@ -167,6 +211,7 @@ int conv_first_launch(const float* x_nchw, const float* x_lay, const rtpose_layo
   a.o_ws = lo->ws;
   a.o_hs = lo->hs;
   a.o_lead = lo->lead;
+  a.o_pq = out_plane_pixels;
   a.N = N;
   a.H = H;
   a.W = W;
@@ -175,7 +220,8 @@ int conv_first_launch(const float* x_nchw, const float* x_lay, const rtpose_layo
   a.tiles_y = ceil_div(H, TH);
   const long blocks = (long)N * a.tiles_x * a.tiles_y;
   if (blocks > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv_first: grid too large");
-  hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  if (out_plane_pixels) hipLaunchKernelGGL(conv_first_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(conv_first_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -193,7 +239,15 @@ int rtpose_pack_conv_first(const float* w_oihw, const float* bias, float* w_pack
 
 int rtpose_conv_first(const float* x_nchw, const float* x_layout, const rtpose_layout* lx, const float* w_packed,
                       float* out, const rtpose_layout* lout, int relu, int N, int H, int W, void* stream) {
-  return rtpose::conv_first_launch(x_nchw, x_layout, lx, w_packed, out, lout, relu, N, H, W, rtpose::as_stream(stream));
+  return rtpose::conv_first_launch(x_nchw, x_layout, lx, w_packed, out, lout, 0, relu, N, H, W, rtpose::as_stream(stream));
+}
+
+int rtpose_conv_first_planes(const float* x_nchw, const float* x_layout, const rtpose_layout* lx, const float* w_packed,
+                             float* out, const rtpose_layout* lout, int out_plane_pixels, int relu, int N, int H, int W,
+                             void* stream) {
+  if (out_plane_pixels <= 0) return rtpose::fail(RTPOSE_E_INVAL, "conv_first_planes: out_plane_pixels must be positive");
+  return rtpose::conv_first_launch(x_nchw, x_layout, lx, w_packed, out, lout, out_plane_pixels, relu, N, H, W,
+                                   rtpose::as_stream(stream));
 }
 
 }  // extern "C"

@@ -734,6 +734,7 @@ static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) 
 
 int conv2d_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s) {
   if (!d || ngroups < 1 || ngroups > 2) return fail(RTPOSE_E_INVAL, "conv2d: ngroups must be 1 or 2");
+  RTPOSE_REFUSE_PLANES(d, ngroups, "conv2d");
   const rtpose_conv_desc& d0 = d[0];
   if (d0.k != 1 && d0.k != 3 && d0.k != 7) return fail(RTPOSE_E_INVAL, "conv2d: k must be 1, 3 or 7");
   if (d0.cin % 8 != 0 || d0.cin <= 0) return fail(RTPOSE_E_INVAL, "conv2d: cin must be a multiple of 8");

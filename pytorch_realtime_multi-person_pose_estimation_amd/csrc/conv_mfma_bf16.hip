@@ -1079,6 +1079,7 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
   using namespace bf;
   const int sp = split ? 2 : 1;
   if (!d || ngroups < 1 || ngroups > 2) return fail(RTPOSE_E_INVAL, "conv2d_bf16: ngroups must be 1 or 2");
+  RTPOSE_REFUSE_PLANES(d, ngroups, "conv2d_bf16");
   const rtpose_conv_desc& d0 = d[0];
   if (d0.k != 1 && d0.k != 3 && d0.k != 7) return fail(RTPOSE_E_INVAL, "conv2d_bf16: k must be 1, 3 or 7");
   if (d0.cin % 16 != 0 || d0.cin <= 0) return fail(RTPOSE_E_INVAL, "conv2d_bf16: cin must be a multiple of 16");

@@ -183,6 +183,8 @@ int conv_tail_launch(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int
   using namespace tail;
   if (!conv_tail_fits(d1, d2, ngroups) || N <= 0 || H <= 0 || W <= 0)
     return fail(RTPOSE_E_INVAL, "conv_tail: needs 128 -> 128 | 512 (+ReLU) -> <= 64 pointwise convs");
+  RTPOSE_REFUSE_PLANES(d1, ngroups, "conv_tail");
+  RTPOSE_REFUSE_PLANES(d2, ngroups, "conv_tail");
   const long M = (long)N * H * W;
   if (M > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv_tail: tensor too large");
   Args a;

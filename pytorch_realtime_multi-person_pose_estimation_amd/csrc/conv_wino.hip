@@ -756,6 +756,7 @@ int conv2d_wino_ok(int cin, int cout, int k) {
 int conv2d_wino_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, hipStream_t s) {
   using namespace wino;
   if (!d || ngroups < 1 || ngroups > 2) return fail(RTPOSE_E_INVAL, "conv2d_winograd: ngroups must be 1 or 2");
+  RTPOSE_REFUSE_PLANES(d, ngroups, "conv2d_winograd (2x2)");
   const rtpose_conv_desc& d0 = d[0];
   if (!conv2d_wino_ok(d0.cin, d0.cout, d0.k))
     return fail(RTPOSE_E_INVAL, "conv2d_winograd: k must be 3 and cin a multiple of %d", wino_ck(d0.cout, d0.cin));

@@ -43,6 +43,15 @@
 //    through the transforms they cancel only up to rounding, and an image would depend on its neighbour in the batch.
 //  * B = transformed filters packed [chunk][frequency pair][kq][cout_pad][2 frequencies][2 channels]
 //    (rtpose_pack_conv_weights_winograd3, m = 4).
+//  * round 4 - CHANNEL-PLANE activations (rtpose_conv_desc.in_plane_pixels / out_plane_pixels): a chunk reads 32 bytes per
+//    patch pixel.  Pixel-major (NHWC) that is a quarter of a 128-byte line; the rest of the line belongs to the next three
+//    chunks, thousands of cycles later, and by then the line has left the L1 and often the L2: every line is moved up to four
+//    times (FETCH_SIZE 3.7x the layer inputs).  Stored as planes of 8 channels - element (pixel q, channel c) at
+//    ((c / 8) * Q + q) * 8 + c % 8, Q = the buffer's pixel slots - the 32 bytes of the six pixels of a patch row are ONE
+//    192-byte run, used in full by the six loads a lane issues back to back: 3x3 layers of the 32-image forward 8.13 -> 7.50
+//    ms.  Nothing else changes: the patch loader has two more runtime strides (pixel pitch 32 bytes, chunk pitch = one plane),
+//    the epilogue's column offset becomes (ncol / 8) * plane + ncol % 8.  Both sides are per launch, so the first and the
+//    last conv of a chain convert for free (csrc/net.hip decides per buffer).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -70,8 +79,16 @@ struct Group {
   int in_cstride, in_choff, in_ws, in_hs, in_lead;
   int out_cstride, out_choff, out_ws, out_hs, out_lead;
   int cout, cout_pad;
+  int in_pq, out_pq;  // > 0: the slice is stored as planes of 8 channels, this many pixel slots per plane (0: pixel-major)
   size_t in_bytes, w_bytes, out_bytes;
 };
+
+// strides of a slice in either storage: floats per pixel step, float offset of the slice's first channel, bytes per
+// 8-channel chunk step
+__device__ __forceinline__ int px_floats(int cstride, int pq) { return pq ? 8 : cstride; }
+__device__ __forceinline__ size_t ch0_floats(int choff, int pq) { return pq ? (size_t)(choff >> 3) * pq * 8 + (choff & 7) : choff; }
+// float offset of output column `col` (relative to the slice) from its pixel's base
+__device__ __forceinline__ unsigned col_floats(int col, int pq) { return pq ? (unsigned)(col >> 3) * pq * 8 + (col & 7) : col; }
 
 struct Args {
   Group g[2];
@@ -198,7 +215,10 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
   i32x4 rin;
   unsigned pv[4];  // byte offsets of pixel 0 and of the pixels 3, 4, 5 (clamped to the gap column) of the row
   int lt = j0, lc = 3;
-  const unsigned pxb = (unsigned)g.in_cstride * 4;
+  const int cs_ld = px_floats(g.in_cstride, g.in_pq);
+  const unsigned pxb = (unsigned)cs_ld * 4;                                 // bytes per pixel step
+  const unsigned ckb = g.in_pq ? (unsigned)g.in_pq * (CK * 4) : CK * 4;     // bytes per chunk step
+  const size_t in_ch0 = ch0_floats(g.in_choff, g.in_pq);
   auto set_loader = [&](int mt, i32x4& r_, unsigned (&v_)[4]) {
     size_t q0;
     {
@@ -212,15 +232,15 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
     const int ty = r / A.TX, tx = r - ty * A.TX;
     const int yy = min(4 * ty - 1 + py, A.H);  // rows past the image: the zero gap row
     const size_t qq = (size_t)g.in_lead + (size_t)(n * g.in_hs + yy) * g.in_ws + (4 * tx - 1);
-    const size_t o0 = q0 * g.in_cstride + g.in_choff;
+    const size_t o0 = q0 * cs_ld + in_ch0;
     r_ = make_rsrc(g.in + o0, g.in_bytes - o0 * 4);
-    v_[0] = (unsigned)(((qq - q0) * g.in_cstride + cg1 * 4) * 4);
+    v_[0] = (unsigned)(((qq - q0) * cs_ld + cg1 * 4) * 4);
 #pragma unroll
     for (int n5 = 3; n5 < 6; ++n5) v_[n5 - 2] = v_[0] + (unsigned)min(n5, A.W + 1 - 4 * tx) * pxb;  // columns past W: the gap column
   };
   F4 p[6];
   auto load_piece = [&](const i32x4& r_, const unsigned (&v_)[4], int chunk, int n5) {
-    const unsigned cb = (unsigned)chunk * (CK * 4);
+    const unsigned cb = (unsigned)chunk * ckb;
 #ifdef RTPOSE_EXP_W4_AUX  // cache policy bits of the patch loads (1 sc0, 2 nt, 16 sc1): no effect / nt 2x slower
     const f32x4 t = n5 < 3 ? llvm_raw_buffer_load_v4f32(r_, (int)v_[0], (int)(cb + n5 * pxb), RTPOSE_EXP_W4_AUX)
                            : llvm_raw_buffer_load_v4f32(r_, (int)v_[n5 - 2], (int)cb, RTPOSE_EXP_W4_AUX);
@@ -469,10 +489,11 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
         const int ty = r / A.TX;
         q0 = wt_q(n, ty, r - ty * A.TX);
       }
-      const size_t oo0 = ((size_t)g.out_lead + (size_t)q0) * g.out_cstride + g.out_choff;
+      const int cs_st = px_floats(g.out_cstride, g.out_pq);
+      const size_t oo0 = ((size_t)g.out_lead + (size_t)q0) * cs_st + ch0_floats(g.out_choff, g.out_pq);
       const i32x4 rout = make_rsrc(g.out + oo0, g.out_bytes - oo0 * 4);
-      const unsigned cs4 = (unsigned)g.out_cstride * 4, row4 = (unsigned)g.out_ws * cs4;
-      const unsigned col4 = (unsigned)ncol * 4;
+      const unsigned cs4 = (unsigned)cs_st * 4, row4 = (unsigned)g.out_ws * cs4;
+      const unsigned col4 = col_floats(ncol, g.out_pq) * 4;
       int tcur = (A.mt0 + mt) * NT + FH * 16 + 4 * kq;
       int sn = tcur / TT, sy, sx;
       {
@@ -584,7 +605,9 @@ __global__ __launch_bounds__(384, 2) void wino4s_f32(const Args A) {
   const i32x4 rw = make_rsrc(g.w, g.w_bytes);
   i32x4 rin;
   unsigned pv0, pvx;  // byte offset of pixel 0 of the row; pixels of the row before the gap column (W + 1 - 4 tx)
-  const unsigned pxb = (unsigned)g.in_cstride * 4;
+  const int cs_ld = px_floats(g.in_cstride, g.in_pq);
+  const unsigned pxb = (unsigned)cs_ld * 4;
+  const unsigned ckb = g.in_pq ? (unsigned)g.in_pq * (CK * 4) : CK * 4;
   {
     size_t q0;
     {
@@ -598,14 +621,14 @@ __global__ __launch_bounds__(384, 2) void wino4s_f32(const Args A) {
     const int ty = r / A.TX, tx = r - ty * A.TX;
     const int yy = min(4 * ty - 1 + py, A.H);  // rows past the image: the zero gap row
     const size_t qq = (size_t)g.in_lead + (size_t)(n * g.in_hs + yy) * g.in_ws + (4 * tx - 1);
-    const size_t o0 = q0 * g.in_cstride + g.in_choff;
+    const size_t o0 = q0 * cs_ld + ch0_floats(g.in_choff, g.in_pq);
     rin = make_rsrc(g.in + o0, s1 ? g.in_bytes - o0 * 4 : 0);
-    pv0 = (unsigned)(((qq - q0) * g.in_cstride + cg1 * 4) * 4);
+    pv0 = (unsigned)(((qq - q0) * cs_ld + cg1 * 4) * 4);
     pvx = (unsigned)(A.W + 1 - 4 * tx);
   }
   F4 p[6];
   auto load_piece = [&](int chunk, int n5) {
-    const unsigned cb = (unsigned)min(chunk, nchunks - 1) * (CK * 4);  // (past the last chunk: that chunk again)
+    const unsigned cb = (unsigned)min(chunk, nchunks - 1) * ckb;  // (past the last chunk: that chunk again)
     p[n5] = n5 < 3 ? bload(rin, pv0, cb + n5 * pxb) : bload(rin, pv0 + min((unsigned)n5, pvx) * pxb, cb);
   };
   // (SQ_LDS_BANK_CONFLICT is 14 % of SQ_LDS_IDX_ACTIVE in this kernel - 0 in wino4_f32 - and a further swizzle of the
@@ -742,10 +765,11 @@ __global__ __launch_bounds__(384, 2) void wino4s_f32(const Args A) {
         const int ty = r / A.TX;
         q0 = wt_q(n, ty, r - ty * A.TX);
       }
-      const size_t oo0 = ((size_t)g.out_lead + (size_t)q0) * g.out_cstride + g.out_choff;
+      const int cs_st = px_floats(g.out_cstride, g.out_pq);
+      const size_t oo0 = ((size_t)g.out_lead + (size_t)q0) * cs_st + ch0_floats(g.out_choff, g.out_pq);
       const i32x4 rout = make_rsrc(g.out + oo0, g.out_bytes - oo0 * 4);
-      const unsigned cs4 = (unsigned)g.out_cstride * 4, row4 = (unsigned)g.out_ws * cs4;
-      const unsigned col4 = (unsigned)ncol * 4;
+      const unsigned cs4 = (unsigned)cs_st * 4, row4 = (unsigned)g.out_ws * cs4;
+      const unsigned col4 = col_floats(ncol, g.out_pq) * 4;
       unsigned off[2];
       bool okv[2];
       int ylim[2], xlim[2];
@@ -921,6 +945,17 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
     if (di.lin.choff + di.cin > di.lin.cstride)
       return fail(RTPOSE_E_INVAL, "conv2d_winograd: input slice exceeds cstride");
     if (di.out_cmap) return fail(RTPOSE_E_INVAL, "conv2d_winograd: out_cmap is not supported");
+    if (di.in_plane_pixels < 0 || di.out_plane_pixels < 0 ||
+        (di.in_plane_pixels && ((di.lin.choff % 8) || (size_t)di.in_plane_pixels < rtpose_layout_pixels(&di.lin, N, H, W))) ||
+        (di.out_plane_pixels &&
+         ((di.lout.choff % 8) || (di.cout % 8) ||
+          (size_t)di.out_plane_pixels < rtpose_layout_pixels(&di.lout, N, di.pool ? H / 2 : H, di.pool ? W / 2 : W))))
+      return fail(RTPOSE_E_INVAL, "conv2d_winograd (4x4): channel-plane slices start at a multiple of 8 channels (the output "
+                                  "has a multiple of 8 of them) and a plane holds at least the layout's pixels");
+    // per-lane offsets are 32 bits and the descriptors clamp at 2 GiB: a plane slice spans (channels / 8) planes
+    if ((di.in_plane_pixels && (size_t)(di.lin.choff + di.cin) / 8 * di.in_plane_pixels * 32 > (size_t)winoc::kMaxRange) ||
+        (di.out_plane_pixels && (size_t)(di.lout.choff + cout_pad(di.cout)) / 8 * di.out_plane_pixels * 32 > (size_t)winoc::kMaxRange))
+      return fail(RTPOSE_E_INVAL, "conv2d_winograd (4x4): channel-plane slice beyond 2 GiB");
     Group& g = a.g[i];
     g.in = di.in;
     g.w = di.w_packed;
@@ -938,10 +973,15 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
     g.out_lead = di.lout.lead;
     g.cout = di.cout;
     g.cout_pad = cout_pad(di.cout);
-    g.in_bytes = rtpose_layout_pixels(&di.lin, N, H, W) * (size_t)di.lin.cstride * sizeof(float);
+    g.in_pq = di.in_plane_pixels;
+    g.out_pq = di.out_plane_pixels;
+    // bytes addressable from the buffer base: the whole pixel-major tensor, or the planes up to the slice's last one
+    g.in_bytes = g.in_pq ? (size_t)(di.lin.choff + di.cin) / 8 * g.in_pq * 32
+                         : rtpose_layout_pixels(&di.lin, N, H, W) * (size_t)di.lin.cstride * sizeof(float);
     g.w_bytes = packed_weight_floats_wino4(di.cout, di.cin) * sizeof(float);
-    g.out_bytes = rtpose_layout_pixels(&di.lout, N, di.pool ? H / 2 : H, di.pool ? W / 2 : W) *
-                  (size_t)di.lout.cstride * sizeof(float);
+    g.out_bytes = g.out_pq ? (size_t)(di.lout.choff + di.cout) / 8 * g.out_pq * 32
+                           : rtpose_layout_pixels(&di.lout, N, di.pool ? H / 2 : H, di.pool ? W / 2 : W) *
+                                 (size_t)di.lout.cstride * sizeof(float);
   }
   a.N = N;
   a.H = H;

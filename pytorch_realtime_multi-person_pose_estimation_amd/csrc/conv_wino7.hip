@@ -1069,6 +1069,7 @@ int conv2d_wino7_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
   using namespace wino7;
   fm = resolve_fm(fm);
   if (!d || ngroups < 1 || ngroups > 2) return fail(RTPOSE_E_INVAL, "conv2d_winograd: ngroups must be 1 or 2");
+  RTPOSE_REFUSE_PLANES(d, ngroups, "conv2d_winograd (7x7)");
   const rtpose_conv_desc& d0 = d[0];
   if (d0.k != 7 || d0.pool || !conv2d_wino7_fits(d0.cin, d0.cout, N, H, W, d0.lin.hs, fm))
     return fail(RTPOSE_E_INVAL, "conv2d_winograd: no F(%d,7) instance for cin %d cout %d at %d x %d x %d", fm, d0.cin,

@@ -48,7 +48,7 @@ int conv_tail_launch(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int
 size_t conv_first_packed_floats();
 int conv_first_pack_launch(const float* w_oihw, const float* bias, float* wp, hipStream_t s);
 int conv_first_launch(const float* x_nchw, const float* x_lay, const rtpose_layout* lx, const float* wp, float* out,
-                      const rtpose_layout* lo, int relu, int N, int H, int W, hipStream_t s);
+                      const rtpose_layout* lo, int out_plane_pixels, int relu, int N, int H, int W, hipStream_t s);
 int pack_weights_launch(const float* w, const float* bias, int cout, int cin_src, int k,
                         const int32_t* cin_map, int cin_packed, float* wp, float* bp, hipStream_t s);
 // bf16 path (conv_mfma_bf16.hip)
@@ -68,6 +68,11 @@ struct Buf {
   size_t floats = 0;
   rtpose_layout lay{};
   int C = 0, H = 0, W = 0;
+  // fp32 plans: the buffer is stored as 8-channel planes of `plane_px` pixel slots (mark_plane_bufs) - what the forms of
+  // its producer and consumers allow; `stale`: its bytes were written in the other storage and must be cleared first
+  // (the gaps of either storage are data positions of the other)
+  int plane_px = 0;
+  bool stale = false;
 };
 
 struct ConvW {
@@ -140,6 +145,7 @@ struct rtpose_net {
   // captured once per keep_intermediates setting on a private non-blocking stream that is
   // joined to the caller's stream by events, so it also works under the legacy NULL stream
   int graph_mode = -1;             // -1 unread, 0 off (default), 1 on (RTPOSE_GRAPH=1)
+  bool zeroed_at_bind = false;     // rtpose_net_bind cleared the workspace (nothing to clear before the first forward)
   int forwards = 0;                // the first forward runs directly (lazy statics, attributes)
   hipStream_t gstream = nullptr;
   hipEvent_t gev_in = nullptr, gev_out = nullptr;
@@ -284,6 +290,43 @@ void pick_forms(rtpose_net* n) {
     ConvW &a = n->convs[o.conv_idx[0]], &b = n->convs[o.conv_idx[1]];
     const int f = a.form < b.form ? a.form : b.form;  // 3x3: 0 < 3 < 43, 7x7: 0 < 4 < 6: direct is the lowest
     a.form = b.form = f;
+  }
+}
+
+// Channel-plane storage (conv_wino4.hip) for every buffer that only F(4x4,3x3) launches - and conv1_1 - touch: written by
+// ONE conv (conv1_1's own kernel or a conv in form 43; a branch of a grouped launch counts) as a whole, read only by convs in
+// form 43 as a whole.  Depends on the
+// forms, so it is re-derived whenever they are; a buffer that changes storage is cleared before the next forward.
+void mark_plane_bufs(rtpose_net* n) {
+  const int nb = (int)n->bufs.size();
+  std::vector<int> writers(nb, 0), readers(nb, 0);
+  std::vector<char> ok(nb, 1);
+  for (const Op& o : n->ops) {
+    const bool conv = o.kind == OP_CONV;
+    for (int g = 0; g < (o.ngroups > 0 ? o.ngroups : 1); ++g) {
+      const int bi = o.in_buf[g], bo = o.out_buf[g];
+      const ConvW* c = conv ? &n->convs[o.conv_idx[g]] : nullptr;
+      if (bi >= 0) {
+        ++readers[bi];
+        if (!(conv && c->form == 43 && o.in_choff[g] == 0 && c->cin_packed == n->bufs[bi].C)) ok[bi] = 0;
+      }
+      if (bo >= 0) {
+        ++writers[bo];
+        if (!(conv && (c->form == 43 || c->first) && o.out_choff[g] == 0 && c->cout == n->bufs[bo].C))
+          ok[bo] = 0;
+      }
+    }
+  }
+  for (int b = 0; b < nb; ++b) {
+    Buf& bf = n->bufs[b];
+    const size_t px = bf.C > 0 ? bf.floats / (size_t)bf.C : 0;  // pixel slots of the buffer (>= the layout's pixels)
+    const bool planes = !n->bf16 && ok[b] && writers[b] == 1 && readers[b] >= 1 && bf.C % 8 == 0 &&
+                        px * (size_t)bf.C * sizeof(float) < 0x7ffffffeull && px <= 0x7fffffffull;
+    const int want = planes ? (int)px : 0;
+    if (want != bf.plane_px) {
+      bf.plane_px = want;
+      bf.stale = true;
+    }
   }
 }
 
@@ -593,6 +636,7 @@ int rtpose_net_create_opts(int N, int H, int W, const rtpose_net_options* opt, r
   build_plan(n);
   if (!forms_need_amps(n)) {  // AUTO waits for the filters (rtpose_net_finalize_weights)
     pick_forms(n);
+    mark_plane_bufs(n);
     n->forms_final = true;
   }
   *out = n;
@@ -643,6 +687,9 @@ int rtpose_net_bind(rtpose_net* net, void* workspace, size_t workspace_bytes, vo
     g = nullptr;
   }
   net->forwards = 0;
+  // a zeroed workspace suits either storage of a buffer; a caller-kept one is taken to hold pixel-major data with clean gaps
+  net->zeroed_at_bind = zero_workspace != 0;
+  for (Buf& b : net->bufs) b.stale = !zero_workspace && b.plane_px != 0;
   net->amps_read = false;
   net->seen_gen = ~0ull;
   if (forms_need_amps(net)) net->forms_final = false;
@@ -749,6 +796,7 @@ int rtpose_net_finalize_weights(rtpose_net* net, void* stream) {
   const int rc = read_amps(net, as_stream(stream));
   if (rc) return rc;
   pick_forms(net);
+  mark_plane_bufs(net);
   net->forms_final = true;
   for (hipGraphExec_t& g : net->gexec) {  // a captured launch list may hold other forms
     if (g) (void)hipGraphExecDestroy(g);
@@ -886,6 +934,12 @@ static int net_forward_impl(rtpose_net* net, const float* x_nchw, void* stream) 
     const int rcf = rtpose_net_finalize_weights(net, stream);
     if (rcf) return rcf;
   }
+  for (Buf& b : net->bufs) {  // buffers that changed between pixel-major and channel-plane storage (forms re-derived)
+    if (!b.stale) continue;
+    if (net->forwards > 0 || !net->zeroed_at_bind)
+      RTPOSE_HIP_CHECK(hipMemsetAsync(net->ws + b.off_floats, 0, b.floats * sizeof(float), s));
+    b.stale = false;
+  }
   const bool prof = net->profiling && !net->ev.empty();
   const size_t nops = net->ops.size();
   if (net->graph_mode < 0) {
@@ -984,10 +1038,13 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
       }
       case OP_CONV: {
         rtpose_conv_desc d[2];
+        memset(d, 0, sizeof(d));
         for (int g = 0; g < o.ngroups; ++g) {
           const ConvW& c = net->convs[o.conv_idx[g]];
           const Buf& bi = net->bufs[o.in_buf[g]];
           const Buf& bo = net->bufs[o.out_buf[g]];
+          d[g].in_plane_pixels = bi.plane_px;
+          d[g].out_plane_pixels = bo.plane_px;
           d[g].in = net->ws + bi.off_floats;
           d[g].out = net->ws + bo.off_floats;
           d[g].w_packed = net->wt + (c.form == 3    ? c.w_off_w3
@@ -1018,7 +1075,7 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
           const ConvW& c = net->convs[o.conv_idx[0]];
           const bool direct_src = x_nchw && first == 0;  // the image itself; else the plan's NHWC8 input buffer
           rc = conv_first_launch(direct_src ? x_nchw : nullptr, d[0].in, &d[0].lin, net->wt + c.w_off_first, d[0].out,
-                                 &d[0].lout, o.relu, N, o.H, o.W, s);
+                                 &d[0].lout, d[0].out_plane_pixels, o.relu, N, o.H, o.W, s);
           break;
         }
         const int form = net->convs[o.conv_idx[0]].form;  // grouped convs run one form (pick_forms)

@@ -1163,6 +1163,7 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
       }
       case O_PW: {
         rtpose_conv_desc d[2];
+        memset(d, 0, sizeof(d));
         for (int g = 0; g < o.ngroups; ++g) {
           const SLayer& l = n->layers[o.layer[g]];
           const SBuf& bi = n->bufs[o.in_buf[g]];

@@ -305,6 +305,164 @@ def test_winograd4_small_grid_form_is_bit_identical(capi, cuda):
             assert torch.equal(a[first:first + count], b)
 
 
+def _to_planes(pm, q_slots, lead_planes=0, fill=0.0):
+    """pixel-major [Q, C] -> channel planes [lead_planes + C / 8][q_slots][8] (flat); unused slots / planes = `fill`."""
+    q, c = pm.shape
+    out = torch.full((lead_planes + c // 8, q_slots, 8), fill, device=pm.device)
+    out[lead_planes:, :q] = pm.view(q, c // 8, 8).permute(1, 0, 2)
+    return out.reshape(-1)
+
+
+def _from_planes(buf, q_slots):
+    """channel planes (flat) -> pixel-major [q_slots, 8 * planes]"""
+    return buf.view(-1, q_slots, 8).permute(1, 0, 2).reshape(q_slots, -1).contiguous()
+
+
+def _run_conv4_planes(capi, dev, n, h, w, cin, cout, relu, pool, pad_in, pad_out, seed, groups, in_planes, out_planes):
+    """F(4x4,3x3) through the C ABI with the input and / or the output stored as channel planes
+    (rtpose_conv_desc.in_plane_pixels / out_plane_pixels); same random stream as _run_conv."""
+    lib, Layout = capi.lib, capi.Layout
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, h, w, generator=g)
+    ws, bs = [], []
+    for gi in range(groups):
+        ws.append((torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5).to(dev))
+        bs.append((torch.randn(cout, generator=g) * 0.1).to(dev))
+    stream = capi.current_stream()
+    lin = Layout.padded(cin, h, w, pad_in)
+    q_in = lib.rtpose_layout_pixels(C.byref(lin), n, h, w)
+    xin = torch.zeros(q_in * cin, device=dev)
+    xd = x.contiguous().to(dev)
+    capi.check(lib.rtpose_nchw_to_layout(capi.ptr(xd), capi.ptr(xin), C.byref(lin), cin, cin, n, h, w, stream))
+    torch.cuda.synchronize()
+    qs_in = q_in + 5                               # more slots per plane than the layout has pixels
+    if in_planes:                                  # one plane of junk in front: the slice starts at channel 8
+        xin = _to_planes(xin.view(q_in, cin), qs_in, lead_planes=1, fill=7.0)
+        xin[:qs_in * 8] = 7.0
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    ctot = cout * groups + 8
+    lout = Layout.padded(ctot, ho, wo, pad_out)
+    q_out = lib.rtpose_layout_pixels(C.byref(lout), n, ho, wo)
+    qs_out = q_out + 3
+    obuf = torch.zeros((qs_out if out_planes else q_out) * ctot, device=dev)
+    descs = (capi.ConvDesc * groups)()
+    keep = []
+    for gi in range(groups):
+        wp = torch.zeros(lib.rtpose_packed_weight_floats_winograd3(cout, cin, 4), device=dev)
+        bp = torch.zeros(lib.rtpose_packed_bias_floats(cout), device=dev)
+        capi.check(lib.rtpose_pack_conv_weights_winograd3(capi.ptr(ws[gi]), capi.ptr(bs[gi]), cout, cin, 4, None, cin,
+                                                          capi.ptr(wp), capi.ptr(bp), stream))
+        keep += [wp, bp]
+        d = descs[gi]
+        d.inp, d.w_packed, d.bias_packed, d.out = xin.data_ptr(), wp.data_ptr(), bp.data_ptr(), obuf.data_ptr()
+        d.lin = Layout.padded(cin + 8, h, w, pad_in, choff=8) if in_planes else lin
+        d.lout = Layout.padded(ctot, ho, wo, pad_out, choff=8 + gi * cout)
+        d.cin, d.cout, d.k, d.relu, d.pool, d.wino_m = cin, cout, 3, int(relu), int(pool), 4
+        d.in_plane_pixels = qs_in if in_planes else 0
+        d.out_plane_pixels = qs_out if out_planes else 0
+    capi.check(lib.rtpose_conv2d_winograd_ex(descs, groups, n, h, w, None, 0, stream), "rtpose_conv2d_winograd_ex (planes)")
+    torch.cuda.synchronize()
+    pm = _from_planes(obuf, qs_out)[:q_out].contiguous() if out_planes else obuf
+    outs = []
+    for gi in range(groups):
+        o = torch.empty(n, cout, ho, wo, device=dev)
+        lo = Layout.padded(ctot, ho, wo, pad_out, choff=8 + gi * cout)
+        capi.check(lib.rtpose_layout_to_nchw(capi.ptr(pm), C.byref(lo), capi.ptr(o), cout, n, ho, wo, stream))
+        outs.append(o.cpu())
+    torch.cuda.synchronize()
+    total, inner = obuf.abs().sum().item(), sum(o.abs().sum().item() for o in outs)
+    assert abs(total - inner) <= 1e-3 * max(1.0, inner), "conv wrote outside its slice / into the gaps / into the slack slots"
+    return outs
+
+
+PLANE_CASES = [
+    # n, h, w, cin, cout, relu, pool, pad_in, pad_out, groups
+    (2, 46, 46, 64, 128, 1, 0, 1, 1, 1),      # small-grid form (wino4s_f32)
+    (40, 46, 46, 64, 128, 1, 0, 1, 1, 1),     # persistent blocks
+    (3, 96, 80, 64, 64, 1, 1, 1, 1, 1),       # fused pool
+    (5, 7, 9, 48, 24, 0, 0, 1, 3, 1),         # tiny maps, ragged cout (24 = 3 planes), no ReLU
+    (20, 45, 47, 128, 128, 1, 0, 3, 3, 2),    # two branches in one grid, odd sizes, one round + a left-over launch
+]
+
+
+@pytest.mark.parametrize("case", PLANE_CASES)
+def test_winograd4_channel_planes_are_bit_identical_to_pixel_major(capi, cuda, case):
+    """Round 4: the F(4x4,3x3) kernel reads and / or writes activations stored as planes of 8 channels
+    (rtpose_conv_desc.in_plane_pixels / out_plane_pixels: the storage the executor keeps between the convs of the VGG front
+    end) - only addresses change: every combination gives the bits of the pixel-major launch, nothing lands in the gaps, the
+    slack slots of a plane or a neighbouring plane, and a junk plane in front of the slice is not read."""
+    n, h, w, cin, cout, relu, pool, pin, pout, groups = case
+    ref = _run_conv4_planes(capi, cuda, n, h, w, cin, cout, relu, pool, pin, pout, 77, groups, False, False)
+    for inp, outp in ((True, False), (False, True), (True, True)):
+        got = _run_conv4_planes(capi, cuda, n, h, w, cin, cout, relu, pool, pin, pout, 77, groups, inp, outp)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), (inp, outp)
+    if n <= 5:   # and the pixel-major launch is the one the other tests pin to torch's CPU conv2d
+        g = torch.Generator().manual_seed(77)
+        x = torch.randn(n, cin, h, w, generator=g)
+        for gi in range(groups):
+            wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+            b = torch.randn(cout, generator=g) * 0.1
+            y = F.conv2d(x, wt, b, padding=1)
+            y = F.relu(y) if relu else y
+            y = F.max_pool2d(y, 2, 2, 0) if pool else y
+            assert (ref[gi] - y).abs().max().item() <= TOL * max(1.0, y.abs().max().item())
+
+
+def test_channel_planes_are_refused_where_no_kernel_reads_them(capi, cuda):
+    lib, Layout = capi.lib, capi.Layout
+    d = (capi.ConvDesc * 1)()
+    buf = torch.zeros(1 << 16, device=cuda)
+    d[0].inp = d[0].w_packed = d[0].bias_packed = d[0].out = buf.data_ptr()
+    d[0].lin = Layout.padded(32, 8, 8, 1)
+    d[0].lout = Layout.padded(64, 8, 8, 1)
+    d[0].cin, d[0].cout, d[0].k, d[0].relu = 32, 64, 3, 1
+    d[0].in_plane_pixels = 4096
+    assert lib.rtpose_conv2d(d, 1, 1, 8, 8, None) != 0 and "channel-plane" in capi.last_error()
+    d[0].wino_m = 2
+    assert lib.rtpose_conv2d_winograd_ex(d, 1, 1, 8, 8, None, 0, None) != 0 and "channel-plane" in capi.last_error()
+    d[0].wino_m = 4
+    d[0].in_plane_pixels = 10                     # fewer slots than the layout has pixels
+    assert lib.rtpose_conv2d_winograd_ex(d, 1, 1, 8, 8, None, 0, None) != 0 and "plane" in capi.last_error()
+    d[0].in_plane_pixels = 4096
+    d[0].lin = Layout.padded(40, 8, 8, 1, choff=4)   # a slice that does not start on a plane
+    assert lib.rtpose_conv2d_winograd_ex(d, 1, 1, 8, 8, None, 0, None) != 0 and "plane" in capi.last_error()
+    d[0].lin = Layout.padded(32, 8, 8, 1)
+    d[0].out_plane_pixels = 4096
+    d[0].cout = 20                                   # not whole planes
+    assert lib.rtpose_conv2d_winograd_ex(d, 1, 1, 8, 8, None, 0, None) != 0 and "plane" in capi.last_error()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 72), (1, 37, 45), (1, 368, 368)])
+def test_first_layer_kernel_writes_channel_planes_bit_identically(capi, cuda, shape):
+    """rtpose_conv_first_planes (the transposed product: a lane holds one pixel and 16 channels) against rtpose_conv_first:
+    the same bits, the slack slots and the neighbouring planes untouched."""
+    lib, Layout = capi.lib, capi.Layout
+    n, h, w = shape
+    g = torch.Generator().manual_seed(h * 1000 + w + 1)
+    x = (torch.rand(n, 3, h, w, generator=g) - 0.5).to(cuda)
+    wd = (torch.randn(64, 3, 3, 3, generator=g) * (2.0 / 27) ** 0.5).to(cuda)
+    bd = (torch.randn(64, generator=g) * 0.1).to(cuda)
+    stream = capi.current_stream()
+    wp = torch.zeros(lib.rtpose_conv_first_packed_floats(), device=cuda)
+    capi.check(lib.rtpose_pack_conv_first(capi.ptr(wd), capi.ptr(bd), capi.ptr(wp), stream))
+    lo_pm = Layout.padded(64, h, w, 1)
+    q = lib.rtpose_layout_pixels(C.byref(lo_pm), n, h, w)
+    o_pm = torch.zeros(q * 64, device=cuda)
+    capi.check(lib.rtpose_conv_first(capi.ptr(x), None, None, capi.ptr(wp), capi.ptr(o_pm), C.byref(lo_pm), 1, n, h, w, stream))
+    qs = q + 7
+    lo_pl = Layout.padded(80, h, w, 1, choff=8)     # planes 1..8 of a 10-plane buffer
+    o_pl = torch.zeros(qs * 80, device=cuda)
+    capi.check(lib.rtpose_conv_first_planes(capi.ptr(x), None, None, capi.ptr(wp), capi.ptr(o_pl), C.byref(lo_pl), qs, 1,
+                                            n, h, w, stream), "rtpose_conv_first_planes")
+    torch.cuda.synchronize()
+    pm = _from_planes(o_pl, qs)
+    assert torch.equal(pm[:q, 8:72], o_pm.view(q, 64))
+    assert pm[:, :8].abs().sum().item() == 0 and pm[:, 72:].abs().sum().item() == 0 and pm[q:].abs().sum().item() == 0
+    assert lib.rtpose_conv_first_planes(capi.ptr(x), None, None, capi.ptr(wp), capi.ptr(o_pl), C.byref(lo_pl), q - 1, 1,
+                                        n, h, w, stream) != 0
+
+
 def test_winograd_grouped_branches_and_direct_agree(capi, cuda):
     outs, refs = _run_conv(capi, cuda, 2, 46, 46, 128, 128, 3, 1, 0, 3, 3, seed=9, groups=2, winograd=True)
     direct, _ = _run_conv(capi, cuda, 2, 46, 46, 128, 128, 3, 1, 0, 3, 3, seed=9, groups=2)

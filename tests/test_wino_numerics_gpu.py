@@ -389,6 +389,47 @@ def test_default_is_the_guarded_choice_and_one_hostile_layer_drops_alone(pkg, mo
     assert m.device_status(plan) == 0
 
 
+def test_channel_plane_buffers_follow_the_forms_of_their_convs(pkg, model_and_sd, cuda):
+    """Round 4: the executor keeps a buffer as channel planes exactly while conv1_1 / F(4x4,3x3) launches are the only ones
+    that touch it (csrc/net.hip: mark_plane_bufs).  A conv whose filters fail the amplification limit runs F(2x2,3x3), a
+    pixel-major kernel: the buffers on both sides of it change storage - and are cleared first, the gaps of one storage being
+    data of the other.  One 3x3 conv gets single-tap corner filters (F(4x4,3x3) estimate 205, the worst a 3x3 filter can do)
+    under amp_limit 150: that conv alone leaves form 43, the maps stay in contract; with the He filters back, the first
+    result returns bit for bit."""
+    from oracle import net_oracle
+    _, sd = model_and_sd
+    x = torch.rand(2, 3, 64, 72, generator=torch.Generator().manual_seed(15)) - 0.5
+    xd = x.to(cuda)
+    m = pkg.get_model('vgg19')
+    m.load_state_dict(sd)
+    m = m.cuda().float().eval()
+    m.set_winograd(winograd3='auto', winograd7='auto', amp_limit=150.0)
+    k3 = [nm for nm, mod in m._convs() if mod.kernel_size[0] == 3 and mod.in_channels >= 32]
+    with torch.no_grad():
+        (p0, h0), _ = m(xd)
+    plan = m.plan_for(xd)
+    assert all(form == 43 for nm, form, _ in m.conv_numerics(plan) if nm in k3)
+    sd_c = {k: v.clone() for k, v in sd.items()}
+    wc = torch.zeros_like(sd_c["model0.12.weight"])
+    wc[:, :, 2, 2] = (2.0 / wc.shape[1]) ** 0.5
+    sd_c["model0.12.weight"] = wc
+    m.load_state_dict(sd_c)
+    (_, _), saved_r = net_oracle.forward(sd_c, x)
+    with torch.no_grad():
+        (_, _), saved = m(xd)
+    num = {nm: (form, amp) for nm, form, amp in m.conv_numerics(plan)}
+    assert 195.0 < num["model0.12"][1][3] < 215.0 and num["model0.12"][0] == 3, num["model0.12"]
+    assert all(num[nm][0] == 43 for nm in k3 if nm != "model0.12")
+    for a, b in zip(saved, saved_r):
+        assert (a.cpu() - b).abs().max().item() <= 1e-3 * max(1.0, b.abs().max().item())
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        (p2, h2), _ = m(xd)
+    assert all(form == 43 for nm, form, _ in m.conv_numerics(plan) if nm in k3)
+    assert torch.equal(p0, p2) and torch.equal(h0, h2)
+    assert m.device_status(plan) == 0
+
+
 def test_auto_forms_follow_a_reload_made_through_a_sibling_plan(pkg, model_and_sd, cuda):
     """Plans of one module share ONE weight arena and the host re-packs through whichever plan sees the new
     parameters first.  Every other AUTO plan must re-decide its forms from the NEW filters' estimates (round-3 advisor
