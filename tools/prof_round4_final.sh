@@ -41,6 +41,7 @@ python $R/tools/bench_config5.py > $O/r04_config5.json 2>/dev/null
 python $R/tools/bench_tta.py 32 3 > $O/r04_tta.txt 2>&1
 python $R/tools/bench_streaming.py > $O/r04_streaming.txt 2>&1
 python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-traffic --dtype bf16 > $O/r04_bench_bf16.json 2>/dev/null
+python $R/tools/profile_layers.py 32 368 368 5 bf16 2>&1 | grep -v amdgpu.ids > $O/r04_bf16_layers.txt
 cd $R && python -c "import __graft_entry__ as g; g.smoke()" > $O/r04_smoke.txt 2>&1
 # the torch-free C++ host on bench.py's decoder input (scene + 1e-3 * maps): the scene of synth.make_batch as a file
 python - <<PY

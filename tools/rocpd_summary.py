@@ -24,7 +24,7 @@ def main(paths):
         if pm:
             print("%-60s %-28s %9s %18s %16s" % ("kernel", "counter", "dispatch", "sum", "per-dispatch"))
             for kn, cn, nd, sv, vg, lds in pm:
-                if "conv_mfma" in kn or "kernel" in kn or "pw_gemm" in kn or "wino" in kn:
+                if any(t in kn for t in ("conv_mfma", "kernel", "pw_gemm", "pw_head", "wino")):
                     print("%-60s %-28s %9d %18.0f %16.1f" % (kn[:60], cn, nd, sv, sv / max(nd, 1)))
         con.close()
 
