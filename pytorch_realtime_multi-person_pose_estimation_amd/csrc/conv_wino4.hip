@@ -154,7 +154,18 @@ __device__ __forceinline__ void at4_hi(const f2 (&m)[6], f2& y2, f2& y3) {
   y3 = __builtin_elementwise_fma(splat(3.375f), d34, splat(0.421875f) * d12) + m[5];
 }
 
+// RT = row tiles of 16 wtiles per block: 2 = the 32 x 64 tile described above; 1 = HALF tiles, 16 wtiles x 64 columns (round 4),
+// for the left-over of a layer whose tiles are not whole rounds of the 256 CUs (8.27 rounds of 32 x 64 tiles on the 92 x 92 maps,
+// 4.5 on 46 x 46: the ninth / fifth round ran a quarter / half empty).  Same waves (fh, wn), same frequencies per wave, same
+// sums in the same order - bit-identical; a wave multiplies ONE row tile (36 MFMAs per chunk instead of 72), the transform
+// items are spread as in wino4s_f32 (waves 0..2: two patch rows each, waves 3..5: two fx each), and before the output
+// transform the siblings split the row tile by wtile PAIRS: wave (fh, wn) finishes the wtiles 4 kq + 2 fh, + 1 and hands the
+// first-pass row sums of the other pair over.  One tile per block (never persistent).
+template <int RT>
 __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
+  constexpr int NT = 16 * RT;           // (shadow the 32-wtile constants of the namespace inside the kernel)
+  constexpr int VBUF = NFP * 4 * NT;
+  constexpr int UBUF = 36 * 2 * NT;
   extern __shared__ __attribute__((aligned(16))) float4 L4[];
   // LDS: [V0][U1][V1][U0] - the two buffers that are dead at a tile boundary (V1, U0) are adjacent: the exchange area
   auto Vb = [&](int i) -> float4* { return L4 + i * (VBUF + UBUF); };
@@ -199,16 +210,17 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
   const int TT = A.TY * A.TX;
 
   // ---- transform roles ----------------------------------------------------------------------------------------------
-  const bool s1 = wv < 6, s2 = wv >= 2;
+  const bool s1 = RT == 2 ? wv < 6 : wv < 3, s2 = RT == 2 ? wv >= 2 : (wv >= 3 && wv < 6);
   const int turn = wv >> 2;               // siblings on a SIMD (waves w, w + 4) take their turns one step apart
   // stage 1 lanes: (wtile, channel group) = (lane / 2, lane % 2) - the two lanes that share a pixel's 32 bytes are
   // neighbours, so the patch loads touch 32 lines per instruction, not 64; stage 2 lanes: (lane % 32, lane / 32) - a
   // plane of V per channel-group half.  U[fx][y][cg][wtile ^ 4 cg]: the swizzle keeps both access patterns off each
   // other's banks (8 consecutive stage-1 lanes write 4 + 4 slots of two planes).
-  const int wl1 = lane >> 1, cg1 = lane & 1;
-  const int wl = lane & 31, cg = lane >> 5;
-  const int py = wv;                      // stage 1: patch row
-  const int fx = max(wv - 2, 0);          // stage 2: frequency along x
+  // (half tiles: 16 wtiles x 2 channel groups are 32 lanes - a wave takes two patch rows / two fx)
+  const int wl1 = RT == 2 ? lane >> 1 : (lane >> 1) & 15, cg1 = lane & 1;
+  const int wl = RT == 2 ? lane & 31 : lane & 15, cg = RT == 2 ? lane >> 5 : (lane >> 4) & 1;
+  const int py = RT == 2 ? wv : 2 * (s1 ? wv : 0) + (lane >> 5);               // stage 1: patch row
+  const int fx = RT == 2 ? max(wv - 2, 0) : 2 * (s2 ? wv - 3 : 0) + (lane >> 5);  // stage 2: frequency along x
   const i32x4 rw = make_rsrc(g.w, g.w_bytes);
   const i32x4 rnull = make_rsrc(g.in, 0);
   // the "load cursor": the (tile, chunk) position whose patch rows are requested next, 3 positions ahead of the multiply
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
   // acc[l][0]: frequency 18 fh + l of the row tile this wave FINISHES (row tile fh), acc[l][1]: of the other row tile,
   // handed to the sibling (wave wv ^ 4) before the output transform
   const int ncol = nt * NC + wn * 16 + r16;
-  floatx4 acc[NFW][2];
+  floatx4 acc[NFW][RT];
   const float bias0 = g.bias[ncol];
   const unsigned boff = (unsigned)((kq * g.cout_pad + ncol) * 16);
   const unsigned fstep = (unsigned)(4 * g.cout_pad * 16);  // bytes per (chunk, frequency pair)
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
 #pragma unroll
     for (int f = 0; f < NFW; ++f)
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc[f][rt][v] = 0.f;
 
@@ -347,8 +359,8 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
         ar[0] = va[fh * 16];
         ar[1] = va[(fh ^ 1) * 16];
 #else
-        a0 = va[fh * 16];
-        a1 = va[(fh ^ 1) * 16];
+        a0 = va[RT == 2 ? fh * 16 : 0];
+        if (RT == 2) a1 = va[(fh ^ 1) * 16];
 #endif
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
@@ -378,7 +390,7 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
 #if RTPOSE_EXP_W4_A3
           if (i < NPW - 1) ar[(2 * i + 2) % 3] = RTPOSE_EXP_A(va[(i + 1) * 4 * NT + fh * 16], ar[(2 * i) % 3]);
 #else
-          if (i < NPW - 1) a0 = RTPOSE_EXP_A(va[(i + 1) * 4 * NT + fh * 16], a0);
+          if (i < NPW - 1) a0 = RTPOSE_EXP_A(va[(i + 1) * 4 * NT + (RT == 2 ? fh * 16 : 0)], a0);
 #endif
           {
             // B PF pairs ahead.  After a chunk's ninth pair the sibling's nine are skipped; after the tile's last chunk
@@ -389,10 +401,12 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
             else wso += fstep;
           }
           RTPOSE_PIN();
-          acc[2 * i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bv.x, acc[2 * i][1], 0, 0, 0);
-          acc[2 * i + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bv.z, acc[2 * i + 1][1], 0, 0, 0);
-          acc[2 * i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bv.y, acc[2 * i][1], 0, 0, 0);
-          acc[2 * i + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bv.w, acc[2 * i + 1][1], 0, 0, 0);
+          if (RT == 2) {
+            acc[2 * i][RT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bv.x, acc[2 * i][RT - 1], 0, 0, 0);
+            acc[2 * i + 1][RT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bv.z, acc[2 * i + 1][RT - 1], 0, 0, 0);
+            acc[2 * i][RT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bv.y, acc[2 * i][RT - 1], 0, 0, 0);
+            acc[2 * i + 1][RT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bv.w, acc[2 * i + 1][RT - 1], 0, 0, 0);
+          }
           RTPOSE_PIN();
 #if RTPOSE_EXP_W4_PRIO >= 4
           __builtin_amdgcn_s_sleep(RTPOSE_EXP_W4_PRIO - 3);
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
 #if RTPOSE_EXP_W4_A3
           if (i < NPW - 1) ar[(2 * i + 3) % 3] = RTPOSE_EXP_A(va[(i + 1) * 4 * NT + (fh ^ 1) * 16], ar[(2 * i + 1) % 3]);
 #else
-          if (i < NPW - 1) a1 = RTPOSE_EXP_A(va[(i + 1) * 4 * NT + (fh ^ 1) * 16], a1);
+          if (RT == 2 && i < NPW - 1) a1 = RTPOSE_EXP_A(va[(i + 1) * 4 * NT + (fh ^ 1) * 16], a1);
 #endif
           if (RTPOSE_EXP_STAGE) {
             if (i < 2) {
@@ -435,17 +449,17 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
     //    sums of the row tile they do not finish, through the two LDS buffers that are dead at a tile boundary (V1, U0),
     //    in two rounds (one per wtile pair);  3. second pass (along x), + bias (+ReLU) (+2x2 max-pool), masked stores.
     // Register v of acc[l][0] = wtile fh * 16 + 4 kq + v of the tile, column ncol: 16 lanes = 64 contiguous bytes.
-    f2 sk[3][2][4], sr[3][2][4];  // [fx - 3 fh][wtile pair][output row]: kept row tile, received from the sibling
-    {
+    f2 sk[3][RT][4], sr[3][RT][4];  // [fx - 3 fh][wtile pair][output row]: kept, received from the sibling
+    if (RT == 2) {
       float4* const E = L4 + VBUF + UBUF;
 #pragma unroll
-      for (int vp = 0; vp < 2; ++vp) {
+      for (int vp = 0; vp < RT; ++vp) {
         f2 sg[3][4];
 #pragma unroll
         for (int xl = 0; xl < 3; ++xl) {
           f2 m[6];
 #pragma unroll
-          for (int y = 0; y < 6; ++y) m[y] = f2{acc[xl * 6 + y][1][2 * vp], acc[xl * 6 + y][1][2 * vp + 1]};
+          for (int y = 0; y < 6; ++y) m[y] = f2{acc[xl * 6 + y][RT - 1][2 * vp], acc[xl * 6 + y][RT - 1][2 * vp + 1]};
           at4_lo(m, sg[xl][0], sg[xl][1]);
           at4_hi(m, sg[xl][2], sg[xl][3]);
         }
@@ -474,6 +488,38 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
           }
         __syncthreads();
       }
+    } else {
+      // half tile: ONE row tile, split between the siblings by wtile pair - the wave keeps the pair fh (registers 2 fh, + 1 of
+      // every accumulator) and sends the row sums of the other one.  The block has no next tile: every buffer is dead.
+      float4* const E = L4;
+      auto rowsums = [&](int pair, f2 (&dst)[3][RT][4]) {
+#pragma unroll
+        for (int xl = 0; xl < 3; ++xl) {
+          f2 m[6];
+#pragma unroll
+          for (int y = 0; y < 6; ++y)
+            m[y] = pair ? f2{acc[xl * 6 + y][0][2], acc[xl * 6 + y][0][3]} : f2{acc[xl * 6 + y][0][0], acc[xl * 6 + y][0][1]};
+          at4_lo(m, dst[xl][0][0], dst[xl][0][1]);
+          at4_hi(m, dst[xl][0][2], dst[xl][0][3]);
+        }
+      };
+      rowsums(fh ^ 1, sr);  // (sr as scratch: the sums that leave)
+#pragma unroll
+      for (int xl = 0; xl < 3; ++xl)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+          E[(wv * 6 + xl * 2 + hh) * 64 + lane] =
+              make_float4(sr[xl][0][2 * hh].x, sr[xl][0][2 * hh].y, sr[xl][0][2 * hh + 1].x, sr[xl][0][2 * hh + 1].y);
+      rowsums(fh, sk);
+      __syncthreads();
+#pragma unroll
+      for (int xl = 0; xl < 3; ++xl)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const float4 t = E[((wv ^ 4) * 6 + xl * 2 + hh) * 64 + lane];
+          sr[xl][0][2 * hh] = f2{t.x, t.y};
+          sr[xl][0][2 * hh + 1] = f2{t.z, t.w};
+        }
     }
     auto finish = [&](auto fhc) {
       constexpr int FH = decltype(fhc)::value;
@@ -494,7 +540,7 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
       const i32x4 rout = make_rsrc(g.out + oo0, g.out_bytes - oo0 * 4);
       const unsigned cs4 = (unsigned)cs_st * 4, row4 = (unsigned)g.out_ws * cs4;
       const unsigned col4 = col_floats(ncol, g.out_pq) * 4;
-      int tcur = (A.mt0 + mt) * NT + FH * 16 + 4 * kq;
+      int tcur = (A.mt0 + mt) * NT + (RT == 2 ? FH * 16 + 4 * kq : 4 * kq + 2 * FH);
       int sn = tcur / TT, sy, sx;
       {
         const int r = tcur - sn * TT;
@@ -502,7 +548,7 @@ __global__ __launch_bounds__(512, 1) void wino4_f32(const Args A) {
         sx = r - sy * A.TX;
       }
 #pragma unroll
-      for (int vp = 0; vp < 2; ++vp) {
+      for (int vp = 0; vp < RT; ++vp) {
         // geometry of the two wtiles of the pair
         unsigned off[2];
         bool okv[2];
@@ -1021,10 +1067,30 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
     RTPOSE_HIP_CHECK(hipGetLastError());
     return 0;
   };
+  auto launch_half = [&](const Args& a0, int mt0_32, long wtiles) -> int {
+    // half tiles (wino4_f32<1>: 16 wtiles x 64 columns, one per block), bit-identical: `wtiles` wtiles from m tile mt0_32 on
+    Args b = a0;
+    b.persist = 0;
+    b.mt0 = 2 * mt0_32;
+    b.mtiles = (int)((wtiles + 15) / 16);
+    b.xcd_remap = (b.ncombo > 1 && b.mtiles >= 64) ? 1 : 0;
+    const long idh = b.xcd_remap ? (long)8 * b.ncombo * ceil_div(b.mtiles, 8) : (long)b.mtiles * b.ncombo;
+    static PerDeviceOnce attr_h;
+    const int dev_h = current_device();
+    if (!attr_h.is_set(dev_h)) {
+      RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_f32<1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr_h.set(dev_h);
+    }
+    hipLaunchKernelGGL(wino4_f32<1>, dim3((unsigned)idh), dim3(512), (size_t)(VBUF + UBUF) * sizeof(float4), s, b);
+    RTPOSE_HIP_CHECK(hipGetLastError());
+    return 0;
+  };
   // launches that fill at most half the CUs with 32 x 64 tiles run the 16 x 16 form (measured: at one round and beyond
   // the big tiles win - the small form fetches the filters four times as often; tools/r3_sessions/session27.sh)
   if ((long)a.mtiles * a.ncombo * 2 <= n_cu) return launch_small(a, 0, a.T);
   int rest = 0;  // m tiles left to a second launch
+  bool rest_half = false;  // ... in half tiles (else the 16 x 16 form)
   if ((long)a.mtiles * a.ncombo > n_cu && n_cu % (8 * a.ncombo) == 0) {
     // Persistent blocks: block (column tile / group c, q) takes the m tiles q, q + Pc, ...  When the tiles do not come out
     // as whole rounds and what is left over is at most a quarter of a round, the whole rounds run here and the rest as a
@@ -1039,8 +1105,20 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
       const char* e = dev_env("RTPOSE_W4_CUT_PCT");
       cut_pct = e ? atoi(e) : 25;
     }
+    static int half_on = -1;  // developer switch: RTPOSE_W4_HALF=0 runs a left-over of 25..50 % of a round as a round of big tiles
+    if (half_on < 0) {
+      const char* e = dev_env("RTPOSE_W4_HALF");
+      half_on = e ? atoi(e) : 1;
+    }
     if (r && (long)r * a.ncombo * 100 <= (long)cut_pct * n_cu) {
       rest = r;
+      a.mtiles -= r;
+    } else if (r && half_on && 2L * r * a.ncombo <= n_cu) {
+      // Round 4: up to half a round left over runs as ONE round of half tiles (16 wtiles x 64 columns: half the multiplies of a
+      // tile, the same transform work per wtile) instead of a round of big tiles that leaves 50..75 % of the CUs idle:
+      // conv3_x 8.27 rounds -> 8 + a half-tile round, conv4_1 / conv4_2 4.5 -> 4 + one.
+      rest = r;
+      rest_half = true;
       a.mtiles -= r;
     }
     a.persist = 1;
@@ -1049,7 +1127,7 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
   static PerDeviceOnce attr_set;
   const int dev = current_device();
   if (!attr_set.is_set(dev)) {
-    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_f32),
+    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_f32<2>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set.set(dev);
   }
@@ -1070,8 +1148,9 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
     }
   }
 #endif
-  hipLaunchKernelGGL(wino4_f32, dim3((unsigned)ids), dim3(512), (size_t)(2 * VBUF + 2 * UBUF) * sizeof(float4), s, a);
+  hipLaunchKernelGGL(wino4_f32<2>, dim3((unsigned)ids), dim3(512), (size_t)(2 * VBUF + 2 * UBUF) * sizeof(float4), s, a);
   RTPOSE_HIP_CHECK(hipGetLastError());
+  if (rest && rest_half) return launch_half(a, a.mtiles, (long)a.T - (long)a.mtiles * NT);
   if (rest) return launch_small(a, a.mtiles, (long)a.T - (long)a.mtiles * NT);
   return 0;
 }

@@ -305,6 +305,29 @@ def test_winograd4_small_grid_form_is_bit_identical(capi, cuda):
             assert torch.equal(a[first:first + count], b)
 
 
+@pytest.mark.parametrize("geom", [(32, 92, 92, 32, 256, 1), (32, 46, 46, 64, 512, 1), (32, 45, 47, 64, 256, 2)])
+def test_winograd4_half_tiles_of_the_left_over_round_are_bit_identical(capi, cuda, geom):
+    """Round 4: when the 32 x 64 tiles of a layer are not whole rounds of the CUs and 25..50 % of a round is left over (the
+    92 x 92 layers of the 32-image batch: 8.27 rounds; 46 x 46 with 512 columns: 4.5), the left-over runs as one round of HALF
+    tiles (wino4_f32<1>: 16 wtiles x 64 columns).  Same sums in the same order: the images of the batch's tail - they lie in
+    the left-over - and of its head are the bits of the same images run alone (a small grid: the 16 x 16 form)."""
+    n, h, w, cin, cout, groups = geom
+    big, _ = _run_conv(capi, cuda, n, h, w, cin, cout, 3, 1, 0, 1, 1, seed=41, groups=groups, cin_pad=cin, winograd=True,
+                       wino_m=4, skip_ref=True)
+    for first in (0, n - 2, n - 1):
+        one, _ = _run_conv(capi, cuda, n, h, w, cin, cout, 3, 1, 0, 1, 1, seed=41, groups=groups, cin_pad=cin, winograd=True,
+                           wino_m=4, skip_ref=True, only_images=1, first_image=first)
+        for a, b in zip(big, one):
+            assert torch.equal(a[first:first + 1], b), first
+    if cin == 32:   # one image of the tail against torch's CPU conv2d as well
+        g = torch.Generator().manual_seed(41)
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        y = F.relu(F.conv2d(x[n - 1:], wt, b, padding=1))
+        assert (big[0][n - 1:] - y).abs().max().item() <= TOL * max(1.0, y.abs().max().item())
+
+
 def _to_planes(pm, q_slots, lead_planes=0, fill=0.0):
     """pixel-major [Q, C] -> channel planes [lead_planes + C / 8][q_slots][8] (flat); unused slots / planes = `fill`."""
     q, c = pm.shape
@@ -382,6 +405,7 @@ PLANE_CASES = [
     (3, 96, 80, 64, 64, 1, 1, 1, 1, 1),       # fused pool
     (5, 7, 9, 48, 24, 0, 0, 1, 3, 1),         # tiny maps, ragged cout (24 = 3 planes), no ReLU
     (20, 45, 47, 128, 128, 1, 0, 3, 3, 2),    # two branches in one grid, odd sizes, one round + a left-over launch
+    (32, 92, 92, 32, 256, 1, 0, 1, 1, 1),     # 8.27 rounds: whole rounds + a round of half tiles (wino4_f32<1>)
 ]
 
 
