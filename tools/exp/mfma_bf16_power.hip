@@ -53,8 +53,9 @@ int main(int argc, char** argv) {
   std::vector<unsigned short> hb(n16);
   hipMalloc(&out, 512 * 256 * 4);
   const char* names[] = {"zeros", "constant 1.0", "random N(0,1) bf16", "random N(0,1) * relu (half zeros)", "random bit patterns (finite)",
-                         "A = relu(N(0,1)), B = N(0,1) (a conv layer's operands)"};
-  for (int mode : {5, 2, 0, 3, 4, 1, 5}) {
+                         "A = relu(N(0,1)), B = N(0,1) (a conv layer's operands)",
+                         "A = N(0,1), B = relu(N(0,1)) (the same, roles swapped)"};
+  for (int mode : {5, 6, 5, 6, 2, 0, 3, 4, 1}) {
     srand(1);
     for (int i = 0; i < n16; ++i) {
       const float u1 = (rand() + 1.0f) / (RAND_MAX + 2.0f), u2 = rand() / (float)RAND_MAX;
@@ -64,9 +65,10 @@ int main(int argc, char** argv) {
       if (mode == 2) b = bf16_of(g);
       if (mode == 3) b = bf16_of(g > 0 ? g : 0.f);
       if (mode == 4) b = (unsigned short)((rand() & 0xffff) & ~0x4000);  // exponent < 2^1: finite, no overflow in fp32 sums
-      if (mode == 5) b = bf16_of(g > 0 ? g : 0.f);
-      h[i] = b;
-      hb[i] = mode == 5 ? bf16_of(sqrtf(-2.f * logf((rand() + 1.0f) / (RAND_MAX + 2.0f))) * cosf(6.2831853f * (rand() / (float)RAND_MAX))) : b;
+      if (mode >= 5) b = bf16_of(g > 0 ? g : 0.f);
+      const unsigned short nb = bf16_of(sqrtf(-2.f * logf((rand() + 1.0f) / (RAND_MAX + 2.0f))) * cosf(6.2831853f * (rand() / (float)RAND_MAX)));
+      h[i] = mode == 6 ? nb : b;
+      hb[i] = mode == 5 ? nb : b;
     }
     hipMemcpy(d, h.data(), n16 * 2, hipMemcpyHostToDevice);
     hipMemcpy(db, hb.data(), n16 * 2, hipMemcpyHostToDevice);
