@@ -25,6 +25,36 @@ def test_every_declared_symbol_is_exported(capi):
     assert set(names) == set(capi.EXPORTED)
 
 
+def test_ctypes_mirrors_have_the_layout_of_the_header_structs(capi, tmp_path):
+    """The descriptors of the ABI have grown by trailing fields (rtpose_conv_desc: wino_m, then the channel-plane fields):
+    a binding that lags behind passes a shorter struct and the library reads garbage past it.  The header is compiled as C
+    (gcc) and every struct's size and field offsets are compared with the ctypes mirror the Python side uses."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    mirrors = {"rtpose_layout": capi.Layout, "rtpose_conv_desc": capi.ConvDesc, "rtpose_pw_desc": capi.PwDesc,
+               "rtpose_net_options": capi.NetOptions, "rtpose_prep_image": capi.PrepImage,
+               "rtpose_decode_cfg": capi.DecodeCfg}
+    cname = {"inp": "in"}                       # ctypes field -> C member where the names differ
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rtpose_mi355x.h"', 'int main(void) {']
+    for st, cls in mirrors.items():
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (st, st))
+        for f, _ in cls._fields_:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (st, f, st, cname.get(f, f)))
+    lines += ['  return 0;', '}']
+    src = tmp_path / "abi_layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "abi_layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE, text=True).stdout
+    got = dict(ln.split() for ln in out.splitlines())
+    for st, cls in mirrors.items():
+        assert int(got[st]) == C.sizeof(cls), (st, got[st], C.sizeof(cls))
+        for f, _ in cls._fields_:
+            assert int(got["%s.%s" % (st, f)]) == getattr(cls, f).offset, (st, f)
+
+
 def test_version_and_sizes(capi):
     lib = capi.lib
     assert b"gfx950" in lib.rtpose_version()
