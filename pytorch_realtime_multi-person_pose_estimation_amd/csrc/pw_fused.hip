@@ -116,7 +116,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f32(const PwArgs A) {
   const int wm = wave % WM, wn = wave / WM;
   const int l31 = lane & 31, kh = lane >> 5;
   const int HW = A.H * A.W;
-  const int pl = tid & 7, px = tid >> 3;  // staging role: channel-group plane, first pixel
+  // staging role: channel-group plane, first pixel.  8 consecutive lanes = 4 planes x 2 pixels (not 8 planes of one pixel): a
+  // ds_write_b128 is serviced 8 lanes at a time on 32 banks, and with the planes 32 bytes apart (mod 256: what the 16-lane
+  // reads want) the planes p and p + 4 of one pixel met in the same banks - every park / A-tile write 2-way conflicted
+  // (SQ_LDS_BANK_CONFLICT 23 % of SQ_LDS_IDX_ACTIVE in the plain launches, 38 % in the depthwise ones)
+  const int pl = (tid & 3) | ((tid >> 1) & 4), px = ((tid >> 4) << 1) | ((tid >> 2) & 1);
 
   // ---- LDS carve-up (float4 units) ---------------------------------------------------------
   constexpr int ASUB = kPwPL * kPwQS;  // one A chunk buffer
