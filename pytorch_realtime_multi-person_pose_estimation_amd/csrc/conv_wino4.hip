@@ -1074,6 +1074,9 @@ int conv2d_wino4_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, in
     b.mt0 = 2 * mt0_32;
     b.mtiles = (int)((wtiles + 15) / 16);
     b.xcd_remap = (b.ncombo > 1 && b.mtiles >= 64) ? 1 : 0;
+#ifdef RTPOSE_EXP_TIMELINE4
+    b.dbg = nullptr;  // (the stamps are the main launch's)
+#endif
     const long idh = b.xcd_remap ? (long)8 * b.ncombo * ceil_div(b.mtiles, 8) : (long)b.mtiles * b.ncombo;
     static PerDeviceOnce attr_h;
     const int dev_h = current_device();
