@@ -107,3 +107,29 @@ def test_full_size_properties_batch32(model_and_sd, cuda):
         worst = max(worst, e_paf.max().item(), e_heat.max().item())
         assert e_paf.max().item() <= ABS_TOL and e_heat.max().item() <= ABS_TOL, (i0, e_paf, e_heat)
     print("config 2, all 32 images vs the oracle: worst |err| %.2e" % worst)
+
+
+def test_an_images_maps_are_the_same_bits_in_every_batch_size(model_and_sd, cuda):
+    """Which launch form a conv runs in depends on the batch: small grids (one image), whole rounds of persistent blocks plus a
+    left-over in the 16 x 16 form or - 25..50 % of a round - in half tiles, split tiles of the 7x7 kernel.  All forms sum in
+    the same order: images 0, 11 and 39 of a 40-image batch give the bits of their batch-1 runs in batches of 5, 12, 24 and
+    40 (368 x 368, fp32 default plan)."""
+    m, _ = model_and_sd
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(40, 3, 368, 368, generator=g) - 0.5).to(cuda)
+    keep = m.keep_intermediates
+    m.keep_intermediates = False
+    try:
+        with torch.no_grad():
+            ref = {}
+            for i in (0, 11, 39):
+                (p, h), _ = m(x[i:i + 1])
+                ref[i] = (p.clone(), h.clone())
+            for n in (5, 12, 24, 40):
+                (p, h), _ = m(x[:n])
+                for i, (pr, hr) in ref.items():
+                    if i < n:
+                        assert torch.equal(p[i:i + 1], pr) and torch.equal(h[i:i + 1], hr), (n, i)
+    finally:
+        m.keep_intermediates = keep
+
