@@ -370,13 +370,12 @@ static void std_sort_desc(Cand* first, Cand* last) {
 int oracle_process_paf(const float* joint_list, int P, const float* paf, int h, int w, int up, int h1,
                        int max_humans, int* human_parts, float* human_score, int* line_x, int* line_y,
                        float* line_score, int* had_ties, int sort_mode) {
-  /* sort_mode 0: ties keep (idx1, idx2) order = the product's documented contract;
-   * sort_mode 1: order candidates exactly as libstdc++'s std::sort would. */
-  /* *had_ties (optional): set when two candidates of one limb have exactly equal
-   * scores.  The reference sorts with std::sort (cpp:97, not stable), so which of
-   * them wins is implementation-defined there; this restatement (and the GPU
-   * kernel) break ties towards the lower (idx1, idx2).  Tests skip the bit-exact
-   * comparison against the compiled reference for such scenes. */
+  /* sort_mode 1: order candidates exactly as libstdc++'s std::sort would (the product's
+   * contract since round 5: the GPU kernel replays the same moves on a limb with a tie);
+   * sort_mode 0: ties keep (idx1, idx2) order (the contract of rounds 1-4). */
+  /* *had_ties (optional, sort_mode 0 only): set when two candidates of one limb have exactly
+   * equal scores.  The reference sorts with std::sort (cpp:97, not stable), so which of them
+   * wins is decided by the library's introsort; without a tie both modes must agree. */
   if (had_ties) *had_ties = 0;
   /* phase 1 (cpp:24-43) */
   Peak* by_part[NUM_PART];

@@ -110,10 +110,12 @@ def find_peaks_scipy(thr, img):
     return np.array(np.nonzero(peaks_binary)[::-1]).T
 
 
-def process_paf(joint_list, paf, up=8, max_humans=512, libstdcxx_sort=False):
+def process_paf(joint_list, paf, up=8, max_humans=512, libstdcxx_sort=True):
     """C restatement.  paf HWC [h,w,38] at network resolution.  Returns dict.
-    libstdcxx_sort=True orders equal-score candidates the way the reference binary's
-    std::sort does (for comparisons with oracle/_ref); False = the product's contract."""
+    libstdcxx_sort=True (the contract since round 5: "identical to pafprocess.cpp built with this
+    image's g++ 11") orders equal-score candidates the way the reference binary's std::sort
+    does; False = ties towards the lower (idx1, idx2), the product's contract of rounds 1-4,
+    kept because the two must agree on every scene whose result has had_ties False."""
     jl = _f32(joint_list).reshape(-1, 5)
     paf = _f32(paf)
     h, w, _ = paf.shape

@@ -33,7 +33,7 @@ inline int decode_row_cap(const rtpose_decode_cfg* c) {
   return r;
 }
 // workspace: [conn lists][candidate-score matrices when they exceed LDS][subset rows when
-// they exceed LDS]
+// they exceed LDS][candidate lists of the limbs that replay std::sort on an exact score tie]
 inline size_t decode_ws_conn_bytes(const rtpose_decode_cfg* c, int N) {
   return round_up((size_t)N * decode_conn_words(c) * sizeof(int32_t), 256);
 }
@@ -45,8 +45,13 @@ inline size_t decode_ws_rows_bytes(const rtpose_decode_cfg* c, int N) {
   const int r = decode_row_cap(c);
   return r > kLdsRows ? round_up((size_t)N * r * 21 * sizeof(float), 256) : 0;
 }
+inline size_t decode_ws_tie_bytes(const rtpose_decode_cfg* c, int N) {
+  const size_t p = (size_t)c->max_peaks_per_part;
+  return round_up((size_t)N * RTPOSE_NUM_LIMB * p * p * sizeof(int32_t), 256);
+}
 inline size_t decode_workspace_bytes(const rtpose_decode_cfg* c, int N) {
-  return decode_ws_conn_bytes(c, N) + decode_ws_score_bytes(c, N) + decode_ws_rows_bytes(c, N);
+  return decode_ws_conn_bytes(c, N) + decode_ws_score_bytes(c, N) + decode_ws_rows_bytes(c, N) +
+         decode_ws_tie_bytes(c, N);
 }
 
 int nms_launch(const float* heat, const rtpose_layout* lheat, int N, int h, int w,

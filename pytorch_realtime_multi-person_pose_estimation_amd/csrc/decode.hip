@@ -387,6 +387,151 @@ __global__ void peak_prefix_kernel(int pcap, int32_t* __restrict__ result, int r
   }
 }
 
+
+// ------------------------------------------------------------------------------
+// std::sort(candidates.begin(), candidates.end(), comp_candidate) (pafprocess.cpp:97, :244-246)
+// as libstdc++ (GCC 11 bits/stl_algo.h - what the reference links against when built with this
+// image's g++) executes it, run by ONE lane.  std::sort is not stable: when two candidates of a
+// limb score exactly the same (two peaks refined to the same pixel), which one the greedy scan
+// meets first is decided by the introsort's moves - median-of-3 quicksort down to 16-element
+// runs under a 2 floor(log2 n) depth limit (heap sort beyond it), then one insertion pass.  The
+// product is "identical to pafprocess.cpp built with g++ 11", so the rare limb with such a tie
+// replays those moves on its candidate list L (entries = a * nB + b in the reference's push
+// order, scores looked up in S); comp(a, b) = S[a] > S[b].
+// ------------------------------------------------------------------------------
+struct SortReplay {
+  int* L;
+  const float* S;
+  int* stk;  // LDS, 3 ints per pending range
+  __device__ __forceinline__ bool gt(int pa, int pb) const { return S[pa] > S[pb]; }
+  __device__ __forceinline__ void swap(int i, int j) {
+    const int t = L[i];
+    L[i] = L[j];
+    L[j] = t;
+  }
+  __device__ void unguarded_linear_insert(int last) {
+    const int val = L[last];
+    int next = last - 1;
+    while (gt(val, L[next])) {
+      L[last] = L[next];
+      last = next;
+      --next;
+    }
+    L[last] = val;
+  }
+  __device__ void insertion_sort(int first, int last) {
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+      if (gt(L[i], L[first])) {
+        const int val = L[i];
+        for (int k = i; k > first; --k) L[k] = L[k - 1];  // move_backward(first, i, i + 1)
+        L[first] = val;
+      } else {
+        unguarded_linear_insert(i);
+      }
+    }
+  }
+  __device__ void push_heap(int first, int hole, int top, int value) {
+    int parent = (hole - 1) / 2;
+    while (hole > top && gt(L[first + parent], value)) {
+      L[first + hole] = L[first + parent];
+      hole = parent;
+      parent = (hole - 1) / 2;
+    }
+    L[first + hole] = value;
+  }
+  __device__ void adjust_heap(int first, int hole, int len, int value) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+      child = 2 * (child + 1);
+      if (gt(L[first + child], L[first + child - 1])) child--;
+      L[first + hole] = L[first + child];
+      hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+      child = 2 * (child + 1);
+      L[first + hole] = L[first + child - 1];
+      hole = child - 1;
+    }
+    push_heap(first, hole, top, value);
+  }
+  __device__ void heap_sort(int first, int last) {  // __partial_sort(first, last, last)
+    const int len = last - first;
+    if (len >= 2)
+      for (int parent = (len - 2) / 2;; --parent) {  // __make_heap
+        adjust_heap(first, parent, len, L[first + parent]);
+        if (parent == 0) break;
+      }
+    while (last - first > 1) {  // __sort_heap
+      --last;
+      const int value = L[last];
+      L[last] = L[first];
+      adjust_heap(first, 0, last - first, value);
+    }
+  }
+  __device__ void move_median_to_first(int result, int a, int b, int c) {
+    if (gt(L[a], L[b])) {
+      if (gt(L[b], L[c])) swap(result, b);
+      else if (gt(L[a], L[c])) swap(result, c);
+      else swap(result, a);
+    } else if (gt(L[a], L[c])) swap(result, a);
+    else if (gt(L[b], L[c])) swap(result, c);
+    else swap(result, b);
+  }
+  __device__ int unguarded_partition(int first, int last, int pivot) {
+    for (;;) {
+      while (gt(L[first], L[pivot])) ++first;
+      --last;
+      while (gt(L[pivot], L[last])) --last;
+      if (!(first < last)) return first;
+      swap(first, last);
+      ++first;
+    }
+  }
+  // __introsort_loop: the recursion on [cut, last) becomes a pending range (the ranges are
+  // disjoint, so the order they are finished in does not change a single move)
+  __device__ void introsort(int n, int depth_limit) {
+    int sp = 0;
+    stk[0] = 0;
+    stk[1] = n;
+    stk[2] = depth_limit;
+    sp = 1;
+    while (sp > 0) {
+      --sp;
+      int first = stk[3 * sp], last = stk[3 * sp + 1], depth = stk[3 * sp + 2];
+      while (last - first > 16) {
+        if (depth == 0) {
+          heap_sort(first, last);
+          break;
+        }
+        --depth;
+        const int mid = first + (last - first) / 2;
+        move_median_to_first(first, first + 1, mid, last - 1);
+        const int cut = unguarded_partition(first + 1, last, first);
+        stk[3 * sp] = cut;
+        stk[3 * sp + 1] = last;
+        stk[3 * sp + 2] = depth;
+        ++sp;
+        last = cut;
+      }
+    }
+  }
+  __device__ void sort_desc(int n) {
+    if (n == 0) return;
+    int lg = 0;
+    while ((n >> (lg + 1)) > 0) ++lg;
+    introsort(n, 2 * lg);
+    if (n > 16) {
+      insertion_sort(0, 16);
+      for (int i = 16; i != n; ++i) unguarded_linear_insert(i);
+    } else {
+      insertion_sort(0, n);
+    }
+  }
+};
+constexpr int kSortStack = 3 * 64;  // pending ranges <= the depth limit 2 floor(log2 n) <= 40
+
 // ------------------------------------------------------------------------------
 // 2. PAF scoring + greedy assignment (pafprocess.cpp:46-124, :220-246)
 // ------------------------------------------------------------------------------
@@ -396,7 +541,8 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
                                                           int h1, int pcap,
                                                           const int32_t* __restrict__ result,
                                                           int result_words, int32_t* __restrict__ conn,
-                                                          int conn_words, float* __restrict__ score_ws) {
+                                                          int conn_words, float* __restrict__ score_ws,
+                                                          int32_t* __restrict__ tie_ws) {
   const int pair_id = blockIdx.x, n = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int32_t* res = result + (size_t)n * result_words;
@@ -405,8 +551,9 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
   extern __shared__ float s_score_lds[];  // [nA * nB] candidate scores, 0 = none
   __shared__ unsigned char s_usedA[kDecodeMaxPeaks], s_usedB[kDecodeMaxPeaks];
   __shared__ float s_wbest[4];
-  __shared__ int s_widx[4];
+  __shared__ int s_widx[4], s_wcnt[4];
   __shared__ int s_nconn;
+  __shared__ int s_stack[kSortStack];
 
   const int partA = kPairs[pair_id][0], partB = kPairs[pair_id][1];
   const int chx = kPairNet[pair_id][0], chy = kPairNet[pair_id][1];
@@ -466,19 +613,30 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
   __syncthreads();
 
   // greedy: repeatedly take the best remaining candidate whose endpoints are
-  // both free == scanning the list sorted by descending score (cpp:96-124);
-  // equal scores resolve to the lower (a, b).
+  // both free == scanning the list sorted by descending score (cpp:96-124).
+  // That equivalence needs the best free candidate to be UNIQUE at every step: when two free
+  // candidates share the best score, std::sort's moves decide which the reference meets first
+  // (and, if they do not exclude each other, the order of their connections, which orders the
+  // subset rows).  Every step therefore also counts the free candidates AT the best score; a
+  // count above one sends the limb to the replay below.  (Equal scores of which at most one is
+  // still free when their turn comes cannot change anything: a used peak stays used.)
   const int max_conn = min(nA, nB);
+  bool tie = false;
   for (int it = 0; it < max_conn; ++it) {
     float best = 0.f;
-    int bidx = 0x7fffffff;
+    int bidx = 0x7fffffff, cnt = 0;
     for (int p = tid; p < npairs; p += 256) {
       const float s = s_score[p];
-      if (s > best) {
+      if (s >= best && s > 0.f) {
         const int a = p / nB, b = p - a * nB;
         if (!s_usedA[a] && !s_usedB[b]) {
-          best = s;
-          bidx = p;
+          if (s > best) {
+            best = s;
+            bidx = p;
+            cnt = 1;
+          } else {
+            ++cnt;  // p ascends: bidx stays the lowest
+          }
         }
       }
     }
@@ -486,25 +644,41 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
     for (int o = 32; o >= 1; o >>= 1) {
       const float ob = __shfl_xor(best, o);
       const int oi = __shfl_xor(bidx, o);
-      if (ob > best || (ob == best && oi < bidx)) {
+      const int oc = __shfl_xor(cnt, o);
+      if (ob > best) {
         best = ob;
         bidx = oi;
+        cnt = oc;
+      } else if (ob == best) {
+        bidx = min(bidx, oi);
+        cnt += oc;
       }
     }
     if (lane == 0) {
       s_wbest[wave] = best;
       s_widx[wave] = bidx;
+      s_wcnt[wave] = cnt;
     }
     __syncthreads();
     best = s_wbest[0];
     bidx = s_widx[0];
+    cnt = s_wcnt[0];
 #pragma unroll
-    for (int k = 1; k < 4; ++k)
-      if (s_wbest[k] > best || (s_wbest[k] == best && s_widx[k] < bidx)) {
+    for (int k = 1; k < 4; ++k) {
+      if (s_wbest[k] > best) {
         best = s_wbest[k];
         bidx = s_widx[k];
+        cnt = s_wcnt[k];
+      } else if (s_wbest[k] == best) {
+        bidx = min(bidx, s_widx[k]);
+        cnt += s_wcnt[k];
       }
+    }
     if (!(best > 0.f)) break;  // uniform
+    if (cnt > 1) {             // uniform
+      tie = true;
+      break;
+    }
     if (tid == 0) {
       const int a = bidx / nB, b = bidx - a * nB;
       s_usedA[a] = 1;
@@ -513,6 +687,38 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
       cn[1 + 3 * k + 0] = a;
       cn[1 + 3 * k + 1] = b;
       cn[1 + 3 * k + 2] = __float_as_int(best);
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tie) {
+    // the reference's own sequence for this limb, from the start: candidates in push order
+    // (a ascending, b ascending, cpp:56-94), libstdc++'s std::sort, scan (cpp:98-123)
+    for (int i = tid; i < kDecodeMaxPeaks; i += 256) {
+      s_usedA[i] = 0;
+      s_usedB[i] = 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int* list = tie_ws + ((size_t)n * RTPOSE_NUM_LIMB + pair_id) * pcap * pcap;
+      int nc = 0;
+      for (int p = 0; p < npairs; ++p)
+        if (s_score[p] > 0.f) list[nc++] = p;
+      SortReplay sr{list, s_score, s_stack};
+      sr.sort_desc(nc);
+      int k = 0;
+      for (int c = 0; c < nc && k < max_conn; ++c) {
+        const int p = list[c];
+        const int a = p / nB, b = p - a * nB;
+        if (s_usedA[a] || s_usedB[b]) continue;
+        s_usedA[a] = 1;
+        s_usedB[b] = 1;
+        cn[1 + 3 * k + 0] = a;
+        cn[1 + 3 * k + 1] = b;
+        cn[1 + 3 * k + 2] = __float_as_int(s_score[p]);
+        ++k;
+      }
+      s_nconn = k;
     }
     __syncthreads();
   }
@@ -737,6 +943,8 @@ int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int 
   char* wsb = static_cast<char*>(workspace);
   float* score_ws = reinterpret_cast<float*>(wsb + decode_ws_conn_bytes(cfg, N));
   float* rows_ws = reinterpret_cast<float*>(wsb + decode_ws_conn_bytes(cfg, N) + decode_ws_score_bytes(cfg, N));
+  int32_t* tie_ws = reinterpret_cast<int32_t*>(wsb + decode_ws_conn_bytes(cfg, N) + decode_ws_score_bytes(cfg, N) +
+                                               decode_ws_rows_bytes(cfg, N));
   const size_t lds = pcap * pcap <= kLdsPairs ? (size_t)pcap * pcap * sizeof(float) : 0;
   static PerDeviceOnce attr_set;  // zero-initialised; the attribute is per device
   const int dev = current_device();
@@ -748,7 +956,7 @@ int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int 
     attr_set.set(dev);
   }
   hipLaunchKernelGGL(limb_assign_kernel, dim3(RTPOSE_NUM_LIMB, N), dim3(256), lds, s, to_view(paf, lpaf), h,
-                     w, inv_up, h1, pcap, res, words, conn, conn_words, score_ws);
+                     w, inv_up, h1, pcap, res, words, conn, conn_words, score_ws, tie_ws);
   const int row_cap = decode_row_cap(cfg);
   const size_t rows_lds = row_cap <= kLdsRows ? (size_t)row_cap * 21 * sizeof(float) : 0;
   hipLaunchKernelGGL(group_kernel, dim3(N), dim3(64), rows_lds, s, pcap, cfg->max_humans, res, words, conn,

@@ -65,9 +65,9 @@ def test_process_paf_oracle_vs_compiled_reference_random(synth):
         assert np.array_equal(ref["parts"], mine["parts"]), trial
         assert np.array_equal(ref["score"].view(np.uint32), mine["score"].view(np.uint32)), trial
         hits += len(ref["parts"])
-        # ... and the contract mode (ties -> lower (idx1, idx2), what the GPU kernel does)
-        # must agree with it whenever there is no tie
-        contract = po.process_paf(jl, paf, 8)
+        # ... and the stable mode (ties -> lower (idx1, idx2), what the GPU kernel's arg-max loop
+        # does until it meets a tie and replays the sort) must agree with it whenever there is no tie
+        contract = po.process_paf(jl, paf, 8, libstdcxx_sort=False)
         ties += contract["had_ties"]
         if not contract["had_ties"]:
             assert np.array_equal(ref["parts"], contract["parts"]), trial
