@@ -307,6 +307,8 @@ def main():
     args = ap.parse_args()
 
     par = importlib.import_module(PKG + ".parallel")
+    if not args.stub_step:
+        par.require_devices(args.gpus, "bench.py")      # before any rank is spawned
     if args.gpus > 1 and not par.launched_by_torchrun():
         # started plain: run the N ranks ourselves (the driver's own launch line), relay their output
         raise SystemExit(par.relaunch_under_torchrun(os.path.abspath(__file__), sys.argv[1:], args.gpus))

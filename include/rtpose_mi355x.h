@@ -311,6 +311,18 @@ int rtpose_pack_pw_weights_bf16(const float* w_oi, const float* bias, int cout, 
                                 float* bias_packed, void* stream);
 int rtpose_pw_fused_bf16(const rtpose_pw_desc* d, int out_f32, int N, int H, int W, void* stream);
 
+/* conv5 + both heads as ONE launch in the bf16 plan (csrc/pw_head_bf16.hip; same reference lines as rtpose_pw_head):
+ * d1 = the wide conv (+ReLU): bf16 input slice (layouts count ELEMENTS, multiples of 8) or a gather of cin / 8 16-byte
+ * planes (d1->in_planes), cin a multiple of 16 up to 480, w_packed [cin / 8][coutp][8 bf16] from
+ * rtpose_pack_pw_weights_bf16 (plain column order), cout = coutp a multiple of 256 up to 1024; d2 = the heads: ONE shared matrix [coutp1 / 8][64][8 bf16] packed by rtpose_pack_pw_head2_bf16
+ * (the k order in which the first GEMM's accumulators come out of the matrix pipe; columns at their output channels,
+ * columns nobody owns must be zero), fp32 bias [64], 64 fp32 channels stored at d2->lout.choff.  The conv5 feature is
+ * rounded to bf16 (RNE) after its ReLU and never leaves the registers; sums are fp32 in a fixed order. */
+int rtpose_pw_head_bf16_fits(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2);
+int rtpose_pw_head_bf16(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2, int N, int H, int W, void* stream);
+int rtpose_pack_pw_head2_bf16(const float* w_oi, const float* bias, int cout, int cin, int col_off, void* w_packed,
+                              float* bias_packed, void* stream);
+
 /* ---- bf16 variant (BASELINE config 3: "bf16, multi-scale x4 + flip") ----------------
  * Same modules, bf16 activations and weights, fp32 accumulate
  * (v_mfma_f32_32x32x16_bf16), bias/ReLU/pool in fp32, output rounded to bf16
@@ -525,6 +537,11 @@ int rtpose_net_conv_numerics(rtpose_net* net, int idx, int* form, float* amp, vo
 /* Device-side error word of the plan (synchronises `stream`): bit 0 = a split-tile hand-over of a
  * persistent 7x7 launch timed out (see rtpose_conv2d_winograd_ex); 0 = none.  The word is cleared. */
 int rtpose_net_device_status(rtpose_net* net, int* error_word, void* stream);
+/* The same without the wait: queues the copy of the error word into *host_word (pinned host memory, or the copy
+ * is not asynchronous) and its clearing on `stream` and returns; the word is valid once the caller has waited for
+ * anything it queued on `stream` afterwards (an event behind the D2H of a batch's records: the host that
+ * pipelines batches never synchronises the whole stream for it). */
+int rtpose_net_device_status_async(rtpose_net* net, int* host_word, void* stream);
 /* 1 when forwards of this plan replay a captured hipGraph (RTPOSE_GRAPH=1 in the environment and the capture
  * succeeded), else 0. */
 int rtpose_net_graph_active(const rtpose_net* net);

@@ -127,6 +127,9 @@ _SIGS = {
     "rtpose_packed_pw_bytes_bf16": (_sz, [_i, _i]),
     "rtpose_pack_pw_weights_bf16": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "rtpose_pw_fused_bf16": (_i, [C.POINTER(PwDesc), _i, _i, _i, _i, _vp]),
+    "rtpose_pw_head_bf16_fits": (_i, [C.POINTER(PwDesc), C.POINTER(PwDesc)]),
+    "rtpose_pw_head_bf16": (_i, [C.POINTER(PwDesc), C.POINTER(PwDesc), _i, _i, _i, _vp]),
+    "rtpose_pack_pw_head2_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "rtpose_maxpool2x2": (_i, [_vp, _LP, _vp, _LP, _i, _i, _i, _i, _vp]),
     "rtpose_nchw_to_layout": (_i, [_vp, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
     "rtpose_layout_to_nchw": (_i, [_vp, _LP, _vp, _i, _i, _i, _i, _vp]),
@@ -150,6 +153,7 @@ _SIGS = {
     "rtpose_net_finalize_weights": (_i, [_vp, _vp]),
     "rtpose_net_conv_numerics": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_float), _vp]),
     "rtpose_net_device_status": (_i, [_vp, C.POINTER(_i), _vp]),
+    "rtpose_net_device_status_async": (_i, [_vp, _vp, _vp]),
     "rtpose_net_graph_active": (_i, [_vp]),
     "rtpose_net_dtype": (_i, [_vp]),
     "rtpose_packed_weight_bytes_bf16": (_sz, [_i, _i, _i]),

@@ -40,6 +40,45 @@ inline int current_device() {
   return d;
 }
 
+// HIP device that owns device memory `p`, or -1 (host / unregistered memory).  One look-up in the runtime's
+// allocation map (~1 us): done where a pointer is handed over (bind) and once per NEW pointer on the hot path.
+inline int pointer_device(const void* p) {
+  hipPointerAttribute_t a;
+  if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) ? a.device : -1;
+}
+// A launch goes to the CURRENT device with pointers that are only valid on the device that owns them: one
+// process may hold several GPUs (nn.DataParallel replicas, demo/picture_demo.py:47; a mis-set LOCAL_RANK on an
+// 8-GPU node), so every entry point that takes device memory refuses memory of another device - or of none -
+// instead of launching.  Returns 0 or fail(...).
+inline int check_device_ptr(const void* p, int dev, const char* who, const char* what) {
+  const int owner = pointer_device(p);
+  if (owner == dev) return 0;
+  if (owner < 0)
+    return fail(RTPOSE_E_INVAL, "%s: %s (%p) is not device memory of a HIP device (host pointer? freed?)", who, what, p);
+  return fail(RTPOSE_E_INVAL, "%s: %s lives on HIP device %d but the current device is %d (hipSetDevice / "
+                              "torch.cuda.device before the call, or bind the plan on the device that runs it)",
+              who, what, owner, dev);
+}
+// the last pointer an entry point verified for one of its arguments (per plan, or thread_local for the free
+// functions): the look-up is repeated only when the caller passes another pointer
+struct CheckedPtr {
+  const void* p = nullptr;
+  int dev = -1;
+  int check(const void* q, int cur, const char* who, const char* what) {
+    if (q == p && dev == cur) return 0;
+    const int rc = check_device_ptr(q, cur, who, what);
+    if (!rc) {
+      p = q;
+      dev = cur;
+    }
+    return rc;
+  }
+};
+
 // "done once per device" flag set (e.g. hipFuncSetAttribute of one kernel instantiation);
 // benign if two threads race: the attribute is simply set twice.
 struct PerDeviceOnce {

@@ -7,6 +7,7 @@ namespace rtpose {
 constexpr int kDecodeMaxPeaks = 1024;  // per (image, part) table capacity limit
 constexpr int kLdsPairs = 110 * 110;   // candidate-score matrix entries that fit in LDS
 constexpr int kLdsRows = 720;          // subset rows (21 floats each) that fit in LDS
+constexpr int kTieLdsCands = 4096;     // candidates (8 bytes each) of a limb that replays std::sort in LDS
 
 // word (4-byte) offsets inside one image's result record
 constexpr int kResHeader = 0;      // [0] n_peaks [1] n_humans [2] overflow flags [3] max_peaks_per_part [4] max_humans
@@ -47,7 +48,7 @@ inline size_t decode_ws_rows_bytes(const rtpose_decode_cfg* c, int N) {
 }
 inline size_t decode_ws_tie_bytes(const rtpose_decode_cfg* c, int N) {
   const size_t p = (size_t)c->max_peaks_per_part;
-  return round_up((size_t)N * RTPOSE_NUM_LIMB * p * p * sizeof(int32_t), 256);
+  return round_up((size_t)N * RTPOSE_NUM_LIMB * p * p * sizeof(unsigned long long), 256);
 }
 inline size_t decode_workspace_bytes(const rtpose_decode_cfg* c, int N) {
   return decode_ws_conn_bytes(c, N) + decode_ws_score_bytes(c, N) + decode_ws_rows_bytes(c, N) +

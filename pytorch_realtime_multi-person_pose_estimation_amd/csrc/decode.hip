@@ -396,34 +396,40 @@ __global__ void peak_prefix_kernel(int pcap, int32_t* __restrict__ result, int r
 // meets first is decided by the introsort's moves - median-of-3 quicksort down to 16-element
 // runs under a 2 floor(log2 n) depth limit (heap sort beyond it), then one insertion pass.  The
 // product is "identical to pafprocess.cpp built with g++ 11", so the rare limb with such a tie
-// replays those moves on its candidate list L (entries = a * nB + b in the reference's push
-// order, scores looked up in S); comp(a, b) = S[a] > S[b].
+// replays those moves on its candidate list L (entries in the reference's push order, each the
+// score's bits above the pair index a * nB + b); comp(a, b) = a.score > b.score.  The list lives
+// in LDS when it has at most kTieLdsCands entries (a dependent access every ~100 cycles instead
+// of every ~500-2000), else in the workspace.
 // ------------------------------------------------------------------------------
 struct SortReplay {
-  int* L;
-  const float* S;
-  int* stk;  // LDS, 3 ints per pending range
-  __device__ __forceinline__ bool gt(int pa, int pb) const { return S[pa] > S[pb]; }
+  unsigned long long* L;  // entry = score bits << 32 | (a * nB + b); LDS when the list fits, else the workspace
+  int* stk;               // LDS, 3 ints per pending range
+  // scores are positive finite floats: their bit patterns order like their values, equal iff the floats are equal
+  static __device__ __forceinline__ bool gt(unsigned long long a, unsigned long long b) {
+    return (unsigned)(a >> 32) > (unsigned)(b >> 32);
+  }
   __device__ __forceinline__ void swap(int i, int j) {
-    const int t = L[i];
+    const unsigned long long t = L[i];
     L[i] = L[j];
     L[j] = t;
   }
   __device__ void unguarded_linear_insert(int last) {
-    const int val = L[last];
+    const unsigned long long val = L[last];
     int next = last - 1;
-    while (gt(val, L[next])) {
-      L[last] = L[next];
+    unsigned long long nv = L[next];
+    while (gt(val, nv)) {
+      L[last] = nv;
       last = next;
       --next;
+      nv = L[next];
     }
     L[last] = val;
   }
   __device__ void insertion_sort(int first, int last) {
     if (first == last) return;
     for (int i = first + 1; i != last; ++i) {
-      if (gt(L[i], L[first])) {
-        const int val = L[i];
+      const unsigned long long val = L[i];
+      if (gt(val, L[first])) {
         for (int k = i; k > first; --k) L[k] = L[k - 1];  // move_backward(first, i, i + 1)
         L[first] = val;
       } else {
@@ -431,7 +437,7 @@ struct SortReplay {
       }
     }
   }
-  __device__ void push_heap(int first, int hole, int top, int value) {
+  __device__ void push_heap(int first, int hole, int top, unsigned long long value) {
     int parent = (hole - 1) / 2;
     while (hole > top && gt(L[first + parent], value)) {
       L[first + hole] = L[first + parent];
@@ -440,7 +446,7 @@ struct SortReplay {
     }
     L[first + hole] = value;
   }
-  __device__ void adjust_heap(int first, int hole, int len, int value) {
+  __device__ void adjust_heap(int first, int hole, int len, unsigned long long value) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
@@ -465,25 +471,27 @@ struct SortReplay {
       }
     while (last - first > 1) {  // __sort_heap
       --last;
-      const int value = L[last];
+      const unsigned long long value = L[last];
       L[last] = L[first];
       adjust_heap(first, 0, last - first, value);
     }
   }
   __device__ void move_median_to_first(int result, int a, int b, int c) {
-    if (gt(L[a], L[b])) {
-      if (gt(L[b], L[c])) swap(result, b);
-      else if (gt(L[a], L[c])) swap(result, c);
+    const unsigned long long va = L[a], vb = L[b], vc = L[c];
+    if (gt(va, vb)) {
+      if (gt(vb, vc)) swap(result, b);
+      else if (gt(va, vc)) swap(result, c);
       else swap(result, a);
-    } else if (gt(L[a], L[c])) swap(result, a);
-    else if (gt(L[b], L[c])) swap(result, c);
+    } else if (gt(va, vc)) swap(result, a);
+    else if (gt(vb, vc)) swap(result, c);
     else swap(result, b);
   }
   __device__ int unguarded_partition(int first, int last, int pivot) {
+    const unsigned long long pv = L[pivot];  // (the pivot sits at `first - 1`, outside the range being swapped)
     for (;;) {
-      while (gt(L[first], L[pivot])) ++first;
+      while (gt(L[first], pv)) ++first;
       --last;
-      while (gt(L[pivot], L[last])) --last;
+      while (gt(pv, L[last])) --last;
       if (!(first < last)) return first;
       swap(first, last);
       ++first;
@@ -542,13 +550,13 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
                                                           const int32_t* __restrict__ result,
                                                           int result_words, int32_t* __restrict__ conn,
                                                           int conn_words, float* __restrict__ score_ws,
-                                                          int32_t* __restrict__ tie_ws) {
+                                                          unsigned long long* __restrict__ tie_ws) {
   const int pair_id = blockIdx.x, n = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int32_t* res = result + (size_t)n * result_words;
   int32_t* cn = conn + (size_t)n * conn_words + (size_t)pair_id * (1 + 3 * pcap);
 
-  extern __shared__ float s_score_lds[];  // [nA * nB] candidate scores, 0 = none
+  extern __shared__ float s_score_lds[];  // [pcap * pcap] candidate scores, 0 = none (when they fit), then the tie list
   __shared__ unsigned char s_usedA[kDecodeMaxPeaks], s_usedB[kDecodeMaxPeaks];
   __shared__ float s_wbest[4];
   __shared__ int s_widx[4], s_wcnt[4];
@@ -699,23 +707,49 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
       s_usedB[i] = 0;
     }
     __syncthreads();
+    // candidates in push order: ordered compaction by ballot / popcount, like the peak ids
+    const bool score_in_lds = pcap * pcap <= kLdsPairs;
+    unsigned long long* lds_list =
+        reinterpret_cast<unsigned long long*>(s_score_lds + (score_in_lds ? ((pcap * pcap + 1) & ~1) : 0));
+    unsigned long long* ws_list = tie_ws + ((size_t)n * RTPOSE_NUM_LIMB + pair_id) * pcap * pcap;
+    for (int pass = 0; pass < 2; ++pass) {  // pass 0 counts (LDS or workspace?), pass 1 writes
+      unsigned long long* list = (s_nconn <= kTieLdsCands) ? lds_list : ws_list;  // (s_nconn = the count after pass 0)
+      int base = 0;
+      for (int start = 0; start < npairs; start += 256) {
+        const int p = start + tid;
+        const float sc = p < npairs ? s_score[p] : 0.f;
+        const bool c = sc > 0.f;
+        const unsigned long long mask = __ballot(c);
+        if (lane == 0) s_wcnt[wave] = __popcll(mask);
+        __syncthreads();
+        int off = base;
+        for (int k = 0; k < wave; ++k) off += s_wcnt[k];
+        if (c && pass == 1)
+          list[off + __popcll(mask & ((1ull << lane) - 1ull))] =
+              ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned)p;
+        base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
+      }
+      if (tid == 0) s_nconn = base;
+      __syncthreads();
+    }
+    __threadfence_block();
     if (tid == 0) {
-      int* list = tie_ws + ((size_t)n * RTPOSE_NUM_LIMB + pair_id) * pcap * pcap;
-      int nc = 0;
-      for (int p = 0; p < npairs; ++p)
-        if (s_score[p] > 0.f) list[nc++] = p;
-      SortReplay sr{list, s_score, s_stack};
+      const int nc = s_nconn;
+      unsigned long long* list = (nc <= kTieLdsCands) ? lds_list : ws_list;
+      SortReplay sr{list, s_stack};
       sr.sort_desc(nc);
       int k = 0;
       for (int c = 0; c < nc && k < max_conn; ++c) {
-        const int p = list[c];
+        const unsigned long long e = list[c];
+        const int p = (int)(unsigned)e;
         const int a = p / nB, b = p - a * nB;
         if (s_usedA[a] || s_usedB[b]) continue;
         s_usedA[a] = 1;
         s_usedB[b] = 1;
         cn[1 + 3 * k + 0] = a;
         cn[1 + 3 * k + 1] = b;
-        cn[1 + 3 * k + 2] = __float_as_int(s_score[p]);
+        cn[1 + 3 * k + 2] = (int)(unsigned)(e >> 32);
         ++k;
       }
       s_nconn = k;
@@ -943,14 +977,16 @@ int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int 
   char* wsb = static_cast<char*>(workspace);
   float* score_ws = reinterpret_cast<float*>(wsb + decode_ws_conn_bytes(cfg, N));
   float* rows_ws = reinterpret_cast<float*>(wsb + decode_ws_conn_bytes(cfg, N) + decode_ws_score_bytes(cfg, N));
-  int32_t* tie_ws = reinterpret_cast<int32_t*>(wsb + decode_ws_conn_bytes(cfg, N) + decode_ws_score_bytes(cfg, N) +
+  unsigned long long* tie_ws = reinterpret_cast<unsigned long long*>(wsb + decode_ws_conn_bytes(cfg, N) + decode_ws_score_bytes(cfg, N) +
                                                decode_ws_rows_bytes(cfg, N));
-  const size_t lds = pcap * pcap <= kLdsPairs ? (size_t)pcap * pcap * sizeof(float) : 0;
+  // scores (when they fit) + the LDS-resident candidate list of a limb that replays std::sort
+  const size_t lds = (pcap * pcap <= kLdsPairs ? (size_t)((pcap * pcap + 1) & ~1) * sizeof(float) : 0) +
+                     (size_t)kTieLdsCands * sizeof(unsigned long long);
   static PerDeviceOnce attr_set;  // zero-initialised; the attribute is per device
   const int dev = current_device();
   if (!attr_set.is_set(dev)) {
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(limb_assign_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     attr_set.set(dev);
@@ -984,6 +1020,11 @@ size_t rtpose_decode_result_bytes(const rtpose_decode_cfg* cfg, int N) {
 int rtpose_nms_batch_ex(const float* heat, const rtpose_layout* lheat, int N, int h, int w,
                         const rtpose_decode_cfg* cfg, int nms_flags, void* result, void* stream) {
   if (!heat || !lheat || !result) return fail(RTPOSE_E_INVAL, "nms: NULL argument");
+  static thread_local CheckedPtr c_heat, c_res;
+  const int dev = current_device();
+  int rcd = c_heat.check(heat, dev, "nms", "the heat-map tensor");
+  if (!rcd) rcd = c_res.check(result, dev, "nms", "the result block");
+  if (rcd) return rcd;
   return nms_launch(heat, lheat, N, h, w, cfg, result, as_stream(stream), nms_flags);
 }
 
@@ -1010,6 +1051,14 @@ int rtpose_decode_batch_ex(const float* heat, const rtpose_layout* lheat, const 
                            int nms_flags, void* workspace, size_t workspace_bytes, void* result, void* stream) {
   if (!heat || !lheat || !paf || !lpaf || !workspace || !result)
     return fail(RTPOSE_E_INVAL, "decode: NULL argument");
+  // (the look-ups are repeated only when a caller passes other pointers than last time on this thread)
+  static thread_local CheckedPtr c_heat, c_paf, c_ws, c_res;
+  const int dev = current_device();
+  int rcd = c_heat.check(heat, dev, "decode", "the heat-map tensor");
+  if (!rcd) rcd = c_paf.check(paf, dev, "decode", "the PAF tensor");
+  if (!rcd) rcd = c_ws.check(workspace, dev, "decode", "the workspace");
+  if (!rcd) rcd = c_res.check(result, dev, "decode", "the result block");
+  if (rcd) return rcd;
   int rc = nms_launch(heat, lheat, N, h, w, cfg, result, as_stream(stream), nms_flags);
   if (rc) return rc;
   return assign_group_launch(paf, lpaf, N, h, w, 1.0 / (double)cfg->upsample, h * cfg->upsample, cfg,

@@ -126,6 +126,8 @@ struct rtpose_net {
   bool amps_read = false;
   uint64_t seen_gen = ~0ull;     // generation of the weight arena the estimates / forms above were taken from
   int n_cu = 0;                  // CUs of the device the plan was created for (sizes the hand-over scratch)
+  int device = -1;               // HIP device that owns the bound arenas: the only device this plan launches on
+  CheckedPtr in_checked;         // last input pointer verified to live on that device
   size_t scratch_off = 0, scratch_bytes = 0;  // persistent 7x7 launches: hand-over scratch inside the workspace
   int x0f_buf = -1;              // bf16 plans: fp32 NHWC8 staging buffer for rtpose_preprocess_u8
   int H3 = 0, W3 = 0;            // stride-8 map
@@ -682,6 +684,15 @@ int rtpose_net_bind(rtpose_net* net, void* workspace, size_t workspace_bytes, vo
     return fail(RTPOSE_E_INVAL, "net_bind: arena too small");
   if (((uintptr_t)workspace | (uintptr_t)weights) & 255)
     return fail(RTPOSE_E_INVAL, "net_bind: arenas must be 256-byte aligned");
+  const int dev = current_device();
+  int rcd = check_device_ptr(workspace, dev, "net_bind", "the workspace");
+  if (!rcd) rcd = check_device_ptr(weights, dev, "net_bind", "the weight arena");
+  if (rcd) return rcd;
+  if (device_cu_count() != net->n_cu)
+    return fail(RTPOSE_E_STATE, "net_bind: the plan was created for a device of %d CUs, the current device %d has %d "
+                                "(create the plan with that device current)", net->n_cu, dev, device_cu_count());
+  net->device = dev;
+  net->in_checked = CheckedPtr();
   for (hipGraphExec_t& g : net->gexec) {  // captured pointers are about to change
     if (g) (void)hipGraphExecDestroy(g);
     g = nullptr;
@@ -730,9 +741,15 @@ int rtpose_net_conv_info(const rtpose_net* net, int idx, char* name, int name_ca
   return 0;
 }
 
+static int net_on_its_device(const rtpose_net* net, const char* who);
+
 int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw, const float* bias, void* stream) {
   if (!net || !net->bound) return fail(RTPOSE_E_STATE, "net_load_conv: net not bound");
   if (idx < 0 || idx >= (int)net->convs.size()) return fail(RTPOSE_E_INVAL, "net_load_conv: bad index");
+  int rcd = net_on_its_device(net, "net_load_conv");
+  if (!rcd) rcd = check_device_ptr(w_oihw, net->device, "net_load_conv", "the filter tensor");
+  if (!rcd && bias) rcd = check_device_ptr(bias, net->device, "net_load_conv", "the bias tensor");
+  if (rcd) return rcd;
   const ConvW& c = net->convs[idx];
   const int32_t* map = c.cat_perm ? reinterpret_cast<const int32_t*>(net->wt + net->catmap_off) : nullptr;
   hipStream_t s = as_stream(stream);
@@ -780,6 +797,10 @@ int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw, const fl
 
 static int read_amps(rtpose_net* net, hipStream_t s) {
   if (net->amps_read || net->bf16) return 0;
+  // the estimates are written by the pack kernels of rtpose_net_load_conv on whatever stream THAT call was given -
+  // possibly a sibling plan's, another stream than `s` (the arena is shared by the plans of a module).  Once per
+  // weight load, so the whole device is drained rather than an event kept per arena.
+  RTPOSE_HIP_CHECK(hipDeviceSynchronize());
   // one contiguous read-back of the arena span that holds the estimates would drag the packed filters along;
   // 92 small copies once per weight load are cheaper
   for (ConvW& c : net->convs)
@@ -831,6 +852,19 @@ int rtpose_net_device_status(rtpose_net* net, int* error_word, void* stream) {
   RTPOSE_HIP_CHECK(hipMemcpyAsync(error_word, err, sizeof(int), hipMemcpyDeviceToHost, s));
   RTPOSE_HIP_CHECK(hipMemsetAsync(err, 0, sizeof(int), s));
   RTPOSE_HIP_CHECK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int rtpose_net_device_status_async(rtpose_net* net, int* host_word, void* stream) {
+  if (!net || !net->bound || !host_word) return fail(RTPOSE_E_STATE, "net_device_status_async: net not bound / NULL argument");
+  if (net->bf16 || !net->scratch_bytes) {
+    *host_word = 0;
+    return 0;
+  }
+  hipStream_t s = as_stream(stream);
+  int* err = conv2d_wino7_scratch_err(net->ws + net->scratch_off, net->n_cu);
+  RTPOSE_HIP_CHECK(hipMemcpyAsync(host_word, err, sizeof(int), hipMemcpyDeviceToHost, s));
+  RTPOSE_HIP_CHECK(hipMemsetAsync(err, 0, sizeof(int), s));
   return 0;
 }
 
@@ -926,10 +960,33 @@ int rtpose_net_input_view(const rtpose_net* net, float** base, rtpose_layout* la
 
 static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* x_nchw, void* stream, bool prof);
 
+// the plan's kernels go to the CURRENT device with pointers into the arenas bound on net->device
+static int net_on_its_device(const rtpose_net* net, const char* who) {
+  const int cur = current_device();
+  if (cur == net->device) return 0;
+  return fail(RTPOSE_E_STATE, "%s: the plan's arenas live on HIP device %d but the current device is %d", who,
+              net->device, cur);
+}
+
 static int net_forward_impl(rtpose_net* net, const float* x_nchw, void* stream) {
   if (!net || !net->bound) return fail(RTPOSE_E_STATE, "net_forward: net not bound");
   hipStream_t s = as_stream(stream);
+  int rcd = net_on_its_device(net, "net_forward");
+  if (!rcd && x_nchw) rcd = net->in_checked.check(x_nchw, net->device, "net_forward", "the input tensor");
+  if (rcd) return rcd;
   sync_arena_generation(net);
+  bool stale = false;
+  for (const Buf& b : net->bufs) stale |= b.stale;
+  if (!net->forms_final || stale) {
+    // deciding AUTO forms reads the amplification estimates back (92 small D2H copies + a stream synchronise) and a
+    // buffer that changed storage is cleared: neither may happen inside a stream capture, where the first is illegal
+    // and the second would be baked into the graph
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+      return fail(RTPOSE_E_STATE, "net_forward: the stream is capturing but the plan's forms are not final (weights were "
+                                  "loaded since the last forward): call rtpose_net_finalize_weights and run one forward "
+                                  "outside the capture first");
+  }
   if (!net->forms_final) {  // AUTO forms, and the host did not call rtpose_net_finalize_weights since the last load
     const int rcf = rtpose_net_finalize_weights(net, stream);
     if (rcf) return rcf;
@@ -1158,6 +1215,9 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
 int rtpose_net_read_output(rtpose_net* net, int which, float* dst_nchw, void* stream) {
   if (!net || !net->bound) return fail(RTPOSE_E_STATE, "net_read_output: net not bound");
   if (which < 0 || which > 11 || !dst_nchw) return fail(RTPOSE_E_INVAL, "net_read_output: bad argument");
+  int rcd = net_on_its_device(net, "net_read_output");
+  if (!rcd) rcd = check_device_ptr(dst_nchw, net->device, "net_read_output", "the destination tensor");
+  if (rcd) return rcd;
   const int stage = which / 2 + 1, br = which % 2;
   const int C = br == 0 ? 38 : 19;
   int buf, choff;

@@ -44,6 +44,11 @@ int pw_halo_stride(const rtpose_layout& l, int H, int W);
 // conv5 + the two heads as one back-to-back launch (pw_head.hip)
 int pw_head_launch(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2, int N, int H, int W, hipStream_t s);
 int pw_zero_columns_launch(float* wp, float* bp, int K, int coutp, int c0, int c1, hipStream_t s);
+// ... and of the bf16 plan (pw_head_bf16.hip)
+int pw_head_bf16_launch(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2, int N, int H, int W, hipStream_t s);
+int pack_head_w2_bf16_launch(const float* w, const float* bias, int cout, int K, int col_off, void* wp, float* bp,
+                             hipStream_t s);
+int zero_head_columns_bf16_launch(void* wp, float* bp, int K, int c0, int c1, hipStream_t s);
 // column-mapped fp32 packing (pw_fused.hip): a layer's columns in the memory order of the runs it writes
 int pack_pw_cols_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map, int K,
                         int ncols, const int32_t* col_map, int coutp, int col_off, float* wp, float* bp,
@@ -107,7 +112,7 @@ struct SBuf {
   int C = 0, H = 0, W = 0;
 };
 
-enum OKind { O_INPUT, O_STEM, O_POOL3, O_DW, O_PW, O_COPYMAP, O_PWF, O_STEMPOOL, O_HEAD };
+enum OKind { O_INPUT, O_STEM, O_POOL3, O_DW, O_PWF, O_STEMPOOL, O_HEAD };
 
 struct SOp {
   OKind kind;
@@ -137,7 +142,8 @@ struct Map {
 struct rtpose_shufflenet {
   int N = 0, H = 0, W = 0, Hm = 0, Wm = 0;  // Hm x Wm: stride-8 maps
   int bf16 = 0;  // 1: 2-byte activations + bf16 pointwise weights (fp32 accumulate); outputs stay fp32
-  int fused = 0; // fp32 plans: pointwise chains run as fused launches (pw_fused.hip)
+  int device = -1;      // HIP device that owns the bound arenas
+  CheckedPtr in_checked;
   std::vector<SBuf> bufs;
   std::vector<SLayer> layers;
   std::vector<SOp> ops;
@@ -198,10 +204,9 @@ int add_layer(rtpose_shufflenet* n, LKind kind, const std::string& name, int cou
     case L_PW:
       // (fused bf16 plans: a layer that writes whole slot groups of the stage buffer packs up to 256 columns -
       //  116 channels in 18 groups of 8 = 144 columns run in the 256-column instance)
-      wf = n->bf16 ? (n->fused ? (size_t)(cin_packed + 64) * (cout_pad(cout > 0 ? cout : 1) < 256 ? 256 : cout_pad(cout)) / 2
-                               : rtpose_packed_weight_bytes_bf16(cout, cin_packed, 1) / 4)
+      wf = n->bf16 ? (size_t)(cin_packed + 64) * (cout_pad(cout > 0 ? cout : 1) < 256 ? 256 : cout_pad(cout)) / 2
                    : (size_t)(cin_packed + 32) * cout_pad(cout + 8);
-      bf = (n->bf16 && n->fused && cout_pad(cout) < 256) ? 256 : rtpose_packed_bias_floats(cout);
+      bf = (n->bf16 && cout_pad(cout) < 256) ? 256 : rtpose_packed_bias_floats(cout);
       break;
   }
   n->wt_floats += round_up(wf, 64);
@@ -211,39 +216,6 @@ int add_layer(rtpose_shufflenet* n, LKind kind, const std::string& name, int cou
   return (int)n->layers.size() - 1;
 }
 
-
-// logical -> physical channel of a stage buffer (logical = the order after torch.cat + channel_shuffle(2)).
-//  * unfused (bf16) plans: two halves of h channels padded to hp: [0, h) | pad | [h, 2h) | pad - the
-//    next unit's x2 is the contiguous slice at hp; the shuffle is a strided scatter on the store side.
-//  * fused (fp32) plans: four runs of h/2 channels padded to q = hp / 2:
-//        [even-low | even-high | odd-low | odd-high],  logical 2i -> even, 2i+1 -> odd, i < h/2 -> low.
-//    Producers write CONTIGUOUS runs (the pass-through half = the evens, the GEMM = the odds), and the
-//    next unit reads x1 = (even-low, odd-low) interleaved, x2 = even-high + odd-high as two runs through
-//    the kernel's 16-byte plane gather: no strided 4-byte stores, every line written once.
-int fphys(int j, int h, int hp, bool quarter = false) {
-  if (!quarter) return j < h ? j : hp + (j - h);
-  const int q = hp / 2, hh = h / 2, i = j >> 1;
-  return (2 * (j & 1) + (i >= hh ? 1 : 0)) * q + (i >= hh ? i - hh : i);
-}
-
-void add_pw(rtpose_shufflenet* n, const std::string& name, int H, int W, int layer, int in_buf, int in_choff,
-            int out_buf, int out_choff, int cmap, int relu) {
-  SOp o;
-  o.kind = O_PW;
-  o.name = name;
-  o.H = H;
-  o.W = W;
-  o.layer[0] = layer;
-  o.in_buf[0] = in_buf;
-  o.in_choff[0] = in_choff;
-  o.out_buf[0] = out_buf;
-  o.out_choff[0] = out_choff;
-  o.cmap[0] = cmap;
-  o.relu = relu;
-  const SLayer& l = n->layers[layer];
-  o.flops = 2.0 * n->N * H * W * (double)l.cout * l.cin;
-  n->ops.push_back(o);
-}
 
 void add_dw(rtpose_shufflenet* n, const std::string& name, int H, int W, int layer, int in_buf, int out_buf,
             int stride) {
@@ -288,16 +260,6 @@ void add_pwf(rtpose_shufflenet* n, const std::string& name, int H, int W, int la
   if (dw_layer >= 0) o.flops += 2.0 * n->N * H * W * (double)n->layers[dw_layer].cin * 9;
   n->ops.push_back(o);
 }
-
-// can the depthwise 3x3 that reads `b` be evaluated inside the fused pointwise kernel?  (Always, since the
-// kernel works on 8 x 8 tiles with a 10 x 10 halo; the 64-pixel strips of its first version needed W <= 60.)
-bool dw_fusable(const rtpose_shufflenet* n, int buf, int H, int W) {
-  (void)buf;
-  (void)H;
-  (void)W;
-  return n->fused != 0;
-}
-
 
 // ---- zero-copy channel shuffle: slot plan of one stage ---------------------------------------------------------------
 // torch.cat((x1, conv(x2)), 1) + channel_shuffle(2) (rtpose_shufflenetV2.py:56-62) moves no data in the fused plans.
@@ -462,8 +424,8 @@ void build(rtpose_shufflenet* n) {
   // channel alignment of slices that feed a pointwise conv: 8 floats (fp32 kernel: cin % 8 == 0),
   // 16 elements for bf16 plans (one K = 16 MFMA step)
   // (fp32 fused plans: 16 too - the wave-autonomous head kernel, pw_head.hip, walks K in pairs of 8-channel groups)
-  const int al = (n->bf16 || n->fused) ? 16 : 8;
-  auto up8 = [al](int v) { return (v + al - 1) / al * al; };
+  const int al = 16;
+  auto up8 = [](int v) { return (v + al - 1) / al * al; };
   const int H0 = n->H, W0 = n->W;
   const int H1 = (H0 - 1) / 2 + 1, W1 = (W0 - 1) / 2 + 1;          // stem 3x3 s2 p1
   const int H2 = (H1 - 3 + 1) / 2 + 1, W2 = (W1 - 3 + 1) / 2 + 1;  // maxpool 3/2 ceil
@@ -510,17 +472,12 @@ void build(rtpose_shufflenet* n) {
   std::vector<int32_t> in_kmap, in_planes_v;
   int Hc = H2, Wc = W2;
   for (int si = 0; si < 3; ++si) {
-    // bf16 plans: halves padded to 64 channels (58 -> 64, 116 -> 128, 232 -> 256) so that every
-    // pointwise conv runs with 64-channel LDS chunks (232 padded to 240 would fall back to 16)
-    const bool qt = n->fused != 0;  // four-run channel layout (see fphys)
-    const int C = widths[si], h = C / 2,
-              hp = qt ? 2 * ((h / 2 + (n->bf16 ? 7 : 3)) / (n->bf16 ? 8 : 4) * (n->bf16 ? 8 : 4))  // 2 q, q = run pitch
-                      : (n->bf16 ? (h + 63) / 64 * 64 : up8(h));
+    const int C = widths[si], h = C / 2;
     const int stride = si == 0 ? 2 : 1;
     const int Ho = si == 0 ? H3 : Hc, Wo = si == 0 ? W3 : Wc;
     const std::string sp = "network." + std::to_string(3 + si) + ".";
-    if (n->fused) {
-      // ================= fused plans (round 4): ZERO-COPY channel shuffle, see zc_plan above =========================
+    {
+      // ================= ZERO-COPY channel shuffle (round 4), see zc_plan above =========================
       const int U = nblocks[si];
       const int in_phys = in_is_stage ? (int)in_kmap.size() : in_c;   // K of the layers that read the whole input buffer
       const int G = n->bf16 ? 8 : 4;                      // channels per 16-byte plane
@@ -622,169 +579,7 @@ void build(rtpose_shufflenet* n) {
       }
       Hc = Ho;
       Wc = Wo;
-      continue;
     }
-    // two ping-pong stage buffers (P = 1: the next stage's first block runs a dw conv on them)
-    const int SA = add_buf(n, 2 * hp, 1, Ho, Wo), SB = add_buf(n, 2 * hp, 1, Ho, Wo);
-    std::vector<int32_t> even(h), odd(h);
-    for (int i = 0; i < h; ++i) {
-      even[i] = fphys(2 * i, h, hp, qt);
-      odd[i] = fphys(2 * i + 1, h, hp, qt);
-    }
-    const int M_even = add_map(n, even), M_odd = add_map(n, odd);
-    // fused plans: x2 of a unit = logical [h, 2h) = the even-high run then the odd-high run.  Packed K position
-    // k reads x2 channel M_x2[k] (weights are permuted at pack time), plane j of K sits at channel M_pl[j].
-    int M_x2 = -1, M_pl = -1;
-    if (qt) {
-      const int q = hp / 2, hh = h / 2;
-      const int pg = n->bf16 ? 8 : 4;  // channels per 16-byte plane
-      // (K is padded to a whole number of 16-channel steps: the extra planes repeat plane 0 under zero weights)
-      std::vector<int32_t> x2(up8(hp), -1), pln(up8(hp) / pg);
-      for (int k = 0; k < hp; ++k) {
-        const int p = k < q ? k : k - q;
-        if (p < hh) x2[k] = 2 * p + (k < q ? 0 : 1);  // logical (h + 2p [+1]) - h
-      }
-      for (int j = 0; j < (int)pln.size(); ++j)
-        pln[j] = pg * j >= hp ? q : (pg * j < q ? q + pg * j : 3 * q + (pg * j - q));
-      M_x2 = add_map(n, x2);
-      M_pl = add_map(n, pln);
-    }
-    // bf16 fused plans: the epilogue stores the GEMM's columns as contiguous channels, so a layer that writes
-    // the even or the odd runs has its columns packed in run order: column c' = (low run | pad | high run | pad)
-    int M_cols = -1;
-    if (qt) {
-      const int q = hp / 2, hh = h / 2;
-      std::vector<int32_t> cm(cout_pad(hp), -1);  // (columns past hp: zero columns of the packed matrix)
-      for (int c = 0; c < hp; ++c) {
-        const int p = c < q ? c : c - q;
-        if (p < hh) cm[c] = c < q ? p : hh + p;
-      }
-      M_cols = add_map(n, cm);
-    }
-    auto runs_out = [&](int layer) {  // the layer writes both runs of a parity: hp packed / stored columns
-      if (M_cols < 0) return;
-      n->layers[layer].colmap_id = M_cols;
-      n->layers[layer].ncols = hp;
-      n->layers[layer].coutp = cout_pad(hp);
-    };
-    auto plain_out = [&](int layer, int cout) {  // contiguous output channels, whole 8-channel groups stored
-      if (!qt) return;
-      n->layers[layer].ncols = (cout + 7) / 8 * 8;
-      n->layers[layer].coutp = cout_pad(cout);
-    };
-    // temporaries
-    const int in_phys = in_is_stage ? (int)in_pmap.size() : in_c;
-    const int T0 = add_buf(n, up8(in_phys), 0, Ho, Wo);  // conv0 branch after dw
-    // (their channels past hp stay zero: the depthwise / pointwise convs that read them walk K = up8(hp))
-    const int T1a = add_buf(n, up8(hp), 1, Hc, Wc);     // first block: 1x1 at the INPUT resolution
-    const int T1 = add_buf(n, up8(hp), 1, Ho, Wo);
-    const int T2 = add_buf(n, up8(hp), 0, Ho, Wo);
-
-    // -- block 0: two-branch (reference :47-53, :60-61) --
-    {
-      const std::string bp = sp + "0.";
-      int M_in = -1, M_inphys = -1;
-      if (in_is_stage) {  // the previous stage's buffer: its own physical -> logical channel map
-        M_in = add_map(n, in_pmap);
-        M_inphys = M_in;
-      }
-      const int l_c00 = add_layer(n, L_DW, bp + "conv0.0", in_c, in_c, in_phys, M_inphys);
-      const int l_c01 = add_layer(n, L_PW, bp + "conv0.1", h, in_c, up8(in_phys), M_in);
-      const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, in_c, up8(in_phys), M_in);
-      const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, up8(hp), -1);
-      const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, up8(hp), -1);
-      runs_out(l_c01);
-      runs_out(l_c2);
-      plain_out(l_c0, h);
-      if (!n->fused) {
-        add_dw(n, bp + "conv0.0", Hc, Wc, l_c00, in_buf, T0, stride);
-        add_pw(n, bp + "conv0.1", Ho, Wo, l_c01, T0, 0, SA, 0, M_even, 1);
-        add_pw(n, bp + "conv.0", Hc, Wc, l_c0, in_buf, 0, T1a, 0, -1, 1);
-        add_dw(n, bp + "conv.1", Hc, Wc, l_c1, T1a, T2, stride);
-        add_pw(n, bp + "conv.2", Ho, Wo, l_c2, T2, 0, SA, 0, M_odd, 1);
-      } else {
-        // stride-1 depthwise convs are evaluated inside the pointwise launch that consumes them
-        if (stride == 1 && dw_fusable(n, in_buf, Hc, Wc)) {
-          add_pwf(n, bp + "conv0.0+conv0.1", Ho, Wo, l_c01, l_c00, in_buf, 0, SA, 0, M_even, 1);
-        } else {
-          add_dw(n, bp + "conv0.0", Hc, Wc, l_c00, in_buf, T0, stride);
-          add_pwf(n, bp + "conv0.1", Ho, Wo, l_c01, -1, T0, 0, SA, 0, M_even, 1);
-        }
-        add_pwf(n, bp + "conv.0", Hc, Wc, l_c0, -1, in_buf, 0, T1a, 0, -1, 1);
-        if (stride == 1 && dw_fusable(n, T1a, Hc, Wc)) {
-          add_pwf(n, bp + "conv.1+conv.2", Ho, Wo, l_c2, l_c1, T1a, 0, SA, 0, M_odd, 1);
-        n->ops.back().out_choff[0] = hp;  // the odd runs as contiguous columns
-        } else {
-          add_dw(n, bp + "conv.1", Hc, Wc, l_c1, T1a, T2, stride);
-          add_pwf(n, bp + "conv.2", Ho, Wo, l_c2, -1, T2, 0, SA, 0, M_odd, 1);
-        n->ops.back().out_choff[0] = hp;  // the odd runs as contiguous columns
-        }
-      }
-    }
-    int cur = SA, nxt = SB;
-    // -- blocks 1..: pass-through half + processed half (reference :31-39, :56-59) --
-    for (int b = 1; b < nblocks[si]; ++b) {
-      const std::string bp = sp + std::to_string(b) + ".";
-      const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, h, qt ? up8(hp) : hp, qt ? M_x2 : -1);
-      const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, qt ? up8(hp) : hp, -1);
-      const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, qt ? up8(hp) : hp, -1);
-      runs_out(l_c2);
-      plain_out(l_c0, h);
-      if (n->fused && dw_fusable(n, T1, Ho, Wo)) {
-        // two launches per unit: conv.0 (x2 gathered as two runs), then conv.1 (in LDS) -> conv.2 -> the odd
-        // runs + the next x1 = (even-low, odd-low) interleaved -> the even runs
-        add_pwf(n, bp + "conv.0", Ho, Wo, l_c0, -1, cur, 0, T1, 0, -1, 1);
-        n->ops.back().planes_map = M_pl;
-        add_pwf(n, bp + "conv.1+conv.2+x1", Ho, Wo, l_c2, l_c1, T1, 0, nxt, 0, M_odd, 1, cur, -1, 0);
-        n->ops.back().out_choff[0] = hp;  // the odd runs as contiguous columns
-        SOp& o = n->ops.back();
-        o.pt_pairs = h / 2;
-        o.pt_a = 0;
-        o.pt_b = hp;          // odd-low run = run 2 at 2 q
-        o.pt_split = h / 2;
-        o.pt_d0 = 0;
-        o.pt_d1 = hp / 2;     // even-high run at q
-      } else if (n->fused) {
-        // map too wide for the in-kernel depthwise halo: the depthwise conv runs as its own launch, the
-        // pointwise launches (plane gather, interleaved pass-through) stay the same
-        add_pwf(n, bp + "conv.0", Ho, Wo, l_c0, -1, cur, 0, T1, 0, -1, 1);
-        n->ops.back().planes_map = M_pl;
-        add_dw(n, bp + "conv.1", Ho, Wo, l_c1, T1, T2, 1);
-        add_pwf(n, bp + "conv.2+x1", Ho, Wo, l_c2, -1, T2, 0, nxt, 0, M_odd, 1, cur, -1, 0);
-        n->ops.back().out_choff[0] = hp;  // the odd runs as contiguous columns
-        SOp& o = n->ops.back();
-        o.pt_pairs = h / 2;
-        o.pt_a = 0;
-        o.pt_b = hp;
-        o.pt_split = h / 2;
-        o.pt_d0 = 0;
-        o.pt_d1 = hp / 2;
-      } else {
-        SOp c;
-        c.kind = O_COPYMAP;
-        c.name = bp + "x1->even";
-        c.H = Ho;
-        c.W = Wo;
-        c.in_buf[0] = cur;
-        c.out_buf[0] = nxt;
-        c.cmap[0] = M_even;
-        c.C = h;
-        n->ops.push_back(c);
-        add_pw(n, bp + "conv.0", Ho, Wo, l_c0, cur, hp, T1, 0, -1, 1);
-        add_dw(n, bp + "conv.1", Ho, Wo, l_c1, T1, T2, 1);
-        add_pw(n, bp + "conv.2", Ho, Wo, l_c2, T2, 0, nxt, 0, M_odd, 1);
-      }
-      std::swap(cur, nxt);
-    }
-    in_buf = cur;
-    in_c = C;
-    in_is_stage = true;
-    in_pmap.assign(2 * hp, -1);
-    for (int j = 0; j < C; ++j) in_pmap[fphys(j, h, hp, qt)] = j;
-    in_kmap = in_pmap;  // (these plans read the buffer as one contiguous slice)
-    in_planes_v.clear();
-    Hc = Ho;
-    Wc = Wo;
   }
 
   // ---- conv5 + heads -------------------------------------------------------------------
@@ -794,85 +589,41 @@ void build(rtpose_shufflenet* n) {
     const int l5 = add_layer(n, L_PW, "network.6", 1024, in_c, up8((int)in_kmap.size()), M_in);
     const int lp = add_layer(n, L_PW, "paf", 38, 1024, 1024, -1);
     const int lh = add_layer(n, L_PW, "heatmap", 19, 1024, 1024, -1);
-    // fp32 fused plans: conv5 and the heads are ONE launch (pw_head.hip) - the 1024-channel feature has no buffer
-    const bool one_launch = n->fused && !n->bf16;
-    const int F = one_launch ? -1 : add_buf(n, 1024, 0, Hc, Wc);
+    // conv5 and the heads are ONE launch (pw_head.hip / pw_head_bf16.hip) - the 1024-channel feature has no buffer
     const int OUT = add_buf(n, 64, 0, Hc, Wc, true);  // fp32 [PAF 0..37 | 2 pad | heat 40..58 | pad]
     n->out_buf = OUT;
-    if (one_launch) {
-      // the heads share a 64-column matrix whose columns sit AT their output channels (PAF 0..37, heat-map 40..58):
-      // the kernel stores 16 bytes per lane, no column map; the columns nobody owns are zeroed at load time
-      SLayer& P = n->layers[lp];
-      SLayer& Hh = n->layers[lh];
-      P.coutp = Hh.coutp = 64;
-      Hh.col_off = 40;
-      P.ncols = 38;
-      Hh.ncols = 19;
-      P.zero_c0 = 38;
-      P.zero_c1 = 40;
-      Hh.zero_c0 = 59;
-      Hh.zero_c1 = 64;
-      Hh.w_off = P.w_off = n->wt_floats;
-      n->wt_floats += round_up((size_t)(1024 + 32) * 64, 64);
-      Hh.b_off = P.b_off = n->wt_floats;
-      n->wt_floats += 64;
-      SOp o;
-      o.kind = O_HEAD;
-      o.name = "conv5+paf+heatmap";
-      o.H = Hc;
-      o.W = Wc;
-      o.layer[0] = l5;
-      o.layer[1] = lp;
-      o.in_buf[0] = in_buf;
-      o.out_buf[0] = OUT;
-      o.planes_map = M_inpl;
-      o.relu = 1;
-      o.flops = 2.0 * n->N * Hc * Wc * (1024.0 * in_c + 1024.0 * 57);
-      n->ops.push_back(o);
-      return;
+    // the heads share a 64-column matrix whose columns sit AT their output channels (PAF 0..37, heat-map 40..58):
+    // the kernel stores 16 bytes per lane, no column map; the columns nobody owns are zeroed at load time
+    SLayer& P = n->layers[lp];
+    SLayer& Hh = n->layers[lh];
+    P.coutp = Hh.coutp = 64;
+    Hh.col_off = 40;
+    P.ncols = 38;
+    Hh.ncols = 19;
+    P.zero_c0 = 38;
+    P.zero_c1 = 40;
+    Hh.zero_c0 = 59;
+    Hh.zero_c1 = 64;
+    if (n->bf16) {
+      n->layers[l5].ncols = 1024;
+      n->layers[l5].coutp = 1024;
     }
-    if (n->fused) {
-      // the two heads as ONE 64-column GEMM: PAF in columns 0..37, heat-map in 38..56 of a shared packed
-      // matrix (38 + 19 = 57 <= 64); the column -> channel map puts them at [0, 38) and [40, 59)
-      SLayer& P = n->layers[lp];
-      SLayer& Hh = n->layers[lh];
-      P.coutp = Hh.coutp = 64;
-      Hh.col_off = 38;
-      P.ncols = 38;
-      Hh.ncols = 19;
-      if (n->bf16) {
-        n->layers[l5].ncols = 1024;
-        n->layers[l5].coutp = 1024;
-      }
-      Hh.w_off = P.w_off = n->wt_floats;
-      n->wt_floats += round_up((size_t)(1024 + 32) * 64, 64);
-      Hh.b_off = P.b_off = n->wt_floats;
-      n->wt_floats += 64;
-      std::vector<int32_t> hm(64, -1);
-      for (int i = 0; i < 38; ++i) hm[i] = i;
-      for (int i = 0; i < 19; ++i) hm[38 + i] = 40 + i;
-      const int M_heads = add_map(n, hm);
-      add_pwf(n, "conv5", Hc, Wc, l5, -1, in_buf, 0, F, 0, -1, 1);
-      n->ops.back().planes_map = M_inpl;
-      add_pwf(n, "paf+heatmap", Hc, Wc, lp, -1, F, 0, OUT, 0, M_heads, 0, -1, -1, 0, 64);
-      n->ops.back().flops = 2.0 * n->N * Hc * Wc * 1024.0 * 57;
-      return;
-    }
-    add_pw(n, "conv5", Hc, Wc, l5, in_buf, 0, F, 0, -1, 1);
+    Hh.w_off = P.w_off = n->wt_floats;
+    n->wt_floats += round_up((size_t)(1024 + 32) * 64, 64);
+    Hh.b_off = P.b_off = n->wt_floats;
+    n->wt_floats += 64;
     SOp o;
-    o.kind = O_PW;
-    o.name = "paf+heatmap";
+    o.kind = O_HEAD;
+    o.name = "conv5+paf+heatmap";
     o.H = Hc;
     o.W = Wc;
-    o.ngroups = 2;
-    o.layer[0] = lp;
-    o.layer[1] = lh;
-    o.in_buf[0] = o.in_buf[1] = F;
-    o.out_buf[0] = o.out_buf[1] = OUT;
-    o.out_choff[0] = 0;
-    o.out_choff[1] = 40;
-    o.relu = 0;
-    o.flops = 2.0 * n->N * Hc * Wc * 1024.0 * 57;
+    o.layer[0] = l5;
+    o.layer[1] = lp;
+    o.in_buf[0] = in_buf;
+    o.out_buf[0] = OUT;
+    o.planes_map = M_inpl;
+    o.relu = 1;
+    o.flops = 2.0 * n->N * Hc * Wc * (1024.0 * in_c + 1024.0 * 57);
     n->ops.push_back(o);
   }
 }
@@ -896,7 +647,6 @@ int rtpose_shufflenet_create_ex(int N, int H, int W, int dtype, rtpose_shufflene
   n->H = H;
   n->W = W;
   n->bf16 = dtype == RTPOSE_DTYPE_BF16;
-  n->fused = 1;  // pointwise chains run as fused launches (pw_fused.hip, pw_fused_bf16.hip)
   build(n);
   *out = n;
   return 0;
@@ -920,10 +670,21 @@ int rtpose_shufflenet_bind(rtpose_shufflenet* n, void* workspace, size_t ws_byte
   if (!n || !workspace || !weights) return fail(RTPOSE_E_INVAL, "shufflenet_bind: NULL argument");
   if (ws_bytes < n->ws_floats * 4 || wt_bytes < n->wt_floats * 4)
     return fail(RTPOSE_E_INVAL, "shufflenet_bind: arena too small");
+  const int dev = current_device();
+  int rcd = check_device_ptr(workspace, dev, "shufflenet_bind", "the workspace");
+  if (!rcd) rcd = check_device_ptr(weights, dev, "shufflenet_bind", "the weight arena");
+  if (rcd) return rcd;
+  n->device = dev;
+  n->in_checked = CheckedPtr();
   n->ws = static_cast<float*>(workspace);
   n->wt = static_cast<float*>(weights);
   hipStream_t s = as_stream(stream);
-  if (zero_workspace) RTPOSE_HIP_CHECK(hipMemsetAsync(workspace, 0, n->ws_floats * 4, s));
+  // The workspace is cleared whatever the caller says: the zero-copy stage buffers and the unit temporaries have
+  // slots no launch ever writes (class padding inside a slot group, groups skipped for alignment, Pp - P, channels
+  // past h of a temporary) and the GEMMs gather them as K rows under ZERO weights - 0 x NaN from a recycled arena
+  // would reach every output channel.  (`zero_workspace` is kept in the signature for the callers that pass it.)
+  (void)zero_workspace;
+  RTPOSE_HIP_CHECK(hipMemsetAsync(workspace, 0, n->ws_floats * 4, s));
   for (const Map& m : n->maps)
     RTPOSE_HIP_CHECK(hipMemcpyAsync(n->wt + m.off, m.v.data(), m.v.size() * 4, hipMemcpyHostToDevice, s));
   RTPOSE_HIP_CHECK(hipStreamSynchronize(s));
@@ -973,16 +734,16 @@ int rtpose_shufflenet_load(rtpose_shufflenet* n, int idx, const float* w, const 
       return 0;
     }
     case L_PW:
-      if (n->fused && n->bf16) {  // column-mapped bf16 packing (see pw_fused_bf16.hip)
+      if (n->bf16 && l.zero_c1 > l.zero_c0) {  // a head of the bf16 plan: the k order of pw_head_bf16.hip's GEMM 2
+        const int rc = pack_head_w2_bf16_launch(w, b, l.cout, l.cin, l.col_off, n->wt + l.w_off, n->wt + l.b_off, s);
+        if (rc) return rc;
+        return zero_head_columns_bf16_launch(n->wt + l.w_off, n->wt + l.b_off, l.cin_packed, l.zero_c0, l.zero_c1, s);
+      }
+      if (n->bf16) {  // column-mapped bf16 packing (see pw_fused_bf16.hip)
         const int32_t* cmap = l.colmap_id >= 0 ? reinterpret_cast<const int32_t*>(n->wt + n->maps[l.colmap_id].off) : nullptr;
         // (a column-mapped layer packs ALL coutp columns: the map marks the ones past its stored width as zero columns)
         return pack_pw_bf16_launch(w, b, l.cout, l.cin, map, l.cin_packed, cmap ? l.coutp : l.ncols, cmap, l.coutp,
                                    l.col_off, n->wt + l.w_off, n->wt + l.b_off, s);
-      }
-      if (n->fused && l.ncols > 0 && !l.col_off && l.zero_c1 <= l.zero_c0) {  // column-mapped fp32 packing (pw_fused.hip)
-        const int32_t* cmap = l.colmap_id >= 0 ? reinterpret_cast<const int32_t*>(n->wt + n->maps[l.colmap_id].off) : nullptr;
-        return pack_pw_cols_launch(w, b, l.cout, l.cin, map, l.cin_packed, l.coutp, cmap, l.coutp, 0, n->wt + l.w_off,
-                                   n->wt + l.b_off, s);
       }
       if (l.coutp) {  // shares a packed matrix with another layer (the heads of a fused plan)
         const int rc = pack_pw_launch(w, b, l.cout, l.cin, map, l.cin_packed, l.coutp, l.col_off, n->wt + l.w_off,
@@ -1028,6 +789,11 @@ int rtpose_shufflenet_launch_info(rtpose_shufflenet* n, int i, float* ms, double
 int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* stream) {
   if (!n || !n->bound) return fail(RTPOSE_E_STATE, "shufflenet_forward: not bound");
   if (!x_nchw) return fail(RTPOSE_E_INVAL, "shufflenet_forward: x is NULL");
+  if (current_device() != n->device)
+    return fail(RTPOSE_E_STATE, "shufflenet_forward: the plan's arenas live on HIP device %d but the current device is %d",
+                n->device, current_device());
+  const int rcd = n->in_checked.check(x_nchw, n->device, "shufflenet_forward", "the input tensor");
+  if (rcd) return rcd;
   hipStream_t s = as_stream(stream);
   const bool prof = n->profiling && !n->ev.empty();
   auto imap = [&](int id) -> const int32_t* {
@@ -1076,15 +842,6 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
                                         &bo.lay, o.C, n->N, o.H, o.W, o.stride, stream);
         break;
       }
-      case O_COPYMAP: {
-        const SBuf& bi = n->bufs[o.in_buf[0]];
-        const SBuf& bo = n->bufs[o.out_buf[0]];
-        rc = n->bf16 ? rtpose_layout_copy_cmap_bf16(n->ws + bi.off, &bi.lay, n->ws + bo.off, &bo.lay, o.C,
-                                                    imap(o.cmap[0]), n->N, o.H, o.W, stream)
-                     : rtpose_layout_copy_cmap(n->ws + bi.off, &bi.lay, n->ws + bo.off, &bo.lay, o.C,
-                                               imap(o.cmap[0]), n->N, o.H, o.W, stream);
-        break;
-      }
       case O_PWF: {
         const SLayer& l = n->layers[o.layer[0]];
         const SBuf& bi = n->bufs[o.in_buf[0]];
@@ -1129,10 +886,6 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
           }
           rc = pw_fused_bf16_launch(&d, f32out ? 1 : 0, n->N, o.H, o.W, s);
         } else {
-          if (l.ncols > 0 && !l.col_off) {  // run-ordered / padded columns [0, ncols) -> contiguous channels from out_choff
-            d.cout = l.ncols;
-            d.out_cmap = nullptr;
-          }
           rc = pw_fused_launch(&d, n->N, o.H, o.W, s);
         }
         break;
@@ -1158,33 +911,7 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
         d2.cout = d2.coutp = 64;
         d2.out = n->ws + bo.off;
         d2.lout = slice(bo, 0);
-        rc = pw_head_launch(&d1, &d2, n->N, o.H, o.W, s);
-        break;
-      }
-      case O_PW: {
-        rtpose_conv_desc d[2];
-        memset(d, 0, sizeof(d));
-        for (int g = 0; g < o.ngroups; ++g) {
-          const SLayer& l = n->layers[o.layer[g]];
-          const SBuf& bi = n->bufs[o.in_buf[g]];
-          const SBuf& bo = n->bufs[o.out_buf[g]];
-          d[g].in = n->ws + bi.off;
-          d[g].out = n->ws + bo.off;
-          d[g].w_packed = n->wt + l.w_off;
-          d[g].bias_packed = n->wt + l.b_off;
-          d[g].lin = slice(bi, o.in_choff[g]);
-          d[g].lout = slice(bo, o.out_choff[g]);
-          d[g].cin = l.cin_packed;
-          d[g].cout = l.cout;
-          d[g].k = 1;
-          d[g].relu = o.relu;
-          d[g].pool = 0;
-          d[g].out_cmap = imap(o.cmap[g]);
-          d[g].wino_m = 0;
-        }
-        // bf16 plans: the two heads write the fp32 output record, everything else 2-byte activations
-        rc = n->bf16 ? conv2d_bf16_launch(d, o.ngroups, n->N, o.H, o.W, o.out_buf[0] == n->out_buf, 0, s)
-                     : conv2d_launch(d, o.ngroups, n->N, o.H, o.W, s);
+        rc = n->bf16 ? pw_head_bf16_launch(&d1, &d2, n->N, o.H, o.W, s) : pw_head_launch(&d1, &d2, n->N, o.H, o.W, s);
         break;
       }
     }

@@ -150,6 +150,11 @@ class RtposeVGG(NativeStateMixin, nn.Module):
         check(lib.rtpose_net_device_status(plan.handle, C.byref(word), current_stream()))
         return word.value
 
+    def device_status_async(self, plan, pinned_word):
+        """Queue the copy of the plan's device error word into `pinned_word` (a pinned int32 tensor of one element)
+        on the current stream, without waiting; read it after an event recorded later on that stream."""
+        check(lib.rtpose_net_device_status_async(plan.handle, pinned_word.data_ptr(), current_stream()))
+
     def set_compute_dtype(self, dtype):
         """'fp32' (reference arithmetic, v_mfma_f32_32x32x2_f32), 'bf16' (BASELINE config 3:
         bf16 operands, fp32 accumulate, v_mfma_f32_32x32x16_bf16) or 'bf16x3' (every fp32

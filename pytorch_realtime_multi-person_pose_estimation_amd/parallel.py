@@ -110,6 +110,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def require_devices(n, who):
+    """Fail fast - before any rank is spawned, and again in every rank - when this node shows fewer HIP devices than
+    the run was asked to use: N ranks on fewer devices would either fault in hipSetDevice or, worse, share one GPU
+    and be reported as N."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < int(n):
+        raise SystemExit("%s: %d GPU(s) requested but this node shows %d HIP device(s) "
+                         "(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)" % (who, int(n), have))
+    return have
+
+
 def relaunch_under_torchrun(script, argv, nproc, python=None):
     """Run ``script argv`` as ``nproc`` ranks of ONE node - ``python -m torch.distributed.run --nnodes=1
     --nproc-per-node nproc --master-addr 127.0.0.1 --master-port <free> script argv`` - with this process's

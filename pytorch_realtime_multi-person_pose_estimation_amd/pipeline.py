@@ -129,6 +129,7 @@ class StreamingPoseEstimator(object):
         self.host = [torch.empty((batch, h0, w0, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
         self.devbuf = [torch.empty((batch, h0, w0, 3), dtype=torch.uint8, device=self.dev) for _ in range(2)]
         self.done = torch.cuda.Event()      # recorded behind the D2H of a batch's records
+        self.err_word = torch.zeros(1, dtype=torch.int32).pin_memory()   # the plan's device error word, copied with them
         self.max_peaks_per_part, self.max_humans = max_peaks_per_part, max_humans
         self.scene, self.scene_alpha = scene, scene_alpha
         cfg = dec.make_cfg(self.config, max_peaks_per_part, max_humans)
@@ -173,6 +174,10 @@ class StreamingPoseEstimator(object):
             check(lib.rtpose_layout_axpby(pbase, C.byref(lpaf), ptr(sp), 38, self.B, h, w, self.scene_alpha, 1.0, s))
         dec.decode_enqueue(hbase, lheat, pbase, lpaf, self.B, h, w, self.bufs)
         self.bufs.host.copy_(self.bufs.result, non_blocking=True)
+        # the device error word rides behind the records: _finish reads it after `done`, and never calls a
+        # stream-synchronising API while the next batch's H2D is queued (round-4 advisor finding)
+        if getattr(plan, 'dtype', 0) == _capi.DTYPE_F32 and hasattr(m, 'device_status_async'):
+            m.device_status_async(plan, self.err_word)
         self.done.record(torch.cuda.current_stream())
         return plan, (hbase, lheat, pbase, lpaf, h, w)
 
@@ -183,7 +188,11 @@ class StreamingPoseEstimator(object):
         while True:
             self.done.synchronize()     # the records of THIS batch (the next batch's H2D may still be queued)
             recs = self.bufs.host.numpy().reshape(self.B, self.bufs.words).copy()
-            _raise_on_device_error(self.model, plan)
+            word = int(self.err_word[0])
+            if word:
+                self.err_word[0] = 0
+                raise _capi.RtposeError("device error word %d: a split-tile hand-over of a persistent 7x7 launch timed "
+                                        "out (shared / CU-masked device?); the maps of this batch are invalid" % word)
             flags = int(np.bitwise_or.reduce(recs[:, dec.RES_HEADER + 2]))
             if not flags:
                 return recs

@@ -458,6 +458,99 @@ def test_wide_conv_and_heads_in_one_launch(capi, cuda, n, h, w, cin, c1):
     assert lib.rtpose_pw_head(C.byref(d1), C.byref(d2), n, h, w, stream) != 0
 
 
+@pytest.mark.parametrize("n,h,w,cin,c1,planes", [(20, 46, 46, 480, 1024, True), (1, 9, 7, 32, 256, False),
+                                                  (3, 13, 11, 64, 512, False), (1, 5, 5, 480, 1024, False),
+                                                  (2, 23, 17, 112, 768, True)])
+def test_wide_conv_and_heads_in_one_launch_bf16(capi, cuda, n, h, w, cin, c1, planes):
+    """rtpose_pw_head_bf16 (csrc/pw_head_bf16.hip): conv5 (cin -> c1, ReLU) + the two heads (c1 -> 38 | 19) of
+    lib/network/rtpose_shufflenetV2.py:104-108, :143-147 as one launch in the arithmetic of the bf16 plan - bf16
+    activations and weights, fp32 sums, the conv5 feature rounded to bf16 after its ReLU, fp32 maps - against the same
+    arithmetic in float64 on the CPU (oracle/shufflenet_oracle.py:forward_bf16_emulated semantics): the K = 480 / 1024
+    shape of the network with the input gathered as 16-byte planes of a wider pixel, K of 2 / 4 / 7 k-steps (whole and
+    zero-padded last chunks), 1 - 4 passes, pixel counts that are not a multiple of the 128-pixel item (several items per
+    block: the LDS tile is refilled under the last pass), and more blocks than items."""
+    g = torch.Generator().manual_seed(n * 1000 + cin)
+    x = _rb(torch.randn(n, cin, h, w, generator=g))
+    w1 = _rb(torch.randn(c1, cin, generator=g) / cin ** 0.5)
+    b1 = torch.randn(c1, generator=g) * 0.1
+    wp_, bp_ = _rb(torch.randn(38, c1, generator=g) / c1 ** 0.5), torch.randn(38, generator=g) * 0.1
+    wh_, bh_ = _rb(torch.randn(19, c1, generator=g) / c1 ** 0.5), torch.randn(19, generator=g) * 0.1
+    f = _rb(F.relu(F.conv2d(x.double(), w1[:, :, None, None].double(), b1.double()).float())).double()
+    ref_p = F.conv2d(f, wp_[:, :, None, None].double(), bp_.double()).float()
+    ref_h = F.conv2d(f, wh_[:, :, None, None].double(), bh_.double()).float()
+    lib, stream = capi.lib, capi.current_stream()
+    # the input: channel c of the conv at physical channel phys[c] of a wider pixel (planes of 8 in shuffled order)
+    npl = cin // 8
+    if planes:
+        order = torch.randperm(npl + 3, generator=g)[:npl]          # plane j of K sits at plane order[j] of the pixel
+        cphys = (npl + 3) * 8
+    else:
+        order = torch.arange(npl) + 1                                # a contiguous slice at channel offset 8
+        cphys = (npl + 2) * 8
+    phys = (order[:, None] * 8 + torch.arange(8)[None, :]).reshape(-1)
+    xp = torch.full((n, cphys, h, w), 3.0)                           # (channels outside the slice: junk the kernel must not read)
+    xp[:, phys] = x
+    lin = capi.Layout.padded(cphys, h, w, 1, 0 if planes else 8)
+    npix = lib.rtpose_layout_pixels(C.byref(lin), n, h, w)
+    xin = torch.zeros(npix * cphys, dtype=torch.int16, device=cuda)
+    lfull = capi.Layout.padded(cphys, h, w, 1)
+    capi.check(lib.rtpose_nchw_to_layout_bf16(capi.ptr(xp.to(cuda).contiguous()), capi.ptr(xin), C.byref(lfull), cphys, cphys,
+                                              n, h, w, stream))
+    w1p = torch.zeros(lib.rtpose_packed_pw_bytes_bf16(cin, c1) // 2, dtype=torch.int16, device=cuda)
+    b1p = torch.zeros(c1, device=cuda)
+    w2p = torch.full((c1 * 64 + 4096,), 0x7fc0, dtype=torch.int16, device=cuda)      # NaN until packed / zeroed
+    b2p = torch.full((64,), float("nan"), device=cuda)
+    dev = lambda t: t.contiguous().to(cuda)   # noqa: E731
+    keep = [dev(w1), dev(b1), dev(wp_), dev(bp_), dev(wh_), dev(bh_)]
+    capi.check(lib.rtpose_pack_pw_weights_bf16(capi.ptr(keep[0]), capi.ptr(keep[1]), c1, cin, None, cin, c1, None, c1, 0,
+                                               capi.ptr(w1p), capi.ptr(b1p), stream))
+    w2p[:c1 * 64].zero_()      # columns nobody owns must be zero (the executor zeroes them at load time)
+    b2p.zero_()
+    capi.check(lib.rtpose_pack_pw_head2_bf16(capi.ptr(keep[2]), capi.ptr(keep[3]), 38, c1, 0, capi.ptr(w2p), capi.ptr(b2p), stream))
+    capi.check(lib.rtpose_pack_pw_head2_bf16(capi.ptr(keep[4]), capi.ptr(keep[5]), 19, c1, 40, capi.ptr(w2p), capi.ptr(b2p), stream))
+    lout = capi.Layout.dense(72, h, w, 4)
+    out = torch.full((lib.rtpose_layout_pixels(C.byref(lout), n, h, w) * 72,), 7.0, device=cuda)
+    d1, d2 = capi.PwDesc(), capi.PwDesc()
+    d1.inp, d1.w_packed, d1.bias_packed = xin.data_ptr(), w1p.data_ptr(), b1p.data_ptr()
+    d1.lin, d1.cin, d1.cout, d1.coutp, d1.relu = lin, cin, c1, c1, 1
+    pl_d = (order * 8).to(torch.int32).to(cuda)
+    if planes:
+        d1.in_planes = pl_d.data_ptr()
+    d2.w_packed, d2.bias_packed, d2.out = w2p.data_ptr(), b2p.data_ptr(), out.data_ptr()
+    d2.lout, d2.cin, d2.cout, d2.coutp, d2.relu = lout, c1, 64, 64, 0
+    assert lib.rtpose_pw_head_bf16_fits(C.byref(d1), C.byref(d2)) == 1
+    capi.check(lib.rtpose_pw_head_bf16(C.byref(d1), C.byref(d2), n, h, w, stream), "rtpose_pw_head_bf16")
+    torch.cuda.synchronize()
+    px = out.view(-1, 72).cpu()
+    assert torch.equal(px[:, :4], torch.full_like(px[:, :4], 7.0)) and torch.equal(px[:, 68:], torch.full_like(px[:, 68:], 7.0))
+    assert torch.equal(px[n * h * w:], torch.full_like(px[n * h * w:], 7.0))      # nothing past the last pixel
+    px = px[:n * h * w]
+    got = px[:, 4:68].reshape(n, h, w, 64).permute(0, 3, 1, 2)
+    scale = max(1.0, ref_p.abs().max().item())
+    # fp32 sums of exact bf16 products against float64 ones; a feature value on a bf16 rounding boundary may round the
+    # other way (one bf16 ulp of one of 1024 terms)
+    assert (got[:, 0:38] - ref_p).abs().max().item() <= 2e-3 * scale
+    assert (got[:, 40:59] - ref_h).abs().max().item() <= 2e-3 * scale
+    assert got[:, 38:40].abs().max().item() == 0.0 and got[:, 59:64].abs().max().item() == 0.0
+    # the same launch again: bit-identical (fixed summation order, no atomics)
+    out2 = torch.full_like(out, 7.0)
+    d2.out = out2.data_ptr()
+    capi.check(lib.rtpose_pw_head_bf16(C.byref(d1), C.byref(d2), n, h, w, stream), "rtpose_pw_head_bf16")
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    # an image's maps do not depend on its batch: image 0 alone (other items, other blocks) gives the same bits
+    if n > 1:
+        out3 = torch.full_like(out, 7.0)
+        d2.out = out3.data_ptr()
+        capi.check(lib.rtpose_pw_head_bf16(C.byref(d1), C.byref(d2), 1, h, w, stream), "rtpose_pw_head_bf16")
+        torch.cuda.synchronize()
+        assert torch.equal(out3.view(-1, 72)[:h * w], out.view(-1, 72)[:h * w])
+    # shapes without an instance are refused, not mis-run
+    d1.cin = 488
+    assert lib.rtpose_pw_head_bf16_fits(C.byref(d1), C.byref(d2)) == 0
+    assert lib.rtpose_pw_head_bf16(C.byref(d1), C.byref(d2), n, h, w, stream) != 0
+
+
 def test_bad_arguments_fail_loudly(capi, cuda):
     d = capi.PwDesc()
     assert capi.lib.rtpose_pw_fused(C.byref(d), 1, 8, 8, None) != 0

@@ -70,6 +70,147 @@ def test_rccl_all_gather_of_the_device_record_block(tmp_path, cuda):
     assert p.returncode == 0 and "RCCL_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
 
 
+_TWO_RANKS_ONE_GPU = r"""
+import importlib, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+PKG = "pytorch_realtime_multi-person_pose_estimation_amd"
+pkg = importlib.import_module(PKG)
+par = importlib.import_module(PKG + ".parallel")
+dec = importlib.import_module(PKG + ".decode")
+synth = importlib.import_module(PKG + ".synth")
+pipeline = importlib.import_module(PKG + ".pipeline")
+rank, local_rank, world = par.init_from_env("gloo")          # NOT nccl: RCCL refuses two ranks on one device
+assert world == 2 and dist.get_backend() == "gloo"
+dev = torch.device("cuda", 0)                                # both ranks on THE one GPU of the box
+torch.cuda.set_device(dev)
+B, S, STEPS = 16, 368, 6
+
+def build():
+    m = pkg.get_model('vgg19')
+    m.load_state_dict(synth.he_init_state_dict(m, seed=0))
+    return m.cuda().float().eval()
+
+def shard(r):
+    g = torch.Generator().manual_seed(50 + r)
+    x = (torch.rand(B, 3, S, S, generator=g) - 0.5).to(dev)
+    h, p, _ = synth.make_batch(B, S, S, seed=200 + r)
+    return x, (torch.from_numpy(h).to(dev), torch.from_numpy(p).to(dev))
+
+model = build()
+est = pipeline.PoseEstimator(model)
+x, scene = shard(rank)
+est(x, scene)                                                # capacities settle, weights packed
+dist.barrier()
+blocks = []
+for _ in range(STEPS):                                       # both processes drive the device at the same time
+    bufs = est.enqueue(x, scene)
+    local = dec.fetch(bufs)                                  # records -> host (pinned D2H + stream sync)
+    out = par.gather_records(torch.from_numpy(np.ascontiguousarray(local)), world)   # gloo all_gather of host blocks
+    blocks.append(out.numpy().copy())
+status = model.device_status(model.plan_for(x))
+assert status == 0, "device error word %d with a second process on the GPU" % status
+def content(block):       # what a record SAYS (the slack of its fixed-capacity tables is never written)
+    out = []
+    for r in block:
+        d = dec.parse_image(r)
+        out.append((d["peaks"].view(np.uint32).tobytes(), d["parts"].tobytes(), d["score"].view(np.uint32).tobytes(),
+                    d["flags"]))
+    return out
+said = content(blocks[0])
+for b in blocks[1:]:
+    assert content(b) == said, "a step's records changed while the other process was running"
+dist.barrier()
+if rank == 0:       # alone on the GPU now: both shards serially through ONE process - must be the gathered bits
+    ref = []
+    for r in range(world):
+        xr, sr = shard(r)
+        ref.append(dec.fetch(est.enqueue(xr, sr)).copy())
+    ref = np.concatenate(ref)
+    assert ref.shape == blocks[0].shape and content(ref) == said, "records differ from the one-process run"
+    people = sum(dec.parse_image(r)["parts"].shape[0] for r in ref)
+    assert people > 2 * B
+    print("TWO_RANKS_ONE_GPU_OK images", ref.shape[0], "people", people)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_processes_share_the_one_gpu(tmp_path, cuda):
+    """What a 1-GPU lease CAN show of the multi-process path: two ranks (torch.distributed.run --nproc-per-node 2,
+    gloo - RCCL refuses two ranks on one device, so RCCL itself stays at world 1 until an 8-GPU node exists) both on
+    cuda:0, each with its own plan, weight arena, decode buffers and persistent-kernel grids (the 7x7 launches hand
+    split tiles from block to block through device flags: their bounded waits must survive a second process's
+    kernels on the same CUs), stepping its own 16-image shard concurrently; the records gathered through the host
+    equal, bit for bit, the two shards run serially in one process, and the device error word stays 0.  This is NOT a
+    scaling measurement: multi-GPU throughput stays unmeasured on hardware."""
+    script = tmp_path / "two_ranks.py"
+    script.write_text(_TWO_RANKS_ONE_GPU)
+    port = 29400 + (os.getpid() % 200)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "two_ranks_one_gpu.txt"), "w") as f:
+            f.write("rc %d\n--- stdout ---\n%s\n--- stderr ---\n%s\n" % (p.returncode, p.stdout[-4000:], p.stderr[-12000:]))
+    except OSError:
+        pass
+    assert p.returncode == 0 and "TWO_RANKS_ONE_GPU_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+
+
+def test_memory_that_is_not_of_the_current_device_is_refused(cuda):
+    """Every entry point that takes device memory asks the runtime which device owns it (hipPointerGetAttributes, once
+    per new pointer) and refuses host memory - and, on a multi-GPU node, memory of another device than the current one
+    (a DataParallel replica, a mis-set LOCAL_RANK) - instead of launching on it.  A 1-GPU box can show the host-memory
+    half; the other-device half is the same comparison with another owner."""
+    import ctypes as C
+    import importlib
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    pkg = importlib.import_module(PKG_NAME)
+    capi = pkg._capi
+    lib = capi.lib
+    dec = importlib.import_module(PKG_NAME + ".decode")
+    synth = importlib.import_module(PKG_NAME + ".synth")
+    s = capi.current_stream()
+    # plan arenas in pinned host memory
+    net = C.c_void_p()
+    capi.check(lib.rtpose_net_create(1, 64, 64, C.byref(net)))
+    ws_b, wt_b = lib.rtpose_net_workspace_bytes(net), lib.rtpose_net_weight_bytes(net)
+    host_ws = torch.empty(ws_b + 256, dtype=torch.uint8).pin_memory()
+    dev_ws = torch.empty(ws_b + 256, dtype=torch.uint8, device="cuda")
+    dev_wt = torch.zeros(wt_b + 256, dtype=torch.uint8, device="cuda")
+    al = lambda t: (t.data_ptr() + 255) // 256 * 256
+    rc = lib.rtpose_net_bind(net, al(host_ws), ws_b, al(dev_wt), wt_b, 1, s)
+    assert rc != 0 and b"not device memory" in lib.rtpose_last_error(), lib.rtpose_last_error()
+    capi.check(lib.rtpose_net_bind(net, al(dev_ws), ws_b, al(dev_wt), wt_b, 1, s))
+    # the input of a forward in host memory
+    x_host = torch.zeros(1, 3, 64, 64).pin_memory()
+    rc = lib.rtpose_net_forward(net, x_host.data_ptr(), s)
+    assert rc != 0 and b"input tensor" in lib.rtpose_last_error(), lib.rtpose_last_error()
+    x_dev = torch.zeros(1, 3, 64, 64, device="cuda")
+    # (weights never loaded: the forward only has to be ACCEPTED for launch - finalize reads the estimates of zeros)
+    assert lib.rtpose_net_forward(net, x_dev.data_ptr(), s) == 0, lib.rtpose_last_error()
+    torch.cuda.synchronize()
+    lib.rtpose_net_destroy(net)
+    # decoder: maps in host memory
+    heat, paf, _ = synth.make_batch(1, 184, 184, seed=5)
+    cfg = dec.make_cfg(None, 32, 64)
+    bufs = dec.DecodeBuffers(cfg, 1, torch.device("cuda", 0))
+    hh, ph = torch.from_numpy(heat).pin_memory(), torch.from_numpy(paf).pin_memory()
+    lay = capi.Layout
+    with pytest.raises(capi.RtposeError, match="heat-map tensor"):
+        dec.decode_enqueue(hh.data_ptr(), lay.dense(19, 23, 23), ph.data_ptr(), lay.dense(38, 23, 23), 1, 23, 23, bufs)
+    hd, pd = hh.cuda(), ph.cuda()
+    dec.decode_enqueue(capi.ptr(hd), lay.dense(19, 23, 23), capi.ptr(pd), lay.dense(38, 23, 23), 1, 23, 23, bufs)
+    assert dec.parse_image(dec.fetch(bufs)[0])["n_peaks"] > 0
+
+
 def _bench_line(p):
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert p.returncode == 0 and lines, (p.stdout[-2000:], p.stderr[-3000:])

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=0, help="ranks (0 = whatever the launcher's WORLD_SIZE says, else 1)")
     args = ap.parse_args()
     par = importlib.import_module(PKG + ".parallel")
+    par.require_devices(max(args.gpus, 1), "bench_config5.py")
     if args.gpus > 1 and not par.launched_by_torchrun():
         raise SystemExit(par.relaunch_under_torchrun(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     if args.gpus and par.env_world()[2] != args.gpus:
