@@ -318,6 +318,19 @@ int rtpose_pw_fused_bf16(const rtpose_pw_desc* d, int out_f32, int N, int H, int
  * (the k order in which the first GEMM's accumulators come out of the matrix pipe; columns at their output channels,
  * columns nobody owns must be zero), fp32 bias [64], 64 fp32 channels stored at d2->lout.choff.  The conv5 feature is
  * rounded to bf16 (RNE) after its ReLU and never leaves the registers; sums are fp32 in a fixed order. */
+/* One stride-1 ShuffleNetV2 unit - conv.0 (1x1 + ReLU) -> conv.1 (depthwise 3x3) -> conv.2 (1x1 + ReLU),
+ * lib/network/rtpose_shufflenetV2.py:31-39 - as ONE launch in the bf16 plan (csrc/unit_bf16.hip): the conv.0 output only
+ * exists in LDS (8 x 8 output tiles, conv.0 recomputed on the 10 x 10 halo; halo pixels outside the image are zero, as
+ * the depthwise conv's padding wants).  d0 = conv.0: `in` / `lin` the stage buffer (bf16, ELEMENT counts, layout gap >= 1)
+ * as a contiguous slice or a gather of cin / 8 planes (in_planes), cin a multiple of 16 up to 272, w_packed
+ * [cin / 8][coutp][8 bf16] with coutp = 128 or 256 and zero columns past the real ones; d0->dw_w / dw_b = conv.1's fp32
+ * taps [9][Kt] and bias [Kt], Kt = d2->cin (a multiple of 16, <= d0->coutp).  d2 = conv.2: w_packed [Kt / 8][coutp][8 bf16],
+ * coutp = 128 or 256, `cout` existing columns (a multiple of 8), out_cmap[column] = absolute channel of the output pixel
+ * (groups of 8 columns contiguous and 8-aligned, < 0: not stored), `out` / `lout` = the output buffer (may be the input
+ * buffer when the output channels are not read by this launch: other blocks read x2 as their halo). */
+int rtpose_unit_bf16_fits(const rtpose_pw_desc* d0, const rtpose_pw_desc* d2, int H, int W);
+int rtpose_unit_bf16(const rtpose_pw_desc* d0, const rtpose_pw_desc* d2, int N, int H, int W, void* stream);
+
 int rtpose_pw_head_bf16_fits(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2);
 int rtpose_pw_head_bf16(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2, int N, int H, int W, void* stream);
 int rtpose_pack_pw_head2_bf16(const float* w_oi, const float* bias, int cout, int cin, int col_off, void* w_packed,

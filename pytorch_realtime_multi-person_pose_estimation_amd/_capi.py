@@ -127,6 +127,8 @@ _SIGS = {
     "rtpose_packed_pw_bytes_bf16": (_sz, [_i, _i]),
     "rtpose_pack_pw_weights_bf16": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "rtpose_pw_fused_bf16": (_i, [C.POINTER(PwDesc), _i, _i, _i, _i, _vp]),
+    "rtpose_unit_bf16_fits": (_i, [C.POINTER(PwDesc), C.POINTER(PwDesc), _i, _i]),
+    "rtpose_unit_bf16": (_i, [C.POINTER(PwDesc), C.POINTER(PwDesc), _i, _i, _i, _vp]),
     "rtpose_pw_head_bf16_fits": (_i, [C.POINTER(PwDesc), C.POINTER(PwDesc)]),
     "rtpose_pw_head_bf16": (_i, [C.POINTER(PwDesc), C.POINTER(PwDesc), _i, _i, _i, _vp]),
     "rtpose_pack_pw_head2_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -14,7 +14,8 @@
     defined(RTPOSE_EXP_STAGGER) || defined(RTPOSE_EXP_TB1X1) || defined(RTPOSE_EXP_HD) ||               \
     defined(RTPOSE_EXP_RB2) || defined(RTPOSE_EXP_W7_PF) || defined(RTPOSE_EXP_W7_TMASK) || defined(RTPOSE_EXP_W7_LPS) || defined(RTPOSE_EXP_W_EPI) || \
     defined(RTPOSE_EXP_W3_SWOLD) || defined(RTPOSE_EXP_W7_XSPLIT) || defined(RTPOSE_EXP_W7_PRIO) || defined(RTPOSE_EXP_W7_FS2SETS) || defined(RTPOSE_EXP_W7_CGMAJOR) || defined(RTPOSE_EXP_TIMELINE3) || \
-    defined(RTPOSE_EXP_W4_NOXF) || defined(RTPOSE_EXP_W4_NOLOAD) || defined(RTPOSE_EXP_W4_XCDMAP) || defined(RTPOSE_EXP_W4_A3) || defined(RTPOSE_EXP_W4_PRIO) || defined(RTPOSE_EXP_TIMELINE4) || defined(RTPOSE_EXP_W7_NULLDESC) || defined(RTPOSE_EXP_W4_AUX) || defined(RTPOSE_EXP_W4_L0) || defined(RTPOSE_EXP_STAGE_NEAR)
+    defined(RTPOSE_EXP_W4_NOXF) || defined(RTPOSE_EXP_W4_NOLOAD) || defined(RTPOSE_EXP_W4_XCDMAP) || defined(RTPOSE_EXP_W4_A3) || defined(RTPOSE_EXP_W4_PRIO) || defined(RTPOSE_EXP_TIMELINE4) || defined(RTPOSE_EXP_W7_NULLDESC) || defined(RTPOSE_EXP_W4_AUX) || defined(RTPOSE_EXP_W4_L0) || defined(RTPOSE_EXP_STAGE_NEAR) || \
+    defined(RTPOSE_EXP_TIMELINE_UNIT)
 #error "RTPOSE_EXP_* ablation switches need -DRTPOSE_DEV_BUILD (they are not part of production builds)"
 #endif
 #endif

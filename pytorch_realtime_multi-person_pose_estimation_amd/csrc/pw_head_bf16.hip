@@ -56,6 +56,11 @@ __device__ __forceinline__ bf16x8 as_bf8(const float4& v) {
 __device__ __forceinline__ unsigned short to_bf16(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 // ReLU on the bit pattern: a negative float (and -0) is a negative int, a positive one orders like its bits - one
 // v_max_i32 where fmaxf costs a canonicalising v_max_f32 more (no NaN reaches here that the reference would keep)
+// The compiler's hazard recogniser does not know that the asm above reads an MFMA result: the wait states between the last
+// MFMA that wrote an accumulator and its first v_accvgpr_read (up to 18 for a 16-pass 32x32x16) are inserted by hand,
+// once, in front of every read-out section.  (Found the hard way: registers 0 and 1 of the first fragment read stale
+// values in one instance of unit_bf16_kernel whose epilogue followed the last MFMA directly.)
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 __device__ __forceinline__ float relu_bits(float v) {
   return __builtin_bit_cast(float, max(__builtin_bit_cast(int, v), 0));
 }
@@ -105,8 +110,8 @@ struct IntTag {
   static constexpr int value = V;
 };
 
-// A pass walks K1 in k-steps of 16 channels, four to a chunk (= one turn of the filter ring's four slots, one staged
-// chunk of the next item).  K1 = 480 is 30 steps: the pass runs 32, the last two on all-zero filter fragments (loaded
+// A pass walks K1 in k-steps of 16 channels, four to a chunk (= one turn of the filter ring's four slots), two chunks to
+// a staging granule.  K1 = 480 is 30 steps: the pass runs 32, the last two on all-zero filter fragments (loaded
 // through a zero-extent descriptor: nothing fetched) against the activations of step 29 - exact zeros added, 6 % more
 // matrix time in this launch, and every pass is the same straight-line code (a separate two-step tail made the
 // register allocator park the heads' 128 accumulators in VGPRs during GEMM 1 and spill).
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(256, 1) void pw_head_bf16_kernel(const Args A) {
   const int l31 = lane & 31, kh = lane >> 5;
   const int npl = A.K1 >> 3;   // 16-byte planes of K1
   const int kreal = A.K1 >> 4;          // k-steps of GEMM 1 that carry channels
-  const int kst = (kreal + 3) & ~3;     // k-steps a pass runs (whole chunks)
+  const int kst = (kreal + 7) & ~7;     // k-steps a pass runs (whole PAIRS of chunks: the staging granule)
   const int NP = A.N1 >> 8;    // passes of 256 channels
   const int nch = (npl + 7) >> 3;
   float4* const xs = smem4;                    // [npl][XP]: plane pl of pixel px at pl * XP + px
@@ -158,16 +163,16 @@ __global__ __launch_bounds__(256, 1) void pw_head_bf16_kernel(const Args A) {
       q[u] = ((unsigned)pixel_q(m, A.in_lead, A.in_hs, A.in_ws) * (unsigned)A.in_cstride + (unsigned)A.in_choff) * 2u;
     }
   };
-  float4 sr[4];
-  auto stage_load = [&](const i32x4 r, const unsigned* q, int c) {
+  float4 sr[2][4];  // two chunks in flight: requested at the first step of a chunk pair, stored behind its eighth
+  auto stage_load = [&](float4(&dst)[4], const i32x4 r, const unsigned* q, int c) {
     const unsigned pofs = (unsigned)s_plane[min(8 * c + spl, npl - 1)] * 2u;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) sr[u] = bload4(r, q[u] + pofs, 0);
+    for (int u = 0; u < 4; ++u) dst[u] = bload4(r, q[u] + pofs, 0);
   };
-  auto stage_store = [&](int c) {
+  auto stage_store = [&](const float4(&src)[4], int c) {
     if (8 * c + spl < npl) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) xs[(8 * c + spl) * XP + spx + 32 * u] = sr[u];
+      for (int u = 0; u < 4; ++u) xs[(8 * c + spl) * XP + spx + 32 * u] = src[u];
     }
   };
 
@@ -213,9 +218,11 @@ __global__ __launch_bounds__(256, 1) void pw_head_bf16_kernel(const Args A) {
 
   // ---- prologue of the block: the first item's tile, the first filter fragments ----------------------------------
   setup_stage(item, sq);
-  for (int c = 0; c < nch; ++c) {
-    stage_load(rin, sq, c);
-    stage_store(c);
+  for (int c = 0; c < nch; c += 2) {
+    stage_load(sr[0], rin, sq, c);
+    stage_load(sr[1], rin, sq, min(c + 1, nch - 1));
+    stage_store(sr[0], c);
+    if (c + 1 < nch) stage_store(sr[1], c + 1);
   }
   wload(wr[0], 0, 0);
   wload(wr[1], 0, 1);
@@ -262,18 +269,29 @@ __global__ __launch_bounds__(256, 1) void pw_head_bf16_kernel(const Args A) {
       w2load(w2r[0], p, 0);  // the first two groups of the fold at the end of the pass; the other two under it
       w2load(w2r[1], p, 1);
       init_acc(p);
-      for (int g0 = 0; g0 < kst; g0 += 4) {
+      for (int g0 = 0; g0 < kst; g0 += 8) {
+        // two chunks of the next item are requested behind the first step's filter request (the next wait for filters
+        // does not cover them) and stored eight steps - 64 MFMAs, ~2 k cycles - later: one chunk ahead (round-5 first
+        // version) the HBM round trip under load was longer than the chunk
+        const int c0 = g0 >> 2;
         step(IntTag<0>(), p, g0);
-        stage_load(rs, sqn, g0 >> 2);  // behind this step's filter request: the next wait for filters does not cover it
+        stage_load(sr[0], rs, sqn, c0);
+        stage_load(sr[1], rs, sqn, min(c0 + 1, nch - 1));
         step(IntTag<1>(), p, g0 + 1);
         step(IntTag<2>(), p, g0 + 2);
         step(IntTag<3>(), p, g0 + 3);
+        step(IntTag<0>(), p, g0 + 4);
+        step(IntTag<1>(), p, g0 + 5);
+        step(IntTag<2>(), p, g0 + 6);
+        step(IntTag<3>(), p, g0 + 7);
         if (lastp) {
-          __syncthreads();  // every wave has read chunk g0 / 4 for the last time
-          stage_store(g0 >> 2);
+          __syncthreads();  // every wave has read the chunks c0, c0 + 1 for the last time
+          stage_store(sr[0], c0);
+          if (c0 + 1 < nch) stage_store(sr[1], c0 + 1);
         }
       }
       // ---- GEMM 2: fold the wave's 64 channels of this pass into its heads' sums, straight from the accumulators
+      mfma_drain();
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int f = ks >> 1, h = ks & 1;
@@ -297,6 +315,7 @@ __global__ __launch_bounds__(256, 1) void pw_head_bf16_kernel(const Args A) {
 
     // ---- the four partial sums of every pixel fragment meet in LDS; wave w adds the head columns 16 w .. 16 w + 15
     //      (register quadruples r4 = 2 w, 2 w + 1 of the 8 a lane holds per fragment) in wave order and stores -------
+    mfma_drain();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int mo = item * PXB + 32 * j + l31;

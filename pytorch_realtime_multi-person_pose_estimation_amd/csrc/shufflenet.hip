@@ -49,6 +49,9 @@ int pw_head_bf16_launch(const rtpose_pw_desc* d1, const rtpose_pw_desc* d2, int 
 int pack_head_w2_bf16_launch(const float* w, const float* bias, int cout, int K, int col_off, void* wp, float* bp,
                              hipStream_t s);
 int zero_head_columns_bf16_launch(void* wp, float* bp, int K, int c0, int c1, hipStream_t s);
+// conv.0 -> depthwise -> conv.2 of a stride-1 unit as one launch (unit_bf16.hip)
+int unit_bf16_fits(const rtpose_pw_desc* d0, const rtpose_pw_desc* d2, int H, int W);
+int unit_bf16_launch(const rtpose_pw_desc* d0, const rtpose_pw_desc* d2, int N, int H, int W, hipStream_t s);
 // column-mapped fp32 packing (pw_fused.hip): a layer's columns in the memory order of the runs it writes
 int pack_pw_cols_launch(const float* w, const float* bias, int cout, int cin_src, const int32_t* cin_map, int K,
                         int ncols, const int32_t* col_map, int coutp, int col_off, float* wp, float* bp,
@@ -112,7 +115,7 @@ struct SBuf {
   int C = 0, H = 0, W = 0;
 };
 
-enum OKind { O_INPUT, O_STEM, O_POOL3, O_DW, O_PWF, O_STEMPOOL, O_HEAD };
+enum OKind { O_INPUT, O_STEM, O_POOL3, O_DW, O_PWF, O_STEMPOOL, O_HEAD, O_UNIT };
 
 struct SOp {
   OKind kind;
@@ -287,7 +290,7 @@ struct ZcStage {
   std::vector<int> phys_final;  // slot of logical channel j of the stage's output
 };
 
-ZcStage zc_plan(int h, int U, int G, int kalign) {
+ZcStage zc_plan(int h, int U, int G, int kalign, bool y_beside_x2 = false) {
   const int INF = 1 << 30;
   auto death_from = [&](int pos, int born) {  // the unit that consumes the channel at logical position pos of L_born
     for (int u = born + 1; u < U; ++u) {
@@ -374,8 +377,12 @@ ZcStage zc_plan(int h, int U, int G, int kalign) {
       zu.planes.push_back(zu.planes[0]);
       for (int e = 0; e < G; ++e) zu.x2map.push_back(-1);
     }
-    for (int g : touched) freeg.push_back(g);
-    std::sort(freeg.begin(), freeg.end());
+    // a unit that runs as ONE launch (conv.0 -> depthwise -> conv.2, unit_bf16.hip) reads x2 with a halo while other
+    // blocks of the same launch store y: y must not land in the slots x2 leaves - they are freed only afterwards
+    if (!y_beside_x2) {
+      for (int g : touched) freeg.push_back(g);
+      std::sort(freeg.begin(), freeg.end());
+    }
     // y_u: classes by consumption time, soonest first
     zu.yslot.assign(h, -1);
     std::vector<int> uniq;
@@ -387,6 +394,10 @@ ZcStage zc_plan(int h, int U, int G, int kalign) {
       for (int i = 0; i < h; ++i)
         if (death_from(2 * i + 1, u) == d) ids.push_back(i);
       place(ids, zu.yslot);
+    }
+    if (y_beside_x2) {
+      for (int g : touched) freeg.push_back(g);
+      std::sort(freeg.begin(), freeg.end());
     }
     std::vector<int> np(2 * h);
     for (int i = 0; i < h; ++i) {
@@ -481,7 +492,11 @@ void build(rtpose_shufflenet* n) {
       const int U = nblocks[si];
       const int in_phys = in_is_stage ? (int)in_kmap.size() : in_c;   // K of the layers that read the whole input buffer
       const int G = n->bf16 ? 8 : 4;                      // channels per 16-byte plane
-      const ZcStage zs = zc_plan(h, U, G, n->bf16 ? 16 : 8);
+      // bf16 plans run the units 1 .. U-1 of the 116- and 232-channel stages as ONE launch each (unit_bf16.hip): y next
+      // to x2, not in its place.  (The 58-channel stage stays at two launches: 0.067 against 0.083 ms per unit - the
+      // one-launch kernel's tiles are 128 x 128-column GEMMs whatever the width.)
+      const bool one_launch_units = n->bf16 != 0 && h >= 100;
+      const ZcStage zs = zc_plan(h, U, G, n->bf16 ? 16 : 8, one_launch_units);
       // physical channels of the stage buffer: a pixel is a whole number of 128-byte lines (and a multiple of 16 channels:
       // conv5 / the next stage read all of it)
       const int Pp = (zs.P + 8 * G - 1) / (8 * G) * (8 * G);
@@ -494,13 +509,14 @@ void build(rtpose_shufflenet* n) {
       // a pointwise layer that writes into the stage buffer.  fp32: natural column order, the kernel scatters column i to
       // out_cmap[i]; bf16: the columns are packed as the whole slot groups the layer owns (col_map), the kernel stores a
       // group of 8 columns at out_cmap[first column]
-      auto to_stage = [&](int layer, const std::vector<int32_t>& slot_of) -> int {
+      auto to_stage = [&](int layer, const std::vector<int32_t>& slot_of, int min_coutp = 64) -> int {
         if (!n->bf16) return add_map(n, slot_of);
         std::vector<int32_t> cols, chan;
         zc_columns(slot_of, G, &cols, &chan);
         SLayer& L = n->layers[layer];
         L.ncols = (int)cols.size();
         L.coutp = L.ncols <= 64 ? 64 : (L.ncols <= 128 ? 128 : (L.ncols + 255) / 256 * 256);
+        if (L.coutp < min_coutp) L.coutp = min_coutp;
         cols.resize(L.coutp, -1);       // (columns past ncols: zero columns of the packed matrix)
         chan.resize(L.coutp, -1);
         L.colmap_id = add_map(n, cols);
@@ -553,8 +569,31 @@ void build(rtpose_shufflenet* n) {
         const int l_c0 = add_layer(n, L_PW, bp + "conv.0", h, h, (int)zu.x2map.size(), M_x2);
         const int l_c1 = add_layer(n, L_DW, bp + "conv.1", h, h, Kt, -1);
         const int l_c2 = add_layer(n, L_PW, bp + "conv.2", h, h, Kt, -1);
-        const int M_y = to_stage(l_c2, zu.yslot);
+        // (the one-launch kernel wants both matrices 128 or 256 columns wide, every column of conv.0 packed - zeros
+        //  past the real ones)
+        const int M_y = to_stage(l_c2, zu.yslot, one_launch_units ? 128 : 64);
         to_temp(l_c0, h);
+        if (one_launch_units) {
+          SLayer& L0 = n->layers[l_c0];
+          L0.coutp = Kt <= 128 ? 128 : 256;
+          L0.ncols = L0.coutp;
+          SOp o;
+          o.kind = O_UNIT;
+          o.name = bp + "conv.0+conv.1+conv.2";
+          o.H = Ho;
+          o.W = Wo;
+          o.layer[0] = l_c0;
+          o.layer[1] = l_c2;
+          o.dw_layer = l_c1;
+          o.in_buf[0] = S;
+          o.out_buf[0] = S;
+          o.planes_map = M_pl;
+          o.cmap[0] = M_y;
+          o.relu = 1;
+          o.flops = 2.0 * n->N * Ho * Wo * ((double)h * h * 2 + (double)h * 9);
+          n->ops.push_back(o);
+          continue;
+        }
         add_pwf(n, bp + "conv.0", Ho, Wo, l_c0, -1, S, 0, T1, 0, -1, 1);
         n->ops.back().planes_map = M_pl;
         add_pwf(n, bp + "conv.1+conv.2", Ho, Wo, l_c2, l_c1, T1, 0, S, 0, M_y, 1);
@@ -888,6 +927,34 @@ int rtpose_shufflenet_forward(rtpose_shufflenet* n, const float* x_nchw, void* s
         } else {
           rc = pw_fused_launch(&d, n->N, o.H, o.W, s);
         }
+        break;
+      }
+      case O_UNIT: {
+        const SLayer &l0 = n->layers[o.layer[0]], &l1 = n->layers[o.dw_layer], &l2 = n->layers[o.layer[1]];
+        const SBuf& bs = n->bufs[o.in_buf[0]];
+        rtpose_pw_desc d0, d2;
+        memset(&d0, 0, sizeof(d0));
+        memset(&d2, 0, sizeof(d2));
+        d0.in = n->ws + bs.off;
+        d0.lin = slice(bs, 0);
+        d0.w_packed = n->wt + l0.w_off;
+        d0.bias_packed = n->wt + l0.b_off;
+        d0.cin = l0.cin_packed;
+        d0.cout = d0.coutp = l0.coutp;
+        d0.relu = 1;
+        d0.in_planes = imap(o.planes_map);
+        d0.dw_w = n->wt + l1.w_off;
+        d0.dw_b = n->wt + l1.b_off;
+        d2.w_packed = n->wt + l2.w_off;
+        d2.bias_packed = n->wt + l2.b_off;
+        d2.cin = l2.cin_packed;
+        d2.cout = l2.ncols;
+        d2.coutp = l2.coutp;
+        d2.relu = 1;
+        d2.out = n->ws + bs.off;
+        d2.lout = slice(bs, 0);
+        d2.out_cmap = imap(o.cmap[0]);
+        rc = unit_bf16_launch(&d0, &d2, n->N, o.H, o.W, s);
         break;
       }
       case O_HEAD: {
