@@ -303,6 +303,9 @@ def main():
                          "product (fp32-grade maps from the bf16 pipe) - both on the same workload, for reference")
     # test infrastructure (tests/test_host_cpu.py): the launcher / barrier / timing / gather skeleton on CPU ranks
     # over gloo with a stand-in for the GPU step.  Its line says so and is not a measurement.
+    ap.add_argument("--decode-overlap", type=int, choices=(0, 1), default=1,
+                    help="1 (default): the decoder and the record D2H of step k run on a second stream under the forward "
+                         "of step k + 1 (PoseEstimator.submit / collect); 0: everything on one stream, step by step")
     ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -357,12 +360,30 @@ def main():
             host = dec.fetch(bufs)                   # pinned D2H + stream sync
         return bufs, host
 
+    post = (lambda blk: par.gather_records(blk, world, force=True)) if collective else None
+
+    def run_steps(k):
+        """k steps of the production configuration -> (buffers, records) of the last one.  With --decode-overlap 1
+        step i's decoder, gather and record D2H run on the side stream while step i + 1's forward is already on the
+        compute stream; the host takes step i's records after it has submitted step i + 1, and the last step's before
+        it returns - all k steps are complete when this returns."""
+        if not args.decode_overlap:
+            for _ in range(k):
+                out = step()
+            return out
+        prev = None
+        for _ in range(k):
+            t = est.submit(x, scene, post=post)
+            if prev is not None:
+                est.collect(prev)
+            prev = t
+        return est.collect(prev)
+
     # capacity check + warm-up (untimed)
     recs0 = est(x, scene)
     humans_per_batch = sum(r["parts"].shape[0] for r in recs0)
     peaks_per_batch = sum(r["n_peaks"] for r in recs0)
-    for _ in range(max(args.warmup, 1)):        # >= 1 untimed step: also warms the RCCL gather
-        step()
+    run_steps(max(args.warmup, 1))              # >= 1 untimed step: also warms the RCCL gather
 
     plan = model.plan_for(x)
     nl = lib.rtpose_net_num_launches(plan.handle)
@@ -384,8 +405,7 @@ def main():
     torch.cuda.synchronize()
     par.barrier(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        bufs, host = step()
+    bufs, host = run_steps(args.steps)
     torch.cuda.synchronize()
     par.barrier(dev)
     elapsed_local = time.perf_counter() - t0
@@ -462,6 +482,8 @@ def main():
                        "global_batch": BATCH * world, "image": [SIZE, SIZE],
                        "weights": "seeded He init (no checkpoint offline)",
                        "decoder_input": "synthetic scene + 1e-3 * net output (blend kernel timed)",
+                       "pipeline": ("decoder + record D2H of step k on a second stream under the forward of step k + 1"
+                                    if args.decode_overlap else "one stream, step by step"),
                        "humans_per_batch": humans_per_batch, "peaks_per_batch": peaks_per_batch,
                        "conv_numerics": numerics,
                        "parallelism": ("image-sharded, all_gather of result records only" if world > 1 else

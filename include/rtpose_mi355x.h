@@ -550,6 +550,19 @@ int rtpose_net_conv_numerics(rtpose_net* net, int idx, int* form, float* amp, vo
 /* Device-side error word of the plan (synchronises `stream`): bit 0 = a split-tile hand-over of a
  * persistent 7x7 launch timed out (see rtpose_conv2d_winograd_ex); 0 = none.  The word is cleared. */
 int rtpose_net_device_status(rtpose_net* net, int* error_word, void* stream);
+/* The persistent 7x7 launches (>= one tile per CU, not whole rounds) split tiles between neighbouring blocks and hand
+ * the partial sums over through device flags - valid on a device that dispatches a 1-D grid in order with the blocks of
+ * a round resident together, i.e. an exclusive, unmasked MI355X.  enable = 0 makes every 7x7 launch of the plan run one
+ * block per tile instead: the same results, bit for bit (the sums run in the order of an unsplit tile either way), a
+ * few per cent slower at batch 32 - for CU-masked or shared devices.  Default 1, or 0 when RTPOSE_W7_PERSIST=0 is in the
+ * environment; rtpose_net_device_status switches it off by itself when it reads a timed-out hand-over. */
+int rtpose_net_set_persistent7(rtpose_net* net, int enable);
+/* A consumer that reads the stage-6 maps where the net wrote them (rtpose_net_output_view) on ANOTHER stream - the pose
+ * decoder of batch k under the forward of batch k + 1 - hands in the HIP event it records behind its last read: every
+ * later forward of the plan waits for that event (hipStreamWaitEvent on the forward's stream) before its first launch
+ * that writes the maps' buffer, and for nothing else.  NULL = no guard.  The event must have been recorded. */
+int rtpose_net_set_output_guard(rtpose_net* net, void* hip_event);
+int rtpose_net_persistent7(const rtpose_net* net);
 /* The same without the wait: queues the copy of the error word into *host_word (pinned host memory, or the copy
  * is not asynchronous) and its clearing on `stream` and returns; the word is valid once the caller has waited for
  * anything it queued on `stream` afterwards (an event behind the D2H of a batch's records: the host that

@@ -156,6 +156,9 @@ _SIGS = {
     "rtpose_net_conv_numerics": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_float), _vp]),
     "rtpose_net_device_status": (_i, [_vp, C.POINTER(_i), _vp]),
     "rtpose_net_device_status_async": (_i, [_vp, _vp, _vp]),
+    "rtpose_net_set_output_guard": (_i, [_vp, _vp]),
+    "rtpose_net_set_persistent7": (_i, [_vp, _i]),
+    "rtpose_net_persistent7": (_i, [_vp]),
     "rtpose_net_graph_active": (_i, [_vp]),
     "rtpose_net_dtype": (_i, [_vp]),
     "rtpose_packed_weight_bytes_bf16": (_sz, [_i, _i, _i]),

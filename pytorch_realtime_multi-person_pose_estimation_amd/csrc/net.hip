@@ -126,6 +126,10 @@ struct rtpose_net {
   bool amps_read = false;
   uint64_t seen_gen = ~0ull;     // generation of the weight arena the estimates / forms above were taken from
   int n_cu = 0;                  // CUs of the device the plan was created for (sizes the hand-over scratch)
+  hipEvent_t out_guard = nullptr;  // rtpose_net_set_output_guard: waited for before the first launch that writes the buffer
+  int guard_op = -1;               // the stage-6 maps are read from (index of that launch)
+  int persist7 = 1;              // 1: 7x7 launches whose tiles are not whole rounds run as persistent blocks with split tiles
+                                 // (rtpose_net_set_persistent7; cleared by a hand-over that timed out)
   int device = -1;               // HIP device that owns the bound arenas: the only device this plan launches on
   CheckedPtr in_checked;         // last input pointer verified to live on that device
   size_t scratch_off = 0, scratch_bytes = 0;  // persistent 7x7 launches: hand-over scratch inside the workspace
@@ -634,6 +638,10 @@ int rtpose_net_create_opts(int N, int H, int W, const rtpose_net_options* opt, r
                                                                                            : RTPOSE_WINO7_AUTO)
                                                   : 0;
     n->amp_limit = opt->amp_limit > 0.f ? opt->amp_limit : 256.f;
+    // RTPOSE_W7_PERSIST=0 in the environment of the process: plans start with the split-tile launches off
+    // (rtpose_net_set_persistent7 changes it per plan)
+    const char* ep = getenv("RTPOSE_W7_PERSIST");
+    n->persist7 = (ep && ep[0] == '0') ? 0 : 1;
   }
   build_plan(n);
   if (!forms_need_amps(n)) {  // AUTO waits for the filters (rtpose_net_finalize_weights)
@@ -852,8 +860,37 @@ int rtpose_net_device_status(rtpose_net* net, int* error_word, void* stream) {
   RTPOSE_HIP_CHECK(hipMemcpyAsync(error_word, err, sizeof(int), hipMemcpyDeviceToHost, s));
   RTPOSE_HIP_CHECK(hipMemsetAsync(err, 0, sizeof(int), s));
   RTPOSE_HIP_CHECK(hipStreamSynchronize(s));
+  // a hand-over wait ran out: this device does not dispatch the grid the way the split tiles assume (a CU mask, a
+  // co-tenant that starves it).  The maps of that forward are invalid - the caller is told - and the plan stops
+  // splitting tiles: every later forward runs one block per tile (same results, bit for bit, a few per cent slower).
+  if (*error_word & 1) net->persist7 = 0;
   return 0;
 }
+
+int rtpose_net_set_output_guard(rtpose_net* net, void* hip_event) {
+  if (!net) return fail(RTPOSE_E_INVAL, "net_set_output_guard: NULL net");
+  if (net->guard_op < 0) {  // the first launch of the list that writes the buffer rtpose_net_output_view hands out
+    const int target = net->bf16 ? net->save_buf[5] : net->cat_buf[0];
+    for (size_t i = 0; i < net->ops.size() && net->guard_op < 0; ++i)
+      for (int g = 0; g < 2; ++g)
+        if (net->ops[i].out_buf[g] == target) net->guard_op = (int)i;
+    if (net->guard_op < 0) net->guard_op = 0;
+  }
+  net->out_guard = static_cast<hipEvent_t>(hip_event);
+  return 0;
+}
+
+int rtpose_net_set_persistent7(rtpose_net* net, int enable) {
+  if (!net) return fail(RTPOSE_E_INVAL, "net_set_persistent7: NULL net");
+  net->persist7 = enable ? 1 : 0;
+  for (hipGraphExec_t& g : net->gexec) {  // a captured launch list holds the other grids
+    if (g) (void)hipGraphExecDestroy(g);
+    g = nullptr;
+  }
+  return 0;
+}
+
+int rtpose_net_persistent7(const rtpose_net* net) { return net && net->persist7 ? 1 : 0; }
 
 int rtpose_net_device_status_async(rtpose_net* net, int* host_word, void* stream) {
   if (!net || !net->bound || !host_word) return fail(RTPOSE_E_STATE, "net_device_status_async: net not bound / NULL argument");
@@ -1061,6 +1098,7 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
   for (size_t i = first; i < last; ++i) {
     const Op& o = net->ops[i];
     if (prof) RTPOSE_HIP_CHECK(hipEventRecord(net->ev[i], s));
+    if (net->out_guard && (int)i == net->guard_op) RTPOSE_HIP_CHECK(hipStreamWaitEvent(s, net->out_guard, 0));
     int rc = 0;
     switch (o.kind) {
       case OP_INPUT: {
@@ -1139,8 +1177,9 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
         rc = net->bf16   ? conv2d_bf16_launch(d, o.ngroups, N, o.H, o.W, o.out_f32, net->split, s)
              : form == 3  ? conv2d_wino_launch(d, o.ngroups, N, o.H, o.W, s)
              : form == 43 ? conv2d_wino4_launch(d, o.ngroups, N, o.H, o.W, s)
-             : form      ? conv2d_wino7_launch(d, o.ngroups, N, o.H, o.W, form, net->ws + net->scratch_off,
-                                               net->scratch_bytes, s)
+             : form      ? conv2d_wino7_launch(d, o.ngroups, N, o.H, o.W, form,
+                                               net->persist7 ? net->ws + net->scratch_off : nullptr,  // (no scratch:
+                                               net->persist7 ? net->scratch_bytes : 0, s)             //  one block per tile)
                          : conv2d_launch(d, o.ngroups, N, o.H, o.W, s);
         break;
       }

@@ -19,7 +19,7 @@
 //   * The waves split the CHANNELS: in a pass wave w owns conv5 channels [256 p + 64 w, + 64) of all 128 pixels.
 //     A filter fragment (1 KB, straight from L2 through a buffer load: one SGPR offset, no address VALU) feeds FOUR
 //     MFMAs, an activation fragment (one ds_read_b128 per lane) two: 32 B/clk per CU from L2, 64 B/clk from LDS at
-//     the full matrix rate.  Filters are requested three k-steps (24 MFMAs) ahead in a four-set register ring.
+//     the full matrix rate.  Filters are requested seven k-steps (56 MFMAs) ahead in an eight-set register ring.
 //   * BOTH GEMMs ARE COMPUTED TRANSPOSED (as in pw_head.hip): C1^T[channel][pixel] = W1^T X^T leaves lane (l31, kh)
 //     with the channels rg 8 + 4 kh + rr of ITS pixel - packed to bf16 after bias + ReLU, eight of them are exactly
 //     the B operand of one K = 16 step of OUT^T[head column][pixel] += W2^T[column][k] relu(C1^T)[k][pixel]; the heads'
@@ -111,10 +111,9 @@ struct IntTag {
 };
 
 // A pass walks K1 in k-steps of 16 channels, four to a chunk (= one turn of the filter ring's four slots), two chunks to
-// a staging granule.  K1 = 480 is 30 steps: the pass runs 32, the last two on all-zero filter fragments (loaded
-// through a zero-extent descriptor: nothing fetched) against the activations of step 29 - exact zeros added, 6 % more
-// matrix time in this launch, and every pass is the same straight-line code (a separate two-step tail made the
-// register allocator park the heads' 128 accumulators in VGPRs during GEMM 1 and spill).
+// a staging granule.  K1 = 480 is 30 steps: the pass walks 32, the last two request their filter fragments through a
+// zero-extent descriptor (nothing fetched) and skip their MFMAs - every pass is the same code (a separate two-step tail
+// made the register allocator park the heads' 128 accumulators in VGPRs during GEMM 1 and spill).
 __global__ __launch_bounds__(256, 1) void pw_head_bf16_kernel(const Args A) {
   extern __shared__ __attribute__((aligned(16))) float4 smem4[];
   __shared__ __attribute__((aligned(16))) float4 s_b1[256], s_b2[16];
@@ -176,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void pw_head_bf16_kernel(const Args A) {
     }
   };
 
-  float4 wr[4][2];   // filter fragments of GEMM 1: ring of four k-steps x the wave's two channel fragments
+  float4 wr[8][2];   // filter fragments of GEMM 1: ring of eight k-steps x the wave's two channel fragments
   float4 xr[2][4];   // activation fragments: two k-steps x four pixel fragments
   float4 w2r[2][2];  // fragments of the heads' matrix: two 16-channel groups in flight x two head-column fragments
   floatx16 acc[2][4];  // C1^T of the pass: channel fragment f, pixel fragment j
@@ -224,9 +223,8 @@ __global__ __launch_bounds__(256, 1) void pw_head_bf16_kernel(const Args A) {
     stage_store(sr[0], c);
     if (c + 1 < nch) stage_store(sr[1], c + 1);
   }
-  wload(wr[0], 0, 0);
-  wload(wr[1], 0, 1);
-  wload(wr[2], 0, 2);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) wload(wr[i], 0, i);  // (kst >= 8)
   __syncthreads();
   xload(xr[0], 0);
 
@@ -244,23 +242,28 @@ __global__ __launch_bounds__(256, 1) void pw_head_bf16_kernel(const Args A) {
         for (int j = 0; j < 4; ++j) o[i][j] = z;
     }
 
-    // one k-step: request the filters of step + 3 and the activations of step + 1, multiply step
+    // one k-step: request the filters of step + 7 and the activations of step + 1, multiply step.  (Seven steps - at the
+    // rate the matrix pipe really runs at, ~3.5 k cycles: loads complete in order, so a filter request issued right
+    // after the last pass' HBM requests for the next tile comes back behind them; three steps ahead, as in the first
+    // version, the multiply loop sat out an HBM round trip per staging granule.)
     auto step = [&](auto i_tag, int p, int g) {
-      constexpr int S = decltype(i_tag)::value & 3;
+      constexpr int S = decltype(i_tag)::value & 7;
       constexpr int XS = decltype(i_tag)::value & 1;
-      int g3 = g + 3, p3 = p;
+      int g3 = g + 7, p3 = p;
       while (g3 >= kst) {  // (uniform; the heads of the next pass - or of the next item's first pass)
         g3 -= kst;
         p3 = p3 + 1 == NP ? 0 : p3 + 1;
       }
-      wload(wr[(S + 3) & 3], p3, g3);
+      wload(wr[(S + 7) & 7], p3, g3);
       xload(xr[XS ^ 1], g + 1 == kst ? 0 : g + 1);
       RTPOSE_HB_PIN();
+      if (g < kreal) {  // (uniform, no load inside; a step past K1 - the ring and the chunk pairs want whole turns - is skipped)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
-          acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(wr[S][f]), as_bf8(xr[XS][j]), acc[f][j], 0, 0, 0);
+          for (int f = 0; f < 2; ++f)
+            acc[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf8(wr[S][f]), as_bf8(xr[XS][j]), acc[f][j], 0, 0, 0);
+      }
       RTPOSE_HB_PIN();
     };
     auto run_pass = [&](int p) {
@@ -280,10 +283,10 @@ __global__ __launch_bounds__(256, 1) void pw_head_bf16_kernel(const Args A) {
         step(IntTag<1>(), p, g0 + 1);
         step(IntTag<2>(), p, g0 + 2);
         step(IntTag<3>(), p, g0 + 3);
-        step(IntTag<0>(), p, g0 + 4);
-        step(IntTag<1>(), p, g0 + 5);
-        step(IntTag<2>(), p, g0 + 6);
-        step(IntTag<3>(), p, g0 + 7);
+        step(IntTag<4>(), p, g0 + 4);
+        step(IntTag<5>(), p, g0 + 5);
+        step(IntTag<6>(), p, g0 + 6);
+        step(IntTag<7>(), p, g0 + 7);
         if (lastp) {
           __syncthreads();  // every wave has read the chunks c0, c0 + 1 for the last time
           stage_store(sr[0], c0);

@@ -211,6 +211,130 @@ def test_memory_that_is_not_of_the_current_device_is_refused(cuda):
     assert dec.parse_image(dec.fetch(bufs)[0])["n_peaks"] > 0
 
 
+_MASKED = r"""
+import ctypes as C, importlib, sys
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+PKG = "pytorch_realtime_multi-person_pose_estimation_amd"
+pkg = importlib.import_module(PKG)
+synth = importlib.import_module(PKG + ".synth")
+lib = pkg._capi.lib
+m = pkg.get_model('vgg19')
+m.load_state_dict(synth.he_init_state_dict(m, seed=0))
+m = m.cuda().float().eval()
+x = (torch.rand(12, 3, 368, 368, generator=torch.Generator().manual_seed(5)) - 0.5).cuda()
+out = {}
+with torch.no_grad():
+    for persist in (1, 0):
+        plan = m.plan_for(x)
+        pkg._capi.check(lib.rtpose_net_set_persistent7(plan.handle, persist))
+        assert lib.rtpose_net_persistent7(plan.handle) == persist
+        (paf, heat), _ = m(x)
+        torch.cuda.synchronize()
+        status = m.device_status(plan)
+        out[persist] = (paf.cpu().numpy(), heat.cpu().numpy(), status)
+assert out[0][2] == 0, "error word %d with one block per tile" % out[0][2]
+np.savez(sys.argv[2], paf1=out[1][0], heat1=out[1][1], status1=out[1][2], paf0=out[0][0], heat0=out[0][1])
+print("MASKED_OK cus", torch.cuda.get_device_properties(0).multi_processor_count, "status", out[1][2])
+"""
+
+
+def test_seven_by_seven_launches_without_split_tiles_and_under_a_cu_mask(tmp_path, cuda):
+    """rtpose_net_set_persistent7(plan, 0): every 7x7 launch runs one block per tile instead of persistent blocks that hand
+    split tiles over through device flags - for CU-masked / shared devices, where the dispatch order and residency the
+    hand-over assumes are not given.  Both forms give the same bits (the sums run in the order of an unsplit tile), on
+    the whole device and - in a child process - under HSA_CU_MASK (64 of the 256 CUs): there the split-tile form either
+    works (error word 0: same bits again) or reports its timed-out hand-over in the error word, never silently wrong;
+    the one-block-per-tile form must always be clean.  12 x 368 x 368: 2 x 12 x 12 strips of 46 x 46 = 288 tiles per
+    grouped launch on 256 CUs - not whole rounds, so the default plan does split tiles."""
+    script = tmp_path / "masked.py"
+    script.write_text(_MASKED)
+    res = {}
+    for tag, extra in (("full", {}), ("masked", {"HSA_CU_MASK": "0:0-63"})):
+        env = dict(os.environ, **extra)
+        out = tmp_path / ("%s.npz" % tag)
+        p = subprocess.run([sys.executable, str(script), ROOT, str(out)], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=900)
+        assert p.returncode == 0 and "MASKED_OK" in p.stdout, (tag, p.stdout[-2000:], p.stderr[-3000:])
+        import numpy as np
+        res[tag] = dict(np.load(str(out)))
+    import numpy as np
+    full, masked = res["full"], res["masked"]
+    assert int(full["status1"]) == 0
+    assert np.array_equal(full["paf1"], full["paf0"]) and np.array_equal(full["heat1"], full["heat0"])
+    assert np.array_equal(masked["paf0"], full["paf0"]) and np.array_equal(masked["heat0"], full["heat0"])
+    if int(masked["status1"]) == 0:
+        assert np.array_equal(masked["paf1"], full["paf0"]) and np.array_equal(masked["heat1"], full["heat0"])
+
+
+def test_decoder_of_one_batch_under_the_forward_of_the_next(cuda):
+    """PoseEstimator.submit / collect: the decoder and the record D2H of batch k run on a second stream while the forward of
+    batch k + 1 is already on the compute stream; that forward waits for the decoder's last read of the maps only where
+    it first writes their buffer (rtpose_net_set_output_guard).  Three different batches through one 16-image plan,
+    interleaved and repeated, two tickets in flight: every collected record block SAYS what the serial path
+    (enqueue + fetch, one stream) says for the same batch - peaks, people, float scores, bit for bit."""
+    import importlib
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    pkg = importlib.import_module(PKG_NAME)
+    dec = importlib.import_module(PKG_NAME + ".decode")
+    synth = importlib.import_module(PKG_NAME + ".synth")
+    pipeline = importlib.import_module(PKG_NAME + ".pipeline")
+    dev = torch.device("cuda", 0)
+    m = pkg.get_model('vgg19')
+    m.load_state_dict(synth.he_init_state_dict(m, seed=0))
+    m = m.cuda().float().eval()
+    B, S = 16, 368
+
+    def batch(r):
+        g = torch.Generator().manual_seed(300 + r)
+        h, p, _ = synth.make_batch(B, S, S, seed=400 + r)
+        return (torch.rand(B, 3, S, S, generator=g) - 0.5).to(dev), (torch.from_numpy(h).to(dev), torch.from_numpy(p).to(dev))
+
+    def content(block):
+        out = []
+        for r in block:
+            d = dec.parse_image(r)
+            out.append((d["peaks"].view(np.uint32).tobytes(), d["parts"].tobytes(), d["score"].view(np.uint32).tobytes(), d["flags"]))
+        return out
+    data = [batch(r) for r in range(3)]
+    est = pipeline.PoseEstimator(m)
+    want = []
+    for x, scene in data:
+        est(x, scene)                                            # capacities settle
+        want.append(content(dec.fetch(est.enqueue(x, scene)).copy()))
+    assert sum(len(dec.parse_image(r)["parts"]) for r in dec.fetch(est.enqueue(*data[0]))) > B
+    order = [0, 1, 2, 2, 1, 0, 0, 1, 2, 1]
+    prev, got = None, []
+    for r in order:
+        t = est.submit(*data[r])
+        if prev is not None:
+            got.append(content(est.collect(prev[0])[1].reshape(B, -1)))
+        prev = (t, r)
+    got.append(content(est.collect(prev[0])[1].reshape(B, -1)))
+    torch.cuda.synchronize()
+    for k, r in enumerate(order):
+        assert got[k] == want[r], "step %d (batch %d): the overlapped path's records differ from the serial path's" % (k, r)
+    # the same under bf16 (the decoder's share of a step is larger there, the forward 2.6x shorter)
+    m.set_compute_dtype('bf16')
+    try:
+        est(data[0][0], data[0][1])
+        want_b = [content(dec.fetch(est.enqueue(x, scene)).copy()) for x, scene in data]
+        prev, got = None, []
+        for r in order:
+            t = est.submit(*data[r])
+            if prev is not None:
+                got.append(content(est.collect(prev[0])[1].reshape(B, -1)))
+            prev = (t, r)
+        got.append(content(est.collect(prev[0])[1].reshape(B, -1)))
+        for k, r in enumerate(order):
+            assert got[k] == want_b[r], "bf16 step %d (batch %d)" % (k, r)
+    finally:
+        m.set_compute_dtype('fp32')
+
+
 def _bench_line(p):
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert p.returncode == 0 and lines, (p.stdout[-2000:], p.stderr[-3000:])
