@@ -560,7 +560,10 @@ int rtpose_net_set_persistent7(rtpose_net* net, int enable);
 /* A consumer that reads the stage-6 maps where the net wrote them (rtpose_net_output_view) on ANOTHER stream - the pose
  * decoder of batch k under the forward of batch k + 1 - hands in the HIP event it records behind its last read: every
  * later forward of the plan waits for that event (hipStreamWaitEvent on the forward's stream) before its first launch
- * that writes the maps' buffer, and for nothing else.  NULL = no guard.  The event must have been recorded. */
+ * that writes the maps' buffer, and for nothing else (fp32 plans).  bf16 / bf16x3 plans - and fp32 ones under
+ * RTPOSE_GUARD_WHOLE_FORWARD=1 - wait in FRONT of their launch list: a decoder running beside the bf16 MFMA kernels
+ * returned a limb score one sample off in ~1 % of the batches, cause not found, so it never does.
+ * NULL = no guard.  The event must have been recorded. */
 int rtpose_net_set_output_guard(rtpose_net* net, void* hip_event);
 int rtpose_net_persistent7(const rtpose_net* net);
 /* The same without the wait: queues the copy of the error word into *host_word (pinned host memory, or the copy

@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256) void nms_refine_kernel(MapView heat, int h, in
   // per-destination-index source offset and cubic weights (cv2.resize INTER_CUBIC:
   // fx = (float)((dx+0.5)*scale - 0.5); sx = floor(fx); fx -= sx)
   if (tid < 5 * up) {
-    float fx = (float)(((double)tid + 0.5) * inv_up - 0.5);
+    // (double)(tid + 0.5) * inv_up - 0.5 rounded to float: exact in fp32 when up is a power of two (no double-precision
+    // instruction then: see limb_assign_kernel)
+    float fx = (up & (up - 1)) == 0 ? ((float)tid + 0.5f) * (float)inv_up - 0.5f
+                                    : (float)(((double)tid + 0.5) * inv_up - 0.5);
     const int sx = (int)floorf(fx);
     fx -= (float)sx;
     float c[4];
@@ -238,7 +241,10 @@ __global__ __launch_bounds__(256) void nms_refine_opt_kernel(MapView heat, int h
   float* s_tmp = s_dyn + 25 * up * up;
 
   if (tid < 5 * up) {
-    float fx = (float)(((double)tid + 0.5) * inv_up - 0.5);
+    // (double)(tid + 0.5) * inv_up - 0.5 rounded to float: exact in fp32 when up is a power of two (no double-precision
+    // instruction then: see limb_assign_kernel)
+    float fx = (up & (up - 1)) == 0 ? ((float)tid + 0.5f) * (float)inv_up - 0.5f
+                                    : (float)(((double)tid + 0.5) * inv_up - 0.5);
     const int sx = (int)floorf(fx);
     fx -= (float)sx;
     float c[4];
@@ -543,9 +549,21 @@ constexpr int kSortStack = 3 * 64;  // pending ranges <= the depth limit 2 floor
 // ------------------------------------------------------------------------------
 // 2. PAF scoring + greedy assignment (pafprocess.cpp:46-124, :220-246)
 // ------------------------------------------------------------------------------
-__device__ __forceinline__ int roundpaf(float v) { return (int)((double)v + 0.5); }
 
-__global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, int w, double inv_up,
+// Round 5: (a) SCORES_IN_LDS is a template parameter - the score matrix is addressed with LDS instructions (or global
+// ones), not through a generic pointer (flat_load / flat_store, the aperture decided per access); (b) NO double-precision
+// instruction in the per-sample loop: the reference's (int)(v + 0.5) on a double and floor(l / up) are computed exactly
+// in integers / fp32 (v >= 0 and up a power of two, the only case the configs use; any other `up` keeps the doubles),
+// and the length penalty needs its double division only for limbs longer than half the image.  Why (b): with the
+// decoder on a second stream next to the bf16 forward's MFMA kernels (pipeline.SideDecoder), ~1 % of the batches came
+// back with ONE candidate score a sample off (e.g. 1.0020 -> 0.9050: one of the ten samples taken at the previous
+// sample's position), always a candidate scored by the HIGH lanes (41..63) of the wave - reversing the pair -> lane map
+// moved the damage to the other end of the table - with maps and peaks bit-identical before and after, never in the
+// serial flow, never next to the fp32 plan's kernels (tools/exp/overlap_flake.py, profiles/r05_decoder_next_to_mfma.txt;
+// DESIGN.md 3.3).  The half-rate double-precision chain v_cvt_f64 -> v_add_f64 -> v_cvt_i32_f64 -> v_mul_f64 ->
+// v_floor_f64 was the one multi-pass VALU sequence in the loop.
+template <bool SCORES_IN_LDS, bool UP_POW2>
+__global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, int w, double inv_up, int up_shift,
                                                           int h1, int pcap,
                                                           const int32_t* __restrict__ result,
                                                           int result_words, int32_t* __restrict__ conn,
@@ -556,7 +574,7 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
   const int32_t* res = result + (size_t)n * result_words;
   int32_t* cn = conn + (size_t)n * conn_words + (size_t)pair_id * (1 + 3 * pcap);
 
-  extern __shared__ float s_score_lds[];  // [pcap * pcap] candidate scores, 0 = none (when they fit), then the tie list
+  extern __shared__ __attribute__((aligned(16))) float s_score_lds[];  // [pcap * pcap] candidate scores, 0 = none (when they fit), then the tie list
   __shared__ unsigned char s_usedA[kDecodeMaxPeaks], s_usedB[kDecodeMaxPeaks];
   __shared__ float s_wbest[4];
   __shared__ int s_widx[4], s_wcnt[4];
@@ -581,16 +599,20 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
   const int npairs = nA * nB;
   // the score matrix lives in LDS unless the tables were grown past what LDS holds
   // (junk maps with hundreds of peaks per part): then in the global workspace
-  float* s_score = (pcap * pcap <= kLdsPairs)
-                       ? s_score_lds
-                       : score_ws + ((size_t)n * RTPOSE_NUM_LIMB + pair_id) * pcap * pcap;
+  float* const score_g = score_ws + ((size_t)n * RTPOSE_NUM_LIMB + pair_id) * pcap * pcap;
+  auto s_score = [&](int p) -> float& {
+    if constexpr (SCORES_IN_LDS)
+      return s_score_lds[p];
+    else
+      return score_g[p];
+  };
   for (int p = tid; p < npairs; p += 256) {
     const int a = p / nB, b = p - a * nB;
     const rtpose_peak A = pA[a], B = pB[b];
     float cand = 0.f;
     float vx = (float)(B.x - A.x), vy = (float)(B.y - A.y);
     const float norm = sqrtf(vx * vx + vy * vy);
-    if (!((double)norm < 1e-12)) {
+    if (norm > 0.f) {  // (double)norm < 1e-12 of the reference: norm is the root of a sum of integer squares, 0 or >= 1
       vx = vx / norm;
       vy = vy / norm;
       const float step_x = (float)(B.x - A.x) / 10.f;
@@ -599,10 +621,21 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
       int crit1 = 0;
 #pragma unroll
       for (int i = 0; i < 10; ++i) {
-        const int lx = roundpaf((float)A.x + (float)i * step_x);
-        const int ly = roundpaf((float)A.y + (float)i * step_y);
-        // nearest x8 up-sampling of the PAF as an index map (paf_to_pose.py:382)
-        int sx = (int)floor((double)lx * inv_up), sy = (int)floor((double)ly * inv_up);
+        // lx = (int)(v + 0.5) evaluated in double (pafprocess.cpp:232-233): v >= 0 is a float, so v + 0.5 is exact there
+        // and the cast is floor(v + 0.5) = trunc(v) + (frac(v) >= 0.5), frac exact in fp32
+        const float fx = (float)A.x + (float)i * step_x, fy = (float)A.y + (float)i * step_y;
+        int lx = (int)fx, ly = (int)fy;
+        if (fx - (float)lx >= 0.5f) ++lx;
+        if (fy - (float)ly >= 0.5f) ++ly;
+        // nearest x8 up-sampling of the PAF as an index map (paf_to_pose.py:382): floor(l / up)
+        int sx, sy;
+        if constexpr (UP_POW2) {
+          sx = lx >> up_shift;
+          sy = ly >> up_shift;
+        } else {
+          sx = (int)floor((double)lx * inv_up);
+          sy = (int)floor((double)ly * inv_up);
+        }
         sx = min(max(sx, 0), w - 1);
         sy = min(max(sy, 0), h - 1);
         const float px = map_at(paf, n, sy, sx, chx);
@@ -611,11 +644,16 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
         scores = scores + s;
         if (s > 0.05f) ++crit1;
       }
-      const double pen = fmin(0.0, 0.5 * (double)h1 / (double)norm - 1.0);
-      const float crit2 = (float)((double)(scores / 10.f) + pen);
+      // min(0.5 h1 / norm - 1, 0) in double (cpp:238-240): 0 for every limb no longer than half the image (the quotient is
+      // >= 1 then, and adding 0.0 to a float widened to double changes nothing)
+      float crit2 = scores / 10.f;
+      if (2.f * norm > (float)h1) {
+        const double pen = fmin(0.0, 0.5 * (double)h1 / (double)norm - 1.0);
+        crit2 = (float)((double)crit2 + pen);
+      }
       if (crit1 > 6 && crit2 > 0.f) cand = crit2;
     }
-    s_score[p] = cand;
+    s_score(p) = cand;
   }
   __threadfence_block();
   __syncthreads();
@@ -634,7 +672,7 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
     float best = 0.f;
     int bidx = 0x7fffffff, cnt = 0;
     for (int p = tid; p < npairs; p += 256) {
-      const float s = s_score[p];
+      const float s = s_score(p);
       if (s >= best && s > 0.f) {
         const int a = p / nB, b = p - a * nB;
         if (!s_usedA[a] && !s_usedB[b]) {
@@ -708,16 +746,15 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
     }
     __syncthreads();
     // candidates in push order: ordered compaction by ballot / popcount, like the peak ids
-    const bool score_in_lds = pcap * pcap <= kLdsPairs;
     unsigned long long* lds_list =
-        reinterpret_cast<unsigned long long*>(s_score_lds + (score_in_lds ? ((pcap * pcap + 1) & ~1) : 0));
+        reinterpret_cast<unsigned long long*>(s_score_lds + (SCORES_IN_LDS ? ((pcap * pcap + 1) & ~1) : 0));
     unsigned long long* ws_list = tie_ws + ((size_t)n * RTPOSE_NUM_LIMB + pair_id) * pcap * pcap;
     for (int pass = 0; pass < 2; ++pass) {  // pass 0 counts (LDS or workspace?), pass 1 writes
       unsigned long long* list = (s_nconn <= kTieLdsCands) ? lds_list : ws_list;  // (s_nconn = the count after pass 0)
       int base = 0;
       for (int start = 0; start < npairs; start += 256) {
         const int p = start + tid;
-        const float sc = p < npairs ? s_score[p] : 0.f;
+        const float sc = p < npairs ? s_score(p) : 0.f;
         const bool c = sc > 0.f;
         const unsigned long long mask = __ballot(c);
         if (lane == 0) s_wcnt[wave] = __popcll(mask);
@@ -759,6 +796,7 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
   __syncthreads();
   if (tid == 0) cn[0] = s_nconn;
 }
+
 
 // ------------------------------------------------------------------------------
 // 3. Person grouping + prune (pafprocess.cpp:126-191), one wave per image
@@ -985,14 +1023,31 @@ int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int 
   static PerDeviceOnce attr_set;  // zero-initialised; the attribute is per device
   const int dev = current_device();
   if (!attr_set.is_set(dev)) {
-    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(limb_assign_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    const void* limb_kernels[4] = {reinterpret_cast<const void*>(limb_assign_kernel<true, true>),
+                                   reinterpret_cast<const void*>(limb_assign_kernel<true, false>),
+                                   reinterpret_cast<const void*>(limb_assign_kernel<false, true>),
+                                   reinterpret_cast<const void*>(limb_assign_kernel<false, false>)};
+    for (const void* k : limb_kernels)
+      RTPOSE_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     attr_set.set(dev);
   }
-  hipLaunchKernelGGL(limb_assign_kernel, dim3(RTPOSE_NUM_LIMB, N), dim3(256), lds, s, to_view(paf, lpaf), h,
-                     w, inv_up, h1, pcap, res, words, conn, conn_words, score_ws, tie_ws);
+  const int up = cfg->upsample;
+  int up_shift = -1;  // log2(up) when it is a power of two
+  for (int k = 0; k < 8; ++k)
+    if (up == (1 << k)) up_shift = k;
+  const bool in_lds = pcap * pcap <= kLdsPairs;
+  {
+#define RTPOSE_LIMB(L, P)                                                                                              \
+  hipLaunchKernelGGL((limb_assign_kernel<L, P>), dim3(RTPOSE_NUM_LIMB, N), dim3(256), lds, s, to_view(paf, lpaf), h, w, \
+                     inv_up, up_shift, h1, pcap, res, words, conn, conn_words, score_ws, tie_ws)
+    if (in_lds && up_shift >= 0) RTPOSE_LIMB(true, true);
+    else if (in_lds) RTPOSE_LIMB(true, false);
+    else if (up_shift >= 0) RTPOSE_LIMB(false, true);
+    else RTPOSE_LIMB(false, false);
+#undef RTPOSE_LIMB
+  }
   const int row_cap = decode_row_cap(cfg);
   const size_t rows_lds = row_cap <= kLdsRows ? (size_t)row_cap * 21 * sizeof(float) : 0;
   hipLaunchKernelGGL(group_kernel, dim3(N), dim3(64), rows_lds, s, pcap, cfg->max_humans, res, words, conn,

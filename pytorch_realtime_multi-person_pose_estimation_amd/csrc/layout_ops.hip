@@ -5,6 +5,9 @@
 // NHWC side where the slice is 16-byte aligned.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+#include <type_traits>
+
 #include "common.h"
 
 namespace rtpose {
@@ -445,35 +448,87 @@ __global__ void stem_conv3x3_s2_nchw_kernel(const float* __restrict__ x, const f
 // touch (13 % recomputed at tile borders) into LDS, and writes the window maxima.  The 184 x 184 x 24
 // stem tensor (416 MB fp32 / 208 MB bf16 at batch 128) is never stored: the two launches it replaces
 // cost 0.60 (fp32) / 0.52 ms (bf16) of a 10.5 / 4.7 ms forward.
+//
+// Round 5: the kernel was bound by its VALU work around the matrix instructions, not by them (per block and wave ~4300
+// issue cycles of address arithmetic, masks and selects against 2240 of MFMA).  Now
+//  * VEC: image rows are read as aligned float4 (W % 4 == 0: the patch columns 32 bx - 4 .. 32 bx + 35 are ten whole
+//    float4 per row, each entirely inside or outside the image): 5 loads per thread instead of 15, a quarter of the
+//    index arithmetic; the scalar loader stays for other widths;
+//  * the ReLU and the "conv output does not exist" mask left the MFMA write-out: the pool starts from 0 (max(0, .) IS
+//    the ReLU) and only the tiles at the map's right / bottom edge test the window positions; the write-out is 16
+//    ds_write_b32 at immediate offsets;
+//  * tap offsets / filter registers are picked from compile-time tables and loaded before the patch arrives; fragments
+//    wholly below the conv map are skipped; the waves that take the odd fragments rotate with the block index.
 constexpr int kSpT = 8;                   // pool outputs per tile side
 constexpr int kSpS = 2 * kSpT + 1;        // conv outputs per tile side (17)
 constexpr int kSpI = 2 * kSpS + 1;        // input pixels per tile side (35)
-constexpr int kSpIP = kSpI + 1;           // LDS row pitch of the input patch
+constexpr int kSpIP = 40;                 // LDS row pitch of the input patch: column j holds image column ix0 - 3 + j
+constexpr int kSpX0 = 3;                  // LDS column of the tile's first input pixel (ix0 = 32 bx - 1)
 constexpr int kSpC = 24;
 constexpr int kSpCP = 28;                 // LDS pitch of one conv output's channels (conflict skew)
-template <int OUT_BF16>
+constexpr int kSpF = (kSpS * kSpS + 31) / 32;  // MFMA fragments of 32 conv positions per tile (10)
+// tap k = (ky * 3 + kx) * 3 + c of the K dimension (k = 27: tap 26 again, under a zero weight)
+__host__ __device__ constexpr int sp_tap_off(int k) {
+  const int kk = k < 26 ? k : 26;
+  return ((kk % 3) * kSpI + (kk / 3) / 3) * kSpIP + (kk / 3) % 3 + kSpX0;
+}
+__host__ __device__ constexpr int sp_tap_w(int k) {  // packed filters [ky][kx][8][24]
+  const int kk = k < 26 ? k : 26;
+  return ((kk / 3) * 8 + kk % 3) * kSpC;
+}
+template <int OUT_BF16, int VEC>
 __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, const float* __restrict__ w,
                                                         const float* __restrict__ bias, void* __restrict__ out_v,
                                                         Lay lo, int H, int W, int H1, int W1, int H2, int W2) {
-  __shared__ float s_in[3][kSpI][kSpIP];
-  __shared__ float s_st[kSpS * kSpS][kSpCP];
-  __shared__ unsigned char s_ok[kSpS * kSpS];    // conv output of the tile exists (inside the H1 x W1 map)
+  __shared__ __attribute__((aligned(16))) float s_in[3 * kSpI][kSpIP];
+  __shared__ __attribute__((aligned(16))) float s_st[kSpF * 32][kSpCP];
   const int tid = threadIdx.x;
   const int n = blockIdx.z;
   const int py0 = blockIdx.y * kSpT, px0 = blockIdx.x * kSpT;
   const int sy0 = 2 * py0, sx0 = 2 * px0;        // first conv output of the tile
-  for (int p = tid; p < kSpS * kSpS; p += 256) s_ok[p] = (sy0 + p / kSpS < H1 && sx0 + p % kSpS < W1) ? 1 : 0;
   const int iy0 = 2 * sy0 - 1, ix0 = 2 * sx0 - 1;  // first input pixel of the tile (may be -1: padding)
-  {  // the input patch: all of a thread's loads are issued before the first is used (one memory round trip
-     // per block instead of fifteen)
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+  // filter registers of the matrix phase (B operand: channel l31, tap 2 j + kh), requested before the patch
+  float bw[14];
+#pragma unroll
+  for (int j = 0; j < 14; ++j) {
+    const int wi = (kh ? sp_tap_w(2 * j + 1) : sp_tap_w(2 * j)) + min(l31, kSpC - 1);
+    const float t = w[wi];
+    bw[j] = (l31 < kSpC && 2 * j + kh < 27) ? t : 0.f;
+  }
+  const float bv = l31 < kSpC ? bias[min(l31, kSpC - 1)] : 0.f;
+  const float sc[3] = {scale ? scale[0] : 1.f, scale ? scale[1] : 1.f, scale ? scale[2] : 1.f};
+  const float sh[3] = {scale ? shift[0] : 0.f, scale ? shift[1] : 0.f, scale ? shift[2] : 0.f};
+  const float* xn = x + (size_t)n * 3 * H * W;
+  if (VEC) {  // rows as aligned float4: thread = (float4 q of the row, row r0 + 25 u of the 105 patch rows)
+    constexpr int NR = 5;
+    const int q = tid % 10, r0 = tid / 10;
+    const int ix4 = ix0 - kSpX0 + 4 * q;
+    const bool xin = ix4 >= 0 && ix4 < W && tid < 250;
+    const int ixc = min(max(ix4, 0), W - 4);
+    float4 v[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {  // branch-free: clamped addresses, masked afterwards
+      const int r = min(r0 + 25 * u, 3 * kSpI - 1);
+      const int c = r / kSpI, yy = r - c * kSpI;
+      const int iy = iy0 + yy;
+      const bool in = xin && iy >= 0 && iy < H;
+      const float4 t = *reinterpret_cast<const float4*>(xn + (size_t)(unsigned)(c * H + min(max(iy, 0), H - 1)) * (unsigned)W + ixc);
+      const float a = c == 0 ? sc[0] : (c == 1 ? sc[1] : sc[2]), b = c == 0 ? sh[0] : (c == 1 ? sh[1] : sh[2]);
+      v[u] = in ? make_float4(t.x * a + b, t.y * a + b, t.z * a + b, t.w * a + b) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const int r = r0 + 25 * u;
+      if (tid < 250 && r < 3 * kSpI) *reinterpret_cast<float4*>(&s_in[r][4 * q]) = v[u];
+    }
+  } else {  // any width: one pixel per load, all of a thread's loads issued before the first is used
     constexpr int NL = (3 * kSpI * kSpI + 255) / 256;
     float v[NL];
-    const float sc[3] = {scale ? scale[0] : 1.f, scale ? scale[1] : 1.f, scale ? scale[2] : 1.f};
-    const float sh[3] = {scale ? shift[0] : 0.f, scale ? shift[1] : 0.f, scale ? shift[2] : 0.f};
-    const float* xn = x + (size_t)n * 3 * H * W;
 #pragma unroll
-    for (int u = 0; u < NL; ++u) {  // branch-free: clamped addresses, masked afterwards
+    for (int u = 0; u < NL; ++u) {
       const int i = min(tid + 256 * u, 3 * kSpI * kSpI - 1);
       const int xx = i % kSpI;
       const int r = i / kSpI;
@@ -487,11 +542,7 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
       const int i = tid + 256 * u;
-      if (i < 3 * kSpI * kSpI) {
-        const int xx = i % kSpI;
-        const int r = i / kSpI;
-        s_in[r / kSpI][r % kSpI][xx] = v[u];
-      }
+      if (i < 3 * kSpI * kSpI) s_in[i / kSpI][i % kSpI + kSpX0] = v[u];
     }
   }
   __syncthreads();
@@ -504,41 +555,31 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
   // and was bound by exactly that: 0.38 ms of an 8.9 / 4.05 ms forward.
   {
     typedef float floatx16 __attribute__((ext_vector_type(16)));
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
-    float bw[14];
-    int aoff[14];
-#pragma unroll
-    for (int j = 0; j < 14; ++j) {
-      const int k = 2 * j + kh;            // tap-major K: k = (ky * 3 + kx) * 3 + c
-      const int t = min(k, 26) / 3, c = min(k, 26) - 3 * t;
-      const int ky = t / 3, kx = t - 3 * ky;
-      bw[j] = (l31 < kSpC && k < 27) ? w[(t * 8 + c) * kSpC + l31] : 0.f;   // packed [ky][kx][8][24]
-      aoff[j] = (c * kSpI + ky) * kSpIP + kx;                                // (k = 27 re-reads tap 26 under a zero weight)
-    }
-    const float bv = l31 < kSpC ? bias[l31] : 0.f;
-    for (int f = wv; f < (kSpS * kSpS + 31) / 32; f += 4) {
+    // fragments whose positions all lie below the conv map are not computed (the tiles of the last tile row)
+    const int nf = min(kSpF, (min(kSpS, H1 - sy0) * kSpS + 31) / 32);
+    const int w0 = (wv + blockIdx.x + blockIdx.y) & 3;  // the SIMDs take turns at the third fragment
+    for (int f = w0; f < nf; f += 4) {
       const int p = min(f * 32 + l31, kSpS * kSpS - 1);  // the position this lane feeds (rows past the end replay the last)
       const int sy = p / kSpS, sx = p - sy * kSpS;
-      const float* ab = &s_in[0][2 * sy][2 * sx];
+      const float* ab = &s_in[2 * sy][2 * sx];
       floatx16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = bv;
 #pragma unroll
-      for (int j = 0; j < 14; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[aoff[j]], bw[j], acc, 0, 0, 0);
-      // C layout: lane = channel l31, register r = position (r / 4) * 8 + 4 kh + r % 4 of the fragment.
-      // conv outputs outside the 184 x 184 map do not exist: -inf so that the (ceil-mode) windows ignore them
+      for (int j = 0; j < 14; ++j)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[kh ? sp_tap_off(2 * j + 1) : sp_tap_off(2 * j)], bw[j], acc, 0, 0, 0);
+      // C layout: lane = channel l31, register r = position (r / 4) * 8 + 4 kh + r % 4 of the fragment
       if (l31 < kSpC) {
+        float* st = &s_st[f * 32 + 4 * kh][l31];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int pp = f * 32 + (r >> 2) * 8 + 4 * kh + (r & 3);
-          if (pp < kSpS * kSpS) s_st[pp][l31] = s_ok[pp] ? fmaxf(acc[r], 0.f) : -INFINITY;
-        }
+        for (int r = 0; r < 16; ++r) st[((r >> 2) * 8 + (r & 3)) * kSpCP] = acc[r];
       }
     }
   }
   __syncthreads();
-  // window maxima: item = (pool output, 8-channel group)
+  // window maxima: item = (pool output, 8-channel group).  The maxima start from 0 - the ReLU; windows that hang over the
+  // conv map (ceil mode) skip the positions that do not exist (only tiles on the map's right / bottom edge can have any).
+  const bool edge = sy0 + kSpS > H1 || sx0 + kSpS > W1;
   for (int it = tid; it < kSpT * kSpT * 3; it += 256) {
     const int g = it % 3, q = it / 3;
     const int ty = q / kSpT, tx = q - ty * kSpT;
@@ -546,15 +587,23 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
     if (py >= H2 || px >= W2) continue;
     float m[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+    for (int j = 0; j < 8; ++j) m[j] = 0.f;
+    auto window = [&](auto masked) {
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+      for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const float* sp = &s_st[(2 * ty + dy) * kSpS + 2 * tx + dx][8 * g];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], sp[j]);
-      }
+        for (int dx = 0; dx < 3; ++dx) {
+          if (masked && !(sy0 + 2 * ty + dy < H1 && sx0 + 2 * tx + dx < W1)) continue;
+          const float* sp = &s_st[(2 * ty + dy) * kSpS + 2 * tx + dx][8 * g];
+          const float4 a = *reinterpret_cast<const float4*>(sp), b = *reinterpret_cast<const float4*>(sp + 4);
+          m[0] = fmaxf(m[0], a.x), m[1] = fmaxf(m[1], a.y), m[2] = fmaxf(m[2], a.z), m[3] = fmaxf(m[3], a.w);
+          m[4] = fmaxf(m[4], b.x), m[5] = fmaxf(m[5], b.y), m[6] = fmaxf(m[6], b.z), m[7] = fmaxf(m[7], b.w);
+        }
+    };
+    if (edge)
+      window(std::true_type{});
+    else
+      window(std::false_type{});
     if (OUT_BF16) {
       unsigned short* o = reinterpret_cast<unsigned short*>(out_v) + lay_off(lo, n, py, px) + 8 * g;
       uint4 u;
@@ -1163,12 +1212,17 @@ int rtpose_stem_pool_nchw(const float* x_nchw, const float* scale, const float* 
   const int H1 = (H - 1) / 2 + 1, W1 = (W - 1) / 2 + 1;              // conv 3x3 s2 p1
   const int H2 = (H1 - 3 + 1) / 2 + 1, W2 = (W1 - 3 + 1) / 2 + 1;    // max-pool 3/2, ceil mode
   const dim3 grid(ceil_div(W2, kSpT), ceil_div(H2, kSpT), N);
-  if (out_bf16)
-    hipLaunchKernelGGL(stem_pool_kernel<1>, grid, dim3(256), 0, as_stream(stream), x_nchw, scale, shift, w, bias, out,
-                       to_lay(lout), H, W, H1, W1, H2, W2);
-  else
-    hipLaunchKernelGGL(stem_pool_kernel<0>, grid, dim3(256), 0, as_stream(stream), x_nchw, scale, shift, w, bias, out,
-                       to_lay(lout), H, W, H1, W1, H2, W2);
+  // rows as aligned float4 when the image allows it (every row starts on a 16-byte boundary)
+  const bool vec = W % 4 == 0 && reinterpret_cast<uintptr_t>(x_nchw) % 16 == 0;
+#define RTPOSE_STEM_POOL(B, V)                                                                                         \
+  hipLaunchKernelGGL((stem_pool_kernel<B, V>), grid, dim3(256), 0, as_stream(stream), x_nchw, scale, shift, w, bias, \
+                     out, to_lay(lout), H, W, H1, W1, H2, W2)
+  if (out_bf16) {
+    if (vec) RTPOSE_STEM_POOL(1, 1); else RTPOSE_STEM_POOL(1, 0);
+  } else {
+    if (vec) RTPOSE_STEM_POOL(0, 1); else RTPOSE_STEM_POOL(0, 0);
+  }
+#undef RTPOSE_STEM_POOL
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }

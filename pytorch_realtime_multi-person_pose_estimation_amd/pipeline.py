@@ -28,6 +28,68 @@ def _raise_on_device_error(model, plan):
                                 "(shared / CU-masked device?); the maps of this batch are invalid" % word)
 
 
+class SideDecoder(object):
+    """The decoder's launches and the D2H of their records on a SECOND stream, behind an event, so that the next forward
+    starts at once on the compute stream (round 5).  The decoder's four launches are latency-bound chains on small grids
+    (134 us of them one wave per image): on the compute stream they are 0.9 % of an fp32 step and 2.4 % of a bf16 one in
+    which nothing else runs.  The next forward waits for the decoder's last read of the maps only where it first writes
+    their buffer (`guarded_forward` -> rtpose_net_set_output_guard).  Two slots (record block, pinned copy, events)."""
+
+    def __init__(self, config):
+        self.config = config
+        self.stream = None
+        self.slots = [None, None]
+        self.last = None            # slot of the decode enqueued last: the maps' reader the next forward has to respect
+
+    def guarded(self, plan, forward):
+        """Run `forward()` (which enqueues the plan's launches on the current stream) with the plan's output guard set
+        to the last decode's final read of the maps."""
+        guard = self.last["dec_done"].cuda_event if self.last is not None else None
+        check(lib.rtpose_net_set_output_guard(plan.handle, guard))
+        try:
+            return forward()
+        finally:
+            check(lib.rtpose_net_set_output_guard(plan.handle, None))
+
+    def decode(self, i, maps, n, device, max_peaks_per_part, max_humans, post=None):
+        """Enqueue decode + record D2H of slot i (0 / 1) behind everything queued on the current stream so far.
+        maps = (hbase, lheat, pbase, lpaf, h, w).  ``post(result_block)``, if given, runs on the side stream after the
+        decode and returns the device tensor whose copy wait() hands out (bench.py: the RCCL gather of the ranks' blocks)."""
+        import torch
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        hbase, lheat, pbase, lpaf, h, w = maps
+        slot = self.slots[i]
+        key = (n, device.index, max_peaks_per_part, max_humans)
+        if slot is None or slot["key"] != key:
+            cfg = dec.make_cfg(self.config, max_peaks_per_part, max_humans)
+            slot = {"key": key, "bufs": dec.DecodeBuffers(cfg, n, device), "maps": torch.cuda.Event(),
+                    "dec_done": torch.cuda.Event(), "done": torch.cuda.Event(), "host": None}
+            self.slots[i] = slot
+        bufs = slot["bufs"]
+        slot["maps"].record(torch.cuda.current_stream())
+        self.stream.wait_event(slot["maps"])
+        with torch.cuda.stream(self.stream):
+            dec.decode_enqueue(hbase, lheat, pbase, lpaf, n, h, w, bufs)
+            slot["dec_done"].record(self.stream)        # the decoder's last read of the maps
+            block = bufs.result.view(n, bufs.words)
+            if post is not None:
+                block = post(block)
+            if slot["host"] is None or slot["host"].shape != block.shape:
+                slot["host"] = torch.empty(block.shape, dtype=block.dtype).pin_memory()
+            slot["host"].copy_(block, non_blocking=True)
+            slot["done"].record(self.stream)
+        bufs.map_hw = (h, w)
+        self.last = slot
+        return bufs
+
+    def wait(self, i):
+        """-> (buffers, numpy int32 view of slot i's pinned record block; valid until the slot is used again)."""
+        slot = self.slots[i]
+        slot["done"].synchronize()
+        return slot["bufs"], slot["host"].numpy()
+
+
 class PoseEstimator(object):
     def __init__(self, model, config=None, max_peaks_per_part=32, max_humans=64):
         self.model = model
@@ -70,11 +132,7 @@ class PoseEstimator(object):
         bufs.plan = plan
         return bufs
 
-    # ---- decode(k) under forward(k + 1) -------------------------------------------------------------------------------
-    # The decoder's four launches are latency-bound chains on small grids (134 us of them one wave per image): on the
-    # compute stream they are 0.9 % of an fp32 step and 2.4 % of a bf16 one in which nothing else runs.  submit() puts
-    # them - and the D2H of the records - on a second stream behind an event, and the NEXT forward starts at once; it
-    # waits for the decoder's last read of the maps only where it first writes their buffer (rtpose_net_set_output_guard).
+    # ---- decode(k) under forward(k + 1): see SideDecoder ------------------------------------------------------------
     def submit(self, x, scene=None, scene_alpha=1e-3, post=None):
         """Enqueue forward (+ blend) on the current stream and decode + record D2H on the side stream; returns a ticket
         for collect().  At most two tickets may be outstanding (two record blocks ping-pong).  ``post(result_block)``,
@@ -84,20 +142,11 @@ class PoseEstimator(object):
         m = self.model
         with torch.cuda.device(x.device):
             if not hasattr(self, '_side'):
-                self._side = torch.cuda.Stream()
+                self._side = SideDecoder(self.config)
                 self._ticket = 0
-                self._slots = [None, None]
-            main = torch.cuda.current_stream()
             k = self._ticket
             self._ticket += 1
-            prev = self._slots[(k + 1) & 1]          # the previous submit: its decoder may still be reading the maps
-            plan = m.plan_for(x)
-            guard = prev["dec_done"].cuda_event if prev is not None else None
-            check(lib.rtpose_net_set_output_guard(plan.handle, guard))
-            try:
-                plan = m.forward_native(x, keep_intermediates=False)
-            finally:
-                check(lib.rtpose_net_set_output_guard(plan.handle, None))
+            plan = self._side.guarded(m.plan_for(x), lambda: m.forward_native(x, keep_intermediates=False))
             n = x.shape[0]
             pbase, lpaf, _, h, w = m.output_view(plan, 0)
             hbase, lheat, _, _, _ = m.output_view(plan, 1)
@@ -106,37 +155,15 @@ class PoseEstimator(object):
                 s = current_stream()
                 check(lib.rtpose_layout_axpby(hbase, C.byref(lheat), ptr(sh), 19, n, h, w, scene_alpha, 1.0, s))
                 check(lib.rtpose_layout_axpby(pbase, C.byref(lpaf), ptr(sp), 38, n, h, w, scene_alpha, 1.0, s))
-            slot = self._slots[k & 1]
-            key = (n, x.device.index, self.max_peaks_per_part, self.max_humans)
-            if slot is None or slot["key"] != key:
-                cfg = dec.make_cfg(self.config, self.max_peaks_per_part, self.max_humans)
-                slot = {"key": key, "bufs": dec.DecodeBuffers(cfg, n, x.device), "maps": torch.cuda.Event(),
-                        "dec_done": torch.cuda.Event(), "done": torch.cuda.Event(), "host": None}
-                self._slots[k & 1] = slot
-            bufs = slot["bufs"]
-            slot["maps"].record(main)
-            self._side.wait_event(slot["maps"])
-            with torch.cuda.stream(self._side):
-                dec.decode_enqueue(hbase, lheat, pbase, lpaf, n, h, w, bufs)
-                slot["dec_done"].record(self._side)        # the decoder's last read of the maps
-                block = bufs.result.view(n, bufs.words)
-                if post is not None:
-                    block = post(block)
-                if slot["host"] is None or slot["host"].shape != block.shape:
-                    slot["host"] = torch.empty(block.shape, dtype=block.dtype).pin_memory()
-                slot["host"].copy_(block, non_blocking=True)
-                slot["done"].record(self._side)
-            bufs.map_hw = (h, w)
+            bufs = self._side.decode(k & 1, (hbase, lheat, pbase, lpaf, h, w), n, x.device, self.max_peaks_per_part,
+                                     self.max_humans, post)
             bufs.plan = plan
-            slot["live"] = True
             return k
 
     def collect(self, ticket):
         """Wait for the records of submit()'s ticket -> (buffers, numpy int32 view of the pinned record block; valid
         until the ticket after next is submitted)."""
-        slot = self._slots[ticket & 1]
-        slot["done"].synchronize()
-        return slot["bufs"], slot["host"].numpy()
+        return self._side.wait(ticket & 1)
 
     def __call__(self, x, scene=None, scene_alpha=1e-3):
         """-> list of per-image dicts (decode.parse_image); grows table capacity on overflow."""
@@ -174,9 +201,11 @@ class StreamingPoseEstimator(object):
     and its H2D is queued while the previous batch is still in the network; the GPU then does
     resize + pad + normalise (rtpose_preprocess_u8) straight into the plan's input buffer, the
     forward and the decode; only the fixed-size result records come back.  Two pinned host / device
-    staging pairs ping-pong.  ONE stream (round 4): the 13 MB H2D of a 32-image batch takes 0.24 ms on the compute
-    stream - 1 % of an fp32 batch - while the same copy on a second stream took 8.9 ms (tools/exp/host_copy_probe.py,
-    profiles/r04_streaming_probe.txt).
+    staging pairs ping-pong.  The H2D rides on the COMPUTE stream (round 4): the 13 MB of a 32-image batch take 0.24 ms
+    there - 1 % of an fp32 batch - while the same copy on a second stream took 8.9 ms (tools/exp/host_copy_probe.py,
+    profiles/r04_streaming_probe.txt).  Round 5: the decoder and the D2H of the records run on a second stream
+    (SideDecoder) and batch k + 1 is enqueued BEFORE the host waits for batch k's records, so the compute stream goes
+    from one forward straight into the next.
     """
 
     def __init__(self, model, batch, h0, w0, preprocess='rtpose', config=None, max_peaks_per_part=32,
@@ -196,12 +225,12 @@ class StreamingPoseEstimator(object):
         self.dev = torch.device('cuda', torch.cuda.current_device())
         self.host = [torch.empty((batch, h0, w0, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
         self.devbuf = [torch.empty((batch, h0, w0, 3), dtype=torch.uint8, device=self.dev) for _ in range(2)]
-        self.done = torch.cuda.Event()      # recorded behind the D2H of a batch's records
-        self.err_word = torch.zeros(1, dtype=torch.int32).pin_memory()   # the plan's device error word, copied with them
+        # the plan's device error word, copied behind each batch's forward (one word per slot: two batches are in flight)
+        self.err_word = torch.zeros(2, dtype=torch.int32).pin_memory()
         self.max_peaks_per_part, self.max_humans = max_peaks_per_part, max_humans
         self.scene, self.scene_alpha = scene, scene_alpha
-        cfg = dec.make_cfg(self.config, max_peaks_per_part, max_humans)
-        self.bufs = dec.DecodeBuffers(cfg, batch, self.dev)
+        self.side = SideDecoder(self.config)
+        self.bufs = None                    # the decode buffers of the batch enqueued last (tests read .cfg)
         self._torch = torch
         self._pre = pre
 
@@ -221,9 +250,9 @@ class StreamingPoseEstimator(object):
         self.devbuf[slot].copy_(self.host[slot], non_blocking=True)
 
     def _enqueue(self, slot):
-        """Everything of one batch on the compute stream, asynchronously: wait for its upload, image prep, forward,
-        (scene blend,) decode, D2H of the records into the pinned block.  Returns what _finish needs."""
-        torch = self._torch
+        """Everything of the batch whose images sit in devbuf[slot], asynchronously: image prep and forward on the
+        compute stream (the forward guarded against the decoder still reading the previous maps), (scene blend,) the
+        device error word, then decode + D2H of the records on the side stream."""
         m = self.model
         plan = m.plan_for_shape(self.B, self.hn, self.wn, self.dev)
         s = current_stream()
@@ -233,63 +262,59 @@ class StreamingPoseEstimator(object):
                                        [(self.h0, self.w0)] * self.B, int(self.config.DATASET.IMAGE_SIZE),
                                        self.mode, s)                      # ONE launch for the whole batch
         check(lib.rtpose_net_set_keep_intermediates(plan.handle, 0))
-        check(lib.rtpose_net_forward_prepared(plan.handle, s), "rtpose_net_forward_prepared")
+        self.side.guarded(plan, lambda: check(lib.rtpose_net_forward_prepared(plan.handle, s),
+                                              "rtpose_net_forward_prepared"))
         pbase, lpaf, _, h, w = m.output_view(plan, 0)
         hbase, lheat, _, _, _ = m.output_view(plan, 1)
         if self.scene is not None:      # bench / tests only, see PoseEstimator.enqueue
             sh, sp = self.scene
             check(lib.rtpose_layout_axpby(hbase, C.byref(lheat), ptr(sh), 19, self.B, h, w, self.scene_alpha, 1.0, s))
             check(lib.rtpose_layout_axpby(pbase, C.byref(lpaf), ptr(sp), 38, self.B, h, w, self.scene_alpha, 1.0, s))
-        dec.decode_enqueue(hbase, lheat, pbase, lpaf, self.B, h, w, self.bufs)
-        self.bufs.host.copy_(self.bufs.result, non_blocking=True)
-        # the device error word rides behind the records: _finish reads it after `done`, and never calls a
-        # stream-synchronising API while the next batch's H2D is queued (round-4 advisor finding)
+        # the device error word rides in front of the decode: _finish reads it after the records' event, and never
+        # calls a stream-synchronising API while the next batch is queued (round-4 advisor finding)
         if getattr(plan, 'dtype', 0) == _capi.DTYPE_F32 and hasattr(m, 'device_status_async'):
-            m.device_status_async(plan, self.err_word)
-        self.done.record(torch.cuda.current_stream())
-        return plan, (hbase, lheat, pbase, lpaf, h, w)
+            m.device_status_async(plan, self.err_word[slot:slot + 1])
+        self.bufs = self.side.decode(slot, (hbase, lheat, pbase, lpaf, h, w), self.B, self.dev,
+                                     self.max_peaks_per_part, self.max_humans)
+        return slot
 
-    def _finish(self, state):
-        """Wait for the batch enqueued by _enqueue and return its records (a copy: the pinned block is reused)."""
-        torch = self._torch
-        plan, (hbase, lheat, pbase, lpaf, h, w) = state
+    def _finish(self, slot):
+        """Wait for the batch enqueued into `slot` and return its records (a copy: the pinned block is reused)."""
         while True:
-            self.done.synchronize()     # the records of THIS batch (the next batch's H2D may still be queued)
-            recs = self.bufs.host.numpy().reshape(self.B, self.bufs.words).copy()
-            word = int(self.err_word[0])
+            bufs, host = self.side.wait(slot)    # the records of THIS batch (the next batch may already be running)
+            recs = host.reshape(self.B, bufs.words).copy()
+            word = int(self.err_word[slot])
             if word:
-                self.err_word[0] = 0
+                self.err_word[slot] = 0
                 raise _capi.RtposeError("device error word %d: a split-tile hand-over of a persistent 7x7 launch timed "
                                         "out (shared / CU-masked device?); the maps of this batch are invalid" % word)
             flags = int(np.bitwise_or.reduce(recs[:, dec.RES_HEADER + 2]))
             if not flags:
                 return recs
-            # a crowded image overflowed a device table: grow it and decode the SAME maps again (they are
-            # still in the plan's workspace; the next batch has only been uploaded, not run) - records
-            # are never handed out truncated
+            # a crowded image overflowed a device table: grow it and run the SAME batch again - its images are still in
+            # devbuf[slot] (the next upload into this slot comes after this call), its maps are not (the next batch's
+            # forward has been enqueued behind it) - records are never handed out truncated.  Capacities only grow, so
+            # this happens a handful of times in the life of a stream.
             if flags & dec.OVERFLOW_PEAKS and self.max_peaks_per_part < dec.MAX_PEAKS_LIMIT:
                 self.max_peaks_per_part = min(2 * self.max_peaks_per_part, dec.MAX_PEAKS_LIMIT)
             elif flags & dec.OVERFLOW_HUMANS and self.max_humans < dec.MAX_HUMANS_LIMIT:
                 self.max_humans = min(2 * self.max_humans, dec.MAX_HUMANS_LIMIT)
             else:
                 raise _capi.RtposeError("decode tables overflowed at maximum capacity (flags=%d)" % flags)
-            self.bufs = dec.DecodeBuffers(dec.make_cfg(self.config, self.max_peaks_per_part, self.max_humans),
-                                          self.B, self.dev)
-            dec.decode_enqueue(hbase, lheat, pbase, lpaf, self.B, h, w, self.bufs)
-            self.bufs.host.copy_(self.bufs.result, non_blocking=True)
-            self.done.record(torch.cuda.current_stream())
+            self._enqueue(slot)
 
     def run(self, batches):
         """batches: iterable of uint8 arrays [B, h0, w0, 3] (BGR).  Yields one int32 record block
-        [B, words] per batch (decode.parse_image(rec) / humans_from_record turn them into Humans).  The decode
+        [B, words] per batch, in order (decode.parse_image(rec) / humans_from_record turn them into Humans).  The decode
         tables grow on overflow, so blocks of one run may differ in width; every record carries the capacities
         it was written with in its header (words 3, 4) and parse_image reads them from there - a consumer that
         collects blocks first, or parses a step late, never needs this object's cfg of the moment.
 
-        Order per batch k (round 4): enqueue k's kernels and the D2H of its records (asynchronous), THEN copy batch
-        k + 1 from the caller's (pageable) array into pinned memory and queue its H2D - under k's kernels - and only
-        then wait for k's records (an event behind their D2H).  Between two batches the GPU waits for the host's
-        ~0.5 ms of launch calls and the 0.24 ms H2D."""
+        Order (round 5): batch k's kernels are enqueued; batch k + 1 is taken from the iterator, copied from the
+        caller's (pageable) array into pinned memory, its H2D and its kernels queued behind k's; only then does the host
+        wait for k's records (an event behind their D2H on the side stream) and yield them.  The compute stream never
+        waits for the host, and the decoder of k runs beside the forward of k + 1; the price is that the iterator is
+        read one batch ahead."""
         it = iter(batches)
         try:
             cur = next(it)
@@ -297,15 +322,16 @@ class StreamingPoseEstimator(object):
             return
         slot = 0
         self._upload(slot, cur)
+        self._enqueue(slot)
         while True:
-            state = self._enqueue(slot)
             try:
                 nxt = next(it)
             except StopIteration:
                 nxt = None
             if nxt is not None:
-                self._upload(slot ^ 1, nxt)     # host copy + H2D of the next batch under this batch's kernels
-            yield self._finish(state)
+                self._upload(slot ^ 1, nxt)     # host copy + H2D + kernels of the next batch behind this batch's
+                self._enqueue(slot ^ 1)
+            yield self._finish(slot)
             if nxt is None:
                 return
             slot ^= 1

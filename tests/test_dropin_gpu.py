@@ -296,9 +296,12 @@ def test_multiscale_batch_matches_per_image(compat, cuda):
     assert len(recs) == 3 and all(r["flags"] == 0 or r["n_peaks"] > 0 for r in recs)
 
 
-def test_streaming_estimator_matches_direct_path(compat, cuda):
-    """StreamingPoseEstimator (uint8 upload on a copy stream, GPU image prep, forward, decode) returns
-    the records the direct path computes for the same images, batch after batch."""
+@pytest.mark.parametrize("caps", [(512, 512), (4, 2)])
+def test_streaming_estimator_matches_direct_path(compat, cuda, caps):
+    """StreamingPoseEstimator (uint8 upload, GPU image prep, forward on the compute stream; decode + record D2H on a second
+    stream beside the next batch's forward) returns the records the direct path computes for the same images, batch
+    after batch.  caps (4, 2): the device tables overflow on the first batches - each is run again with grown tables
+    while its successor is already in flight, and no record comes back truncated."""
     from lib.network.rtpose_vgg import get_model
     from oracle import net_oracle
     pipeline = importlib.import_module(PKG_NAME + ".pipeline")
@@ -310,9 +313,11 @@ def test_streaming_estimator_matches_direct_path(compat, cuda):
     rng = np.random.default_rng(4)
     B, h0, w0 = 3, 120, 150
     batches = [np.clip(rng.normal(128, 6, (B, h0, w0, 3)), 0, 255).astype(np.uint8) for _ in range(4)]
-    est = pipeline.StreamingPoseEstimator(model, B, h0, w0, max_peaks_per_part=512, max_humans=512)
+    est = pipeline.StreamingPoseEstimator(model, B, h0, w0, max_peaks_per_part=caps[0], max_humans=caps[1])
     got = list(est.run(batches))
     assert len(got) == 4
+    if caps[0] < 512:
+        assert est.max_peaks_per_part > caps[0]        # the tables did overflow and grow
     for rec_block, imgs in zip(got, batches):
         for b in range(B):
             paf, heat, _ = pre.get_outputs_gpu(imgs[b], model, 'rtpose')

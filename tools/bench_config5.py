@@ -74,36 +74,50 @@ def main():
         heat, paf, _ = synth.make_batch(B, HW, HW, seed=2000 + s)
         pool.append((torch.from_numpy(heat).to(dev), torch.from_numpy(paf).to(dev)))
     plan = model.plan_for_shape(B, HW, HW, dev)
-    cfg = dec.make_cfg(None, 64, 64)
-    bufs = dec.DecodeBuffers(cfg, B, dev)
+    pipeline = importlib.import_module(PKG + ".pipeline")
+    side = pipeline.SideDecoder(None)       # decode + record D2H (+ gather) of batch k beside the forward of batch k + 1
     stream = capi.current_stream()
+    post = (lambda blk: par.gather_records(blk, world)) if world > 1 else None
 
-    def run_batch(i0, n_valid):
+    def enqueue_batch(i0, n_valid, slot):
         idx = [index[min(i0 + k, len(index) - 1)] for k in range(B)] if n_valid else [index[0]] * B
         imgs = synth_images(idx, HW, dev)
         pre.preprocess_into_plan(plan, [imgs.data_ptr() + k * HW * HW * 3 for k in range(B)], [(HW, HW)] * B, HW, 0, stream)
         capi.check(lib.rtpose_net_set_keep_intermediates(plan.handle, 0))
-        capi.check(lib.rtpose_net_forward_prepared(plan.handle, stream), "rtpose_net_forward_prepared")
+        side.guarded(plan, lambda: capi.check(lib.rtpose_net_forward_prepared(plan.handle, stream),
+                                              "rtpose_net_forward_prepared"))
         pbase, lpaf, _, h, w = model.output_view(plan, 0)
         hbase, lheat, _, _, _ = model.output_view(plan, 1)
         sh, sp = pool[(i0 // B) % len(pool)]
         capi.check(lib.rtpose_layout_axpby(hbase, C.byref(lheat), capi.ptr(sh), 19, B, h, w, 1e-3, 1.0, stream))
         capi.check(lib.rtpose_layout_axpby(pbase, C.byref(lpaf), capi.ptr(sp), 38, B, h, w, 1e-3, 1.0, stream))
-        dec.decode_enqueue(hbase, lheat, pbase, lpaf, B, h, w, bufs)
-        rec = bufs.result.view(B, bufs.words)
-        host = par.gather_records(rec, world).cpu() if world > 1 else dec.fetch(bufs)
-        return np.asarray(host).reshape(-1, bufs.words), imgs
+        side.decode(slot, (hbase, lheat, pbase, lpaf, h, w), B, dev, 64, 64, post)
 
-    run_batch(0, B)                     # plan / weights / RCCL warm-up (untimed)
+    def records(slot):
+        bufs, host = side.wait(slot)
+        return host.reshape(-1, bufs.words)
+
+    enqueue_batch(0, B, 0)              # plan / weights / RCCL warm-up (untimed)
+    records(0)
     humans = flags = 0
-    torch.cuda.synchronize()
-    par.barrier(dev)
-    t0 = time.perf_counter()
-    for i0, n_valid in sched:
-        host, _ = run_batch(i0, n_valid)
+
+    def count(host):
+        nonlocal humans, flags
         if rank == 0:
             humans += int(host[:, dec.RES_HEADER + 1].sum())
             flags |= int(np.bitwise_or.reduce(host[:, dec.RES_HEADER + 2]))
+
+    torch.cuda.synchronize()
+    par.barrier(dev)
+    t0 = time.perf_counter()
+    prev = None
+    for j, (i0, n_valid) in enumerate(sched):      # the host reads batch j - 1's records after it has queued batch j
+        enqueue_batch(i0, n_valid, j & 1)
+        if prev is not None:
+            count(records(prev))
+        prev = j & 1
+    if prev is not None:
+        count(records(prev))
     torch.cuda.synchronize()
     par.barrier(dev)
     elapsed = par.max_over_ranks(time.perf_counter() - t0, dev)
@@ -116,7 +130,9 @@ def main():
                           "index": "%d distinct synthetic uint8 images (device hash of (entry, pixel)), contiguous "
                                    "shards; image prep by one rtpose_preprocess_u8_batch launch per batch" % args.images,
                           "note": "the last batch of a shard is padded to the batch size (the padded images are "
-                                  "computed and gathered, not counted)", "humans_seen_rank0_gather": humans,
+                                  "computed and gathered, not counted)",
+                          "pipeline": "decoder + record D2H (+ gather) of batch k on a second stream under the forward "
+                                      "of batch k + 1", "humans_seen_rank0_gather": humans,
                           "overflow_flags": flags}))
     if world > 1:
         torch.distributed.destroy_process_group()
