@@ -146,6 +146,17 @@ def main(rounds=10, dtypes=("bf16", "fp32")):
                                         [(int(x[0]), int(x[1]), float(x[2:3].view(np.float32)[0])) for x in fb]))
                         print("%s round %d step %d (batch %d) image %d: %s" % (dt, rd, k, r, b, "; ".join(what)))
         print("%s: %d differing records in %d rounds x %d steps x %d images; %d map copies differ" % (dt, bad, rounds, len(order), B, maps_bad))
+        if hasattr(pkg._capi.lib, "rtpose_exp_decode_probe"):   # probe build (tools/r5_sessions/session_c.sh): score-matrix readback
+            buf = (C.c_uint * (4 + 64 + 3 * 256))()
+            rc = pkg._capi.lib.rtpose_exp_decode_probe(buf, len(buf))
+            w = np.frombuffer(buf, dtype=np.uint32)
+            print("%s: probe rc %d: %d score-matrix readbacks differ from what the lane wrote; lanes %s" % (
+                dt, rc, int(w[0]), {i: int(w[4 + i]) for i in range(64) if w[4 + i]}))
+            for k in range(min(int(w[1]), 12)):
+                t = int(w[68 + 3 * k])
+                print("   thread %d of %d pairs: read %.9g, wrote %.9g" % (
+                    t & 0xffff, t >> 16, float(w[68 + 3 * k + 1:68 + 3 * k + 2].view(np.float32)[0]),
+                    float(w[68 + 3 * k + 2:68 + 3 * k + 3].view(np.float32)[0])))
 
 
 if __name__ == "__main__":
