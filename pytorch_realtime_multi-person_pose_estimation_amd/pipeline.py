@@ -32,8 +32,10 @@ class SideDecoder(object):
     """The decoder's launches and the D2H of their records on a SECOND stream, behind an event, so that the next forward
     starts at once on the compute stream (round 5).  The decoder's four launches are latency-bound chains on small grids
     (134 us of them one wave per image): on the compute stream they are 0.9 % of an fp32 step and 2.4 % of a bf16 one in
-    which nothing else runs.  The next forward waits for the decoder's last read of the maps only where it first writes
-    their buffer (`guarded_forward` -> rtpose_net_set_output_guard).  Two slots (record block, pinned copy, events)."""
+    which nothing else runs.  The next forward waits for the decoder's last read of the maps (`guarded` ->
+    rtpose_net_set_output_guard): an fp32 plan only where it first writes their buffer, a bf16 / bf16x3 plan in front of
+    its whole launch list (the decoder beside the bf16 kernels was not reliable: DESIGN.md 3.3).  Two slots (record block,
+    pinned copy, events)."""
 
     def __init__(self, config):
         self.config = config

@@ -271,7 +271,8 @@ def test_seven_by_seven_launches_without_split_tiles_and_under_a_cu_mask(tmp_pat
 def test_decoder_of_one_batch_under_the_forward_of_the_next(cuda):
     """PoseEstimator.submit / collect: the decoder and the record D2H of batch k run on a second stream while the forward of
     batch k + 1 is already on the compute stream; that forward waits for the decoder's last read of the maps only where
-    it first writes their buffer (rtpose_net_set_output_guard).  Three different batches through one 16-image plan,
+    it first writes their buffer (rtpose_net_set_output_guard; fp32 plans - a bf16 plan waits in front of its whole launch
+    list since round 5, see the soak test below).  Three different batches through one 16-image plan,
     interleaved and repeated, two tickets in flight: every collected record block SAYS what the serial path
     (enqueue + fetch, one stream) says for the same batch - peaks, people, float scores, bit for bit."""
     import importlib
