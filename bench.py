@@ -482,8 +482,12 @@ def main():
                        "global_batch": BATCH * world, "image": [SIZE, SIZE],
                        "weights": "seeded He init (no checkpoint offline)",
                        "decoder_input": "synthetic scene + 1e-3 * net output (blend kernel timed)",
-                       "pipeline": ("decoder + record D2H of step k on a second stream under the forward of step k + 1"
-                                    if args.decode_overlap else "one stream, step by step"),
+                       "pipeline": ("one stream, step by step" if not args.decode_overlap else
+                                    "decoder + record D2H of step k on a second stream under the forward of step k + 1"
+                                    if args.dtype == "fp32" and os.environ.get("RTPOSE_GUARD_WHOLE_FORWARD") != "1" else
+                                    "decoder + record D2H of step k on a second stream; the forward of step k + 1 is queued "
+                                    "at once but starts when that decoder has read the maps (bf16 plans / "
+                                    "RTPOSE_GUARD_WHOLE_FORWARD=1: DESIGN.md 3.3)"),
                        "humans_per_batch": humans_per_batch, "peaks_per_batch": peaks_per_batch,
                        "conv_numerics": numerics,
                        "parallelism": ("image-sharded, all_gather of result records only" if world > 1 else
