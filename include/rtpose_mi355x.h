@@ -322,7 +322,7 @@ int rtpose_pw_fused_bf16(const rtpose_pw_desc* d, int out_f32, int N, int H, int
  * lib/network/rtpose_shufflenetV2.py:31-39 - as ONE launch in the bf16 plan (csrc/unit_bf16.hip): the conv.0 output only
  * exists in LDS (8 x 8 output tiles, conv.0 recomputed on the 10 x 10 halo; halo pixels outside the image are zero, as
  * the depthwise conv's padding wants).  d0 = conv.0: `in` / `lin` the stage buffer (bf16, ELEMENT counts, layout gap >= 1)
- * as a contiguous slice or a gather of cin / 8 planes (in_planes), cin a multiple of 16 up to 272, w_packed
+ * as a contiguous slice or a gather of cin / 8 planes (in_planes), cin a multiple of 16 up to 256, w_packed
  * [cin / 8][coutp][8 bf16] with coutp = 128 or 256 and zero columns past the real ones; d0->dw_w / dw_b = conv.1's fp32
  * taps [9][Kt] and bias [Kt], Kt = d2->cin (a multiple of 16, <= d0->coutp).  d2 = conv.2: w_packed [Kt / 8][coutp][8 bf16],
  * coutp = 128 or 256, `cout` existing columns (a multiple of 8), out_cmap[column] = absolute channel of the output pixel
@@ -555,7 +555,9 @@ int rtpose_net_device_status(rtpose_net* net, int* error_word, void* stream);
  * a round resident together, i.e. an exclusive, unmasked MI355X.  enable = 0 makes every 7x7 launch of the plan run one
  * block per tile instead: the same results, bit for bit (the sums run in the order of an unsplit tile either way), a
  * few per cent slower at batch 32 - for CU-masked or shared devices.  Default 1, or 0 when RTPOSE_W7_PERSIST=0 is in the
- * environment; rtpose_net_device_status switches it off by itself when it reads a timed-out hand-over. */
+ * environment; rtpose_net_device_status switches it off by itself when it reads a timed-out hand-over (captured launch
+ * lists are dropped with it); a caller of rtpose_net_device_status_async that later finds bit 0 in its host word calls
+ * rtpose_net_set_persistent7(net, 0) itself (pipeline.py does). */
 int rtpose_net_set_persistent7(rtpose_net* net, int enable);
 /* A consumer that reads the stage-6 maps where the net wrote them (rtpose_net_output_view) on ANOTHER stream - the pose
  * decoder of batch k under the forward of batch k + 1 - hands in the HIP event it records behind its last read: every

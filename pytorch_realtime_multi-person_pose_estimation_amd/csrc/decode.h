@@ -46,8 +46,11 @@ inline size_t decode_ws_rows_bytes(const rtpose_decode_cfg* c, int N) {
   const int r = decode_row_cap(c);
   return r > kLdsRows ? round_up((size_t)N * r * 21 * sizeof(float), 256) : 0;
 }
+// (a limb's candidate list is at most p * p long and stays in LDS up to kTieLdsCands entries: at the default capacities -
+//  p = 32 ... 64 - nothing is reserved; at p = 1024 this was 5.1 GB for 32 images whatever the maps held)
 inline size_t decode_ws_tie_bytes(const rtpose_decode_cfg* c, int N) {
   const size_t p = (size_t)c->max_peaks_per_part;
+  if (p * p <= (size_t)kTieLdsCands) return 0;
   return round_up((size_t)N * RTPOSE_NUM_LIMB * p * p * sizeof(unsigned long long), 256);
 }
 inline size_t decode_workspace_bytes(const rtpose_decode_cfg* c, int N) {

@@ -562,7 +562,7 @@ constexpr int kSortStack = 3 * 64;  // pending ranges <= the depth limit 2 floor
 // serial flow, never next to the fp32 plan's kernels (tools/exp/overlap_flake.py, profiles/r05_decoder_next_to_mfma.txt;
 // DESIGN.md 3.3).  The half-rate double-precision chain v_cvt_f64 -> v_add_f64 -> v_cvt_i32_f64 -> v_mul_f64 ->
 // v_floor_f64 was the one multi-pass VALU sequence in the loop.
-template <bool SCORES_IN_LDS, bool UP_POW2>
+template <bool SCORES_IN_LDS, bool UP_POW2, bool A32>
 __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, int w, double inv_up, int up_shift,
                                                           int h1, int pcap,
                                                           const int32_t* __restrict__ result,
@@ -597,6 +597,12 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
   }
 
   const int npairs = nA * nB;
+  // A32: the image's two PAF channel planes as wave-uniform bases (SGPR pairs) + ONE 32-bit byte offset per sample
+  // (global_load_dword v, v_off, s[base:base+1]); the host picks it when every offset of an image fits 31 bits
+  const char* const img_x =
+      reinterpret_cast<const char*>(paf.base + ((size_t)paf.lead + (size_t)n * paf.hs * paf.ws) * paf.cstride + paf.choff + chx);
+  const char* const img_y = img_x + (ptrdiff_t)(chy - chx) * (ptrdiff_t)sizeof(float);
+  const unsigned pix_bytes = (unsigned)paf.cstride * (unsigned)sizeof(float);
   // the score matrix lives in LDS unless the tables were grown past what LDS holds
   // (junk maps with hundreds of peaks per part): then in the global workspace
   float* const score_g = score_ws + ((size_t)n * RTPOSE_NUM_LIMB + pair_id) * pcap * pcap;
@@ -638,8 +644,18 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
         }
         sx = min(max(sx, 0), w - 1);
         sy = min(max(sy, 0), h - 1);
-        const float px = map_at(paf, n, sy, sx, chx);
-        const float py = map_at(paf, n, sy, sx, chy);
+        float px, py;
+        if constexpr (A32) {
+          // two full-rate 24-bit multiplies, spelled out: the compiler turns __umul24 into v_mad_u64_u32 + v_mul_lo_u32
+          unsigned pix, boff;
+          asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pix) : "v"(sy), "s"(paf.ws), "v"(sx));
+          asm("v_mul_u32_u24 %0, %1, %2" : "=v"(boff) : "s"(pix_bytes), "v"(pix));
+          px = *reinterpret_cast<const float*>(img_x + boff);
+          py = *reinterpret_cast<const float*>(img_y + boff);
+        } else {
+          px = map_at(paf, n, sy, sx, chx);
+          py = map_at(paf, n, sy, sx, chy);
+        }
         const float s = vx * px + vy * py;
         scores = scores + s;
         if (s > 0.05f) ++crit1;
@@ -1023,10 +1039,14 @@ int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int 
   static PerDeviceOnce attr_set;  // zero-initialised; the attribute is per device
   const int dev = current_device();
   if (!attr_set.is_set(dev)) {
-    const void* limb_kernels[4] = {reinterpret_cast<const void*>(limb_assign_kernel<true, true>),
-                                   reinterpret_cast<const void*>(limb_assign_kernel<true, false>),
-                                   reinterpret_cast<const void*>(limb_assign_kernel<false, true>),
-                                   reinterpret_cast<const void*>(limb_assign_kernel<false, false>)};
+    const void* limb_kernels[8] = {reinterpret_cast<const void*>(limb_assign_kernel<true, true, true>),
+                                   reinterpret_cast<const void*>(limb_assign_kernel<true, false, true>),
+                                   reinterpret_cast<const void*>(limb_assign_kernel<false, true, true>),
+                                   reinterpret_cast<const void*>(limb_assign_kernel<false, false, true>),
+                                   reinterpret_cast<const void*>(limb_assign_kernel<true, true, false>),
+                                   reinterpret_cast<const void*>(limb_assign_kernel<true, false, false>),
+                                   reinterpret_cast<const void*>(limb_assign_kernel<false, true, false>),
+                                   reinterpret_cast<const void*>(limb_assign_kernel<false, false, false>)};
     for (const void* k : limb_kernels)
       RTPOSE_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_kernel),
@@ -1038,14 +1058,29 @@ int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int 
   for (int k = 0; k < 8; ++k)
     if (up == (1 << k)) up_shift = k;
   const bool in_lds = pcap * pcap <= kLdsPairs;
+  // 32-bit per-sample offsets when an image's maps span less than 2^31 bytes and the pixel index fits the 24-bit multiplier
+  bool a32 = (long long)lpaf->hs * lpaf->ws < (1ll << 24) && (long long)lpaf->cstride * (long long)sizeof(float) < (1 << 24) &&
+             (long long)lpaf->hs * lpaf->ws * lpaf->cstride * (long long)sizeof(float) < (1ll << 31);
+#ifdef RTPOSE_DEV_BUILD
   {
-#define RTPOSE_LIMB(L, P)                                                                                              \
-  hipLaunchKernelGGL((limb_assign_kernel<L, P>), dim3(RTPOSE_NUM_LIMB, N), dim3(256), lds, s, to_view(paf, lpaf), h, w, \
-                     inv_up, up_shift, h1, pcap, res, words, conn, conn_words, score_ws, tie_ws)
+    static const char* e = getenv("RTPOSE_LIMB_A32");  // developer A/B of the two addressing forms (tools/exp/overlap_flake.py)
+    if (e && e[0] == '0') a32 = false;
+  }
+#endif
+  {
+#define RTPOSE_LIMB_A(L, P, A)                                                                                         \
+  hipLaunchKernelGGL((limb_assign_kernel<L, P, A>), dim3(RTPOSE_NUM_LIMB, N), dim3(256), lds, s, to_view(paf, lpaf), h, \
+                     w, inv_up, up_shift, h1, pcap, res, words, conn, conn_words, score_ws, tie_ws)
+#define RTPOSE_LIMB(L, P)              \
+  do {                                 \
+    if (a32) RTPOSE_LIMB_A(L, P, true); \
+    else RTPOSE_LIMB_A(L, P, false);   \
+  } while (0)
     if (in_lds && up_shift >= 0) RTPOSE_LIMB(true, true);
     else if (in_lds) RTPOSE_LIMB(true, false);
     else if (up_shift >= 0) RTPOSE_LIMB(false, true);
     else RTPOSE_LIMB(false, false);
+#undef RTPOSE_LIMB_A
 #undef RTPOSE_LIMB
   }
   const int row_cap = decode_row_cap(cfg);

@@ -863,30 +863,40 @@ int rtpose_net_device_status(rtpose_net* net, int* error_word, void* stream) {
   // a hand-over wait ran out: this device does not dispatch the grid the way the split tiles assume (a CU mask, a
   // co-tenant that starves it).  The maps of that forward are invalid - the caller is told - and the plan stops
   // splitting tiles: every later forward runs one block per tile (same results, bit for bit, a few per cent slower).
-  if (*error_word & 1) net->persist7 = 0;
+  if (*error_word & 1) return rtpose_net_set_persistent7(net, 0);  // (also drops captured launch lists: they hold the split-tile grids)
   return 0;
 }
 
 int rtpose_net_set_output_guard(rtpose_net* net, void* hip_event) {
   if (!net) return fail(RTPOSE_E_INVAL, "net_set_output_guard: NULL net");
   if (net->guard_op < 0) {
-    // fp32 plans: the first launch of the list that writes the buffer rtpose_net_output_view hands out (CATa: the trunk's
-    // ~8 ms run next to the reader).  bf16 / bf16x3 plans: the FRONT of the list - the reader never runs next to their
-    // kernels.  The buffer itself is only written by the very last launch there, but a decoder running beside the bf16
-    // MFMA kernels returned, in ~1 % of the batches, one limb score computed from a sample taken one position off - with
-    // maps and peaks bit-identical before and after, only in lanes 41..63 of the scoring wave, never beside the fp32
-    // plan's kernels (0 of 1840 batches) and never alone (profiles/r05_decoder_next_to_mfma.txt).  The
-    // cause was not found; until it is, results come first.  RTPOSE_GUARD_WHOLE_FORWARD=1 asks for the same for fp32.
+    // Where a forward waits for the reader of its previous maps (the decoder of the batch before on a second stream,
+    // pipeline.SideDecoder).  Default, every arithmetic: in front of the FIRST launch that writes the buffer
+    // rtpose_net_output_view hands out - fp32: CATa, first written by conv4_4_CPM (its out1 channels), so the reader runs beside
+    // the trunk's ~8 ms; bf16 / bf16x3: the stage-6 record, written by the last launch only.  RTPOSE_GUARD_WHOLE_FORWARD=1 (or
+    // RTPOSE_GUARD_FINE=0): in FRONT of the launch list - the reader never runs beside this plan's kernels (costs 0.9 % of an
+    // fp32 step, 1.1 % of a bf16 one).  History: in round 5 a decoder beside the bf16 plan's kernels returned a
+    // limb score one sample off in ~1 % of the batches and bf16 plans waited in front; round 6 traced it to the packed-fp32
+    // VALU instructions clang's SLP vectoriser had put into limb_assign_kernel's sample loop (wrong values in lanes 48..63
+    // when the wave shares a CU with those kernels), the decoder is built without them (csrc/Makefile) and gave 0 differing
+    // records in 240,000 decodes beside the bf16 forward on the box where the old build gave 342 in 48,000.
+    const int target = net->bf16 ? net->save_buf[5] : net->cat_buf[0];
+    net->guard_op = 0;
+    for (size_t i = 0, found = 0; i < net->ops.size() && !found; ++i)
+      for (int g = 0; g < 2; ++g)
+        if (net->ops[i].out_buf[g] == target) {
+          net->guard_op = (int)i;
+          found = 1;
+        }
     const char* e = getenv("RTPOSE_GUARD_WHOLE_FORWARD");
-    if (net->bf16 || (e && e[0] == '1')) {
-      net->guard_op = 0;
-    } else {
-      const int target = net->cat_buf[0];
-      for (size_t i = 0; i < net->ops.size() && net->guard_op < 0; ++i)
-        for (int g = 0; g < 2; ++g)
-          if (net->ops[i].out_buf[g] == target) net->guard_op = (int)i;
-      if (net->guard_op < 0) net->guard_op = 0;
+    const char* f = getenv("RTPOSE_GUARD_FINE");
+    if ((e && e[0] == '1') || (f && f[0] == '0')) net->guard_op = 0;
+#ifdef RTPOSE_DEV_BUILD
+    if (const char* o = getenv("RTPOSE_GUARD_OP")) {  // experiments: the wait in front of launch <n> (negative: from the end)
+      const int n = atoi(o), nops = (int)net->ops.size();
+      net->guard_op = n < 0 ? (nops + n > 0 ? nops + n : 0) : (n < nops ? n : nops - 1);
     }
+#endif
   }
   net->out_guard = static_cast<hipEvent_t>(hip_event);
   return 0;
@@ -1114,7 +1124,18 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
   for (size_t i = first; i < last; ++i) {
     const Op& o = net->ops[i];
     if (prof) RTPOSE_HIP_CHECK(hipEventRecord(net->ev[i], s));
-    if (net->out_guard && (int)i == net->guard_op) RTPOSE_HIP_CHECK(hipStreamWaitEvent(s, net->out_guard, 0));
+    if (net->out_guard && (int)i == net->guard_op) {
+      RTPOSE_HIP_CHECK(hipStreamWaitEvent(s, net->out_guard, 0));
+#ifdef RTPOSE_DEV_BUILD
+      // experiment: behind the reader's last read, in front of the launch that rewrites them, the bf16
+      // plan's maps become NaNs - a reader that returns a NaN afterwards was served a stale copy of the same address
+      static const char* poison = getenv("RTPOSE_EXP_POISON");
+      if (poison && poison[0] == '1' && net->bf16) {
+        const Buf& b = net->bufs[net->save_buf[5]];
+        RTPOSE_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(net->ws + b.off_floats), 0x7fc00000, b.floats, s));
+      }
+#endif
+    }
     int rc = 0;
     switch (o.kind) {
       case OP_INPUT: {

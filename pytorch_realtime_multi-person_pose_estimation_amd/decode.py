@@ -101,6 +101,28 @@ def parse_image(rec, cfg=None):
             "n_peaks": int(rec[RES_HEADER])}
 
 
+def result_mask(block):
+    """Boolean mask [N, words] of the words of a record block that carry results - header, part counts, the peaks of every
+    part up to its count, the part assignments and scores of the humans up to the human count.  Words behind the counts are
+    scratch (left-overs of earlier batches): two blocks say the same iff they agree on the mask of either
+    (``np.array_equal(a[m], b[m])`` with ``m = result_mask(b)``; a differing count differs inside the mask)."""
+    block = np.asarray(block)
+    pcap, hcap = int(block[0, RES_HEADER + 3]), int(block[0, RES_HEADER + 4])
+    mask = np.zeros(block.shape, dtype=bool)
+    mask[:, RES_HEADER:RES_HEADER + 5] = True
+    mask[:, RES_PART_COUNT:RES_PART_COUNT + NUM_PART] = True
+    hoff = RES_PEAKS + 4 * NUM_PART * pcap
+    for b in range(block.shape[0]):
+        for p in range(NUM_PART):
+            c = min(int(block[b, RES_PART_COUNT + p]), pcap)
+            o = RES_PEAKS + 4 * p * pcap
+            mask[b, o:o + 4 * c] = True
+        nh = min(int(block[b, RES_HEADER + 1]), hcap)
+        mask[b, hoff:hoff + NUM_PART * nh] = True
+        mask[b, hoff + NUM_PART * hcap:hoff + NUM_PART * hcap + nh] = True
+    return mask
+
+
 def decode_maps(heat, paf, config=None, max_peaks_per_part=32, max_humans=64, nms_only=False, nms_flags=0):
     """heat [N,h,w,C>=num_keypoints], paf [N,h,w,38]: dense NHWC float32 CUDA tensors.
     Returns a list of per-image dicts (see parse_image).  Grows capacities on overflow."""

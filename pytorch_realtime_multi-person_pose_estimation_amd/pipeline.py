@@ -30,45 +30,76 @@ def _raise_on_device_error(model, plan):
 
 class SideDecoder(object):
     """The decoder's launches and the D2H of their records on a SECOND stream, behind an event, so that the next forward
-    starts at once on the compute stream (round 5).  The decoder's four launches are latency-bound chains on small grids
-    (134 us of them one wave per image): on the compute stream they are 0.9 % of an fp32 step and 2.4 % of a bf16 one in
-    which nothing else runs.  The next forward waits for the decoder's last read of the maps (`guarded` ->
-    rtpose_net_set_output_guard): an fp32 plan only where it first writes their buffer, a bf16 / bf16x3 plan in front of
-    its whole launch list (the decoder beside the bf16 kernels was not reliable: DESIGN.md 3.3).  Two slots (record block,
-    pinned copy, events)."""
+    is queued at once on the compute stream (round 5).  The decoder's four launches are latency-bound chains on small grids:
+    on the compute stream they are 0.9 % of an fp32 step and 2.4 % of a bf16 one in which nothing else runs.
+
+    The maps' buffer belongs to the plan, so the plan carries the guard (rtpose_net_set_output_guard): from the moment a
+    decode is enqueued here, EVERY later forward of that plan - this object's next batch, PoseEstimator.__call__, a bare
+    model(x), another estimator over the same module - waits for this decode's last read of the maps before it rewrites
+    them (library default: in front of its whole launch list; RTPOSE_GUARD_FINE=1: only where it first writes the buffer.
+    DESIGN.md 3.3 has the history: the decoder's kernels are built without packed-fp32 VALU instructions because those
+    returned wrong values beside the bf16 plan's kernels).  The guard stays installed until the next decode replaces it or
+    close() removes it.  The plan's device error word (persistent 7x7 hand-over, fp32 plans) rides in front of every decode and
+    is checked in wait().  Two slots (record block, pinned copy, events, error word)."""
 
     def __init__(self, config):
         self.config = config
         self.stream = None
         self.slots = [None, None]
-        self.last = None            # slot of the decode enqueued last: the maps' reader the next forward has to respect
+        self.last = None            # slot of the decode enqueued last
+        self._plans = {}            # id -> plan whose guard points at one of this object's events
 
     def guarded(self, plan, forward):
-        """Run `forward()` (which enqueues the plan's launches on the current stream) with the plan's output guard set
-        to the last decode's final read of the maps."""
-        guard = self.last["dec_done"].cuda_event if self.last is not None else None
-        check(lib.rtpose_net_set_output_guard(plan.handle, guard))
-        try:
-            return forward()
-        finally:
-            check(lib.rtpose_net_set_output_guard(plan.handle, None))
+        """Run `forward()` (which enqueues the plan's launches on the current stream).  The guard a previous decode() left on
+        the plan makes it wait for that decode's final read of the maps; nothing to do here any more - kept as the one place
+        the pipelined callers enqueue their forward through."""
+        return forward()
 
-    def decode(self, i, maps, n, device, max_peaks_per_part, max_humans, post=None):
+    def close(self):
+        """Remove this object's guard from the plans it was installed on (their events die with the slots)."""
+        for plan in self._plans.values():
+            try:
+                lib.rtpose_net_set_output_guard(plan.handle, None)
+            except Exception:   # noqa: BLE001  (interpreter shutdown)
+                pass
+        self._plans = {}
+
+    def __del__(self):
+        self.close()
+
+    def decode(self, i, maps, n, device, max_peaks_per_part, max_humans, post=None, plan=None, model=None):
         """Enqueue decode + record D2H of slot i (0 / 1) behind everything queued on the current stream so far.
         maps = (hbase, lheat, pbase, lpaf, h, w).  ``post(result_block)``, if given, runs on the side stream after the
-        decode and returns the device tensor whose copy wait() hands out (bench.py: the RCCL gather of the ranks' blocks)."""
+        decode and returns the device tensor whose copy wait() hands out (bench.py: the RCCL gather of the ranks' blocks).
+        ``plan`` (+ ``model``): the plan whose output buffer `maps` points into - it gets the guard and its device error
+        word is read."""
         import torch
+        if plan is None:
+            raise _capi.RtposeError("SideDecoder.decode: plan= is required (the plan whose output buffer the maps live in "
+                                    "carries the guard that keeps its next forward off them)")
         if self.stream is None:
             self.stream = torch.cuda.Stream()
         hbase, lheat, pbase, lpaf, h, w = maps
         slot = self.slots[i]
         key = (n, device.index, max_peaks_per_part, max_humans)
         if slot is None or slot["key"] != key:
+            if slot is not None:
+                # the old buffers may still be read / written by side-stream work queued earlier: the caching allocator
+                # hands a dropped block back to the COMPUTE stream's pool at once (round-5 advisor finding)
+                slot["done"].synchronize()
+                if self.last is slot:
+                    self.close()        # a guard must not outlive its event
+                    self.last = None
             cfg = dec.make_cfg(self.config, max_peaks_per_part, max_humans)
             slot = {"key": key, "bufs": dec.DecodeBuffers(cfg, n, device), "maps": torch.cuda.Event(),
-                    "dec_done": torch.cuda.Event(), "done": torch.cuda.Event(), "host": None}
+                    "dec_done": torch.cuda.Event(), "done": torch.cuda.Event(), "host": None,
+                    "err": torch.zeros(1, dtype=torch.int32).pin_memory(), "plan": None}
             self.slots[i] = slot
         bufs = slot["bufs"]
+        slot["plan"] = plan
+        if (model is not None and getattr(plan, 'dtype', 0) == _capi.DTYPE_F32
+                and hasattr(model, 'device_status_async')):
+            model.device_status_async(plan, slot["err"])       # compute stream: behind the forward, in front of `maps`
         slot["maps"].record(torch.cuda.current_stream())
         self.stream.wait_event(slot["maps"])
         with torch.cuda.stream(self.stream):
@@ -81,14 +112,27 @@ class SideDecoder(object):
                 slot["host"] = torch.empty(block.shape, dtype=block.dtype).pin_memory()
             slot["host"].copy_(block, non_blocking=True)
             slot["done"].record(self.stream)
+        check(lib.rtpose_net_set_output_guard(plan.handle, slot["dec_done"].cuda_event))
+        self._plans[id(plan)] = plan
         bufs.map_hw = (h, w)
         self.last = slot
         return bufs
 
     def wait(self, i):
-        """-> (buffers, numpy int32 view of slot i's pinned record block; valid until the slot is used again)."""
+        """-> (buffers, numpy int32 view of slot i's pinned record block; valid until the slot is used again).  Raises when
+        the plan's device error word came back non-zero (the maps of that batch are invalid)."""
         slot = self.slots[i]
         slot["done"].synchronize()
+        word = int(slot["err"][0])
+        if word:
+            slot["err"][0] = 0
+            if word & 1 and slot["plan"] is not None:
+                # every later forward of the plan runs one block per tile (same bits, a few per cent slower); captured
+                # launch lists are dropped with it
+                check(lib.rtpose_net_set_persistent7(slot["plan"].handle, 0))
+            raise _capi.RtposeError("device error word %d: a split-tile hand-over of a persistent 7x7 launch timed out "
+                                    "(shared / CU-masked device?); the maps of this batch are invalid - the plan has "
+                                    "stopped splitting tiles, run the batch again" % word)
         return slot["bufs"], slot["host"].numpy()
 
 
@@ -158,13 +202,14 @@ class PoseEstimator(object):
                 check(lib.rtpose_layout_axpby(hbase, C.byref(lheat), ptr(sh), 19, n, h, w, scene_alpha, 1.0, s))
                 check(lib.rtpose_layout_axpby(pbase, C.byref(lpaf), ptr(sp), 38, n, h, w, scene_alpha, 1.0, s))
             bufs = self._side.decode(k & 1, (hbase, lheat, pbase, lpaf, h, w), n, x.device, self.max_peaks_per_part,
-                                     self.max_humans, post)
+                                     self.max_humans, post, plan=plan, model=m)
             bufs.plan = plan
             return k
 
     def collect(self, ticket):
         """Wait for the records of submit()'s ticket -> (buffers, numpy int32 view of the pinned record block; valid
-        until the ticket after next is submitted)."""
+        until the ticket after next is submitted).  Raises RtposeError when the plan's device error word of that batch is
+        non-zero (a persistent 7x7 hand-over timed out: its maps are invalid)."""
         return self._side.wait(ticket & 1)
 
     def __call__(self, x, scene=None, scene_alpha=1e-3):
@@ -227,8 +272,6 @@ class StreamingPoseEstimator(object):
         self.dev = torch.device('cuda', torch.cuda.current_device())
         self.host = [torch.empty((batch, h0, w0, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
         self.devbuf = [torch.empty((batch, h0, w0, 3), dtype=torch.uint8, device=self.dev) for _ in range(2)]
-        # the plan's device error word, copied behind each batch's forward (one word per slot: two batches are in flight)
-        self.err_word = torch.zeros(2, dtype=torch.int32).pin_memory()
         self.max_peaks_per_part, self.max_humans = max_peaks_per_part, max_humans
         self.scene, self.scene_alpha = scene, scene_alpha
         self.side = SideDecoder(self.config)
@@ -272,12 +315,10 @@ class StreamingPoseEstimator(object):
             sh, sp = self.scene
             check(lib.rtpose_layout_axpby(hbase, C.byref(lheat), ptr(sh), 19, self.B, h, w, self.scene_alpha, 1.0, s))
             check(lib.rtpose_layout_axpby(pbase, C.byref(lpaf), ptr(sp), 38, self.B, h, w, self.scene_alpha, 1.0, s))
-        # the device error word rides in front of the decode: _finish reads it after the records' event, and never
-        # calls a stream-synchronising API while the next batch is queued (round-4 advisor finding)
-        if getattr(plan, 'dtype', 0) == _capi.DTYPE_F32 and hasattr(m, 'device_status_async'):
-            m.device_status_async(plan, self.err_word[slot:slot + 1])
+        # (the plan's device error word rides in front of the decode and is checked by side.wait(): the host never calls a
+        #  stream-synchronising API while the next batch is queued - round-4 advisor finding)
         self.bufs = self.side.decode(slot, (hbase, lheat, pbase, lpaf, h, w), self.B, self.dev,
-                                     self.max_peaks_per_part, self.max_humans)
+                                     self.max_peaks_per_part, self.max_humans, plan=plan, model=m)
         return slot
 
     def _finish(self, slot):
@@ -285,11 +326,6 @@ class StreamingPoseEstimator(object):
         while True:
             bufs, host = self.side.wait(slot)    # the records of THIS batch (the next batch may already be running)
             recs = host.reshape(self.B, bufs.words).copy()
-            word = int(self.err_word[slot])
-            if word:
-                self.err_word[slot] = 0
-                raise _capi.RtposeError("device error word %d: a split-tile hand-over of a persistent 7x7 launch timed "
-                                        "out (shared / CU-masked device?); the maps of this batch are invalid" % word)
             flags = int(np.bitwise_or.reduce(recs[:, dec.RES_HEADER + 2]))
             if not flags:
                 return recs

@@ -201,3 +201,31 @@ def test_winograd_fits_is_host_only_logic(capi):
     d[0].wino_m = 5
     assert fits(7, 128, 128, 32) == 0
     d[0].wino_m = 0
+
+
+def test_decoder_objects_hold_no_packed_fp32_instruction(tmp_path):
+    """The decoder's kernels run on a second stream beside the forward's MFMA kernels (pipeline.SideDecoder).  Round 6
+    (DESIGN.md 3.3): with clang's vectorisers on, limb_assign_kernel's sample loop was compiled into packed-fp32 VALU
+    instructions (v_pk_mul_f32 / v_pk_add_f32) and returned wrong scores in lanes 48..63 beside the bf16 plan's kernels
+    (~2 launches in 1000); the same source without them: 0 of 240,000.  csrc/Makefile therefore builds decode.hip /
+    legacy_pafprocess.hip with -fno-slp-vectorize -fno-vectorize; this test disassembles the gfx950 code of the built
+    objects and refuses any packed-fp32 arithmetic instruction in them."""
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("no ROCm LLVM tools here")
+    build = os.path.join(ROOT, "pytorch_realtime_multi-person_pose_estimation_amd", "csrc", "build")
+    obj = os.path.join(build, "decode.o")
+    if not os.path.exists(obj):
+        pytest.skip("csrc/build/decode.o not built (run __graft_entry__.build())")
+    fat, co = str(tmp_path / "decode.fatbin"), str(tmp_path / "decode.co")
+    subprocess.run([tools[0], "--dump-section", ".hip_fatbin=" + fat, obj], check=True)
+    subprocess.run([tools[1], "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co,
+                    "--unbundle"], check=True)
+    dis = subprocess.run([tools[2], "-d", co], check=True, stdout=subprocess.PIPE, text=True).stdout
+    assert "limb_assign_kernel" in dis and "global_load_dword" in dis        # (it is the device code we are looking at)
+    packed = sorted(set(re.findall(r"\bv_pk_[a-z0-9_]*f32\b", dis)))
+    assert not packed, "packed-fp32 instructions in the decoder's device code: %s" % packed
+    mk = open(os.path.join(ROOT, "pytorch_realtime_multi-person_pose_estimation_amd", "csrc", "Makefile")).read()
+    assert re.search(r"build/decode\.o build/legacy_pafprocess\.o: CXXFLAGS \+= -fno-slp-vectorize -fno-vectorize", mk)

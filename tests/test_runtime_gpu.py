@@ -336,16 +336,20 @@ def test_decoder_of_one_batch_under_the_forward_of_the_next(cuda):
         m.set_compute_dtype('fp32')
 
 
-def test_decoder_beside_the_next_forward_gives_the_serial_records_every_time(cuda):
-    """Soak of the overlapped pipeline: 60 rounds of 10 steps per arithmetic (9600 image decodes each), every record
-    compared with the serial path's.  Round 5 found that a decoder running beside the bf16 plan's MFMA kernels returned,
-    in ~1 % of the batches, one limb score a sample off (lanes 41..63 of the scoring wave; maps and peaks identical
-    before and after): bf16 plans therefore hold their whole forward back until the decoder has finished,
-    the decoder's sample loop lost its double-precision chain - and this test keeps watch over both arithmetics (the
-    three images with 7-8 peaks per part, the ones that fill the high lanes, are in the batches)."""
+def test_decoder_beside_the_next_forward_gives_the_serial_records_every_time(cuda, monkeypatch):
+    """Soak of the overlapped pipeline in its default, most exposed form - the forward of batch k + 1 waits for the decoder
+    of batch k only where it first rewrites the maps' buffer, so the decoder runs BESIDE the next forward's first launches - 600 bf16 and 200 fp32 steps of 16 images that carry 8 people each (49-64 candidate pairs per limb: the high
+    lanes of the scoring wave are busy in every image), every record block compared with the serial path's.
+    Round 5 found one limb score a sample off in ~1 % of such bf16 batches; round 6 traced it to the packed-fp32 VALU
+    instructions clang's SLP vectoriser had put into the scoring loop (wrong values in lanes 48..63 when the wave shares a CU
+    with the bf16 plan's kernels: 342 of 48,000 decodes on the box where the same source built without them gave 0 of
+    240,000 - DESIGN.md 3.3, profiles/r06_decoder_beside_forward.txt).  The decoder is now built without them
+    (tests/test_capi_cpu.py checks the object); this test keeps watch."""
     import importlib
     import numpy as np
     import torch
+    monkeypatch.delenv("RTPOSE_GUARD_WHOLE_FORWARD", raising=False)   # the library default is the exposed form; the variables
+    monkeypatch.setenv("RTPOSE_GUARD_FINE", "1")                      # are read when a plan's guard position is first decided
     sys.path.insert(0, ROOT)
     pkg = importlib.import_module(PKG_NAME)
     dec = importlib.import_module(PKG_NAME + ".decode")
@@ -359,33 +363,31 @@ def test_decoder_beside_the_next_forward_gives_the_serial_records_every_time(cud
     data = []
     for r in range(3):
         g = torch.Generator().manual_seed(300 + r)
-        h, p, _ = synth.make_batch(B, S, S, seed=400 + r)
-        data.append(((torch.rand(B, 3, S, S, generator=g) - 0.5).to(dev), (torch.from_numpy(h).to(dev), torch.from_numpy(p).to(dev))))
+        rng = np.random.default_rng(400 + r)
+        hp = [synth.render(synth.random_people(rng, 8, S, S, drop_prob=0.02), S, S, noise=0.02, rng=rng) for _ in range(B)]
+        data.append(((torch.rand(B, 3, S, S, generator=g) - 0.5).to(dev),
+                     (torch.from_numpy(np.stack([h for h, _ in hp])).to(dev), torch.from_numpy(np.stack([p for _, p in hp])).to(dev))))
     order = [0, 1, 2, 2, 1, 0, 0, 1, 2, 1]
     est = pipeline.PoseEstimator(m)
     try:
-        for dt in ('fp32', 'bf16'):
+        for dt, steps in (('bf16', 600), ('fp32', 200)):
             m.set_compute_dtype(dt)
             for x, scene in data:
                 est(x, scene)
             want = [dec.fetch(est.enqueue(x, scene)).copy() for x, scene in data]
-            assert max(int(w[:, dec.RES_PART_COUNT:dec.RES_PART_COUNT + 18].max()) for w in want) >= 7
+            masks = [dec.result_mask(w) for w in want]
+            assert np.mean([w[:, dec.RES_PART_COUNT:dec.RES_PART_COUNT + 18].mean() for w in want]) >= 6.5
             bad = []
-            for rd in range(60):
-                prev = None
-                for k, r in enumerate(order + [None]):
-                    t = est.submit(*data[r]) if r is not None else None
-                    if prev is not None:
-                        got = est.collect(prev[0])[1].reshape(B, -1)
-                        if not np.array_equal(got, want[prev[1]]):
-                            # (the blocks hold uninitialised slack past the counts: compare what they SAY)
-                            for b in range(B):
-                                ga, wa = dec.parse_image(got[b]), dec.parse_image(want[prev[1]][b])
-                                if not all(np.array_equal(ga[f].view(np.uint32) if ga[f].dtype == np.float32 else ga[f],
-                                                          wa[f].view(np.uint32) if wa[f].dtype == np.float32 else wa[f])
-                                           for f in ("peaks", "parts", "score")):
-                                    bad.append((dt, rd, k - 1, b))
-                    prev = (t, r)
+            prev = None
+            for k in range(steps + 1):
+                r = order[k % len(order)] if k < steps else None
+                t = est.submit(*data[r]) if r is not None else None
+                if prev is not None:
+                    got = est.collect(prev[0])[1].reshape(B, -1)
+                    w, mk = want[prev[1]], masks[prev[1]]
+                    if got.shape != w.shape or not np.array_equal(got[mk], w[mk]):
+                        bad.append((dt, k - 1, [b for b in range(B) if not np.array_equal(got[b][mk[b]], w[b][mk[b]])]))
+                prev = (t, r)
             assert not bad, bad
     finally:
         m.set_compute_dtype('fp32')

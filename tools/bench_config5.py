@@ -91,7 +91,7 @@ def main():
         sh, sp = pool[(i0 // B) % len(pool)]
         capi.check(lib.rtpose_layout_axpby(hbase, C.byref(lheat), capi.ptr(sh), 19, B, h, w, 1e-3, 1.0, stream))
         capi.check(lib.rtpose_layout_axpby(pbase, C.byref(lpaf), capi.ptr(sp), 38, B, h, w, 1e-3, 1.0, stream))
-        side.decode(slot, (hbase, lheat, pbase, lpaf, h, w), B, dev, 64, 64, post)
+        side.decode(slot, (hbase, lheat, pbase, lpaf, h, w), B, dev, 64, 64, post, plan=plan, model=model)
 
     def records(slot):
         bufs, host = side.wait(slot)

@@ -16,16 +16,18 @@ CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract
 objs=""
 for f in $FILES; do
   o=tools/exp/objs/$f.o
+  # the decoder is built without the vectorisers (no packed-fp32 VALU: csrc/Makefile); DECODE_FLAGS="" gives the round-5 form back
+  case $f in decode|legacy_pafprocess) X="${DECODE_FLAGS--fno-slp-vectorize -fno-vectorize}";; *) X="";; esac
   if [ -n "$ONLY" ]; then
     if [ "$f" = "$ONLY" ]; then
       o=tools/exp/objs/$f.$(basename $OUT .so).o
-      $CC "$@" -c $SRC/$f.hip -o $o &
+      $CC $X "$@" -c $SRC/$f.hip -o $o &
     elif [ ! -f $o ] || [ $SRC/$f.hip -nt $o ]; then
-      $CC -c $SRC/$f.hip -o $o &
+      $CC $X -c $SRC/$f.hip -o $o &
     fi
   else
     o=tools/exp/objs/$f.all.o
-    $CC "$@" -c $SRC/$f.hip -o $o &
+    $CC $X "$@" -c $SRC/$f.hip -o $o &
   fi
   objs="$objs $o"
 done
