@@ -58,10 +58,13 @@ inline size_t decode_workspace_bytes(const rtpose_decode_cfg* c, int N) {
          decode_ws_tie_bytes(c, N);
 }
 
+// with_ids: also run peak_prefix_kernel (the running peak ids + the peak total); a full decode leaves that to
+// assign_group_launch(write_ids = true), which writes them in its grouping kernel
 int nms_launch(const float* heat, const rtpose_layout* lheat, int N, int h, int w,
-               const rtpose_decode_cfg* cfg, void* result, hipStream_t s, int flags = 0);
+               const rtpose_decode_cfg* cfg, void* result, hipStream_t s, int flags, bool with_ids);
+// write_ids = false: the peak tables already carry the caller's ids (legacy process_paf: ids of the caller's joint list)
 int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int h, int w, double inv_up,
                         int h1, const rtpose_decode_cfg* cfg, void* workspace, size_t workspace_bytes,
-                        void* result, hipStream_t s);
+                        void* result, hipStream_t s, bool write_ids);
 
 }  // namespace rtpose

@@ -56,38 +56,58 @@ __device__ __forceinline__ void cubic_coeffs(float x, float* c) {
 
 // find_peaks (paf_to_pose.py:25-38) for one (image, part): 4-neighbour maximum, > thr, peaks
 // compacted in row-major order into s_px / s_py (the order defines the peak ids).  Whole block.
+constexpr int kPeakBatch = 5;  // 256-pixel sweeps whose loads are in flight together (a 46 x 46 map is 8.3 sweeps: 2 batches)
 __device__ __forceinline__ int find_peaks_block(const MapView& heat, int n, int part, int h, int w, float thr,
-                                                int pcap, int* s_wcount, int* s_px, int* s_py, int32_t* res) {
+                                                int pcap, int (*s_wcount)[4], int* s_px, int* s_py, int32_t* res) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int base = 0;
   const int npix = h * w;
-  for (int start = 0; start < npix; start += 256) {
-    const int idx = start + tid;
-    bool pk = false;
-    int x = 0, y = 0;
-    if (idx < npix) {
-      y = idx / w;
-      x = idx - y * w;
-      const float v = map_at(heat, n, y, x, part);
-      pk = v > thr;
-      if (pk && y > 0) pk = v >= map_at(heat, n, y - 1, x, part);
-      if (pk && y + 1 < h) pk = v >= map_at(heat, n, y + 1, x, part);
-      if (pk && x > 0) pk = v >= map_at(heat, n, y, x - 1, part);
-      if (pk && x + 1 < w) pk = v >= map_at(heat, n, y, x + 1, part);
+  // Round 6: the centre and its four neighbours of kPeakBatch sweeps are requested up front, unconditionally (border
+  // neighbours clamped to the pixel itself and ignored): one global round trip per batch instead of two dependent ones per
+  // sweep, one pair of barriers per batch instead of per sweep.  The tests are the ones of the sweep-by-sweep form.
+  for (int start = 0; start < npix; start += 256 * kPeakBatch) {
+    float v[kPeakBatch], vu[kPeakBatch], vd[kPeakBatch], vl[kPeakBatch], vr[kPeakBatch];
+    int xs[kPeakBatch], ys[kPeakBatch];
+#pragma unroll
+    for (int b = 0; b < kPeakBatch; ++b) {
+      const int idx = min(start + 256 * b + tid, npix - 1);
+      const int y = idx / w, x = idx - y * w;
+      ys[b] = y;
+      xs[b] = x;
+      v[b] = map_at(heat, n, y, x, part);
+      vu[b] = map_at(heat, n, max(y - 1, 0), x, part);
+      vd[b] = map_at(heat, n, min(y + 1, h - 1), x, part);
+      vl[b] = map_at(heat, n, y, max(x - 1, 0), part);
+      vr[b] = map_at(heat, n, y, min(x + 1, w - 1), part);
     }
-    const unsigned long long mask = __ballot(pk);
-    if (lane == 0) s_wcount[wave] = __popcll(mask);
+    bool pk[kPeakBatch];
+    unsigned long long mask[kPeakBatch];
+#pragma unroll
+    for (int b = 0; b < kPeakBatch; ++b) {
+      const int x = xs[b], y = ys[b];
+      bool p = start + 256 * b + tid < npix && v[b] > thr;
+      if (p && y > 0) p = v[b] >= vu[b];
+      if (p && y + 1 < h) p = v[b] >= vd[b];
+      if (p && x > 0) p = v[b] >= vl[b];
+      if (p && x + 1 < w) p = v[b] >= vr[b];
+      pk[b] = p;
+      mask[b] = __ballot(p);
+      if (lane == 0) s_wcount[b][wave] = __popcll(mask[b]);
+    }
     __syncthreads();
-    int off = base;
-    for (int k = 0; k < wave; ++k) off += s_wcount[k];
-    if (pk) {
-      const int pos = off + __popcll(mask & ((1ull << lane) - 1ull));
-      if (pos < pcap) {
-        s_px[pos] = x;
-        s_py[pos] = y;
+#pragma unroll
+    for (int b = 0; b < kPeakBatch; ++b) {
+      int off = base;
+      for (int k = 0; k < wave; ++k) off += s_wcount[b][k];
+      if (pk[b]) {
+        const int pos = off + __popcll(mask[b] & ((1ull << lane) - 1ull));
+        if (pos < pcap) {
+          s_px[pos] = xs[b];
+          s_py[pos] = ys[b];
+        }
       }
+      base += s_wcount[b][0] + s_wcount[b][1] + s_wcount[b][2] + s_wcount[b][3];
     }
-    base += s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
     __syncthreads();
   }
   const int count = min(base, pcap);
@@ -108,7 +128,7 @@ __global__ __launch_bounds__(256) void nms_refine_kernel(MapView heat, int h, in
 
   __shared__ int s_sx[kMaxDst];
   __shared__ float s_alpha[kMaxDst][4];
-  __shared__ int s_wcount[4];
+  __shared__ int s_wcount[kPeakBatch][4];
   __shared__ int s_px[kDecodeMaxPeaks], s_py[kDecodeMaxPeaks];
   __shared__ float s_patch[4][25];
   __shared__ float s_hbuf[4][5 * kMaxDst];
@@ -231,7 +251,7 @@ __global__ __launch_bounds__(256) void nms_refine_opt_kernel(MapView heat, int h
   extern __shared__ float s_dyn[];  // [2][(5 up)^2]: the up-sampled patch and the first Gaussian pass
   __shared__ int s_sx[kMaxDst];
   __shared__ float s_alpha[kMaxDst][4];
-  __shared__ int s_wcount[4];
+  __shared__ int s_wcount[kPeakBatch][4];
   __shared__ int s_px[kDecodeMaxPeaks], s_py[kDecodeMaxPeaks];
   __shared__ float s_patch[25];
   __shared__ float s_hbuf[5 * kMaxDst];
@@ -580,6 +600,10 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
   __shared__ int s_widx[4], s_wcnt[4];
   __shared__ int s_nconn;
   __shared__ int s_stack[kSortStack];
+  // the limb's connections (a, b, score bits) as they are accepted; written to the workspace in one parallel sweep at the end
+  // (round 6: thread 0 stored each one to global memory inside the greedy loop, and the store had to land before the loop's
+  // barrier let the next step start - a global round trip per connection)
+  __shared__ int s_conn[3 * kDecodeMaxPeaks];
 
   const int partA = kPairs[pair_id][0], partB = kPairs[pair_id][1];
   const int chx = kPairNet[pair_id][0], chy = kPairNet[pair_id][1];
@@ -625,11 +649,27 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
       const float step_y = (float)(B.y - A.y) / 10.f;
       float scores = 0.f;
       int crit1 = 0;
+#ifdef RTPOSE_EXP_LIMB_WAIT0  // experiment: every map load has landed before the first value is consumed
+      float pxa[10], pya[10];
+#endif
+#ifdef RTPOSE_EXP_LIMB_KEEP  // experiment: the loads' offset registers stay live until every load has returned
+      unsigned keep[10];
+#endif
 #pragma unroll
       for (int i = 0; i < 10; ++i) {
         // lx = (int)(v + 0.5) evaluated in double (pafprocess.cpp:232-233): v >= 0 is a float, so v + 0.5 is exact there
         // and the cast is floor(v + 0.5) = trunc(v) + (frac(v) >= 0.5), frac exact in fp32
+#ifdef RTPOSE_EXP_LIMB_ASM_COORD  // experiment: the y coordinate through opaque scalar instructions - the
+        const float fx = (float)A.x + (float)i * step_x;   // vectoriser cannot pair it with x
+        float fy;
+        {
+          float ty;
+          asm("v_mul_f32 %0, %1, %2" : "=v"(ty) : "v"((float)i), "v"(step_y));
+          asm("v_add_f32 %0, %1, %2" : "=v"(fy) : "v"((float)A.y), "v"(ty));
+        }
+#else
         const float fx = (float)A.x + (float)i * step_x, fy = (float)A.y + (float)i * step_y;
+#endif
         int lx = (int)fx, ly = (int)fy;
         if (fx - (float)lx >= 0.5f) ++lx;
         if (fy - (float)ly >= 0.5f) ++ly;
@@ -652,14 +692,37 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
           asm("v_mul_u32_u24 %0, %1, %2" : "=v"(boff) : "s"(pix_bytes), "v"(pix));
           px = *reinterpret_cast<const float*>(img_x + boff);
           py = *reinterpret_cast<const float*>(img_y + boff);
+#ifdef RTPOSE_EXP_LIMB_KEEP
+          keep[i] = boff;
+#endif
         } else {
           px = map_at(paf, n, sy, sx, chx);
           py = map_at(paf, n, sy, sx, chy);
         }
+#ifdef RTPOSE_EXP_LIMB_WAIT0
+        pxa[i] = px;
+        pya[i] = py;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        float px = pxa[i], py = pya[i];
+        asm volatile("" : "+v"(px), "+v"(py));
+#endif
+#ifdef RTPOSE_EXP_LIMB_ASM_DOT  // experiment: one product of the dot product opaque - no packed multiply / add there
+        float typ;
+        asm("v_mul_f32 %0, %1, %2" : "=v"(typ) : "v"(vy), "v"(py));
+        const float s = vx * px + typ;
+#else
         const float s = vx * px + vy * py;
+#endif
         scores = scores + s;
         if (s > 0.05f) ++crit1;
       }
+#ifdef RTPOSE_EXP_LIMB_KEEP
+      asm volatile("" ::"v"(scores), "v"(keep[0]), "v"(keep[1]), "v"(keep[2]), "v"(keep[3]), "v"(keep[4]), "v"(keep[5]),
+                   "v"(keep[6]), "v"(keep[7]), "v"(keep[8]), "v"(keep[9]));
+#endif
       // min(0.5 h1 / norm - 1, 0) in double (cpp:238-240): 0 for every limb no longer than half the image (the quotient is
       // >= 1 then, and adding 0.0 to a float widened to double changes nothing)
       float crit2 = scores / 10.f;
@@ -746,9 +809,9 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
       s_usedA[a] = 1;
       s_usedB[b] = 1;
       const int k = s_nconn++;
-      cn[1 + 3 * k + 0] = a;
-      cn[1 + 3 * k + 1] = b;
-      cn[1 + 3 * k + 2] = __float_as_int(best);
+      s_conn[3 * k + 0] = a;
+      s_conn[3 * k + 1] = b;
+      s_conn[3 * k + 2] = __float_as_int(best);
     }
     __syncthreads();
   }
@@ -800,9 +863,9 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
         if (s_usedA[a] || s_usedB[b]) continue;
         s_usedA[a] = 1;
         s_usedB[b] = 1;
-        cn[1 + 3 * k + 0] = a;
-        cn[1 + 3 * k + 1] = b;
-        cn[1 + 3 * k + 2] = (int)(unsigned)(e >> 32);
+        s_conn[3 * k + 0] = a;
+        s_conn[3 * k + 1] = b;
+        s_conn[3 * k + 2] = (int)(unsigned)(e >> 32);
         ++k;
       }
       s_nconn = k;
@@ -810,13 +873,23 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
     __syncthreads();
   }
   __syncthreads();
-  if (tid == 0) cn[0] = s_nconn;
+  const int nconn = s_nconn;
+  if (tid == 0) cn[0] = nconn;
+  for (int i = tid; i < 3 * nconn; i += 256) cn[1 + i] = s_conn[i];
 }
 
 
 // ------------------------------------------------------------------------------
 // 3. Person grouping + prune (pafprocess.cpp:126-191), one wave per image
 // ------------------------------------------------------------------------------
+// The walk over the connections is the reference's serial loop (every connection sees the rows the previous one left), so
+// what it costs is the latency of one step.  Round 6: a limb's connections are STAGED first - the 64 lanes fetch the
+// (a, b, score) triples, the two peak ids and the two peak scores of up to 64 connections at a time into LDS, in parallel - and
+// the serial walk then touches LDS only (round 5: three dependent global loads per connection, ~1.6 us each step: 164 us per
+// batch whatever its size; now ~20).  WRITE_IDS: the running peak ids of paf_to_pose.py:141-142 (the former peak_prefix_kernel
+// launch) are written here - and taken arithmetically, id = s_start[part] + index, instead of read back.
+constexpr int kStageWords = 5;  // per staged connection: cid1, cid2, connection score, score of peak 2, score of peak 1
+template <bool WRITE_IDS>
 __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* __restrict__ result,
                                                    int result_words, const int32_t* __restrict__ conn,
                                                    int conn_words, int row_cap,
@@ -825,8 +898,9 @@ __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* 
   int32_t* res = result + (size_t)n * result_words;
   const int32_t* cnb = conn + (size_t)n * conn_words;
   extern __shared__ float rows_lds[];
-  // [row_cap][20 + alive]: the reference's `subset`; LDS unless grown past kLdsRows
+  // [row_cap][20 + alive]: the reference's `subset`; LDS unless grown past kLdsRows; then the staged connections of one limb
   float* rows = row_cap <= kLdsRows ? rows_lds : rows_ws + (size_t)n * row_cap * 21;
+  float* stage = rows_lds + (row_cap <= kLdsRows ? (size_t)row_cap * 21 : 0);
 
   __shared__ int s_start[RTPOSE_NUM_PART + 1];
   if (lane == 0) {
@@ -836,14 +910,22 @@ __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* 
       acc += res[kResPartCount + p];
     }
     s_start[RTPOSE_NUM_PART] = acc;
+    if (WRITE_IDS) res[kResHeader + 0] = acc;
   }
   __syncthreads();
-  const rtpose_peak* peaks = reinterpret_cast<const rtpose_peak*>(res + kResPeaks);
+  rtpose_peak* peaks = reinterpret_cast<rtpose_peak*>(res + kResPeaks);
+  if (WRITE_IDS) {
+    // ids = running counter over parts then peaks (paf_to_pose.py:141-142)
+    for (int p = 0; p < RTPOSE_NUM_PART; ++p) {
+      const int cnt = s_start[p + 1] - s_start[p];
+      for (int i = lane; i < cnt; i += 64) peaks[(size_t)p * pcap + i].id = s_start[p] + i;
+    }
+  }
   // peak_infos_line[pos] (cpp:38-43): part-major position -> peak
-  auto line_peak = [&](int pos) -> rtpose_peak {
+  auto line_peak_score = [&](int pos) -> float {
     int p = 0;
     while (p + 1 < RTPOSE_NUM_PART && pos >= s_start[p + 1]) ++p;
-    return peaks[(size_t)p * pcap + (pos - s_start[p])];
+    return peaks[(size_t)p * pcap + (pos - s_start[p])].score;
   };
   const int npeaks = s_start[RTPOSE_NUM_PART];
 
@@ -855,10 +937,23 @@ __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* 
     const int nconn = cn[0];
     const rtpose_peak* pA = peaks + (size_t)part1 * pcap;
     const rtpose_peak* pB = peaks + (size_t)part2 * pcap;
-    for (int c = 0; c < nconn; ++c) {
+    // stage the limb's connections: everything the walk needs from global memory, 64 connections in flight at a time
+    for (int c = lane; c < nconn; c += 64) {
       const int ia = cn[1 + 3 * c], ib = cn[1 + 3 * c + 1];
-      const float cscore = __int_as_float(cn[1 + 3 * c + 2]);
-      const float cid1 = (float)pA[ia].id, cid2 = (float)pB[ib].id;
+      const int id1 = WRITE_IDS ? s_start[part1] + ia : pA[ia].id;
+      const int id2 = WRITE_IDS ? s_start[part2] + ib : pB[ib].id;
+      float* st = stage + (size_t)c * kStageWords;
+      st[0] = (float)id1;
+      st[1] = (float)id2;
+      st[2] = __int_as_float(cn[1 + 3 * c + 2]);
+      st[3] = (id2 >= 0 && id2 < npeaks) ? (WRITE_IDS ? pB[ib].score : line_peak_score(id2)) : 0.f;
+      st[4] = (id1 >= 0 && id1 < npeaks) ? (WRITE_IDS ? pA[ia].score : line_peak_score(id1)) : 0.f;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int c = 0; c < nconn; ++c) {
+      const float* st = stage + (size_t)c * kStageWords;
+      const float cid1 = st[0], cid2 = st[1], cscore = st[2], s2 = st[3];
       // search alive rows in order
       int found = 0, idx1 = 0, idx2 = 0;
       for (int r0 = 0; r0 < nrows; r0 += 64) {
@@ -875,8 +970,6 @@ __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* 
           m &= m - 1;
         }
       }
-      const int c2 = (int)cid2;
-      const float s2 = (c2 >= 0 && c2 < npeaks) ? line_peak(c2).score : 0.f;
       if (found == 1) {
         float* row = rows + (size_t)idx1 * 21;
         if (lane == 0 && row[part2] != cid2) {
@@ -906,8 +999,7 @@ __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* 
       } else if (found == 0 && pair_id < 18) {
         if (nrows < row_cap) {
           float* row = rows + (size_t)nrows * 21;
-          const int c1 = (int)cid1;
-          const float s1 = (c1 >= 0 && c1 < npeaks) ? line_peak(c1).score : 0.f;
+          const float s1 = st[4];
           if (lane < 18) row[lane] = (lane == part1) ? cid1 : ((lane == part2) ? cid2 : -1.f);
           if (lane == 0) {
             row[19] = 2.f;
@@ -992,7 +1084,7 @@ static GaussW gauss_weights() {
 }
 
 int nms_launch(const float* heat, const rtpose_layout* lheat, int N, int h, int w,
-               const rtpose_decode_cfg* cfg, void* result, hipStream_t s, int flags) {
+               const rtpose_decode_cfg* cfg, void* result, hipStream_t s, int flags, bool with_ids) {
   int rc = check_cfg(cfg);
   if (rc) return rc;
   if (N <= 0 || h <= 0 || w <= 0) return fail(RTPOSE_E_INVAL, "decode: empty batch");
@@ -1011,8 +1103,9 @@ int nms_launch(const float* heat, const rtpose_layout* lheat, int N, int h, int 
                        h, w, cfg->upsample, 1.0 / (double)cfg->upsample, cfg->thresh_heatmap,
                        cfg->max_peaks_per_part, res, words);
   }
-  hipLaunchKernelGGL(peak_prefix_kernel, dim3(N), dim3(64), 0, s, cfg->max_peaks_per_part, res, words,
-                     cfg->num_keypoints);
+  if (with_ids)  // (a full decode writes the ids and the peak total in group_kernel<true> instead: one launch less)
+    hipLaunchKernelGGL(peak_prefix_kernel, dim3(N), dim3(64), 0, s, cfg->max_peaks_per_part, res, words,
+                       cfg->num_keypoints);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -1020,7 +1113,7 @@ int nms_launch(const float* heat, const rtpose_layout* lheat, int N, int h, int 
 // assignment + grouping on peak tables already in `result`
 int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int h, int w, double inv_up,
                         int h1, const rtpose_decode_cfg* cfg, void* workspace, size_t workspace_bytes,
-                        void* result, hipStream_t s) {
+                        void* result, hipStream_t s, bool write_ids) {
   if (workspace_bytes < decode_workspace_bytes(cfg, N))
     return fail(RTPOSE_E_INVAL, "decode: workspace too small");
   const int pcap = cfg->max_peaks_per_part;
@@ -1049,8 +1142,10 @@ int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int 
                                    reinterpret_cast<const void*>(limb_assign_kernel<false, false, false>)};
     for (const void* k : limb_kernels)
       RTPOSE_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_set.set(dev);
   }
   const int up = cfg->upsample;
@@ -1084,9 +1179,15 @@ int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int 
 #undef RTPOSE_LIMB
   }
   const int row_cap = decode_row_cap(cfg);
-  const size_t rows_lds = row_cap <= kLdsRows ? (size_t)row_cap * 21 * sizeof(float) : 0;
-  hipLaunchKernelGGL(group_kernel, dim3(N), dim3(64), rows_lds, s, pcap, cfg->max_humans, res, words, conn,
-                     conn_words, row_cap, rows_ws);
+  // subset rows (when they fit) + the staged connections of one limb (at most pcap of them)
+  const size_t rows_lds = (row_cap <= kLdsRows ? (size_t)row_cap * 21 * sizeof(float) : 0) +
+                          (size_t)pcap * kStageWords * sizeof(float);
+  if (write_ids)
+    hipLaunchKernelGGL(group_kernel<true>, dim3(N), dim3(64), rows_lds, s, pcap, cfg->max_humans, res, words, conn,
+                       conn_words, row_cap, rows_ws);
+  else
+    hipLaunchKernelGGL(group_kernel<false>, dim3(N), dim3(64), rows_lds, s, pcap, cfg->max_humans, res, words, conn,
+                       conn_words, row_cap, rows_ws);
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -1115,7 +1216,7 @@ int rtpose_nms_batch_ex(const float* heat, const rtpose_layout* lheat, int N, in
   int rcd = c_heat.check(heat, dev, "nms", "the heat-map tensor");
   if (!rcd) rcd = c_res.check(result, dev, "nms", "the result block");
   if (rcd) return rcd;
-  return nms_launch(heat, lheat, N, h, w, cfg, result, as_stream(stream), nms_flags);
+  return nms_launch(heat, lheat, N, h, w, cfg, result, as_stream(stream), nms_flags, /*with_ids=*/true);
 }
 
 int rtpose_nms_batch(const float* heat, const rtpose_layout* lheat, int N, int h, int w,
@@ -1149,10 +1250,10 @@ int rtpose_decode_batch_ex(const float* heat, const rtpose_layout* lheat, const 
   if (!rcd) rcd = c_ws.check(workspace, dev, "decode", "the workspace");
   if (!rcd) rcd = c_res.check(result, dev, "decode", "the result block");
   if (rcd) return rcd;
-  int rc = nms_launch(heat, lheat, N, h, w, cfg, result, as_stream(stream), nms_flags);
+  int rc = nms_launch(heat, lheat, N, h, w, cfg, result, as_stream(stream), nms_flags, /*with_ids=*/false);
   if (rc) return rc;
   return assign_group_launch(paf, lpaf, N, h, w, 1.0 / (double)cfg->upsample, h * cfg->upsample, cfg,
-                             workspace, workspace_bytes, result, as_stream(stream));
+                             workspace, workspace_bytes, result, as_stream(stream), /*write_ids=*/true);
 }
 
 }  // extern "C"

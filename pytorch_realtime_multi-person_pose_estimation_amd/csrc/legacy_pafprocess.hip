@@ -134,7 +134,7 @@ int process_paf(int p1, int p2, int p3, float* peaks, int h1, int h2, int h3, fl
     lp.hs = f1;
     lp.lead = 0;
     rc = assign_group_launch(static_cast<const float*>(S.d_paf), &lp, 1, f1, f2, 1.0, h1, &cfg, S.d_ws,
-                             S.ws_bytes, S.d_res, nullptr);
+                             S.ws_bytes, S.d_res, nullptr, /*write_ids=*/false);
     if (rc) return rc;
     RTPOSE_HIP_CHECK(hipMemcpy(host.data(), S.d_res, (size_t)words * 4, hipMemcpyDeviceToHost));
     if (host[kResHeader + 2] & kOverflowHumans) {

@@ -56,6 +56,32 @@ def test_parse_record_roundtrip_and_humans(dec):
     assert "BodyPart:" in str(h0)
 
 
+def test_result_mask_covers_what_a_record_says_and_nothing_else(dec):
+    """decode.result_mask: the words of a record block that carry results.  bench.py and the GPU soak compare blocks through
+    it (scratch behind the counts differs from run to run): any change of a meaningful word must show, scratch must not."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "post_scenes.npz"))
+    cfg = dec.make_cfg(None, 32, 16)
+    rec = _pack_record(dec, cfg, z["jl3"], z["parts3"], z["score3"])
+    rec[3], rec[4] = 32, 16                       # the capacities a device record carries in its header
+    blk = np.stack([rec, rec])
+    m = dec.result_mask(blk)
+    nh, npk = len(z["parts3"]), len(z["jl3"])
+    assert m.shape == blk.shape and m[0].sum() == 5 + 18 + 4 * npk + 18 * nh + nh
+    rng = np.random.default_rng(0)
+    junk = blk.copy()
+    junk[~m] = rng.integers(-2 ** 31, 2 ** 31 - 1, (~m).sum())             # scratch behind the counts
+    assert np.array_equal(junk[m], blk[m])
+    parsed = dec.parse_image(junk[1])
+    assert np.array_equal(parsed["peaks"], z["jl3"]) and np.array_equal(parsed["score"], z["score3"])
+    for w in np.flatnonzero(m[0])[::7]:                                    # any meaningful word
+        other = blk.copy()
+        other[0, w] ^= 1
+        assert not np.array_equal(other[m], blk[m])
+    more = blk.copy()
+    more[1, 1] += 1                                                        # a count that grew is seen through either mask
+    assert not np.array_equal(more[m], blk[m]) and not np.array_equal(more[dec.result_mask(more)], blk[dec.result_mask(more)])
+
+
 def test_state_dict_surface_matches_reference_names(pkg):
     m = pkg.get_model('vgg19')
     sd = m.state_dict()

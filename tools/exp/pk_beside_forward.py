@@ -44,7 +44,7 @@ def main(steps, dtypes):
             with torch.cuda.stream(compute):
                 m.forward_native(x, keep_intermediates=False)
             torch.cuda.synchronize()
-        for variant in (0, 1, 2, 3, 4, 5):
+        for variant in (() if os.environ.get('ONLY_WAR') else (0, 1, 2, 3, 4, 5)):
             hist = torch.zeros(65, dtype=torch.int32, device=dev)
             detail = torch.zeros(64 * 8, dtype=torch.int32, device=dev)
             torch.cuda.synchronize()
@@ -69,6 +69,41 @@ def main(steps, dtypes):
             for r in d:
                 print("    block %d lane %d sample %d round %d: packed (%d, %d) scalar (%d, %d)" % (r[0], r[1] & 63, r[2], r[7], r[3], r[4], r[5], r[6]))
             out["%s/%d" % (dt, variant)] = {"mismatches": int(h[64]), "lanes": lanes}
+        # address-register WAR victim (tools/exp/vmem_war_victim.hip): 8 loads, then their offset registers are overwritten
+        if os.path.exists(os.path.join(ROOT, "tools", "exp", "vmem_war_victim.so")) and not os.environ.get("SKIP_WAR"):
+            wv = C.CDLL(os.path.join(ROOT, "tools", "exp", "vmem_war_victim.so"))
+            wv.war_victim_launch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]
+            words = 46 * 46 * 57 * 16          # the size of a 16-image map buffer
+            table = torch.cat([torch.arange(words, dtype=torch.int32),
+                               (torch.arange(words, dtype=torch.int64) | 0xBAD00000).to(torch.int32)]).to(dev)
+            for gap in (0, 2, 8, 32):
+                for act in (49, 64, 256):
+                    hist = torch.zeros(65, dtype=torch.int32, device=dev)
+                    detail = torch.zeros(64 * 4, dtype=torch.int32, device=dev)
+                    torch.cuda.synchronize()
+                    t0 = time.time()
+                    for k in range(steps):
+                        if dt != "none":
+                            with torch.cuda.stream(compute):
+                                m.forward_native(x, keep_intermediates=False)
+                        for _ in range(L):
+                            rc = wv.war_victim_launch(gap, blocks, act, rounds, table.data_ptr(), words, words * 4,
+                                                      hist.data_ptr(), detail.data_ptr(), side.cuda_stream)
+                            assert rc == 0, rc
+                        if k % 8 == 7:
+                            torch.cuda.synchronize()
+                    torch.cuda.synchronize()
+                    h = hist.cpu().numpy()
+                    lanes = {i: int(h[i]) for i in range(64) if h[i]}
+                    print("%s WAR victim gap %d active %d: %d wrong loads in %d steps x %d launches x %d blocks x %d lanes x %d x 8 "
+                          "loads; lanes %s; %.1f s" % (dt, gap, act, int(h[64]), steps, L, blocks, act, rounds, lanes, time.time() - t0), flush=True)
+                    dd = detail.cpu().numpy().reshape(64, 4)[:min(int(h[64]), 4)]
+                    for r in dd:
+                        print("    thread %d load %d round %d: got 0x%08x want 0x%08x" % (r[0], r[1] & 255, r[1] >> 8, r[2] & 0xffffffff, r[3] & 0xffffffff))
+                    out["%s/war/%d/%d" % (dt, gap, act)] = {"mismatches": int(h[64]), "lanes": lanes}
+        if os.environ.get("ONLY_WAR"):
+            continue
         # the scoring loop itself (tools/exp/limb_victim.hip), SLP-vectorised and not: every launch against the same launch alone
         for build in ("slp", "noslp"):
             lv = C.CDLL(os.path.join(ROOT, "tools", "exp", "limb_victim_%s.so" % build))
