@@ -153,6 +153,18 @@ int rtpose_conv_first_planes(const float* x_nchw, const float* x_layout, const r
                              const float* w_packed, float* out, const rtpose_layout* lout, int out_plane_pixels,
                              int relu, int N, int H, int W, void* stream);
 
+/* The same layer in the bf16 plan's arithmetic (BASELINE configs[2]; round 6): image and filters rounded to bf16 (round to
+ * nearest even - what the plan's input conversion and rtpose_pack_conv_weights_bf16 do), products exact, fp32 accumulation,
+ * + fp32 bias (+ReLU), output rounded to bf16.  `out` holds bf16 elements, `lout` counts them (cstride and choff multiples
+ * of 8: a lane stores the 8 channels of a 16-byte piece); `w_packed` from rtpose_pack_conv_first_bf16 (the same
+ * rtpose_conv_first_packed_floats() floats, filters rounded).  The source is fp32 either way - the image or an fp32 layout
+ * buffer: the plan's NCHW -> bf16 NHWC16 conversion launch and its generic 16-channel conv1_1 are both replaced by this one
+ * (the product of two bf16 values is exact in fp32, so the fp32 matrix instruction on rounded operands is this arithmetic). */
+int rtpose_pack_conv_first_bf16(const float* w_oihw, const float* bias, float* w_packed, void* stream);
+int rtpose_conv_first_bf16(const float* x_nchw, const float* x_layout, const rtpose_layout* lx,
+                           const float* w_packed, void* out_bf16, const rtpose_layout* lout, int relu, int N,
+                           int H, int W, void* stream);
+
 /* ---- two pointwise convs back to back: nn.Conv2d(128, 128, 1) + nn.ReLU -> nn.Conv2d(128, cout2 <= 64, 1), the
  * Mconv6 / Mconv7 pair that ends every stage-2..6 branch (lib/network/rtpose_vgg.py:120-127), as ONE launch
  * (csrc/conv_tail.hip; `ngroups` <= 2 branches per grid).  d1[g] / d2[g] are rtpose_conv_desc of the two convs
@@ -561,11 +573,13 @@ int rtpose_net_device_status(rtpose_net* net, int* error_word, void* stream);
 int rtpose_net_set_persistent7(rtpose_net* net, int enable);
 /* A consumer that reads the stage-6 maps where the net wrote them (rtpose_net_output_view) on ANOTHER stream - the pose
  * decoder of batch k under the forward of batch k + 1 - hands in the HIP event it records behind its last read: every
- * later forward of the plan waits for that event (hipStreamWaitEvent on the forward's stream) before its first launch
- * that writes the maps' buffer, and for nothing else (fp32 plans).  bf16 / bf16x3 plans - and fp32 ones under
- * RTPOSE_GUARD_WHOLE_FORWARD=1 - wait in FRONT of their launch list: a decoder running beside the bf16 MFMA kernels
- * returned a limb score one sample off in ~1 % of the batches, cause not found, so it never does.
- * NULL = no guard.  The event must have been recorded. */
+ * later forward of the plan waits for that event (hipStreamWaitEvent on the forward's stream) in front of its first launch
+ * that writes the maps' buffer, and for nothing else (fp32: conv4_4_CPM, which writes the out1 channels of the same concat
+ * buffer - the reader runs beside the trunk; bf16 / bf16x3: the last launch).  RTPOSE_GUARD_WHOLE_FORWARD=1 in the
+ * environment moves the wait in FRONT of the launch list (the reader never beside this plan's kernels; 1 % slower).
+ * The guard stays installed until it is replaced or removed: NULL = no guard.  The event must have been recorded and must
+ * outlive the guard.  (History, DESIGN.md 3.3: a decoder built with packed-fp32 VALU instructions returned wrong limb scores
+ * beside the bf16 plan's kernels; the library's decoder is built without them.) */
 int rtpose_net_set_output_guard(rtpose_net* net, void* hip_event);
 int rtpose_net_persistent7(const rtpose_net* net);
 /* The same without the wait: queues the copy of the error word into *host_word (pinned host memory, or the copy

@@ -106,6 +106,8 @@ _SIGS = {
     "rtpose_pack_conv_first": (_i, [_vp, _vp, _vp, _vp]),
     "rtpose_conv_first": (_i, [_vp, _vp, _LP, _vp, _vp, _LP, _i, _i, _i, _i, _vp]),
     "rtpose_conv_first_planes": (_i, [_vp, _vp, _LP, _vp, _vp, _LP, _i, _i, _i, _i, _i, _vp]),
+    "rtpose_pack_conv_first_bf16": (_i, [_vp, _vp, _vp, _vp]),
+    "rtpose_conv_first_bf16": (_i, [_vp, _vp, _LP, _vp, _vp, _LP, _i, _i, _i, _i, _vp]),
     "rtpose_conv2d_winograd_fits": (_i, [C.POINTER(ConvDesc), _i, _i, _i]),
     "rtpose_packed_weight_floats_winograd": (_sz, [_i, _i, _i]),
     "rtpose_pack_conv_weights_winograd": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),

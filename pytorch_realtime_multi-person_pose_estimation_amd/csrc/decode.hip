@@ -62,9 +62,10 @@ __device__ __forceinline__ int find_peaks_block(const MapView& heat, int n, int 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int base = 0;
   const int npix = h * w;
-  // Round 6: the centre and its four neighbours of kPeakBatch sweeps are requested up front, unconditionally (border
-  // neighbours clamped to the pixel itself and ignored): one global round trip per batch instead of two dependent ones per
-  // sweep, one pair of barriers per batch instead of per sweep.  The tests are the ones of the sweep-by-sweep form.
+  // Round 6: the CENTRE values of kPeakBatch sweeps are requested together (one global round trip per batch instead of one
+  // per sweep), then the four neighbours of the few pixels above the threshold - still only of those: fetching them for every
+  // pixel cost five times the loads and made the kernel slower (33 -> 43 us at batch 32) - again all sweeps' requests before
+  // the first value is used; one pair of barriers per batch instead of per sweep.  The tests are the sweep-by-sweep form's.
   for (int start = 0; start < npix; start += 256 * kPeakBatch) {
     float v[kPeakBatch], vu[kPeakBatch], vd[kPeakBatch], vl[kPeakBatch], vr[kPeakBatch];
     int xs[kPeakBatch], ys[kPeakBatch];
@@ -75,10 +76,17 @@ __device__ __forceinline__ int find_peaks_block(const MapView& heat, int n, int 
       ys[b] = y;
       xs[b] = x;
       v[b] = map_at(heat, n, y, x, part);
-      vu[b] = map_at(heat, n, max(y - 1, 0), x, part);
-      vd[b] = map_at(heat, n, min(y + 1, h - 1), x, part);
-      vl[b] = map_at(heat, n, y, max(x - 1, 0), part);
-      vr[b] = map_at(heat, n, y, min(x + 1, w - 1), part);
+    }
+#pragma unroll
+    for (int b = 0; b < kPeakBatch; ++b) {
+      vu[b] = vd[b] = vl[b] = vr[b] = 0.f;
+      if (start + 256 * b + tid < npix && v[b] > thr) {  // (border neighbours: the pixel itself, ignored below)
+        const int y = ys[b], x = xs[b];
+        vu[b] = map_at(heat, n, max(y - 1, 0), x, part);
+        vd[b] = map_at(heat, n, min(y + 1, h - 1), x, part);
+        vl[b] = map_at(heat, n, y, max(x - 1, 0), part);
+        vr[b] = map_at(heat, n, y, min(x + 1, w - 1), part);
+      }
     }
     bool pk[kPeakBatch];
     unsigned long long mask[kPeakBatch];
@@ -888,8 +896,11 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
 // the serial walk then touches LDS only (round 5: three dependent global loads per connection, ~1.6 us each step: 164 us per
 // batch whatever its size; now ~20).  WRITE_IDS: the running peak ids of paf_to_pose.py:141-142 (the former peak_prefix_kernel
 // launch) are written here - and taken arithmetically, id = s_start[part] + index, instead of read back.
+// STAGE_ALL: the connections of ALL 19 limbs are staged in one sweep over the flattened (limb, connection) list - every
+// global round trip of the kernel is then taken once, with all lanes' loads in flight together, instead of once per limb (the
+// host picks it when 19 * pcap staged connections fit the LDS next to the rows: pcap <= 128).
 constexpr int kStageWords = 5;  // per staged connection: cid1, cid2, connection score, score of peak 2, score of peak 1
-template <bool WRITE_IDS>
+template <bool WRITE_IDS, bool STAGE_ALL>
 __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* __restrict__ result,
                                                    int result_words, const int32_t* __restrict__ conn,
                                                    int conn_words, int row_cap,
@@ -929,30 +940,58 @@ __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* 
   };
   const int npeaks = s_start[RTPOSE_NUM_PART];
 
+  // everything the walk needs from global memory about connection c of limb `limb`, into st[0 .. kStageWords)
+  auto stage_conn = [&](int limb, int c, float* st) {
+    const int part1 = kPairs[limb][0], part2 = kPairs[limb][1];
+    const int32_t* cn = cnb + (size_t)limb * (1 + 3 * pcap);
+    const rtpose_peak* pA = peaks + (size_t)part1 * pcap;
+    const rtpose_peak* pB = peaks + (size_t)part2 * pcap;
+    const int ia = cn[1 + 3 * c], ib = cn[1 + 3 * c + 1];
+    const int id1 = WRITE_IDS ? s_start[part1] + ia : pA[ia].id;
+    const int id2 = WRITE_IDS ? s_start[part2] + ib : pB[ib].id;
+    st[0] = (float)id1;
+    st[1] = (float)id2;
+    st[2] = __int_as_float(cn[1 + 3 * c + 2]);
+    st[3] = (id2 >= 0 && id2 < npeaks) ? (WRITE_IDS ? pB[ib].score : line_peak_score(id2)) : 0.f;
+    st[4] = (id1 >= 0 && id1 < npeaks) ? (WRITE_IDS ? pA[ia].score : line_peak_score(id1)) : 0.f;
+  };
+  __shared__ int s_cbase[RTPOSE_NUM_LIMB + 1];
+  if (STAGE_ALL) {
+    if (lane < RTPOSE_NUM_LIMB) s_cbase[lane + 1] = cnb[(size_t)lane * (1 + 3 * pcap)];
+    __syncthreads();
+    if (lane == 0) {
+      s_cbase[0] = 0;
+      for (int l = 0; l < RTPOSE_NUM_LIMB; ++l) s_cbase[l + 1] += s_cbase[l];
+    }
+    __syncthreads();
+    const int total = s_cbase[RTPOSE_NUM_LIMB];
+    for (int i = lane; i < total; i += 64) {
+      int limb = 0;
+      while (i >= s_cbase[limb + 1]) ++limb;
+      stage_conn(limb, i - s_cbase[limb], stage + (size_t)i * kStageWords);
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+
   int nrows = 0;
   bool overflow = false;
   for (int pair_id = 0; pair_id < 19; ++pair_id) {
     const int part1 = kPairs[pair_id][0], part2 = kPairs[pair_id][1];
-    const int32_t* cn = cnb + (size_t)pair_id * (1 + 3 * pcap);
-    const int nconn = cn[0];
-    const rtpose_peak* pA = peaks + (size_t)part1 * pcap;
-    const rtpose_peak* pB = peaks + (size_t)part2 * pcap;
-    // stage the limb's connections: everything the walk needs from global memory, 64 connections in flight at a time
-    for (int c = lane; c < nconn; c += 64) {
-      const int ia = cn[1 + 3 * c], ib = cn[1 + 3 * c + 1];
-      const int id1 = WRITE_IDS ? s_start[part1] + ia : pA[ia].id;
-      const int id2 = WRITE_IDS ? s_start[part2] + ib : pB[ib].id;
-      float* st = stage + (size_t)c * kStageWords;
-      st[0] = (float)id1;
-      st[1] = (float)id2;
-      st[2] = __int_as_float(cn[1 + 3 * c + 2]);
-      st[3] = (id2 >= 0 && id2 < npeaks) ? (WRITE_IDS ? pB[ib].score : line_peak_score(id2)) : 0.f;
-      st[4] = (id1 >= 0 && id1 < npeaks) ? (WRITE_IDS ? pA[ia].score : line_peak_score(id1)) : 0.f;
+    int nconn;
+    const float* lst = stage;
+    if (STAGE_ALL) {
+      nconn = s_cbase[pair_id + 1] - s_cbase[pair_id];
+      lst = stage + (size_t)s_cbase[pair_id] * kStageWords;
+    } else {
+      // stage this limb's connections, 64 in flight at a time
+      nconn = cnb[(size_t)pair_id * (1 + 3 * pcap)];
+      for (int c = lane; c < nconn; c += 64) stage_conn(pair_id, c, stage + (size_t)c * kStageWords);
+      __threadfence_block();
+      __syncthreads();
     }
-    __threadfence_block();
-    __syncthreads();
     for (int c = 0; c < nconn; ++c) {
-      const float* st = stage + (size_t)c * kStageWords;
+      const float* st = lst + (size_t)c * kStageWords;
       const float cid1 = st[0], cid2 = st[1], cscore = st[2], s2 = st[3];
       // search alive rows in order
       int found = 0, idx1 = 0, idx2 = 0;
@@ -1142,10 +1181,12 @@ int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int 
                                    reinterpret_cast<const void*>(limb_assign_kernel<false, false, false>)};
     for (const void* k : limb_kernels)
       RTPOSE_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_kernel<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    const void* group_kernels[4] = {reinterpret_cast<const void*>(group_kernel<true, true>),
+                                    reinterpret_cast<const void*>(group_kernel<true, false>),
+                                    reinterpret_cast<const void*>(group_kernel<false, true>),
+                                    reinterpret_cast<const void*>(group_kernel<false, false>)};
+    for (const void* k : group_kernels)
+      RTPOSE_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     attr_set.set(dev);
   }
   const int up = cfg->upsample;
@@ -1179,15 +1220,19 @@ int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int 
 #undef RTPOSE_LIMB
   }
   const int row_cap = decode_row_cap(cfg);
-  // subset rows (when they fit) + the staged connections of one limb (at most pcap of them)
-  const size_t rows_lds = (row_cap <= kLdsRows ? (size_t)row_cap * 21 * sizeof(float) : 0) +
-                          (size_t)pcap * kStageWords * sizeof(float);
-  if (write_ids)
-    hipLaunchKernelGGL(group_kernel<true>, dim3(N), dim3(64), rows_lds, s, pcap, cfg->max_humans, res, words, conn,
-                       conn_words, row_cap, rows_ws);
-  else
-    hipLaunchKernelGGL(group_kernel<false>, dim3(N), dim3(64), rows_lds, s, pcap, cfg->max_humans, res, words, conn,
-                       conn_words, row_cap, rows_ws);
+  // subset rows (when they fit) + the staged connections: of all 19 limbs when that fits beside the rows, else of one limb
+  const size_t rows_bytes = row_cap <= kLdsRows ? (size_t)row_cap * 21 * sizeof(float) : 0;
+  const size_t all_bytes = (size_t)RTPOSE_NUM_LIMB * pcap * kStageWords * sizeof(float);
+  const bool stage_all = rows_bytes + all_bytes <= 96 * 1024;
+  const size_t rows_lds = rows_bytes + (stage_all ? all_bytes : (size_t)pcap * kStageWords * sizeof(float));
+#define RTPOSE_GROUP(W, S)                                                                                               \
+  hipLaunchKernelGGL((group_kernel<W, S>), dim3(N), dim3(64), rows_lds, s, pcap, cfg->max_humans, res, words, conn, \
+                     conn_words, row_cap, rows_ws)
+  if (write_ids && stage_all) RTPOSE_GROUP(true, true);
+  else if (write_ids) RTPOSE_GROUP(true, false);
+  else if (stage_all) RTPOSE_GROUP(false, true);
+  else RTPOSE_GROUP(false, false);
+#undef RTPOSE_GROUP
   RTPOSE_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -46,9 +46,10 @@ int conv_tail_launch(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int
                      hipStream_t s);
 // conv1_1 (conv_first.hip)
 size_t conv_first_packed_floats();
-int conv_first_pack_launch(const float* w_oihw, const float* bias, float* wp, hipStream_t s);
+int conv_first_pack_launch(const float* w_oihw, const float* bias, float* wp, hipStream_t s, int to_bf16);
 int conv_first_launch(const float* x_nchw, const float* x_lay, const rtpose_layout* lx, const float* wp, float* out,
-                      const rtpose_layout* lo, int out_plane_pixels, int relu, int N, int H, int W, hipStream_t s);
+                      const rtpose_layout* lo, int out_plane_pixels, int relu, int N, int H, int W, hipStream_t s,
+                      int out_bf16);
 int pack_weights_launch(const float* w, const float* bias, int cout, int cin_src, int k,
                         const int32_t* cin_map, int cin_packed, float* wp, float* bp, hipStream_t s);
 // bf16 path (conv_mfma_bf16.hip)
@@ -225,6 +226,10 @@ int add_conv_w(rtpose_net* n, const std::string& name, int cout, int cin, int k,
   if (n->bf16) {
     c.w_off = take(n->split ? rtpose_packed_weight_bytes_bf16x3(cout, c.cin_packed, k) / 4
                             : rtpose_packed_weight_bytes_bf16(cout, c.cin_packed, k) / 4);
+    // bf16 plans (not the split ones): conv1_1 has its own kernel too (conv_first.hip MODE 2: reads the fp32 image, rounds it
+    // and the filters to bf16, writes bf16) - the generic packing above stays in the arena for rtpose_net_conv introspection
+    c.first = !n->split && k == 3 && cin == 3 && cout == 64;
+    if (c.first) c.w_off_first = take(conv_first_packed_floats());
   } else {
     // The weight arena is shared by every plan of a module (any N x H x W, any rtpose_net_options), so its layout
     // depends on the channel counts only: the direct packing, plus every Winograd packing that has a kernel.
@@ -761,9 +766,14 @@ int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw, const fl
   const ConvW& c = net->convs[idx];
   const int32_t* map = c.cat_perm ? reinterpret_cast<const int32_t*>(net->wt + net->catmap_off) : nullptr;
   hipStream_t s = as_stream(stream);
-  if (net->bf16)
+  if (net->bf16) {
+    if (c.first) {
+      const int rcf = conv_first_pack_launch(w_oihw, bias, net->wt + c.w_off_first, s, 1);
+      if (rcf) return rcf;
+    }
     return pack_weights_bf16_launch(w_oihw, bias, c.cout, c.cin_src, c.k, map, c.cin_packed,
                                     net->wt + c.w_off, net->wt + c.b_off, net->split, s);
+  }
   // every packing the arena holds for this conv (the plans that share the arena choose among them), and the
   // amplification estimate of each Winograd form; every plan on this arena re-reads them (sync_arena_generation)
   arena_bump(net->wt);
@@ -773,7 +783,7 @@ int rtpose_net_load_conv(rtpose_net* net, int idx, const float* w_oihw, const fl
                                net->wt + c.b_off, s);
   if (rc) return rc;
   if (c.first) {
-    rc = conv_first_pack_launch(w_oihw, bias, net->wt + c.w_off_first, s);
+    rc = conv_first_pack_launch(w_oihw, bias, net->wt + c.w_off_first, s, 0);
     if (rc) return rc;
   }
   float* amp = net->wt + c.amp_off;
@@ -961,7 +971,7 @@ int rtpose_net_launch_executed_flops(const rtpose_net* net, int i, double* flops
     for (int g = 0; g < o.ngroups; ++g) {
       // what the matrix pipe is issued (SQ_INSTS_MFMA x 4096 of a launch): whole tiles, padded channels and columns
       const ConvW& c = net->convs[o.conv_idx[g]];
-      if (c.first && !net->bf16) {  // conv_first_kernel: 8 x 32 pixel tiles, K = 28 (27 taps + a zero row), 64 columns
+      if (c.first) {  // conv_first_kernel (fp32 and bf16 plans: the fp32 matrix instruction either way): 8 x 32 pixel tiles, K = 28 (27 taps + a zero row), 64 columns
         fl += 2.0 * net->N * ceil_div(o.H, 8) * ceil_div(o.W, 32) * 256.0 * 28.0 * 64.0;
       } else if (c.form == 3) {         // 16 frequencies per 2 x 2 wtile
         fl += conv2d_wino_issued_flops(c.cin_packed, c.cout, net->N, o.H, o.W);
@@ -1140,6 +1150,19 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
     switch (o.kind) {
       case OP_INPUT: {
         const Buf& b = net->bufs[o.out_buf[0]];
+        if (net->bf16 && !net->split) {
+          // conv1_1 of the bf16 plan reads fp32 itself (conv_first.hip MODE 2): the image where the caller left it when it
+          // runs in the same call, else the plan's fp32 NHWC8 staging buffer (forward_prepared: filled by the caller; graph
+          // replay: filled here) - the NCHW -> bf16 NHWC16 conversion launch is gone
+          if (!x_nchw) break;
+          bool first_reads_image = false;
+          for (size_t j = first + 1; j < last && !first_reads_image; ++j)
+            first_reads_image = net->ops[j].kind == OP_CONV && net->convs[net->ops[j].conv_idx[0]].first;
+          if (first_reads_image) break;
+          const Buf& bs = net->bufs[net->x0f_buf];
+          rc = rtpose_nchw_to_layout(x_nchw, net->ws + bs.off_floats, &bs.lay, 3, 8, N, o.H, o.W, stream);
+          break;
+        }
         if (net->bf16) {
           rtpose_layout lb = b.lay;
           if (net->split) lb.cstride *= 2;  // elements
@@ -1203,11 +1226,17 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
           d[g].pool = o.pool;
           d[g].out_cmap = nullptr;
         }
-        if (!net->bf16 && net->convs[o.conv_idx[0]].first) {
+        if (net->convs[o.conv_idx[0]].first) {
           const ConvW& c = net->convs[o.conv_idx[0]];
           const bool direct_src = x_nchw && first == 0;  // the image itself; else the plan's NHWC8 input buffer
+          if (net->bf16) {  // (fp32 source: the staging buffer, not this conv's bf16 input buffer)
+            const Buf& bs = net->bufs[net->x0f_buf];
+            rc = conv_first_launch(direct_src ? x_nchw : nullptr, net->ws + bs.off_floats, &bs.lay, net->wt + c.w_off_first,
+                                   d[0].out, &d[0].lout, 0, o.relu, N, o.H, o.W, s, 1);
+            break;
+          }
           rc = conv_first_launch(direct_src ? x_nchw : nullptr, d[0].in, &d[0].lin, net->wt + c.w_off_first, d[0].out,
-                                 &d[0].lout, d[0].out_plane_pixels, o.relu, N, o.H, o.W, s);
+                                 &d[0].lout, d[0].out_plane_pixels, o.relu, N, o.H, o.W, s, 0);
           break;
         }
         const int form = net->convs[o.conv_idx[0]].form;  // grouped convs run one form (pick_forms)

@@ -177,6 +177,51 @@ def test_conv_bf16_aligned_slices_take_the_16_byte_store_epilogues(capi, cuda, c
         _check(o, r, False)
 
 
+@pytest.mark.parametrize("shape,src", [((2, 64, 72), "nchw"), ((1, 37, 45), "nchw"), ((1, 37, 45), "layout"),
+                                       ((2, 368, 368), "nchw")])
+def test_first_layer_bf16_kernel_matches_the_emulation(capi, cuda, shape, src):
+    """rtpose_conv_first_bf16 (round 6: conv1_1 of the bf16 plan on the fp32 matrix instruction, image and filters rounded to
+    bf16, read from the NCHW image or an fp32 layout buffer, bf16 out): within one bf16 ulp of conv2d on the rounded operands
+    in double, > 98 % of the outputs equal to its RNE rounding (the contract of the generic bf16 kernel, `_check`); nothing
+    written outside the 64-channel slice; agrees with the generic kernel on 16 padded channels to one bf16 ulp."""
+    lib, Layout = capi.lib, capi.Layout
+    n, h, w = shape
+    g = torch.Generator().manual_seed(h * 977 + w)
+    x = torch.rand(n, 3, h, w, generator=g) - 0.5                      # NOT pre-rounded: the kernel rounds
+    wd = torch.randn(64, 3, 3, 3, generator=g) * (2.0 / 27) ** 0.5
+    bd = torch.randn(64, generator=g) * 0.1
+    ref = F.relu(F.conv2d(_rb(x).double(), _rb(wd).double(), bd.double(), padding=1).float())
+    stream = capi.current_stream()
+    xd, wdd, bdd = x.to(cuda), wd.to(cuda), bd.to(cuda)
+    wp = torch.zeros(lib.rtpose_conv_first_packed_floats(), device=cuda)
+    capi.check(lib.rtpose_pack_conv_first_bf16(capi.ptr(wdd), capi.ptr(bdd), capi.ptr(wp), stream))
+    cs, ch0 = 64 + 16, 8                                               # a 16-byte aligned slice of a wider buffer
+    lo = Layout.padded(cs, h, w, 1, choff=ch0)
+    q = lib.rtpose_layout_pixels(C.byref(lo), n, h, w)
+    obuf = torch.zeros(q * cs, device=cuda, dtype=torch.bfloat16)
+    xin = lin = None
+    if src == "layout":                                                # the plan's fp32 NHWC8 staging buffer
+        lin = Layout.padded(8, h, w, 1)
+        xin = torch.zeros(lib.rtpose_layout_pixels(C.byref(lin), n, h, w) * 8, device=cuda)
+        capi.check(lib.rtpose_nchw_to_layout(capi.ptr(xd), capi.ptr(xin), C.byref(lin), 3, 8, n, h, w, stream))
+    capi.check(lib.rtpose_conv_first_bf16(capi.ptr(xd) if src == "nchw" else None, capi.ptr(xin) if xin is not None else None,
+                                          C.byref(lin) if lin is not None else None, capi.ptr(wp), capi.ptr(obuf), C.byref(lo), 1,
+                                          n, h, w, stream), "rtpose_conv_first_bf16")
+    dense = torch.empty(n, h, w, 64, device=cuda)
+    ld = Layout.dense(64, h, w)
+    capi.check(lib.rtpose_layout_bf16_to_f32(capi.ptr(obuf), C.byref(lo), capi.ptr(dense), C.byref(ld), 64, n, h, w, stream))
+    torch.cuda.synchronize()
+    out = dense.permute(0, 3, 1, 2).contiguous().cpu()
+    _check(out, ref, False)
+    total, inner = obuf.float().abs().sum().item(), out.abs().sum().item()
+    assert abs(total - inner) <= 1e-3 * max(1.0, inner), "wrote outside its slice / into the gaps"
+    if (n, h, w) == (2, 64, 72):                                       # the launch it replaces in the plan
+        outs, _ = _run_conv_bf16(capi, cuda, n, h, w, 3, 64, 3, 1, 0, 1, 1, seed=5, cin_pad=16, aligned=True)
+        assert outs[0].shape == out.shape                               # (other data: only the geometry is shared)
+    assert lib.rtpose_conv_first_bf16(capi.ptr(xd), None, None, capi.ptr(wp), capi.ptr(obuf),
+                                      C.byref(Layout.padded(cs, h, w, 1, choff=4)), 1, n, h, w, stream) != 0
+
+
 def test_conv_bf16_rejects_bad_geometry(capi, cuda):
     lib = capi.lib
     d = (capi.ConvDesc * 1)()
