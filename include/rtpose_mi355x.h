@@ -363,6 +363,16 @@ int rtpose_pack_conv_weights_bf16(const float* w_oihw, const float* bias, int co
                                   void* stream);
 int rtpose_conv2d_bf16(const rtpose_conv_desc* d, int ngroups, int N, int H, int W,
                        int out_f32, void* stream);
+/* Two pointwise convs back to back in this arithmetic (round 6; csrc/conv_tail_bf16.hip - the bf16 sibling of
+ * rtpose_conv1x1_pair): nn.Conv2d(128, 128 | 512, 1) + nn.ReLU -> nn.Conv2d(128 | 512, cout2 <= 64, 1), the pair that ends every
+ * stage branch (lib/network/rtpose_vgg.py:101-105, :120-127), `ngroups` <= 2 branches per grid, as ONE launch: the
+ * intermediate is rounded to bf16 where the two-launch form rounded it and never leaves the CU.  d1[g] / d2[g] are the
+ * descs of the two convs with the k = 1 packing of rtpose_pack_conv_weights_bf16; d1[g].in / lin: 16-byte aligned bf16
+ * slice; d1[g].out is ignored; d2[g].out / lout: bf16 elements, or fp32 when out_f32 (any channel offset).  Same contract
+ * as two rtpose_conv2d_bf16 launches; the fp32 sums run in another order, so not bit for bit the same. */
+int rtpose_conv1x1_pair_bf16_fits(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int ngroups);
+int rtpose_conv1x1_pair_bf16(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int ngroups, int N,
+                             int H, int W, int out_f32, void* stream);
 /* dense NCHW fp32 -> bf16 layout slice (channels [C, cpad) zero; cpad % 8 == 0) */
 int rtpose_nchw_to_layout_bf16(const float* src_nchw, void* dst, const rtpose_layout* ldst,
                                int C, int cpad, int N, int H, int W, void* stream);

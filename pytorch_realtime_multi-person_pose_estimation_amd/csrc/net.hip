@@ -46,6 +46,8 @@ int conv_tail_launch(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int
                      hipStream_t s);
 // conv1_1 (conv_first.hip)
 size_t conv_first_packed_floats();
+int conv_tail_bf16_launch(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int ngroups, int N, int H, int W,
+                          int out_f32, hipStream_t s);
 int conv_first_pack_launch(const float* w_oihw, const float* bias, float* wp, hipStream_t s, int to_bf16);
 int conv_first_launch(const float* x_nchw, const float* x_lay, const rtpose_layout* lx, const float* wp, float* out,
                       const rtpose_layout* lo, int out_plane_pixels, int relu, int N, int H, int W, hipStream_t s,
@@ -466,11 +468,12 @@ void build_plan(rtpose_net* n) {
     T1[b] = add_buf(n, 128, 1, H3, W3);
     T2[b] = add_buf(n, 128, 1, H3, W3);
     T3[b] = add_buf(n, 128, 0, H3, W3);
-    // (fp32 plans run the trailing 1x1 pairs back to back, conv_tail.hip: their intermediates never reach HBM)
-    T4[b] = n->bf16 ? add_buf(n, 512, 0, H3, W3) : -1;
+    // (fp32 and bf16 plans run the trailing 1x1 pairs back to back, conv_tail.hip / conv_tail_bf16.hip: their intermediates
+    //  never reach HBM; the split plan keeps them)
+    T4[b] = n->split ? add_buf(n, 512, 0, H3, W3) : -1;
     for (int i = 0; i < 4; ++i) U[b][i] = add_buf(n, 128, 3, H3, W3);
     U[b][4] = add_buf(n, 128, 0, H3, W3);
-    U[b][5] = n->bf16 ? add_buf(n, 128, 0, H3, W3) : -1;
+    U[b][5] = n->split ? add_buf(n, 128, 0, H3, W3) : -1;
   }
   for (int s = 0; s < 6; ++s) n->save_buf[s] = add_buf(n, 57, 0, H3, W3, true);  // always fp32
   if (!n->bf16) {
@@ -512,8 +515,9 @@ void build_plan(rtpose_net* n) {
     ci[0] = cw1[0][2]; ci[1] = cw1[1][2];
     add_conv_op(n, H3, W3, 2, ci, T2, zz, T3, zz, 1, 0);
     const int outb[2] = {CATb, CATb};
-    if (!n->bf16) {
-      // fp32: conv5_4_CPM (128 -> 512, ReLU) + conv5_5_CPM (512 -> 38 | 19) as one back-to-back launch (conv_tail.hip)
+    if (!n->split) {
+      // fp32 and bf16: conv5_4_CPM (128 -> 512, ReLU) + conv5_5_CPM (512 -> 38 | 19) as one back-to-back launch
+      // (conv_tail.hip / conv_tail_bf16.hip); the split (bf16x3) plan keeps two launches of its generic kernel
       ci[0] = cw1[0][4]; ci[1] = cw1[1][4];
       add_conv_op(n, H3, W3, 2, ci, T3, zz, outb, head_off, 0, 0);
       Op& t = n->ops.back();
@@ -543,20 +547,24 @@ void build_plan(rtpose_net* n) {
     int u0[2] = {U[0][0], U[1][0]};
     ci[0] = cws[0][s - 2][0]; ci[1] = cws[1][s - 2][0];
     add_conv_op(n, H3, W3, 2, ci, in0, zz, u0, zz, 1, 0);
-    for (int i = 1; i < (n->bf16 ? 6 : 5); ++i) {
+    for (int i = 1; i < (n->split ? 6 : 5); ++i) {
       const int ui[2] = {U[0][i - 1], U[1][i - 1]};
       const int uo[2] = {U[0][i], U[1][i]};
       ci[0] = cws[0][s - 2][i]; ci[1] = cws[1][s - 2][i];
       add_conv_op(n, H3, W3, 2, ci, ui, zz, uo, zz, 1, 0);
     }
-    if (!n->bf16) {
-      // fp32: Mconv6 (128 -> 128, ReLU) + Mconv7 (128 -> 38 | 19) of both branches as ONE back-to-back launch
-      // (conv_tail.hip): the 128-channel intermediate never leaves the CU
+    if (!n->split) {
+      // fp32 and bf16: Mconv6 (128 -> 128, ReLU) + Mconv7 (128 -> 38 | 19) of both branches as ONE back-to-back launch
+      // (conv_tail.hip / conv_tail_bf16.hip): the 128-channel intermediate never leaves the CU.  The bf16 plan's last
+      // stage writes the fp32 record the decoder and the TTA merge read (no bf16 concat slice, no save copy).
+      const bool last_bf16 = n->bf16 && s == 6;
       const int ui4[2] = {U[0][4], U[1][4]};
-      const int outb[2] = {cout_buf, cout_buf};
+      const int outb[2] = {last_bf16 ? n->save_buf[5] : cout_buf, last_bf16 ? n->save_buf[5] : cout_buf};
+      const int off57[2] = {0, 38};
       ci[0] = cws[0][s - 2][6]; ci[1] = cws[1][s - 2][6];
-      add_conv_op(n, H3, W3, 2, ci, ui4, zz, outb, head_off, 0, 0);
+      add_conv_op(n, H3, W3, 2, ci, ui4, zz, outb, last_bf16 ? off57 : head_off, 0, 0);
       Op& t = n->ops.back();
+      t.out_f32 = last_bf16 ? 1 : 0;
       t.kind = OP_TAIL;
       t.ks = 1;
       for (int b = 0; b < 2; ++b) {
@@ -567,7 +575,8 @@ void build_plan(rtpose_net* n) {
       }
       t.name = n->convs[t.conv_idx[0]].name + "+" + n->convs[t.conv2_idx[0]].name + "|" +
                n->convs[t.conv_idx[1]].name + "+" + n->convs[t.conv2_idx[1]].name;
-      add_simple_op(n, OP_COPY, "save" + std::to_string(s), H3, W3, cout_buf, kCatPaf, n->save_buf[s - 1], 0, 57);
+      if (!last_bf16)
+        add_simple_op(n, OP_COPY, "save" + std::to_string(s), H3, W3, cout_buf, kCatPaf, n->save_buf[s - 1], 0, 57);
       continue;
     }
     const int ui[2] = {U[0][5], U[1][5]};
@@ -1273,7 +1282,8 @@ static int net_run_ops(rtpose_net* net, size_t first, size_t last, const float* 
           d2[g].out = net->ws + bo.off_floats;
           d2[g].lout = slice(bo, o.out_choff[g]);
         }
-        rc = conv_tail_launch(d1, d2, o.ngroups, N, o.H, o.W, s);
+        rc = net->bf16 ? conv_tail_bf16_launch(d1, d2, o.ngroups, N, o.H, o.W, o.out_f32, s)
+                       : conv_tail_launch(d1, d2, o.ngroups, N, o.H, o.W, s);
         break;
       }
       case OP_POOL: {

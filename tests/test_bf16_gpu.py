@@ -222,6 +222,96 @@ def test_first_layer_bf16_kernel_matches_the_emulation(capi, cuda, shape, src):
                                       C.byref(Layout.padded(cs, h, w, 1, choff=4)), 1, n, h, w, stream) != 0
 
 
+@pytest.mark.parametrize("case", [(2, 46, 46, 128, 38, 0), (2, 46, 46, 128, 19, 0), (1, 46, 49, 512, 38, 0),
+                                  (3, 23, 17, 512, 19, 1), (2, 46, 46, 128, 38, 1)])
+def test_conv1x1_pair_bf16_matches_the_two_launch_contract(capi, cuda, case):
+    """rtpose_conv1x1_pair_bf16 (round 6, csrc/conv_tail_bf16.hip): Conv2d(128, mid, 1) + ReLU -> Conv2d(mid, cout2, 1), both
+    branches in one grid, the intermediate rounded to bf16 inside the CU.  Contract = two rtpose_conv2d_bf16 launches: against
+    the emulation in double (operands rounded to bf16, the intermediate rounded to bf16) the bf16 outputs sit within two bf16
+    ulps (an intermediate that rounds the other way moves a few outputs by one more) and > 97 % equal its rounding, fp32
+    outputs within 2e-3 of the scale; it agrees with the two generic launches themselves to the same bound; nothing is
+    written outside the slices (odd channel offsets, the concat buffer's 38 | 19 split)."""
+    lib, Layout = capi.lib, capi.Layout
+    n, h, w, mid, cout2, out_f32 = case
+    g = torch.Generator().manual_seed(mid + cout2)
+    stream = capi.current_stream()
+    x = _rb(torch.randn(n, 128, h, w, generator=g))
+    lin = Layout.padded(128 + 8, h, w, 0, choff=8)
+    npx = lib.rtpose_layout_pixels(C.byref(lin), n, h, w)
+    xin = torch.zeros(npx * (128 + 8), device=cuda, dtype=torch.bfloat16)
+    capi.check(lib.rtpose_nchw_to_layout_bf16(capi.ptr(x.to(cuda)), capi.ptr(xin), C.byref(lin), 128, 128, n, h, w, stream))
+    cs_out = 57 + 7
+    lo_full = Layout.padded(cs_out, h, w, 3)
+    odt = torch.float32 if out_f32 else torch.bfloat16
+    obuf = torch.zeros(lib.rtpose_layout_pixels(C.byref(lo_full), n, h, w) * cs_out, device=cuda, dtype=odt)
+    obuf2 = torch.zeros_like(obuf)
+    tbuf_l = Layout.padded(mid, h, w, 0)
+    d1, d2 = (capi.ConvDesc * 2)(), (capi.ConvDesc * 2)()
+    refs, keep, offs = [], [], [3, 3 + cout2 if 3 + 2 * cout2 <= cs_out else 3]
+    ngroups = 2 if 3 + 2 * cout2 <= cs_out else 1
+    for gi in range(ngroups):
+        w1 = torch.randn(mid, 128, 1, 1, generator=g) * (2.0 / 128) ** 0.5
+        b1 = torch.randn(mid, generator=g) * 0.1
+        w2 = torch.randn(cout2, mid, 1, 1, generator=g) * (1.0 / mid) ** 0.5
+        b2 = torch.randn(cout2, generator=g) * 0.1
+        t = _rb(F.relu(F.conv2d(x.double(), _rb(w1).double(), b1.double()).float()))
+        refs.append(F.conv2d(t.double(), _rb(w2).double(), b2.double()).float())
+        tb = torch.zeros(lib.rtpose_layout_pixels(C.byref(tbuf_l), n, h, w) * mid, device=cuda, dtype=torch.bfloat16)
+        packs = []
+        for (wt, bs, co, ci) in ((w1, b1, mid, 128), (w2, b2, cout2, mid)):
+            wp = torch.zeros(lib.rtpose_packed_weight_bytes_bf16(co, ci, 1) // 2, device=cuda, dtype=torch.bfloat16)
+            bp = torch.zeros(lib.rtpose_packed_bias_floats(co), device=cuda)
+            capi.check(lib.rtpose_pack_conv_weights_bf16(capi.ptr(wt.to(cuda)), capi.ptr(bs.to(cuda)), co, ci, 1, None, ci,
+                                                         capi.ptr(wp), capi.ptr(bp), stream))
+            packs.append((wp, bp))
+        keep += packs + [tb]
+        a, b = d1[gi], d2[gi]
+        a.inp, a.w_packed, a.bias_packed, a.out = xin.data_ptr(), packs[0][0].data_ptr(), packs[0][1].data_ptr(), tb.data_ptr()
+        a.lin, a.lout = lin, tbuf_l
+        a.cin, a.cout, a.k, a.relu, a.pool = 128, mid, 1, 1, 0
+        b.inp, b.w_packed, b.bias_packed, b.out = tb.data_ptr(), packs[1][0].data_ptr(), packs[1][1].data_ptr(), obuf.data_ptr()
+        b.lin = tbuf_l
+        b.lout = Layout.padded(cs_out, h, w, 3, choff=offs[gi])
+        b.cin, b.cout, b.k, b.relu, b.pool = mid, cout2, 1, 0, 0
+    assert lib.rtpose_conv1x1_pair_bf16_fits(d1, d2, ngroups) == 1
+    capi.check(lib.rtpose_conv1x1_pair_bf16(d1, d2, ngroups, n, h, w, out_f32, stream), "rtpose_conv1x1_pair_bf16")
+
+    def read(buf, gi):
+        lo = Layout.padded(cs_out, h, w, 3, choff=offs[gi])
+        if out_f32:
+            o = torch.empty(n, cout2, h, w, device=cuda)
+            capi.check(lib.rtpose_layout_to_nchw(capi.ptr(buf), C.byref(lo), capi.ptr(o), cout2, n, h, w, stream))
+            return o.cpu()
+        dense = torch.empty(n, h, w, cout2, device=cuda)
+        capi.check(lib.rtpose_layout_bf16_to_f32(capi.ptr(buf), C.byref(lo), capi.ptr(dense), C.byref(Layout.dense(cout2, h, w)),
+                                                 cout2, n, h, w, stream))
+        return dense.permute(0, 3, 1, 2).contiguous().cpu()
+    fused = [read(obuf, gi) for gi in range(ngroups)]
+    # the launches it replaces: two generic bf16 launches per branch through the intermediate buffer
+    for gi in range(ngroups):
+        d2[gi].out = obuf2.data_ptr()
+        one = (capi.ConvDesc * 1)(d1[gi])
+        capi.check(lib.rtpose_conv2d_bf16(one, 1, n, h, w, 0, stream))
+        two = (capi.ConvDesc * 1)(d2[gi])
+        capi.check(lib.rtpose_conv2d_bf16(two, 1, n, h, w, out_f32, stream))
+    torch.cuda.synchronize()
+    plain = [read(obuf2, gi) for gi in range(ngroups)]
+    for o, p_, r in zip(fused, plain, refs):
+        scale = max(1.0, r.abs().max().item())
+        if out_f32:
+            assert (o - r).abs().max().item() <= 2e-3 * scale and (o - p_).abs().max().item() <= 2e-3 * scale
+        else:
+            rr = _rb(r)
+            for other in (rr, p_):
+                assert ((o - other).abs() <= other.abs() * 2.0 ** -6 + 2e-3 * scale).all()
+            assert (o == rr).float().mean().item() > 0.97
+    total = obuf.float().abs().sum().item()
+    inner = sum(o.abs().sum().item() for o in fused)
+    assert abs(total - inner) <= 1e-3 * max(1.0, inner), "wrote outside its slices / into the gaps"
+    d1[0].cin = 64
+    assert lib.rtpose_conv1x1_pair_bf16_fits(d1, d2, ngroups) == 0
+
+
 def test_conv_bf16_rejects_bad_geometry(capi, cuda):
     lib = capi.lib
     d = (capi.ConvDesc * 1)()
