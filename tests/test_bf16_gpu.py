@@ -261,9 +261,11 @@ def test_conv1x1_pair_bf16_matches_the_two_launch_contract(capi, cuda, case):
         for (wt, bs, co, ci) in ((w1, b1, mid, 128), (w2, b2, cout2, mid)):
             wp = torch.zeros(lib.rtpose_packed_weight_bytes_bf16(co, ci, 1) // 2, device=cuda, dtype=torch.bfloat16)
             bp = torch.zeros(lib.rtpose_packed_bias_floats(co), device=cuda)
-            capi.check(lib.rtpose_pack_conv_weights_bf16(capi.ptr(wt.to(cuda)), capi.ptr(bs.to(cuda)), co, ci, 1, None, ci,
+            wd, bdev = wt.to(cuda), bs.to(cuda)      # (kept alive: a temporary's block is re-used before the pack kernel runs)
+            capi.check(lib.rtpose_pack_conv_weights_bf16(capi.ptr(wd), capi.ptr(bdev), co, ci, 1, None, ci,
                                                          capi.ptr(wp), capi.ptr(bp), stream))
             packs.append((wp, bp))
+            keep += [wd, bdev]
         keep += packs + [tb]
         a, b = d1[gi], d2[gi]
         a.inp, a.w_packed, a.bias_packed, a.out = xin.data_ptr(), packs[0][0].data_ptr(), packs[0][1].data_ptr(), tb.data_ptr()
