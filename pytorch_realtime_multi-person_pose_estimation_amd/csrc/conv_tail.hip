@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void tail_kernel(const Args A
 
   const int mf2 = wave & 1, nf2 = wave >> 1;
   const int col2 = nf2 * 32 + l31;
+  const bool live2 = nf2 * 32 < g.cout2;  // wave-uniform
   floatx16 acc2;
   {
     const float bias2 = g.b2[col2];
@@ -117,10 +118,14 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void tail_kernel(const Args A
     }
     // B fragments of GEMM 2 for this pass' 128 k rows (requested now: their latency hides under the LDS round trip
     // of the intermediate), and GEMM 1's for the next pass
+    // (round 6: the waves whose 32 output columns are all padding - columns 32..63 of the 19-column heat-map branch - skip
+    //  their half of GEMM 2: their SIMD's matrix pipe goes to the co-resident blocks)
     float4 b2v[N1 / 8];
+    if (live2) {
 #pragma unroll
-    for (int gi = 0; gi < N1 / 8; ++gi)
-      b2v[gi] = reinterpret_cast<const float4*>(g.w2)[(size_t)(ps * (N1 / 4) + 2 * gi + kh) * N2 + col2];
+      for (int gi = 0; gi < N1 / 8; ++gi)
+        b2v[gi] = reinterpret_cast<const float4*>(g.w2)[(size_t)(ps * (N1 / 4) + 2 * gi + kh) * N2 + col2];
+    }
     if (ps + 1 < NP) {
 #pragma unroll
       for (int gi = 0; gi < KC / 8; ++gi)
@@ -143,13 +148,15 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void tail_kernel(const Args A
     __syncthreads();
 
     // ---- GEMM 2: 32 px x 32 columns per wave (2 x 2 waves), the next 128 of its K ----------------------------
+    if (live2) {
 #pragma unroll
-    for (int gi = 0; gi < N1 / 8; ++gi) {
-      const float4 a = T[(2 * gi + kh) * PS + mf2 * 32 + l31];
-      const float av[4] = {a.x, a.y, a.z, a.w};
-      const float bv[4] = {b2v[gi].x, b2v[gi].y, b2v[gi].z, b2v[gi].w};
+      for (int gi = 0; gi < N1 / 8; ++gi) {
+        const float4 a = T[(2 * gi + kh) * PS + mf2 * 32 + l31];
+        const float av[4] = {a.x, a.y, a.z, a.w};
+        const float bv[4] = {b2v[gi].x, b2v[gi].y, b2v[gi].z, b2v[gi].w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc2, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc2, 0, 0, 0);
+      }
     }
   }
   if (col2 < g.cout2) {

@@ -178,10 +178,10 @@ def test_conv_bf16_aligned_slices_take_the_16_byte_store_epilogues(capi, cuda, c
 
 
 @pytest.mark.parametrize("shape,src", [((2, 64, 72), "nchw"), ((1, 37, 45), "nchw"), ((1, 37, 45), "layout"),
-                                       ((2, 368, 368), "nchw")])
+                                       ((1, 184, 200), "layout")])
 def test_first_layer_bf16_kernel_matches_the_emulation(capi, cuda, shape, src):
     """rtpose_conv_first_bf16 (round 6: conv1_1 of the bf16 plan on the fp32 matrix instruction, image and filters rounded to
-    bf16, read from the NCHW image or an fp32 layout buffer, bf16 out): within one bf16 ulp of conv2d on the rounded operands
+    bf16, read from the NCHW image or an fp32 layout buffer, bf16 out; tiles with ragged right / bottom edges): within one bf16 ulp of conv2d on the rounded operands
     in double, > 98 % of the outputs equal to its RNE rounding (the contract of the generic bf16 kernel, `_check`); nothing
     written outside the 64-channel slice; agrees with the generic kernel on 16 padded channels to one bf16 ulp."""
     lib, Layout = capi.lib, capi.Layout
@@ -222,8 +222,8 @@ def test_first_layer_bf16_kernel_matches_the_emulation(capi, cuda, shape, src):
                                       C.byref(Layout.padded(cs, h, w, 1, choff=4)), 1, n, h, w, stream) != 0
 
 
-@pytest.mark.parametrize("case", [(2, 46, 46, 128, 38, 0), (2, 46, 46, 128, 19, 0), (1, 46, 49, 512, 38, 0),
-                                  (3, 23, 17, 512, 19, 1), (2, 46, 46, 128, 38, 1)])
+@pytest.mark.parametrize("case", [(1, 46, 46, 128, 38, 0), (2, 23, 17, 128, 19, 0), (1, 46, 49, 512, 38, 0),
+                                  (3, 23, 17, 512, 19, 1), (1, 30, 46, 128, 38, 1)])
 def test_conv1x1_pair_bf16_matches_the_two_launch_contract(capi, cuda, case):
     """rtpose_conv1x1_pair_bf16 (round 6, csrc/conv_tail_bf16.hip): Conv2d(128, mid, 1) + ReLU -> Conv2d(mid, cout2, 1), both
     branches in one grid, the intermediate rounded to bf16 inside the CU.  Contract = two rtpose_conv2d_bf16 launches: against
