@@ -945,6 +945,17 @@ __global__ void wino_amp_kernel(const float* __restrict__ w, int cout, int cin, 
 #pragma unroll
   for (int f = 0; f < 16; ++f) sf[f] = 0.f;
   const int nfq = fm + 6;
+  const double pts[11] = {0.0, 1.0, -1.0, 2.0, -2.0, 0.5, -0.5, 1.5, -1.5, 2.0 / 3.0, -2.0 / 3.0};
+  // N_f = prod_{l != f} (p_f - p_l): once per block (round 6; every thread used to rebuild it for every filter row - the
+  // 117 launches of a weight load took 8.3 ms), by the same multiplications in the same order
+  __shared__ double s_nf[12];
+  if (k == 7 && tid < nfq - 1) {
+    double nf = 1.0;
+    for (int l = 0; l < nfq - 1; ++l)
+      if (l != tid) nf *= pts[tid] - pts[l];
+    s_nf[tid] = nf;
+  }
+  __syncthreads();
   for (int c = tid; c < cin; c += 256) {
     const float* gw = w + ((size_t)o * cin + c) * k * k;
     if (k == 3) {
@@ -964,7 +975,6 @@ __global__ void wino_amp_kernel(const float* __restrict__ w, int cout, int cin, 
         sf[fy * 4 + 3] += fabsf(u[fy][2]);
       }
     } else {
-      const double pts[11] = {0.0, 1.0, -1.0, 2.0, -2.0, 0.5, -0.5, 1.5, -1.5, 2.0 / 3.0, -2.0 / 3.0};
       for (int ky = 0; ky < 7; ++ky) {
         const float* row = gw + ky * 7;
         for (int kx = 0; kx < 7; ++kx) den += fabsf(row[kx]);
@@ -973,9 +983,7 @@ __global__ void wino_amp_kernel(const float* __restrict__ w, int cout, int cin, 
           if (f == nfq - 1) {
             v = row[6];
           } else {
-            double nf = 1.0;
-            for (int l = 0; l < nfq - 1; ++l)
-              if (l != f) nf *= pts[f] - pts[l];
+            const double nf = s_nf[f];
             double sacc = 0.0, pw = 1.0;
             for (int kx = 0; kx < 7; ++kx) {
               sacc += pw * (double)row[kx];
