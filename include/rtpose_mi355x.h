@@ -591,6 +591,9 @@ int rtpose_net_set_persistent7(rtpose_net* net, int enable);
  * outlive the guard.  (History, DESIGN.md 3.3: a decoder built with packed-fp32 VALU instructions returned wrong limb scores
  * beside the bf16 plan's kernels; the library's decoder is built without them.) */
 int rtpose_net_set_output_guard(rtpose_net* net, void* hip_event);
+/* Index (rtpose_net_launch_info numbering) of the launch a guarded forward waits in front of - decided, like the guard
+ * itself, the first time either function is called on the plan (the environment is read then); host-only. */
+int rtpose_net_output_guard_launch(rtpose_net* net);
 int rtpose_net_persistent7(const rtpose_net* net);
 /* The same without the wait: queues the copy of the error word into *host_word (pinned host memory, or the copy
  * is not asynchronous) and its clearing on `stream` and returns; the word is valid once the caller has waited for

@@ -161,6 +161,7 @@ _SIGS = {
     "rtpose_net_device_status": (_i, [_vp, C.POINTER(_i), _vp]),
     "rtpose_net_device_status_async": (_i, [_vp, _vp, _vp]),
     "rtpose_net_set_output_guard": (_i, [_vp, _vp]),
+    "rtpose_net_output_guard_launch": (_i, [_vp]),
     "rtpose_net_set_persistent7": (_i, [_vp, _i]),
     "rtpose_net_persistent7": (_i, [_vp]),
     "rtpose_net_graph_active": (_i, [_vp]),

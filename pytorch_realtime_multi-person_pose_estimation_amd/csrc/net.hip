@@ -886,8 +886,22 @@ int rtpose_net_device_status(rtpose_net* net, int* error_word, void* stream) {
   return 0;
 }
 
+static void decide_guard_launch(rtpose_net* net);
+
+int rtpose_net_output_guard_launch(rtpose_net* net) {
+  if (!net) return fail(RTPOSE_E_INVAL, "net_output_guard_launch: NULL net");
+  decide_guard_launch(net);
+  return net->guard_op;
+}
+
 int rtpose_net_set_output_guard(rtpose_net* net, void* hip_event) {
   if (!net) return fail(RTPOSE_E_INVAL, "net_set_output_guard: NULL net");
+  decide_guard_launch(net);
+  net->out_guard = static_cast<hipEvent_t>(hip_event);
+  return 0;
+}
+
+static void decide_guard_launch(rtpose_net* net) {
   if (net->guard_op < 0) {
     // Where a forward waits for the reader of its previous maps (the decoder of the batch before on a second stream,
     // pipeline.SideDecoder).  Default, every arithmetic: in front of the FIRST launch that writes the buffer
@@ -917,8 +931,6 @@ int rtpose_net_set_output_guard(rtpose_net* net, void* hip_event) {
     }
 #endif
   }
-  net->out_guard = static_cast<hipEvent_t>(hip_event);
-  return 0;
 }
 
 int rtpose_net_set_persistent7(rtpose_net* net, int enable) {

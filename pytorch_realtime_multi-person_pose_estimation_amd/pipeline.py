@@ -39,7 +39,8 @@ class SideDecoder(object):
     them (library default: in front of its whole launch list; RTPOSE_GUARD_FINE=1: only where it first writes the buffer.
     DESIGN.md 3.3 has the history: the decoder's kernels are built without packed-fp32 VALU instructions because those
     returned wrong values beside the bf16 plan's kernels).  The guard stays installed until the next decode replaces it or
-    close() removes it.  The plan's device error word (persistent 7x7 hand-over, fp32 plans) rides in front of every decode and
+    close() removes it - ONE guard per plan: two pipelined consumers decoding the maps of the same plan at the same time
+    are not supported (the later decode's event replaces the earlier one's).  The plan's device error word (persistent 7x7 hand-over, fp32 plans) rides in front of every decode and
     is checked in wait().  Two slots (record block, pinned copy, events, error word)."""
 
     def __init__(self, config):

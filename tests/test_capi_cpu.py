@@ -155,6 +155,39 @@ def test_compute_dtype_plans_on_the_host(capi, pkg):
     assert m.set_compute_dtype('bf16x3').compute_dtype == 'bf16x3'
 
 
+def test_output_guard_position_per_arithmetic_and_environment(capi, monkeypatch):
+    """Where a guarded forward waits for the reader of its previous maps (rtpose_net_set_output_guard, the decoder of the
+    batch before on a second stream): by default in front of the FIRST launch that writes the buffer the maps live in -
+    fp32: conv4_4_CPM (`model0.25`, it writes the out1 channels of the same concat buffer), so that the reader runs beside
+    the trunk; bf16 / bf16x3: the last launch (the stage-6 pair writes the fp32 record) - and in front of the whole launch
+    list under RTPOSE_GUARD_WHOLE_FORWARD=1 (or RTPOSE_GUARD_FINE=0).  Host-only: rtpose_net_output_guard_launch."""
+    lib = capi.lib
+    name = C.create_string_buffer(96)
+
+    def guard_launch(dt):
+        h = C.c_void_p()
+        capi.check(lib.rtpose_net_create_ex(2, 368, 368, dt, C.byref(h)))
+        try:
+            g = lib.rtpose_net_output_guard_launch(h)
+            capi.check(lib.rtpose_net_launch_info(h, g, None, None, None, name, 96))
+            assert lib.rtpose_net_set_output_guard(h, None) == 0 and lib.rtpose_net_output_guard_launch(h) == g
+            return g, name.value.decode(), lib.rtpose_net_num_launches(h)
+        finally:
+            lib.rtpose_net_destroy(h)
+    monkeypatch.delenv("RTPOSE_GUARD_WHOLE_FORWARD", raising=False)
+    monkeypatch.delenv("RTPOSE_GUARD_FINE", raising=False)
+    g, nm, n = guard_launch(capi.DTYPE_F32)
+    assert nm == "model0.25" and 0 < g < n - 1
+    for dt in (capi.DTYPE_BF16, capi.DTYPE_BF16X3):
+        g, nm, n = guard_launch(dt)
+        assert g == n - 1 and "model6_1" in nm and "model6_2" in nm
+    for var, val in (("RTPOSE_GUARD_WHOLE_FORWARD", "1"), ("RTPOSE_GUARD_FINE", "0")):
+        monkeypatch.setenv(var, val)
+        for dt in (capi.DTYPE_F32, capi.DTYPE_BF16):
+            assert guard_launch(dt)[0] == 0
+        monkeypatch.delenv(var)
+
+
 def test_header_is_plain_c(tmp_path):
     """The drop-in boundary is a C ABI: include/rtpose_mi355x.h must compile as C99 on its own
     (no C++, no HIP, no torch types in the signatures)."""
