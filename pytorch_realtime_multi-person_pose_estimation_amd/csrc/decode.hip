@@ -755,7 +755,62 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
   // still free when their turn comes cannot change anything: a used peak stays used.)
   const int max_conn = min(nA, nB);
   bool tie = false;
-  for (int it = 0; it < max_conn; ++it) {
+  __shared__ int s_tie;
+  // Round 6: at most 64 candidate pairs (8 x 8 peaks: every limb of a real scene) - ONE wave holds a candidate per lane and
+  // the used peaks as two wave-uniform 64-bit masks; its greedy steps are a butterfly each, with no barrier and no LDS
+  // traffic, while the other waves wait at one barrier (the block-wide loop below: two barriers per step).  Same
+  // reduction, same tie rule.
+  const bool one_wave = SCORES_IN_LDS && npairs <= 64;
+  if (one_wave) {
+    if (wave == 0) {
+      const bool mine = lane < npairs;
+      const float sc = mine ? s_score(lane) : 0.f;
+      const int a = mine ? lane / nB : 0, b = mine ? lane - (lane / nB) * nB : 0;
+      unsigned long long usedA = 0ull, usedB = 0ull;
+      int nc = 0;
+      bool t = false;
+      for (int it = 0; it < max_conn; ++it) {
+        const bool open = mine && sc > 0.f && !((usedA >> a) & 1ull) && !((usedB >> b) & 1ull);
+        float best = open ? sc : 0.f;
+        int bidx = open ? lane : 0x7fffffff, cnt = open ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+          const float ob = __shfl_xor(best, o);
+          const int oi = __shfl_xor(bidx, o);
+          const int oc = __shfl_xor(cnt, o);
+          if (ob > best) {
+            best = ob;
+            bidx = oi;
+            cnt = oc;
+          } else if (ob == best) {
+            bidx = min(bidx, oi);
+            cnt += oc;
+          }
+        }
+        if (!(best > 0.f)) break;  // uniform
+        if (cnt > 1) {             // uniform
+          t = true;
+          break;
+        }
+        const int aw = bidx / nB, bw = bidx - aw * nB;
+        usedA |= 1ull << aw;
+        usedB |= 1ull << bw;
+        if (lane == 0) {
+          s_conn[3 * nc + 0] = aw;
+          s_conn[3 * nc + 1] = bw;
+          s_conn[3 * nc + 2] = __float_as_int(best);
+        }
+        ++nc;
+      }
+      if (lane == 0) {
+        s_nconn = nc;
+        s_tie = t ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    tie = s_tie != 0;
+  }
+  for (int it = 0; it < (one_wave ? 0 : max_conn); ++it) {
     float best = 0.f;
     int bidx = 0x7fffffff, cnt = 0;
     for (int p = tid; p < npairs; p += 256) {
@@ -1077,215 +1132,6 @@ __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* 
   }
 }
 
-// ------------------------------------------------------------------------------
-// 3b. The same grouping with the subset rows in REGISTERS (round 6): lane l holds rows l and l + 64 (20 values + alive each),
-// for tables of at most 128 rows (max_humans <= 64: the default) whose staged connections fit the LDS.  The walk over the
-// connections then has no LDS write, no barrier and no dependent LDS round trip per step: the row search is a compare on
-// the lane's own registers + two ballots, an update happens in the owning lane, a merge fetches the absorbed row with
-// v_readlane.  The 19 limbs are unrolled so that the part columns are compile-time register indices.  Same comparisons,
-// same float operations in the same order as group_kernel above (which stays for larger tables): bit-identical records.
-// ------------------------------------------------------------------------------
-constexpr int kPairsC[19][2] = {{1, 2}, {1, 5},   {2, 3},   {3, 4},   {5, 6},   {6, 7},   {1, 8},
-                                {8, 9}, {9, 10},  {1, 11},  {11, 12}, {12, 13}, {1, 0},   {0, 14},
-                                {14, 16}, {0, 15}, {15, 17}, {2, 16},  {5, 17}};  // == kPairs (pafprocess.h:21-24)
-constexpr int kRegRows = 128;
-
-struct RegRow {
-  float v[20];  // 18 part cids (-1 = none), [18] score sum, [19] part count
-  float alive;
-};
-
-template <bool WRITE_IDS>
-__global__ __launch_bounds__(64) void group_regs_kernel(int pcap, int hcap, int32_t* __restrict__ result,
-                                                        int result_words, const int32_t* __restrict__ conn,
-                                                        int conn_words, int row_cap) {
-  const int n = blockIdx.x, lane = threadIdx.x;
-  int32_t* res = result + (size_t)n * result_words;
-  const int32_t* cnb = conn + (size_t)n * conn_words;
-  extern __shared__ float stage[];  // [total connections][kStageWords]
-
-  __shared__ int s_start[RTPOSE_NUM_PART + 1];
-  __shared__ int s_cbase[RTPOSE_NUM_LIMB + 1];
-  if (lane == 0) {
-    int acc = 0;
-    for (int p = 0; p < RTPOSE_NUM_PART; ++p) {
-      s_start[p] = acc;
-      acc += res[kResPartCount + p];
-    }
-    s_start[RTPOSE_NUM_PART] = acc;
-    if (WRITE_IDS) res[kResHeader + 0] = acc;
-  }
-  if (lane < RTPOSE_NUM_LIMB) s_cbase[lane + 1] = cnb[(size_t)lane * (1 + 3 * pcap)];
-  __syncthreads();
-  if (lane == 0) {
-    s_cbase[0] = 0;
-    for (int l = 0; l < RTPOSE_NUM_LIMB; ++l) s_cbase[l + 1] += s_cbase[l];
-  }
-  __syncthreads();
-  rtpose_peak* peaks = reinterpret_cast<rtpose_peak*>(res + kResPeaks);
-  if (WRITE_IDS) {
-    for (int p = 0; p < RTPOSE_NUM_PART; ++p) {
-      const int cnt = s_start[p + 1] - s_start[p];
-      for (int i = lane; i < cnt; i += 64) peaks[(size_t)p * pcap + i].id = s_start[p] + i;
-    }
-  }
-  const int npeaks = s_start[RTPOSE_NUM_PART];
-  auto line_peak_score = [&](int pos) -> float {
-    int p = 0;
-    while (p + 1 < RTPOSE_NUM_PART && pos >= s_start[p + 1]) ++p;
-    return peaks[(size_t)p * pcap + (pos - s_start[p])].score;
-  };
-  {  // stage every limb's connections (as group_kernel<., true>)
-    const int total = s_cbase[RTPOSE_NUM_LIMB];
-    for (int i = lane; i < total; i += 64) {
-      int limb = 0;
-      while (i >= s_cbase[limb + 1]) ++limb;
-      const int c = i - s_cbase[limb];
-      const int part1 = kPairs[limb][0], part2 = kPairs[limb][1];
-      const int32_t* cn = cnb + (size_t)limb * (1 + 3 * pcap);
-      const rtpose_peak* pA = peaks + (size_t)part1 * pcap;
-      const rtpose_peak* pB = peaks + (size_t)part2 * pcap;
-      const int ia = cn[1 + 3 * c], ib = cn[1 + 3 * c + 1];
-      const int id1 = WRITE_IDS ? s_start[part1] + ia : pA[ia].id;
-      const int id2 = WRITE_IDS ? s_start[part2] + ib : pB[ib].id;
-      float* st = stage + (size_t)i * kStageWords;
-      st[0] = (float)id1;
-      st[1] = (float)id2;
-      st[2] = __int_as_float(cn[1 + 3 * c + 2]);
-      st[3] = (id2 >= 0 && id2 < npeaks) ? (WRITE_IDS ? pB[ib].score : line_peak_score(id2)) : 0.f;
-      st[4] = (id1 >= 0 && id1 < npeaks) ? (WRITE_IDS ? pA[ia].score : line_peak_score(id1)) : 0.f;
-    }
-    __threadfence_block();
-    __syncthreads();
-  }
-
-  RegRow ra, rb;  // rows lane, lane + 64
-#pragma unroll
-  for (int k = 0; k < 20; ++k) ra.v[k] = rb.v[k] = 0.f;
-  ra.alive = rb.alive = 0.f;
-  int nrows = 0;
-  bool overflow = false;
-  // value k of row `idx`, in every lane (v_readlane from the owning lane)
-  auto fetch = [&](int idx, int k) -> float {
-    const int owner = __builtin_amdgcn_readfirstlane(idx & 63);
-    const float mine = (idx >> 6) ? rb.v[k] : ra.v[k];
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), owner));
-  };
-#pragma unroll
-  for (int pair_id = 0; pair_id < 19; ++pair_id) {
-    constexpr int dummy = 0;
-    (void)dummy;
-    const int part1 = kPairsC[pair_id][0], part2 = kPairsC[pair_id][1];
-    const int nconn = s_cbase[pair_id + 1] - s_cbase[pair_id];
-    const float* lst = stage + (size_t)s_cbase[pair_id] * kStageWords;
-    for (int c = 0; c < nconn; ++c) {
-      const float* st = lst + (size_t)c * kStageWords;
-      const float cid1 = st[0], cid2 = st[1], cscore = st[2], s2 = st[3];
-      // search the alive rows in order: rows 0..63 (first halves), then 64..127
-      const bool hitA = ra.alive != 0.f && (ra.v[part1] == cid1 || ra.v[part2] == cid2);
-      const bool hitB = rb.alive != 0.f && (rb.v[part1] == cid1 || rb.v[part2] == cid2);
-      unsigned long long mA = __ballot(hitA), mB = __ballot(hitB);
-      const int found = __popcll(mA) + __popcll(mB);
-      int idx1 = 0, idx2 = 0;
-      if (found >= 1) {
-        if (mA) {
-          idx1 = __ffsll((long long)mA) - 1;
-          mA &= mA - 1;
-        } else {
-          idx1 = 64 + __ffsll((long long)mB) - 1;
-          mB &= mB - 1;
-        }
-      }
-      if (found >= 2) idx2 = mA ? __ffsll((long long)mA) - 1 : 64 + __ffsll((long long)mB) - 1;
-      if (found == 1) {
-        auto upd = [&](RegRow& row) {
-          if (row.v[part2] != cid2) {
-            row.v[part2] = cid2;
-            row.v[19] = row.v[19] + 1.f;
-            row.v[18] = row.v[18] + (s2 + cscore);
-          }
-        };
-        if (lane == (idx1 & 63)) {
-          if (idx1 >> 6) upd(rb);
-          else upd(ra);
-        }
-      } else if (found == 2) {
-        float r2[20];
-#pragma unroll
-        for (int k = 0; k < 20; ++k) r2[k] = fetch(idx2, k);
-        bool both = false;
-        if (lane == (idx1 & 63)) {
-          const RegRow& r1 = (idx1 >> 6) ? rb : ra;
-#pragma unroll
-          for (int k = 0; k < 18; ++k) both = both || (r1.v[k] > 0.f && r2[k] > 0.f);  // cid 0 reads as absent (cpp:155)
-        }
-        const bool membership = __any(both);
-        auto merge = [&](RegRow& r1) {
-          if (!membership) {
-#pragma unroll
-            for (int k = 0; k < 18; ++k) r1.v[k] = r1.v[k] + (r2[k] + 1.f);
-            r1.v[19] = r1.v[19] + r2[19];
-            r1.v[18] = r1.v[18] + r2[18];
-            r1.v[18] = r1.v[18] + cscore;
-          } else {
-            r1.v[part2] = cid2;
-            r1.v[19] = r1.v[19] + 1.f;
-            r1.v[18] = r1.v[18] + (s2 + cscore);
-          }
-        };
-        if (lane == (idx1 & 63)) {
-          if (idx1 >> 6) merge(rb);
-          else merge(ra);
-        }
-        if (!membership && lane == (idx2 & 63)) {  // erase(subset_idx2): order of the survivors is kept
-          if (idx2 >> 6) rb.alive = 0.f;
-          else ra.alive = 0.f;
-        }
-      } else if (found == 0 && pair_id < 18) {
-        if (nrows < row_cap) {
-          const float s1 = st[4];
-          auto fresh = [&](RegRow& row) {
-#pragma unroll
-            for (int k = 0; k < 18; ++k) row.v[k] = (k == part1) ? cid1 : ((k == part2) ? cid2 : -1.f);
-            row.v[19] = 2.f;
-            row.v[18] = (s1 + s2) + cscore;
-            row.alive = 1.f;
-          };
-          if (lane == (nrows & 63)) {
-            if (nrows >> 6) fresh(rb);
-            else fresh(ra);
-          }
-          ++nrows;
-        } else {
-          overflow = true;
-        }
-      }
-    }
-  }
-
-  // prune (cpp:187-191) and emit, in row order: rows 0..63 then 64..127
-  int32_t* hparts = res + kResPeaks + 4 * RTPOSE_NUM_PART * pcap;
-  float* hscore = reinterpret_cast<float*>(hparts + (size_t)RTPOSE_NUM_PART * hcap);
-  const bool keepA = ra.alive != 0.f && !(ra.v[19] < 4.f || ra.v[18] / ra.v[19] < 0.3f);
-  const bool keepB = rb.alive != 0.f && !(rb.v[19] < 4.f || rb.v[18] / rb.v[19] < 0.3f);
-  const unsigned long long kA = __ballot(keepA), kB = __ballot(keepB);
-  const unsigned long long below = (1ull << lane) - 1ull;
-  const int nA = __popcll(kA), total_h = nA + __popcll(kB);
-  auto emit = [&](const RegRow& row, int pos) {
-    if (pos < hcap) {
-#pragma unroll
-      for (int k = 0; k < 18; ++k) hparts[(size_t)pos * RTPOSE_NUM_PART + k] = (int)row.v[k];
-      hscore[pos] = row.v[18] / row.v[19];
-    }
-  };
-  if (keepA) emit(ra, __popcll(kA & below));
-  if (keepB) emit(rb, nA + __popcll(kB & below));
-  if (lane == 0) {
-    res[kResHeader + 1] = min(total_h, hcap);
-    if (overflow || total_h > hcap) atomicOr(&res[kResHeader + 2], kOverflowHumans);
-  }
-}
-
 // header + part counts of every record <- 0, except header[3] / [4] = the capacities the record is laid out for
 // (max_peaks_per_part, max_humans): a record block describes itself, a consumer that parses it later - after the
 // producer has grown its tables - does not need the producer's cfg of that moment.
@@ -1396,10 +1242,6 @@ int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int 
                                     reinterpret_cast<const void*>(group_kernel<false, false>)};
     for (const void* k : group_kernels)
       RTPOSE_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_regs_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    RTPOSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(group_regs_kernel<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_set.set(dev);
   }
   const int up = cfg->upsample;
@@ -1441,14 +1283,7 @@ int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int 
 #define RTPOSE_GROUP(W, S)                                                                                               \
   hipLaunchKernelGGL((group_kernel<W, S>), dim3(N), dim3(64), rows_lds, s, pcap, cfg->max_humans, res, words, conn, \
                      conn_words, row_cap, rows_ws)
-  if (row_cap <= kRegRows && all_bytes <= 96 * 1024) {  // rows in registers, every limb's connections staged in LDS
-    if (write_ids)
-      hipLaunchKernelGGL(group_regs_kernel<true>, dim3(N), dim3(64), all_bytes, s, pcap, cfg->max_humans, res, words, conn,
-                         conn_words, row_cap);
-    else
-      hipLaunchKernelGGL(group_regs_kernel<false>, dim3(N), dim3(64), all_bytes, s, pcap, cfg->max_humans, res, words, conn,
-                         conn_words, row_cap);
-  } else if (write_ids && stage_all) RTPOSE_GROUP(true, true);
+  if (write_ids && stage_all) RTPOSE_GROUP(true, true);
   else if (write_ids) RTPOSE_GROUP(true, false);
   else if (stage_all) RTPOSE_GROUP(false, true);
   else RTPOSE_GROUP(false, false);
