@@ -755,62 +755,7 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
   // still free when their turn comes cannot change anything: a used peak stays used.)
   const int max_conn = min(nA, nB);
   bool tie = false;
-  __shared__ int s_tie;
-  // Round 6: at most 64 candidate pairs (8 x 8 peaks: every limb of a real scene) - ONE wave holds a candidate per lane and
-  // the used peaks as two wave-uniform 64-bit masks; its greedy steps are a butterfly each, with no barrier and no LDS
-  // traffic, while the other waves wait at one barrier (the block-wide loop below: two barriers per step).  Same
-  // reduction, same tie rule.
-  const bool one_wave = SCORES_IN_LDS && npairs <= 64;
-  if (one_wave) {
-    if (wave == 0) {
-      const bool mine = lane < npairs;
-      const float sc = mine ? s_score(lane) : 0.f;
-      const int a = mine ? lane / nB : 0, b = mine ? lane - (lane / nB) * nB : 0;
-      unsigned long long usedA = 0ull, usedB = 0ull;
-      int nc = 0;
-      bool t = false;
-      for (int it = 0; it < max_conn; ++it) {
-        const bool open = mine && sc > 0.f && !((usedA >> a) & 1ull) && !((usedB >> b) & 1ull);
-        float best = open ? sc : 0.f;
-        int bidx = open ? lane : 0x7fffffff, cnt = open ? 1 : 0;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-          const float ob = __shfl_xor(best, o);
-          const int oi = __shfl_xor(bidx, o);
-          const int oc = __shfl_xor(cnt, o);
-          if (ob > best) {
-            best = ob;
-            bidx = oi;
-            cnt = oc;
-          } else if (ob == best) {
-            bidx = min(bidx, oi);
-            cnt += oc;
-          }
-        }
-        if (!(best > 0.f)) break;  // uniform
-        if (cnt > 1) {             // uniform
-          t = true;
-          break;
-        }
-        const int aw = bidx / nB, bw = bidx - aw * nB;
-        usedA |= 1ull << aw;
-        usedB |= 1ull << bw;
-        if (lane == 0) {
-          s_conn[3 * nc + 0] = aw;
-          s_conn[3 * nc + 1] = bw;
-          s_conn[3 * nc + 2] = __float_as_int(best);
-        }
-        ++nc;
-      }
-      if (lane == 0) {
-        s_nconn = nc;
-        s_tie = t ? 1 : 0;
-      }
-    }
-    __syncthreads();
-    tie = s_tie != 0;
-  }
-  for (int it = 0; it < (one_wave ? 0 : max_conn); ++it) {
+  for (int it = 0; it < max_conn; ++it) {
     float best = 0.f;
     int bidx = 0x7fffffff, cnt = 0;
     for (int p = tid; p < npairs; p += 256) {
