@@ -582,14 +582,21 @@ constexpr int kSortStack = 3 * 64;  // pending ranges <= the depth limit 2 floor
 // ones), not through a generic pointer (flat_load / flat_store, the aperture decided per access); (b) NO double-precision
 // instruction in the per-sample loop: the reference's (int)(v + 0.5) on a double and floor(l / up) are computed exactly
 // in integers / fp32 (v >= 0 and up a power of two, the only case the configs use; any other `up` keeps the doubles),
-// and the length penalty needs its double division only for limbs longer than half the image.  Why (b): with the
-// decoder on a second stream next to the bf16 forward's MFMA kernels (pipeline.SideDecoder), ~1 % of the batches came
-// back with ONE candidate score a sample off (e.g. 1.0020 -> 0.9050: one of the ten samples taken at the previous
-// sample's position), always a candidate scored by the HIGH lanes (41..63) of the wave - reversing the pair -> lane map
-// moved the damage to the other end of the table - with maps and peaks bit-identical before and after, never in the
-// serial flow, never next to the fp32 plan's kernels (tools/exp/overlap_flake.py, profiles/r05_decoder_next_to_mfma.txt;
-// DESIGN.md 3.3).  The half-rate double-precision chain v_cvt_f64 -> v_add_f64 -> v_cvt_i32_f64 -> v_mul_f64 ->
-// v_floor_f64 was the one multi-pass VALU sequence in the loop.
+// and the length penalty needs its double division only for limbs longer than half the image.
+// Round 6: (c) A32 - a sample's two map values through the SGPR-base form of global_load_dword with one 32-bit byte offset
+// (two 24-bit multiplies): no 64-bit integer VALU instruction between the peak loads and the last map load; (d) this file is
+// compiled WITHOUT clang's vectorisers (csrc/Makefile).  With the decoder on a second stream beside the bf16 forward's first
+// launches (pipeline.SideDecoder), the vectorised build of this loop - v_pk_mul_f32 (vx, vy) x (px, py) on the loaded map
+// values and op_sel-swizzled v_pk_add_f32 behind them - returned, in ~1 of 150 launches, ONE candidate score computed from a
+// wrong sample, always in lanes 48..63 (most often the top active lane), with maps and peaks bit-identical before and after,
+// never in the serial flow, never on CUs the forward does not use.  Eight discriminating builds and three stand-alone
+// victims: DESIGN.md 3.3, profiles/r06_decoder_beside_forward.txt.  (a) - (c) were each tried as the cure and are not it
+// (they stay: fewer instructions); (d) is.  The RTPOSE_EXP_LIMB_* blocks below are those builds' switches
+// (tools/build_dev.sh -DRTPOSE_EXP_LIMB_...; a production build refuses them).
+#if !defined(RTPOSE_DEV_BUILD) && (defined(RTPOSE_EXP_LIMB_WAIT0) || defined(RTPOSE_EXP_LIMB_KEEP) || \
+                                   defined(RTPOSE_EXP_LIMB_ASM_COORD) || defined(RTPOSE_EXP_LIMB_ASM_DOT))
+#error "RTPOSE_EXP_LIMB_* are developer-build experiments (tools/build_dev.sh)"
+#endif
 template <bool SCORES_IN_LDS, bool UP_POW2, bool A32>
 __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, int w, double inv_up, int up_shift,
                                                           int h1, int pcap,
