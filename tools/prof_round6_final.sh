@@ -7,6 +7,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 python $R/bench.py --steps 20 --warmup 3 > $O/r06_bench.json 2> $O/r06_bench.err
+# the bf16 lines early: session h measured them last, on a box whose bf16 rates had fallen by a third by then
+python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-traffic --dtype bf16 > $O/r06_bench_bf16.json 2>/dev/null
+python $R/tools/bench_tta.py 32 3 > $O/r06_tta.txt 2>&1
 rocprofv3 --kernel-trace --stats -d $O/r06_trace -o t -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic > $O/r06_bench_under_rocprof.json 2> $O/r06_trace.err
 db=$(find $O/r06_trace -name "*.db" | head -1)
 [ -n "$db" ] && python $R/tools/rocpd_summary.py $db > $O/r06_bench_kernel_trace_stats.txt 2>&1
@@ -51,9 +54,8 @@ rm -rf $O/r06_sn_trace
 python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-traffic --decode-overlap 0 > $O/r06_bench_one_stream.json 2>/dev/null
 python $R/tools/latency_b1.py > $O/r06_latency_b1.txt 2>&1
 python $R/tools/bench_config5.py > $O/r06_config5.json 2>/dev/null
-python $R/tools/bench_tta.py 32 3 > $O/r06_tta.txt 2>&1
 python $R/tools/bench_streaming.py > $O/r06_streaming.txt 2>&1
-python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-traffic --dtype bf16 > $O/r06_bench_bf16.json 2>/dev/null
+python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-traffic --dtype bf16 > $O/r06_bench_bf16_late.json 2>/dev/null
 python $R/tools/profile_layers.py 32 368 368 5 bf16 2>&1 | grep -v amdgpu.ids > $O/r06_bf16_layers.txt
 cd $R && python -c "import __graft_entry__ as g; g.smoke()" > $O/r06_smoke.txt 2>&1
 # the torch-free C++ host on bench.py's decoder input (scene + 1e-3 * maps): the scene of synth.make_batch as a file
@@ -68,3 +70,7 @@ for n in (32, 11, 8):
         f.write(np.ascontiguousarray(heat, np.float32).tobytes()); f.write(np.ascontiguousarray(paf, np.float32).tobytes())
 PY
 for args in "32 0 default /tmp/scene32.bin" "11 0 default /tmp/scene11.bin" "8 0 direct /tmp/scene8.bin" "32 2 default /tmp/scene32.bin" "32 1 default /tmp/scene32.bin"; do LD_LIBRARY_PATH=$R/pytorch_realtime_multi-person_pose_estimation_amd/lib $R/examples/c_host $args; done > $O/r06_c_host.txt 2>&1
+
+# the production library's decoder beside the next forward, default guard, 12 decodes per step
+cd $R
+for dt in "50000 bf16" "5000 fp32 bf16x3"; do REPEATS=12 PEOPLE=8 timeout 900 python tools/exp/overlap_soak.py $dt 2>&1 | grep -E "differing records|serial path"; done > $O/r06_decoder_soak_final_tree.txt
