@@ -594,7 +594,8 @@ constexpr int kSortStack = 3 * 64;  // pending ranges <= the depth limit 2 floor
 // (they stay: fewer instructions); (d) is.  The RTPOSE_EXP_LIMB_* blocks below are those builds' switches
 // (tools/build_dev.sh -DRTPOSE_EXP_LIMB_...; a production build refuses them).
 #if !defined(RTPOSE_DEV_BUILD) && (defined(RTPOSE_EXP_LIMB_WAIT0) || defined(RTPOSE_EXP_LIMB_KEEP) || \
-                                   defined(RTPOSE_EXP_LIMB_ASM_COORD) || defined(RTPOSE_EXP_LIMB_ASM_DOT))
+                                   defined(RTPOSE_EXP_LIMB_ASM_COORD) || defined(RTPOSE_EXP_LIMB_ASM_DOT) || \
+                                   defined(RTPOSE_EXP_GROUP_TIMELINE))
 #error "RTPOSE_EXP_LIMB_* are developer-build experiments (tools/build_dev.sh)"
 #endif
 template <bool SCORES_IN_LDS, bool UP_POW2, bool A32>
@@ -907,6 +908,13 @@ __global__ __launch_bounds__(256) void limb_assign_kernel(MapView paf, int h, in
 // global round trip of the kernel is then taken once, with all lanes' loads in flight together, instead of once per limb (the
 // host picks it when 19 * pcap staged connections fit the LDS next to the rows: pcap <= 128).
 constexpr int kStageWords = 5;  // per staged connection: cid1, cid2, connection score, score of peak 2, score of peak 1
+#ifdef RTPOSE_EXP_GROUP_TIMELINE  // developer build: wall_clock64 stamps of the kernel's phases, per image (tools/exp/group_timeline.py)
+__device__ unsigned long long g_group_tl[256][8];
+#define RTPOSE_GTL(i)                                        \
+  if (lane == 0 && n < 256) g_group_tl[n][i] = wall_clock64()
+#else
+#define RTPOSE_GTL(i)
+#endif
 template <bool WRITE_IDS, bool STAGE_ALL>
 __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* __restrict__ result,
                                                    int result_words, const int32_t* __restrict__ conn,
@@ -919,6 +927,7 @@ __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* 
   // [row_cap][20 + alive]: the reference's `subset`; LDS unless grown past kLdsRows; then the staged connections of one limb
   float* rows = row_cap <= kLdsRows ? rows_lds : rows_ws + (size_t)n * row_cap * 21;
   float* stage = rows_lds + (row_cap <= kLdsRows ? (size_t)row_cap * 21 : 0);
+  RTPOSE_GTL(0);
 
   __shared__ int s_start[RTPOSE_NUM_PART + 1];
   if (lane == 0) {
@@ -963,6 +972,7 @@ __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* 
     st[4] = (id1 >= 0 && id1 < npeaks) ? (WRITE_IDS ? pA[ia].score : line_peak_score(id1)) : 0.f;
   };
   __shared__ int s_cbase[RTPOSE_NUM_LIMB + 1];
+  RTPOSE_GTL(1);
   if (STAGE_ALL) {
     if (lane < RTPOSE_NUM_LIMB) s_cbase[lane + 1] = cnb[(size_t)lane * (1 + 3 * pcap)];
     __syncthreads();
@@ -981,6 +991,7 @@ __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* 
     __syncthreads();
   }
 
+  RTPOSE_GTL(2);
   int nrows = 0;
   bool overflow = false;
   for (int pair_id = 0; pair_id < 19; ++pair_id) {
@@ -1062,6 +1073,10 @@ __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* 
     }
   }
 
+  RTPOSE_GTL(3);
+#ifdef RTPOSE_EXP_GROUP_TIMELINE
+  if (lane == 0 && n < 256) g_group_tl[n][6] = (unsigned long long)(STAGE_ALL ? s_cbase[RTPOSE_NUM_LIMB] : 0);
+#endif
   // prune (cpp:187-191) and emit
   int nh = 0;
   int32_t* hparts = res + kResPeaks + 4 * RTPOSE_NUM_PART * pcap;
@@ -1082,6 +1097,7 @@ __global__ __launch_bounds__(64) void group_kernel(int pcap, int hcap, int32_t* 
     res[kResHeader + 1] = nh;
     if (overflow) atomicOr(&res[kResHeader + 2], kOverflowHumans);
   }
+  RTPOSE_GTL(4);
 }
 
 // header + part counts of every record <- 0, except header[3] / [4] = the capacities the record is laid out for
@@ -1249,6 +1265,12 @@ int assign_group_launch(const float* paf, const rtpose_layout* lpaf, int N, int 
 using namespace rtpose;
 
 extern "C" {
+
+#ifdef RTPOSE_EXP_GROUP_TIMELINE
+int rtpose_exp_group_timeline(unsigned long long* out, int n) {  // [n][8]: stamps 0..4, [6] = connections of the image
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rtpose::g_group_tl), sizeof(unsigned long long) * 8 * (n < 256 ? n : 256));
+}
+#endif
 
 size_t rtpose_decode_workspace_bytes(const rtpose_decode_cfg* cfg, int N) {
   if (check_cfg(cfg) || N <= 0) return 0;
