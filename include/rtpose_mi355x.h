@@ -373,6 +373,14 @@ int rtpose_conv2d_bf16(const rtpose_conv_desc* d, int ngroups, int N, int H, int
 int rtpose_conv1x1_pair_bf16_fits(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int ngroups);
 int rtpose_conv1x1_pair_bf16(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int ngroups, int N,
                              int H, int W, int out_f32, void* stream);
+/* 3x3 convs with 64 bf16 INPUT channels - conv1_2 (+ fused 2x2 max-pool) and conv2_1 of the VGG-19 front end
+ * (lib/network/rtpose_vgg.py:23-35, :69-72) - in their own kernel (round 6; csrc/conv_c64_bf16.hip): the whole K = 576 of a
+ * 16 x 32 pixel tile in one LDS halo, persistent blocks, 16-byte stores from the accumulators.  d[0]: k = 3, cin = 64,
+ * cout a multiple of 64, the packing of rtpose_pack_conv_weights_bf16, bf16 input and output slices 16-byte aligned, no
+ * out_cmap; same contract as rtpose_conv2d_bf16, which takes this path by itself whenever `_fits` says 1 (the fp32 sums run
+ * in another order than in its generic kernel: the last bits).  `_fits` is host-only. */
+int rtpose_conv3x3_c64_bf16_fits(const rtpose_conv_desc* d, int ngroups, int N, int H, int W);
+int rtpose_conv3x3_c64_bf16(const rtpose_conv_desc* d, int N, int H, int W, void* stream);
 /* dense NCHW fp32 -> bf16 layout slice (channels [C, cpad) zero; cpad % 8 == 0) */
 int rtpose_nchw_to_layout_bf16(const float* src_nchw, void* dst, const rtpose_layout* ldst,
                                int C, int cpad, int N, int H, int W, void* stream);

@@ -104,6 +104,8 @@ _SIGS = {
     "rtpose_conv1x1_pair": (_i, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _i, _i, _i, _i, _vp]),
     "rtpose_conv1x1_pair_bf16_fits": (_i, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _i]),
     "rtpose_conv1x1_pair_bf16": (_i, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _i, _i, _i, _i, _i, _vp]),
+    "rtpose_conv3x3_c64_bf16_fits": (_i, [C.POINTER(ConvDesc), _i, _i, _i, _i]),
+    "rtpose_conv3x3_c64_bf16": (_i, [C.POINTER(ConvDesc), _i, _i, _i, _vp]),
     "rtpose_conv_first_packed_floats": (_sz, []),
     "rtpose_pack_conv_first": (_i, [_vp, _vp, _vp, _vp]),
     "rtpose_conv_first": (_i, [_vp, _vp, _LP, _vp, _vp, _LP, _i, _i, _i, _i, _vp]),

@@ -38,6 +38,10 @@
 #include "conv_exp.h"
 
 namespace rtpose {
+
+int conv_c64_bf16_fits(const rtpose_conv_desc* d, int ngroups, int N, int H, int W, int out_f32, int split);
+int conv_c64_bf16_launch(const rtpose_conv_desc* d, int N, int H, int W, hipStream_t s);
+
 namespace bf {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -1119,6 +1123,16 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
     g.out_cmap = di.out_cmap;
   }
   if (d0.pool && ((H | W) & 1)) return fail(RTPOSE_E_INVAL, "conv2d_bf16: fused pool needs even H and W");
+  {
+    // 3x3 layers with 64 input channels (conv1_2, conv2_1) have their own kernel: the whole K of a tile in one LDS halo,
+    // persistent blocks (conv_c64_bf16.hip)
+    static int c64_env = -1;  // developer A/B: RTPOSE_BF16_C64=0 keeps the generic kernel for them
+    if (c64_env < 0) {
+      const char* e = dev_env("RTPOSE_BF16_C64");
+      c64_env = e ? atoi(e) : 1;
+    }
+    if (c64_env && conv_c64_bf16_fits(d, ngroups, N, H, W, out_f32, split)) return conv_c64_bf16_launch(d, N, H, W, s);
+  }
   ConvPlan pl;
   int rc = plan_conv(d0, N, H, W, sp, &pl);
   if (rc) return rc;

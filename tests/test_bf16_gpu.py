@@ -25,7 +25,7 @@ def _rb(t):
 
 
 def _run_conv_bf16(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out, seed, groups=1,
-                   cin_pad=None, out_f32=False, aligned=False):
+                   cin_pad=None, out_f32=False, aligned=False, lead_extra=0):
     lib, Layout = capi.lib, capi.Layout
     g = torch.Generator().manual_seed(seed)
     x = _rb(torch.randn(n, cin, h, w, generator=g))
@@ -44,6 +44,7 @@ def _run_conv_bf16(capi, dev, n, h, w, cin, cout, k, relu, pool, pad_in, pad_out
         refs.append(y)
     stream = capi.current_stream()
     lin = Layout.padded(cin_p, h, w, pad_in)
+    lin.lead += lead_extra  # (a slice far into a large buffer: byte offsets past 2^31)
     npx = lib.rtpose_layout_pixels(C.byref(lin), n, h, w)
     xin = torch.zeros(npx * cin_p, device=dev, dtype=torch.bfloat16)
     xd = x.to(dev)
@@ -312,6 +313,62 @@ def test_conv1x1_pair_bf16_matches_the_two_launch_contract(capi, cuda, case):
     assert abs(total - inner) <= 1e-3 * max(1.0, inner), "wrote outside its slices / into the gaps"
     d1[0].cin = 64
     assert lib.rtpose_conv1x1_pair_bf16_fits(d1, d2, ngroups) == 0
+
+
+C64_CASES = [
+    # n, h, w, cout, relu, pool, pad_in, pad_out
+    (2, 40, 72, 64, 1, 1, 1, 1),     # conv1_2's form: fused pool, ragged right / bottom tiles, two images
+    (1, 37, 45, 128, 1, 0, 1, 1),    # conv2_1's form: two passes of 64 channels, odd map
+    (3, 16, 32, 64, 0, 0, 3, 3),     # exactly one tile per image, no ReLU, the P = 3 layouts
+    (2, 50, 100, 128, 1, 1, 1, 3),   # pool + two passes
+    (1, 184, 120, 128, 1, 0, 1, 1),  # conv2_1 at its real height
+]
+
+
+@pytest.mark.parametrize("case", C64_CASES)
+def test_conv3x3_of_64_input_channels_takes_its_own_kernel_and_keeps_the_contract(capi, cuda, case):
+    """Round 6 (csrc/conv_c64_bf16.hip): 3x3 convs with 64 bf16 input channels and 16-byte aligned slices - conv1_2 (+ pool)
+    and conv2_1 of the bf16 plan - run in a persistent kernel that keeps a tile's whole K in one LDS halo; rtpose_conv2d_bf16
+    dispatches to it.  Same contract as the generic kernel (within one bf16 ulp of the RNE-rounded emulation in double, > 98 %
+    equal to it, nothing written outside the slice), and `_fits` says that it is the kernel that ran."""
+    lib, Layout = capi.lib, capi.Layout
+    n, h, w, cout, relu, pool, pin, pout = case
+    d = (capi.ConvDesc * 1)()
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    d[0].lin = Layout.padded(64, h, w, pin)
+    d[0].lout = Layout.padded(cout + 16, ho, wo, pout, choff=8)
+    d[0].cin, d[0].cout, d[0].k, d[0].relu, d[0].pool = 64, cout, 3, relu, pool
+    assert lib.rtpose_conv3x3_c64_bf16_fits(d, 1, n, h, w) == 1
+    outs, refs = _run_conv_bf16(capi, cuda, n, h, w, 64, cout, 3, relu, pool, pin, pout, seed=64 + cout + h, aligned=True)
+    _check(outs[0], refs[0], False)
+    # what it does not take: other channel counts, unaligned slices, grouped launches
+    d[0].cin = 128
+    assert lib.rtpose_conv3x3_c64_bf16_fits(d, 1, n, h, w) == 0
+    d[0].cin = 64
+    d[0].lout = Layout.padded(cout + 3, ho, wo, pout, choff=1)
+    assert lib.rtpose_conv3x3_c64_bf16_fits(d, 1, n, h, w) == 0
+    d[0].lout = Layout.padded(cout + 16, ho, wo, pout, choff=8)
+    assert lib.rtpose_conv3x3_c64_bf16_fits(d, 2, n, h, w) == 0
+
+
+def test_conv3x3_of_64_input_channels_with_byte_offsets_past_2_to_31(capi, cuda):
+    """The kernel addresses its input with unsigned 32-bit byte offsets: the 2 x 368 scale of the multi-scale flow at batch
+    32 is a 2.2 GB activation buffer.  Here a small image sits 17 M pixel slots into a 2.2 GB buffer (lead): same contract;
+    past 4 GB `_fits` hands the conv back to the generic kernel."""
+    lib, Layout = capi.lib, capi.Layout
+    n, h, w, cout = 1, 40, 72, 64
+    extra = 17_000_000
+    d = (capi.ConvDesc * 1)()
+    d[0].lin = Layout.padded(64, h, w, 1)
+    d[0].lin.lead += extra
+    d[0].lout = Layout.padded(cout + 16, h // 2, w // 2, 1, choff=8)
+    d[0].cin, d[0].cout, d[0].k, d[0].relu, d[0].pool = 64, cout, 3, 1, 1
+    assert lib.rtpose_layout_pixels(C.byref(d[0].lin), n, h, w) * 128 > 2 ** 31
+    assert lib.rtpose_conv3x3_c64_bf16_fits(d, 1, n, h, w) == 1
+    outs, refs = _run_conv_bf16(capi, cuda, n, h, w, 64, cout, 3, 1, 1, 1, 1, seed=5, aligned=True, lead_extra=extra)
+    _check(outs[0], refs[0], False)
+    d[0].lin.lead += extra
+    assert lib.rtpose_conv3x3_c64_bf16_fits(d, 1, n, h, w) == 0
 
 
 def test_conv_bf16_rejects_bad_geometry(capi, cuda):
