@@ -72,29 +72,53 @@ __host__ __device__ constexpr int tap_off(int k) {
 
 // MODE 0: fp32, pixel-major output; 1: fp32, channel planes (PLANES); 2: bf16 arithmetic, bf16 pixel-major output
 template <int MODE>
-__global__ __launch_bounds__(256) void conv_first_kernel(const Args A) {
+__global__ __launch_bounds__(256, 3) void conv_first_kernel(const Args A) {
   constexpr bool PLANES = MODE != 0;  // (the transposed product: a lane holds one pixel)
   constexpr bool BF16 = MODE == 2;
-  __shared__ float halo[3 * HH * WW];
+  // PERSISTENT (round 6): the grid is a few blocks per CU and a block walks the tiles blockIdx.x, + gridDim.x, ...  As one
+  // tile per block the launch was bound by the rate at which workgroups are DISPATCHED - 17,664 blocks that live 4.3 us each:
+  // SQ_WAVE_CYCLES / (launch time x clock) = 870 waves resident on the whole chip, less than one block per CU, the matrix pipe
+  // 29 % busy and the stores at 3.3 TB/s where a fill of the same buffer runs at 6.8 (tools/exp/write_bw.py).  The filters
+  // and the bias stay in registers; the next tile's halo is requested before this tile's multiply and parked in the other
+  // LDS buffer behind it: one barrier per tile.
+  __shared__ float halo2[2][3 * HH * WW];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
-  int b = blockIdx.x;
-  const int tx = b % A.tiles_x;
-  b /= A.tiles_x;
-  const int ty = b % A.tiles_y, n = b / A.tiles_y;
-  const int y0 = ty * TH, x0 = tx * TW;
-
+  const int ntiles = A.N * A.tiles_y * A.tiles_x;
+  constexpr int NH = (3 * HH * WW + 255) / 256;  // halo elements per thread
   // ---- halo: rows y0 - 1 .. y0 + TH, columns x0 - 1 .. x0 + TW of the 3 channels; outside the image = 0 ----
-  for (int i = tid; i < 3 * HH * WW; i += 256) {
-    const int c = i / (HH * WW), r = i - c * (HH * WW);
-    const int yy = y0 - 1 + r / WW, xx = x0 - 1 + r % WW;
-    float v = 0.f;
-    if (yy >= 0 && yy < A.H && xx >= 0 && xx < A.W) {
-      v = A.x_nchw ? A.x_nchw[((size_t)(n * 3 + c) * A.H + yy) * A.W + xx]
-                   : A.x_lay[((size_t)A.xl_lead + (size_t)(n * A.xl_hs + yy) * A.xl_ws + xx) * A.xl_cstride + A.xl_choff + c];
+  auto fetch_halo = [&](int b, float (&hv)[NH]) {
+    const int tx = b % A.tiles_x;
+    b /= A.tiles_x;
+    const int ty = b % A.tiles_y, n = b / A.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    int tv = tid;  // (opaque: as loop invariants the halo coordinates of the NH elements would be held across the multiply)
+    asm volatile("" : "+v"(tv));
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int i = min(tv + 256 * j, 3 * HH * WW - 1);
+      const int c = i / (HH * WW), r = i - c * (HH * WW);
+      const int yy = y0 - 1 + r / WW, xx = x0 - 1 + r % WW;
+      float v = 0.f;
+      if (yy >= 0 && yy < A.H && xx >= 0 && xx < A.W) {
+        v = A.x_nchw ? A.x_nchw[((size_t)(n * 3 + c) * A.H + yy) * A.W + xx]
+                     : A.x_lay[((size_t)A.xl_lead + (size_t)(n * A.xl_hs + yy) * A.xl_ws + xx) * A.xl_cstride + A.xl_choff + c];
+      }
+      hv[j] = BF16 ? round_bf16(v) : v;
     }
-    halo[i] = BF16 ? round_bf16(v) : v;
+  };
+  auto park_halo = [&](float* dst, const float (&hv)[NH]) {
+#pragma unroll
+    for (int j = 0; j < NH; ++j)
+      if (tid + 256 * j < 3 * HH * WW) dst[tid + 256 * j] = hv[j];
+  };
+  int bcur = blockIdx.x;
+  if (bcur >= ntiles) return;
+  {
+    float hv[NH];
+    fetch_halo(bcur, hv);
+    park_halo(halo2[0], hv);
   }
   // ---- filters: 28 values per lane (k = 2 step + kh, column = half * 32 + l31), bias in the accumulators ----
   // (MODE 2: 4 x 8 bf16 per lane - channel half * 32 + l31, taps 16 s + 8 kh .. + 7)
@@ -118,25 +142,36 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const Args A) {
       for (int e = 0; e < 4; ++e) wv[(4 * q + e) / KS][(4 * q + e) % KS] = tv[e];
     }
   }
-  floatx16 acc[2][2];  // [row of the wave][column half]
+  float bias_r[2][PLANES ? 16 : 1];
 #pragma unroll
   for (int nh = 0; nh < 2; ++nh) {
     if (PLANES) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float b0 = A.bias[nh * 32 + 8 * (r >> 2) + 4 * kh + (r & 3)];
-        acc[0][nh][r] = b0;
-        acc[1][nh][r] = b0;
-      }
+      for (int r = 0; r < 16; ++r) bias_r[nh][r] = A.bias[nh * 32 + 8 * (r >> 2) + 4 * kh + (r & 3)];
     } else {
-      const float b0 = A.bias[nh * 32 + l31];
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nh][r] = b0;
+      bias_r[nh][0] = A.bias[nh * 32 + l31];
     }
   }
   __syncthreads();
+
+  for (int buf = 0;; buf ^= 1) {
+  const int bnext = bcur + (int)gridDim.x;
+  const bool more = bnext < ntiles;
+  float hv[NH];
+  fetch_halo(more ? bnext : bcur, hv);  // (the last tile fetches its own halo again: no branch around the loads)
+  int b = bcur;
+  const int tx = b % A.tiles_x;
+  b /= A.tiles_x;
+  const int ty = b % A.tiles_y, n = b / A.tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const float* const halo = halo2[buf];
+  floatx16 acc[2][2];  // [row of the wave][column half]
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nh][r] = bias_r[nh][PLANES ? r : 0];
 
   // ---- 14 K steps: A = halo[tap(2 step + kh)] at (row 2 wave + mt, pixel l31) ----------------------------
   const float* hb = halo + (2 * wave) * WW + l31;
@@ -211,9 +246,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const Args A) {
           if (ok) *reinterpret_cast<uint4*>(op + nh * 32 + 8 * (2 * m + kh)) = make_uint4(a[0], a[1], b[0], b[1]);
         }
     }
-    return;
-  }
-  if (PLANES) {
+  } else if (PLANES) {
     // ---- store: lane = pixel x0 + l31 of the row, registers 4 j .. 4 j + 3 = floats 4 kh .. 4 kh + 3 of plane 4 half + j ----
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -230,8 +263,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const Args A) {
           *reinterpret_cast<float4*>(op + (size_t)(4 * nh + j) * A.o_pq * 8) = v;
         }
     }
-    return;
-  }
+  } else {
   // ---- store: register r of a lane = pixel x0 + (r / 4) * 8 + 4 kh + r % 4 of the row, channel half * 32 + l31 ----
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -249,6 +281,12 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const Args A) {
         }
       }
     }
+  }
+  }
+  if (!more) break;
+  park_halo(halo2[buf ^ 1], hv);
+  __syncthreads();
+  bcur = bnext;
   }
 }
 
@@ -334,8 +372,10 @@ int conv_first_launch(const float* x_nchw, const float* x_lay, const rtpose_layo
   a.relu = relu;
   a.tiles_x = ceil_div(W, TW);
   a.tiles_y = ceil_div(H, TH);
-  const long blocks = (long)N * a.tiles_x * a.tiles_y;
-  if (blocks > 0x7fffffffL) return fail(RTPOSE_E_INVAL, "conv_first: grid too large");
+  const long tiles = (long)N * a.tiles_x * a.tiles_y;
+  if (tiles > 0x3fffffffL) return fail(RTPOSE_E_INVAL, "conv_first: too many tiles");
+  // persistent: 3 blocks per CU (<= 168 registers, 8 KB of LDS each) walk the tiles
+  const long blocks = tiles < 3L * device_cu_count() ? tiles : 3L * device_cu_count();
   if (out_bf16) hipLaunchKernelGGL(conv_first_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   else if (out_plane_pixels) hipLaunchKernelGGL(conv_first_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(conv_first_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, a);
