@@ -75,12 +75,12 @@ template <int MODE>
 __global__ __launch_bounds__(256, 3) void conv_first_kernel(const Args A) {
   constexpr bool PLANES = MODE != 0;  // (the transposed product: a lane holds one pixel)
   constexpr bool BF16 = MODE == 2;
-  // PERSISTENT (round 6): the grid is a few blocks per CU and a block walks the tiles blockIdx.x, + gridDim.x, ...  As one
-  // tile per block the launch was bound by the rate at which workgroups are DISPATCHED - 17,664 blocks that live 4.3 us each:
-  // SQ_WAVE_CYCLES / (launch time x clock) = 870 waves resident on the whole chip, less than one block per CU, the matrix pipe
-  // 29 % busy and the stores at 3.3 TB/s where a fill of the same buffer runs at 6.8 (tools/exp/write_bw.py).  The filters
-  // and the bias stay in registers; the next tile's halo is requested before this tile's multiply and parked in the other
-  // LDS buffer behind it: one barrier per tile.
+  // PERSISTENT (round 6): the grid is 3 blocks per CU and a block walks the tiles blockIdx.x, + gridDim.x, ...  As one tile per
+  // block every one of the 17,664 blocks (4.3 us each) loaded its filters and bias (7 + 8 16-byte loads per lane) and waited
+  // for its own halo before its first MFMA; the matrix pipe was 29 % busy and the stores ran at 3.3 TB/s where a fill of the
+  // same buffer runs at 6.8 (tools/exp/write_bw.py).  Now the filters and the bias stay in registers, and the next tile's halo
+  // is requested before this tile's multiply and parked in the other LDS buffer behind it: one barrier per tile, no exposed
+  // load in front of the multiply after the first tile (fp32: 0.336 -> 0.275 ms).
   __shared__ float halo2[2][3 * HH * WW];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
