@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, 3) void conv_first_kernel(const Args A) {
   const int bnext = bcur + (int)gridDim.x;
   const bool more = bnext < ntiles;
   float hv[NH];
-  fetch_halo(more ? bnext : bcur, hv);  // (the last tile fetches its own halo again: no branch around the loads)
+  if (more) fetch_halo(bnext, hv);
   int b = bcur;
   const int tx = b % A.tiles_x;
   b /= A.tiles_x;
@@ -374,8 +374,11 @@ int conv_first_launch(const float* x_nchw, const float* x_lay, const rtpose_layo
   a.tiles_y = ceil_div(H, TH);
   const long tiles = (long)N * a.tiles_x * a.tiles_y;
   if (tiles > 0x3fffffffL) return fail(RTPOSE_E_INVAL, "conv_first: too many tiles");
-  // persistent: 3 blocks per CU (<= 168 registers, 8 KB of LDS each) walk the tiles
-  const long blocks = tiles < 3L * device_cu_count() ? tiles : 3L * device_cu_count();
+  // fp32: persistent, 3 blocks per CU (<= 168 registers, 8 KB of LDS each) walk the tiles.  bf16 output (MODE 2): one tile per
+  // block - the persistent form bought it nothing (0.213 -> 0.210 ms) and, filling every SIMD's registers for the whole launch,
+  // kept the decoder of the batch before off the CUs while it ran: host-to-host streaming of the bf16 plan 1.01 -> 0.79 of the
+  // device-resident rate (profiles/r06_conv_first_persistent.txt)
+  const long blocks = (out_bf16 || tiles < 3L * device_cu_count()) ? tiles : 3L * device_cu_count();
   if (out_bf16) hipLaunchKernelGGL(conv_first_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   else if (out_plane_pixels) hipLaunchKernelGGL(conv_first_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(conv_first_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, a);
