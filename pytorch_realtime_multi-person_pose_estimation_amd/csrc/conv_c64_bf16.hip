@@ -10,15 +10,17 @@
 //   * 64 channels are ONE chunk: the whole K of a tile is resident.  A block owns a 16 x 32 pixel tile; its 18 x 34 halo is
 //     8 planes of 16 bytes per pixel in LDS (77 KB; plane stride 617 pixels, = 1 mod 8, so the 8 lanes that store one pixel's
 //     128 bytes hit 8 different bank groups and the 32 lanes that read 32 neighbouring pixels of a plane read 512 contiguous
-//     bytes).  Two blocks fit a CU: while one multiplies, the other's halo is on its way - the phases of a tile overlap
-//     ACROSS the blocks, and inside a block nothing but the halo load is ever waited for.
+//     bytes).  Two blocks fit a CU: while one is in its epilogue or parks its next halo, the other multiplies - measured
+//     (tools/exp/c64_timeline.py), the K loops of the two overlap almost always: the matrix pipe is busy at the rate the power
+//     controller allows with these operands (profiles/r04_bf16_mfma_power_cap.txt).
 //   * a wave multiplies 4 image rows x 32 pixels x 64 output channels (8 accumulators of 32 x 32): per K step of 16 channels
 //     it reads 4 pixel fragments from LDS (ds_read_b128, compile-time offsets: tap and plane are immediates) and 2 filter
 //     fragments through the L1 (16-byte buffer loads at a uniform offset, five steps ahead in a 6-entry register ring that
 //     runs on across tile boundaries - the filters are the same for every tile) for 8 v_mfma_f32_32x32x16_bf16: half of the
 //     LDS and a quarter of the L1 bandwidth at full matrix rate.
-//   * persistent blocks (2 per CU) walk the tiles; layers with 128 output channels are two passes of 64 (the blocks of a CU
-//     take the two passes of neighbouring tiles).
+//   * persistent blocks (2 per CU) walk the tiles; the next tile's halo is requested in two halves AROUND the halves of the
+//     epilogue - into the accumulator registers it has finished with - and parked behind it.  Layers with 128 output channels
+//     are two passes of 64 (a block keeps its pass: grid = a multiple of the pass count).
 //   * the TRANSPOSED product (filters as the row operand): a lane holds one pixel and, after one v_permlane32_swap per register
 //     pair, 8 consecutive output channels of it - 16-byte stores, no LDS in the epilogue.  The fused 2 x 2 max-pool is a max
 //     over the wave's row pairs (registers) and over lane pairs (one DPP quad permute) in front of that.
