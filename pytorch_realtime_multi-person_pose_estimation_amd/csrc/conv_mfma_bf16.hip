@@ -1131,7 +1131,9 @@ int conv2d_bf16_launch(const rtpose_conv_desc* d, int ngroups, int N, int H, int
       const char* e = dev_env("RTPOSE_BF16_C64");
       c64_env = e ? atoi(e) : 1;
     }
-    if (c64_env && conv_c64_bf16_fits(d, ngroups, N, H, W, out_f32, split)) return conv_c64_bf16_launch(d, N, H, W, s);
+    // (it reads the packing for 32-channel chunks: what conv_ck gives these layers unless a developer build forces 64)
+    if (c64_env && conv_ck(d0.cin, d0.k, sp) == 32 && conv_c64_bf16_fits(d, ngroups, N, H, W, out_f32, split))
+      return conv_c64_bf16_launch(d, N, H, W, s);
   }
   ConvPlan pl;
   int rc = plan_conv(d0, N, H, W, sp, &pl);
