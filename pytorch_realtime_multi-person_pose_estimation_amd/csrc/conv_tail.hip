@@ -46,8 +46,20 @@ struct Args {
 // NP = passes of 128 intermediate columns: 1 for Mconv6 / Mconv7 (128 -> 128 -> 38 | 19), 4 for the stage-1 pair
 // conv5_4_CPM / conv5_5_CPM (128 -> 512 -> 38 | 19, rtpose_vgg.py:95-105): GEMM 1 produces 128 columns at a time, GEMM 2
 // consumes them as the next 128 of its K = 512 - the accumulators of GEMM 2 live across the passes, k ascending.
+#ifdef RTPOSE_EXP_TAIL_TIMELINE  // developer build: wall_clock64 stamps per block (tools/exp/tail_timeline.py)
+#ifndef RTPOSE_DEV_BUILD
+#error "RTPOSE_EXP_TAIL_TIMELINE is a developer-build experiment (tools/build_dev.sh)"
+#endif
+__device__ unsigned long long g_tail_tl[4096][8];
+#define RTPOSE_TAIL_TL(i) \
+  if (threadIdx.x == 0 && blockIdx.x < 4096) g_tail_tl[blockIdx.x][i] = wall_clock64()
+#else
+#define RTPOSE_TAIL_TL(i)
+#endif
+
 template <int NP>
 __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void tail_kernel(const Args A) {
+  RTPOSE_TAIL_TL(0);
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   float4* const X = lds4;
   // one pass: the intermediate takes the input tile's place (a barrier after GEMM 1); several: its own buffer
@@ -76,6 +88,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void tail_kernel(const Args A
   for (int gi = 0; gi < KC / 8; ++gi)
     b1v[gi] = reinterpret_cast<const float4*>(g.w1)[(size_t)(2 * gi + kh) * N1T + wave * 32 + l31];
   __syncthreads();
+  RTPOSE_TAIL_TL(1);
 
   // ---- X tile: 64 px x 32 planes of 16 bytes; consecutive lanes = consecutive planes of a pixel (512 B runs) ----
 #pragma unroll
@@ -85,6 +98,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void tail_kernel(const Args A
     X[plane * PS + px] = *reinterpret_cast<const float4*>(g.in + (size_t)qin[px] + plane * 4);
   }
   __syncthreads();
+  RTPOSE_TAIL_TL(2);
 
   const int mf2 = wave & 1, nf2 = wave >> 1;
   const int col2 = nf2 * 32 + l31;
@@ -133,7 +147,9 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void tail_kernel(const Args A
     }
     // ReLU, then the intermediate in the A layout: T[column / 4][pixel].[column % 4]
     // (register r of a lane = pixel (r / 4) * 8 + 4 kh + r % 4 of the fragment, column wave * 32 + l31 of the pass)
+    if (NP == 1) { RTPOSE_TAIL_TL(3); }
     __syncthreads();  // every wave has read its last X fragment (one pass) / its last T fragment of the previous pass
+    if (NP == 1) { RTPOSE_TAIL_TL(4); }
     {
       const int cl = wave * 32 + l31;
       float* Tf = reinterpret_cast<float*>(T) + ((cl >> 2) * PS) * 4 + (cl & 3);
@@ -146,6 +162,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void tail_kernel(const Args A
         }
     }
     __syncthreads();
+    if (NP == 1) { RTPOSE_TAIL_TL(5); }
 
     // ---- GEMM 2: 32 px x 32 columns per wave (2 x 2 waves), the next 128 of its K ----------------------------
     if (live2) {
@@ -159,6 +176,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void tail_kernel(const Args A
       }
     }
   }
+  RTPOSE_TAIL_TL(6);
   if (col2 < g.cout2) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -166,6 +184,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void tail_kernel(const Args A
       if (mt * BM + px < A.M) g.out[(size_t)qout[px] + col2] = acc2[r];
     }
   }
+  RTPOSE_TAIL_TL(7);
 }
 
 }  // namespace tail
@@ -247,6 +266,12 @@ int conv_tail_launch(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int
 }  // namespace rtpose
 
 extern "C" {
+
+#ifdef RTPOSE_EXP_TAIL_TIMELINE
+int rtpose_exp_tail_timeline(unsigned long long* out) {  // [4096 blocks][8 stamps]
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rtpose::tail::g_tail_tl), sizeof(unsigned long long) * 4096 * 8);
+}
+#endif
 
 int rtpose_conv1x1_pair_fits(const rtpose_conv_desc* d1, const rtpose_conv_desc* d2, int ngroups) {
   return rtpose::conv_tail_fits(d1, d2, ngroups);
