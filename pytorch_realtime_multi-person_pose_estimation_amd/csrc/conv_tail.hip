@@ -46,6 +46,9 @@ struct Args {
 // NP = passes of 128 intermediate columns: 1 for Mconv6 / Mconv7 (128 -> 128 -> 38 | 19), 4 for the stage-1 pair
 // conv5_4_CPM / conv5_5_CPM (128 -> 512 -> 38 | 19, rtpose_vgg.py:95-105): GEMM 1 produces 128 columns at a time, GEMM 2
 // consumes them as the next 128 of its K = 512 - the accumulators of GEMM 2 live across the passes, k ascending.
+#if defined(RTPOSE_EXP_TAIL_STAGGER) && !defined(RTPOSE_DEV_BUILD)
+#error "RTPOSE_EXP_TAIL_STAGGER is a developer-build experiment (tools/build_dev.sh)"
+#endif
 #ifdef RTPOSE_EXP_TAIL_TIMELINE  // developer build: wall_clock64 stamps per block (tools/exp/tail_timeline.py)
 #ifndef RTPOSE_DEV_BUILD
 #error "RTPOSE_EXP_TAIL_TIMELINE is a developer-build experiment (tools/build_dev.sh)"
@@ -59,6 +62,12 @@ __device__ unsigned long long g_tail_tl[4096][8];
 
 template <int NP>
 __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void tail_kernel(const Args A) {
+#ifdef RTPOSE_EXP_TAIL_STAGGER  // developer build: the k-th resident block of a CU (ids go round the CUs) starts k x this many 10 ns ticks late
+  if (blockIdx.x < 1024) {
+    const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)(blockIdx.x >> 8) * (RTPOSE_EXP_TAIL_STAGGER);
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   RTPOSE_TAIL_TL(0);
   extern __shared__ __attribute__((aligned(16))) float4 lds4[];
   float4* const X = lds4;
@@ -91,11 +100,19 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void tail_kernel(const Args A
   RTPOSE_TAIL_TL(1);
 
   // ---- X tile: 64 px x 32 planes of 16 bytes; consecutive lanes = consecutive planes of a pixel (512 B runs) ----
+  // (offsets, then all loads, then all LDS writes: written as one loop the table read of piece i + 1 - LDS, like X - could
+  //  not be moved across the LDS write of piece i, and the eight global round trips ran one after the other: 7.3 of a block's
+  //  29 us, tools/exp/tail_timeline.py)
+  {
+    constexpr int NX = BM * (KC / 4) / 256;
+    int qx[NX];
+    float4 xv[NX];
 #pragma unroll
-  for (int i = 0; i < BM * (KC / 4) / 256; ++i) {
-    const int idx = tid + 256 * i;
-    const int px = idx >> 5, plane = idx & 31;
-    X[plane * PS + px] = *reinterpret_cast<const float4*>(g.in + (size_t)qin[px] + plane * 4);
+    for (int i = 0; i < NX; ++i) qx[i] = qin[(tid + 256 * i) >> 5];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xv[i] = *reinterpret_cast<const float4*>(g.in + (size_t)qx[i] + (tid & 31) * 4);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) X[(tid & 31) * PS + ((tid + 256 * i) >> 5)] = xv[i];
   }
   __syncthreads();
   RTPOSE_TAIL_TL(2);

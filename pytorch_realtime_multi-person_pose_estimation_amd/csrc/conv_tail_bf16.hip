@@ -94,11 +94,18 @@ __global__ __launch_bounds__(256) void tail_bf16_kernel(const Args A) {
   __syncthreads();
 
   // ---- X tile: 64 px x 16 pieces; consecutive lanes = consecutive pieces of a pixel (256-byte runs) ----
+  // (offsets, then all loads, then all LDS writes: as one loop the table read of piece i + 1 could not be moved across the LDS
+  //  write of piece i and the global round trips ran one after the other - found in the fp32 kernel, tools/exp/tail_timeline.py)
+  {
+    constexpr int NX = BM * 16 / 256;
+    int qx[NX];
+    uintx4 xv[NX];
 #pragma unroll
-  for (int i = 0; i < BM * 16 / 256; ++i) {
-    const int idx = tid + 256 * i;
-    const int px = idx >> 4, plane = idx & 15;
-    X[plane * PS + px] = *reinterpret_cast<const uintx4*>(g.in + (size_t)qin[px] + plane * 8);
+    for (int i = 0; i < NX; ++i) qx[i] = qin[(tid + 256 * i) >> 4];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xv[i] = *reinterpret_cast<const uintx4*>(g.in + (size_t)qx[i] + (tid & 15) * 8);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) X[(tid & 15) * PS + ((tid + 256 * i) >> 4)] = xv[i];
   }
 
   const int mf2 = wave & 1, nf2 = wave >> 1;
