@@ -15,9 +15,7 @@ checkpoint exists offline).  Because random weights produce no meaningful peaks,
 the maps the decoder consumes are  scene + 1e-3 * net_output  where `scene` is a
 rasterised multi-person stick-figure batch resident in HBM (pkg.synth, 1-8 people
 per image); the blend is an extra elementwise kernel INSIDE the timed region, so
-no work is skipped and the decoder still depends on what the network wrote.  It
-is decoder-input scaffolding and runs where the decoder runs: on the second
-stream in the overlapped flow, on the one stream with --decode-overlap 0.
+no work is skipped and the decoder still depends on what the network wrote.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
@@ -513,7 +511,7 @@ def main():
                                     "(BASELINE.json configs[1]); per-GPU batch 32, one process per GPU"),
                        "global_batch": BATCH * world, "image": [SIZE, SIZE],
                        "weights": "seeded He init (no checkpoint offline)",
-                       "decoder_input": "synthetic scene + 1e-3 * net output (blend kernel timed, on the decoder's stream)",
+                       "decoder_input": "synthetic scene + 1e-3 * net output (blend kernel timed)",
                        "pipeline": ("one stream, step by step" if not args.decode_overlap else
                                     "decoder + record D2H of step k on a second stream; the forward of step k + 1 is queued "
                                     "at once but starts when that decoder has read the maps (RTPOSE_GUARD_WHOLE_FORWARD=1)"

@@ -68,13 +68,12 @@ class SideDecoder(object):
     def __del__(self):
         self.close()
 
-    def decode(self, i, maps, n, device, max_peaks_per_part, max_humans, post=None, plan=None, model=None, pre=None):
+    def decode(self, i, maps, n, device, max_peaks_per_part, max_humans, post=None, plan=None, model=None):
         """Enqueue decode + record D2H of slot i (0 / 1) behind everything queued on the current stream so far.
         maps = (hbase, lheat, pbase, lpaf, h, w).  ``post(result_block)``, if given, runs on the side stream after the
         decode and returns the device tensor whose copy wait() hands out (bench.py: the RCCL gather of the ranks' blocks).
         ``plan`` (+ ``model``): the plan whose output buffer `maps` points into - it gets the guard and its device error
-        word is read.  ``pre()``, if given, runs on the side stream in front of the decode (bench / tests: the scene blend
-        into the maps - decoder-input scaffolding that belongs with the decoder, not on the forward's stream)."""
+        word is read."""
         import torch
         if plan is None:
             raise _capi.RtposeError("SideDecoder.decode: plan= is required (the plan whose output buffer the maps live in "
@@ -105,8 +104,6 @@ class SideDecoder(object):
         slot["maps"].record(torch.cuda.current_stream())
         self.stream.wait_event(slot["maps"])
         with torch.cuda.stream(self.stream):
-            if pre is not None:
-                pre()
             dec.decode_enqueue(hbase, lheat, pbase, lpaf, n, h, w, bufs)
             slot["dec_done"].record(self.stream)        # the decoder's last read of the maps
             block = bufs.result.view(n, bufs.words)
@@ -184,7 +181,7 @@ class PoseEstimator(object):
 
     # ---- decode(k) under forward(k + 1): see SideDecoder ------------------------------------------------------------
     def submit(self, x, scene=None, scene_alpha=1e-3, post=None):
-        """Enqueue forward on the current stream and (blend +) decode + record D2H on the side stream; returns a ticket
+        """Enqueue forward (+ blend) on the current stream and decode + record D2H on the side stream; returns a ticket
         for collect().  At most two tickets may be outstanding (two record blocks ping-pong).  ``post(result_block)``,
         if given, runs on the side stream after the decode and returns the device tensor whose copy collect() hands
         out (bench.py: the RCCL gather of the ranks' blocks)."""
@@ -200,16 +197,13 @@ class PoseEstimator(object):
             n = x.shape[0]
             pbase, lpaf, _, h, w = m.output_view(plan, 0)
             hbase, lheat, _, _, _ = m.output_view(plan, 1)
-            pre = None
             if scene is not None:
                 sh, sp = scene
-
-                def pre():      # on the side stream, in front of the decode (the maps are guarded until the decode has read them)
-                    s = current_stream()
-                    check(lib.rtpose_layout_axpby(hbase, C.byref(lheat), ptr(sh), 19, n, h, w, scene_alpha, 1.0, s))
-                    check(lib.rtpose_layout_axpby(pbase, C.byref(lpaf), ptr(sp), 38, n, h, w, scene_alpha, 1.0, s))
+                s = current_stream()
+                check(lib.rtpose_layout_axpby(hbase, C.byref(lheat), ptr(sh), 19, n, h, w, scene_alpha, 1.0, s))
+                check(lib.rtpose_layout_axpby(pbase, C.byref(lpaf), ptr(sp), 38, n, h, w, scene_alpha, 1.0, s))
             bufs = self._side.decode(k & 1, (hbase, lheat, pbase, lpaf, h, w), n, x.device, self.max_peaks_per_part,
-                                     self.max_humans, post, plan=plan, model=m, pre=pre)
+                                     self.max_humans, post, plan=plan, model=m)
             bufs.plan = plan
             return k
 
