@@ -237,6 +237,36 @@ def test_winograd_fits_is_host_only_logic(capi):
     d[0].wino_m = 0
 
 
+def test_conv3x3_c64_fits_is_host_only_logic(capi):
+    """rtpose_conv3x3_c64_bf16_fits (round 6, csrc/conv_c64_bf16.hip) decides on the host which 3x3 bf16 convs
+    rtpose_conv2d_bf16 hands to the 64-input-channel kernel: conv1_2 (+ pool) and conv2_1 of the VGG-19 front end in the
+    network's layouts at every size of the multi-scale flow that fits 32-bit byte offsets - and nothing else."""
+    lib, Layout = capi.lib, capi.Layout
+
+    def desc(cin, cout, h, w, pool, pin=1, cs_in=None, ch_in=0, cs_out=None, ch_out=0):
+        d = (capi.ConvDesc * 1)()
+        ho, wo = (h // 2, w // 2) if pool else (h, w)
+        d[0].lin = Layout.padded(cs_in or cin, h, w, pin, choff=ch_in)
+        d[0].lout = Layout.padded(cs_out or cout, ho, wo, 1, choff=ch_out)
+        d[0].cin, d[0].cout, d[0].k, d[0].relu, d[0].pool = cin, cout, 3, 1, pool
+        return d
+
+    for n, size in ((32, 368), (32, 184), (32, 552), (32, 736), (1, 46)):
+        assert lib.rtpose_conv3x3_c64_bf16_fits(desc(64, 64, size, size, 1), 1, n, size, size) == 1      # conv1_2 + pool
+        assert lib.rtpose_conv3x3_c64_bf16_fits(desc(64, 128, size // 2, size // 2, 0), 1, n, size // 2, size // 2) == 1  # conv2_1
+    assert lib.rtpose_conv3x3_c64_bf16_fits(desc(64, 64, 368, 368, 1, cs_in=80, ch_in=16, cs_out=80, ch_out=8), 1, 2, 368, 368) == 1
+    assert lib.rtpose_conv3x3_c64_bf16_fits(desc(128, 128, 184, 184, 1), 1, 32, 184, 184) == 0     # other channel counts
+    assert lib.rtpose_conv3x3_c64_bf16_fits(desc(64, 96, 184, 184, 0), 1, 32, 184, 184) == 0       # cout not a multiple of 64
+    assert lib.rtpose_conv3x3_c64_bf16_fits(desc(64, 64, 368, 368, 1, cs_out=67, ch_out=1), 1, 2, 368, 368) == 0   # unaligned slice
+    assert lib.rtpose_conv3x3_c64_bf16_fits(desc(64, 64, 368, 368, 1, pin=0), 1, 2, 368, 368) == 0  # no gap for the padding
+    assert lib.rtpose_conv3x3_c64_bf16_fits(desc(64, 64, 367, 368, 1), 1, 2, 367, 368) == 0       # fused pool needs even sizes
+    assert lib.rtpose_conv3x3_c64_bf16_fits(desc(64, 64, 368, 368, 1), 2, 32, 368, 368) == 0      # grouped launches
+    assert lib.rtpose_conv3x3_c64_bf16_fits(desc(64, 64, 1104, 1104, 1), 1, 32, 1104, 1104) == 0  # 5 GB: past 32-bit offsets
+    d7 = desc(64, 64, 368, 368, 0)
+    d7[0].k = 7
+    assert lib.rtpose_conv3x3_c64_bf16_fits(d7, 1, 2, 368, 368) == 0
+
+
 def test_decoder_objects_hold_no_packed_fp32_instruction(tmp_path):
     """The decoder's kernels run on a second stream beside the forward's MFMA kernels (pipeline.SideDecoder).  Round 6
     (DESIGN.md 3.3): with clang's vectorisers on, limb_assign_kernel's sample loop was compiled into packed-fp32 VALU
